@@ -1,0 +1,588 @@
+// zs_model.cpp -- CPU walk-through of the GPU pipeline's algorithm (TEST TOOL).
+//
+// Runs, with plain host loops, the same stages the HIP kernels run (bucket
+// links -> per-position matches for both chain budgets -> chunked lazy-parse
+// maps -> compose -> symbol emission -> sequential tail engine -> blocks ->
+// trees -> bit emission) using the shared ZS_HD code in zlibstream_amd/csrc,
+// and checks every stage against the oracle (oracle/zs_oracle.c): the symbol
+// stream, the block table and the final bytes.  It exists to validate the
+// absolute-coordinate reformulation on a machine without a GPU; it is not part
+// of the product.
+//
+// usage: zs_model <file> <level> [strategy] [chunk]      -> prints PASS/FAIL
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../oracle/zs_oracle.h"
+#include "../../zlibstream_amd/csrc/zs_core.h"
+#include "../../zlibstream_amd/csrc/zs_lit_engine.h"
+
+using namespace zs;
+
+struct OracleTrace {
+    std::vector<uint32_t> syms;
+    struct Blk {
+        int type, nsyms;
+        int64_t start;
+        int stored_len, eof;
+        int64_t bit_start;
+    };
+    std::vector<Blk> blocks;
+    std::vector<int64_t> read_pos;
+};
+static void on_symbol(void *u, int dist, int lc, int64_t) { ((OracleTrace *)u)->syms.push_back(((uint32_t)dist << 16) | (uint32_t)lc); }
+static void on_block(void *u, int type, int nsyms, int64_t start, int stored_len, int eof, int64_t bit_start) {
+    ((OracleTrace *)u)->blocks.push_back({type, nsyms, start, stored_len, eof, bit_start});
+}
+static void on_read(void *u, int64_t s, int, int, int64_t) { ((OracleTrace *)u)->read_pos.push_back(s); }
+
+struct Model {
+    const uint8_t *data;
+    int64_t n;
+    int level, strategy;
+    LevelCfg lv;
+    std::vector<uint32_t> crc_tab;
+    std::vector<uint16_t> link;
+    std::vector<uint32_t> mK, mK4;
+    std::vector<uint32_t> syms;
+    std::vector<BlockRec> blocks;
+    std::vector<int64_t> events;  // s_k for k = 1..
+    int64_t body_end;             // last body loop-top position (n - 262), or -1
+
+    uint32_t bucket(int64_t p) const {
+        uint32_t v = (uint32_t)data[p + 2] | ((uint32_t)data[p + 3] << 8) | ((uint32_t)data[p + 4] << 16) | ((uint32_t)data[p + 5] << 24);
+        return crc32c_u32_tab(crc_tab.data(), v) & kHashMask;
+    }
+    void build_links() {
+        link.assign((size_t)n + 8, 0);
+        std::vector<int64_t> head(kHashSize, -1);
+        for (int64_t p = 0; p + 5 < n; p++) {
+            uint32_t h = bucket(p);
+            int64_t c = head[h];
+            link[p] = (c >= 0 && p - c <= 32767) ? (uint16_t)(p - c) : 0;
+            head[h] = p;
+        }
+    }
+    int lcp(int64_t p, int64_t c) const {
+        int len = 0;
+        while (len < kMaxMatch && data[p + len] == data[c + len]) len++;
+        return len;
+    }
+    // floor-2 walk for both budgets (Deflate.cs:1022-1100 with prevLength == 2)
+    void walk(int64_t p, uint32_t &outK, uint32_t &outK4) const {
+        outK = outK4 = kNoMatch;
+        if (lv.func != 2 || strategy == kHuffmanOnly) return;
+        int l = link[p];
+        if (!l) return;
+        int64_t c = p - l;
+        if (c < 1 || p - c > kMaxDist) return;
+        int best = 2, bdist = 0, n_eval = 0, k4 = lv.chain >> 2;
+        bool snap = false;
+        for (;;) {
+            int len = lcp(p, c);
+            n_eval++;
+            bool nice_exit = false;
+            if (len > best) {
+                best = len;
+                bdist = (int)(p - c);
+                if (len >= lv.nice) nice_exit = true;
+            }
+            if (n_eval == k4 || (nice_exit && n_eval < k4)) {
+                if (!snap) outK4 = best >= kMinMatch ? pack_match(best, bdist) : kNoMatch, snap = true;
+            }
+            if (nice_exit || n_eval == lv.chain) break;
+            l = link[c];
+            if (!l) break;
+            c -= l;
+            if (c < 1 || p - c >= kMaxDist) break;
+        }
+        outK = best >= kMinMatch ? pack_match(best, bdist) : kNoMatch;
+        if (!snap) outK4 = outK;
+    }
+    uint32_t flt(uint32_t m) const { return m ? filter_match(match_len(m), match_dist(m), strategy) : kNoMatch; }
+    void match_all() {
+        mK.assign((size_t)n + 8, 0);
+        mK4.assign((size_t)n + 8, 0);
+        for (int64_t p = 1; p <= body_end; p++) walk(p, mK[p], mK4[p]);
+    }
+};
+
+// ---- stage A: sequential parse with on-demand matches (validates the rules) ----
+static void parse_sequential(Model &m, bool on_demand, int64_t &p_out, int &kind_out, uint32_t &pend_out, int &kdone_out,
+                             int64_t &preins_out) {
+    int kind = kR;
+    int64_t p = 0;
+    uint32_t pend = 0;
+    int k_fired = 0;
+    int kl = num_refills(m.n);
+    int64_t killed_pos = -1;
+    int64_t preins = -1;
+    int64_t block_start = 0;
+    while (p <= m.body_end) {
+        if (k_fired < kl && p >= segment_start(k_fired + 1)) {
+            k_fired++;
+            m.events.push_back(p);
+            preins = p + 1;
+            if (m.bucket(p) == m.bucket(p + 1)) {
+                killed_pos = p;
+                m.link[p] = 0;  // later walkers stop after evaluating p
+            } else {
+                killed_pos = p + 1;
+            }
+        }
+        uint32_t cK, cK4;
+        if (p == killed_pos || p == 0) cK = cK4 = kNoMatch;
+        else if (on_demand) m.walk(p, cK, cK4);
+        else cK = m.mK[p], cK4 = m.mK4[p];
+        cK = m.flt(cK), cK4 = m.flt(cK4);
+        Step st = lazy_step(kind, p, pend, cK, cK4, m.lv);
+        if (st.emit) {
+            uint32_t sym = st.emit == 1 ? (uint32_t)m.data[p - 1] : (((uint32_t)st.dist << 16) | (uint32_t)(st.len - 3));
+            m.syms.push_back(sym);
+            if (m.syms.size() % kBlockSyms == 0) {
+                int64_t end = st.emit == 1 ? p : p - 1 + st.len;
+                BlockRec b;
+                b.start = block_start;
+                b.stored_len = (int32_t)(end - block_start);
+                b.nsyms = kBlockSyms;
+                b.can_store = block_start >= (int64_t)kWSize * k_fired;
+                b.eof = 0;
+                m.blocks.push_back(b);
+                block_start = end;
+            }
+        }
+        if (st.kind == kXK) pend = cK;
+        else if (st.kind == kXK4) pend = cK4;
+        kind = st.kind;
+        p = st.pos;
+    }
+    p_out = p;
+    kind_out = kind;
+    pend_out = pend;
+    kdone_out = k_fired;
+    preins_out = preins;
+    (void)block_start;
+}
+
+
+// ---- stage B: the chunked form the GPU runs ----
+static const int kChunk = 2048;
+static const int kSeg0 = 65275;  // segment_start(1)
+static const int kSeg0Chunks = 32;
+static const int kSegChunks = kWSize / kChunk;  // 16
+static const int kSlots = 260;
+
+struct ChunkGeo {
+    int64_t cs, ce;
+    int seg;      // parse segment the chunk belongs to
+    bool first;   // first chunk of a segment >= 1
+};
+static ChunkGeo chunk_geo(int c) {
+    ChunkGeo g;
+    if (c < kSeg0Chunks) {
+        g.cs = (int64_t)c * kChunk;
+        g.ce = g.cs + kChunk;
+        if (g.ce > kSeg0) g.ce = kSeg0;
+        g.seg = 0;
+        g.first = false;
+    } else {
+        int k = 1 + (c - kSeg0Chunks) / kSegChunks, j = (c - kSeg0Chunks) % kSegChunks;
+        g.cs = kSeg0 + (int64_t)(k - 1) * kWSize + (int64_t)j * kChunk;
+        g.ce = g.cs + kChunk;
+        g.seg = k;
+        g.first = (j == 0);
+    }
+    return g;
+}
+static int chunk_of(int64_t p) {
+    if (p < kSeg0) return (int)(p / kChunk);
+    int64_t r = p - kSeg0;
+    return kSeg0Chunks + (int)(r / kChunk);
+}
+
+struct Sink {
+    Model *m;
+    int64_t idx;          // next symbol index (stream-global)
+    std::vector<uint32_t> *syms;
+    std::vector<int64_t> *blk_end, *blk_top;
+};
+
+// walk one chunk from an entry slot; returns exit slot and symbol count
+static void chunk_walk(Model &m, int c, int slot, int kl, int &exit_slot, int &nsyms, Sink *sink) {
+    ChunkGeo g = chunk_geo(c);
+    int64_t ce = g.ce;
+    if (ce > m.body_end + 1) ce = m.body_end + 1;
+    int kind;
+    int64_t p;
+    if (slot <= 256) kind = kR, p = g.cs + slot;
+    else kind = slot - 256, p = g.cs;  // 257 L, 258 XK, 259 XK4
+    uint32_t pend = kind == kXK ? m.flt(m.mK[p - 1]) : kind == kXK4 ? m.flt(m.mK4[p - 1]) : 0;
+    bool event = g.first && g.seg <= kl;
+    int64_t e = p;
+    bool equal = event && e <= m.body_end && m.bucket(e) == m.bucket(e + 1);
+    int ns = 0;
+    while (p < ce) {
+        uint32_t cK = m.flt(m.mK[p]), cK4 = m.flt(m.mK4[p]);
+        if (p == 0) cK = cK4 = kNoMatch;
+        if (event) {
+            if (equal) {
+                if (p == e) cK = cK4 = kNoMatch;
+                else if (p == e + 1) {
+                    int len = m.strategy == kHuffmanOnly ? 0 : m.lcp(p, e);
+                    cK = cK4 = len >= kMinMatch ? filter_match(len, 1, m.strategy) : kNoMatch;
+                }
+            } else if (p == e + 1) {
+                cK = cK4 = kNoMatch;
+            }
+        }
+        Step st = lazy_step(kind, p, pend, cK, cK4, m.lv);
+        if (st.emit) {
+            if (sink) {
+                uint32_t sym = st.emit == 1 ? (uint32_t)m.data[p - 1] : (((uint32_t)st.dist << 16) | (uint32_t)(st.len - 3));
+                (*sink->syms)[sink->idx] = sym;
+                if ((sink->idx + 1) % kBlockSyms == 0) {
+                    size_t b = (size_t)(sink->idx / kBlockSyms);
+                    (*sink->blk_end)[b] = st.emit == 1 ? p : p - 1 + st.len;
+                    (*sink->blk_top)[b] = p;
+                }
+                sink->idx++;
+            }
+            ns++;
+        }
+        if (st.kind == kXK) pend = cK;
+        else if (st.kind == kXK4) pend = cK4;
+        kind = st.kind;
+        p = st.pos;
+    }
+    exit_slot = kind == kR ? (int)(p - ce) : 256 + kind;
+    nsyms = ns;
+}
+
+static void parse_chunked(Model &m, int64_t &p_out, int &kind_out, uint32_t &pend_out, int &kdone_out, int64_t &preins_out) {
+    int kl = num_refills(m.n);
+    p_out = 0, kind_out = kR, pend_out = 0, kdone_out = 0, preins_out = -1;
+    if (m.body_end < 0) return;
+    int nchunks = chunk_of(m.body_end) + 1;
+    // K3: maps for every chunk and entry slot (embarrassingly parallel on the GPU)
+    std::vector<uint32_t> maps((size_t)nchunks * kSlots);
+    for (int c = 0; c < nchunks; c++)
+        for (int s = 0; s < kSlots; s++) {
+            ChunkGeo g = chunk_geo(c);
+            if (s <= 256 && g.cs + s > m.body_end + 257) { maps[(size_t)c * kSlots + s] = 0; continue; }
+            if (s > 256 && g.cs == 0) { maps[(size_t)c * kSlots + s] = 0; continue; }
+            int ex, ns;
+            chunk_walk(m, c, s, kl, ex, ns, nullptr);
+            maps[(size_t)c * kSlots + s] = (uint32_t)ex | ((uint32_t)ns << 16);
+        }
+    // K4: resolve (one workgroup per stream, sequential over chunks)
+    std::vector<int> entry(nchunks);
+    std::vector<int64_t> symbase(nchunks);
+    std::vector<char> stale(nchunks + 40, 0);
+    int slot = 0, k_fired = 0;
+    int64_t total = 0, preins = -1;
+    long n_dirty = 0, n_equal = 0, n_stale = 0;
+    for (int c = 0; c < nchunks; c++) {
+        ChunkGeo g = chunk_geo(c);
+        int64_t e = slot <= 256 ? g.cs + slot : g.cs;
+        if (g.first && g.seg <= kl && e <= m.body_end) {
+            k_fired++;
+            m.events.push_back(e);
+            preins = e + 1;
+            if (m.bucket(e) == m.bucket(e + 1)) {
+                n_equal++;
+                uint32_t B = m.bucket(e);
+                m.link[e] = 0;
+                int64_t hi = e + kMaxDist;
+                if (hi > m.body_end) hi = m.body_end;
+                for (int64_t p = e + 1; p <= hi; p++) {
+                    if (m.bucket(p) != B) continue;
+                    uint32_t a = m.mK[p], b = m.mK4[p];
+                    bool dirty = (a && p - match_dist(a) < e) || (b && p - match_dist(b) < e);
+                    if (!dirty) continue;
+                    n_dirty++;
+                    uint32_t na, nb;
+                    m.walk(p, na, nb);
+                    if (na != a || nb != b) {
+                        m.mK[p] = na, m.mK4[p] = nb;
+                        stale[chunk_of(p)] = 1;
+                        // the pending match of an X entry at the next chunk's first position reads m[p]
+                        if (p + 1 == chunk_geo(chunk_of(p)).ce) stale[chunk_of(p) + 1] = 1;
+                    }
+                }
+            }
+        }
+        entry[c] = slot;
+        symbase[c] = total;
+        int ex, ns;
+        if (stale[c]) {
+            n_stale++;
+            chunk_walk(m, c, slot, kl, ex, ns, nullptr);
+        } else {
+            uint32_t v = maps[(size_t)c * kSlots + slot];
+            ex = (int)(v & 0xFFFF), ns = (int)(v >> 16);
+        }
+        slot = ex;
+        total += ns;
+    }
+    // K5: emission (one lane per chunk on the GPU)
+    m.syms.assign((size_t)total, 0);
+    size_t nb = (size_t)(total / kBlockSyms);
+    std::vector<int64_t> blk_end(nb), blk_top(nb);
+    for (int c = 0; c < nchunks; c++) {
+        Sink sk{&m, symbase[c], &m.syms, &blk_end, &blk_top};
+        int ex, ns;
+        chunk_walk(m, c, entry[c], kl, ex, ns, &sk);
+    }
+    int64_t bs = 0;
+    for (size_t b = 0; b < nb; b++) {
+        BlockRec r;
+        r.start = bs;
+        r.stored_len = (int32_t)(blk_end[b] - bs);
+        r.nsyms = kBlockSyms;
+        int fired = 0;
+        for (int k = 1; k <= kl; k++)
+            if (segment_start(k) <= blk_top[b]) fired = k;
+        r.can_store = bs >= (int64_t)kWSize * fired;
+        r.eof = 0;
+        m.blocks.push_back(r);
+        bs = blk_end[b];
+    }
+    int64_t ce = m.body_end + 1;
+    kind_out = slot <= 256 ? kR : slot - 256;
+    p_out = slot <= 256 ? ce + slot : ce;
+    pend_out = kind_out == kXK ? m.flt(m.mK[p_out - 1]) : kind_out == kXK4 ? m.flt(m.mK4[p_out - 1]) : 0;
+    kdone_out = k_fired;
+    preins_out = preins;
+    fprintf(stderr, "  chunked: chunks=%d equal_events=%ld dirty=%ld stale_chunks=%ld\n", nchunks, n_equal, n_dirty, n_stale);
+}
+
+static void run_tail(Model &m, int64_t p, int kind, uint32_t pend, int k_done, int64_t preins) {
+    LitEngine e;
+    memset(&e, 0, sizeof e);
+    std::vector<uint8_t> window(kWindowSize + 512);
+    std::vector<uint16_t> head(kHashSize), prev(kWSize);
+    e.window = window.data();
+    e.head = head.data();
+    e.prev = prev.data();
+    e.crc_tab = m.crc_tab.data();
+    e.data = m.data;
+    e.n = m.n;
+    e.lv = m.lv;
+    e.strategy = m.strategy;
+    e.hash_variant = kHashCrc32c;
+    size_t body_syms = m.syms.size();
+    m.syms.resize(body_syms + 2 * kMinLookahead + 600 + (m.lv.func == 1 ? (size_t)m.n : 0));
+    e.syms = m.syms.data();
+    e.nsyms = (int64_t)body_syms;
+    size_t body_blocks = m.blocks.size();
+    m.blocks.resize(body_blocks + 8 + (m.lv.func == 1 ? (size_t)m.n / 16000 : 0));
+    e.blocks = m.blocks.data();
+    e.nblocks = (int)body_blocks;
+    e.block_start_abs = body_blocks ? m.blocks[body_blocks - 1].start + m.blocks[body_blocks - 1].stored_len : 0;
+    le_restore(e, p, k_done, kind, pend, m.link.data(), preins, 0, 1);
+    if (e.avail_end > 0) {
+        int64_t lo = p - (kWSize - 1);
+        if (lo < e.base) lo = e.base;
+        if (lo < 0) lo = 0;
+        for (int64_t q = lo; q < p && q + 5 < m.n; q++) {
+            le_restore_prev(e, q, m.link.data());
+            e.head[le_bucket(e, q)] = (uint16_t)(q - e.base);  // increasing q: last writer = max
+        }
+        le_restore_finish(e, p, m.link.data(), preins);
+    }
+    if (m.lv.func == 1) le_run_fast(e, 0);
+    else le_run_slow(e, 0);
+    m.syms.resize((size_t)e.nsyms);
+    m.blocks.resize((size_t)e.nblocks);
+}
+
+
+// ---- stage C: blocks -> trees -> bit offsets -> bytes, the way the GPU does it ----
+struct BitOr {
+    std::vector<uint8_t> *out;
+    int64_t pos;  // bit position
+    void operator()(unsigned value, int nbits) {
+        for (int i = 0; i < nbits; i++, pos++)
+            if ((value >> i) & 1u) (*out)[(size_t)(pos >> 3)] |= (uint8_t)(1u << (pos & 7));
+    }
+};
+static std::vector<uint8_t> emit_stream(Model &m) {
+    size_t nb = m.blocks.size();
+    std::vector<TreeWork> tw(nb);
+    std::vector<int> type(nb);
+    std::vector<int64_t> bits(nb), bit_start(nb);
+    std::vector<int64_t> sym_off(nb);
+    int64_t so = 0;
+    for (size_t b = 0; b < nb; b++) {  // K7: one workgroup per block
+        sym_off[b] = so;
+        TreeWork &w = tw[b];
+        memset(&w, 0, sizeof w);
+        for (int i = 0; i < m.blocks[b].nsyms; i++) {
+            uint32_t sy = m.syms[(size_t)(so + i)];
+            int dist = (int)(sy >> 16), lc = (int)(sy & 0xFFFF);
+            if (dist == 0) w.ltree[lc].fc++;
+            else {
+                w.ltree[length_code(lc) + kLiterals + 1].fc++;
+                w.dtree[dist_code(dist - 1)].fc++;
+            }
+        }
+        w.ltree[kEndBlock].fc = 1;
+        so += m.blocks[b].nsyms;
+        type[b] = build_block_trees(w, m.blocks[b].stored_len, m.blocks[b].can_store != 0, m.strategy);
+        bits[b] = type[b] == 1 ? 3 + w.static_len : type[b] == 2 ? 3 + w.opt_len : 0;
+    }
+    int64_t pos = 16;  // after the 2-byte zlib header
+    for (size_t b = 0; b < nb; b++) {  // K8: sequential per stream
+        bit_start[b] = pos;
+        if (type[b] == 0) {
+            pos += 3;
+            pos = (pos + 7) & ~7LL;
+            pos += 32 + 8LL * m.blocks[b].stored_len;
+        } else {
+            pos += bits[b];
+        }
+        if (m.blocks[b].eof) pos = (pos + 7) & ~7LL;
+    }
+    std::vector<uint8_t> out((size_t)(pos / 8) + 4 + 8, 0);
+    unsigned hdr = zlib_header(m.level);
+    out[0] = (uint8_t)(hdr >> 8);
+    out[1] = (uint8_t)hdr;
+    for (size_t b = 0; b < nb; b++) {  // K9: one workgroup per block
+        BitOr put{&out, bit_start[b]};
+        put((unsigned)(type[b] << 1) + (m.blocks[b].eof ? 1u : 0u), 3);
+        if (type[b] == 0) {
+            put.pos = (put.pos + 7) & ~7LL;
+            unsigned len = (unsigned)m.blocks[b].stored_len;
+            put(len & 0xFFFF, 16);
+            put(~len & 0xFFFF, 16);
+            for (unsigned i = 0; i < len; i++) out[(size_t)(put.pos >> 3) + i] = m.data[m.blocks[b].start + i];
+            continue;
+        }
+        TreeWork &w = tw[b];
+        if (type[b] == 2) emit_dyn_header(w, put);
+        StaticLTree sl;
+        StaticDTree sd;
+        for (int i = 0; i < m.blocks[b].nsyms; i++) {
+            uint32_t sy = m.syms[(size_t)(sym_off[b] + i)];
+            uint64_t v;
+            int nbts = type[b] == 2 ? encode_symbol(w.ltree, w.dtree, (int)(sy >> 16), (int)(sy & 0xFFFF), v)
+                                    : encode_symbol(sl, sd, (int)(sy >> 16), (int)(sy & 0xFFFF), v);
+            put((unsigned)(v & 0xFFFFFFFFu), nbts > 32 ? 32 : nbts);
+            if (nbts > 32) put((unsigned)(v >> 32), nbts - 32);
+        }
+        if (type[b] == 2) put(w.ltree[kEndBlock].fc, w.ltree[kEndBlock].dl);
+        else put(sl[kEndBlock].fc, sl[kEndBlock].dl);
+        int64_t want_end = bit_start[b] + bits[b];
+        if (put.pos != want_end) printf("block %zu: emitted %ld bits, trees said %ld\n", b, (long)(put.pos - bit_start[b]), (long)bits[b]);
+    }
+    uint32_t ad = zso_adler32(1, m.data, (size_t)m.n);
+    size_t tb = (size_t)(pos / 8);
+    out[tb] = (uint8_t)(ad >> 24), out[tb + 1] = (uint8_t)(ad >> 16), out[tb + 2] = (uint8_t)(ad >> 8), out[tb + 3] = (uint8_t)ad;
+    out.resize(tb + 4);
+    return out;
+}
+
+int main(int argc, char **argv) {
+    if (argc < 3) {
+        fprintf(stderr, "usage: %s file level [strategy] [mode]\n", argv[0]);
+        return 2;
+    }
+    FILE *f = fopen(argv[1], "rb");
+    if (!f) return 2;
+    std::vector<uint8_t> buf;
+    {
+        uint8_t tmp[65536];
+        size_t r;
+        while ((r = fread(tmp, 1, sizeof tmp, f)) > 0) buf.insert(buf.end(), tmp, tmp + r);
+        fclose(f);
+    }
+    int level = atoi(argv[2]);
+    int strategy = argc > 3 ? atoi(argv[3]) : 0;
+    std::string mode = argc > 4 ? argv[4] : "bulk";
+    int64_t n = (int64_t)buf.size();
+    buf.resize(buf.size() + 1024, 0);
+
+    OracleTrace tr;
+    zso_trace t;
+    memset(&t, 0, sizeof t);
+    t.on_symbol = on_symbol;
+    t.on_block = on_block;
+    t.on_read = on_read;
+    t.user = &tr;
+    std::vector<uint8_t> ref(zso_compress_bound((size_t)n));
+    size_t ref_len = zso_compress_stream(buf.data(), (size_t)n, nullptr, 0, level, strategy, 0, 0, ref.data(), ref.size(), &t);
+    if (ref_len == (size_t)-1) {
+        printf("oracle failed\n");
+        return 1;
+    }
+
+    Model m;
+    m.data = buf.data();
+    m.n = n;
+    m.level = level;
+    m.strategy = strategy;
+    m.lv = level_cfg(level);
+    m.crc_tab.resize(1024);
+    for (int tt = 0; tt < 4; tt++)
+        for (int i = 0; i < 256; i++) m.crc_tab[tt * 256 + i] = crc32c_table_entry(tt, (uint32_t)i);
+    m.body_end = (m.lv.func == 2) ? n - kMinLookahead : -1;
+    m.build_links();
+    int64_t p;
+    int kind, k_done;
+    uint32_t pend;
+    int64_t preins;
+    if (mode == "bulk" || mode == "chunk") m.match_all();
+    if (mode == "chunk") parse_chunked(m, p, kind, pend, k_done, preins);
+    else parse_sequential(m, mode != "bulk", p, kind, pend, k_done, preins);
+    run_tail(m, p, kind, pend, k_done, preins);
+
+    bool ok = true;
+    if (m.syms.size() != tr.syms.size()) {
+        printf("symbol count %zu vs oracle %zu\n", m.syms.size(), tr.syms.size());
+        ok = false;
+    }
+    size_t lim = m.syms.size() < tr.syms.size() ? m.syms.size() : tr.syms.size();
+    for (size_t i = 0; i < lim; i++)
+        if (m.syms[i] != tr.syms[i]) {
+            printf("symbol %zu differs: model %08x oracle %08x\n", i, m.syms[i], tr.syms[i]);
+            ok = false;
+            break;
+        }
+    if (m.blocks.size() != tr.blocks.size()) {
+        printf("block count %zu vs oracle %zu\n", m.blocks.size(), tr.blocks.size());
+        ok = false;
+    } else {
+        for (size_t i = 0; i < m.blocks.size(); i++) {
+            const BlockRec &b = m.blocks[i];
+            const OracleTrace::Blk &o = tr.blocks[i];
+            if (b.start != o.start || b.stored_len != o.stored_len || b.nsyms != o.nsyms || b.eof != o.eof) {
+                printf("block %zu differs: start %ld/%ld len %d/%d nsyms %d/%d eof %d/%d\n", i, (long)b.start, (long)o.start,
+                       b.stored_len, o.stored_len, b.nsyms, o.nsyms, b.eof, o.eof);
+                ok = false;
+                break;
+            }
+        }
+    }
+    // events vs oracle reads (reads k >= 1)
+    for (size_t k = 0; k < m.events.size() && k + 1 < tr.read_pos.size(); k++)
+        if (m.events[k] != tr.read_pos[k + 1]) {
+            printf("event %zu at %ld, oracle %ld\n", k + 1, (long)m.events[k], (long)tr.read_pos[k + 1]);
+            ok = false;
+            break;
+        }
+    {
+        std::vector<uint8_t> out = emit_stream(m);
+        if (out.size() != ref_len || memcmp(out.data(), ref.data(), ref_len) != 0) {
+            size_t i = 0;
+            while (i < out.size() && i < ref_len && out[i] == ref[i]) i++;
+            printf("bytes differ: model %zu oracle %zu first diff at %zu\n", out.size(), ref_len, i);
+            ok = false;
+        }
+    }
+    printf("%s n=%ld level=%d strat=%d mode=%s syms=%zu blocks=%zu events=%zu tail_from=%ld\n", ok ? "PASS" : "FAIL", (long)n, level,
+           strategy, mode.c_str(), m.syms.size(), m.blocks.size(), m.events.size(), (long)p);
+    return ok ? 0 : 1;
+}

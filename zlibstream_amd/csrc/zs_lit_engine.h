@@ -1,0 +1,304 @@
+// zs_lit_engine.h -- the sequential tail of a stream, in the reference's own
+// window coordinates.
+//
+// The bulk kernels treat every loop-top with lookahead >= MIN_LOOKAHEAD in
+// absolute coordinates.  The last <= 261 input bytes (where the reference's
+// Longest_match depends on prevLength through the `nice_match > lookahead`
+// clip, where strings past `max_insert` are not inserted, where hashes and
+// Compare256 read stale window bytes past the end of input, and where
+// Fill_window may slide without reading) are finished by this engine: it
+// rebuilds the reference's window / head / prev state at one loop-top from
+// the bulk arrays and then runs DeflateSlow's loop literally.
+//
+// Reference: Deflate.Slow.cs:18-159, Deflate.cs:866-877 (InsertString),
+// :967-1019 (Fill_window), :1022-1100 (Longest_match),
+// Deflate.Intrinsics.cs:174-285 (SlideHash).
+//
+// All functions are ZS_HD; on the device one wave runs an engine instance with
+// every lane executing the same scalar code (wave-uniform), lane 0 storing.
+#pragma once
+#include "zs_core.h"
+
+namespace zs {
+
+struct BlockRec {
+    int64_t start;      // absolute input position of the block's first byte
+    int32_t stored_len; // bytes covered by the block's symbols
+    int32_t nsyms;      // symbols in the block (END_BLOCK not counted)
+    int32_t can_store;  // blockStart >= 0 in window coordinates at flush time
+    int32_t eof;
+};
+
+struct LitEngine {
+    // scratch (per stream)
+    uint8_t *window;  // kWindowSize + 512 bytes
+    uint16_t *head;   // kHashSize
+    uint16_t *prev;   // kWSize
+    const uint32_t *crc_tab;  // 4*256 table or nullptr (falls back to the bitwise form)
+    // stream
+    const uint8_t *data;
+    int64_t n;
+    LevelCfg lv;
+    int strategy, hash_variant;
+    // reference state
+    int64_t base;       // absolute position of window[0]
+    int64_t avail_end;  // absolute end of the input already copied into the window
+    int strstart, lookahead, match_length, match_start, match_available, prev_length, prev_match;
+    int64_t block_start_abs;
+    // outputs
+    uint32_t *syms;     // symbol i: dist << 16 | lc  (dist 0 = literal)
+    int64_t nsyms;      // symbols emitted so far in this stream (body + tail)
+    BlockRec *blocks;
+    int nblocks;
+};
+
+ZS_HD uint32_t le_hash(const LitEngine &e, uint32_t v) {
+    if (e.hash_variant == kHashMul) return hash_mul(v) & kHashMask;
+    if (e.crc_tab) return crc32c_u32_tab(e.crc_tab, v) & kHashMask;
+    return crc32c_u32_slow(v) & kHashMask;
+}
+ZS_HD uint32_t le_load32(const uint8_t *p) {
+    return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+}
+
+// Deflate.cs:866-877
+ZS_HD int le_insert(LitEngine &e, int str) {
+    uint32_t h = le_hash(e, le_load32(e.window + str + 2));
+    int cur = e.head[h];
+    if (cur != str) {
+        e.prev[str & kWMask] = (uint16_t)cur;
+        e.head[h] = (uint16_t)str;
+    }
+    return cur;
+}
+
+// Deflate.cs:967-1019.  The whole remaining input is available (single Write
+// already issued, flush == Finish).
+ZS_HD_NOINLINE inline void le_fill_window(LitEngine &e) {
+    do {
+        int more = kWindowSize - e.lookahead - e.strstart;
+        if (e.strstart >= kSlideAt) {
+            for (int i = 0; i < kWSize; i++) e.window[i] = e.window[i + kWSize];
+            e.match_start -= kWSize;
+            e.strstart -= kWSize;
+            e.base += kWSize;
+            for (int i = 0; i < kHashSize; i++) e.head[i] = (uint16_t)(e.head[i] >= kWSize ? e.head[i] - kWSize : 0);
+            for (int i = 0; i < kWSize; i++) e.prev[i] = (uint16_t)(e.prev[i] >= kWSize ? e.prev[i] - kWSize : 0);
+            more += kWSize;
+        }
+        if (e.avail_end >= e.n) return;
+        int64_t avail = e.n - e.avail_end;
+        int cnt = avail < more ? (int)avail : more;
+        uint8_t *dst = e.window + e.strstart + e.lookahead;
+        const uint8_t *src = e.data + e.avail_end;
+        for (int i = 0; i < cnt; i++) dst[i] = src[i];
+        e.avail_end += cnt;
+        e.lookahead += cnt;
+        if (e.lookahead >= kMinMatch) le_insert(e, e.strstart + 1);
+    } while (e.lookahead < kMinLookahead && e.avail_end < e.n);
+}
+
+// Deflate.cs:1022-1100
+ZS_HD_NOINLINE inline int le_longest_match(LitEngine &e, int cur_match) {
+    int chain_length = e.lv.chain;
+    const uint8_t *scan = e.window + e.strstart;
+    int best_len = e.prev_length;
+    int limit = e.strstart > kMaxDist ? e.strstart - kMaxDist : 0;
+    int nice = e.lv.nice;
+    int ms = e.match_start;
+    if (best_len == 0) best_len = 1;
+    if (e.prev_length >= e.lv.good) chain_length >>= 2;
+    if (nice > e.lookahead) nice = e.lookahead;
+    do {
+        if (cur_match >= e.strstart) break;
+        const uint8_t *m = e.window + cur_match;
+        if (m[best_len] != scan[best_len] || m[best_len - 1] != scan[best_len - 1] || m[0] != scan[0] || m[1] != scan[1])
+            continue;
+        int len = 2;
+        while (len < kMaxMatch && scan[len] == m[len]) len++;
+        if (len > best_len) {
+            ms = cur_match;
+            best_len = len;
+            if (len >= nice) break;
+        }
+    } while ((cur_match = e.prev[cur_match & kWMask]) > limit && --chain_length != 0);
+    e.match_start = ms;
+    return best_len < e.lookahead ? best_len : e.lookahead;
+}
+
+ZS_HD void le_flush_block(LitEngine &e, bool eof, int lane) {
+    int64_t end_abs = e.base + e.strstart;
+    if (lane == 0) {
+        BlockRec &b = e.blocks[e.nblocks];
+        b.start = e.block_start_abs;
+        b.stored_len = (int32_t)(end_abs - e.block_start_abs);
+        b.nsyms = (int32_t)(e.nsyms - (int64_t)e.nblocks * kBlockSyms);
+        b.can_store = e.block_start_abs >= e.base;
+        b.eof = eof;
+    }
+    e.nblocks++;
+    e.block_start_abs = end_abs;
+}
+
+// returns true when the block must be flushed (Deflate.cs:910-948)
+ZS_HD bool le_tally(LitEngine &e, int dist, int lc, int lane) {
+    if (lane == 0) e.syms[e.nsyms] = ((uint32_t)dist << 16) | (uint32_t)lc;
+    e.nsyms++;
+    return (e.nsyms % kBlockSyms) == 0;
+}
+
+// Deflate.Slow.cs:18-159 with flush == Finish, run to the end of the stream.
+ZS_HD_NOINLINE inline void le_run_slow(LitEngine &e, int lane) {
+    int hash_head = 0;
+    for (;;) {
+        if (e.lookahead < kMinLookahead) {
+            le_fill_window(e);
+            if (e.lookahead == 0) break;
+        }
+        if (e.lookahead >= kMinMatch) hash_head = le_insert(e, e.strstart);
+        e.prev_length = e.match_length;
+        e.prev_match = e.match_start;
+        e.match_length = kMinMatch - 1;
+        if (hash_head != 0 && e.prev_length < e.lv.lazy && e.strstart - hash_head <= kMaxDist) {
+            if (e.strategy != kHuffmanOnly) e.match_length = le_longest_match(e, hash_head);
+            if (e.match_length <= 5 &&
+                (e.strategy == kFiltered || (e.match_length == kMinMatch && e.strstart - e.match_start > kTooFar)))
+                e.match_length = kMinMatch - 1;
+        }
+        if (e.prev_length >= kMinMatch && e.match_length <= e.prev_length) {
+            int max_insert = e.strstart + e.lookahead - kMinMatch;
+            bool bflush = le_tally(e, e.strstart - 1 - e.prev_match, e.prev_length - kMinMatch, lane);
+            e.lookahead -= e.prev_length - 1;
+            e.prev_length -= 2;
+            do {
+                if (++e.strstart <= max_insert) hash_head = le_insert(e, e.strstart);
+            } while (--e.prev_length != 0);
+            e.match_available = 0;
+            e.match_length = kMinMatch - 1;
+            e.strstart++;
+            if (bflush) le_flush_block(e, false, lane);
+        } else if (e.match_available != 0) {
+            bool bflush = le_tally(e, 0, e.window[e.strstart - 1], lane);
+            if (bflush) le_flush_block(e, false, lane);
+            e.strstart++;
+            e.lookahead--;
+        } else {
+            e.match_available = 1;
+            e.strstart++;
+            e.lookahead--;
+        }
+    }
+    if (e.match_available != 0) {
+        le_tally(e, 0, e.window[e.strstart - 1], lane);
+        e.match_available = 0;
+    }
+    le_flush_block(e, true, lane);
+}
+
+// Deflate.Fast.cs:20-128 with flush == Finish, run to the end of the stream.
+ZS_HD_NOINLINE inline void le_run_fast(LitEngine &e, int lane) {
+    for (;;) {
+        if (e.lookahead < kMinLookahead) {
+            le_fill_window(e);
+            if (e.lookahead == 0) break;
+        }
+        int hash_head = 0;
+        if (e.lookahead >= kMinMatch) hash_head = le_insert(e, e.strstart);
+        if (hash_head != 0 && e.strstart - hash_head <= kMaxDist) {
+            if (e.strategy != kHuffmanOnly) e.match_length = le_longest_match(e, hash_head);
+        }
+        bool bflush;
+        if (e.match_length >= kMinMatch) {
+            bflush = le_tally(e, e.strstart - e.match_start, e.match_length - kMinMatch, lane);
+            e.lookahead -= e.match_length;
+            if (e.match_length <= e.lv.lazy && e.lookahead >= kMinMatch) {
+                e.match_length--;
+                do {
+                    e.strstart++;
+                    le_insert(e, e.strstart);
+                } while (--e.match_length != 0);
+                e.strstart++;
+            } else {
+                e.strstart += e.match_length;
+                e.match_length = 0;
+            }
+        } else {
+            bflush = le_tally(e, 0, e.window[e.strstart], lane);
+            e.lookahead--;
+            e.strstart++;
+        }
+        if (bflush) le_flush_block(e, false, lane);
+    }
+    le_flush_block(e, true, lane);
+}
+
+// Rebuild the reference state at absolute loop-top `p` of a single-Write
+// stream whose first `k_done` refills (reads k = 1..k_done, each preceded by a
+// slide) have happened, from the bulk arrays:
+//   link[q]  distance from q to the previous position in q's hash bucket
+//            (0 = none within 32767), valid for q <= n - 6, with link[s] = 0 at
+//            every resolved equal-bucket refill position s;
+//   kind / pend  the lazy-parse node at p (zs_core.h) and its pending match;
+//   preins  the position that the last refill pre-inserted (s_k + 1) or -1.
+// `lane`/`nlanes` split the copy loops across a wave on the device.
+ZS_HD_NOINLINE inline void le_restore(LitEngine &e, int64_t p, int k_done, int kind, uint32_t pend, const uint16_t *link,
+                                      int64_t preins, int lane, int nlanes) {
+    e.base = (int64_t)kWSize * k_done;
+    e.avail_end = read_end_before(k_done + 1);
+    if (e.avail_end > e.n) e.avail_end = e.n;
+    bool started = (p > 0 || k_done > 0 || kind != kR);
+    if (!started) e.avail_end = 0;  // nothing read yet: the engine performs read 0 itself
+    int64_t valid = e.avail_end - e.base;
+    for (int w = lane; w < kWindowSize + 512; w += nlanes) {
+        uint8_t v = 0;
+        if (w < valid) v = e.data[e.base + w];
+        else if (k_done >= 1 && w < kWindowSize) v = e.data[e.base + w - kWSize];  // stale upper half
+        e.window[w] = v;
+    }
+    for (int i = lane; i < kHashSize; i += nlanes) e.head[i] = 0;
+    for (int i = lane; i < kWSize; i += nlanes) e.prev[i] = 0;
+    e.strstart = (int)(p - e.base);
+    e.lookahead = (int)(e.avail_end - p);
+    e.match_available = (kind == kR) ? 0 : 1;
+    e.match_length = (kind == kXK || kind == kXK4) ? match_len(pend) : kMinMatch - 1;
+    e.match_start = (kind == kXK || kind == kXK4) ? (int)((p - 1 - match_dist(pend)) - e.base) : 0;
+    e.prev_length = kMinMatch - 1;
+    e.prev_match = 0;
+}
+
+// Second phase of the restore (after a barrier on the device): prev[] for the
+// positions q in [q0, q1) whose bucket depends on real input only (q <= n-6),
+// straight from the bulk links.  Parallel over q.
+ZS_HD void le_restore_prev(LitEngine &e, int64_t q, const uint16_t *link) {
+    int w = (int)(q - e.base);
+    int64_t c = link[q] ? q - (int64_t)link[q] : -1;
+    e.prev[w & kWMask] = (uint16_t)(c >= e.base ? c - e.base : 0);
+}
+// bucket of an already-restored window position
+ZS_HD uint32_t le_bucket(const LitEngine &e, int64_t q) { return le_hash(e, le_load32(e.window + (q - e.base) + 2)); }
+
+// Third phase, sequential: the few positions below p that were inserted with
+// hashes reaching past the end of input (q in [n-5, p), at most 3 of them are
+// <= max_insert = n-3), then the pending pre-insert of the last refill.
+ZS_HD_NOINLINE inline void le_restore_finish(LitEngine &e, int64_t p, const uint16_t *link, int64_t preins) {
+    int64_t q = e.n - 5;
+    if (q < 0) q = 0;
+    if (q < e.base) q = e.base;
+    for (; q < p && q <= e.n - kMinMatch; q++) le_insert(e, (int)(q - e.base));
+    if (preins >= p && preins >= 1) {
+        // the refill at loop-top preins-1 inserted preins before preins-1 (Deflate.cs:1010-1013)
+        int w = (int)(preins - e.base);
+        uint32_t h1 = le_hash(e, le_load32(e.window + w + 2));
+        uint32_t h0 = le_hash(e, le_load32(e.window + w - 1 + 2));
+        if (h0 == h1) {
+            // head[h] == preins-1 already; the reference left prev[preins-1] = preins
+            e.prev[(w - 1) & kWMask] = (uint16_t)w;
+        } else {
+            int64_t c = link[preins] ? preins - (int64_t)link[preins] : -1;
+            e.prev[w & kWMask] = (uint16_t)(c >= e.base ? c - e.base : 0);
+            e.head[h1] = (uint16_t)w;
+        }
+    }
+}
+
+}  // namespace zs
