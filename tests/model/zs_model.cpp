@@ -71,36 +71,13 @@ struct Model {
         while (len < kMaxMatch && data[p + len] == data[c + len]) len++;
         return len;
     }
-    // floor-2 walk for both budgets (Deflate.cs:1022-1100 with prevLength == 2)
+    // floor-2 walk for both budgets: shared with the device code
     void walk(int64_t p, uint32_t &outK, uint32_t &outK4) const {
         outK = outK4 = kNoMatch;
         if (lv.func != 2 || strategy == kHuffmanOnly) return;
-        int l = link[p];
-        if (!l) return;
-        int64_t c = p - l;
-        if (c < 1 || p - c > kMaxDist) return;
-        int best = 2, bdist = 0, n_eval = 0, k4 = lv.chain >> 2;
-        bool snap = false;
-        for (;;) {
-            int len = lcp(p, c);
-            n_eval++;
-            bool nice_exit = false;
-            if (len > best) {
-                best = len;
-                bdist = (int)(p - c);
-                if (len >= lv.nice) nice_exit = true;
-            }
-            if (n_eval == k4 || (nice_exit && n_eval < k4)) {
-                if (!snap) outK4 = best >= kMinMatch ? pack_match(best, bdist) : kNoMatch, snap = true;
-            }
-            if (nice_exit || n_eval == lv.chain) break;
-            l = link[c];
-            if (!l) break;
-            c -= l;
-            if (c < 1 || p - c >= kMaxDist) break;
-        }
-        outK = best >= kMinMatch ? pack_match(best, bdist) : kNoMatch;
-        if (!snap) outK4 = outK;
+        auto lk = [this](int64_t q) { return (int)link[q]; };
+        auto lc = [this](int64_t a, int64_t c) { return lcp(a, c); };
+        walk_matches(lk, lc, p, lv, outK, outK4);
     }
     uint32_t flt(uint32_t m) const { return m ? filter_match(match_len(m), match_dist(m), strategy) : kNoMatch; }
     void match_all() {
@@ -169,96 +146,35 @@ static void parse_sequential(Model &m, bool on_demand, int64_t &p_out, int &kind
 
 
 // ---- stage B: the chunked form the GPU runs ----
-static const int kChunk = 2048;
-static const int kSeg0 = 65275;  // segment_start(1)
-static const int kSeg0Chunks = 32;
-static const int kSegChunks = kWSize / kChunk;  // 16
-static const int kSlots = 260;
-
-struct ChunkGeo {
-    int64_t cs, ce;
-    int seg;      // parse segment the chunk belongs to
-    bool first;   // first chunk of a segment >= 1
-};
-static ChunkGeo chunk_geo(int c) {
-    ChunkGeo g;
-    if (c < kSeg0Chunks) {
-        g.cs = (int64_t)c * kChunk;
-        g.ce = g.cs + kChunk;
-        if (g.ce > kSeg0) g.ce = kSeg0;
-        g.seg = 0;
-        g.first = false;
-    } else {
-        int k = 1 + (c - kSeg0Chunks) / kSegChunks, j = (c - kSeg0Chunks) % kSegChunks;
-        g.cs = kSeg0 + (int64_t)(k - 1) * kWSize + (int64_t)j * kChunk;
-        g.ce = g.cs + kChunk;
-        g.seg = k;
-        g.first = (j == 0);
-    }
-    return g;
-}
-static int chunk_of(int64_t p) {
-    if (p < kSeg0) return (int)(p / kChunk);
-    int64_t r = p - kSeg0;
-    return kSeg0Chunks + (int)(r / kChunk);
-}
-
 struct Sink {
-    Model *m;
-    int64_t idx;          // next symbol index (stream-global)
+    int64_t base;  // stream-global index of the chunk's first symbol
     std::vector<uint32_t> *syms;
     std::vector<int64_t> *blk_end, *blk_top;
-};
-
-// walk one chunk from an entry slot; returns exit slot and symbol count
-static void chunk_walk(Model &m, int c, int slot, int kl, int &exit_slot, int &nsyms, Sink *sink) {
-    ChunkGeo g = chunk_geo(c);
-    int64_t ce = g.ce;
-    if (ce > m.body_end + 1) ce = m.body_end + 1;
-    int kind;
-    int64_t p;
-    if (slot <= 256) kind = kR, p = g.cs + slot;
-    else kind = slot - 256, p = g.cs;  // 257 L, 258 XK, 259 XK4
-    uint32_t pend = kind == kXK ? m.flt(m.mK[p - 1]) : kind == kXK4 ? m.flt(m.mK4[p - 1]) : 0;
-    bool event = g.first && g.seg <= kl;
-    int64_t e = p;
-    bool equal = event && e <= m.body_end && m.bucket(e) == m.bucket(e + 1);
-    int ns = 0;
-    while (p < ce) {
-        uint32_t cK = m.flt(m.mK[p]), cK4 = m.flt(m.mK4[p]);
-        if (p == 0) cK = cK4 = kNoMatch;
-        if (event) {
-            if (equal) {
-                if (p == e) cK = cK4 = kNoMatch;
-                else if (p == e + 1) {
-                    int len = m.strategy == kHuffmanOnly ? 0 : m.lcp(p, e);
-                    cK = cK4 = len >= kMinMatch ? filter_match(len, 1, m.strategy) : kNoMatch;
-                }
-            } else if (p == e + 1) {
-                cK = cK4 = kNoMatch;
-            }
+    void operator()(int i, uint32_t sym, int64_t end, int64_t top) {
+        int64_t idx = base + i;
+        (*syms)[(size_t)idx] = sym;
+        if ((idx + 1) % kBlockSyms == 0) {
+            size_t b = (size_t)(idx / kBlockSyms);
+            (*blk_end)[b] = end;
+            (*blk_top)[b] = top;
         }
-        Step st = lazy_step(kind, p, pend, cK, cK4, m.lv);
-        if (st.emit) {
-            if (sink) {
-                uint32_t sym = st.emit == 1 ? (uint32_t)m.data[p - 1] : (((uint32_t)st.dist << 16) | (uint32_t)(st.len - 3));
-                (*sink->syms)[sink->idx] = sym;
-                if ((sink->idx + 1) % kBlockSyms == 0) {
-                    size_t b = (size_t)(sink->idx / kBlockSyms);
-                    (*sink->blk_end)[b] = st.emit == 1 ? p : p - 1 + st.len;
-                    (*sink->blk_top)[b] = p;
-                }
-                sink->idx++;
-            }
-            ns++;
-        }
-        if (st.kind == kXK) pend = cK;
-        else if (st.kind == kXK4) pend = cK4;
-        kind = st.kind;
-        p = st.pos;
     }
-    exit_slot = kind == kR ? (int)(p - ce) : 256 + kind;
-    nsyms = ns;
+};
+struct ModelAcc {
+    const Model *m;
+    uint32_t mK(int64_t p) const { return m->flt(m->mK[p]); }
+    uint32_t mK4(int64_t p) const { return m->flt(m->mK4[p]); }
+    uint8_t byte(int64_t p) const { return m->data[p]; }
+    uint32_t bucket(int64_t p) const { return m->bucket(p); }
+    int run1(int64_t p) const { return m->lcp(p, p - 1); }
+};
+static void chunk_walk(Model &m, int c, int slot, int kl, int &exit_slot, int &nsyms, Sink *sink) {
+    ModelAcc acc{&m};
+    if (sink) walk_chunk(acc, *sink, c, slot, kl, m.body_end, m.lv, m.strategy, exit_slot, nsyms);
+    else {
+        NullSink ns;
+        walk_chunk(acc, ns, c, slot, kl, m.body_end, m.lv, m.strategy, exit_slot, nsyms);
+    }
 }
 
 static void parse_chunked(Model &m, int64_t &p_out, int &kind_out, uint32_t &pend_out, int &kdone_out, int64_t &preins_out) {
@@ -270,9 +186,7 @@ static void parse_chunked(Model &m, int64_t &p_out, int &kind_out, uint32_t &pen
     std::vector<uint32_t> maps((size_t)nchunks * kSlots);
     for (int c = 0; c < nchunks; c++)
         for (int s = 0; s < kSlots; s++) {
-            ChunkGeo g = chunk_geo(c);
-            if (s <= 256 && g.cs + s > m.body_end + 257) { maps[(size_t)c * kSlots + s] = 0; continue; }
-            if (s > 256 && g.cs == 0) { maps[(size_t)c * kSlots + s] = 0; continue; }
+            if (!slot_valid(c, s, m.body_end)) { maps[(size_t)c * kSlots + s] = 0; continue; }
             int ex, ns;
             chunk_walk(m, c, s, kl, ex, ns, nullptr);
             maps[(size_t)c * kSlots + s] = (uint32_t)ex | ((uint32_t)ns << 16);
@@ -332,7 +246,7 @@ static void parse_chunked(Model &m, int64_t &p_out, int &kind_out, uint32_t &pen
     size_t nb = (size_t)(total / kBlockSyms);
     std::vector<int64_t> blk_end(nb), blk_top(nb);
     for (int c = 0; c < nchunks; c++) {
-        Sink sk{&m, symbase[c], &m.syms, &blk_end, &blk_top};
+        Sink sk{symbase[c], &m.syms, &blk_end, &blk_top};
         int ex, ns;
         chunk_walk(m, c, entry[c], kl, ex, ns, &sk);
     }
@@ -342,9 +256,7 @@ static void parse_chunked(Model &m, int64_t &p_out, int &kind_out, uint32_t &pen
         r.start = bs;
         r.stored_len = (int32_t)(blk_end[b] - bs);
         r.nsyms = kBlockSyms;
-        int fired = 0;
-        for (int k = 1; k <= kl; k++)
-            if (segment_start(k) <= blk_top[b]) fired = k;
+        int fired = refills_fired_at(blk_top[b], kl);
         r.can_store = bs >= (int64_t)kWSize * fired;
         r.eof = 0;
         m.blocks.push_back(r);
