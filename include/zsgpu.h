@@ -1,0 +1,135 @@
+/*
+ * zsgpu.h -- C ABI of the MI355X (gfx950) deflate engine for SixLabors/ZlibStream.
+ *
+ * The reference has no native boundary today (it is 100 % managed C#).  The
+ * seam this library replaces is the zlib-style pair inside the reference's
+ * internal z_stream facade:
+ *
+ *     CompressionState ZLibStream.Deflate(FlushMode)   src/ZlibStream/ZlibStream.cs:164-167
+ *       -> Deflate.Compress(ZLibStream, FlushMode)     src/ZlibStream/Deflate.cs:436-636
+ *     CompressionState ZLibStream.Inflate(FlushMode)   src/ZlibStream/ZlibStream.cs:119-122
+ *       -> Inflate.Decompress(ZLibStream, FlushMode)   src/ZlibStream/Inflate.cs:103-357
+ *
+ * i.e. ZlibOutputStream / ZlibInputStream keep their public surface and their
+ * WriteCore / Finish / ReadCore loops (ZlibOutputStream.cs:125-168, 213-256,
+ * ZlibInputStream.cs:133-186); the engine object behind them is this library.
+ * INTEGRATION.md shows the P/Invoke stub.
+ *
+ * Conventions: plain C, no C++ or torch types; return values are the
+ * reference's CompressionState codes (CompressionState.cs); all pointers are
+ * used only for the duration of the call unless stated otherwise (the
+ * reference pins caller spans only inside WriteCore/ReadCore).
+ *
+ * There is NO CPU fallback: every entry point that compresses fails with
+ * ZS_STREAM_ERROR and a message when no gfx950 device is usable.
+ */
+#ifndef ZSGPU_H
+#define ZSGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(_WIN32)
+#define ZS_API __declspec(dllexport)
+#else
+#define ZS_API __attribute__((visibility("default")))
+#endif
+
+/* CompressionState.cs */
+enum {
+    ZS_VERSION_ERROR = -6,
+    ZS_BUF_ERROR = -5,
+    ZS_MEM_ERROR = -4,
+    ZS_DATA_ERROR = -3,
+    ZS_STREAM_ERROR = -2,
+    ZS_ERRNO = -1,
+    ZS_OK = 0,
+    ZS_STREAM_END = 1,
+    ZS_NEED_DICT = 2
+};
+/* FlushMode.cs */
+enum { ZS_NO_FLUSH = 0, ZS_PARTIAL_FLUSH = 1, ZS_SYNC_FLUSH = 2, ZS_FULL_FLUSH = 3, ZS_FINISH = 4 };
+/* CompressionStrategy.cs */
+enum { ZS_DEFAULT_STRATEGY = 0, ZS_FILTERED = 1, ZS_HUFFMAN_ONLY = 2, ZS_RLE = 3, ZS_FIXED = 4 };
+/* Deflate.Intrinsics.cs:295-307: which UpdateHash the managed build would take */
+enum { ZS_HASH_CRC32C = 0, ZS_HASH_MUL = 1 };
+
+/* ------------------------------------------------------------------ */
+/* Engine context: one per GPU (device ordinal as seen by HIP).  Owns the HIP
+ * stream-ordered workspace that is reused across calls.  Not thread-safe;
+ * distinct contexts are independent (as distinct reference Deflate instances
+ * are, Deflate.Buffers.cs). */
+typedef struct zs_ctx zs_ctx;
+
+ZS_API int zs_ctx_create(int device, zs_ctx **out);
+ZS_API void zs_ctx_destroy(zs_ctx *ctx);
+ZS_API const char *zs_ctx_last_error(const zs_ctx *ctx);
+
+/* Upper bound of the zlib stream produced for n input bytes. */
+ZS_API int64_t zs_deflate_bound(int64_t n);
+
+/* ------------------------------------------------------------------ */
+/* Throughput entry points: n independent buffers, each compressed exactly as
+ *     using (var s = new ZlibOutputStream(dst, level)) s.Write(buf, 0, len);
+ * does (one Write of the whole buffer, then Dispose -> Finish;
+ * ZlibOutputStream.cs:114-168,186-256; DeflateCorpusBenchmark.cs:86-100).
+ *
+ * _device: in[i] / out[i] are DEVICE pointers on ctx's GPU (inputs already
+ * resident in HBM); `hip_stream` is a hipStream_t (NULL = the context's own
+ * stream).  out_len[i] is a HOST array; the call returns after the results
+ * are known (it synchronises the stream once).
+ * Returns ZS_OK, or the first failing stream's code; per-stream codes are in
+ * status[i] when status != NULL (ZS_BUF_ERROR when out_cap[i] is too small). */
+ZS_API int zs_deflate_batch_device(zs_ctx *ctx, int n, const void *const *in, const int64_t *in_len, void *const *out,
+                                   const int64_t *out_cap, int64_t *out_len, int *status, int level, int strategy,
+                                   int hash_variant, void *hip_stream);
+
+/* Host-pointer form: copies in over PCIe, runs the device path, copies out. */
+ZS_API int zs_deflate_batch(zs_ctx *ctx, int n, const void *const *in, const int64_t *in_len, void *const *out,
+                            const int64_t *out_cap, int64_t *out_len, int *status, int level, int strategy,
+                            int hash_variant);
+
+/* Stage timing of the last *_batch_device call, measured with hipEvents on
+ * the stream the kernels ran on.  Enable before the call. */
+ZS_API void zs_ctx_set_profiling(zs_ctx *ctx, int enable);
+ZS_API int zs_ctx_stage_count(const zs_ctx *ctx);
+ZS_API const char *zs_ctx_stage_name(const zs_ctx *ctx, int stage);
+ZS_API double zs_ctx_stage_ms(const zs_ctx *ctx, int stage);
+
+/* ------------------------------------------------------------------ */
+/* z_stream-shaped streaming interface: what ZLibStream.Deflate(flush) binds to.
+ *
+ * zs_deflate_init  <- Deflate..ctor (Deflate.cs:228-310): level -1..9,
+ *   strategy 0..4, window_bits +-9..15 (negative = no zlib header/trailer),
+ *   mem_level 1..9.  Argument errors return NULL (the reference throws
+ *   ArgumentOutOfRangeException).
+ * zs_deflate       <- Deflate.Compress (Deflate.cs:436-636).  The cursor fields
+ *   of ZLibStream (ZlibStream.cs:34-94) are passed explicitly: *avail_in /
+ *   *avail_out are decremented, *total_in / *total_out advanced, *adler
+ *   updated.  Input is copied during the call.  Under ZS_NO_FLUSH the engine
+ *   buffers input and records the Write boundary; compression runs on the GPU
+ *   when ZS_FINISH arrives, after which output is handed out avail_out bytes
+ *   at a time exactly like Flush_pending (Deflate.cs:828-854).
+ * zs_deflate_end   <- Deflate.Dispose.
+ * zs_last_message  <- ZLibStream.Message. */
+typedef struct zs_deflate_stream zs_deflate_stream;
+
+ZS_API zs_deflate_stream *zs_deflate_init(zs_ctx *ctx, int level, int strategy, int window_bits, int mem_level,
+                                          int hash_variant);
+ZS_API int zs_deflate(zs_deflate_stream *s, const uint8_t *next_in, int32_t *avail_in, uint8_t *next_out,
+                      int32_t *avail_out, int flush, uint32_t *adler, int64_t *total_in, int64_t *total_out);
+ZS_API void zs_deflate_end(zs_deflate_stream *s);
+ZS_API const char *zs_last_message(const zs_deflate_stream *s);
+
+/* Adler32.Calculate (Adler32.cs:61-78) on the GPU, for a device-resident
+ * buffer; result returned to the host. */
+ZS_API int zs_adler32_device(zs_ctx *ctx, const void *d_buf, int64_t len, uint32_t seed, uint32_t *out, void *hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -12,6 +12,7 @@
 // usage: zs_model <file> <level> [strategy] [chunk]      -> prints PASS/FAIL
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -51,6 +52,7 @@ struct Model {
     std::vector<BlockRec> blocks;
     std::vector<int64_t> events;  // s_k for k = 1..
     int64_t body_end;             // last body loop-top position (n - 262), or -1
+    std::vector<int64_t> wr_end;
 
     uint32_t bucket(int64_t p) const {
         uint32_t v = (uint32_t)data[p + 2] | ((uint32_t)data[p + 3] << 8) | ((uint32_t)data[p + 4] << 16) | ((uint32_t)data[p + 5] << 24);
@@ -285,12 +287,15 @@ static void run_tail(Model &m, int64_t p, int kind, uint32_t pend, int k_done, i
     e.lv = m.lv;
     e.strategy = m.strategy;
     e.hash_variant = kHashCrc32c;
+    e.wr_end = m.wr_end.size() > 1 ? m.wr_end.data() : nullptr;
+    e.n_wr = (int)m.wr_end.size();
+    e.cur_wr = 0;
     size_t body_syms = m.syms.size();
-    m.syms.resize(body_syms + 2 * kMinLookahead + 600 + (m.lv.func == 1 ? (size_t)m.n : 0));
+    m.syms.resize(body_syms + 2 * kMinLookahead + 600 + (m.body_end < 0 ? (size_t)m.n : 0));
     e.syms = m.syms.data();
     e.nsyms = (int64_t)body_syms;
     size_t body_blocks = m.blocks.size();
-    m.blocks.resize(body_blocks + 8 + (m.lv.func == 1 ? (size_t)m.n / 16000 : 0));
+    m.blocks.resize(body_blocks + 8 + (m.body_end < 0 ? (size_t)m.n / 16000 : 0));
     e.blocks = m.blocks.data();
     e.nblocks = (int)body_blocks;
     e.block_start_abs = body_blocks ? m.blocks[body_blocks - 1].start + m.blocks[body_blocks - 1].stored_len : 0;
@@ -305,8 +310,8 @@ static void run_tail(Model &m, int64_t p, int kind, uint32_t pend, int k_done, i
         }
         le_restore_finish(e, p, m.link.data(), preins);
     }
-    if (m.lv.func == 1) le_run_fast(e, 0);
-    else le_run_slow(e, 0);
+    if (m.lv.func == 1) le_run_fast(e, 0, 1);
+    else le_run_slow(e, 0, 1);
     m.syms.resize((size_t)e.nsyms);
     m.blocks.resize((size_t)e.nblocks);
 }
@@ -414,6 +419,7 @@ int main(int argc, char **argv) {
     int level = atoi(argv[2]);
     int strategy = argc > 3 ? atoi(argv[3]) : 0;
     std::string mode = argc > 4 ? argv[4] : "bulk";
+    size_t wchunk = argc > 5 ? (size_t)atol(argv[5]) : 0;
     int64_t n = (int64_t)buf.size();
     buf.resize(buf.size() + 1024, 0);
 
@@ -425,7 +431,16 @@ int main(int argc, char **argv) {
     t.on_read = on_read;
     t.user = &tr;
     std::vector<uint8_t> ref(zso_compress_bound((size_t)n));
-    size_t ref_len = zso_compress_stream(buf.data(), (size_t)n, nullptr, 0, level, strategy, 0, 0, ref.data(), ref.size(), &t);
+    std::vector<size_t> wlens;
+    std::vector<int64_t> wends;
+    if (wchunk) {
+        for (size_t o = 0; o < (size_t)n; o += wchunk) {
+            wlens.push_back(std::min(wchunk, (size_t)n - o));
+            wends.push_back((int64_t)(o + wlens.back()));
+        }
+    }
+    size_t ref_len = zso_compress_stream(buf.data(), (size_t)n, wlens.empty() ? nullptr : wlens.data(), wlens.size(), level, strategy, 0, 0,
+                                         ref.data(), ref.size(), &t);
     if (ref_len == (size_t)-1) {
         printf("oracle failed\n");
         return 1;
@@ -440,7 +455,8 @@ int main(int argc, char **argv) {
     m.crc_tab.resize(1024);
     for (int tt = 0; tt < 4; tt++)
         for (int i = 0; i < 256; i++) m.crc_tab[tt * 256 + i] = crc32c_table_entry(tt, (uint32_t)i);
-    m.body_end = (m.lv.func == 2) ? n - kMinLookahead : -1;
+    m.body_end = (m.lv.func == 2 && wends.size() <= 1) ? n - kMinLookahead : -1;
+    m.wr_end = wends;
     m.build_links();
     int64_t p;
     int kind, k_done;

@@ -1,0 +1,9 @@
+"""zlibstream_amd -- MI355X (gfx950) deflate engine behind the ZlibStream API.
+
+Host-side mirror of the reference's public surface (ZlibOutputStream,
+ZlibOptions, CompressionLevel, CompressionStrategy, FlushMode,
+ZlibStreamException) over the C ABI in include/zsgpu.h.  The compression path
+has no CPU fallback: it needs libzsgpu.so and an MI355X.
+"""
+from .api import (CompressionLevel, CompressionState, CompressionStrategy, Engine, FlushMode, ZlibOptions,  # noqa: F401
+                  ZlibOutputStream, ZlibStreamException, compress, deflate_bound)

@@ -1,0 +1,271 @@
+"""Python mirror of the reference's Stream-level API for the deflate path.
+
+Names, argument meaning and error behaviour follow src/ZlibStream/
+ZlibOutputStream.cs, ZlibOptions.cs, CompressionLevel.cs,
+CompressionStrategy.cs, FlushMode.cs, ZlibStreamException.cs and
+ThrowHelper.cs:21-23 of the reference, so that the parity tests read like the
+reference's own (tests/ZlibStream.Tests/ZlibStreamTests.Roundtrip.cs).
+"""
+import ctypes
+import enum
+import io
+
+from . import _native
+
+
+class CompressionLevel(enum.IntEnum):  # CompressionLevel.cs
+    DefaultCompression = -1
+    Level0 = 0
+    NoCompression = 0
+    Level1 = 1
+    BestSpeed = 1
+    Level2 = 2
+    Level3 = 3
+    Level4 = 4
+    Level5 = 5
+    Level6 = 6
+    Level7 = 7
+    Level8 = 8
+    Level9 = 9
+    BestCompression = 9
+
+
+class CompressionStrategy(enum.IntEnum):  # CompressionStrategy.cs
+    DefaultStrategy = 0
+    Filtered = 1
+    HuffmanOnly = 2
+    Rle = 3
+    Fixed = 4
+
+
+class FlushMode(enum.IntEnum):  # FlushMode.cs
+    NoFlush = 0
+    PartialFlush = 1
+    SyncFlush = 2
+    FullFlush = 3
+    Finish = 4
+
+
+class CompressionState(enum.IntEnum):  # CompressionState.cs
+    ZVERSIONERROR = -6
+    ZBUFERROR = -5
+    ZMEMERROR = -4
+    ZDATAERROR = -3
+    ZSTREAMERROR = -2
+    ZERRNO = -1
+    ZOK = 0
+    ZSTREAMEND = 1
+    ZNEEDDICT = 2
+
+
+class ZlibStreamException(Exception):  # ZlibStreamException.cs
+    pass
+
+
+class ZlibOptions:  # ZlibOptions.cs
+    def __init__(self, CompressionLevel=None, CompressionStrategy=CompressionStrategy.DefaultStrategy,
+                 FlushMode=FlushMode.NoFlush):
+        self.CompressionLevel = CompressionLevel
+        self.CompressionStrategy = CompressionStrategy
+        self.FlushMode = FlushMode
+
+
+def deflate_bound(n):
+    return int(_native.lib().zs_deflate_bound(int(n)))
+
+
+class Engine:
+    """One zs_ctx: a GPU plus its reusable workspace."""
+
+    def __init__(self, device=0):
+        self._lib = _native.lib()
+        h = ctypes.c_void_p()
+        rc = self._lib.zs_ctx_create(int(device), ctypes.byref(h))
+        if rc != 0 or not h:
+            raise RuntimeError("zs_ctx_create(device=%d) failed with %d: no usable MI355X / HIP device. "
+                               "There is no CPU fallback." % (device, rc))
+        self._h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.zs_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        return self._h
+
+    def last_error(self):
+        return (self._lib.zs_ctx_last_error(self._h) or b"").decode()
+
+    def set_profiling(self, on):
+        self._lib.zs_ctx_set_profiling(self._h, 1 if on else 0)
+
+    def stage_ms(self):
+        n = self._lib.zs_ctx_stage_count(self._h)
+        return {self._lib.zs_ctx_stage_name(self._h, i).decode(): self._lib.zs_ctx_stage_ms(self._h, i) for i in range(n)}
+
+    def _call_batch(self, fn, in_ptrs, in_lens, out_ptrs, out_caps, level, strategy, hash_variant, extra=()):
+        n = len(in_ptrs)
+        VP = ctypes.c_void_p * n
+        I64 = ctypes.c_int64 * n
+        I32 = ctypes.c_int * n
+        out_len = I64()
+        status = I32()
+        rc = fn(self._h, n, VP(*in_ptrs), I64(*in_lens), VP(*out_ptrs), I64(*out_caps), out_len, status, int(level),
+                int(strategy), int(hash_variant), *extra)
+        return rc, list(out_len), list(status)
+
+    def deflate_batch_device(self, in_ptrs, in_lens, out_ptrs, out_caps, level=6, strategy=0, hash_variant=0, stream=None):
+        """Device-resident buffers (raw device pointers as ints).  Returns the output lengths."""
+        rc, lens, status = self._call_batch(self._lib.zs_deflate_batch_device, in_ptrs, in_lens, out_ptrs, out_caps, level,
+                                            strategy, hash_variant, (ctypes.c_void_p(stream or 0),))
+        if rc != 0:
+            raise ZlibStreamException("deflating: " + self.last_error())
+        return lens
+
+    def deflate_batch(self, buffers, level=6, strategy=0, hash_variant=0):
+        """Host buffers (bytes-like) -> list of zlib streams (bytes)."""
+        bufs = [bytes(b) for b in buffers]
+        n = len(bufs)
+        if n == 0:
+            return []
+        keep = [ctypes.create_string_buffer(b, len(b)) if len(b) else ctypes.create_string_buffer(1) for b in bufs]
+        caps = [deflate_bound(len(b)) for b in bufs]
+        outs = [ctypes.create_string_buffer(c) for c in caps]
+        rc, lens, status = self._call_batch(self._lib.zs_deflate_batch, [ctypes.addressof(k) for k in keep],
+                                            [len(b) for b in bufs], [ctypes.addressof(o) for o in outs], caps, level,
+                                            strategy, hash_variant)
+        if rc != 0:
+            raise ZlibStreamException("deflating: " + self.last_error())
+        return [outs[i].raw[:lens[i]] for i in range(n)]
+
+
+_default_engine = None
+
+
+def default_engine():
+    global _default_engine
+    if _default_engine is None:
+        _default_engine = Engine(0)
+    return _default_engine
+
+
+def compress(data, level=6, strategy=0, engine=None):
+    """`using (var s = new ZlibOutputStream(ms, level)) s.Write(data)` in one call."""
+    return (engine or default_engine()).deflate_batch([data], level, strategy)[0]
+
+
+class ZlibOutputStream(io.RawIOBase):
+    """ZlibOutputStream.cs: a write-only stream that deflates into `base_stream`.
+
+    Same loop structure as WriteCore / Finish (ZlibOutputStream.cs:125-168,
+    213-256): 512-byte chunk buffer, `Deflate(flush)` until the input is
+    consumed and the chunk buffer was not filled completely.
+    """
+
+    BUFFER_SIZE = 512
+
+    def __init__(self, base_stream, level_or_options=CompressionLevel.DefaultCompression, engine=None, hash_variant=0):
+        super().__init__()
+        if isinstance(level_or_options, ZlibOptions):
+            self.Options = level_or_options
+        else:
+            self.Options = ZlibOptions(CompressionLevel=level_or_options)
+        if self.Options.CompressionLevel is None:
+            # ZlibStream.cs:20-28: a null level means inflate mode
+            raise NotImplementedError("inflate mode of ZlibOutputStream is not on the device path")
+        self.BaseStream = base_stream
+        self._engine = engine or default_engine()
+        self._lib = _native.lib()
+        level = int(self.Options.CompressionLevel)
+        strategy = int(self.Options.CompressionStrategy)
+        if level < -1 or level > 9:
+            raise ValueError("level")  # ArgumentOutOfRangeException (Deflate.cs:273-276)
+        if strategy < 0 or strategy > 4:
+            raise ValueError("strategy")
+        self._z = self._lib.zs_deflate_init(self._engine.handle, level, strategy, 15, 8, hash_variant)
+        if not self._z:
+            raise ValueError("zs_deflate_init rejected the arguments")
+        self._chunk = ctypes.create_string_buffer(self.BUFFER_SIZE)
+        self._finished = False
+        self._total_in = ctypes.c_int64(0)
+        self._total_out = ctypes.c_int64(0)
+        self._adler = ctypes.c_uint32(1)
+
+    @property
+    def TotalIn(self):
+        return self._total_in.value
+
+    @property
+    def TotalOut(self):
+        return self._total_out.value
+
+    def writable(self):
+        return True
+
+    def readable(self):
+        return False
+
+    def seekable(self):
+        return False
+
+    def _deflate_loop(self, data, flush, until_end):
+        buf = ctypes.create_string_buffer(bytes(data), len(data)) if len(data) else None
+        avail_in = ctypes.c_int32(len(data))
+        consumed = 0
+        while True:
+            avail_out = ctypes.c_int32(self.BUFFER_SIZE)
+            next_in = ctypes.c_void_p(ctypes.addressof(buf) + consumed) if buf is not None else ctypes.c_void_p(0)
+            before = avail_in.value
+            state = self._lib.zs_deflate(self._z, next_in, ctypes.byref(avail_in), ctypes.addressof(self._chunk),
+                                         ctypes.byref(avail_out), int(flush), ctypes.byref(self._adler),
+                                         ctypes.byref(self._total_in), ctypes.byref(self._total_out))
+            consumed += before - avail_in.value
+            if state not in (CompressionState.ZOK, CompressionState.ZSTREAMEND):
+                msg = self._lib.zs_last_message(self._z)
+                raise ZlibStreamException("deflating: " + (msg.decode() if msg else ""))  # ThrowHelper.cs:21-23
+            got = self.BUFFER_SIZE - avail_out.value
+            if got:
+                self.BaseStream.write(self._chunk.raw[:got])
+            if state == CompressionState.ZSTREAMEND:
+                break
+            if not (avail_in.value > 0 or avail_out.value == 0):
+                break
+
+    def write(self, b):
+        if self._finished:
+            raise ValueError("write to finished stream")
+        b = bytes(b)
+        if len(b) == 0:
+            return 0  # WriteCore returns immediately on an empty span
+        self._deflate_loop(b, self.Options.FlushMode, False)
+        return len(b)
+
+    def WriteByte(self, value):
+        self.write(bytes([value]))
+
+    def Finish(self):
+        if not self._finished:
+            self._deflate_loop(b"", FlushMode.Finish, True)
+            self._finished = True
+            if hasattr(self.BaseStream, "flush"):
+                self.BaseStream.flush()
+
+    def close(self):
+        if not self.closed:
+            try:
+                if getattr(self, "_z", None):
+                    self.Finish()
+            finally:
+                if getattr(self, "_z", None):
+                    self._lib.zs_deflate_end(self._z)
+                    self._z = None
+                super().close()

@@ -1,0 +1,70 @@
+// zs_device.h -- device-visible descriptors shared by the kernels and the host
+// pipeline (zs_engine.hip).
+#pragma once
+#include "zs_core.h"
+#include "zs_lit_engine.h"
+
+namespace zs {
+
+// Link tile: positions per workgroup of the bucket-link kernel.
+constexpr int kLinkTile = 32768;
+constexpr int kLinkWarm = 32512;  // >= kMaxDist, multiple of 64: history replayed before a tile
+// Match tile: positions per workgroup of the match kernel; its LDS holds the
+// input bytes [t0 - kMatchBack, t0 + kMatchTile + kMatchFwd) and the links of
+// [t0 - kMatchBack, t0 + kMatchTile).
+constexpr int kMatchTile = 16384;
+constexpr int kMatchBack = 32512;  // >= kMaxDist, multiple of 16
+constexpr int kMatchFwd = 272;     // >= kMaxMatch + 8, multiple of 16
+constexpr int kMatchLdsBytes = kMatchBack + kMatchTile + kMatchFwd;
+constexpr int kMatchLdsLinks = kMatchBack + kMatchTile;
+constexpr int kMatchLds = kMatchLdsBytes + 2 * kMatchLdsLinks;  // 146,960 B of the CU's 160 KiB
+constexpr int kAdlerPiece = 65536;
+
+// per-stream tail-engine scratch layout (bytes)
+constexpr int64_t kScratchWindow = 0;
+constexpr int64_t kScratchHead = 66560;                         // window: 65536 + 512, rounded
+constexpr int64_t kScratchPrev = kScratchHead + 2 * kHashSize;  // u16 head
+constexpr int64_t kScratchHead32 = kScratchPrev + 2 * kWSize;   // u16 prev
+constexpr int64_t kScratchBytes = kScratchHead32 + 4 * kHashSize;
+
+struct StreamDesc {
+    const uint8_t *in;
+    uint8_t *out;
+    int64_t out_cap;
+    int64_t pos_off;   // index of position 0 in link / mK / mK4
+    int64_t sym_off;   // index of symbol 0 in syms
+    int32_t n;
+    int32_t body_end;  // last loop-top handled by the bulk path (n - 262), -1 if none
+    int32_t kl;        // refills (reads k >= 1) of the single-Write schedule
+    int32_t nchunks;   // parse chunks covering [0, body_end]
+    int32_t chunk_off; // index of chunk 0 in maps / entry / symbase / stale
+    int32_t blk_off;   // index of block 0 in block arrays
+    int32_t max_blocks;
+    int32_t adler_off; // index of piece 0 in adler pieces
+    int32_t n_adler;
+    int32_t n_wr;            // > 1: several Writes -> the whole stream runs on the literal engine
+    const int64_t *wr_end;   // device array of n_wr cumulative Write ends (or nullptr)
+};
+
+struct StreamState {
+    // written by the resolve kernel
+    int32_t tail_p, tail_kind;
+    uint32_t tail_pend;
+    int32_t k_done, preins;
+    uint32_t body_syms;
+    // written by the tail kernel
+    uint32_t nsyms;
+    int32_t nblocks;
+    // written by the offsets kernel
+    int64_t out_len;
+    uint32_t adler;
+    int32_t status;
+};
+
+struct BlockInfo {
+    int32_t type;  // 0 stored, 1 static, 2 dynamic
+    int32_t bits;  // compressed blocks: 3 + opt_len / static_len
+    int64_t bit_start;
+};
+
+}  // namespace zs

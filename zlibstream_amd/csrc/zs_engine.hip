@@ -1,0 +1,410 @@
+// zs_engine.hip -- host side of the MI355X deflate engine: workspace, kernel
+// pipeline, and the C ABI of include/zsgpu.h.  No CPU fallback: without a
+// usable HIP device every compressing entry point fails.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/zsgpu.h"
+#include "zs_kernels.hip"
+
+using namespace zs;
+
+namespace {
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+enum Stage {
+    kStClear, kStAdler, kStLinks, kStMatch, kStChunkMap, kStResolve, kStEmitSyms, kStTail, kStTrees, kStOffsets, kStEmitBits,
+    kStCount
+};
+const char *const kStageNames[kStCount] = {"clear", "adler", "links", "match", "chunkmap", "resolve",
+                                           "emit_syms", "tail", "trees", "offsets", "emit_bits"};
+
+}  // namespace
+
+struct zs_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    bool profiling = false;
+    hipEvent_t ev[kStCount + 1] = {};
+    double stage_ms[kStCount] = {};
+    uint32_t *crc_tab = nullptr;
+    DevBuf sd, st, work, link, mk, mk4, maps, entry, symbase, stale, syms, blk_end, blk_top, blocks, trees, info, pieces, scratch,
+        stage_in, stage_out, wr;
+    void *pinned = nullptr;
+    size_t pinned_cap = 0;
+};
+
+namespace {
+
+bool fail(zs_ctx *c, const char *what, hipError_t e) {
+    c->err = std::string(what) + ": " + hipGetErrorString(e);
+    return false;
+}
+#define ZS_HIP(c, call)                                  \
+    do {                                                 \
+        hipError_t e_ = (call);                          \
+        if (e_ != hipSuccess) return fail(c, #call, e_); \
+    } while (0)
+
+bool ensure(zs_ctx *c, DevBuf &b, size_t bytes) {
+    if (bytes <= b.cap) return true;
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.cap = 0;
+    size_t want = bytes + bytes / 8 + 4096;
+    ZS_HIP(c, hipMalloc(&b.p, want));
+    b.cap = want;
+    return true;
+}
+bool ensure_pinned(zs_ctx *c, size_t bytes) {
+    if (bytes <= c->pinned_cap) return true;
+    if (c->pinned) (void)hipHostFree(c->pinned);
+    c->pinned = nullptr;
+    c->pinned_cap = 0;
+    ZS_HIP(c, hipHostMalloc(&c->pinned, bytes + 4096, hipHostMallocDefault));
+    c->pinned_cap = bytes + 4096;
+    return true;
+}
+
+struct Plan {
+    std::vector<StreamDesc> sd;
+    std::vector<uint2> w_clear, w_adler, w_links, w_match, w_chunks, w_blocks;
+    int64_t n_pos = 0, n_syms = 0;
+    int64_t n_chunks = 0, n_blocks = 0, n_pieces = 0;
+};
+
+template <class T>
+T *dev(DevBuf &b) {
+    return (T *)b.p;
+}
+
+// `writes` (optional, one stream only): cumulative Write ends of a multi-Write stream
+bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len, void *const *out, const int64_t *out_cap,
+                  int64_t *out_len, int *status, int level, int strategy, int hash_variant, hipStream_t stream,
+                  const std::vector<int64_t> *writes = nullptr) {
+    if (level == -1) level = 6;
+    LevelCfg lv = level_cfg(level);
+    Plan pl;
+    pl.sd.resize((size_t)n);
+    for (int i = 0; i < n; i++) {
+        StreamDesc &s = pl.sd[(size_t)i];
+        int64_t len = in_len[i];
+        s.in = (const uint8_t *)in[i];
+        s.out = (uint8_t *)out[i];
+        s.out_cap = out_cap[i];
+        s.n = (int32_t)len;
+        const bool multi = writes && writes->size() > 1;
+        s.body_end = (lv.func == 2 && len >= kMinLookahead && !multi) ? (int32_t)(len - kMinLookahead) : -1;
+        s.n_wr = multi ? (int32_t)writes->size() : 1;
+        s.wr_end = nullptr;
+        s.kl = num_refills(len);
+        s.nchunks = s.body_end >= 0 ? chunk_of(s.body_end) + 1 : 0;
+        s.pos_off = pl.n_pos;
+        pl.n_pos += (len + 64 + 63) & ~63LL;
+        s.sym_off = pl.n_syms;
+        pl.n_syms += len + 64;
+        s.chunk_off = (int32_t)pl.n_chunks;
+        pl.n_chunks += s.nchunks;
+        s.blk_off = (int32_t)pl.n_blocks;
+        s.max_blocks = (int32_t)(len / kBlockSyms + 2);
+        pl.n_blocks += s.max_blocks;
+        s.adler_off = (int32_t)pl.n_pieces;
+        s.n_adler = (int32_t)((len + kAdlerPiece - 1) / kAdlerPiece);
+        pl.n_pieces += s.n_adler;
+        for (int64_t k = 0; k * 65536 < s.out_cap; k++) pl.w_clear.push_back(make_uint2((unsigned)i, (unsigned)k));
+        for (int k = 0; k < s.n_adler; k++) pl.w_adler.push_back(make_uint2((unsigned)i, (unsigned)k));
+        if (s.body_end >= 0) {
+            for (int64_t t = 0; t * kLinkTile < len - 5; t++) pl.w_links.push_back(make_uint2((unsigned)i, (unsigned)t));
+            for (int64_t t = 0; t * kMatchTile <= s.body_end; t++) pl.w_match.push_back(make_uint2((unsigned)i, (unsigned)t));
+            for (int k = 0; k < s.nchunks; k++) pl.w_chunks.push_back(make_uint2((unsigned)i, (unsigned)k));
+        }
+        for (int k = 0; k < s.max_blocks; k++) pl.w_blocks.push_back(make_uint2((unsigned)i, (unsigned)k));
+    }
+    // ---- workspace ----
+    size_t n_work = pl.w_clear.size() + pl.w_adler.size() + pl.w_links.size() + pl.w_match.size() + pl.w_chunks.size() +
+                    pl.w_blocks.size();
+    if (!ensure(c, c->sd, sizeof(StreamDesc) * (size_t)n) || !ensure(c, c->st, sizeof(StreamState) * (size_t)n) ||
+        !ensure(c, c->work, sizeof(uint2) * (n_work + 1)) || !ensure(c, c->link, 2 * (size_t)pl.n_pos + 64) ||
+        !ensure(c, c->mk, 4 * (size_t)pl.n_pos + 64) || !ensure(c, c->mk4, 4 * (size_t)pl.n_pos + 64) ||
+        !ensure(c, c->maps, 4 * (size_t)(pl.n_chunks + 1) * kSlots) || !ensure(c, c->entry, 2 * (size_t)(pl.n_chunks + 2)) ||
+        !ensure(c, c->symbase, 4 * (size_t)(pl.n_chunks + 2)) || !ensure(c, c->stale, (size_t)pl.n_chunks + 64) ||
+        !ensure(c, c->syms, 4 * (size_t)pl.n_syms + 64) || !ensure(c, c->blk_end, 4 * (size_t)pl.n_blocks + 64) ||
+        !ensure(c, c->blk_top, 4 * (size_t)pl.n_blocks + 64) || !ensure(c, c->blocks, sizeof(BlockRec) * (size_t)pl.n_blocks) ||
+        !ensure(c, c->trees, sizeof(TreeWork) * (size_t)pl.n_blocks) || !ensure(c, c->info, sizeof(BlockInfo) * (size_t)pl.n_blocks) ||
+        !ensure(c, c->pieces, 4 * (size_t)pl.n_pieces + 64) || !ensure(c, c->scratch, (size_t)kScratchBytes * (size_t)n))
+        return false;
+    if (writes && writes->size() > 1) {
+        if (!ensure(c, c->wr, sizeof(int64_t) * writes->size())) return false;
+        ZS_HIP(c, hipMemcpyAsync(c->wr.p, writes->data(), sizeof(int64_t) * writes->size(), hipMemcpyHostToDevice, stream));
+        ZS_HIP(c, hipStreamSynchronize(stream));  // `writes` is caller-owned pageable memory
+        pl.sd[0].wr_end = (const int64_t *)c->wr.p;
+    }
+    // ---- upload descriptors and work lists (one pinned staging copy) ----
+    size_t up_bytes = sizeof(StreamDesc) * (size_t)n + sizeof(uint2) * n_work;
+    if (!ensure_pinned(c, std::max(up_bytes, sizeof(StreamState) * (size_t)n))) return false;
+    uint8_t *hp = (uint8_t *)c->pinned;
+    memcpy(hp, pl.sd.data(), sizeof(StreamDesc) * (size_t)n);
+    uint2 *hw = (uint2 *)(hp + sizeof(StreamDesc) * (size_t)n);
+    size_t o_clear = 0, o_adler, o_links, o_match, o_chunks, o_blocks;
+    auto put = [&](const std::vector<uint2> &v, size_t &off, size_t at) {
+        off = at;
+        if (!v.empty()) memcpy(hw + at, v.data(), sizeof(uint2) * v.size());
+        return at + v.size();
+    };
+    size_t at = put(pl.w_clear, o_clear, 0);
+    at = put(pl.w_adler, o_adler, at);
+    at = put(pl.w_links, o_links, at);
+    at = put(pl.w_match, o_match, at);
+    at = put(pl.w_chunks, o_chunks, at);
+    at = put(pl.w_blocks, o_blocks, at);
+    ZS_HIP(c, hipMemcpyAsync(c->sd.p, hp, sizeof(StreamDesc) * (size_t)n, hipMemcpyHostToDevice, stream));
+    if (n_work) ZS_HIP(c, hipMemcpyAsync(c->work.p, hw, sizeof(uint2) * n_work, hipMemcpyHostToDevice, stream));
+    ZS_HIP(c, hipMemsetAsync(c->link.p, 0, 2 * (size_t)pl.n_pos + 64, stream));
+    ZS_HIP(c, hipMemsetAsync(c->stale.p, 0, (size_t)pl.n_chunks + 64, stream));
+    ZS_HIP(c, hipMemsetAsync(c->st.p, 0, sizeof(StreamState) * (size_t)n, stream));
+
+    const StreamDesc *d_sd = dev<StreamDesc>(c->sd);
+    StreamState *d_st = dev<StreamState>(c->st);
+    const uint2 *d_work = dev<uint2>(c->work);
+    const bool prof = c->profiling;
+    auto mark = [&](int i) {
+        if (prof) (void)hipEventRecord(c->ev[i], stream);
+    };
+    mark(0);
+    if (!pl.w_clear.empty())
+        hipLaunchKernelGGL(zs_clear_kernel, dim3((unsigned)pl.w_clear.size()), dim3(256), 0, stream, d_sd, d_work + o_clear);
+    mark(1);
+    if (!pl.w_adler.empty())
+        hipLaunchKernelGGL(zs_adler_kernel, dim3((unsigned)pl.w_adler.size()), dim3(256), 0, stream, d_sd, d_work + o_adler,
+                           dev<uint32_t>(c->pieces));
+    mark(2);
+    if (!pl.w_links.empty())
+        hipLaunchKernelGGL(zs_links_kernel, dim3((unsigned)pl.w_links.size()), dim3(64), 0, stream, d_sd, d_work + o_links,
+                           dev<uint16_t>(c->link), c->crc_tab, hash_variant);
+    mark(3);
+    if (!pl.w_match.empty())
+        hipLaunchKernelGGL(zs_match_kernel, dim3((unsigned)pl.w_match.size()), dim3(1024), kMatchLds, stream, d_sd, d_work + o_match,
+                           dev<uint16_t>(c->link), dev<uint32_t>(c->mk), dev<uint32_t>(c->mk4), lv, strategy);
+    mark(4);
+    if (!pl.w_chunks.empty())
+        hipLaunchKernelGGL(zs_chunkmap_kernel, dim3((unsigned)pl.w_chunks.size()), dim3(320), 0, stream, d_sd, d_work + o_chunks,
+                           dev<uint32_t>(c->mk), dev<uint32_t>(c->mk4), dev<uint32_t>(c->maps), c->crc_tab, lv, strategy,
+                           hash_variant);
+    mark(5);
+    hipLaunchKernelGGL(zs_resolve_kernel, dim3((unsigned)n), dim3(256), 0, stream, d_sd, d_st, dev<uint16_t>(c->link),
+                       dev<uint32_t>(c->mk), dev<uint32_t>(c->mk4), dev<uint32_t>(c->maps), dev<uint16_t>(c->entry),
+                       dev<uint32_t>(c->symbase), dev<uint8_t>(c->stale), c->crc_tab, lv, strategy, hash_variant);
+    mark(6);
+    if (!pl.w_chunks.empty())
+        hipLaunchKernelGGL(zs_emit_syms_kernel, dim3((unsigned)pl.w_chunks.size()), dim3(64), 0, stream, d_sd, d_work + o_chunks,
+                           dev<uint32_t>(c->mk), dev<uint32_t>(c->mk4), dev<uint16_t>(c->entry), dev<uint32_t>(c->symbase),
+                           dev<uint32_t>(c->syms), dev<int32_t>(c->blk_end), dev<int32_t>(c->blk_top), c->crc_tab, lv, strategy,
+                           hash_variant);
+    mark(7);
+    hipLaunchKernelGGL(zs_tail_kernel, dim3((unsigned)n), dim3(64), 0, stream, d_sd, d_st, dev<uint16_t>(c->link),
+                       dev<uint32_t>(c->syms), dev<int32_t>(c->blk_end), dev<int32_t>(c->blk_top), dev<BlockRec>(c->blocks),
+                       dev<uint8_t>(c->scratch), c->crc_tab, lv, strategy, hash_variant);
+    mark(8);
+    hipLaunchKernelGGL(zs_trees_kernel, dim3((unsigned)pl.w_blocks.size()), dim3(256), 0, stream, d_sd, d_st, d_work + o_blocks,
+                       dev<uint32_t>(c->syms), dev<BlockRec>(c->blocks), dev<TreeWork>(c->trees), dev<BlockInfo>(c->info), strategy);
+    mark(9);
+    hipLaunchKernelGGL(zs_offsets_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, d_sd, d_st, dev<BlockRec>(c->blocks),
+                       dev<BlockInfo>(c->info), dev<uint32_t>(c->pieces), level, n);
+    mark(10);
+    hipLaunchKernelGGL(zs_emit_bits_kernel, dim3((unsigned)pl.w_blocks.size()), dim3(256), 0, stream, d_sd, d_st, d_work + o_blocks,
+                       dev<uint32_t>(c->syms), dev<BlockRec>(c->blocks), dev<TreeWork>(c->trees), dev<BlockInfo>(c->info));
+    mark(11);
+    ZS_HIP(c, hipGetLastError());
+    StreamState *hst = (StreamState *)c->pinned;
+    ZS_HIP(c, hipMemcpyAsync(hst, d_st, sizeof(StreamState) * (size_t)n, hipMemcpyDeviceToHost, stream));
+    ZS_HIP(c, hipStreamSynchronize(stream));
+    if (prof)
+        for (int i = 0; i < kStCount; i++) {
+            float ms = 0;
+            (void)hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]);
+            c->stage_ms[i] = ms;
+        }
+    for (int i = 0; i < n; i++) {
+        out_len[i] = hst[i].out_len;
+        if (status) status[i] = hst[i].status;
+        if (hst[i].status != 0) {
+            c->err = "buffer error";
+            return false;
+        }
+    }
+    return true;
+}
+
+bool check_args(zs_ctx *c, int n, const int64_t *in_len, int level, int strategy) {
+    if (!c) return false;
+    if (n < 0 || level < -1 || level > 9 || strategy < 0 || strategy > 4) {
+        c->err = "stream error";
+        return false;
+    }
+    if (level == 0 || strategy == ZS_RLE) {
+        // Deflate.Stored.cs / Deflate.Rle.cs are outside the accelerated path (SURVEY.md section 8 f)
+        c->err = "level 0 (stored) and the Rle strategy are not implemented on the device path";
+        return false;
+    }
+    for (int i = 0; i < n; i++)
+        if (in_len[i] < 0 || in_len[i] > 0x7FFFFFFF - 1024) {
+            c->err = "stream error";
+            return false;
+        }
+    return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+int zs_ctx_create(int device, zs_ctx **out) {
+    if (!out) return ZS_STREAM_ERROR;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count) return ZS_STREAM_ERROR;
+    if (hipSetDevice(device) != hipSuccess) return ZS_STREAM_ERROR;
+    zs_ctx *c = new zs_ctx();
+    c->device = device;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        return ZS_MEM_ERROR;
+    }
+    for (auto &e : c->ev) (void)hipEventCreate(&e);
+    std::vector<uint32_t> tab(1024);
+    for (int t = 0; t < 4; t++)
+        for (int i = 0; i < 256; i++) tab[(size_t)t * 256 + i] = crc32c_table_entry(t, (uint32_t)i);
+    if (hipMalloc((void **)&c->crc_tab, 4096) != hipSuccess ||
+        hipMemcpy(c->crc_tab, tab.data(), 4096, hipMemcpyHostToDevice) != hipSuccess ||
+        hipFuncSetAttribute((const void *)zs_match_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kMatchLds) != hipSuccess) {
+        zs_ctx_destroy(c);
+        return ZS_MEM_ERROR;
+    }
+    *out = c;
+    return ZS_OK;
+}
+
+void zs_ctx_destroy(zs_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    DevBuf *bufs[] = {&c->sd, &c->st, &c->work, &c->link, &c->mk, &c->mk4, &c->maps, &c->entry, &c->symbase, &c->stale, &c->syms,
+                      &c->blk_end, &c->blk_top, &c->blocks, &c->trees, &c->info, &c->pieces, &c->scratch, &c->stage_in, &c->stage_out, &c->wr};
+    for (DevBuf *b : bufs)
+        if (b->p) (void)hipFree(b->p);
+    if (c->crc_tab) (void)hipFree(c->crc_tab);
+    if (c->pinned) (void)hipHostFree(c->pinned);
+    for (auto &e : c->ev)
+        if (e) (void)hipEventDestroy(e);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char *zs_ctx_last_error(const zs_ctx *c) { return c ? c->err.c_str() : "no context"; }
+
+int64_t zs_deflate_bound(int64_t n) { return n + (n >> 3) + 1024; }
+
+void zs_ctx_set_profiling(zs_ctx *c, int enable) {
+    if (c) c->profiling = enable != 0;
+}
+int zs_ctx_stage_count(const zs_ctx *) { return kStCount; }
+const char *zs_ctx_stage_name(const zs_ctx *, int s) { return s >= 0 && s < kStCount ? kStageNames[s] : ""; }
+double zs_ctx_stage_ms(const zs_ctx *c, int s) { return c && s >= 0 && s < kStCount ? c->stage_ms[s] : 0.0; }
+
+int zs_deflate_batch_device(zs_ctx *c, int n, const void *const *in, const int64_t *in_len, void *const *out,
+                            const int64_t *out_cap, int64_t *out_len, int *status, int level, int strategy, int hash_variant,
+                            void *hip_stream) {
+    if (!check_args(c, n, in_len, level, strategy)) return ZS_STREAM_ERROR;
+    if (n == 0) return ZS_OK;
+    if (hipSetDevice(c->device) != hipSuccess) return ZS_STREAM_ERROR;
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    if (!run_pipeline(c, n, in, in_len, out, out_cap, out_len, status, level, strategy, hash_variant, s))
+        return c->err == "buffer error" ? ZS_BUF_ERROR : ZS_STREAM_ERROR;
+    return ZS_OK;
+}
+
+int zs_deflate_batch(zs_ctx *c, int n, const void *const *in, const int64_t *in_len, void *const *out, const int64_t *out_cap,
+                     int64_t *out_len, int *status, int level, int strategy, int hash_variant) {
+    if (!check_args(c, n, in_len, level, strategy)) return ZS_STREAM_ERROR;
+    if (n == 0) return ZS_OK;
+    if (hipSetDevice(c->device) != hipSuccess) return ZS_STREAM_ERROR;
+    std::vector<const void *> din((size_t)n);
+    std::vector<void *> dout((size_t)n);
+    std::vector<int64_t> dcap((size_t)n);
+    size_t tin = 0, tout = 0;
+    for (int i = 0; i < n; i++) {
+        tin += ((size_t)in_len[i] + 255) & ~(size_t)255;
+        dcap[(size_t)i] = out_cap[i];
+        tout += ((size_t)out_cap[i] + 255) & ~(size_t)255;
+    }
+    auto chk = [&](hipError_t e, const char *what) {
+        if (e != hipSuccess) fail(c, what, e);
+        return e == hipSuccess;
+    };
+    if (!ensure(c, c->stage_in, tin + 256) || !ensure(c, c->stage_out, tout + 256)) return ZS_MEM_ERROR;
+    size_t oi = 0, oo = 0;
+    for (int i = 0; i < n; i++) {
+        din[(size_t)i] = (uint8_t *)c->stage_in.p + oi;
+        dout[(size_t)i] = (uint8_t *)c->stage_out.p + oo;
+        if (in_len[i] &&
+            !chk(hipMemcpyAsync((void *)din[(size_t)i], in[i], (size_t)in_len[i], hipMemcpyHostToDevice, c->stream), "H2D"))
+            return ZS_STREAM_ERROR;
+        oi += ((size_t)in_len[i] + 255) & ~(size_t)255;
+        oo += ((size_t)out_cap[i] + 255) & ~(size_t)255;
+    }
+    if (!run_pipeline(c, n, din.data(), in_len, dout.data(), dcap.data(), out_len, status, level, strategy, hash_variant, c->stream))
+        return c->err == "buffer error" ? ZS_BUF_ERROR : ZS_STREAM_ERROR;
+    for (int i = 0; i < n; i++)
+        if (!chk(hipMemcpyAsync(out[i], dout[(size_t)i], (size_t)out_len[i], hipMemcpyDeviceToHost, c->stream), "D2H"))
+            return ZS_STREAM_ERROR;
+    if (!chk(hipStreamSynchronize(c->stream), "sync")) return ZS_STREAM_ERROR;
+    return ZS_OK;
+}
+
+int zs_adler32_device(zs_ctx *c, const void *d_buf, int64_t len, uint32_t seed, uint32_t *out, void *hip_stream) {
+    if (!c || !out || len < 0) return ZS_STREAM_ERROR;
+    if (hipSetDevice(c->device) != hipSuccess) return ZS_STREAM_ERROR;
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    StreamDesc sd;
+    memset(&sd, 0, sizeof sd);
+    sd.in = (const uint8_t *)d_buf;
+    sd.n = (int32_t)len;
+    sd.n_adler = (int32_t)((len + kAdlerPiece - 1) / kAdlerPiece);
+    std::vector<uint2> work;
+    for (int k = 0; k < sd.n_adler; k++) work.push_back(make_uint2(0, (unsigned)k));
+    if (!ensure(c, c->sd, sizeof sd) || !ensure(c, c->work, sizeof(uint2) * (work.size() + 1)) ||
+        !ensure(c, c->pieces, 4 * (size_t)sd.n_adler + 64))
+        return ZS_MEM_ERROR;
+    std::vector<uint32_t> pieces((size_t)sd.n_adler);
+    if (hipMemcpyAsync(c->sd.p, &sd, sizeof sd, hipMemcpyHostToDevice, s) != hipSuccess) return ZS_STREAM_ERROR;
+    if (sd.n_adler) {
+        if (hipMemcpyAsync(c->work.p, work.data(), sizeof(uint2) * work.size(), hipMemcpyHostToDevice, s) != hipSuccess)
+            return ZS_STREAM_ERROR;
+        hipLaunchKernelGGL(zs_adler_kernel, dim3((unsigned)sd.n_adler), dim3(256), 0, s, dev<StreamDesc>(c->sd), dev<uint2>(c->work),
+                           dev<uint32_t>(c->pieces));
+        if (hipMemcpyAsync(pieces.data(), c->pieces.p, 4 * (size_t)sd.n_adler, hipMemcpyDeviceToHost, s) != hipSuccess)
+            return ZS_STREAM_ERROR;
+    }
+    if (hipStreamSynchronize(s) != hipSuccess) return ZS_STREAM_ERROR;
+    uint32_t ad = seed;
+    for (int i = 0; i < sd.n_adler; i++) {
+        int64_t l = len - (int64_t)i * kAdlerPiece;
+        if (l > kAdlerPiece) l = kAdlerPiece;
+        ad = adler_combine(ad, pieces[(size_t)i], (uint64_t)l);
+    }
+    *out = ad;
+    return ZS_OK;
+}
+
+}  // extern "C"
+
+#include "zs_stream_api.inc"

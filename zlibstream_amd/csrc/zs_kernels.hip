@@ -1,0 +1,823 @@
+// zs_kernels.hip -- hand-written HIP kernels (gfx950 / CDNA4, wave64) of the
+// deflate engine.  Integer / byte work only: no MFMA.  See DESIGN.md for the
+// pipeline; every kernel names the reference code whose result it reproduces.
+//
+//   K0 zs_clear_kernel     zero the output buffers (bit emission ORs into them)
+//   K1 zs_links_kernel     per-position bucket links  (InsertString, Deflate.cs:866-877)
+//   K2 zs_match_kernel     per-position Longest_match for both chain budgets (Deflate.cs:1022-1100)
+//   K3 zs_chunkmap_kernel  lazy-parse transfer maps per 2 Ki-position chunk (Deflate.Slow.cs:34-145)
+//   K4 zs_resolve_kernel   compose the maps along the true path, refill quirk fix-ups (Deflate.cs:1010-1013)
+//   K5 zs_emit_syms_kernel symbols + block cuts along the true path (Tr_tally_*, Deflate.cs:910-948)
+//   K6 zs_tail_kernel      last <= 261 bytes by the literal engine (zs_lit_engine.h)
+//   K7 zs_trees_kernel     per-block histograms + exact Build_tree replay (Trees.cs:404-643)
+//   K8 zs_offsets_kernel   block bit offsets, zlib header / Adler trailer (Deflate.cs:464-493,627-635)
+//   K9 zs_emit_bits_kernel Huffman bit packing (Compress_block / Send_bits, Trees.cs:956-989, Deflate.cs:799-821)
+//   KA zs_adler_kernel     Adler-32 per 64 KiB piece (Adler32.cs:270-326)
+#include <hip/hip_runtime.h>
+
+#include "zs_device.h"
+
+namespace zs {
+
+typedef uint32_t __attribute__((aligned(1))) u32u;
+typedef uint64_t __attribute__((aligned(1))) u64u;
+
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+__device__ __forceinline__ uint64_t lanemask_lt() { return (1ull << lane_id()) - 1ull; }
+
+__device__ __forceinline__ uint32_t dev_bucket(const uint32_t *tab, uint32_t v, int hash_variant) {
+    return (hash_variant == kHashMul ? hash_mul(v) : crc32c_u32_tab(tab, v)) & kHashMask;
+}
+__device__ __forceinline__ void load_crc_tab(uint32_t *tab, const uint32_t *g) {
+    for (int i = threadIdx.x; i < 1024; i += blockDim.x) tab[i] = g[i];
+}
+
+// ------------------------------------------------------------------ K0
+__global__ void zs_clear_kernel(const StreamDesc *sd, const uint2 *work) {
+    uint2 w = work[blockIdx.x];
+    const StreamDesc &s = sd[w.x];
+    int64_t beg = (int64_t)w.y * 65536, end = beg + 65536;
+    if (end > s.out_cap) end = s.out_cap;
+    uint8_t *o = s.out;
+    // 16-byte stores on the aligned interior, bytes at the edges
+    int64_t a = ((uintptr_t)(o + beg) + 15) & ~(uintptr_t)15;
+    int64_t ab = a - (int64_t)(uintptr_t)o;
+    if (ab > end) ab = end;
+    for (int64_t i = beg + threadIdx.x; i < ab; i += blockDim.x) o[i] = 0;
+    int64_t nvec = (end - ab) / 16;
+    uint4 *v = (uint4 *)(o + ab);
+    for (int64_t i = threadIdx.x; i < nvec; i += blockDim.x) v[i] = make_uint4(0, 0, 0, 0);
+    for (int64_t i = ab + nvec * 16 + threadIdx.x; i < end; i += blockDim.x) o[i] = 0;
+}
+
+// ------------------------------------------------------------------ K1
+// One wave per 32 Ki-position tile.  The wave replays InsertString over
+// [t0 - kLinkWarm, t0 + kLinkTile) 64 positions at a time with the 32 Ki-entry
+// head table in LDS; positions inside the tile get link = distance to the
+// previous position of the same bucket (0 if none within kMaxDist).
+__global__ __launch_bounds__(64) void zs_links_kernel(const StreamDesc *sd, const uint2 *work, uint16_t *link,
+                                                      const uint32_t *crc_tab_g, int hash_variant) {
+    __shared__ uint16_t head[kHashSize];
+    __shared__ uint32_t tab[1024];
+    const int lane = lane_id();
+    uint2 w = work[blockIdx.x];
+    const StreamDesc &s = sd[w.x];
+    const uint8_t *in = s.in;
+    const int64_t t0 = (int64_t)w.y * kLinkTile;
+    const int64_t qend_stream = (int64_t)s.n - 5;  // positions q with q + 5 < n
+    if (t0 >= qend_stream) return;
+    for (int i = lane; i < kHashSize / 2; i += 64) ((uint32_t *)head)[i] = 0;
+    load_crc_tab(tab, crc_tab_g);
+    __syncthreads();
+    int64_t w0 = t0 - kLinkWarm;
+    if (w0 < 0) w0 = 0;
+    int64_t tend = t0 + kLinkTile;
+    if (tend > qend_stream) tend = qend_stream;
+    uint16_t *lk = link + s.pos_off;
+    for (int64_t g = w0; g < tend; g += 64) {
+        const int64_t q = g + lane;
+        const bool valid = q < tend;
+        uint32_t h = 0xFFFFFFFFu;
+        if (valid) h = dev_bucket(tab, *(const u32u *)(in + q + 2), hash_variant);
+        const uint32_t rel = (uint32_t)(q - w0 + 1);  // 1..65280
+        uint32_t prevrel = 0;
+        if (valid) {
+            prevrel = head[h];
+            head[h] = (uint16_t)rel;
+        }
+        // lanes of one wave execute DS ops in order: every lane read the old
+        // head before any lane's store; now find the lanes that lost a store race
+        uint32_t rb = valid ? head[h] : 0;
+        uint64_t lost = __ballot(valid && rb != rel);
+        while (lost) {  // one round per bucket hit by more than one lane
+            int leader = __builtin_ctzll(lost);
+            uint32_t hb = (uint32_t)__shfl((int)h, leader);
+            uint64_t grp = __ballot(valid && h == hb);
+            if (valid && h == hb) {
+                uint64_t lower = grp & lanemask_lt();
+                if (lower) prevrel = rel - (uint32_t)(lane - (63 - __builtin_clzll(lower)));
+                if ((grp >> lane) == 1ull) head[h] = (uint16_t)rel;  // highest lane of the group
+            }
+            lost &= ~grp;
+        }
+        if (valid && q >= t0) {
+            uint32_t d = prevrel ? rel - prevrel : 0;
+            if (d > (uint32_t)kMaxDist) d = 0;
+            lk[q] = (uint16_t)d;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ K2
+// 1024 threads per 16 Ki-position tile; the tile's 48 KiB of input and 96 KiB
+// of links are staged in LDS once, then every lane walks hash chains for one
+// position at a time, pulling the next position from a per-wave cursor as soon
+// as its walk ends (lanes of a wave have very different chain lengths).
+// Per main-loop iteration a lane does one unit of work: test a candidate and
+// compare its first 8 bytes, or compare 8 more bytes of a long match.
+__global__ __launch_bounds__(1024) void zs_match_kernel(const StreamDesc *sd, const uint2 *work, const uint16_t *link,
+                                                        uint32_t *mK, uint32_t *mK4, LevelCfg lv, int strategy) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint8_t *wb = smem;
+    uint16_t *wl = (uint16_t *)(smem + kMatchLdsBytes);
+    uint2 w = work[blockIdx.x];
+    const StreamDesc &s = sd[w.x];
+    const int64_t t0 = (int64_t)w.y * kMatchTile;
+    const int64_t n = s.n;
+    if (t0 > s.body_end) return;
+    const int64_t lo = t0 - kMatchBack;
+    const uint8_t *in = s.in;
+    // ---- stage bytes (dword granularity, zero outside [0, n)) ----
+    {
+        const bool aligned = (((uintptr_t)in) & 3) == 0;
+        for (int i = threadIdx.x; i < kMatchLdsBytes / 4; i += 1024) {
+            int64_t a = lo + (int64_t)i * 4;
+            uint32_t v = 0;
+            if (a >= 0 && a + 3 < n && aligned) {
+                v = *(const uint32_t *)(in + a);
+            } else {
+                for (int k = 0; k < 4; k++) {
+                    int64_t b = a + k;
+                    if (b >= 0 && b < n) v |= (uint32_t)in[b] << (8 * k);
+                }
+            }
+            ((uint32_t *)wb)[i] = v;
+        }
+        const uint16_t *lk = link + s.pos_off;  // pos_off is even and the array 4-byte aligned
+        for (int i = threadIdx.x; i < kMatchLdsLinks / 2; i += 1024) {
+            int64_t a = lo + (int64_t)i * 2;
+            uint32_t v = 0;
+            if (a >= 0 && a + 1 < n) v = *(const uint32_t *)(lk + a);
+            else if (a >= 0 && a < n) v = lk[a];
+            ((uint32_t *)wl)[i] = v;
+        }
+    }
+    __syncthreads();
+    if (strategy == kHuffmanOnly) return;  // Longest_match is never called (Deflate.Slow.cs:66-71)
+
+    // ---- walk ----
+    int64_t pbeg = t0 < 1 ? 1 : t0;
+    int64_t pend = t0 + kMatchTile;
+    if (pend > (int64_t)s.body_end + 1) pend = (int64_t)s.body_end + 1;
+    const int wave = threadIdx.x >> 6, lane = lane_id();
+    const int64_t per = (pend - pbeg + 15) / 16;
+    int64_t next = pbeg + per * wave;  // wave-uniform cursor
+    int64_t wend = next + per;
+    if (wend > pend) wend = pend;
+    uint32_t *oK = mK + s.pos_off, *oK4 = mK4 + s.pos_off;
+    const int K = lv.chain, K4 = lv.chain >> 2, nice = lv.nice;
+
+    bool active = false;
+    int p = 0, c = 0;        // LDS-relative positions (abs - lo)
+    int best = 2, bdist = 0, n_eval = 0, cl = 0;
+    uint32_t snap = 0;
+    bool snapped = false, in_cmp = false;
+    for (;;) {
+        uint64_t need = __ballot(!active);
+        if (need) {
+            if (next < wend) {
+                int64_t mine = next + __builtin_popcountll(need & lanemask_lt());
+                next += __builtin_popcountll(need);
+                if (!active && mine < wend) {
+                    p = (int)(mine - lo);
+                    int l = wl[p];
+                    c = p - l;
+                    int64_t cabs = mine - l;
+                    if (l == 0 || cabs < 1) {  // no candidate: link distances are already <= kMaxDist
+                        oK[mine] = kNoMatch;
+                        oK4[mine] = kNoMatch;
+                    } else {
+                        active = true;
+                        best = 2, bdist = 0, n_eval = 0, snapped = false, in_cmp = false;
+                    }
+                }
+            } else if (need == ~0ull) {
+                break;
+            }
+        }
+        if (!active) continue;
+        bool advance = false, fin = false;
+        int len = 0;
+        if (in_cmp) {
+            uint64_t x = *(const u64u *)(wb + p + cl) ^ *(const u64u *)(wb + c + cl);
+            if (x) {
+                len = cl + (__builtin_ctzll(x) >> 3);
+                advance = true;
+            } else {
+                cl += 8;
+                if (cl >= kMaxMatch) len = kMaxMatch, advance = true;
+            }
+        } else {
+            // a candidate can only beat `best` if byte [best] matches too
+            advance = true;
+            if (wb[c + best] == wb[p + best]) {
+                uint64_t x = *(const u64u *)(wb + p) ^ *(const u64u *)(wb + c);
+                if (x) len = __builtin_ctzll(x) >> 3;
+                else in_cmp = true, cl = 8, advance = false;
+            }
+        }
+        if (advance) {
+            in_cmp = false;
+            if (len > kMaxMatch) len = kMaxMatch;
+            if (len > best) {
+                best = len;
+                bdist = p - c;
+                if (len >= nice) fin = true;
+            }
+            n_eval++;
+            if (!snapped && (n_eval == K4 || fin)) {
+                snap = best >= kMinMatch ? pack_match(best, bdist) : kNoMatch;
+                snapped = true;
+            }
+            if (!fin && n_eval < K) {
+                int l = wl[c];
+                c -= l;
+                // later candidates: `cur_match > limit` (distance < kMaxDist), never position 0
+                if (l == 0 || p - c >= kMaxDist || (int64_t)c + lo < 1) fin = true;
+            } else {
+                fin = true;
+            }
+            if (fin) {
+                uint32_t r = best >= kMinMatch ? pack_match(best, bdist) : kNoMatch;
+                int64_t pa = (int64_t)p + lo;
+                oK[pa] = r;
+                oK4[pa] = snapped ? snap : r;
+                active = false;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ K3 / K4 / K5 accessors
+struct GlobalAcc {
+    const uint8_t *in;
+    const uint32_t *mk, *mk4;  // already offset to the stream's position 0
+    const uint32_t *tab;
+    int strategy, hash_variant;
+    __device__ uint32_t flt(uint32_t m) const { return m ? filter_match(match_len(m), match_dist(m), strategy) : kNoMatch; }
+    __device__ uint32_t mK(int64_t p) const { return flt(mk[p]); }
+    __device__ uint32_t mK4(int64_t p) const { return flt(mk4[p]); }
+    __device__ uint8_t byte(int64_t p) const { return in[p]; }
+    __device__ uint32_t bucket(int64_t p) const { return dev_bucket(tab, *(const u32u *)(in + p + 2), hash_variant); }
+    __device__ int run1(int64_t p) const {
+        int len = 0;
+        while (len < kMaxMatch && in[p + len] == in[p - 1 + len]) len++;
+        return len;
+    }
+};
+// matches staged (already filtered) in LDS for one chunk: index p - (cs - 1)
+struct LdsAcc {
+    const uint8_t *in;
+    const uint32_t *fk, *fk4;
+    int64_t org;  // cs - 1
+    const uint32_t *tab;
+    int hash_variant;
+    __device__ uint32_t mK(int64_t p) const { return fk[p - org]; }
+    __device__ uint32_t mK4(int64_t p) const { return fk4[p - org]; }
+    __device__ uint8_t byte(int64_t p) const { return in[p]; }
+    __device__ uint32_t bucket(int64_t p) const { return dev_bucket(tab, *(const u32u *)(in + p + 2), hash_variant); }
+    __device__ int run1(int64_t p) const {
+        int len = 0;
+        while (len < kMaxMatch && in[p + len] == in[p - 1 + len]) len++;
+        return len;
+    }
+};
+
+__device__ __forceinline__ void stage_chunk_matches(const StreamDesc &s, int c, const uint32_t *mK, const uint32_t *mK4,
+                                                    int strategy, uint32_t *fk, uint32_t *fk4) {
+    ChunkGeo g = chunk_geo(c);
+    const uint32_t *a = mK + s.pos_off, *b = mK4 + s.pos_off;
+    int64_t org = g.cs - 1;
+    for (int i = threadIdx.x; i < kChunk + 1; i += blockDim.x) {
+        int64_t p = org + i;
+        uint32_t x = 0, y = 0;
+        if (p >= 1 && p <= s.body_end) {
+            x = a[p], y = b[p];
+            x = x ? filter_match(match_len(x), match_dist(x), strategy) : kNoMatch;
+            y = y ? filter_match(match_len(y), match_dist(y), strategy) : kNoMatch;
+        }
+        fk[i] = x;
+        fk4[i] = y;
+    }
+}
+
+// ------------------------------------------------------------------ K3
+// One lane per entry slot (260) of one chunk: where does the lazy parse leave
+// the chunk, and how many symbols did it emit on the way.
+__global__ __launch_bounds__(320) void zs_chunkmap_kernel(const StreamDesc *sd, const uint2 *work, const uint32_t *mK,
+                                                          const uint32_t *mK4, uint32_t *maps, const uint32_t *crc_tab_g,
+                                                          LevelCfg lv, int strategy, int hash_variant) {
+    __shared__ uint32_t fk[kChunk + 1], fk4[kChunk + 1];
+    __shared__ uint32_t tab[1024];
+    uint2 w = work[blockIdx.x];
+    const StreamDesc &s = sd[w.x];
+    const int c = (int)w.y;
+    stage_chunk_matches(s, c, mK, mK4, strategy, fk, fk4);
+    load_crc_tab(tab, crc_tab_g);
+    __syncthreads();
+    const int slot = threadIdx.x;
+    if (slot >= kSlots) return;
+    uint32_t out = 0;
+    if (slot_valid(c, slot, s.body_end)) {
+        LdsAcc acc{s.in, fk, fk4, chunk_geo(c).cs - 1, tab, hash_variant};
+        NullSink ns;
+        int ex, cnt;
+        walk_chunk(acc, ns, c, slot, s.kl, s.body_end, lv, strategy, ex, cnt);
+        out = (uint32_t)ex | ((uint32_t)cnt << 16);
+    }
+    maps[((int64_t)s.chunk_off + c) * kSlots + slot] = out;
+}
+
+// ------------------------------------------------------------------ K4
+// One workgroup per stream.  Thread 0 follows the true parse path through the
+// chunk maps, segment by segment.  At each refill loop-top s_k whose bucket
+// equals that of s_k + 1 the reference leaves prev[s_k] = s_k + 1
+// (Deflate.cs:1010-1013, 866-877), which hides everything older than s_k from
+// later chain walks through that bucket: the workgroup cuts link[s_k],
+// re-walks the positions whose recorded winner lies behind the cut, and marks
+// the chunks whose matches changed so that they are walked directly instead
+// of through their (now stale) maps.
+__global__ __launch_bounds__(256) void zs_resolve_kernel(const StreamDesc *sd, StreamState *st, uint16_t *link, uint32_t *mK,
+                                                         uint32_t *mK4, const uint32_t *maps, uint16_t *entry,
+                                                         uint32_t *symbase, uint8_t *stale, const uint32_t *crc_tab_g,
+                                                         LevelCfg lv, int strategy, int hash_variant) {
+    __shared__ uint32_t tab[1024];
+    __shared__ int sh_slot, sh_event;
+    __shared__ uint32_t sh_total;
+    __shared__ int sh_kfired, sh_preins;
+    const StreamDesc &s = sd[blockIdx.x];
+    StreamState &ss = st[blockIdx.x];
+    load_crc_tab(tab, crc_tab_g);
+    if (threadIdx.x == 0) sh_slot = 0, sh_total = 0, sh_kfired = 0, sh_preins = -1, sh_event = 0;
+    __syncthreads();
+    if (s.body_end < 0) {
+        if (threadIdx.x == 0) {
+            ss.tail_p = 0, ss.tail_kind = kR, ss.tail_pend = 0, ss.k_done = 0, ss.preins = -1, ss.body_syms = 0;
+        }
+        return;
+    }
+    uint16_t *lk = link + s.pos_off;
+    uint32_t *a = mK + s.pos_off, *b = mK4 + s.pos_off;
+    GlobalAcc acc{s.in, a, b, tab, strategy, hash_variant};
+    const int nch = s.nchunks;
+    int c = 0;
+    while (c < nch) {
+        ChunkGeo g = chunk_geo(c);
+        // ---- refill event at the head of segment g.seg ----
+        if (g.first && g.seg <= s.kl) {
+            int slot = sh_slot;
+            int64_t e = slot <= 256 ? g.cs + slot : g.cs;
+            bool fire = e <= s.body_end;
+            bool equal = fire && acc.bucket(e) == acc.bucket(e + 1);
+            __syncthreads();
+            if (fire && threadIdx.x == 0) sh_kfired = g.seg, sh_preins = (int)(e + 1);
+            if (equal && strategy != kHuffmanOnly) {
+                const uint32_t B = acc.bucket(e);
+                if (threadIdx.x == 0) lk[e] = 0;
+                __threadfence_block();
+                __syncthreads();
+                int64_t hi = e + kMaxDist;
+                if (hi > s.body_end) hi = s.body_end;
+                for (int64_t p = e + 1 + threadIdx.x; p <= hi; p += blockDim.x) {
+                    if (acc.bucket(p) != B) continue;
+                    uint32_t x = a[p], y = b[p];
+                    bool dirty = (x && p - match_dist(x) < e) || (y && p - match_dist(y) < e);
+                    if (!dirty) continue;
+                    auto lkf = [lk](int64_t q) { return (int)lk[q]; };
+                    const uint8_t *in = s.in;
+                    auto lcp = [in](int64_t u, int64_t v) {
+                        int len = 0;
+                        while (len < kMaxMatch && in[u + len] == in[v + len]) len++;
+                        return len;
+                    };
+                    uint32_t nx, ny;
+                    walk_matches(lkf, lcp, p, lv, nx, ny);
+                    if (nx != x || ny != y) {
+                        a[p] = nx, b[p] = ny;
+                        int cp = chunk_of(p);
+                        stale[s.chunk_off + cp] = 1;
+                        if (p + 1 == chunk_geo(cp).ce && cp + 1 < nch) stale[s.chunk_off + cp + 1] = 1;
+                    }
+                }
+                __threadfence_block();
+            }
+            __syncthreads();
+        }
+        // ---- thread 0 walks the chunks of this segment ----
+        int cend = c + 1;
+        while (cend < nch && !chunk_geo(cend).first) cend++;
+        if (threadIdx.x == 0) {
+            int slot = sh_slot;
+            uint32_t total = sh_total;
+            for (int cc = c; cc < cend; cc++) {
+                entry[s.chunk_off + cc] = (uint16_t)slot;
+                symbase[s.chunk_off + cc] = total;
+                int ex, cnt;
+                if (stale[s.chunk_off + cc]) {
+                    NullSink ns;
+                    walk_chunk(acc, ns, cc, slot, s.kl, s.body_end, lv, strategy, ex, cnt);
+                } else {
+                    uint32_t v = maps[((int64_t)s.chunk_off + cc) * kSlots + slot];
+                    ex = (int)(v & 0xFFFF), cnt = (int)(v >> 16);
+                }
+                slot = ex;
+                total += (uint32_t)cnt;
+            }
+            sh_slot = slot;
+            sh_total = total;
+        }
+        __syncthreads();
+        c = cend;
+    }
+    if (threadIdx.x == 0) {
+        int slot = sh_slot;
+        int64_t ce = (int64_t)s.body_end + 1;
+        int kind = slot <= 256 ? kR : slot - 256;
+        int64_t p = slot <= 256 ? ce + slot : ce;
+        ss.tail_p = (int32_t)p;
+        ss.tail_kind = kind;
+        ss.tail_pend = kind == kXK ? acc.mK(p - 1) : kind == kXK4 ? acc.mK4(p - 1) : 0;
+        ss.k_done = sh_kfired;
+        ss.preins = sh_preins;
+        ss.body_syms = sh_total;
+    }
+}
+
+// ------------------------------------------------------------------ K5
+// One wave per chunk: stage the chunk's matches in LDS, lane 0 walks the true
+// path and collects the symbols in LDS, the wave writes them out coalesced.
+struct LdsSymSink {
+    uint32_t *buf;
+    uint32_t base;  // stream-global index of the chunk's first symbol
+    int32_t *blk_end, *blk_top;
+    __device__ void operator()(int i, uint32_t sym, int64_t end, int64_t top) {
+        buf[i] = sym;
+        uint32_t idx = base + (uint32_t)i;
+        if ((idx + 1) % kBlockSyms == 0) {
+            uint32_t bi = idx / kBlockSyms;
+            blk_end[bi] = (int32_t)end;
+            blk_top[bi] = (int32_t)top;
+        }
+    }
+};
+__global__ __launch_bounds__(64) void zs_emit_syms_kernel(const StreamDesc *sd, const uint2 *work, const uint32_t *mK,
+                                                          const uint32_t *mK4, const uint16_t *entry, const uint32_t *symbase,
+                                                          uint32_t *syms, int32_t *blk_end, int32_t *blk_top,
+                                                          const uint32_t *crc_tab_g, LevelCfg lv, int strategy,
+                                                          int hash_variant) {
+    __shared__ uint32_t fk[kChunk + 1], fk4[kChunk + 1];
+    __shared__ uint32_t sbuf[kChunk + 2];
+    __shared__ uint32_t tab[1024];
+    __shared__ int sh_cnt;
+    uint2 w = work[blockIdx.x];
+    const StreamDesc &s = sd[w.x];
+    const int c = (int)w.y;
+    stage_chunk_matches(s, c, mK, mK4, strategy, fk, fk4);
+    load_crc_tab(tab, crc_tab_g);
+    __syncthreads();
+    const uint32_t base = symbase[s.chunk_off + c];
+    if (threadIdx.x == 0) {
+        LdsAcc acc{s.in, fk, fk4, chunk_geo(c).cs - 1, tab, hash_variant};
+        LdsSymSink sink{sbuf, base, blk_end + s.blk_off, blk_top + s.blk_off};
+        int ex, cnt;
+        walk_chunk(acc, sink, c, (int)entry[s.chunk_off + c], s.kl, s.body_end, lv, strategy, ex, cnt);
+        sh_cnt = cnt;
+    }
+    __syncthreads();
+    uint32_t *o = syms + s.sym_off + base;
+    for (int i = threadIdx.x; i < sh_cnt; i += 64) o[i] = sbuf[i];
+}
+
+// ------------------------------------------------------------------ K6
+// One wave per stream; all lanes run the engine uniformly.  Also turns the
+// block cuts recorded by K5 into BlockRec entries.
+__global__ __launch_bounds__(64) void zs_tail_kernel(const StreamDesc *sd, StreamState *st, const uint16_t *link, uint32_t *syms,
+                                                     const int32_t *blk_end, const int32_t *blk_top, BlockRec *blocks,
+                                                     uint8_t *scratch, const uint32_t *crc_tab_g, LevelCfg lv, int strategy,
+                                                     int hash_variant) {
+    const StreamDesc &s = sd[blockIdx.x];
+    StreamState &ss = st[blockIdx.x];
+    const int lane = lane_id();
+    uint8_t *sc = scratch + (int64_t)blockIdx.x * kScratchBytes;
+    BlockRec *blk = blocks + s.blk_off;
+    const uint32_t body_syms = ss.body_syms;
+    const int nb_body = (int)(body_syms / kBlockSyms);
+    // body blocks: start = end of the previous one; stored blocks are allowed
+    // only while blockStart has not slid out of the window (Deflate.cs:953)
+    for (int i = lane; i < nb_body; i += 64) {
+        int64_t start = i ? blk_end[s.blk_off + i - 1] : 0;
+        int64_t end = blk_end[s.blk_off + i];
+        BlockRec r;
+        r.start = start;
+        r.stored_len = (int32_t)(end - start);
+        r.nsyms = kBlockSyms;
+        r.can_store = start >= (int64_t)kWSize * refills_fired_at(blk_top[s.blk_off + i], s.kl);
+        r.eof = 0;
+        blk[i] = r;
+    }
+    LitEngine e;
+    e.window = sc + kScratchWindow;
+    e.head = (uint16_t *)(sc + kScratchHead);
+    e.prev = (uint16_t *)(sc + kScratchPrev);
+    uint32_t *head32 = (uint32_t *)(sc + kScratchHead32);
+    e.crc_tab = crc_tab_g;
+    e.data = s.in;
+    e.n = s.n;
+    e.wr_end = s.n_wr > 1 ? s.wr_end : nullptr;
+    e.n_wr = s.n_wr;
+    e.cur_wr = 0;
+    e.lv = lv;
+    e.strategy = strategy;
+    e.hash_variant = hash_variant;
+    e.syms = syms + s.sym_off;
+    e.nsyms = body_syms;
+    e.blocks = blk;
+    e.nblocks = nb_body;
+    e.block_start_abs = nb_body ? blk_end[s.blk_off + nb_body - 1] : 0;
+    const uint16_t *lk = link + s.pos_off;
+    const int64_t p = ss.tail_p;
+    le_restore(e, p, ss.k_done, ss.tail_kind, ss.tail_pend, lk, ss.preins, lane, 64);
+    for (int i = lane; i < kHashSize; i += 64) head32[i] = 0;
+    __syncthreads();
+    if (e.avail_end > 0) {
+        int64_t lo = p - (kWSize - 1);
+        if (lo < e.base) lo = e.base;
+        if (lo < 0) lo = 0;
+        int64_t hi = p;
+        if (hi > (int64_t)s.n - 5) hi = (int64_t)s.n - 5;
+        for (int64_t q = lo + lane; q < hi; q += 64) {
+            le_restore_prev(e, q, lk);
+            atomicMax(&head32[le_bucket(e, q)], (uint32_t)(q - e.base) + 1u);
+        }
+        __syncthreads();
+        for (int i = lane; i < kHashSize; i += 64) e.head[i] = (uint16_t)(head32[i] ? head32[i] - 1 : 0);
+        __syncthreads();
+        le_restore_finish(e, p, lk, ss.preins);
+    }
+    __syncthreads();
+    if (lv.func == 1) le_run_fast(e, lane, 64);
+    else le_run_slow(e, lane, 64);
+    if (lane == 0) {
+        ss.nsyms = (uint32_t)e.nsyms;
+        ss.nblocks = e.nblocks;
+    }
+}
+
+// ------------------------------------------------------------------ K7
+// One workgroup per block: histogram the block's symbols (Tr_tally_*), then
+// thread 0 replays Build_tree x3 exactly and picks the block type.
+__global__ __launch_bounds__(256) void zs_trees_kernel(const StreamDesc *sd, const StreamState *st, const uint2 *work,
+                                                       const uint32_t *syms, const BlockRec *blocks, TreeWork *trees,
+                                                       BlockInfo *info, int strategy) {
+    __shared__ TreeWork tw;
+    __shared__ uint32_t hl[kLCodes], hd[kDCodes];
+    uint2 w = work[blockIdx.x];
+    const StreamDesc &s = sd[w.x];
+    const int b = (int)w.y;
+    if (b >= st[w.x].nblocks) return;
+    const BlockRec r = blocks[s.blk_off + b];
+    for (int i = threadIdx.x; i < kLCodes; i += 256) hl[i] = 0;
+    if (threadIdx.x < kDCodes) hd[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t *sy = syms + s.sym_off + (int64_t)b * kBlockSyms;
+    for (int i = threadIdx.x; i < r.nsyms; i += 256) {
+        uint32_t v = sy[i];
+        int dist = (int)(v >> 16), lc = (int)(v & 0xFFFF);
+        if (dist == 0) atomicAdd(&hl[lc], 1u);
+        else {
+            atomicAdd(&hl[length_code(lc) + kLiterals + 1], 1u);
+            atomicAdd(&hd[dist_code(dist - 1)], 1u);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < kHeapSize; i += 256) {
+        tw.ltree[i].fc = i < kLCodes ? (uint16_t)hl[i] : 0;
+        tw.ltree[i].dl = 0;
+    }
+    if (threadIdx.x < 2 * kDCodes + 1) {
+        tw.dtree[threadIdx.x].fc = threadIdx.x < kDCodes ? (uint16_t)hd[threadIdx.x] : 0;
+        tw.dtree[threadIdx.x].dl = 0;
+    }
+    if (threadIdx.x < 2 * kBlCodes + 1) tw.bltree[threadIdx.x].fc = 0, tw.bltree[threadIdx.x].dl = 0;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        tw.ltree[kEndBlock].fc = 1;
+        int type = build_block_trees(tw, r.stored_len, r.can_store != 0, strategy);
+        BlockInfo bi;
+        bi.type = type;
+        bi.bits = type == 1 ? 3 + tw.static_len : type == 2 ? 3 + tw.opt_len : 0;
+        bi.bit_start = 0;
+        info[s.blk_off + b] = bi;
+    }
+    __syncthreads();
+    uint32_t *dst = (uint32_t *)&trees[s.blk_off + b];
+    const uint32_t *src = (const uint32_t *)&tw;
+    for (int i = threadIdx.x; i < (int)(sizeof(TreeWork) / 4); i += 256) dst[i] = src[i];
+}
+
+// ------------------------------------------------------------------ K8
+// One thread per stream: bit offset of every block (Send_bits is a pure
+// concatenation; stored blocks and the last block align to a byte), zlib
+// header, Adler-32 trailer, total length.
+__global__ void zs_offsets_kernel(const StreamDesc *sd, StreamState *st, const BlockRec *blocks, BlockInfo *info,
+                                  const uint32_t *adler_pieces, int level, int nstreams) {
+    int si = blockIdx.x * blockDim.x + threadIdx.x;
+    if (si >= nstreams) return;
+    const StreamDesc &s = sd[si];
+    StreamState &ss = st[si];
+    int64_t pos = 16;
+    for (int b = 0; b < ss.nblocks; b++) {
+        BlockInfo &bi = info[s.blk_off + b];
+        const BlockRec &r = blocks[s.blk_off + b];
+        bi.bit_start = pos;
+        if (bi.type == 0) {
+            pos += 3;
+            pos = (pos + 7) & ~7LL;
+            pos += 32 + 8LL * r.stored_len;
+        } else {
+            pos += bi.bits;
+        }
+        if (r.eof) pos = (pos + 7) & ~7LL;
+    }
+    uint32_t ad = 1;
+    for (int i = 0; i < s.n_adler; i++) {
+        int64_t len = (int64_t)s.n - (int64_t)i * kAdlerPiece;
+        if (len > kAdlerPiece) len = kAdlerPiece;
+        ad = adler_combine(ad, adler_pieces[s.adler_off + i], (uint64_t)len);
+    }
+    ss.adler = ad;
+    int64_t total = pos / 8 + 4;
+    ss.out_len = total;
+    if (total > s.out_cap) {
+        ss.status = -5;  // ZS_BUF_ERROR
+        return;
+    }
+    ss.status = 0;
+    unsigned hdr = zlib_header(level);
+    s.out[0] = (uint8_t)(hdr >> 8);
+    s.out[1] = (uint8_t)hdr;
+    uint8_t *t = s.out + pos / 8;
+    t[0] = (uint8_t)(ad >> 24), t[1] = (uint8_t)(ad >> 16), t[2] = (uint8_t)(ad >> 8), t[3] = (uint8_t)ad;
+}
+
+// ------------------------------------------------------------------ K9
+// OR `nbits` (<= 57) of `v` into the zeroed output at bit position `pos`.
+__device__ __forceinline__ void or_bits(uint8_t *out, int64_t pos, uint64_t v, int nbits) {
+    if (nbits == 0) return;
+    uint32_t *w = (uint32_t *)((uintptr_t)(out + (pos >> 3)) & ~(uintptr_t)3);
+    int sh = (int)(pos - ((int64_t)((uint8_t *)w - out) << 3));  // 0..31
+    uint64_t lo = v << sh;
+    uint32_t w0 = (uint32_t)lo, w1 = (uint32_t)(lo >> 32);
+    uint32_t w2 = sh ? (uint32_t)(v >> (64 - sh)) : 0;
+    if (w0) atomicOr(w, w0);
+    if (w1) atomicOr(w + 1, w1);
+    if (w2) atomicOr(w + 2, w2);
+}
+struct OrPut {
+    uint8_t *out;
+    int64_t pos;
+    __device__ void operator()(unsigned value, int nbits) {
+        or_bits(out, pos, value, nbits);
+        pos += nbits;
+    }
+};
+struct LdsTree {
+    const uint32_t *t;  // fc | dl << 16
+    struct E {
+        uint16_t fc, dl;
+    };
+    __device__ E operator[](int i) const {
+        uint32_t v = t[i];
+        return {(uint16_t)v, (uint16_t)(v >> 16)};
+    }
+};
+// One workgroup per block.  Each thread owns a contiguous run of the block's
+// symbols: pass 1 sums the run's bit lengths, a workgroup scan turns the sums
+// into bit offsets, pass 2 packs the run through a 64-bit accumulator and ORs
+// whole words into the (pre-zeroed) output.
+__global__ __launch_bounds__(256) void zs_emit_bits_kernel(const StreamDesc *sd, const StreamState *st, const uint2 *work,
+                                                           const uint32_t *syms, const BlockRec *blocks, const TreeWork *trees,
+                                                           const BlockInfo *info) {
+    __shared__ uint32_t lt[kLCodes], dt[kDCodes];
+    __shared__ uint32_t scan[256];
+    __shared__ int64_t sh_body;
+    uint2 w = work[blockIdx.x];
+    const StreamDesc &s = sd[w.x];
+    const int b = (int)w.y;
+    if (b >= st[w.x].nblocks || st[w.x].status != 0) return;
+    const BlockRec r = blocks[s.blk_off + b];
+    const BlockInfo bi = info[s.blk_off + b];
+    uint8_t *out = s.out;
+    if (bi.type == 0) {
+        int64_t pos = bi.bit_start;
+        if (threadIdx.x == 0) or_bits(out, pos, (uint64_t)(r.eof ? 1 : 0), 3);
+        int64_t byte = (pos + 3 + 7) >> 3;
+        if (threadIdx.x == 0) {
+            unsigned len = (unsigned)r.stored_len;
+            out[byte] = (uint8_t)len, out[byte + 1] = (uint8_t)(len >> 8);
+            out[byte + 2] = (uint8_t)~len, out[byte + 3] = (uint8_t)(~len >> 8);
+        }
+        const uint8_t *src = s.in + r.start;
+        uint8_t *dst = out + byte + 4;
+        for (int i = threadIdx.x; i < r.stored_len; i += 256) dst[i] = src[i];
+        return;
+    }
+    const TreeWork &tw = trees[s.blk_off + b];
+    if (bi.type == 2) {
+        for (int i = threadIdx.x; i < kLCodes; i += 256) lt[i] = (uint32_t)tw.ltree[i].fc | ((uint32_t)tw.ltree[i].dl << 16);
+        if (threadIdx.x < kDCodes) dt[threadIdx.x] = (uint32_t)tw.dtree[threadIdx.x].fc | ((uint32_t)tw.dtree[threadIdx.x].dl << 16);
+    } else {
+        for (int i = threadIdx.x; i < kLCodes; i += 256) lt[i] = static_lcode(i) | ((uint32_t)static_llen(i) << 16);
+        if (threadIdx.x < kDCodes) dt[threadIdx.x] = bit_reverse((unsigned)threadIdx.x, 5) | (5u << 16);
+    }
+    if (threadIdx.x == 0) {
+        OrPut put{out, bi.bit_start};
+        put((unsigned)(bi.type << 1) + (r.eof ? 1u : 0u), 3);
+        if (bi.type == 2) emit_dyn_header(tw, put);
+        sh_body = put.pos;
+    }
+    __syncthreads();
+    LdsTree L{lt}, D{dt};
+    const uint32_t *sy = syms + s.sym_off + (int64_t)b * kBlockSyms;
+    const int per = (r.nsyms + 255) / 256;
+    int i0 = threadIdx.x * per, i1 = i0 + per;
+    if (i0 > r.nsyms) i0 = r.nsyms;
+    if (i1 > r.nsyms) i1 = r.nsyms;
+    uint32_t mybits = 0;
+    for (int i = i0; i < i1; i++) {
+        uint32_t v = sy[i];
+        uint64_t bits;
+        mybits += (uint32_t)encode_symbol(L, D, (int)(v >> 16), (int)(v & 0xFFFF), bits);
+    }
+    scan[threadIdx.x] = mybits;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        uint32_t t = threadIdx.x >= off ? scan[threadIdx.x - off] : 0;
+        __syncthreads();
+        scan[threadIdx.x] += t;
+        __syncthreads();
+    }
+    int64_t pos = sh_body + (int64_t)(scan[threadIdx.x] - mybits);
+    // pack the run: `acc` holds `fill` pending bits starting at bit position `pos`
+    uint64_t acc = 0;
+    int fill = 0;
+    for (int i = i0; i < i1; i++) {
+        uint32_t v = sy[i];
+        uint64_t bits;
+        int nb = encode_symbol(L, D, (int)(v >> 16), (int)(v & 0xFFFF), bits);
+        acc |= bits << fill;  // nb <= 48, fill <= 15 after a flush
+        fill += nb;
+        if (fill >= 16) {
+            int flush = fill & ~7;
+            if (flush > 56) flush = 56;
+            or_bits(out, pos, acc & ((flush == 64) ? ~0ull : ((1ull << flush) - 1)), flush);
+            pos += flush;
+            acc >>= flush;
+            fill -= flush;
+        }
+    }
+    if (fill) or_bits(out, pos, acc, fill), pos += fill;
+    if (threadIdx.x == 255) {
+        LdsTree::E eob = L[kEndBlock];
+        or_bits(out, sh_body + (int64_t)scan[255], eob.fc, eob.dl);
+    }
+}
+
+// ------------------------------------------------------------------ KA
+// Adler-32 (seed 1) of one 64 KiB piece of a stream.
+__global__ __launch_bounds__(256) void zs_adler_kernel(const StreamDesc *sd, const uint2 *work, uint32_t *pieces) {
+    __shared__ uint64_t ra[256], rb[256];
+    uint2 w = work[blockIdx.x];
+    const StreamDesc &s = sd[w.x];
+    int64_t beg = (int64_t)w.y * kAdlerPiece;
+    int64_t len = (int64_t)s.n - beg;
+    if (len > kAdlerPiece) len = kAdlerPiece;
+    const uint8_t *p = s.in + beg;
+    // thread t covers bytes [t*256, t*256+256): A_t = sum d, B_t = sum (L_t - j) d_j
+    int64_t o = (int64_t)threadIdx.x * 256;
+    int64_t lt = len - o;
+    if (lt > 256) lt = 256;
+    if (lt < 0) lt = 0;
+    uint64_t a = 0, bsum = 0;
+    for (int j = 0; j < lt; j++) {
+        uint64_t d = p[o + j];
+        a += d;
+        bsum += (uint64_t)(lt - j) * d;
+    }
+    // contribution to the piece's s2: B_t + (len - o - lt) * A_t
+    uint64_t tailw = (uint64_t)(len - o - lt);
+    ra[threadIdx.x] = a;
+    rb[threadIdx.x] = lt > 0 ? bsum + tailw * a : 0;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (threadIdx.x < off) ra[threadIdx.x] += ra[threadIdx.x + off], rb[threadIdx.x] += rb[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        uint64_t s1 = (1 + ra[0]) % kAdlerBase;
+        uint64_t s2 = ((uint64_t)len + rb[0]) % kAdlerBase;  // seed s1 = 1 contributes len
+        pieces[s.adler_off + w.y] = (uint32_t)((s2 << 16) | s1);
+    }
+}
+
+}  // namespace zs

@@ -19,6 +19,15 @@
 #pragma once
 #include "zs_core.h"
 
+// On the device one wave runs an engine with all lanes executing the scalar
+// code uniformly; loops marked "lane-strided" split their iterations across
+// the wave and are fenced by ZS_WAVE_SYNC().
+#if defined(__HIP_DEVICE_COMPILE__)
+#define ZS_WAVE_SYNC() __syncthreads()
+#else
+#define ZS_WAVE_SYNC() ((void)0)
+#endif
+
 namespace zs {
 
 struct BlockRec {
@@ -38,6 +47,12 @@ struct LitEngine {
     // stream
     const uint8_t *data;
     int64_t n;
+    // Write boundaries (ZlibOutputStream.WriteCore, ZlibOutputStream.cs:125-168):
+    // wr_end[i] is the input offset at which Write i ends; input beyond the
+    // current Write is not yet available to Fill_window.  n_wr <= 1 / nullptr
+    // means one Write of the whole buffer.
+    const int64_t *wr_end;
+    int n_wr, cur_wr;
     LevelCfg lv;
     int strategy, hash_variant;
     // reference state
@@ -74,28 +89,47 @@ ZS_HD int le_insert(LitEngine &e, int str) {
 
 // Deflate.cs:967-1019.  The whole remaining input is available (single Write
 // already issued, flush == Finish).
-ZS_HD_NOINLINE inline void le_fill_window(LitEngine &e) {
+ZS_HD_NOINLINE inline void le_fill_window(LitEngine &e, int lane, int nlanes) {
     do {
         int more = kWindowSize - e.lookahead - e.strstart;
         if (e.strstart >= kSlideAt) {
-            for (int i = 0; i < kWSize; i++) e.window[i] = e.window[i + kWSize];
+            ZS_WAVE_SYNC();
+            // lane-strided: each i is read and written by one lane only
+            for (int i = lane; i < kWSize; i += nlanes) e.window[i] = e.window[i + kWSize];
+            for (int i = lane; i < kHashSize; i += nlanes) e.head[i] = (uint16_t)(e.head[i] >= kWSize ? e.head[i] - kWSize : 0);
+            for (int i = lane; i < kWSize; i += nlanes) e.prev[i] = (uint16_t)(e.prev[i] >= kWSize ? e.prev[i] - kWSize : 0);
+            ZS_WAVE_SYNC();
             e.match_start -= kWSize;
             e.strstart -= kWSize;
             e.base += kWSize;
-            for (int i = 0; i < kHashSize; i++) e.head[i] = (uint16_t)(e.head[i] >= kWSize ? e.head[i] - kWSize : 0);
-            for (int i = 0; i < kWSize; i++) e.prev[i] = (uint16_t)(e.prev[i] >= kWSize ? e.prev[i] - kWSize : 0);
             more += kWSize;
         }
-        if (e.avail_end >= e.n) return;
-        int64_t avail = e.n - e.avail_end;
+        const int64_t limit = (e.wr_end && e.cur_wr < e.n_wr) ? e.wr_end[e.cur_wr] : e.n;
+        if (e.avail_end >= limit) return;
+        int64_t avail = limit - e.avail_end;
         int cnt = avail < more ? (int)avail : more;
         uint8_t *dst = e.window + e.strstart + e.lookahead;
         const uint8_t *src = e.data + e.avail_end;
-        for (int i = 0; i < cnt; i++) dst[i] = src[i];
+        ZS_WAVE_SYNC();
+        for (int i = lane; i < cnt; i += nlanes) dst[i] = src[i];  // lane-strided
+        ZS_WAVE_SYNC();
         e.avail_end += cnt;
         e.lookahead += cnt;
         if (e.lookahead >= kMinMatch) le_insert(e, e.strstart + 1);
-    } while (e.lookahead < kMinLookahead && e.avail_end < e.n);
+    } while (e.lookahead < kMinLookahead && e.avail_end < ((e.wr_end && e.cur_wr < e.n_wr) ? e.wr_end[e.cur_wr] : e.n));
+}
+
+// `if (lookahead < MIN_LOOKAHEAD) { Fill_window(); if (still short && NoFlush) return NeedMore; }`
+// (Deflate.Slow.cs:34-46): with NoFlush the function returns and is re-entered
+// by the next Write, whose input the next Fill_window can then read; after the
+// last Write the Finish call goes on with whatever lookahead is left.
+ZS_HD_NOINLINE inline void le_refill(LitEngine &e, int lane, int nlanes, int &hash_head) {
+    for (;;) {
+        le_fill_window(e, lane, nlanes);
+        if (e.lookahead >= kMinLookahead || !e.wr_end || e.cur_wr + 1 >= e.n_wr) break;
+        e.cur_wr++;
+        hash_head = 0;  // DeflateSlow's local is reset on every entry (Deflate.Slow.cs:20)
+    }
 }
 
 // Deflate.cs:1022-1100
@@ -148,11 +182,11 @@ ZS_HD bool le_tally(LitEngine &e, int dist, int lc, int lane) {
 }
 
 // Deflate.Slow.cs:18-159 with flush == Finish, run to the end of the stream.
-ZS_HD_NOINLINE inline void le_run_slow(LitEngine &e, int lane) {
+ZS_HD_NOINLINE inline void le_run_slow(LitEngine &e, int lane, int nlanes) {
     int hash_head = 0;
     for (;;) {
         if (e.lookahead < kMinLookahead) {
-            le_fill_window(e);
+            le_refill(e, lane, nlanes, hash_head);
             if (e.lookahead == 0) break;
         }
         if (e.lookahead >= kMinMatch) hash_head = le_insert(e, e.strstart);
@@ -196,10 +230,11 @@ ZS_HD_NOINLINE inline void le_run_slow(LitEngine &e, int lane) {
 }
 
 // Deflate.Fast.cs:20-128 with flush == Finish, run to the end of the stream.
-ZS_HD_NOINLINE inline void le_run_fast(LitEngine &e, int lane) {
+ZS_HD_NOINLINE inline void le_run_fast(LitEngine &e, int lane, int nlanes) {
     for (;;) {
         if (e.lookahead < kMinLookahead) {
-            le_fill_window(e);
+            int dummy = 0;
+            le_refill(e, lane, nlanes, dummy);
             if (e.lookahead == 0) break;
         }
         int hash_head = 0;
