@@ -1,0 +1,167 @@
+#!/usr/bin/env python3
+"""bench.py -- deflate MB/s (input) at level 6 on 64 MiB buffers, one MI355X per rank.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it
+is launched under torch.distributed.run, one rank per GPU.  A step is one pass
+of the hot path (zs_deflate_batch_device) over one 64 MiB pseudo-random-English
+buffer that is already resident in HBM; ranks compress independent buffers
+(no collective in the data path: BASELINE.json north_star), so scaling is weak.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402  (must precede the engine: shared HIP runtime, see _native.py)
+import torch.distributed as dist  # noqa: E402
+
+from zlibstream_amd import Engine, datagen, deflate_bound  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def oracle_lib():
+    """CPU baseline leg only: the oracle (bit-exact restatement of the reference's managed path)."""
+    from zlibstream_amd import build
+    L = ctypes.CDLL(build.build_oracle())
+    L.zso_compress_stream.restype = ctypes.c_size_t
+    L.zso_compress_stream.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int,
+                                      ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_char_p, ctypes.c_size_t,
+                                      ctypes.c_void_p]
+    return L
+
+
+def cpu_baseline(data, level, budget_s=20.0):
+    L = oracle_lib()
+    cap = len(data) + len(data) // 8 + 1024
+    out = ctypes.create_string_buffer(cap)
+    sample = data
+    # one untimed pass on 4 MiB to size the sample for ~budget_s of CPU work
+    probe = data[:4 << 20]
+    t = time.perf_counter()
+    L.zso_compress_stream(probe, len(probe), None, 0, level, 0, 0, 0, out, cap, None)
+    rate = len(probe) / (time.perf_counter() - t)
+    iters = 3
+    max_bytes = int(rate * budget_s / (iters + 1))
+    if max_bytes < len(data):
+        sample = data[:max(max_bytes, 4 << 20)]
+    L.zso_compress_stream(sample, len(sample), None, 0, level, 0, 0, 0, out, cap, None)  # warm-up
+    t = time.perf_counter()
+    for _ in range(iters):
+        n = L.zso_compress_stream(sample, len(sample), None, 0, level, 0, 0, 0, out, cap, None)
+    dt = (time.perf_counter() - t) / iters
+    return {"value": round(len(sample) / dt / 1e6, 2), "unit": "MB/s", "cores": 1, "kind": "port",
+            "sample": "first %d bytes of the english64 buffer, level %d, 1 thread, 1 warm-up + %d timed passes"
+                      % (len(sample), level, iters)}, out.raw[:n], len(sample)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--level", type=int, default=6)
+    ap.add_argument("--size", type=int, default=64 << 20)
+    ap.add_argument("--workload", default="english64", choices=["english64", "sparse64"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    if args.workload == "english64":
+        data = datagen.english(args.size, (datagen.GOLDEN + rank) & datagen.MASK)
+    else:
+        side = int((args.size // 4) ** 0.5)
+        data = datagen.sparse(side, args.size // (4 * side), y0=rank)
+    n = len(data)
+    eng = Engine(local_rank)
+    d_in = torch.frombuffer(bytearray(data), dtype=torch.uint8).to(dev)
+    cap = deflate_bound(n)
+    d_out = torch.empty(cap, dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        return eng.deflate_batch_device([d_in.data_ptr()], [n], [d_out.data_ptr()], [cap], level=args.level, stream=stream)[0]
+
+    for _ in range(args.warmup):
+        out_len = step()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    eng.set_profiling(True)
+    stage_sum = {}
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out_len = step()
+        for k, v in eng.stage_ms().items():
+            stage_sum[k] = stage_sum.get(k, 0.0) + v
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    eng.set_profiling(False)
+
+    # correctness of what was timed: the stream must inflate back to the input
+    import zlib
+    z = d_out[:out_len].cpu().numpy().tobytes()
+    assert zlib.decompress(z) == data, "device output does not inflate to the input"
+
+    if rank == 0:
+        stage_ms = {k: v / args.steps for k, v in stage_sum.items()}
+        dom = max(stage_ms, key=stage_ms.get)
+        alg_bytes = n + out_len  # one read of the input + one write of the stream, per buffer
+        achieved = alg_bytes / (stage_ms[dom] * 1e-3) / 1e9
+        line = {
+            "metric": "deflate MB/s (input) at level %d, 64 MiB buffers" % args.level,
+            "value": round(world * n * args.steps / dt / 1e6, 2),
+            "unit": "MB/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8",
+            "data": "synthetic",
+            "config": {"workload": "%s: one %d-byte pseudo-random-English buffer per GPU (Zipf words of alice29.txt), "
+                                   "level %d, zlib framing, inputs resident in HBM" % (args.workload, n, args.level),
+                       "level": args.level, "buffer_bytes": n, "buffers_per_gpu": 1, "compressed_bytes": out_len,
+                       "parallelism": "independent buffers, %d GPU(s), no collective" % world},
+            "roofline": {"bound": "hbm", "kernel": "zs_%s_kernel" % dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                         "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": round(stage_ms[dom], 4)},
+            "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
+        }
+        if not args.no_cpu_baseline:
+            cb, ref, sample_len = cpu_baseline(data, args.level)
+            line["cpu_baseline"] = cb
+            if sample_len == n:
+                line["compressed_size_delta_vs_cpu"] = out_len - len(ref)
+                line["bit_identical_to_cpu"] = bool(z == ref)
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -19,6 +19,14 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
+    # torch ships its own libamdhip64.so.7; the loader shares one HIP runtime between
+    # torch and this library only when torch's copy is mapped first (same SONAME).
+    import sys
+    if "torch" not in sys.modules and os.environ.get("ZS_NO_TORCH", "0") != "1":
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             "zlibstream_amd/libzsgpu.so is missing: build it with `python -m zlibstream_amd.build` "
