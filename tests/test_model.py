@@ -1,0 +1,64 @@
+"""CPU walk-through of the GPU algorithm (tests/model/zs_model.cpp) against the oracle:
+links -> matches -> chunk maps -> resolve -> symbols -> tail engine -> trees -> bits,
+with the same ZS_HD code the kernels compile."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "build", "zs_model")
+
+
+@pytest.fixture(scope="module")
+def model(tmp_path_factory):
+    os.makedirs(os.path.join(ROOT, "build"), exist_ok=True)
+    subprocess.run(["g++", "-O2", "-std=c++17", "-o", EXE, os.path.join(ROOT, "tests/model/zs_model.cpp"),
+                    os.path.join(ROOT, "oracle/zs_oracle.c"), os.path.join(ROOT, "oracle/zs_inflate_oracle.c")], check=True)
+    d = tmp_path_factory.mktemp("inputs")
+    rng = np.random.default_rng(7)
+    alice = open(os.path.join(ROOT, "tests/golden/corpus/alice29.txt"), "rb").read()
+    files = {}
+
+    def put(name, b):
+        p = d / name
+        p.write_bytes(b)
+        files[name] = str(p)
+    for n in (0, 1, 5, 261, 262, 263, 600, 65274, 65275, 65536, 65537, 65541, 98043, 98304, 98305):
+        put("alice_%d" % n, (alice * 2)[:n])
+        put("zeros_%d" % n, bytes(n))
+        put("lowent_%d" % n, rng.choice(np.array([0, 0, 0, 0, 1, 2, 255], dtype=np.uint8), n).tobytes())
+    put("runs", np.repeat(rng.integers(0, 4, 30000, dtype=np.uint8), rng.integers(1, 40, 30000))[:200000].tobytes())
+    for f in ("ptt5", "sum", "cp.html"):
+        files[f] = os.path.join(ROOT, "tests/golden/corpus", f)
+    return files
+
+
+def run(path, level, strategy=0, mode="chunk", wchunk=None):
+    cmd = [EXE, path, str(level), str(strategy), mode] + ([str(wchunk)] if wchunk else [])
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0 and "PASS" in r.stdout, (cmd, r.stdout[-500:])
+
+
+def test_chunked_pipeline_matches_oracle(model):
+    for name, path in model.items():
+        for level in (4, 6, 9):
+            if level == 9 and name in ("ptt5",):
+                continue
+            run(path, level)
+
+
+def test_strategies_and_fast_levels(model):
+    for name in ("alice_98304", "lowent_98305", "ptt5", "runs"):
+        for strategy in (1, 2, 4):
+            run(model[name], 6, strategy)
+        for level in (1, 2, 3):
+            run(model[name], level, 0, "seq")
+
+
+def test_multi_write_literal_engine(model):
+    for name in ("alice_98304", "lowent_65537", "zeros_98305"):
+        for w in (1, 100, 8192, 65536, 70000):
+            for level in (1, 6):
+                run(model[name], level, 0, "chunk", w)
