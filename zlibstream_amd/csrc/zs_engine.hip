@@ -192,7 +192,11 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
         hipLaunchKernelGGL(zs_links_kernel, dim3((unsigned)pl.w_links.size()), dim3(64), 0, stream, d_sd, d_work + o_links,
                            dev<uint16_t>(c->link), c->crc_tab, hash_variant);
     mark(3);
-    if (!pl.w_match.empty())
+    if (strategy == kHuffmanOnly) {
+        // Longest_match is never called (Deflate.Slow.cs:66-71): every position has no match
+        ZS_HIP(c, hipMemsetAsync(c->mk.p, 0, 4 * (size_t)pl.n_pos + 64, stream));
+        ZS_HIP(c, hipMemsetAsync(c->mk4.p, 0, 4 * (size_t)pl.n_pos + 64, stream));
+    } else if (!pl.w_match.empty())
         hipLaunchKernelGGL(zs_match_kernel, dim3((unsigned)pl.w_match.size()), dim3(1024), kMatchLds, stream, d_sd, d_work + o_match,
                            dev<uint16_t>(c->link), dev<uint32_t>(c->mk), dev<uint32_t>(c->mk4), lv, strategy);
     mark(4);

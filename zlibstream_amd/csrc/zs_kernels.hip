@@ -153,7 +153,6 @@ __global__ __launch_bounds__(1024) void zs_match_kernel(const StreamDesc *sd, co
         }
     }
     __syncthreads();
-    if (strategy == kHuffmanOnly) return;  // Longest_match is never called (Deflate.Slow.cs:66-71)
 
     // ---- walk ----
     int64_t pbeg = t0 < 1 ? 1 : t0;
