@@ -143,8 +143,9 @@ def main():
             "vs_baseline": None,
             "dtype": "u8",
             "data": "synthetic",
-            "config": {"workload": "%s: one %d-byte pseudo-random-English buffer per GPU (Zipf words of alice29.txt), "
-                                   "level %d, zlib framing, inputs resident in HBM" % (args.workload, n, args.level),
+            "config": {"workload": "%s: one %d-byte %s buffer per GPU, level %d, zlib framing, inputs resident in HBM"
+                                   % (args.workload, n, "pseudo-random-English (Zipf words of alice29.txt)"
+                                      if args.workload == "english64" else "sparse RGBA image (reference GetImageBytes)", args.level),
                        "level": args.level, "buffer_bytes": n, "buffers_per_gpu": 1, "compressed_bytes": out_len,
                        "parallelism": "independent buffers, %d GPU(s), no collective" % world},
             "roofline": {"bound": "hbm", "kernel": "zs_%s_kernel" % dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,

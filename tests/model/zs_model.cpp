@@ -186,13 +186,33 @@ static void parse_chunked(Model &m, int64_t &p_out, int &kind_out, uint32_t &pen
     int nchunks = chunk_of(m.body_end) + 1;
     // K3: maps for every chunk and entry slot (embarrassingly parallel on the GPU)
     std::vector<uint32_t> maps((size_t)nchunks * kSlots);
-    for (int c = 0; c < nchunks; c++)
+    std::vector<uint32_t> tbl(kNodeExit);
+    ModelAcc macc{&m};
+    for (int c = 0; c < nchunks; c++) {
+        // jump table of the chunk (the GPU builds it with 512 threads and in-place squaring rounds)
+        ChunkGeo g = chunk_geo(c);
+        int64_t ce = std::min<int64_t>(g.ce, m.body_end + 1);
+        for (int kind = 0; kind < 4; kind++)
+            for (int64_t p = g.cs; p < ce; p++) tbl[kind * kChunk + (int)(p - g.cs)] = node_step(macc, kind, p, g.cs, ce, m.lv);
+        for (int r = 0; r < kJumpRounds; r++)
+            for (int kind = 0; kind < 4; kind++)
+                for (int64_t p = g.cs; p < ce; p++) {
+                    int x = kind * kChunk + (int)(p - g.cs);
+                    uint32_t v = tbl[x];
+                    if (node_succ(v) < kNodeExit) tbl[x] = node_jump(v, tbl[node_succ(v)]);
+                }
         for (int s = 0; s < kSlots; s++) {
             if (!slot_valid(c, s, m.body_end)) { maps[(size_t)c * kSlots + s] = 0; continue; }
+            uint32_t v = chunk_exit_by_table(macc, tbl, c, s, kl, m.body_end, m.lv, m.strategy);
             int ex, ns;
-            chunk_walk(m, c, s, kl, ex, ns, nullptr);
-            maps[(size_t)c * kSlots + s] = (uint32_t)ex | ((uint32_t)ns << 16);
+            chunk_walk(m, c, s, kl, ex, ns, nullptr);  // cross-check against the plain walk
+            if (map_exit(v) != ex || map_count(v) != ns) {
+                printf("chunk %d slot %d: table (%d,%d) walk (%d,%d)\n", c, s, map_exit(v), map_count(v), ex, ns);
+                exit(1);
+            }
+            maps[(size_t)c * kSlots + s] = v;
         }
+    }
     // K4: resolve (one workgroup per stream, sequential over chunks)
     std::vector<int> entry(nchunks);
     std::vector<int64_t> symbase(nchunks);
@@ -238,7 +258,7 @@ static void parse_chunked(Model &m, int64_t &p_out, int &kind_out, uint32_t &pen
             chunk_walk(m, c, slot, kl, ex, ns, nullptr);
         } else {
             uint32_t v = maps[(size_t)c * kSlots + slot];
-            ex = (int)(v & 0xFFFF), ns = (int)(v >> 16);
+            ex = map_exit(v), ns = map_count(v);
         }
         slot = ex;
         total += ns;

@@ -42,6 +42,8 @@ struct StreamDesc {
     int32_t max_blocks;
     int32_t adler_off; // index of piece 0 in adler pieces
     int32_t n_adler;
+    int32_t seg_off;   // index of parse segment 0 in segmap / seg_entry / seg_symbase / seg_stale
+    int32_t nsegs;
     int32_t n_wr;            // > 1: several Writes -> the whole stream runs on the literal engine
     const int64_t *wr_end;   // device array of n_wr cumulative Write ends (or nullptr)
 };

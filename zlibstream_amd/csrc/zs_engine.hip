@@ -22,10 +22,10 @@ struct DevBuf {
 };
 
 enum Stage {
-    kStClear, kStAdler, kStLinks, kStMatch, kStChunkMap, kStResolve, kStEmitSyms, kStTail, kStTrees, kStOffsets, kStEmitBits,
-    kStCount
+    kStClear, kStAdler, kStLinks, kStMatch, kStChunkMap, kStSegMap, kStResolve, kStExpand, kStEmitSyms, kStTail, kStTrees,
+    kStOffsets, kStEmitBits, kStCount
 };
-const char *const kStageNames[kStCount] = {"clear", "adler", "links", "match", "chunkmap", "resolve",
+const char *const kStageNames[kStCount] = {"clear", "adler", "links", "match", "chunkmap", "segmap", "resolve", "expand",
                                            "emit_syms", "tail", "trees", "offsets", "emit_bits"};
 
 }  // namespace
@@ -38,7 +38,7 @@ struct zs_ctx {
     hipEvent_t ev[kStCount + 1] = {};
     double stage_ms[kStCount] = {};
     uint32_t *crc_tab = nullptr;
-    DevBuf sd, st, work, link, mk, mk4, maps, entry, symbase, stale, syms, blk_end, blk_top, blocks, trees, info, pieces, scratch,
+    DevBuf sd, st, work, link, mk, mk4, maps, segmap, seg_entry, seg_symbase, seg_stale, entry, symbase, stale, syms, blk_end, blk_top, blocks, trees, info, pieces, scratch,
         stage_in, stage_out, wr;
     void *pinned = nullptr;
     size_t pinned_cap = 0;
@@ -78,9 +78,9 @@ bool ensure_pinned(zs_ctx *c, size_t bytes) {
 
 struct Plan {
     std::vector<StreamDesc> sd;
-    std::vector<uint2> w_clear, w_adler, w_links, w_match, w_chunks, w_blocks;
+    std::vector<uint2> w_clear, w_adler, w_links, w_match, w_chunks, w_segs, w_blocks;
     int64_t n_pos = 0, n_syms = 0;
-    int64_t n_chunks = 0, n_blocks = 0, n_pieces = 0;
+    int64_t n_chunks = 0, n_segs = 0, n_blocks = 0, n_pieces = 0;
 };
 
 template <class T>
@@ -115,6 +115,9 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
         pl.n_syms += len + 64;
         s.chunk_off = (int32_t)pl.n_chunks;
         pl.n_chunks += s.nchunks;
+        s.seg_off = (int32_t)pl.n_segs;
+        s.nsegs = num_segs(s.nchunks);
+        pl.n_segs += s.nsegs;
         s.blk_off = (int32_t)pl.n_blocks;
         s.max_blocks = (int32_t)(len / kBlockSyms + 2);
         pl.n_blocks += s.max_blocks;
@@ -127,16 +130,19 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
             for (int64_t t = 0; t * kLinkTile < len - 5; t++) pl.w_links.push_back(make_uint2((unsigned)i, (unsigned)t));
             for (int64_t t = 0; t * kMatchTile <= s.body_end; t++) pl.w_match.push_back(make_uint2((unsigned)i, (unsigned)t));
             for (int k = 0; k < s.nchunks; k++) pl.w_chunks.push_back(make_uint2((unsigned)i, (unsigned)k));
+            for (int k = 0; k < s.nsegs; k++) pl.w_segs.push_back(make_uint2((unsigned)i, (unsigned)k));
         }
         for (int k = 0; k < s.max_blocks; k++) pl.w_blocks.push_back(make_uint2((unsigned)i, (unsigned)k));
     }
     // ---- workspace ----
     size_t n_work = pl.w_clear.size() + pl.w_adler.size() + pl.w_links.size() + pl.w_match.size() + pl.w_chunks.size() +
-                    pl.w_blocks.size();
+                    pl.w_segs.size() + pl.w_blocks.size();
     if (!ensure(c, c->sd, sizeof(StreamDesc) * (size_t)n) || !ensure(c, c->st, sizeof(StreamState) * (size_t)n) ||
         !ensure(c, c->work, sizeof(uint2) * (n_work + 1)) || !ensure(c, c->link, 2 * (size_t)pl.n_pos + 64) ||
         !ensure(c, c->mk, 4 * (size_t)pl.n_pos + 64) || !ensure(c, c->mk4, 4 * (size_t)pl.n_pos + 64) ||
-        !ensure(c, c->maps, 4 * (size_t)(pl.n_chunks + 1) * kSlots) || !ensure(c, c->entry, 2 * (size_t)(pl.n_chunks + 2)) ||
+        !ensure(c, c->maps, 4 * (size_t)(pl.n_chunks + 1) * kSlots) || !ensure(c, c->segmap, 8 * (size_t)(pl.n_segs + 1) * kSlots) ||
+        !ensure(c, c->seg_entry, 2 * (size_t)(pl.n_segs + 2)) || !ensure(c, c->seg_symbase, 4 * (size_t)(pl.n_segs + 2)) ||
+        !ensure(c, c->seg_stale, (size_t)pl.n_segs + 64) || !ensure(c, c->entry, 2 * (size_t)(pl.n_chunks + 2)) ||
         !ensure(c, c->symbase, 4 * (size_t)(pl.n_chunks + 2)) || !ensure(c, c->stale, (size_t)pl.n_chunks + 64) ||
         !ensure(c, c->syms, 4 * (size_t)pl.n_syms + 64) || !ensure(c, c->blk_end, 4 * (size_t)pl.n_blocks + 64) ||
         !ensure(c, c->blk_top, 4 * (size_t)pl.n_blocks + 64) || !ensure(c, c->blocks, sizeof(BlockRec) * (size_t)pl.n_blocks) ||
@@ -155,7 +161,7 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
     uint8_t *hp = (uint8_t *)c->pinned;
     memcpy(hp, pl.sd.data(), sizeof(StreamDesc) * (size_t)n);
     uint2 *hw = (uint2 *)(hp + sizeof(StreamDesc) * (size_t)n);
-    size_t o_clear = 0, o_adler, o_links, o_match, o_chunks, o_blocks;
+    size_t o_clear = 0, o_adler, o_links, o_match, o_chunks, o_segs, o_blocks;
     auto put = [&](const std::vector<uint2> &v, size_t &off, size_t at) {
         off = at;
         if (!v.empty()) memcpy(hw + at, v.data(), sizeof(uint2) * v.size());
@@ -166,11 +172,13 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
     at = put(pl.w_links, o_links, at);
     at = put(pl.w_match, o_match, at);
     at = put(pl.w_chunks, o_chunks, at);
+    at = put(pl.w_segs, o_segs, at);
     at = put(pl.w_blocks, o_blocks, at);
     ZS_HIP(c, hipMemcpyAsync(c->sd.p, hp, sizeof(StreamDesc) * (size_t)n, hipMemcpyHostToDevice, stream));
     if (n_work) ZS_HIP(c, hipMemcpyAsync(c->work.p, hw, sizeof(uint2) * n_work, hipMemcpyHostToDevice, stream));
     ZS_HIP(c, hipMemsetAsync(c->link.p, 0, 2 * (size_t)pl.n_pos + 64, stream));
     ZS_HIP(c, hipMemsetAsync(c->stale.p, 0, (size_t)pl.n_chunks + 64, stream));
+    ZS_HIP(c, hipMemsetAsync(c->seg_stale.p, 0, (size_t)pl.n_segs + 64, stream));
     ZS_HIP(c, hipMemsetAsync(c->st.p, 0, sizeof(StreamState) * (size_t)n, stream));
 
     const StreamDesc *d_sd = dev<StreamDesc>(c->sd);
@@ -201,33 +209,45 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
                            dev<uint16_t>(c->link), dev<uint32_t>(c->mk), dev<uint32_t>(c->mk4), lv, strategy);
     mark(4);
     if (!pl.w_chunks.empty())
-        hipLaunchKernelGGL(zs_chunkmap_kernel, dim3((unsigned)pl.w_chunks.size()), dim3(320), 0, stream, d_sd, d_work + o_chunks,
+        hipLaunchKernelGGL(zs_chunkmap_kernel, dim3((unsigned)pl.w_chunks.size()), dim3(512), 0, stream, d_sd, d_work + o_chunks,
                            dev<uint32_t>(c->mk), dev<uint32_t>(c->mk4), dev<uint32_t>(c->maps), c->crc_tab, lv, strategy,
                            hash_variant);
     mark(5);
-    hipLaunchKernelGGL(zs_resolve_kernel, dim3((unsigned)n), dim3(256), 0, stream, d_sd, d_st, dev<uint16_t>(c->link),
-                       dev<uint32_t>(c->mk), dev<uint32_t>(c->mk4), dev<uint32_t>(c->maps), dev<uint16_t>(c->entry),
-                       dev<uint32_t>(c->symbase), dev<uint8_t>(c->stale), c->crc_tab, lv, strategy, hash_variant);
+    if (!pl.w_segs.empty())
+        hipLaunchKernelGGL(zs_segmap_kernel, dim3((unsigned)pl.w_segs.size()), dim3(320), 0, stream, d_sd, d_work + o_segs,
+                           dev<uint32_t>(c->maps), dev<uint2>(c->segmap));
     mark(6);
+    hipLaunchKernelGGL(zs_resolve_kernel, dim3((unsigned)n), dim3(256), 0, stream, d_sd, d_st, dev<uint16_t>(c->link),
+                       dev<uint32_t>(c->mk), dev<uint32_t>(c->mk4), dev<uint32_t>(c->maps), dev<uint2>(c->segmap),
+                       dev<uint16_t>(c->seg_entry), dev<uint32_t>(c->seg_symbase), dev<uint8_t>(c->stale),
+                       dev<uint8_t>(c->seg_stale), c->crc_tab, lv, strategy, hash_variant);
+    mark(7);
+    if (!pl.w_segs.empty())
+        hipLaunchKernelGGL(zs_expand_kernel, dim3((unsigned)((pl.w_segs.size() + 63) / 64)), dim3(64), 0, stream, d_sd,
+                           d_work + o_segs, (int)pl.w_segs.size(), dev<uint32_t>(c->mk), dev<uint32_t>(c->mk4),
+                           dev<uint32_t>(c->maps), dev<uint16_t>(c->seg_entry), dev<uint32_t>(c->seg_symbase),
+                           dev<uint8_t>(c->stale), dev<uint16_t>(c->entry), dev<uint32_t>(c->symbase), c->crc_tab, lv, strategy,
+                           hash_variant);
+    mark(8);
     if (!pl.w_chunks.empty())
         hipLaunchKernelGGL(zs_emit_syms_kernel, dim3((unsigned)pl.w_chunks.size()), dim3(64), 0, stream, d_sd, d_work + o_chunks,
                            dev<uint32_t>(c->mk), dev<uint32_t>(c->mk4), dev<uint16_t>(c->entry), dev<uint32_t>(c->symbase),
                            dev<uint32_t>(c->syms), dev<int32_t>(c->blk_end), dev<int32_t>(c->blk_top), c->crc_tab, lv, strategy,
                            hash_variant);
-    mark(7);
+    mark(9);
     hipLaunchKernelGGL(zs_tail_kernel, dim3((unsigned)n), dim3(64), 0, stream, d_sd, d_st, dev<uint16_t>(c->link),
                        dev<uint32_t>(c->syms), dev<int32_t>(c->blk_end), dev<int32_t>(c->blk_top), dev<BlockRec>(c->blocks),
                        dev<uint8_t>(c->scratch), c->crc_tab, lv, strategy, hash_variant);
-    mark(8);
+    mark(10);
     hipLaunchKernelGGL(zs_trees_kernel, dim3((unsigned)pl.w_blocks.size()), dim3(256), 0, stream, d_sd, d_st, d_work + o_blocks,
                        dev<uint32_t>(c->syms), dev<BlockRec>(c->blocks), dev<TreeWork>(c->trees), dev<BlockInfo>(c->info), strategy);
-    mark(9);
+    mark(11);
     hipLaunchKernelGGL(zs_offsets_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, d_sd, d_st, dev<BlockRec>(c->blocks),
                        dev<BlockInfo>(c->info), dev<uint32_t>(c->pieces), level, n);
-    mark(10);
+    mark(12);
     hipLaunchKernelGGL(zs_emit_bits_kernel, dim3((unsigned)pl.w_blocks.size()), dim3(256), 0, stream, d_sd, d_st, d_work + o_blocks,
                        dev<uint32_t>(c->syms), dev<BlockRec>(c->blocks), dev<TreeWork>(c->trees), dev<BlockInfo>(c->info));
-    mark(11);
+    mark(13);
     ZS_HIP(c, hipGetLastError());
     StreamState *hst = (StreamState *)c->pinned;
     ZS_HIP(c, hipMemcpyAsync(hst, d_st, sizeof(StreamState) * (size_t)n, hipMemcpyDeviceToHost, stream));
@@ -301,7 +321,7 @@ int zs_ctx_create(int device, zs_ctx **out) {
 void zs_ctx_destroy(zs_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    DevBuf *bufs[] = {&c->sd, &c->st, &c->work, &c->link, &c->mk, &c->mk4, &c->maps, &c->entry, &c->symbase, &c->stale, &c->syms,
+    DevBuf *bufs[] = {&c->sd, &c->st, &c->work, &c->link, &c->mk, &c->mk4, &c->maps, &c->segmap, &c->seg_entry, &c->seg_symbase, &c->seg_stale, &c->entry, &c->symbase, &c->stale, &c->syms,
                       &c->blk_end, &c->blk_top, &c->blocks, &c->trees, &c->info, &c->pieces, &c->scratch, &c->stage_in, &c->stage_out, &c->wr};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);

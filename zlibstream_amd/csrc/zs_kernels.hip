@@ -271,9 +271,10 @@ struct LdsAcc {
     int64_t org;  // cs - 1
     const uint32_t *tab;
     int hash_variant;
+    const uint8_t *lbytes = nullptr;  // optional: input bytes [org, org + kChunk + 1) staged in LDS
     __device__ uint32_t mK(int64_t p) const { return fk[p - org]; }
     __device__ uint32_t mK4(int64_t p) const { return fk4[p - org]; }
-    __device__ uint8_t byte(int64_t p) const { return in[p]; }
+    __device__ uint8_t byte(int64_t p) const { return lbytes ? lbytes[p - org] : in[p]; }
     __device__ uint32_t bucket(int64_t p) const { return dev_bucket(tab, *(const u32u *)(in + p + 2), hash_variant); }
     __device__ int run1(int64_t p) const {
         int len = 0;
@@ -301,132 +302,188 @@ __device__ __forceinline__ void stage_chunk_matches(const StreamDesc &s, int c, 
 }
 
 // ------------------------------------------------------------------ K3
-// One lane per entry slot (260) of one chunk: where does the lazy parse leave
-// the chunk, and how many symbols did it emit on the way.
-__global__ __launch_bounds__(320) void zs_chunkmap_kernel(const StreamDesc *sd, const uint2 *work, const uint32_t *mK,
+// Transfer map of one chunk for all 260 entry slots.  512 threads: one lazy_step per
+// automaton node (4 states x 2048 positions) builds the 1-step table in LDS, in-place
+// squaring rounds turn it into node -> (exit slot, symbols), then one lane per slot reads
+// its entry (the refill-rule positions of segment-first chunks are stepped explicitly).
+__global__ __launch_bounds__(512) void zs_chunkmap_kernel(const StreamDesc *sd, const uint2 *work, const uint32_t *mK,
                                                           const uint32_t *mK4, uint32_t *maps, const uint32_t *crc_tab_g,
                                                           LevelCfg lv, int strategy, int hash_variant) {
     __shared__ uint32_t fk[kChunk + 1], fk4[kChunk + 1];
+    __shared__ uint32_t tbl[kNodeExit];
     __shared__ uint32_t tab[1024];
     uint2 w = work[blockIdx.x];
     const StreamDesc &s = sd[w.x];
     const int c = (int)w.y;
     stage_chunk_matches(s, c, mK, mK4, strategy, fk, fk4);
-    load_crc_tab(tab, crc_tab_g);
+    const ChunkGeo g = chunk_geo(c);
+    const bool event_chunk = g.first && g.seg <= s.kl;
+    if (event_chunk) load_crc_tab(tab, crc_tab_g);
     __syncthreads();
+    int64_t ce = g.ce;
+    if (ce > (int64_t)s.body_end + 1) ce = (int64_t)s.body_end + 1;
+    const int len = (int)(ce - g.cs);
+    LdsAcc acc{s.in, fk, fk4, g.cs - 1, tab, hash_variant};
+    for (int i = threadIdx.x; i < 4 * kChunk; i += 512) {
+        int kind = i >> 11, off = i & (kChunk - 1);
+        if (off < len) tbl[i] = node_step(acc, kind, g.cs + off, g.cs, ce, lv);
+    }
+    __syncthreads();
+    for (int r = 0; r < kJumpRounds; r++) {
+        for (int i = threadIdx.x; i < 4 * kChunk; i += 512) {
+            if ((i & (kChunk - 1)) >= len) continue;
+            uint32_t v = tbl[i];
+            if (node_succ(v) < kNodeExit) tbl[i] = node_jump(v, tbl[node_succ(v)]);
+        }
+        __syncthreads();
+    }
     const int slot = threadIdx.x;
     if (slot >= kSlots) return;
     uint32_t out = 0;
-    if (slot_valid(c, slot, s.body_end)) {
-        LdsAcc acc{s.in, fk, fk4, chunk_geo(c).cs - 1, tab, hash_variant};
-        NullSink ns;
-        int ex, cnt;
-        walk_chunk(acc, ns, c, slot, s.kl, s.body_end, lv, strategy, ex, cnt);
-        out = (uint32_t)ex | ((uint32_t)cnt << 16);
-    }
+    if (slot_valid(c, slot, s.body_end)) out = chunk_exit_by_table(acc, tbl, c, slot, s.kl, s.body_end, lv, strategy);
     maps[((int64_t)s.chunk_off + c) * kSlots + slot] = out;
 }
 
+// ------------------------------------------------------------------ K3b
+// Compose the chunk maps of one parse segment (16 chunks; 32 for segment 0) for every
+// entry slot: 260 lanes, one dependent lookup per chunk.
+__global__ __launch_bounds__(320) void zs_segmap_kernel(const StreamDesc *sd, const uint2 *work, const uint32_t *maps,
+                                                        uint2 *segmap) {
+    uint2 w = work[blockIdx.x];
+    const StreamDesc &s = sd[w.x];
+    const int seg = (int)w.y;
+    int slot = threadIdx.x;
+    if (slot >= kSlots) return;
+    const int c0 = seg_first_chunk(seg);
+    int c1 = seg_first_chunk(seg + 1);
+    if (c1 > s.nchunks) c1 = s.nchunks;
+    const int entry_slot = slot;
+    uint32_t total = 0, flags = 0;
+    for (int c = c0; c < c1; c++) {
+        uint32_t v = maps[((int64_t)s.chunk_off + c) * kSlots + slot];
+        if (c == c0) flags = v & kMapEqualBit;
+        slot = map_exit(v);
+        total += (uint32_t)map_count(v);
+    }
+    segmap[((int64_t)s.seg_off + seg) * kSlots + entry_slot] = make_uint2((uint32_t)slot | flags, total);
+}
+
 // ------------------------------------------------------------------ K4
-// One workgroup per stream.  Thread 0 follows the true parse path through the
-// chunk maps, segment by segment.  At each refill loop-top s_k whose bucket
-// equals that of s_k + 1 the reference leaves prev[s_k] = s_k + 1
-// (Deflate.cs:1010-1013, 866-877), which hides everything older than s_k from
-// later chain walks through that bucket: the workgroup cuts link[s_k],
-// re-walks the positions whose recorded winner lies behind the cut, and marks
-// the chunks whose matches changed so that they are walked directly instead
-// of through their (now stale) maps.
+// One workgroup per stream.  Thread 0 follows the true parse path through the segment
+// maps (one dependent lookup per 32 Ki positions).  At a refill loop-top s_k whose bucket
+// equals that of s_k + 1 the reference leaves prev[s_k] = s_k + 1 (Deflate.cs:1010-1013,
+// 866-877), which hides everything older than s_k from later chain walks through that
+// bucket: the workgroup cuts link[s_k], re-walks the positions whose recorded winner lies
+// behind the cut, and marks the chunks whose matches changed; segments holding such
+// chunks are then followed chunk by chunk, stale chunks by a direct walk.
 __global__ __launch_bounds__(256) void zs_resolve_kernel(const StreamDesc *sd, StreamState *st, uint16_t *link, uint32_t *mK,
-                                                         uint32_t *mK4, const uint32_t *maps, uint16_t *entry,
-                                                         uint32_t *symbase, uint8_t *stale, const uint32_t *crc_tab_g,
-                                                         LevelCfg lv, int strategy, int hash_variant) {
+                                                         uint32_t *mK4, const uint32_t *maps, const uint2 *segmap,
+                                                         uint16_t *seg_entry, uint32_t *seg_symbase, uint8_t *stale,
+                                                         uint8_t *seg_stale, const uint32_t *crc_tab_g, LevelCfg lv,
+                                                         int strategy, int hash_variant) {
     __shared__ uint32_t tab[1024];
-    __shared__ int sh_slot, sh_event;
+    __shared__ int sh_seg, sh_slot, sh_scan, sh_kfired, sh_preins;
     __shared__ uint32_t sh_total;
-    __shared__ int sh_kfired, sh_preins;
     const StreamDesc &s = sd[blockIdx.x];
     StreamState &ss = st[blockIdx.x];
     load_crc_tab(tab, crc_tab_g);
-    if (threadIdx.x == 0) sh_slot = 0, sh_total = 0, sh_kfired = 0, sh_preins = -1, sh_event = 0;
+    if (threadIdx.x == 0) sh_seg = 0, sh_slot = 0, sh_total = 0, sh_kfired = 0, sh_preins = -1, sh_scan = 0;
     __syncthreads();
     if (s.body_end < 0) {
-        if (threadIdx.x == 0) {
-            ss.tail_p = 0, ss.tail_kind = kR, ss.tail_pend = 0, ss.k_done = 0, ss.preins = -1, ss.body_syms = 0;
-        }
+        if (threadIdx.x == 0) ss.tail_p = 0, ss.tail_kind = kR, ss.tail_pend = 0, ss.k_done = 0, ss.preins = -1, ss.body_syms = 0;
         return;
     }
     uint16_t *lk = link + s.pos_off;
     uint32_t *a = mK + s.pos_off, *b = mK4 + s.pos_off;
     GlobalAcc acc{s.in, a, b, tab, strategy, hash_variant};
-    const int nch = s.nchunks;
-    int c = 0;
-    while (c < nch) {
-        ChunkGeo g = chunk_geo(c);
-        // ---- refill event at the head of segment g.seg ----
-        if (g.first && g.seg <= s.kl) {
-            int slot = sh_slot;
-            int64_t e = slot <= 256 ? g.cs + slot : g.cs;
-            bool fire = e <= s.body_end;
-            bool equal = fire && acc.bucket(e) == acc.bucket(e + 1);
-            __syncthreads();
-            if (fire && threadIdx.x == 0) sh_kfired = g.seg, sh_preins = (int)(e + 1);
-            if (equal && strategy != kHuffmanOnly) {
-                const uint32_t B = acc.bucket(e);
-                if (threadIdx.x == 0) lk[e] = 0;
-                __threadfence_block();
-                __syncthreads();
-                int64_t hi = e + kMaxDist;
-                if (hi > s.body_end) hi = s.body_end;
-                for (int64_t p = e + 1 + threadIdx.x; p <= hi; p += blockDim.x) {
-                    if (acc.bucket(p) != B) continue;
-                    uint32_t x = a[p], y = b[p];
-                    bool dirty = (x && p - match_dist(x) < e) || (y && p - match_dist(y) < e);
-                    if (!dirty) continue;
-                    auto lkf = [lk](int64_t q) { return (int)lk[q]; };
-                    const uint8_t *in = s.in;
-                    auto lcp = [in](int64_t u, int64_t v) {
-                        int len = 0;
-                        while (len < kMaxMatch && in[u + len] == in[v + len]) len++;
-                        return len;
-                    };
-                    uint32_t nx, ny;
-                    walk_matches(lkf, lcp, p, lv, nx, ny);
-                    if (nx != x || ny != y) {
-                        a[p] = nx, b[p] = ny;
-                        int cp = chunk_of(p);
-                        stale[s.chunk_off + cp] = 1;
-                        if (p + 1 == chunk_geo(cp).ce && cp + 1 < nch) stale[s.chunk_off + cp + 1] = 1;
+    const int nseg = s.nsegs, nch = s.nchunks;
+    for (;;) {
+        // ---- thread 0 runs ahead until a refill needs the workgroup (or the end) ----
+        if (threadIdx.x == 0) {
+            int seg = sh_seg, slot = sh_slot;
+            uint32_t total = sh_total;
+            bool scanned = sh_scan != 0;  // the pending segment's cut has just been applied
+            sh_scan = 0;
+            while (seg < nseg) {
+                const int c0 = seg_first_chunk(seg);
+                const uint2 v = segmap[((int64_t)s.seg_off + seg) * kSlots + slot];
+                if (seg >= 1 && seg <= s.kl) {
+                    int64_t e = slot <= 256 ? chunk_geo(c0).cs + slot : chunk_geo(c0).cs;
+                    if (e <= s.body_end) {
+                        sh_kfired = seg, sh_preins = (int)(e + 1);
+                        if ((v.x & kMapEqualBit) && strategy != kHuffmanOnly && !scanned) {
+                            sh_scan = 1;
+                            break;
+                        }
                     }
                 }
-                __threadfence_block();
-            }
-            __syncthreads();
-        }
-        // ---- thread 0 walks the chunks of this segment ----
-        int cend = c + 1;
-        while (cend < nch && !chunk_geo(cend).first) cend++;
-        if (threadIdx.x == 0) {
-            int slot = sh_slot;
-            uint32_t total = sh_total;
-            for (int cc = c; cc < cend; cc++) {
-                entry[s.chunk_off + cc] = (uint16_t)slot;
-                symbase[s.chunk_off + cc] = total;
-                int ex, cnt;
-                if (stale[s.chunk_off + cc]) {
-                    NullSink ns;
-                    walk_chunk(acc, ns, cc, slot, s.kl, s.body_end, lv, strategy, ex, cnt);
+                scanned = false;
+                seg_entry[s.seg_off + seg] = (uint16_t)slot;
+                seg_symbase[s.seg_off + seg] = total;
+                if (seg_stale[s.seg_off + seg]) {
+                    int c1 = seg_first_chunk(seg + 1);
+                    if (c1 > nch) c1 = nch;
+                    for (int cc = c0; cc < c1; cc++) {
+                        int ex, cnt;
+                        if (stale[s.chunk_off + cc]) {
+                            NullSink ns;
+                            walk_chunk(acc, ns, cc, slot, s.kl, s.body_end, lv, strategy, ex, cnt);
+                        } else {
+                            uint32_t m = maps[((int64_t)s.chunk_off + cc) * kSlots + slot];
+                            ex = map_exit(m), cnt = map_count(m);
+                        }
+                        slot = ex;
+                        total += (uint32_t)cnt;
+                    }
                 } else {
-                    uint32_t v = maps[((int64_t)s.chunk_off + cc) * kSlots + slot];
-                    ex = (int)(v & 0xFFFF), cnt = (int)(v >> 16);
+                    slot = (int)(v.x & 0x1FF);
+                    total += v.y;
                 }
-                slot = ex;
-                total += (uint32_t)cnt;
+                seg++;
             }
-            sh_slot = slot;
-            sh_total = total;
+            sh_seg = seg, sh_slot = slot, sh_total = total;
         }
         __syncthreads();
-        c = cend;
+        if (!sh_scan) break;
+        // ---- equal-bucket refill at the head of segment sh_seg: cut and repair ----
+        {
+            const int c0 = seg_first_chunk(sh_seg);
+            const int slot = sh_slot;
+            const int64_t e = slot <= 256 ? chunk_geo(c0).cs + slot : chunk_geo(c0).cs;
+            const uint32_t B = acc.bucket(e);
+            if (threadIdx.x == 0) lk[e] = 0;
+            __threadfence_block();
+            __syncthreads();
+            int64_t hi = e + kMaxDist;
+            if (hi > s.body_end) hi = s.body_end;
+            for (int64_t p = e + 1 + threadIdx.x; p <= hi; p += blockDim.x) {
+                if (acc.bucket(p) != B) continue;
+                uint32_t x = a[p], y = b[p];
+                bool dirty = (x && p - match_dist(x) < e) || (y && p - match_dist(y) < e);
+                if (!dirty) continue;
+                auto lkf = [lk](int64_t q) { return (int)lk[q]; };
+                const uint8_t *in = s.in;
+                auto lcp = [in](int64_t u, int64_t v) {
+                    int len = 0;
+                    while (len < kMaxMatch && in[u + len] == in[v + len]) len++;
+                    return len;
+                };
+                uint32_t nx, ny;
+                walk_matches(lkf, lcp, p, lv, nx, ny);
+                if (nx != x || ny != y) {
+                    a[p] = nx, b[p] = ny;
+                    int cp = chunk_of(p);
+                    stale[s.chunk_off + cp] = 1;
+                    seg_stale[s.seg_off + seg_of_chunk(cp)] = 1;
+                    if (p + 1 == chunk_geo(cp).ce && cp + 1 < nch) {
+                        stale[s.chunk_off + cp + 1] = 1;
+                        seg_stale[s.seg_off + seg_of_chunk(cp + 1)] = 1;
+                    }
+                }
+            }
+            __threadfence_block();
+        }
+        __syncthreads();
     }
     if (threadIdx.x == 0) {
         int slot = sh_slot;
@@ -439,6 +496,40 @@ __global__ __launch_bounds__(256) void zs_resolve_kernel(const StreamDesc *sd, S
         ss.k_done = sh_kfired;
         ss.preins = sh_preins;
         ss.body_syms = sh_total;
+    }
+}
+
+// ------------------------------------------------------------------ K4b
+// One thread per parse segment: entry slot and first-symbol index of each of its chunks.
+__global__ __launch_bounds__(64) void zs_expand_kernel(const StreamDesc *sd, const uint2 *work, int nwork, const uint32_t *mK,
+                                                       const uint32_t *mK4, const uint32_t *maps, const uint16_t *seg_entry,
+                                                       const uint32_t *seg_symbase, const uint8_t *stale, uint16_t *entry,
+                                                       uint32_t *symbase, const uint32_t *crc_tab_g, LevelCfg lv, int strategy,
+                                                       int hash_variant) {
+    int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= nwork) return;
+    uint2 w = work[i];
+    const StreamDesc &s = sd[w.x];
+    const int seg = (int)w.y;
+    GlobalAcc acc{s.in, mK + s.pos_off, mK4 + s.pos_off, crc_tab_g, strategy, hash_variant};
+    int slot = seg_entry[s.seg_off + seg];
+    uint32_t total = seg_symbase[s.seg_off + seg];
+    const int c0 = seg_first_chunk(seg);
+    int c1 = seg_first_chunk(seg + 1);
+    if (c1 > s.nchunks) c1 = s.nchunks;
+    for (int c = c0; c < c1; c++) {
+        entry[s.chunk_off + c] = (uint16_t)slot;
+        symbase[s.chunk_off + c] = total;
+        int ex, cnt;
+        if (stale[s.chunk_off + c]) {
+            NullSink ns;
+            walk_chunk(acc, ns, c, slot, s.kl, s.body_end, lv, strategy, ex, cnt);
+        } else {
+            uint32_t m = maps[((int64_t)s.chunk_off + c) * kSlots + slot];
+            ex = map_exit(m), cnt = map_count(m);
+        }
+        slot = ex;
+        total += (uint32_t)cnt;
     }
 }
 
@@ -467,16 +558,24 @@ __global__ __launch_bounds__(64) void zs_emit_syms_kernel(const StreamDesc *sd, 
     __shared__ uint32_t fk[kChunk + 1], fk4[kChunk + 1];
     __shared__ uint32_t sbuf[kChunk + 2];
     __shared__ uint32_t tab[1024];
+    __shared__ uint8_t lb[kChunk + 8];
     __shared__ int sh_cnt;
     uint2 w = work[blockIdx.x];
     const StreamDesc &s = sd[w.x];
     const int c = (int)w.y;
     stage_chunk_matches(s, c, mK, mK4, strategy, fk, fk4);
     load_crc_tab(tab, crc_tab_g);
+    {
+        int64_t org = chunk_geo(c).cs - 1;
+        for (int i = threadIdx.x; i < kChunk + 1; i += 64) {
+            int64_t p = org + i;
+            lb[i] = (p >= 0 && p < s.n) ? s.in[p] : 0;
+        }
+    }
     __syncthreads();
     const uint32_t base = symbase[s.chunk_off + c];
     if (threadIdx.x == 0) {
-        LdsAcc acc{s.in, fk, fk4, chunk_geo(c).cs - 1, tab, hash_variant};
+        LdsAcc acc{s.in, fk, fk4, chunk_geo(c).cs - 1, tab, hash_variant, lb};
         LdsSymSink sink{sbuf, base, blk_end + s.blk_off, blk_top + s.blk_off};
         int ex, cnt;
         walk_chunk(acc, sink, c, (int)entry[s.chunk_off + c], s.kl, s.body_end, lv, strategy, ex, cnt);
