@@ -166,84 +166,97 @@ __global__ __launch_bounds__(1024) void zs_match_kernel(const StreamDesc *sd, co
     uint32_t *oK = mK + s.pos_off, *oK4 = mK4 + s.pos_off;
     const int K = lv.chain, K4 = lv.chain >> 2, nice = lv.nice;
 
-    bool active = false;
-    int p = 0, c = 0;        // LDS-relative positions (abs - lo)
-    int best = 2, bdist = 0, n_eval = 0, cl = 0;
-    uint32_t snap = 0;
-    bool snapped = false, in_cmp = false;
+    // Two independent walks per lane (A and B): with one 1024-thread workgroup per CU
+    // there are only 4 waves per SIMD, so a single dependent chain per lane
+    // (link -> candidate bytes -> compare -> next link) leaves the LDS latency exposed;
+    // two chains per lane overlap their LDS round trips.  Each iteration does, for each
+    // walk: phase 1 (issue the link read and the 4-byte prefilter read of the current
+    // candidate), phase 2 (rare: 8 bytes of a real compare), phase 3 (bookkeeping with
+    // selects, move to the next candidate or finish).
+    struct Walk {
+        int st;  // 0 idle, 1 at a candidate, 2 inside a long compare
+        int p, c, best, bdist, n_eval, cl, snapped;
+        uint32_t snap, scan_end;  // scan_end = bytes p+best-3 .. p+best
+    };
+    Walk A = {0, 8, 8, 3, 0, 0, 0, 0, 0, 0}, B = A;
+    const int lo32 = (int)lo;  // |lo| < 2^31 (streams are < 2 GiB)
+    int nexti = (int)(next - lo), wendi = (int)(wend - lo);  // wave-uniform, LDS-relative
+    auto start = [&](Walk &w, int mine) {
+        const int l = wl[mine];
+        const bool has = l != 0 && (mine - l) + lo32 >= 1;  // link distances are already <= kMaxDist
+        if (!has) {
+            oK[(int64_t)mine + lo] = kNoMatch;
+            oK4[(int64_t)mine + lo] = kNoMatch;
+        }
+        w.p = mine, w.c = mine - l, w.st = has ? 1 : 0;
+        w.best = 2, w.bdist = 0, w.n_eval = 0, w.snapped = 0, w.cl = 0;
+        w.scan_end = *(const u32u *)(wb + mine - 1);
+    };
+    auto compare8 = [&](Walk &w, int &len, int &adv) {  // phase 2
+        const int off = w.st == 2 ? w.cl : 0;
+        const uint64_t x = *(const u64u *)(wb + w.p + off) ^ *(const u64u *)(wb + w.c + off);
+        if (x) {
+            len = off + (int)(__builtin_ctzll(x) >> 3);
+            len = len > kMaxMatch ? kMaxMatch : len;
+        } else if (off + 8 >= kMaxMatch) {
+            len = kMaxMatch;
+        } else {
+            w.cl = off + 8, w.st = 2, adv = 0;
+        }
+    };
+    auto finish_step = [&](Walk &w, int l, int len, int adv) {  // phase 3
+        const int better = adv & (len > w.best);
+        w.best = better ? len : w.best;
+        w.bdist = better ? w.p - w.c : w.bdist;
+        const int nice_hit = better & (len >= nice);
+        if (better) w.scan_end = *(const u32u *)(wb + w.p + w.best - 3);
+        w.n_eval += adv;
+        const int do_snap = adv & !w.snapped & ((w.n_eval == K4) | nice_hit);
+        const uint32_t rec = w.best >= kMinMatch ? pack_match(w.best, w.bdist) : kNoMatch;
+        w.snap = do_snap ? rec : w.snap;
+        w.snapped |= do_snap;
+        // next candidate: `cur_match > limit` (distance < kMaxDist), never position 0
+        const int nc = w.c - l;
+        const int stop = nice_hit | (w.n_eval >= K) | (l == 0) | (w.p - nc >= kMaxDist) | (nc + lo32 < 1);
+        const int done = adv & stop;
+        w.c = (adv & !stop) ? nc : w.c;
+        w.st = done ? 0 : (adv ? 1 : w.st);
+        if (done) {
+            const int64_t pa = (int64_t)w.p + lo;
+            oK[pa] = rec;
+            oK4[pa] = w.snapped ? w.snap : rec;
+        }
+    };
     for (;;) {
-        uint64_t need = __ballot(!active);
-        if (need) {
-            if (next < wend) {
-                int64_t mine = next + __builtin_popcountll(need & lanemask_lt());
-                next += __builtin_popcountll(need);
-                if (!active && mine < wend) {
-                    p = (int)(mine - lo);
-                    int l = wl[p];
-                    c = p - l;
-                    int64_t cabs = mine - l;
-                    if (l == 0 || cabs < 1) {  // no candidate: link distances are already <= kMaxDist
-                        oK[mine] = kNoMatch;
-                        oK4[mine] = kNoMatch;
-                    } else {
-                        active = true;
-                        best = 2, bdist = 0, n_eval = 0, snapped = false, in_cmp = false;
-                    }
+        const uint64_t needA = __ballot(A.st == 0), needB = __ballot(B.st == 0);
+        if (needA | needB) {
+            if (nexti < wendi) {
+                if (needA) {
+                    const int mine = nexti + __builtin_popcountll(needA & lanemask_lt());
+                    nexti += __builtin_popcountll(needA);
+                    if (A.st == 0 && mine < wendi) start(A, mine);
                 }
-            } else if (need == ~0ull) {
+                if (needB && nexti < wendi) {
+                    const int mine = nexti + __builtin_popcountll(needB & lanemask_lt());
+                    nexti += __builtin_popcountll(needB);
+                    if (B.st == 0 && mine < wendi) start(B, mine);
+                }
+            } else if ((needA & needB) == ~0ull) {
                 break;
             }
         }
-        if (!active) continue;
-        bool advance = false, fin = false;
-        int len = 0;
-        if (in_cmp) {
-            uint64_t x = *(const u64u *)(wb + p + cl) ^ *(const u64u *)(wb + c + cl);
-            if (x) {
-                len = cl + (__builtin_ctzll(x) >> 3);
-                advance = true;
-            } else {
-                cl += 8;
-                if (cl >= kMaxMatch) len = kMaxMatch, advance = true;
-            }
-        } else {
-            // a candidate can only beat `best` if byte [best] matches too
-            advance = true;
-            if (wb[c + best] == wb[p + best]) {
-                uint64_t x = *(const u64u *)(wb + p) ^ *(const u64u *)(wb + c);
-                if (x) len = __builtin_ctzll(x) >> 3;
-                else in_cmp = true, cl = 8, advance = false;
-            }
-        }
-        if (advance) {
-            in_cmp = false;
-            if (len > kMaxMatch) len = kMaxMatch;
-            if (len > best) {
-                best = len;
-                bdist = p - c;
-                if (len >= nice) fin = true;
-            }
-            n_eval++;
-            if (!snapped && (n_eval == K4 || fin)) {
-                snap = best >= kMinMatch ? pack_match(best, bdist) : kNoMatch;
-                snapped = true;
-            }
-            if (!fin && n_eval < K) {
-                int l = wl[c];
-                c -= l;
-                // later candidates: `cur_match > limit` (distance < kMaxDist), never position 0
-                if (l == 0 || p - c >= kMaxDist || (int64_t)c + lo < 1) fin = true;
-            } else {
-                fin = true;
-            }
-            if (fin) {
-                uint32_t r = best >= kMinMatch ? pack_match(best, bdist) : kNoMatch;
-                int64_t pa = (int64_t)p + lo;
-                oK[pa] = r;
-                oK4[pa] = snapped ? snap : r;
-                active = false;
-            }
-        }
+        // phase 1: both walks' reads in flight together (idle walks read their stale, in-range c)
+        const int lA = wl[A.c], lB = wl[B.c];
+        const uint32_t eA = *(const u32u *)(wb + A.c + A.best - 3), eB = *(const u32u *)(wb + B.c + B.best - 3);
+        // a candidate can only beat `best` if bytes [best-3 .. best] match too (bytes [0 .. 2]
+        // when best == 2: the byte before the strings is masked out)
+        const int passA = (A.st == 2) | ((A.st == 1) & (((eA ^ A.scan_end) & (A.best == 2 ? 0xFFFFFF00u : 0xFFFFFFFFu)) == 0));
+        const int passB = (B.st == 2) | ((B.st == 1) & (((eB ^ B.scan_end) & (B.best == 2 ? 0xFFFFFF00u : 0xFFFFFFFFu)) == 0));
+        int lenA = 0, lenB = 0, advA = A.st != 0, advB = B.st != 0;
+        if (passA) compare8(A, lenA, advA);
+        if (passB) compare8(B, lenB, advB);
+        finish_step(A, lA, lenA, advA);
+        finish_step(B, lB, lenB, advB);
     }
 }
 
@@ -550,7 +563,7 @@ struct LdsSymSink {
         }
     }
 };
-__global__ __launch_bounds__(64) void zs_emit_syms_kernel(const StreamDesc *sd, const uint2 *work, const uint32_t *mK,
+__global__ __launch_bounds__(256) void zs_emit_syms_kernel(const StreamDesc *sd, const uint2 *work, const uint32_t *mK,
                                                           const uint32_t *mK4, const uint16_t *entry, const uint32_t *symbase,
                                                           uint32_t *syms, int32_t *blk_end, int32_t *blk_top,
                                                           const uint32_t *crc_tab_g, LevelCfg lv, int strategy,
@@ -564,15 +577,17 @@ __global__ __launch_bounds__(64) void zs_emit_syms_kernel(const StreamDesc *sd, 
     const StreamDesc &s = sd[w.x];
     const int c = (int)w.y;
     stage_chunk_matches(s, c, mK, mK4, strategy, fk, fk4);
-    load_crc_tab(tab, crc_tab_g);
     {
-        int64_t org = chunk_geo(c).cs - 1;
-        for (int i = threadIdx.x; i < kChunk + 1; i += 64) {
+        const ChunkGeo g = chunk_geo(c);
+        if (g.first && g.seg <= s.kl) load_crc_tab(tab, crc_tab_g);
+        int64_t org = g.cs - 1;
+        for (int i = threadIdx.x; i < kChunk + 1; i += blockDim.x) {
             int64_t p = org + i;
             lb[i] = (p >= 0 && p < s.n) ? s.in[p] : 0;
         }
     }
     __syncthreads();
+    if (threadIdx.x >= 64) return;  // staging used the whole workgroup; the walk is one lane's job
     const uint32_t base = symbase[s.chunk_off + c];
     if (threadIdx.x == 0) {
         LdsAcc acc{s.in, fk, fk4, chunk_geo(c).cs - 1, tab, hash_variant, lb};
@@ -581,7 +596,9 @@ __global__ __launch_bounds__(64) void zs_emit_syms_kernel(const StreamDesc *sd, 
         walk_chunk(acc, sink, c, (int)entry[s.chunk_off + c], s.kl, s.body_end, lv, strategy, ex, cnt);
         sh_cnt = cnt;
     }
-    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     uint32_t *o = syms + s.sym_off + base;
     for (int i = threadIdx.x; i < sh_cnt; i += 64) o[i] = sbuf[i];
 }
