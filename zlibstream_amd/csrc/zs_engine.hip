@@ -230,7 +230,7 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
                            hash_variant);
     mark(8);
     if (!pl.w_chunks.empty())
-        hipLaunchKernelGGL(zs_emit_syms_kernel, dim3((unsigned)pl.w_chunks.size()), dim3(64), 0, stream, d_sd, d_work + o_chunks,
+        hipLaunchKernelGGL(zs_emit_syms_kernel, dim3((unsigned)pl.w_chunks.size()), dim3(256), kEmitLds, stream, d_sd, d_work + o_chunks,
                            dev<uint32_t>(c->mk), dev<uint32_t>(c->mk4), dev<uint16_t>(c->entry), dev<uint32_t>(c->symbase),
                            dev<uint32_t>(c->syms), dev<int32_t>(c->blk_end), dev<int32_t>(c->blk_top), c->crc_tab, lv, strategy,
                            hash_variant);
@@ -310,7 +310,8 @@ int zs_ctx_create(int device, zs_ctx **out) {
         for (int i = 0; i < 256; i++) tab[(size_t)t * 256 + i] = crc32c_table_entry(t, (uint32_t)i);
     if (hipMalloc((void **)&c->crc_tab, 4096) != hipSuccess ||
         hipMemcpy(c->crc_tab, tab.data(), 4096, hipMemcpyHostToDevice) != hipSuccess ||
-        hipFuncSetAttribute((const void *)zs_match_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kMatchLds) != hipSuccess) {
+        hipFuncSetAttribute((const void *)zs_match_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kMatchLds) != hipSuccess ||
+        hipFuncSetAttribute((const void *)zs_emit_syms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kEmitLds) != hipSuccess) {
         zs_ctx_destroy(c);
         return ZS_MEM_ERROR;
     }

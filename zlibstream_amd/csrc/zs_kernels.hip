@@ -178,7 +178,13 @@ __global__ __launch_bounds__(1024) void zs_match_kernel(const StreamDesc *sd, co
         int p, c, best, bdist, n_eval, cl, snapped;
         uint32_t snap, scan_end;  // scan_end = bytes p+best-3 .. p+best
     };
-    Walk A = {0, 8, 8, 3, 0, 0, 0, 0, 0, 0}, B = A;
+#ifndef ZS_NW
+#define ZS_NW 2
+#endif
+    constexpr int NW = ZS_NW;  // independent walks per lane
+    Walk W[NW];
+#pragma unroll
+    for (int k = 0; k < NW; k++) W[k] = {0, 8, 8, 3, 0, 0, 0, 0, 0, 0};
     const int lo32 = (int)lo;  // |lo| < 2^31 (streams are < 2 GiB)
     int nexti = (int)(next - lo), wendi = (int)(wend - lo);  // wave-uniform, LDS-relative
     auto start = [&](Walk &w, int mine) {
@@ -228,35 +234,49 @@ __global__ __launch_bounds__(1024) void zs_match_kernel(const StreamDesc *sd, co
         }
     };
     for (;;) {
-        const uint64_t needA = __ballot(A.st == 0), needB = __ballot(B.st == 0);
-        if (needA | needB) {
+        uint64_t need[NW], any_need = 0, all_need = ~0ull;
+#pragma unroll
+        for (int k = 0; k < NW; k++) {
+            need[k] = __ballot(W[k].st == 0);
+            any_need |= need[k];
+            all_need &= need[k];
+        }
+        if (any_need) {
             if (nexti < wendi) {
-                if (needA) {
-                    const int mine = nexti + __builtin_popcountll(needA & lanemask_lt());
-                    nexti += __builtin_popcountll(needA);
-                    if (A.st == 0 && mine < wendi) start(A, mine);
+#pragma unroll
+                for (int k = 0; k < NW; k++) {
+                    if (need[k] && nexti < wendi) {
+                        const int mine = nexti + __builtin_popcountll(need[k] & lanemask_lt());
+                        nexti += __builtin_popcountll(need[k]);
+                        if (W[k].st == 0 && mine < wendi) start(W[k], mine);
+                    }
                 }
-                if (needB && nexti < wendi) {
-                    const int mine = nexti + __builtin_popcountll(needB & lanemask_lt());
-                    nexti += __builtin_popcountll(needB);
-                    if (B.st == 0 && mine < wendi) start(B, mine);
-                }
-            } else if ((needA & needB) == ~0ull) {
+            } else if (all_need == ~0ull) {
                 break;
             }
         }
-        // phase 1: both walks' reads in flight together (idle walks read their stale, in-range c)
-        const int lA = wl[A.c], lB = wl[B.c];
-        const uint32_t eA = *(const u32u *)(wb + A.c + A.best - 3), eB = *(const u32u *)(wb + B.c + B.best - 3);
+        // phase 1: all walks' reads in flight together (idle walks read their stale, in-range c)
+        int l[NW], pass[NW], len[NW], adv[NW];
+        uint32_t e[NW];
+#pragma unroll
+        for (int k = 0; k < NW; k++) {
+            l[k] = wl[W[k].c];
+            e[k] = *(const u32u *)(wb + W[k].c + W[k].best - 3);
+        }
         // a candidate can only beat `best` if bytes [best-3 .. best] match too (bytes [0 .. 2]
         // when best == 2: the byte before the strings is masked out)
-        const int passA = (A.st == 2) | ((A.st == 1) & (((eA ^ A.scan_end) & (A.best == 2 ? 0xFFFFFF00u : 0xFFFFFFFFu)) == 0));
-        const int passB = (B.st == 2) | ((B.st == 1) & (((eB ^ B.scan_end) & (B.best == 2 ? 0xFFFFFF00u : 0xFFFFFFFFu)) == 0));
-        int lenA = 0, lenB = 0, advA = A.st != 0, advB = B.st != 0;
-        if (passA) compare8(A, lenA, advA);
-        if (passB) compare8(B, lenB, advB);
-        finish_step(A, lA, lenA, advA);
-        finish_step(B, lB, lenB, advB);
+#pragma unroll
+        for (int k = 0; k < NW; k++) {
+            pass[k] = (W[k].st == 2) |
+                      ((W[k].st == 1) & (((e[k] ^ W[k].scan_end) & (W[k].best == 2 ? 0xFFFFFF00u : 0xFFFFFFFFu)) == 0));
+            len[k] = 0;
+            adv[k] = W[k].st != 0;
+        }
+#pragma unroll
+        for (int k = 0; k < NW; k++)
+            if (pass[k]) compare8(W[k], len[k], adv[k]);
+#pragma unroll
+        for (int k = 0; k < NW; k++) finish_step(W[k], l[k], len[k], adv[k]);
     }
 }
 
@@ -547,8 +567,18 @@ __global__ __launch_bounds__(64) void zs_expand_kernel(const StreamDesc *sd, con
 }
 
 // ------------------------------------------------------------------ K5
-// One wave per chunk: stage the chunk's matches in LDS, lane 0 walks the true
-// path and collects the symbols in LDS, the wave writes them out coalesced.
+// Symbols of one chunk along the true path.  The path is a chain through the chunk's
+// automaton; following it one lazy_step at a time on a single lane is ~1000 dependent
+// steps.  Instead: (1) every node's 1-step successor (J1, u16) and a jump table J
+// (kEmitRounds rounds of in-place squaring: every entry jumps >= 2^kEmitRounds steps and
+// carries its symbol count) are built by the whole workgroup; (2) lane 0 hops along J
+// from the entry node, recording checkpoints (node, symbol index); (3) each checkpoint
+// interval is expanded by one lane walking J1 and writing its symbols to LDS; (4) the
+// workgroup copies the symbols out coalesced.
+constexpr int kEmitRounds = 4;
+constexpr int kMaxCheckpoints = kChunk / (1 << kEmitRounds) + 8;
+constexpr int kEmitLds = 4 * (3 * (kChunk + 4) + kNodeExit + 1024) + 2 * (kNodeExit + 2 * (kMaxCheckpoints + 8)) + kChunk + 8;
+
 struct LdsSymSink {
     uint32_t *buf;
     uint32_t base;  // stream-global index of the chunk's first symbol
@@ -568,39 +598,78 @@ __global__ __launch_bounds__(256) void zs_emit_syms_kernel(const StreamDesc *sd,
                                                           uint32_t *syms, int32_t *blk_end, int32_t *blk_top,
                                                           const uint32_t *crc_tab_g, LevelCfg lv, int strategy,
                                                           int hash_variant) {
-    __shared__ uint32_t fk[kChunk + 1], fk4[kChunk + 1];
-    __shared__ uint32_t sbuf[kChunk + 2];
-    __shared__ uint32_t tab[1024];
-    __shared__ uint8_t lb[kChunk + 8];
-    __shared__ int sh_cnt;
+    // > 64 KiB of LDS: dynamic allocation (hipFuncAttributeMaxDynamicSharedMemorySize), carved by hand
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint32_t *fk = (uint32_t *)smem;                 // kChunk + 4
+    uint32_t *fk4 = fk + (kChunk + 4);               // kChunk + 4
+    uint32_t *J = fk4 + (kChunk + 4);                // kNodeExit
+    uint32_t *sbuf = J + kNodeExit;                  // kChunk + 4
+    uint32_t *tab = sbuf + (kChunk + 4);             // 1024
+    uint16_t *J1 = (uint16_t *)(tab + 1024);         // kNodeExit
+    uint16_t *cp_node = J1 + kNodeExit;              // kMaxCheckpoints + 8
+    uint16_t *cp_idx = cp_node + (kMaxCheckpoints + 8);
+    uint8_t *lb = (uint8_t *)(cp_idx + (kMaxCheckpoints + 8));  // kChunk + 8
+    __shared__ int sh_ncp, sh_cnt;
     uint2 w = work[blockIdx.x];
     const StreamDesc &s = sd[w.x];
     const int c = (int)w.y;
+    const ChunkGeo g = chunk_geo(c);
     stage_chunk_matches(s, c, mK, mK4, strategy, fk, fk4);
-    {
-        const ChunkGeo g = chunk_geo(c);
-        if (g.first && g.seg <= s.kl) load_crc_tab(tab, crc_tab_g);
-        int64_t org = g.cs - 1;
-        for (int i = threadIdx.x; i < kChunk + 1; i += blockDim.x) {
-            int64_t p = org + i;
-            lb[i] = (p >= 0 && p < s.n) ? s.in[p] : 0;
+    if (g.first && g.seg <= s.kl) load_crc_tab(tab, crc_tab_g);
+    const int64_t org = g.cs - 1;
+    for (int i = threadIdx.x; i < kChunk + 1; i += 256) {
+        int64_t p = org + i;
+        lb[i] = (p >= 0 && p < s.n) ? s.in[p] : 0;
+    }
+    __syncthreads();
+    int64_t ce = g.ce;
+    if (ce > (int64_t)s.body_end + 1) ce = (int64_t)s.body_end + 1;
+    const int len = (int)(ce - g.cs);
+    LdsAcc acc{s.in, fk, fk4, org, tab, hash_variant, lb};
+    for (int i = threadIdx.x; i < 4 * kChunk; i += 256) {
+        int kind = i >> 11, off = i & (kChunk - 1);
+        if (off < len) {
+            uint32_t v = node_step(acc, kind, g.cs + off, g.cs, ce, lv);
+            J[i] = v;
+            J1[i] = j1_pack(v);
         }
     }
     __syncthreads();
-    if (threadIdx.x >= 64) return;  // staging used the whole workgroup; the walk is one lane's job
-    const uint32_t base = symbase[s.chunk_off + c];
-    if (threadIdx.x == 0) {
-        LdsAcc acc{s.in, fk, fk4, chunk_geo(c).cs - 1, tab, hash_variant, lb};
-        LdsSymSink sink{sbuf, base, blk_end + s.blk_off, blk_top + s.blk_off};
-        int ex, cnt;
-        walk_chunk(acc, sink, c, (int)entry[s.chunk_off + c], s.kl, s.body_end, lv, strategy, ex, cnt);
-        sh_cnt = cnt;
+    for (int r = 0; r < kEmitRounds; r++) {
+        for (int i = threadIdx.x; i < 4 * kChunk; i += 256) {
+            if ((i & (kChunk - 1)) >= len) continue;
+            uint32_t v = J[i];
+            if (node_succ(v) < kNodeExit) J[i] = node_jump(v, J[node_succ(v)]);
+        }
+        __syncthreads();
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    const uint32_t base = symbase[s.chunk_off + c];
+    LdsSymSink sink{sbuf, base, blk_end + s.blk_off, blk_top + s.blk_off};
+    if (threadIdx.x == 0) {
+        int kind, ns;
+        int64_t p;
+        bool equal;
+        chunk_special_prefix(acc, sink, c, (int)entry[s.chunk_off + c], s.kl, s.body_end, lv, strategy, kind, p, ns, equal);
+        int ncp = 0;
+        int x = node_of(kind, p, g.cs, ce);
+        while (x < kNodeExit) {
+            cp_node[ncp] = (uint16_t)x;
+            cp_idx[ncp] = (uint16_t)ns;
+            ncp++;
+            uint32_t v = J[x];
+            x = node_succ(v);
+            ns += node_cnt(v);
+        }
+        cp_node[ncp] = (uint16_t)x;  // exit sentinel (>= kNodeExit never equals a node id)
+        cp_idx[ncp] = (uint16_t)ns;
+        sh_ncp = ncp;
+        sh_cnt = ns;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < sh_ncp; i += 256) expand_interval(acc, J1, cp_node[i], cp_node[i + 1], cp_idx[i], g.cs, sink);
+    __syncthreads();
     uint32_t *o = syms + s.sym_off + base;
-    for (int i = threadIdx.x; i < sh_cnt; i += 64) o[i] = sbuf[i];
+    for (int i = threadIdx.x; i < sh_cnt; i += 256) o[i] = sbuf[i];
 }
 
 // ------------------------------------------------------------------ K6
