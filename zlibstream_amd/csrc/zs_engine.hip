@@ -235,7 +235,7 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
                            dev<uint32_t>(c->syms), dev<int32_t>(c->blk_end), dev<int32_t>(c->blk_top), c->crc_tab, lv, strategy,
                            hash_variant);
     mark(9);
-    hipLaunchKernelGGL(zs_tail_kernel, dim3((unsigned)n), dim3(64), 0, stream, d_sd, d_st, dev<uint16_t>(c->link),
+    hipLaunchKernelGGL(zs_tail_kernel, dim3((unsigned)n), dim3(1024), 0, stream, d_sd, d_st, dev<uint16_t>(c->link),
                        dev<uint32_t>(c->syms), dev<int32_t>(c->blk_end), dev<int32_t>(c->blk_top), dev<BlockRec>(c->blocks),
                        dev<uint8_t>(c->scratch), c->crc_tab, lv, strategy, hash_variant);
     mark(10);

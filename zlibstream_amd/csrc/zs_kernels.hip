@@ -74,11 +74,15 @@ __global__ __launch_bounds__(64) void zs_links_kernel(const StreamDesc *sd, cons
     int64_t tend = t0 + kLinkTile;
     if (tend > qend_stream) tend = qend_stream;
     uint16_t *lk = link + s.pos_off;
+    // software pipeline: the 4 input bytes of the next group are in flight while this one is processed
+    uint32_t vnext = (w0 + lane < tend) ? *(const u32u *)(in + w0 + lane + 2) : 0;
     for (int64_t g = w0; g < tend; g += 64) {
         const int64_t q = g + lane;
         const bool valid = q < tend;
+        const uint32_t vcur = vnext;
+        vnext = (q + 64 < tend) ? *(const u32u *)(in + q + 64 + 2) : 0;
         uint32_t h = 0xFFFFFFFFu;
-        if (valid) h = dev_bucket(tab, *(const u32u *)(in + q + 2), hash_variant);
+        if (valid) h = dev_bucket(tab, vcur, hash_variant);
         const uint32_t rel = (uint32_t)(q - w0 + 1);  // 1..65280
         uint32_t prevrel = 0;
         if (valid) {
@@ -675,20 +679,20 @@ __global__ __launch_bounds__(256) void zs_emit_syms_kernel(const StreamDesc *sd,
 // ------------------------------------------------------------------ K6
 // One wave per stream; all lanes run the engine uniformly.  Also turns the
 // block cuts recorded by K5 into BlockRec entries.
-__global__ __launch_bounds__(64) void zs_tail_kernel(const StreamDesc *sd, StreamState *st, const uint16_t *link, uint32_t *syms,
+__global__ __launch_bounds__(1024) void zs_tail_kernel(const StreamDesc *sd, StreamState *st, const uint16_t *link, uint32_t *syms,
                                                      const int32_t *blk_end, const int32_t *blk_top, BlockRec *blocks,
                                                      uint8_t *scratch, const uint32_t *crc_tab_g, LevelCfg lv, int strategy,
                                                      int hash_variant) {
     const StreamDesc &s = sd[blockIdx.x];
     StreamState &ss = st[blockIdx.x];
-    const int lane = lane_id();
+    const int tid = threadIdx.x, nth = blockDim.x;  // all threads restore; wave 0 then runs the engine
     uint8_t *sc = scratch + (int64_t)blockIdx.x * kScratchBytes;
     BlockRec *blk = blocks + s.blk_off;
     const uint32_t body_syms = ss.body_syms;
     const int nb_body = (int)(body_syms / kBlockSyms);
     // body blocks: start = end of the previous one; stored blocks are allowed
     // only while blockStart has not slid out of the window (Deflate.cs:953)
-    for (int i = lane; i < nb_body; i += 64) {
+    for (int i = tid; i < nb_body; i += nth) {
         int64_t start = i ? blk_end[s.blk_off + i - 1] : 0;
         int64_t end = blk_end[s.blk_off + i];
         BlockRec r;
@@ -720,8 +724,8 @@ __global__ __launch_bounds__(64) void zs_tail_kernel(const StreamDesc *sd, Strea
     e.block_start_abs = nb_body ? blk_end[s.blk_off + nb_body - 1] : 0;
     const uint16_t *lk = link + s.pos_off;
     const int64_t p = ss.tail_p;
-    le_restore(e, p, ss.k_done, ss.tail_kind, ss.tail_pend, lk, ss.preins, lane, 64);
-    for (int i = lane; i < kHashSize; i += 64) head32[i] = 0;
+    le_restore(e, p, ss.k_done, ss.tail_kind, ss.tail_pend, lk, ss.preins, tid, nth);
+    for (int i = tid; i < kHashSize; i += nth) head32[i] = 0;
     __syncthreads();
     if (e.avail_end > 0) {
         int64_t lo = p - (kWSize - 1);
@@ -729,19 +733,20 @@ __global__ __launch_bounds__(64) void zs_tail_kernel(const StreamDesc *sd, Strea
         if (lo < 0) lo = 0;
         int64_t hi = p;
         if (hi > (int64_t)s.n - 5) hi = (int64_t)s.n - 5;
-        for (int64_t q = lo + lane; q < hi; q += 64) {
+        for (int64_t q = lo + tid; q < hi; q += nth) {
             le_restore_prev(e, q, lk);
             atomicMax(&head32[le_bucket(e, q)], (uint32_t)(q - e.base) + 1u);
         }
         __syncthreads();
-        for (int i = lane; i < kHashSize; i += 64) e.head[i] = (uint16_t)(head32[i] ? head32[i] - 1 : 0);
-        __syncthreads();
-        le_restore_finish(e, p, lk, ss.preins);
+        for (int i = tid; i < kHashSize; i += nth) e.head[i] = (uint16_t)(head32[i] ? head32[i] - 1 : 0);
     }
     __syncthreads();
-    if (lv.func == 1) le_run_fast(e, lane, 64);
-    else le_run_slow(e, lane, 64);
-    if (lane == 0) {
+    if (tid >= 64) return;  // the engine is one wave, every lane running the same scalar code
+    if (e.avail_end > 0) le_restore_finish(e, p, lk, ss.preins);
+    __syncthreads();
+    if (lv.func == 1) le_run_fast(e, tid, 64);
+    else le_run_slow(e, tid, 64);
+    if (tid == 0) {
         ss.nsyms = (uint32_t)e.nsyms;
         ss.nblocks = e.nblocks;
     }
