@@ -38,7 +38,7 @@ struct zs_ctx {
     hipEvent_t ev[kStCount + 1] = {};
     double stage_ms[kStCount] = {};
     uint32_t *crc_tab = nullptr;
-    DevBuf sd, st, work, link, mk, mk4, maps, segmap, seg_entry, seg_symbase, seg_stale, entry, symbase, stale, syms, blk_end, blk_top, blocks, trees, info, pieces, scratch,
+    DevBuf sd, st, work, link, mm, maps, segmap, seg_entry, seg_symbase, seg_stale, entry, symbase, stale, syms, blk_end, blk_top, blocks, trees, info, pieces, scratch,
         stage_in, stage_out, wr;
     void *pinned = nullptr;
     size_t pinned_cap = 0;
@@ -139,7 +139,7 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
                     pl.w_segs.size() + pl.w_blocks.size();
     if (!ensure(c, c->sd, sizeof(StreamDesc) * (size_t)n) || !ensure(c, c->st, sizeof(StreamState) * (size_t)n) ||
         !ensure(c, c->work, sizeof(uint2) * (n_work + 1)) || !ensure(c, c->link, 2 * (size_t)pl.n_pos + 64) ||
-        !ensure(c, c->mk, 4 * (size_t)pl.n_pos + 64) || !ensure(c, c->mk4, 4 * (size_t)pl.n_pos + 64) ||
+        !ensure(c, c->mm, 8 * (size_t)pl.n_pos + 64) ||
         !ensure(c, c->maps, 4 * (size_t)(pl.n_chunks + 1) * kSlots) || !ensure(c, c->segmap, 8 * (size_t)(pl.n_segs + 1) * kSlots) ||
         !ensure(c, c->seg_entry, 2 * (size_t)(pl.n_segs + 2)) || !ensure(c, c->seg_symbase, 4 * (size_t)(pl.n_segs + 2)) ||
         !ensure(c, c->seg_stale, (size_t)pl.n_segs + 64) || !ensure(c, c->entry, 2 * (size_t)(pl.n_chunks + 2)) ||
@@ -202,15 +202,14 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
     mark(3);
     if (strategy == kHuffmanOnly) {
         // Longest_match is never called (Deflate.Slow.cs:66-71): every position has no match
-        ZS_HIP(c, hipMemsetAsync(c->mk.p, 0, 4 * (size_t)pl.n_pos + 64, stream));
-        ZS_HIP(c, hipMemsetAsync(c->mk4.p, 0, 4 * (size_t)pl.n_pos + 64, stream));
+        ZS_HIP(c, hipMemsetAsync(c->mm.p, 0, 8 * (size_t)pl.n_pos + 64, stream));
     } else if (!pl.w_match.empty())
         hipLaunchKernelGGL(zs_match_kernel, dim3((unsigned)pl.w_match.size()), dim3(1024), kMatchLds, stream, d_sd, d_work + o_match,
-                           dev<uint16_t>(c->link), dev<uint32_t>(c->mk), dev<uint32_t>(c->mk4), lv, strategy);
+                           dev<uint16_t>(c->link), dev<uint2>(c->mm), lv, strategy);
     mark(4);
     if (!pl.w_chunks.empty())
         hipLaunchKernelGGL(zs_chunkmap_kernel, dim3((unsigned)pl.w_chunks.size()), dim3(512), 0, stream, d_sd, d_work + o_chunks,
-                           dev<uint32_t>(c->mk), dev<uint32_t>(c->mk4), dev<uint32_t>(c->maps), c->crc_tab, lv, strategy,
+                           dev<uint2>(c->mm), dev<uint32_t>(c->maps), c->crc_tab, lv, strategy,
                            hash_variant);
     mark(5);
     if (!pl.w_segs.empty())
@@ -218,20 +217,20 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
                            dev<uint32_t>(c->maps), dev<uint2>(c->segmap));
     mark(6);
     hipLaunchKernelGGL(zs_resolve_kernel, dim3((unsigned)n), dim3(256), 0, stream, d_sd, d_st, dev<uint16_t>(c->link),
-                       dev<uint32_t>(c->mk), dev<uint32_t>(c->mk4), dev<uint32_t>(c->maps), dev<uint2>(c->segmap),
+                       dev<uint2>(c->mm), dev<uint32_t>(c->maps), dev<uint2>(c->segmap),
                        dev<uint16_t>(c->seg_entry), dev<uint32_t>(c->seg_symbase), dev<uint8_t>(c->stale),
                        dev<uint8_t>(c->seg_stale), c->crc_tab, lv, strategy, hash_variant);
     mark(7);
     if (!pl.w_segs.empty())
         hipLaunchKernelGGL(zs_expand_kernel, dim3((unsigned)((pl.w_segs.size() + 63) / 64)), dim3(64), 0, stream, d_sd,
-                           d_work + o_segs, (int)pl.w_segs.size(), dev<uint32_t>(c->mk), dev<uint32_t>(c->mk4),
+                           d_work + o_segs, (int)pl.w_segs.size(), dev<uint2>(c->mm),
                            dev<uint32_t>(c->maps), dev<uint16_t>(c->seg_entry), dev<uint32_t>(c->seg_symbase),
                            dev<uint8_t>(c->stale), dev<uint16_t>(c->entry), dev<uint32_t>(c->symbase), c->crc_tab, lv, strategy,
                            hash_variant);
     mark(8);
     if (!pl.w_chunks.empty())
         hipLaunchKernelGGL(zs_emit_syms_kernel, dim3((unsigned)pl.w_chunks.size()), dim3(256), kEmitLds, stream, d_sd, d_work + o_chunks,
-                           dev<uint32_t>(c->mk), dev<uint32_t>(c->mk4), dev<uint16_t>(c->entry), dev<uint32_t>(c->symbase),
+                           dev<uint2>(c->mm), dev<uint16_t>(c->entry), dev<uint32_t>(c->symbase),
                            dev<uint32_t>(c->syms), dev<int32_t>(c->blk_end), dev<int32_t>(c->blk_top), c->crc_tab, lv, strategy,
                            hash_variant);
     mark(9);
@@ -322,7 +321,7 @@ int zs_ctx_create(int device, zs_ctx **out) {
 void zs_ctx_destroy(zs_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    DevBuf *bufs[] = {&c->sd, &c->st, &c->work, &c->link, &c->mk, &c->mk4, &c->maps, &c->segmap, &c->seg_entry, &c->seg_symbase, &c->seg_stale, &c->entry, &c->symbase, &c->stale, &c->syms,
+    DevBuf *bufs[] = {&c->sd, &c->st, &c->work, &c->link, &c->mm, &c->maps, &c->segmap, &c->seg_entry, &c->seg_symbase, &c->seg_stale, &c->entry, &c->symbase, &c->stale, &c->syms,
                       &c->blk_end, &c->blk_top, &c->blocks, &c->trees, &c->info, &c->pieces, &c->scratch, &c->stage_in, &c->stage_out, &c->wr};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);

@@ -120,7 +120,7 @@ __global__ __launch_bounds__(64) void zs_links_kernel(const StreamDesc *sd, cons
 // Per main-loop iteration a lane does one unit of work: test a candidate and
 // compare its first 8 bytes, or compare 8 more bytes of a long match.
 __global__ __launch_bounds__(1024) void zs_match_kernel(const StreamDesc *sd, const uint2 *work, const uint16_t *link,
-                                                        uint32_t *mK, uint32_t *mK4, LevelCfg lv, int strategy) {
+                                                        uint2 *mm, LevelCfg lv, int strategy) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t *wb = smem;
     uint16_t *wl = (uint16_t *)(smem + kMatchLdsBytes);
@@ -133,27 +133,39 @@ __global__ __launch_bounds__(1024) void zs_match_kernel(const StreamDesc *sd, co
     const uint8_t *in = s.in;
     // ---- stage bytes (dword granularity, zero outside [0, n)) ----
     {
-        const bool aligned = (((uintptr_t)in) & 3) == 0;
-        for (int i = threadIdx.x; i < kMatchLdsBytes / 4; i += 1024) {
-            int64_t a = lo + (int64_t)i * 4;
-            uint32_t v = 0;
-            if (a >= 0 && a + 3 < n && aligned) {
-                v = *(const uint32_t *)(in + a);
-            } else {
-                for (int k = 0; k < 4; k++) {
+        // 16 bytes per lane (lo is a multiple of 16; the caller's buffer and the link array are 16-byte aligned
+        // in the common case), scalar fallback at the edges of the stream
+        const bool aligned = (((uintptr_t)in) & 15) == 0;
+        for (int i = threadIdx.x; i < kMatchLdsBytes / 16; i += 1024) {
+            int64_t a = lo + (int64_t)i * 16;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (a >= 0 && a + 15 < n && aligned) {
+                v = *(const uint4 *)(in + a);
+            } else if (a + 15 >= 0 && a < n) {
+                uint32_t t[4] = {0, 0, 0, 0};
+                for (int k = 0; k < 16; k++) {
                     int64_t b = a + k;
-                    if (b >= 0 && b < n) v |= (uint32_t)in[b] << (8 * k);
+                    if (b >= 0 && b < n) t[k >> 2] |= (uint32_t)in[b] << (8 * (k & 3));
                 }
+                v = make_uint4(t[0], t[1], t[2], t[3]);
             }
-            ((uint32_t *)wb)[i] = v;
+            ((uint4 *)wb)[i] = v;
         }
-        const uint16_t *lk = link + s.pos_off;  // pos_off is even and the array 4-byte aligned
-        for (int i = threadIdx.x; i < kMatchLdsLinks / 2; i += 1024) {
-            int64_t a = lo + (int64_t)i * 2;
-            uint32_t v = 0;
-            if (a >= 0 && a + 1 < n) v = *(const uint32_t *)(lk + a);
-            else if (a >= 0 && a < n) v = lk[a];
-            ((uint32_t *)wl)[i] = v;
+        const uint16_t *lk = link + s.pos_off;  // pos_off is a multiple of 64 and the array 16-byte aligned
+        for (int i = threadIdx.x; i < kMatchLdsLinks / 8; i += 1024) {
+            int64_t a = lo + (int64_t)i * 8;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (a >= 0 && a + 7 < n) {
+                v = *(const uint4 *)(lk + a);
+            } else if (a + 7 >= 0 && a < n) {
+                uint32_t t[4] = {0, 0, 0, 0};
+                for (int k = 0; k < 8; k++) {
+                    int64_t b = a + k;
+                    if (b >= 0 && b < n) t[k >> 1] |= (uint32_t)lk[b] << (16 * (k & 1));
+                }
+                v = make_uint4(t[0], t[1], t[2], t[3]);
+            }
+            ((uint4 *)wl)[i] = v;
         }
     }
     __syncthreads();
@@ -167,7 +179,7 @@ __global__ __launch_bounds__(1024) void zs_match_kernel(const StreamDesc *sd, co
     int64_t next = pbeg + per * wave;  // wave-uniform cursor
     int64_t wend = next + per;
     if (wend > pend) wend = pend;
-    uint32_t *oK = mK + s.pos_off, *oK4 = mK4 + s.pos_off;
+    uint2 *om = mm + s.pos_off;
     const int K = lv.chain, K4 = lv.chain >> 2, nice = lv.nice;
 
     // Two independent walks per lane (A and B): with one 1024-thread workgroup per CU
@@ -194,10 +206,7 @@ __global__ __launch_bounds__(1024) void zs_match_kernel(const StreamDesc *sd, co
     auto start = [&](Walk &w, int mine) {
         const int l = wl[mine];
         const bool has = l != 0 && (mine - l) + lo32 >= 1;  // link distances are already <= kMaxDist
-        if (!has) {
-            oK[(int64_t)mine + lo] = kNoMatch;
-            oK4[(int64_t)mine + lo] = kNoMatch;
-        }
+        if (!has) om[(int64_t)mine + lo] = make_uint2(kNoMatch, kNoMatch);
         w.p = mine, w.c = mine - l, w.st = has ? 1 : 0;
         w.best = 2, w.bdist = 0, w.n_eval = 0, w.snapped = 0, w.cl = 0;
         w.scan_end = *(const u32u *)(wb + mine - 1);
@@ -232,9 +241,7 @@ __global__ __launch_bounds__(1024) void zs_match_kernel(const StreamDesc *sd, co
         w.c = (adv & !stop) ? nc : w.c;
         w.st = done ? 0 : (adv ? 1 : w.st);
         if (done) {
-            const int64_t pa = (int64_t)w.p + lo;
-            oK[pa] = rec;
-            oK4[pa] = w.snapped ? w.snap : rec;
+            om[(int64_t)w.p + lo] = make_uint2(rec, w.snapped ? w.snap : rec);
         }
     };
     for (;;) {
@@ -287,12 +294,12 @@ __global__ __launch_bounds__(1024) void zs_match_kernel(const StreamDesc *sd, co
 // ------------------------------------------------------------------ K3 / K4 / K5 accessors
 struct GlobalAcc {
     const uint8_t *in;
-    const uint32_t *mk, *mk4;  // already offset to the stream's position 0
+    const uint2 *mm;  // already offset to the stream's position 0
     const uint32_t *tab;
     int strategy, hash_variant;
     __device__ uint32_t flt(uint32_t m) const { return m ? filter_match(match_len(m), match_dist(m), strategy) : kNoMatch; }
-    __device__ uint32_t mK(int64_t p) const { return flt(mk[p]); }
-    __device__ uint32_t mK4(int64_t p) const { return flt(mk4[p]); }
+    __device__ uint32_t mK(int64_t p) const { return flt(mm[p].x); }
+    __device__ uint32_t mK4(int64_t p) const { return flt(mm[p].y); }
     __device__ uint8_t byte(int64_t p) const { return in[p]; }
     __device__ uint32_t bucket(int64_t p) const { return dev_bucket(tab, *(const u32u *)(in + p + 2), hash_variant); }
     __device__ int run1(int64_t p) const {
@@ -320,16 +327,17 @@ struct LdsAcc {
     }
 };
 
-__device__ __forceinline__ void stage_chunk_matches(const StreamDesc &s, int c, const uint32_t *mK, const uint32_t *mK4,
-                                                    int strategy, uint32_t *fk, uint32_t *fk4) {
+__device__ __forceinline__ void stage_chunk_matches(const StreamDesc &s, int c, const uint2 *mm, int strategy, uint32_t *fk,
+                                                    uint32_t *fk4) {
     ChunkGeo g = chunk_geo(c);
-    const uint32_t *a = mK + s.pos_off, *b = mK4 + s.pos_off;
+    const uint2 *a = mm + s.pos_off;
     int64_t org = g.cs - 1;
     for (int i = threadIdx.x; i < kChunk + 1; i += blockDim.x) {
         int64_t p = org + i;
         uint32_t x = 0, y = 0;
         if (p >= 1 && p <= s.body_end) {
-            x = a[p], y = b[p];
+            const uint2 v = a[p];
+            x = v.x, y = v.y;
             x = x ? filter_match(match_len(x), match_dist(x), strategy) : kNoMatch;
             y = y ? filter_match(match_len(y), match_dist(y), strategy) : kNoMatch;
         }
@@ -343,8 +351,8 @@ __device__ __forceinline__ void stage_chunk_matches(const StreamDesc &s, int c, 
 // automaton node (4 states x 2048 positions) builds the 1-step table in LDS, in-place
 // squaring rounds turn it into node -> (exit slot, symbols), then one lane per slot reads
 // its entry (the refill-rule positions of segment-first chunks are stepped explicitly).
-__global__ __launch_bounds__(512) void zs_chunkmap_kernel(const StreamDesc *sd, const uint2 *work, const uint32_t *mK,
-                                                          const uint32_t *mK4, uint32_t *maps, const uint32_t *crc_tab_g,
+__global__ __launch_bounds__(512) void zs_chunkmap_kernel(const StreamDesc *sd, const uint2 *work, const uint2 *mm,
+                                                          uint32_t *maps, const uint32_t *crc_tab_g,
                                                           LevelCfg lv, int strategy, int hash_variant) {
     __shared__ uint32_t fk[kChunk + 1], fk4[kChunk + 1];
     __shared__ uint32_t tbl[kNodeExit];
@@ -352,7 +360,7 @@ __global__ __launch_bounds__(512) void zs_chunkmap_kernel(const StreamDesc *sd, 
     uint2 w = work[blockIdx.x];
     const StreamDesc &s = sd[w.x];
     const int c = (int)w.y;
-    stage_chunk_matches(s, c, mK, mK4, strategy, fk, fk4);
+    stage_chunk_matches(s, c, mm, strategy, fk, fk4);
     const ChunkGeo g = chunk_geo(c);
     const bool event_chunk = g.first && g.seg <= s.kl;
     if (event_chunk) load_crc_tab(tab, crc_tab_g);
@@ -413,8 +421,8 @@ __global__ __launch_bounds__(320) void zs_segmap_kernel(const StreamDesc *sd, co
 // bucket: the workgroup cuts link[s_k], re-walks the positions whose recorded winner lies
 // behind the cut, and marks the chunks whose matches changed; segments holding such
 // chunks are then followed chunk by chunk, stale chunks by a direct walk.
-__global__ __launch_bounds__(256) void zs_resolve_kernel(const StreamDesc *sd, StreamState *st, uint16_t *link, uint32_t *mK,
-                                                         uint32_t *mK4, const uint32_t *maps, const uint2 *segmap,
+__global__ __launch_bounds__(256) void zs_resolve_kernel(const StreamDesc *sd, StreamState *st, uint16_t *link, uint2 *mm,
+                                                         const uint32_t *maps, const uint2 *segmap,
                                                          uint16_t *seg_entry, uint32_t *seg_symbase, uint8_t *stale,
                                                          uint8_t *seg_stale, const uint32_t *crc_tab_g, LevelCfg lv,
                                                          int strategy, int hash_variant) {
@@ -431,8 +439,8 @@ __global__ __launch_bounds__(256) void zs_resolve_kernel(const StreamDesc *sd, S
         return;
     }
     uint16_t *lk = link + s.pos_off;
-    uint32_t *a = mK + s.pos_off, *b = mK4 + s.pos_off;
-    GlobalAcc acc{s.in, a, b, tab, strategy, hash_variant};
+    uint2 *a = mm + s.pos_off;
+    GlobalAcc acc{s.in, a, tab, strategy, hash_variant};
     const int nseg = s.nsegs, nch = s.nchunks;
     for (;;) {
         // ---- thread 0 runs ahead until a refill needs the workgroup (or the end) ----
@@ -495,7 +503,8 @@ __global__ __launch_bounds__(256) void zs_resolve_kernel(const StreamDesc *sd, S
             if (hi > s.body_end) hi = s.body_end;
             for (int64_t p = e + 1 + threadIdx.x; p <= hi; p += blockDim.x) {
                 if (acc.bucket(p) != B) continue;
-                uint32_t x = a[p], y = b[p];
+                const uint2 old = a[p];
+                uint32_t x = old.x, y = old.y;
                 bool dirty = (x && p - match_dist(x) < e) || (y && p - match_dist(y) < e);
                 if (!dirty) continue;
                 auto lkf = [lk](int64_t q) { return (int)lk[q]; };
@@ -508,7 +517,7 @@ __global__ __launch_bounds__(256) void zs_resolve_kernel(const StreamDesc *sd, S
                 uint32_t nx, ny;
                 walk_matches(lkf, lcp, p, lv, nx, ny);
                 if (nx != x || ny != y) {
-                    a[p] = nx, b[p] = ny;
+                    a[p] = make_uint2(nx, ny);
                     int cp = chunk_of(p);
                     stale[s.chunk_off + cp] = 1;
                     seg_stale[s.seg_off + seg_of_chunk(cp)] = 1;
@@ -538,8 +547,8 @@ __global__ __launch_bounds__(256) void zs_resolve_kernel(const StreamDesc *sd, S
 
 // ------------------------------------------------------------------ K4b
 // One thread per parse segment: entry slot and first-symbol index of each of its chunks.
-__global__ __launch_bounds__(64) void zs_expand_kernel(const StreamDesc *sd, const uint2 *work, int nwork, const uint32_t *mK,
-                                                       const uint32_t *mK4, const uint32_t *maps, const uint16_t *seg_entry,
+__global__ __launch_bounds__(64) void zs_expand_kernel(const StreamDesc *sd, const uint2 *work, int nwork, const uint2 *mm,
+                                                       const uint32_t *maps, const uint16_t *seg_entry,
                                                        const uint32_t *seg_symbase, const uint8_t *stale, uint16_t *entry,
                                                        uint32_t *symbase, const uint32_t *crc_tab_g, LevelCfg lv, int strategy,
                                                        int hash_variant) {
@@ -548,7 +557,7 @@ __global__ __launch_bounds__(64) void zs_expand_kernel(const StreamDesc *sd, con
     uint2 w = work[i];
     const StreamDesc &s = sd[w.x];
     const int seg = (int)w.y;
-    GlobalAcc acc{s.in, mK + s.pos_off, mK4 + s.pos_off, crc_tab_g, strategy, hash_variant};
+    GlobalAcc acc{s.in, mm + s.pos_off, crc_tab_g, strategy, hash_variant};
     int slot = seg_entry[s.seg_off + seg];
     uint32_t total = seg_symbase[s.seg_off + seg];
     const int c0 = seg_first_chunk(seg);
@@ -597,8 +606,8 @@ struct LdsSymSink {
         }
     }
 };
-__global__ __launch_bounds__(256) void zs_emit_syms_kernel(const StreamDesc *sd, const uint2 *work, const uint32_t *mK,
-                                                          const uint32_t *mK4, const uint16_t *entry, const uint32_t *symbase,
+__global__ __launch_bounds__(256) void zs_emit_syms_kernel(const StreamDesc *sd, const uint2 *work, const uint2 *mm,
+                                                          const uint16_t *entry, const uint32_t *symbase,
                                                           uint32_t *syms, int32_t *blk_end, int32_t *blk_top,
                                                           const uint32_t *crc_tab_g, LevelCfg lv, int strategy,
                                                           int hash_variant) {
@@ -618,7 +627,7 @@ __global__ __launch_bounds__(256) void zs_emit_syms_kernel(const StreamDesc *sd,
     const StreamDesc &s = sd[w.x];
     const int c = (int)w.y;
     const ChunkGeo g = chunk_geo(c);
-    stage_chunk_matches(s, c, mK, mK4, strategy, fk, fk4);
+    stage_chunk_matches(s, c, mm, strategy, fk, fk4);
     if (g.first && g.seg <= s.kl) load_crc_tab(tab, crc_tab_g);
     const int64_t org = g.cs - 1;
     for (int i = threadIdx.x; i < kChunk + 1; i += 256) {
