@@ -93,6 +93,16 @@ ZS_API int zs_deflate_batch(zs_ctx *ctx, int n, const void *const *in, const int
                             const int64_t *out_cap, int64_t *out_len, int *status, int level, int strategy,
                             int hash_variant);
 
+/* Inflate (Inflate.Decompress, Inflate.cs:103-357; InflateBlocks.cs; InfCodes.cs; InfTree.cs): n independent
+ * zlib streams, each decoded completely (what `new ZlibInputStream(src).Read(...)` to the end of the stream
+ * yields, ZlibInputStream.cs:133-186).  out_cap[i] must hold the whole output.  status[i] is ZS_STREAM_END on
+ * success; ZS_DATA_ERROR / ZS_BUF_ERROR / ZS_NEED_DICT with the reference's message in zs_ctx_last_error
+ * otherwise (e.g. "incorrect data check", Inflate.cs:339).  Returns ZS_OK when every stream ended cleanly. */
+ZS_API int zs_inflate_batch_device(zs_ctx *ctx, int n, const void *const *in, const int64_t *in_len, void *const *out,
+                                   const int64_t *out_cap, int64_t *out_len, int *status, void *hip_stream);
+ZS_API int zs_inflate_batch(zs_ctx *ctx, int n, const void *const *in, const int64_t *in_len, void *const *out,
+                            const int64_t *out_cap, int64_t *out_len, int *status);
+
 /* Stage timing of the last *_batch_device call, measured with hipEvents on
  * the stream the kernels ran on.  Enable before the call. */
 ZS_API void zs_ctx_set_profiling(zs_ctx *ctx, int enable);

@@ -196,3 +196,65 @@ def test_sparse_levels_4_and_9(engine, oracle):
     d = datagen.sparse(1024, 1024)
     for lvl in (4, 9):
         assert engine.deflate_batch([d], level=lvl)[0] == oracle.compress(d, lvl)
+
+
+# ---- inflate (SURVEY a16 / BASELINE config 5): any conformant decode is bit-exact by construction ----
+def test_inflate_roundtrip_of_device_streams(engine):
+    names = ["alice29.txt", "ptt5", "kennedy.xls", "sum", "xargs.1"]
+    datas = [oracle_binding.corpus(n) for n in names] + [b"", b"a", bytes(70000), datagen.sparse(128, 128)]
+    for lvl in (6, 9):
+        zs = engine.deflate_batch(datas, level=lvl)
+        outs = engine.inflate_batch(zs, [len(d) for d in datas])
+        assert outs == datas
+
+
+def test_inflate_foreign_streams(engine, oracle):
+    """Streams made by another encoder (Python zlib): stored, fixed and dynamic blocks, all window sizes."""
+    rng = np.random.default_rng(5)
+    text = oracle_binding.corpus("lcet10.txt")
+    cases = [zlib.compress(text, 0), zlib.compress(text, 1), zlib.compress(text, 9), zlib.compress(rng.integers(0, 256, 200000, dtype=np.uint8).tobytes(), 6)]
+    co = zlib.compressobj(6, zlib.DEFLATED, 15, 8, zlib.Z_FIXED)
+    cases.append(co.compress(text[:100000]) + co.flush())
+    co = zlib.compressobj(6, zlib.DEFLATED, 9)
+    cases.append(co.compress(text[:50000]) + co.flush())
+    want = [zlib.decompress(z) for z in cases]
+    got = engine.inflate_batch(cases, [len(w) for w in want])
+    assert got == want
+    for z, w in zip(cases, want):
+        rc, out, msg = oracle.inflate(z, len(w))
+        assert rc == 1 and out == w
+
+
+def test_inflate_errors_match_reference_messages(engine, oracle):
+    d = oracle_binding.corpus("fields.c")
+    z = engine.deflate_batch([d], level=6)[0]
+    bad_check = z[:-1] + bytes([z[-1] ^ 1])
+    bad_hdr = b"\x78\x9d" + z[2:]
+    bad_method = b"\x79\x9c" + z[2:]
+    truncated = z[:len(z) // 2]
+    for stream, cap in ((bad_check, len(d)), (bad_hdr, len(d)), (bad_method, len(d)), (truncated, len(d)), (z, len(d) - 10)):
+        rc, _, msg = oracle.inflate(stream, cap)
+        with pytest.raises(ZlibStreamException) as ei:
+            engine.inflate_batch([stream], [cap])
+        assert rc != 1
+        assert str(ei.value) == "inflating: " + msg, (str(ei.value), msg)
+
+
+def test_zlib_input_stream_mirror(engine):
+    from zlibstream_amd import ZlibInputStream
+    d = oracle_binding.corpus("asyoulik.txt")
+    z = engine.deflate_batch([d], level=6)[0]
+    s = ZlibInputStream(io.BytesIO(z), engine=engine)
+    assert s.read(1000) == d[:1000]
+    assert s.read() == d[1000:]
+
+
+def test_inflate_large_device_resident(engine):
+    import torch
+    data = datagen.english(8 << 20)
+    z = engine.deflate_batch([data], level=6)[0]
+    d_in = torch.frombuffer(bytearray(z), dtype=torch.uint8).cuda()
+    d_out = torch.empty(len(data), dtype=torch.uint8, device="cuda")
+    n = engine.inflate_batch_device([d_in.data_ptr()], [len(z)], [d_out.data_ptr()], [len(data)],
+                                    stream=torch.cuda.current_stream().cuda_stream)[0]
+    assert n == len(data) and d_out.cpu().numpy().tobytes() == data

@@ -5,5 +5,5 @@ ZlibOptions, CompressionLevel, CompressionStrategy, FlushMode,
 ZlibStreamException) over the C ABI in include/zsgpu.h.  The compression path
 has no CPU fallback: it needs libzsgpu.so and an MI355X.
 """
-from .api import (CompressionLevel, CompressionState, CompressionStrategy, Engine, FlushMode, ZlibOptions,  # noqa: F401
+from .api import (CompressionLevel, CompressionState, CompressionStrategy, Engine, FlushMode, ZlibInputStream, ZlibOptions,  # noqa: F401
                   ZlibOutputStream, ZlibStreamException, compress, deflate_bound)

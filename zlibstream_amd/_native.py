@@ -10,6 +10,7 @@ SYMBOLS = [
     "zs_ctx_create", "zs_ctx_destroy", "zs_ctx_last_error", "zs_deflate_bound", "zs_deflate_batch_device",
     "zs_deflate_batch", "zs_ctx_set_profiling", "zs_ctx_stage_count", "zs_ctx_stage_name", "zs_ctx_stage_ms",
     "zs_deflate_init", "zs_deflate", "zs_deflate_end", "zs_last_message", "zs_adler32_device",
+    "zs_inflate_batch_device", "zs_inflate_batch",
 ]
 
 _lib = None
@@ -47,6 +48,11 @@ def lib():
     L.zs_deflate_batch_device.argtypes = batch_args + [vp]
     L.zs_deflate_batch.restype = i32
     L.zs_deflate_batch.argtypes = batch_args
+    inf_args = [vp, i32, P(vp), P(i64), P(vp), P(i64), P(i64), P(i32)]
+    L.zs_inflate_batch_device.restype = i32
+    L.zs_inflate_batch_device.argtypes = inf_args + [vp]
+    L.zs_inflate_batch.restype = i32
+    L.zs_inflate_batch.argtypes = inf_args
     L.zs_ctx_set_profiling.restype = None
     L.zs_ctx_set_profiling.argtypes = [vp, i32]
     L.zs_ctx_stage_count.restype = i32

@@ -148,6 +148,38 @@ class Engine:
         return [outs[i].raw[:lens[i]] for i in range(n)]
 
 
+    def _call_inflate(self, fn, in_ptrs, in_lens, out_ptrs, out_caps, extra=()):
+        n = len(in_ptrs)
+        VP = ctypes.c_void_p * n
+        I64 = ctypes.c_int64 * n
+        I32 = ctypes.c_int * n
+        out_len = I64()
+        status = I32()
+        rc = fn(self._h, n, VP(*in_ptrs), I64(*in_lens), VP(*out_ptrs), I64(*out_caps), out_len, status, *extra)
+        return rc, list(out_len), list(status)
+
+    def inflate_batch_device(self, in_ptrs, in_lens, out_ptrs, out_caps, stream=None):
+        rc, lens, status = self._call_inflate(self._lib.zs_inflate_batch_device, in_ptrs, in_lens, out_ptrs, out_caps,
+                                              (ctypes.c_void_p(stream or 0),))
+        if rc != 0:
+            raise ZlibStreamException("inflating: " + self.last_error())  # ThrowHelper.cs:21-23
+        return lens
+
+    def inflate_batch(self, streams, out_sizes):
+        """Host buffers: zlib streams -> decoded bytes; out_sizes[i] is the capacity for stream i."""
+        zs = [bytes(z) for z in streams]
+        n = len(zs)
+        if n == 0:
+            return []
+        keep = [ctypes.create_string_buffer(z, len(z)) if len(z) else ctypes.create_string_buffer(1) for z in zs]
+        outs = [ctypes.create_string_buffer(max(int(c), 1)) for c in out_sizes]
+        rc, lens, status = self._call_inflate(self._lib.zs_inflate_batch, [ctypes.addressof(k) for k in keep], [len(z) for z in zs],
+                                              [ctypes.addressof(o) for o in outs], [int(c) for c in out_sizes])
+        if rc != 0:
+            raise ZlibStreamException("inflating: " + self.last_error())
+        return [outs[i].raw[:lens[i]] for i in range(n)]
+
+
 _default_engine = None
 
 
@@ -161,6 +193,45 @@ def default_engine():
 def compress(data, level=6, strategy=0, engine=None):
     """`using (var s = new ZlibOutputStream(ms, level)) s.Write(data)` in one call."""
     return (engine or default_engine()).deflate_batch([data], level, strategy)[0]
+
+
+class ZlibInputStream(io.RawIOBase):
+    """ZlibInputStream.cs: a read-only stream that inflates `base_stream`.
+
+    The device decodes whole streams, so the first read drains the base stream, inflates it on the GPU
+    (growing the output buffer until it fits) and later reads are served from the decoded bytes.
+    """
+
+    def __init__(self, base_stream, engine=None):
+        super().__init__()
+        self.BaseStream = base_stream
+        self._engine = engine or default_engine()
+        self._data = None
+        self._pos = 0
+
+    def readable(self):
+        return True
+
+    def _decode(self):
+        z = self.BaseStream.read()
+        cap = max(4 * len(z), 1 << 16)
+        while True:
+            try:
+                self._data = self._engine.inflate_batch([z], [cap])[0]
+                return
+            except ZlibStreamException as e:
+                if "buffer error" in str(e) and cap < (1 << 31):
+                    cap *= 4
+                    continue
+                raise
+
+    def readinto(self, b):
+        if self._data is None:
+            self._decode()
+        n = min(len(b), len(self._data) - self._pos)
+        b[:n] = self._data[self._pos:self._pos + n]
+        self._pos += n
+        return n
 
 
 class ZlibOutputStream(io.RawIOBase):

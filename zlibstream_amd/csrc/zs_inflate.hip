@@ -1,0 +1,353 @@
+// zs_inflate.hip -- stream-parallel inflate (BASELINE config 5).
+//
+// RFC 1950/1951 decoding is deterministic, so any conformant decoder returns the bytes the
+// reference's Inflate.cs / InflateBlocks.cs / InfCodes.cs / InfTree.cs return; what is kept
+// from the reference is the error taxonomy (Inflate.cs:134,142,166,243,339;
+// InflateBlocks.cs:237,278,394,569; InfCodes.cs:294,349; InfTree.cs:377-427).
+//
+// One wave per stream.  A deflate stream is bit-serial and every match may reference the
+// 32 KiB before it, so a single stream offers little parallelism without speculation;
+// this first version runs the symbol decode wave-uniformly (every lane executes the same
+// scalar code on the same bits) and uses the 64 lanes for what is parallel: match copies,
+// table fills and the coalesced flush of the 64 KiB LDS output ring to HBM.
+#include <hip/hip_runtime.h>
+
+#include "zs_device.h"
+
+namespace zs {
+
+enum InfMsg {
+    kInfOk = 0, kInfBadMethod, kInfBadWindow, kInfBadHeaderCheck, kInfNeedDict, kInfBadBlockType, kInfBadStoredLen,
+    kInfTooManySyms, kInfBadRepeat, kInfOverBl, kInfIncompleteBl, kInfOverLit, kInfIncompleteLit, kInfOverDist, kInfIncompleteDist,
+    kInfEmptyDist, kInfBadLitCode, kInfBadDistCode, kInfTruncated, kInfOutputFull, kInfBadCheck, kInfMsgCount
+};
+
+struct InfDesc {
+    const uint8_t *in;
+    uint8_t *out;
+    int64_t in_len, out_cap;
+};
+struct InfState {
+    int64_t out_len, in_used;
+    uint32_t adler_stored;
+    int32_t status;  // CompressionState
+    int32_t msg;     // InfMsg
+    int32_t pad_;
+};
+
+constexpr int kInfRing = 65536;
+constexpr int kInfLitBits = 10, kInfDistBits = 9;
+constexpr uint16_t kInfEsc = 0xFFFF;
+
+struct InfTables {
+    uint16_t lit[1 << kInfLitBits];    // sym << 4 | len, or kInfEsc
+    uint16_t dist[1 << kInfDistBits];
+    uint16_t lcount[16], dcount[16];   // canonical description for codes longer than the primary index
+    uint16_t lsym[288], dsym[32];
+};
+
+struct InfBits {
+    const uint8_t *in;
+    int64_t n, pos;  // next byte to load
+    uint64_t buf;
+    int cnt;
+    bool bad;  // a read ran past the end of the input
+    __device__ void fill() {  // top the 64-bit buffer up to >= 56 bits while input lasts
+        if (cnt < 56 && pos + 8 <= n) {
+            // one unaligned 8-byte load; bits above the whole bytes taken are re-ORed identically next time
+            buf |= *(const uint64_t __attribute__((aligned(1))) *)(in + pos) << cnt;
+            const int adv = (63 - cnt) >> 3;
+            pos += adv;
+            cnt += adv * 8;
+        } else {
+            while (cnt <= 56 && pos < n) {
+                buf |= (uint64_t)in[pos++] << cnt;
+                cnt += 8;
+            }
+        }
+    }
+    __device__ uint32_t peek(int k) const { return (uint32_t)(buf & ((1ull << k) - 1)); }
+    __device__ void drop(int k) {
+        if (k > cnt) bad = true, k = cnt;
+        buf >>= k;
+        cnt -= k;
+    }
+    __device__ uint32_t take(int k) {
+        uint32_t v = peek(k);
+        drop(k);
+        return v;
+    }
+};
+
+// canonical tables from code lengths; returns 0 complete, > 0 incomplete, < 0 oversubscribed
+__device__ int inf_build(const uint8_t *lens, int n, uint16_t *primary, int pbits, uint16_t *count, uint16_t *symtab) {
+    const int lane = threadIdx.x & 63;
+    uint16_t offs[16];
+    for (int i = 0; i < 16; i++) count[i] = 0;
+    for (int i = 0; i < n; i++) count[lens[i]]++;
+    int left = 1;
+    for (int len = 1; len <= 15; len++) {
+        left <<= 1;
+        left -= count[len];
+        if (left < 0) return left;
+    }
+    offs[1] = 0;
+    for (int len = 1; len < 15; len++) offs[len + 1] = (uint16_t)(offs[len] + count[len]);
+    for (int i = 0; i < n; i++)
+        if (lens[i]) symtab[offs[lens[i]]++] = (uint16_t)i;
+    // primary table: every lane fills a strided share of the entries
+    for (int i = lane; i < (1 << pbits); i += 64) primary[i] = kInfEsc;
+    __syncthreads();
+    unsigned code = 0;
+    int index = 0;
+    for (int len = 1; len <= pbits; len++) {
+        for (int k = 0; k < count[len]; k++) {
+            unsigned rev = bit_reverse(code, len);
+            uint16_t e = (uint16_t)((symtab[index] << 4) | len);
+            for (unsigned r = rev + ((unsigned)lane << len); r < (1u << pbits); r += 64u << len) primary[r] = e;
+            code++;
+            index++;
+        }
+        code <<= 1;
+    }
+    __syncthreads();
+    return left;
+}
+
+// symbol for codes longer than the primary index (puff-style canonical walk, MSB-first code growth)
+__device__ int inf_slow(InfBits &b, const uint16_t *count, const uint16_t *symtab, int &len_out) {
+    int code = 0, first = 0, index = 0;
+    uint64_t bits = b.buf;
+    for (int len = 1; len <= 15; len++) {
+        code |= (int)(bits & 1);
+        bits >>= 1;
+        int c = count[len];
+        if (code - c < first) {
+            len_out = len;
+            return symtab[index + (code - first)];
+        }
+        index += c;
+        first += c;
+        first <<= 1;
+        code <<= 1;
+    }
+    len_out = 0;
+    return -1;
+}
+
+__global__ __launch_bounds__(64) void zs_inflate_kernel(const InfDesc *descs, InfState *states) {
+    // ~70 KiB of LDS: dynamic allocation, carved by hand
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint8_t *ring = smem;
+    InfTables &T = *(InfTables *)(smem + kInfRing);
+    uint8_t *lens = smem + kInfRing + sizeof(InfTables);
+    uint8_t *ll = lens + 320;
+    const int lane = threadIdx.x;
+    const InfDesc d = descs[blockIdx.x];
+    InfState &st = states[blockIdx.x];
+    InfBits b{d.in, d.in_len, 0, 0, 0, false};
+    int64_t pos = 0, flushed = 0;
+    enum { ZS_OK_ = 0, ZS_END_ = 1, ZS_NEED_DICT_ = 2, ZS_DATA_ = -3, ZS_BUF_ = -5 };
+    int status = ZS_OK_, msg = kInfOk;
+#define INF_FAIL(code, m) \
+    do {                  \
+        status = (code);  \
+        msg = (m);        \
+        goto done;        \
+    } while (0)
+    auto flush_to = [&](int64_t upto) {  // ring -> HBM, coalesced
+        for (int64_t o = flushed + lane * 4; o + 3 < upto; o += 256)
+            *(uint32_t *)(d.out + o) = *(const uint32_t *)(ring + (o & (kInfRing - 1)));  // flushed and ring offsets are multiples of 4 apart
+        int64_t tail = flushed + ((upto - flushed) & ~3LL);
+        if (lane < (int)(upto - tail)) d.out[tail + lane] = ring[(tail + lane) & (kInfRing - 1)];
+        __syncthreads();
+        flushed = upto;
+    };
+    // zlib header (Inflate.cs:120-170, 243)
+    b.fill();
+    if (d.in_len < 2) INF_FAIL(ZS_BUF_, kInfTruncated);
+    {
+        unsigned cmf = b.take(8), flg = b.take(8);
+        if ((cmf & 0x0F) != 8) INF_FAIL(ZS_DATA_, kInfBadMethod);
+        if ((cmf >> 4) + 8 > 15) INF_FAIL(ZS_DATA_, kInfBadWindow);
+        if (((cmf << 8) + flg) % 31 != 0) INF_FAIL(ZS_DATA_, kInfBadHeaderCheck);
+        if (flg & 0x20) INF_FAIL(ZS_NEED_DICT_, kInfNeedDict);
+    }
+    for (int last = 0; !last;) {
+        b.fill();
+        if (b.cnt < 3) INF_FAIL(ZS_BUF_, kInfTruncated);
+        last = (int)b.take(1);
+        const unsigned type = b.take(2);
+        if (type == 0) {  // stored (InflateBlocks.cs:244-330)
+            b.drop(b.cnt & 7);
+            b.fill();
+            if (b.cnt < 32) INF_FAIL(ZS_BUF_, kInfTruncated);
+            unsigned len = b.take(16), nlen = b.take(16);
+            if (len != (~nlen & 0xFFFF)) INF_FAIL(ZS_DATA_, kInfBadStoredLen);
+            // give the bytes still in the bit buffer back to the byte cursor
+            int64_t src = b.pos - (b.cnt >> 3);
+            if (src + len > d.in_len) INF_FAIL(ZS_BUF_, kInfTruncated);
+            if (pos + len > d.out_cap) INF_FAIL(ZS_BUF_, kInfOutputFull);
+            for (unsigned done = 0; done < len;) {
+                unsigned room = (unsigned)(flushed + kInfRing / 2 + kInfRing / 4 - pos);
+                unsigned n = len - done < room ? len - done : room;
+                for (unsigned i = lane; i < n; i += 64) ring[(pos + i) & (kInfRing - 1)] = d.in[src + done + i];
+                __syncthreads();
+                pos += n;
+                done += n;
+                if (pos - flushed >= kInfRing / 2) flush_to(flushed + kInfRing / 2);
+            }
+            b.pos = src + len;
+            b.buf = 0;
+            b.cnt = 0;
+            continue;
+        }
+        if (type == 3) INF_FAIL(ZS_DATA_, kInfBadBlockType);
+        if (type == 1) {  // fixed codes
+            for (int i = lane; i < 288; i += 64) lens[i] = (uint8_t)static_llen(i);
+            __syncthreads();
+            inf_build(lens, 288, T.lit, kInfLitBits, T.lcount, T.lsym);
+            for (int i = lane; i < 32; i += 64) lens[i] = 5;
+            __syncthreads();
+            inf_build(lens, 30, T.dist, kInfDistBits, T.dcount, T.dsym);
+        } else {  // dynamic codes (InflateBlocks.cs:380-610)
+            b.fill();
+            if (b.cnt < 14) INF_FAIL(ZS_BUF_, kInfTruncated);
+            const int nlen = (int)b.take(5) + 257, ndist = (int)b.take(5) + 1, ncode = (int)b.take(4) + 4;
+            if (nlen > 286 || ndist > 30) INF_FAIL(ZS_DATA_, kInfTooManySyms);
+            for (int i = lane; i < 320; i += 64) lens[i] = 0;
+            __syncthreads();
+            for (int i = 0; i < ncode; i++) {
+                b.fill();
+                if (b.cnt < 3) INF_FAIL(ZS_BUF_, kInfTruncated);
+                unsigned v = b.take(3);
+                if (lane == 0) lens[bl_order(i)] = (uint8_t)v;
+            }
+            __syncthreads();
+            int r = inf_build(lens, 19, T.lit, 7, T.lcount, T.lsym);  // bit-length code: <= 7 bits, fits the primary table
+            if (r < 0) INF_FAIL(ZS_DATA_, kInfOverBl);
+            if (r > 0) INF_FAIL(ZS_DATA_, kInfIncompleteBl);
+            __syncthreads();
+            uint8_t prev = 0;
+            int idx = 0;
+            while (idx < nlen + ndist) {
+                if (b.bad) INF_FAIL(ZS_BUF_, kInfTruncated);
+                b.fill();
+                uint16_t e = T.lit[b.peek(7)];
+                if (e == kInfEsc || (int)(e & 15) > b.cnt) INF_FAIL(b.cnt < 7 && b.pos >= b.n ? ZS_BUF_ : ZS_DATA_, kInfBadRepeat);
+                b.drop(e & 15);
+                int sym = e >> 4;
+                if (sym < 16) {
+                    if (lane == 0) ll[idx] = (uint8_t)sym;
+                    prev = (uint8_t)sym;
+                    idx++;
+                } else {
+                    int rep;
+                    uint8_t val = 0;
+                    if (sym == 16) {
+                        if (idx == 0) INF_FAIL(ZS_DATA_, kInfBadRepeat);
+                        val = prev;
+                        rep = 3 + (int)b.take(2);
+                    } else if (sym == 17) {
+                        rep = 3 + (int)b.take(3);
+                    } else {
+                        rep = 11 + (int)b.take(7);
+                    }
+                    if (idx + rep > nlen + ndist) INF_FAIL(ZS_DATA_, kInfBadRepeat);
+                    if (lane < rep) ll[idx + lane] = val;
+                    if (lane + 64 < rep) ll[idx + lane + 64] = val;
+                    if (lane + 128 < rep) ll[idx + lane + 128] = val;
+                    prev = val;
+                    idx += rep;
+                }
+            }
+            __syncthreads();
+            for (int i = lane; i < 320; i += 64) lens[i] = i < nlen + ndist ? ll[i] : 0;
+            __syncthreads();
+            r = inf_build(lens, nlen, T.lit, kInfLitBits, T.lcount, T.lsym);
+            if (r < 0) INF_FAIL(ZS_DATA_, kInfOverLit);
+            if (r > 0 && nlen - T.lcount[0] != 1) INF_FAIL(ZS_DATA_, kInfIncompleteLit);
+            r = inf_build(lens + nlen, ndist, T.dist, kInfDistBits, T.dcount, T.dsym);
+            if (r < 0) INF_FAIL(ZS_DATA_, kInfOverDist);
+            if (r > 0 && ndist - T.dcount[0] != 1) {
+                if (ndist - T.dcount[0] == 0 && nlen > 257) INF_FAIL(ZS_DATA_, kInfEmptyDist);
+                if (ndist - T.dcount[0] > 1) INF_FAIL(ZS_DATA_, kInfIncompleteDist);
+            }
+        }
+        __syncthreads();
+        // ---- symbols (InfCodes.cs:106-386) ----
+        for (;;) {
+            if (b.bad) INF_FAIL(ZS_BUF_, kInfTruncated);
+            b.fill();
+            int sym, clen;
+            {
+                uint16_t e = T.lit[b.peek(kInfLitBits)];
+                if (e != kInfEsc) sym = e >> 4, clen = e & 15;
+                else sym = inf_slow(b, T.lcount, T.lsym, clen);
+            }
+            if (sym < 0 || clen > b.cnt) INF_FAIL(b.pos >= b.n && b.cnt < 15 ? ZS_BUF_ : ZS_DATA_, sym < 0 ? kInfBadLitCode : kInfTruncated);
+            b.drop(clen);
+            if (sym < 256) {
+                if (pos >= d.out_cap) INF_FAIL(ZS_BUF_, kInfOutputFull);
+                if (lane == 0) ring[pos & (kInfRing - 1)] = (uint8_t)sym;
+                pos++;
+            } else if (sym == 256) {
+                break;
+            } else {
+                sym -= 257;
+                if (sym >= 29) INF_FAIL(ZS_DATA_, kInfBadLitCode);
+                const int mlen = (sym == 28 ? 258 : base_length(sym) + 3) + (int)b.take(extra_lbits(sym));
+                b.fill();
+                int ds, dl;
+                {
+                    uint16_t e = T.dist[b.peek(kInfDistBits)];
+                    if (e != kInfEsc) ds = e >> 4, dl = e & 15;
+                    else ds = inf_slow(b, T.dcount, T.dsym, dl);
+                }
+                if (ds < 0 || ds >= 30 || dl > b.cnt) INF_FAIL(b.pos >= b.n && b.cnt < 15 ? ZS_BUF_ : ZS_DATA_, kInfBadDistCode);
+                b.drop(dl);
+                const int dist = base_dist(ds) + 1 + (int)b.take(extra_dbits(ds));
+                if (dist > pos || dist > kWSize) INF_FAIL(ZS_DATA_, kInfBadDistCode);
+                if (pos + mlen > d.out_cap) INF_FAIL(ZS_BUF_, kInfOutputFull);
+                // one wave: DS operations execute in program order, so lane 0's literal stores are
+                // visible to every lane here without a barrier
+                for (int i = lane; i < mlen; i += 64) {
+                    int srcoff = dist >= mlen ? i : i % dist;
+                    ring[(pos + i) & (kInfRing - 1)] = ring[(pos - dist + srcoff) & (kInfRing - 1)];
+                }
+                pos += mlen;
+            }
+            if (pos - flushed >= kInfRing / 2 + 1024) flush_to(flushed + kInfRing / 2);
+        }
+    }
+    // Adler-32 trailer (Inflate.cs:300-345): compared on the host against the device-computed checksum
+    b.drop(b.cnt & 7);
+    b.fill();
+    if (b.cnt < 32) INF_FAIL(ZS_BUF_, kInfTruncated);
+    {
+        uint32_t a = b.take(8);
+        a = (a << 8) | b.take(8);
+        a = (a << 8) | b.take(8);
+        a = (a << 8) | b.take(8);
+        if (lane == 0) st.adler_stored = a;
+    }
+    status = b.bad ? (int)ZS_BUF_ : (int)ZS_END_;
+    if (b.bad) msg = kInfTruncated;
+done:
+    __syncthreads();
+    if (pos > flushed) {
+        if (pos - flushed > kInfRing / 2) flush_to(flushed + kInfRing / 2);
+        flush_to(pos);
+    }
+    if (lane == 0) {
+        st.out_len = pos;
+        st.in_used = b.pos - (b.cnt >> 3);
+        st.status = status;
+        st.msg = msg;
+    }
+#undef INF_FAIL
+}
+
+constexpr int kInfLds = kInfRing + (int)sizeof(InfTables) + 320 + 320 + 64;
+
+}  // namespace zs
