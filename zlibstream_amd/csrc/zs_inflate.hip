@@ -46,22 +46,47 @@ struct InfTables {
     uint16_t lsym[288], dsym[32];
 };
 
+constexpr int kInfInBuf = 8192;  // LDS window over the compressed bytes [ibase, ibase + kInfInBuf)
 struct InfBits {
     const uint8_t *in;
     int64_t n, pos;  // next byte to load
     uint64_t buf;
     int cnt;
     bool bad;  // a read ran past the end of the input
+    uint8_t *ibuf;
+    int64_t ibase;
+    // every lane calls this (wave-uniform): slide the LDS window so that [pos, pos + 2 KiB) is resident
+    __device__ void stage() {
+        if (pos - ibase < kInfInBuf - 2048 && ibase >= 0) return;
+        const int lane = threadIdx.x & 63;
+        ibase = pos & ~(int64_t)15;
+        for (int o = lane * 16; o < kInfInBuf; o += 64 * 16) {
+            int64_t a = ibase + o;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (a + 16 <= n && ((uintptr_t)in & 15) == 0) {
+                v = *(const uint4 *)(in + a);
+            } else {
+                uint32_t t[4] = {0, 0, 0, 0};
+                for (int k = 0; k < 16; k++)
+                    if (a + k < n) t[k >> 2] |= (uint32_t)in[a + k] << (8 * (k & 3));
+                v = make_uint4(t[0], t[1], t[2], t[3]);
+            }
+            *(uint4 *)(ibuf + o) = v;
+        }
+        __syncthreads();
+    }
     __device__ void fill() {  // top the 64-bit buffer up to >= 56 bits while input lasts
+        stage();
         if (cnt < 56 && pos + 8 <= n) {
-            // one unaligned 8-byte load; bits above the whole bytes taken are re-ORed identically next time
-            buf |= *(const uint64_t __attribute__((aligned(1))) *)(in + pos) << cnt;
+            // one unaligned 8-byte LDS read; bits above the whole bytes taken are re-ORed identically next time
+            buf |= *(const uint64_t __attribute__((aligned(1))) *)(ibuf + (pos - ibase)) << cnt;
             const int adv = (63 - cnt) >> 3;
             pos += adv;
             cnt += adv * 8;
         } else {
             while (cnt <= 56 && pos < n) {
-                buf |= (uint64_t)in[pos++] << cnt;
+                buf |= (uint64_t)ibuf[pos - ibase] << cnt;
+                pos++;
                 cnt += 8;
             }
         }
@@ -142,10 +167,11 @@ __global__ __launch_bounds__(64) void zs_inflate_kernel(const InfDesc *descs, In
     InfTables &T = *(InfTables *)(smem + kInfRing);
     uint8_t *lens = smem + kInfRing + sizeof(InfTables);
     uint8_t *ll = lens + 320;
+    uint8_t *ibuf = ll + 320 + 64;  // 16-byte aligned (kInfRing and sizeof(InfTables) are multiples of 16)
     const int lane = threadIdx.x;
     const InfDesc d = descs[blockIdx.x];
     InfState &st = states[blockIdx.x];
-    InfBits b{d.in, d.in_len, 0, 0, 0, false};
+    InfBits b{d.in, d.in_len, 0, 0, 0, false, ibuf, -1};
     int64_t pos = 0, flushed = 0;
     enum { ZS_OK_ = 0, ZS_END_ = 1, ZS_NEED_DICT_ = 2, ZS_DATA_ = -3, ZS_BUF_ = -5 };
     int status = ZS_OK_, msg = kInfOk;
@@ -200,6 +226,7 @@ __global__ __launch_bounds__(64) void zs_inflate_kernel(const InfDesc *descs, In
             b.pos = src + len;
             b.buf = 0;
             b.cnt = 0;
+            b.ibase = -1;
             continue;
         }
         if (type == 3) INF_FAIL(ZS_DATA_, kInfBadBlockType);
@@ -348,6 +375,7 @@ done:
 #undef INF_FAIL
 }
 
-constexpr int kInfLds = kInfRing + (int)sizeof(InfTables) + 320 + 320 + 64;
+constexpr int kInfLds = kInfRing + (int)sizeof(InfTables) + 320 + 320 + 64 + kInfInBuf + 64;
+static_assert(sizeof(InfTables) % 16 == 0, "LDS carve alignment");
 
 }  // namespace zs
