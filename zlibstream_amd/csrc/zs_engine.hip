@@ -235,7 +235,7 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
                            dev<uint32_t>(c->syms), dev<int32_t>(c->blk_end), dev<int32_t>(c->blk_top), c->crc_tab, lv, strategy,
                            hash_variant);
     mark(9);
-    hipLaunchKernelGGL(zs_tail_kernel, dim3((unsigned)n), dim3(1024), 0, stream, d_sd, d_st, dev<uint16_t>(c->link),
+    hipLaunchKernelGGL(zs_tail_kernel, dim3((unsigned)n), dim3(1024), kTailLds, stream, d_sd, d_st, dev<uint16_t>(c->link),
                        dev<uint32_t>(c->syms), dev<int32_t>(c->blk_end), dev<int32_t>(c->blk_top), dev<BlockRec>(c->blocks),
                        dev<uint8_t>(c->scratch), c->crc_tab, lv, strategy, hash_variant);
     mark(10);
@@ -312,6 +312,7 @@ int zs_ctx_create(int device, zs_ctx **out) {
         hipMemcpy(c->crc_tab, tab.data(), 4096, hipMemcpyHostToDevice) != hipSuccess ||
         hipFuncSetAttribute((const void *)zs_match_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kMatchLds) != hipSuccess ||
         hipFuncSetAttribute((const void *)zs_emit_syms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kEmitLds) != hipSuccess ||
+        hipFuncSetAttribute((const void *)zs_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kTailLds) != hipSuccess ||
         hipFuncSetAttribute((const void *)zs_inflate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kInfLds) != hipSuccess) {
         zs_ctx_destroy(c);
         return ZS_MEM_ERROR;

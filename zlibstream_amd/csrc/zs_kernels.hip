@@ -712,10 +712,12 @@ __global__ __launch_bounds__(1024) void zs_tail_kernel(const StreamDesc *sd, Str
         r.eof = 0;
         blk[i] = r;
     }
+    // window and prev live in LDS (129 KiB: the engine is latency-bound on them), head in HBM scratch
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     LitEngine e;
-    e.window = sc + kScratchWindow;
+    e.window = smem;
     e.head = (uint16_t *)(sc + kScratchHead);
-    e.prev = (uint16_t *)(sc + kScratchPrev);
+    e.prev = (uint16_t *)(smem + kScratchHead);
     uint32_t *head32 = (uint32_t *)(sc + kScratchHead32);
     e.crc_tab = crc_tab_g;
     e.data = s.in;
@@ -760,6 +762,8 @@ __global__ __launch_bounds__(1024) void zs_tail_kernel(const StreamDesc *sd, Str
         ss.nblocks = e.nblocks;
     }
 }
+
+constexpr int kTailLds = (int)kScratchHead + 2 * kWSize;
 
 // ------------------------------------------------------------------ K7
 // One workgroup per block: histogram the block's symbols (Tr_tally_*), then
