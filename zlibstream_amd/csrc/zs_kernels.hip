@@ -211,17 +211,22 @@ __global__ __launch_bounds__(1024) void zs_match_kernel(const StreamDesc *sd, co
         w.best = 2, w.bdist = 0, w.n_eval = 0, w.snapped = 0, w.cl = 0;
         w.scan_end = *(const u32u *)(wb + mine - 1);
     };
-    auto compare8 = [&](Walk &w, int &len, int &adv) {  // phase 2
-        const int off = w.st == 2 ? w.cl : 0;
-        const uint64_t x = *(const u64u *)(wb + w.p + off) ^ *(const u64u *)(wb + w.c + off);
-        if (x) {
-            len = off + (int)(__builtin_ctzll(x) >> 3);
-            len = len > kMaxMatch ? kMaxMatch : len;
-        } else if (off + 8 >= kMaxMatch) {
-            len = kMaxMatch;
-        } else {
-            w.cl = off + 8, w.st = 2, adv = 0;
+    auto compare8 = [&](Walk &w, int &len, int &adv) {  // phase 2: up to 32 bytes per call
+        int off = w.st == 2 ? w.cl : 0;
+        for (int r = 0; r < 4; r++) {
+            const uint64_t x = *(const u64u *)(wb + w.p + off) ^ *(const u64u *)(wb + w.c + off);
+            if (x) {
+                len = off + (int)(__builtin_ctzll(x) >> 3);
+                len = len > kMaxMatch ? kMaxMatch : len;
+                return;
+            }
+            off += 8;
+            if (off >= kMaxMatch) {
+                len = kMaxMatch;
+                return;
+            }
         }
+        w.cl = off, w.st = 2, adv = 0;
     };
     auto finish_step = [&](Walk &w, int l, int len, int adv) {  // phase 3
         const int better = adv & (len > w.best);
