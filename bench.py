@@ -61,6 +61,18 @@ def cpu_baseline(data, level, budget_s=20.0):
                       % (len(sample), level, iters)}, out.raw[:n], len(sample)
 
 
+def pmc_traffic(kernel, args):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/), for the workload they were taken on."""
+    if args.workload != "english64" or args.level != 6 or args.size != 64 << 20:
+        return None
+    pdir = os.path.join(ROOT, "profiles")
+    cands = sorted(f for f in os.listdir(pdir) if "pmc_traffic_english64_L6" in f) if os.path.isdir(pdir) else []
+    if not cands:
+        return None
+    k = json.load(open(os.path.join(pdir, cands[-1])))["kernels"].get(kernel)
+    return k["hbm_bytes_corrected"] if k else None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -68,7 +80,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--level", type=int, default=6)
     ap.add_argument("--size", type=int, default=64 << 20)
-    ap.add_argument("--workload", default="english64", choices=["english64", "sparse64"])
+    ap.add_argument("--workload", default="english64", choices=["english64", "sparse64", "batch"])
+    ap.add_argument("--buffers", type=int, default=128, help="--workload batch: buffers per GPU (1 MiB each by default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -81,19 +94,28 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     if args.workload == "english64":
-        data = datagen.english(args.size, (datagen.GOLDEN + rank) & datagen.MASK)
-    else:
+        datas = [datagen.english(args.size, (datagen.GOLDEN + rank) & datagen.MASK)]
+    elif args.workload == "sparse64":
         side = int((args.size // 4) ** 0.5)
-        data = datagen.sparse(side, args.size // (4 * side), y0=rank)
-    n = len(data)
+        datas = [datagen.sparse(side, args.size // (4 * side), y0=rank)]
+    else:  # BASELINE config 4 shape: independent 1 MiB buffers, even = english, odd = sparse rows
+        if args.size == 64 << 20:
+            args.size = 1 << 20
+        datas = [datagen.batch_buffer(rank * args.buffers + i, args.size) for i in range(args.buffers)]
+    data = datas[0]
+    n = sum(len(d) for d in datas)
     eng = Engine(local_rank)
-    d_in = torch.frombuffer(bytearray(data), dtype=torch.uint8).to(dev)
-    cap = deflate_bound(n)
-    d_out = torch.empty(cap, dtype=torch.uint8, device=dev)
+    d_ins = [torch.frombuffer(bytearray(d), dtype=torch.uint8).to(dev) for d in datas]
+    caps = [deflate_bound(len(d)) for d in datas]
+    d_outs = [torch.empty(c, dtype=torch.uint8, device=dev) for c in caps]
+    d_out = d_outs[0]
     stream = torch.cuda.current_stream().cuda_stream
+    in_ptrs, in_lens, out_ptrs = [t.data_ptr() for t in d_ins], [len(d) for d in datas], [t.data_ptr() for t in d_outs]
+    out_lens = []
 
     def step():
-        return eng.deflate_batch_device([d_in.data_ptr()], [n], [d_out.data_ptr()], [cap], level=args.level, stream=stream)[0]
+        out_lens[:] = eng.deflate_batch_device(in_ptrs, in_lens, out_ptrs, caps, level=args.level, stream=stream)
+        return out_lens[0]
 
     for _ in range(args.warmup):
         out_len = step()
@@ -124,14 +146,18 @@ def main():
     import zlib
     z = d_out[:out_len].cpu().numpy().tobytes()
     assert zlib.decompress(z) == data, "device output does not inflate to the input"
+    for i in range(1, len(datas), max(1, len(datas) // 8)):
+        assert zlib.decompress(d_outs[i][:out_lens[i]].cpu().numpy().tobytes()) == datas[i]
+    total_out = sum(out_lens)
 
     if rank == 0:
         stage_ms = {k: v / args.steps for k, v in stage_sum.items()}
         dom = max(stage_ms, key=stage_ms.get)
-        alg_bytes = n + out_len  # one read of the input + one write of the stream, per buffer
+        alg_bytes = n + total_out  # one read of the input + one write of the stream, per buffer
         achieved = alg_bytes / (stage_ms[dom] * 1e-3) / 1e9
         line = {
-            "metric": "deflate MB/s (input) at level %d, 64 MiB buffers" % args.level,
+            "metric": "deflate MB/s (input) at level %d, %s" % (args.level, "64 MiB buffers" if args.workload != "batch"
+                                                                      else "%d x %d-byte buffers" % (len(datas), args.size)),
             "value": round(world * n * args.steps / dt / 1e6, 2),
             "unit": "MB/s",
             "n_gpus": world,
@@ -143,20 +169,21 @@ def main():
             "vs_baseline": None,
             "dtype": "u8",
             "data": "synthetic",
-            "config": {"workload": "%s: one %d-byte %s buffer per GPU, level %d, zlib framing, inputs resident in HBM"
-                                   % (args.workload, n, "pseudo-random-English (Zipf words of alice29.txt)"
-                                      if args.workload == "english64" else "sparse RGBA image (reference GetImageBytes)", args.level),
-                       "level": args.level, "buffer_bytes": n, "buffers_per_gpu": 1, "compressed_bytes": out_len,
+            "config": {"workload": "%s: %d x %d-byte %s buffer(s) per GPU, level %d, zlib framing, inputs resident in HBM"
+                                   % (args.workload, len(datas), len(data), {"english64": "pseudo-random-English (Zipf words of alice29.txt)",
+                                      "sparse64": "sparse RGBA image (reference GetImageBytes)",
+                                      "batch": "alternating english / sparse-row"}[args.workload], args.level),
+                       "level": args.level, "buffer_bytes": len(data), "buffers_per_gpu": len(datas), "compressed_bytes": total_out,
                        "parallelism": "independent buffers, %d GPU(s), no collective" % world},
             "roofline": {"bound": "hbm", "kernel": "zs_%s_kernel" % dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": pmc_traffic("zs_%s_kernel" % dom, args),
                          "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": round(stage_ms[dom], 4)},
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
         }
         if not args.no_cpu_baseline:
             cb, ref, sample_len = cpu_baseline(data, args.level)
             line["cpu_baseline"] = cb
-            if sample_len == n:
+            if sample_len == n and len(datas) == 1:
                 line["compressed_size_delta_vs_cpu"] = out_len - len(ref)
                 line["bit_identical_to_cpu"] = bool(z == ref)
         print(json.dumps(line))
