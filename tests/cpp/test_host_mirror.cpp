@@ -1,0 +1,106 @@
+// The reference's xunit tests (tests/ZlibStream.Tests/ZlibStreamTests.Roundtrip.cs:25-125), restated against
+// the C++ host mirror (include/zsgpu.hpp) over the C ABI, with the oracle as the byte-level checker.
+// Built and run by tests/test_gpu_parity.py::test_cpp_host_mirror on the GPU box.
+#include <cstdio>
+#include <cstring>
+#include <sstream>
+#include <vector>
+
+#include "../../include/zsgpu.hpp"
+#include "../../oracle/zs_oracle.h"
+
+using namespace SixLabors::ZlibStream;
+
+static std::vector<uint8_t> GetBuffer(int length) {  // new Random(1).NextBytes
+    std::vector<uint8_t> d((size_t)length);
+    zso_dotnet_random_bytes(1, d.data(), d.size());
+    return d;
+}
+static int fails = 0;
+#define CHECK(c)                                              \
+    do {                                                      \
+        if (!(c)) {                                           \
+            printf("FAIL %s:%d %s\n", __FILE__, __LINE__, #c); \
+            fails++;                                          \
+        }                                                     \
+    } while (0)
+
+static std::vector<uint8_t> oracle(const std::vector<uint8_t> &d, int level, int strategy, const std::vector<size_t> &chunks) {
+    std::vector<uint8_t> out(zso_compress_bound(d.size()));
+    size_t n = zso_compress_stream(d.data(), d.size(), chunks.empty() ? nullptr : chunks.data(), chunks.size(), level, strategy, 0, 0,
+                                   out.data(), out.size(), nullptr);
+    out.resize(n);
+    return out;
+}
+
+int main() {
+    const int count = 2 * 4096 * 4, chunk = 2 * 4096;
+    std::vector<uint8_t> expected = GetBuffer(count);
+    const CompressionLevel levels[] = {CompressionLevel::Level1, CompressionLevel::Level2, CompressionLevel::Level3, CompressionLevel::Level4,
+                                       CompressionLevel::Level5, CompressionLevel::Level6, CompressionLevel::Level7,
+                                       CompressionLevel::BestCompression, CompressionLevel::DefaultCompression};
+    const CompressionStrategy strategies[] = {CompressionStrategy::DefaultStrategy, CompressionStrategy::Filtered,
+                                              CompressionStrategy::HuffmanOnly, CompressionStrategy::Fixed};
+    for (CompressionLevel level : levels) {
+        for (CompressionStrategy strategy : strategies) {
+            // EncodeDecode
+            std::stringstream compressed;
+            {
+                ZlibOptions options;
+                options.CompressionLevel_ = level;
+                options.CompressionStrategy_ = strategy;
+                ZlibOutputStream deflate(compressed, options);
+                deflate.Write(expected.data(), 0, (int)expected.size());
+            }
+            std::string z = compressed.str();
+            std::vector<uint8_t> ref = oracle(expected, (int)level, (int)strategy, {});
+            CHECK(z.size() == ref.size() && memcmp(z.data(), ref.data(), ref.size()) == 0);
+            std::vector<uint8_t> actual((size_t)count);
+            ZlibInputStream inflate(compressed);
+            CHECK(inflate.Read(actual.data(), 0, count) == count);
+            CHECK(actual == expected);
+        }
+        // EncodeDecodePerChunk
+        std::stringstream compressed;
+        {
+            ZlibOutputStream deflate(compressed, level);
+            for (int i = 0; i < count; i += chunk) deflate.Write(expected.data(), i, chunk);
+        }
+        std::string z = compressed.str();
+        std::vector<uint8_t> ref = oracle(expected, (int)level, 0, {(size_t)chunk, (size_t)chunk, (size_t)chunk, (size_t)chunk});
+        CHECK(z.size() == ref.size() && memcmp(z.data(), ref.data(), ref.size()) == 0);
+        std::vector<uint8_t> actual((size_t)count);
+        ZlibInputStream inflate(compressed);
+        for (int i = 0; i < count; i += chunk) CHECK(inflate.Read(actual.data(), i, chunk) == chunk);
+        CHECK(actual == expected);
+    }
+    // error behaviour: level 0 is outside the device path -> ZlibStreamException("deflating: ...")
+    try {
+        std::stringstream s;
+        ZlibOutputStream deflate(s, CompressionLevel::NoCompression);
+        deflate.Write(expected.data(), 0, 10);
+        deflate.Dispose();
+        CHECK(!"expected ZlibStreamException");
+    } catch (const ZlibStreamException &e) {
+        CHECK(std::string(e.what()).rfind("deflating: ", 0) == 0);
+    }
+    // corrupt trailer -> "inflating: incorrect data check" (Inflate.cs:339)
+    try {
+        std::stringstream s;
+        {
+            ZlibOutputStream deflate(s, CompressionLevel::Level6);
+            deflate.Write(expected.data(), 0, 1000);
+        }
+        std::string z = s.str();
+        z[z.size() - 1] ^= 1;
+        std::stringstream bad(z);
+        ZlibInputStream inflate(bad);
+        uint8_t b[16];
+        inflate.Read(b, 0, 16);
+        CHECK(!"expected ZlibStreamException");
+    } catch (const ZlibStreamException &e) {
+        CHECK(std::string(e.what()) == "inflating: incorrect data check");
+    }
+    printf(fails ? "FAILED %d\n" : "PASS\n", fails);
+    return fails ? 1 : 0;
+}

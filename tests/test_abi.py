@@ -54,3 +54,8 @@ def test_engine_fails_loudly_without_gpu():
     from zlibstream_amd import Engine
     with pytest.raises(RuntimeError):
         Engine(0)
+
+
+def test_cpp_host_mirror_compiles():
+    import subprocess
+    subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-Wall", os.path.join(ROOT, "tests", "cpp", "test_host_mirror.cpp")], check=True)

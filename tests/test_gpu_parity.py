@@ -258,3 +258,17 @@ def test_inflate_large_device_resident(engine):
     n = engine.inflate_batch_device([d_in.data_ptr()], [len(z)], [d_out.data_ptr()], [len(data)],
                                     stream=torch.cuda.current_stream().cuda_stream)[0]
     assert n == len(data) and d_out.cpu().numpy().tobytes() == data
+
+
+def test_cpp_host_mirror(tmp_path):
+    """The C++ host-side mirror of ZlibOutputStream / ZlibInputStream (include/zsgpu.hpp) replays the reference's
+    EncodeDecode / EncodeDecodePerChunk tests through the C ABI; bytes are checked against the oracle."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "test_host_mirror")
+    subprocess.run(["g++", "-O1", "-std=c++17", "-o", exe, os.path.join(root, "tests/cpp/test_host_mirror.cpp"),
+                    os.path.join(root, "oracle/zs_oracle.c"), os.path.join(root, "oracle/zs_inflate_oracle.c"),
+                    "-L" + os.path.join(root, "zlibstream_amd"), "-lzsgpu", "-Wl,-rpath," + os.path.join(root, "zlibstream_amd")],
+                   check=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "PASS" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
