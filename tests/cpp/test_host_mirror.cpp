@@ -36,11 +36,11 @@ static std::vector<uint8_t> oracle(const std::vector<uint8_t> &d, int level, int
 int main() {
     const int count = 2 * 4096 * 4, chunk = 2 * 4096;
     std::vector<uint8_t> expected = GetBuffer(count);
-    const CompressionLevel levels[] = {CompressionLevel::Level1, CompressionLevel::Level2, CompressionLevel::Level3, CompressionLevel::Level4,
+    const CompressionLevel levels[] = {CompressionLevel::NoCompression, CompressionLevel::Level1, CompressionLevel::Level2, CompressionLevel::Level3, CompressionLevel::Level4,
                                        CompressionLevel::Level5, CompressionLevel::Level6, CompressionLevel::Level7,
                                        CompressionLevel::BestCompression, CompressionLevel::DefaultCompression};
     const CompressionStrategy strategies[] = {CompressionStrategy::DefaultStrategy, CompressionStrategy::Filtered,
-                                              CompressionStrategy::HuffmanOnly, CompressionStrategy::Fixed};
+                                              CompressionStrategy::HuffmanOnly, CompressionStrategy::Rle, CompressionStrategy::Fixed};
     for (CompressionLevel level : levels) {
         for (CompressionStrategy strategy : strategies) {
             // EncodeDecode
@@ -74,12 +74,14 @@ int main() {
         for (int i = 0; i < count; i += chunk) CHECK(inflate.Read(actual.data(), i, chunk) == chunk);
         CHECK(actual == expected);
     }
-    // error behaviour: level 0 is outside the device path -> ZlibStreamException("deflating: ...")
+    // error behaviour: flush modes other than NoFlush / Finish are outside the device path -> ZlibStreamException("deflating: ...")
     try {
         std::stringstream s;
-        ZlibOutputStream deflate(s, CompressionLevel::NoCompression);
+        ZlibOptions options;
+        options.CompressionLevel_ = CompressionLevel::Level6;
+        options.FlushMode_ = FlushMode::SyncFlush;
+        ZlibOutputStream deflate(s, options);
         deflate.Write(expected.data(), 0, 10);
-        deflate.Dispose();
         CHECK(!"expected ZlibStreamException");
     } catch (const ZlibStreamException &e) {
         CHECK(std::string(e.what()).rfind("deflating: ", 0) == 0);

@@ -125,6 +125,7 @@ static void parse_sequential(Model &m, bool on_demand, int64_t &p_out, int &kind
                 int64_t end = st.emit == 1 ? p : p - 1 + st.len;
                 BlockRec b;
                 b.start = block_start;
+                b.sym_start = (int64_t)m.syms.size() - kBlockSyms;
                 b.stored_len = (int32_t)(end - block_start);
                 b.nsyms = kBlockSyms;
                 b.can_store = block_start >= (int64_t)kWSize * k_fired;
@@ -317,6 +318,7 @@ static void parse_chunked(Model &m, int64_t &p_out, int &kind_out, uint32_t &pen
     for (size_t b = 0; b < nb; b++) {
         BlockRec r;
         r.start = bs;
+        r.sym_start = (int64_t)b * kBlockSyms;
         r.stored_len = (int32_t)(blk_end[b] - bs);
         r.nsyms = kBlockSyms;
         int fired = refills_fired_at(blk_top[b], kl);
@@ -356,10 +358,12 @@ static void run_tail(Model &m, int64_t p, int kind, uint32_t pend, int k_done, i
     e.syms = m.syms.data();
     e.nsyms = (int64_t)body_syms;
     size_t body_blocks = m.blocks.size();
-    m.blocks.resize(body_blocks + 8 + (m.body_end < 0 ? (size_t)m.n / 16000 : 0));
+    m.blocks.resize(body_blocks + 8 + (m.body_end < 0 ? (size_t)m.n / 8000 : 0));
     e.blocks = m.blocks.data();
     e.nblocks = (int)body_blocks;
     e.block_start_abs = body_blocks ? m.blocks[body_blocks - 1].start + m.blocks[body_blocks - 1].stored_len : 0;
+    e.block_sym_start = (int64_t)body_blocks * kBlockSyms;
+    e.block_syms = m.level == 0 ? (kLitBufsize / 2) - 1 : kBlockSyms;
     le_restore(e, p, k_done, kind, pend, m.link.data(), preins, 0, 1);
     if (e.avail_end > 0) {
         int64_t lo = p - (kWSize - 1);
@@ -371,8 +375,7 @@ static void run_tail(Model &m, int64_t p, int kind, uint32_t pend, int k_done, i
         }
         le_restore_finish(e, p, m.link.data(), preins);
     }
-    if (m.lv.func == 1) le_run_fast(e, 0, 1);
-    else le_run_slow(e, 0, 1);
+    le_run(e, m.level, 0, 1);
     m.syms.resize((size_t)e.nsyms);
     m.blocks.resize((size_t)e.nblocks);
 }
@@ -395,9 +398,11 @@ static std::vector<uint8_t> emit_stream(Model &m) {
     std::vector<int64_t> sym_off(nb);
     int64_t so = 0;
     for (size_t b = 0; b < nb; b++) {  // K7: one workgroup per block
+        so = m.blocks[b].sym_start;
         sym_off[b] = so;
         TreeWork &w = tw[b];
         memset(&w, 0, sizeof w);
+
         for (int i = 0; i < m.blocks[b].nsyms; i++) {
             uint32_t sy = m.syms[(size_t)(so + i)];
             int dist = (int)(sy >> 16), lc = (int)(sy & 0xFFFF);
@@ -410,6 +415,7 @@ static std::vector<uint8_t> emit_stream(Model &m) {
         w.ltree[kEndBlock].fc = 1;
         so += m.blocks[b].nsyms;
         type[b] = build_block_trees(w, m.blocks[b].stored_len, m.blocks[b].can_store != 0, m.strategy);
+        if (m.level == 0) type[b] = m.blocks[b].can_store ? 0 : 1;
         bits[b] = type[b] == 1 ? 3 + w.static_len : type[b] == 2 ? 3 + w.opt_len : 0;
     }
     int64_t pos = 16;  // after the 2-byte zlib header
@@ -516,7 +522,7 @@ int main(int argc, char **argv) {
     m.crc_tab.resize(1024);
     for (int tt = 0; tt < 4; tt++)
         for (int i = 0; i < 256; i++) m.crc_tab[tt * 256 + i] = crc32c_table_entry(tt, (uint32_t)i);
-    m.body_end = (m.lv.func == 2 && wends.size() <= 1) ? n - kMinLookahead : -1;
+    m.body_end = (m.lv.func == 2 && strategy != kRle && wends.size() <= 1) ? n - kMinLookahead : -1;
     m.wr_end = wends;
     m.build_links();
     int64_t p;

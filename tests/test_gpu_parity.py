@@ -108,13 +108,12 @@ def test_batch_of_ragged_buffers(engine, oracle):
 
 
 # ---- the reference's own tests against the device path (ZlibStreamTests.Roundtrip.cs:25-125) ----
-@pytest.mark.parametrize("level", [CompressionLevel.Level1, CompressionLevel.Level2, CompressionLevel.Level3, CompressionLevel.Level4,
-                                   CompressionLevel.Level5, CompressionLevel.Level6, CompressionLevel.Level7,
+@pytest.mark.parametrize("level", [CompressionLevel.NoCompression, CompressionLevel.Level1, CompressionLevel.Level2, CompressionLevel.Level3,
+                                   CompressionLevel.Level4, CompressionLevel.Level5, CompressionLevel.Level6, CompressionLevel.Level7,
                                    CompressionLevel.BestCompression, CompressionLevel.DefaultCompression])
 def test_encode_decode(engine, oracle, level):
     expected = oracle.dotnet_random(1, 2 * 4096 * 4)
-    for strategy in (CompressionStrategy.DefaultStrategy, CompressionStrategy.Filtered, CompressionStrategy.HuffmanOnly,
-                     CompressionStrategy.Fixed):
+    for strategy in CompressionStrategy:  # all five, like the reference's foreach over Enum.GetValues
         compressed = io.BytesIO()
         with ZlibOutputStream(compressed, ZlibOptions(CompressionLevel=level, CompressionStrategy=strategy), engine=engine) as deflate:
             deflate.write(expected)
@@ -123,7 +122,8 @@ def test_encode_decode(engine, oracle, level):
         assert z == oracle.compress(expected, int(level), int(strategy))
 
 
-@pytest.mark.parametrize("level", [CompressionLevel.Level1, CompressionLevel.Level6, CompressionLevel.BestCompression])
+@pytest.mark.parametrize("level", [CompressionLevel.NoCompression, CompressionLevel.Level1, CompressionLevel.Level6,
+                                   CompressionLevel.BestCompression])
 def test_encode_decode_per_chunk(engine, oracle, level):
     count, chunk = 2 * 4096 * 4, 2 * 4096
     expected = oracle.dotnet_random(1, count)
@@ -139,12 +139,20 @@ def test_encode_decode_per_chunk(engine, oracle, level):
         assert z == oracle.compress(data, int(level), chunks=chunks)   # Write boundaries are read events: bytes depend on them
 
 
+def test_stored_level_and_rle_strategy(engine, oracle):
+    """Level 0 (Deflate.Stored.cs) and CompressionStrategy.Rle (Deflate.Rle.cs) run on the device's literal engine."""
+    for name in ("alice29.txt", "ptt5", "sum"):
+        d = oracle_binding.corpus(name)[:300000]
+        for level, strategy in ((0, 0), (0, 3), (6, 3), (1, 3), (0, 4)):
+            assert engine.deflate_batch([d], level=level, strategy=strategy)[0] == oracle.compress(d, level, strategy), (name, level, strategy)
+    z = engine.deflate_batch([bytes(200000)], level=0, strategy=3)[0]   # level 0 + Rle: static-tree blocks once the block start slid out
+    assert z == oracle.compress(bytes(200000), 0, 3) and len(z) < 2000
+
+
 def test_stream_api_errors_and_unsupported(engine):
-    with pytest.raises(ZlibStreamException):  # level 0 / Rle are outside the device path
-        with ZlibOutputStream(io.BytesIO(), CompressionLevel.NoCompression, engine=engine) as s:
+    with pytest.raises(ZlibStreamException):  # flush modes other than NoFlush / Finish are not on the device path
+        with ZlibOutputStream(io.BytesIO(), ZlibOptions(CompressionLevel=CompressionLevel.Level6, FlushMode=2), engine=engine) as s:
             s.write(b"abc")
-    with pytest.raises(ZlibStreamException):
-        engine.deflate_batch([b"abc"], level=6, strategy=int(CompressionStrategy.Rle))
     with pytest.raises(ValueError):
         ZlibOutputStream(io.BytesIO(), 12, engine=engine)
     s = ZlibOutputStream(io.BytesIO(), CompressionLevel.Level6, engine=engine)

@@ -105,7 +105,7 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
         s.out_cap = out_cap[i];
         s.n = (int32_t)len;
         const bool multi = writes && writes->size() > 1;
-        s.body_end = (lv.func == 2 && len >= kMinLookahead && !multi) ? (int32_t)(len - kMinLookahead) : -1;
+        s.body_end = (lv.func == 2 && strategy != kRle && len >= kMinLookahead && !multi) ? (int32_t)(len - kMinLookahead) : -1;
         s.n_wr = multi ? (int32_t)writes->size() : 1;
         s.wr_end = nullptr;
         s.kl = num_refills(len);
@@ -120,7 +120,7 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
         s.nsegs = num_segs(s.nchunks);
         pl.n_segs += s.nsegs;
         s.blk_off = (int32_t)pl.n_blocks;
-        s.max_blocks = (int32_t)(len / kBlockSyms + 2);
+        s.max_blocks = (int32_t)(level == 0 ? len / 8191 + len / 32506 + 4 : len / kBlockSyms + 2);
         pl.n_blocks += s.max_blocks;
         s.adler_off = (int32_t)pl.n_pieces;
         s.n_adler = (int32_t)((len + kAdlerPiece - 1) / kAdlerPiece);
@@ -237,10 +237,10 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
     mark(9);
     hipLaunchKernelGGL(zs_tail_kernel, dim3((unsigned)n), dim3(1024), kTailLds, stream, d_sd, d_st, dev<uint16_t>(c->link),
                        dev<uint32_t>(c->syms), dev<int32_t>(c->blk_end), dev<int32_t>(c->blk_top), dev<BlockRec>(c->blocks),
-                       dev<uint8_t>(c->scratch), c->crc_tab, lv, strategy, hash_variant);
+                       dev<uint8_t>(c->scratch), c->crc_tab, lv, strategy, hash_variant, level);
     mark(10);
     hipLaunchKernelGGL(zs_trees_kernel, dim3((unsigned)pl.w_blocks.size()), dim3(256), 0, stream, d_sd, d_st, d_work + o_blocks,
-                       dev<uint32_t>(c->syms), dev<BlockRec>(c->blocks), dev<TreeWork>(c->trees), dev<BlockInfo>(c->info), strategy);
+                       dev<uint32_t>(c->syms), dev<BlockRec>(c->blocks), dev<TreeWork>(c->trees), dev<BlockInfo>(c->info), strategy, level);
     mark(11);
     hipLaunchKernelGGL(zs_offsets_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, d_sd, d_st, dev<BlockRec>(c->blocks),
                        dev<BlockInfo>(c->info), dev<uint32_t>(c->pieces), level, n);
@@ -273,11 +273,6 @@ bool check_args(zs_ctx *c, int n, const int64_t *in_len, int level, int strategy
     if (!c) return false;
     if (n < 0 || level < -1 || level > 9 || strategy < 0 || strategy > 4) {
         c->err = "stream error";
-        return false;
-    }
-    if (level == 0 || strategy == ZS_RLE) {
-        // Deflate.Stored.cs / Deflate.Rle.cs are outside the accelerated path (SURVEY.md section 8 f)
-        c->err = "level 0 (stored) and the Rle strategy are not implemented on the device path";
         return false;
     }
     for (int i = 0; i < n; i++)

@@ -696,7 +696,7 @@ __global__ __launch_bounds__(256) void zs_emit_syms_kernel(const StreamDesc *sd,
 __global__ __launch_bounds__(1024) void zs_tail_kernel(const StreamDesc *sd, StreamState *st, const uint16_t *link, uint32_t *syms,
                                                      const int32_t *blk_end, const int32_t *blk_top, BlockRec *blocks,
                                                      uint8_t *scratch, const uint32_t *crc_tab_g, LevelCfg lv, int strategy,
-                                                     int hash_variant) {
+                                                     int hash_variant, int level) {
     const StreamDesc &s = sd[blockIdx.x];
     StreamState &ss = st[blockIdx.x];
     const int tid = threadIdx.x, nth = blockDim.x;  // all threads restore; wave 0 then runs the engine
@@ -711,6 +711,7 @@ __global__ __launch_bounds__(1024) void zs_tail_kernel(const StreamDesc *sd, Str
         int64_t end = blk_end[s.blk_off + i];
         BlockRec r;
         r.start = start;
+        r.sym_start = (int64_t)i * kBlockSyms;
         r.stored_len = (int32_t)(end - start);
         r.nsyms = kBlockSyms;
         r.can_store = start >= (int64_t)kWSize * refills_fired_at(blk_top[s.blk_off + i], s.kl);
@@ -738,6 +739,8 @@ __global__ __launch_bounds__(1024) void zs_tail_kernel(const StreamDesc *sd, Str
     e.blocks = blk;
     e.nblocks = nb_body;
     e.block_start_abs = nb_body ? blk_end[s.blk_off + nb_body - 1] : 0;
+    e.block_sym_start = (int64_t)nb_body * kBlockSyms;
+    e.block_syms = level == 0 ? (kLitBufsize / 2) - 1 : kBlockSyms;
     const uint16_t *lk = link + s.pos_off;
     const int64_t p = ss.tail_p;
     le_restore(e, p, ss.k_done, ss.tail_kind, ss.tail_pend, lk, ss.preins, tid, nth);
@@ -760,8 +763,7 @@ __global__ __launch_bounds__(1024) void zs_tail_kernel(const StreamDesc *sd, Str
     if (tid >= 64) return;  // the engine is one wave, every lane running the same scalar code
     if (e.avail_end > 0) le_restore_finish(e, p, lk, ss.preins);
     __syncthreads();
-    if (lv.func == 1) le_run_fast(e, tid, 64);
-    else le_run_slow(e, tid, 64);
+    le_run(e, level, tid, 64);
     if (tid == 0) {
         ss.nsyms = (uint32_t)e.nsyms;
         ss.nblocks = e.nblocks;
@@ -775,7 +777,7 @@ constexpr int kTailLds = (int)kScratchHead + 2 * kWSize;
 // thread 0 replays Build_tree x3 exactly and picks the block type.
 __global__ __launch_bounds__(256) void zs_trees_kernel(const StreamDesc *sd, const StreamState *st, const uint2 *work,
                                                        const uint32_t *syms, const BlockRec *blocks, TreeWork *trees,
-                                                       BlockInfo *info, int strategy) {
+                                                       BlockInfo *info, int strategy, int level) {
     __shared__ TreeWork tw;
     __shared__ uint32_t hl[kLCodes], hd[kDCodes];
     uint2 w = work[blockIdx.x];
@@ -786,7 +788,7 @@ __global__ __launch_bounds__(256) void zs_trees_kernel(const StreamDesc *sd, con
     for (int i = threadIdx.x; i < kLCodes; i += 256) hl[i] = 0;
     if (threadIdx.x < kDCodes) hd[threadIdx.x] = 0;
     __syncthreads();
-    const uint32_t *sy = syms + s.sym_off + (int64_t)b * kBlockSyms;
+    const uint32_t *sy = syms + s.sym_off + r.sym_start;
     for (int i = threadIdx.x; i < r.nsyms; i += 256) {
         uint32_t v = sy[i];
         int dist = (int)(v >> 16), lc = (int)(v & 0xFFFF);
@@ -810,6 +812,9 @@ __global__ __launch_bounds__(256) void zs_trees_kernel(const StreamDesc *sd, con
     if (threadIdx.x == 0) {
         tw.ltree[kEndBlock].fc = 1;
         int type = build_block_trees(tw, r.stored_len, r.can_store != 0, strategy);
+        // level 0 skips the tree comparison: opt_lenb = static_lenb = stored_len + 5, i.e. stored when the block
+        // start is still in the window, else static trees (Trees.cs:601-620)
+        if (level == 0) type = r.can_store ? 0 : 1;
         BlockInfo bi;
         bi.type = type;
         bi.bits = type == 1 ? 3 + tw.static_len : type == 2 ? 3 + tw.opt_len : 0;
@@ -945,7 +950,7 @@ __global__ __launch_bounds__(256) void zs_emit_bits_kernel(const StreamDesc *sd,
     }
     __syncthreads();
     LdsTree L{lt}, D{dt};
-    const uint32_t *sy = syms + s.sym_off + (int64_t)b * kBlockSyms;
+    const uint32_t *sy = syms + s.sym_off + r.sym_start;
     const int per = (r.nsyms + 255) / 256;
     int i0 = threadIdx.x * per, i1 = i0 + per;
     if (i0 > r.nsyms) i0 = r.nsyms;
@@ -1006,10 +1011,29 @@ __global__ __launch_bounds__(256) void zs_adler_kernel(const StreamDesc *sd, con
     if (lt > 256) lt = 256;
     if (lt < 0) lt = 0;
     uint64_t a = 0, bsum = 0;
-    for (int j = 0; j < lt; j++) {
-        uint64_t d = p[o + j];
-        a += d;
-        bsum += (uint64_t)(lt - j) * d;
+    if (lt == 256 && (((uintptr_t)(p + o)) & 15) == 0) {
+        // 16 x 16-byte loads; within a 16-byte group byte j has weight (256 - 16 g - j)
+        const uint4 *v = (const uint4 *)(p + o);
+#pragma unroll 4
+        for (int g = 0; g < 16; g++) {
+            const uint4 q = v[g];
+            const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+            uint32_t ga = 0, gb = 0;  // sum of the 16 bytes, sum of j * byte
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t b0 = w[k] & 0xFF, b1 = (w[k] >> 8) & 0xFF, b2 = (w[k] >> 16) & 0xFF, b3 = w[k] >> 24;
+                ga += b0 + b1 + b2 + b3;
+                gb += (4 * k) * b0 + (4 * k + 1) * b1 + (4 * k + 2) * b2 + (4 * k + 3) * b3;
+            }
+            a += ga;
+            bsum += (uint64_t)(256 - 16 * g) * ga - gb;
+        }
+    } else {
+        for (int j = 0; j < lt; j++) {
+            uint64_t d = p[o + j];
+            a += d;
+            bsum += (uint64_t)(lt - j) * d;
+        }
     }
     // contribution to the piece's s2: B_t + (len - o - lt) * A_t
     uint64_t tailw = (uint64_t)(len - o - lt);

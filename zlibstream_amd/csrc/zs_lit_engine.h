@@ -32,6 +32,7 @@ namespace zs {
 
 struct BlockRec {
     int64_t start;      // absolute input position of the block's first byte
+    int64_t sym_start;  // index of the block's first symbol in the stream's symbol array
     int32_t stored_len; // bytes covered by the block's symbols
     int32_t nsyms;      // symbols in the block (END_BLOCK not counted)
     int32_t can_store;  // blockStart >= 0 in window coordinates at flush time
@@ -60,6 +61,8 @@ struct LitEngine {
     int64_t avail_end;  // absolute end of the input already copied into the window
     int strstart, lookahead, match_length, match_start, match_available, prev_length, prev_match;
     int64_t block_start_abs;
+    int64_t block_sym_start;  // symbols emitted before the current block
+    int block_syms;           // litBufsize - 1: 16383, or 8191 at level 0 (memLevel 7, Deflate.cs:246-249,298)
     // outputs
     uint32_t *syms;     // symbol i: dist << 16 | lc  (dist 0 = literal)
     int64_t nsyms;      // symbols emitted so far in this stream (body + tail)
@@ -123,10 +126,10 @@ ZS_HD_NOINLINE inline void le_fill_window(LitEngine &e, int lane, int nlanes) {
 // (Deflate.Slow.cs:34-46): with NoFlush the function returns and is re-entered
 // by the next Write, whose input the next Fill_window can then read; after the
 // last Write the Finish call goes on with whatever lookahead is left.
-ZS_HD_NOINLINE inline void le_refill(LitEngine &e, int lane, int nlanes, int &hash_head) {
+ZS_HD_NOINLINE inline void le_refill(LitEngine &e, int lane, int nlanes, int &hash_head, int enough = kMinLookahead) {
     for (;;) {
         le_fill_window(e, lane, nlanes);
-        if (e.lookahead >= kMinLookahead || !e.wr_end || e.cur_wr + 1 >= e.n_wr) break;
+        if (e.lookahead >= enough || !e.wr_end || e.cur_wr + 1 >= e.n_wr) break;
         e.cur_wr++;
         hash_head = 0;  // DeflateSlow's local is reset on every entry (Deflate.Slow.cs:20)
     }
@@ -165,20 +168,22 @@ ZS_HD void le_flush_block(LitEngine &e, bool eof, int lane) {
     if (lane == 0) {
         BlockRec &b = e.blocks[e.nblocks];
         b.start = e.block_start_abs;
+        b.sym_start = e.block_sym_start;
         b.stored_len = (int32_t)(end_abs - e.block_start_abs);
-        b.nsyms = (int32_t)(e.nsyms - (int64_t)e.nblocks * kBlockSyms);
+        b.nsyms = (int32_t)(e.nsyms - e.block_sym_start);
         b.can_store = e.block_start_abs >= e.base;
         b.eof = eof;
     }
     e.nblocks++;
     e.block_start_abs = end_abs;
+    e.block_sym_start = e.nsyms;
 }
 
 // returns true when the block must be flushed (Deflate.cs:910-948)
 ZS_HD bool le_tally(LitEngine &e, int dist, int lc, int lane) {
     if (lane == 0) e.syms[e.nsyms] = ((uint32_t)dist << 16) | (uint32_t)lc;
     e.nsyms++;
-    return (e.nsyms % kBlockSyms) == 0;
+    return (e.nsyms - e.block_sym_start) == e.block_syms;
 }
 
 // Deflate.Slow.cs:18-159 with flush == Finish, run to the end of the stream.
@@ -265,6 +270,72 @@ ZS_HD_NOINLINE inline void le_run_fast(LitEngine &e, int lane, int nlanes) {
         if (bflush) le_flush_block(e, false, lane);
     }
     le_flush_block(e, true, lane);
+}
+
+
+// Deflate.Stored.cs:24-84 (level 0; memLevel 7 -> pending 32 KiB -> max_block_size 32763), flush == Finish.
+ZS_HD_NOINLINE inline void le_run_stored(LitEngine &e, int lane, int nlanes) {
+    const int max_block_size = 32768 - 5;
+    for (;;) {
+        if (e.lookahead <= 1) {
+            int dummy = 0;
+            le_refill(e, lane, nlanes, dummy, 1);  // NoFlush returns only while lookahead == 0
+            if (e.lookahead == 0) break;
+        }
+        e.strstart += e.lookahead;
+        e.lookahead = 0;
+        const int block_start = (int)(e.block_start_abs - e.base);
+        const int max_start = block_start + max_block_size;
+        if (e.strstart == 0 || e.strstart >= max_start) {
+            e.lookahead = e.strstart - max_start;
+            e.strstart = max_start;
+            le_flush_block(e, false, lane);
+        }
+        if (e.strstart - (int)(e.block_start_abs - e.base) >= kMaxDist) le_flush_block(e, false, lane);
+    }
+    le_flush_block(e, true, lane);
+}
+
+// Deflate.Rle.cs:18-104 (CompressionStrategy.Rle), flush == Finish.
+ZS_HD_NOINLINE inline void le_run_rle(LitEngine &e, int lane, int nlanes) {
+    for (;;) {
+        if (e.lookahead <= kMaxMatch) {
+            int dummy = 0;
+            le_refill(e, lane, nlanes, dummy, kMaxMatch + 1);
+        }
+        if (e.lookahead == 0) break;
+        e.match_length = 0;
+        if (e.lookahead >= kMinMatch && e.strstart > 0) {
+            const uint8_t *w = e.window + e.strstart;
+            const uint8_t prev = w[-1];
+            if (prev == w[0] && prev == w[1] && prev == w[2]) {
+                int len = 3;
+                while (len < kMaxMatch && w[len] == prev) len++;
+                e.match_length = len < e.lookahead ? len : e.lookahead;
+            }
+        }
+        bool bflush;
+        if (e.match_length >= kMinMatch) {
+            bflush = le_tally(e, 1, e.match_length - kMinMatch, lane);
+            e.lookahead -= e.match_length;
+            e.strstart += e.match_length;
+            e.match_length = 0;
+        } else {
+            bflush = le_tally(e, 0, e.window[e.strstart], lane);
+            e.lookahead--;
+            e.strstart++;
+        }
+        if (bflush) le_flush_block(e, false, lane);
+    }
+    le_flush_block(e, true, lane);
+}
+
+// the strategy / level dispatch of Deflate.Compress (Deflate.cs:535-558)
+ZS_HD void le_run(LitEngine &e, int level, int lane, int nlanes) {
+    if (e.strategy == kRle) le_run_rle(e, lane, nlanes);
+    else if (level == 0) le_run_stored(e, lane, nlanes);
+    else if (e.lv.func == 1) le_run_fast(e, lane, nlanes);
+    else le_run_slow(e, lane, nlanes);
 }
 
 // Rebuild the reference state at absolute loop-top `p` of a single-Write
