@@ -227,6 +227,7 @@ struct zso_deflate {
     uint64_t bi_buf;
     int bi_valid;
 
+    int overflow; /* the reference would have thrown (see tr_stored_block) */
     /* instrumentation only */
     int64_t abs_base;
     int64_t out_bits;
@@ -559,6 +560,13 @@ static void tr_stored_block(zso_deflate *s, int buf, int stored_len, int eof) {
     send_bits(s, (0u << 1) + (eof ? 1u : 0u), 3);
     bi_windup(s);
     s->last_eob_len = 8;
+    if (s->pending_n + 4 + stored_len > s->pending_size) {
+        /* The reference's Buffer.BlockCopy into PendingBuffer (Deflate.cs:757-761) throws here: a stored
+         * block larger than the pending buffer (only reachable with level 0 + Rle on compressible data,
+         * where a block can span more than 32 KiB while its start is still in the window). */
+        s->overflow = 1;
+        stored_len = 0;
+    }
     put_short_lsb(s, (unsigned)stored_len & 0xFFFF);
     put_short_lsb(s, (unsigned)~stored_len & 0xFFFF);
     if (stored_len > 0) memcpy(s->pending + s->pending_n, s->window + buf, (size_t)stored_len);
@@ -1164,6 +1172,7 @@ size_t zso_compress_stream(const uint8_t *in, size_t n, const size_t *chunk_lens
         produced += got;
         if (state == ZSO_STREAM_END) break;
     } while (s->avail_in > 0 || s->avail_out == 0);
+    if (s->overflow) goto fail;
     zso_deflate_free(s);
     return produced;
 fail:

@@ -262,7 +262,8 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
         out_len[i] = hst[i].out_len;
         if (status) status[i] = hst[i].status;
         if (hst[i].status != 0) {
-            c->err = "buffer error";
+            c->err = hst[i].status == ZS_BUF_ERROR ? "buffer error"
+                                                   : "stored block larger than the reference's pending buffer (the managed engine throws here)";
             return false;
         }
     }

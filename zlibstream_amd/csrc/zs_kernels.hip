@@ -838,11 +838,15 @@ __global__ void zs_offsets_kernel(const StreamDesc *sd, StreamState *st, const B
     const StreamDesc &s = sd[si];
     StreamState &ss = st[si];
     int64_t pos = 16;
+    bool bad = false;
     for (int b = 0; b < ss.nblocks; b++) {
         BlockInfo &bi = info[s.blk_off + b];
         const BlockRec &r = blocks[s.blk_off + b];
         bi.bit_start = pos;
         if (bi.type == 0) {
+            // the reference copies a stored block through its pending buffer (64 KiB; 32 KiB at level 0) and
+            // throws when it does not fit (Deflate.cs:710-722, 757-761): report instead of emitting a stream it cannot produce
+            if (r.stored_len + 5 > (level == 0 ? 32768 : 65536)) bad = true;
             pos += 3;
             pos = (pos + 7) & ~7LL;
             pos += 32 + 8LL * r.stored_len;
@@ -860,6 +864,10 @@ __global__ void zs_offsets_kernel(const StreamDesc *sd, StreamState *st, const B
     ss.adler = ad;
     int64_t total = pos / 8 + 4;
     ss.out_len = total;
+    if (bad) {
+        ss.status = -2;  // ZS_STREAM_ERROR
+        return;
+    }
     if (total > s.out_cap) {
         ss.status = -5;  // ZS_BUF_ERROR
         return;
