@@ -242,7 +242,7 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
     hipLaunchKernelGGL(zs_trees_kernel, dim3((unsigned)pl.w_blocks.size()), dim3(256), 0, stream, d_sd, d_st, d_work + o_blocks,
                        dev<uint32_t>(c->syms), dev<BlockRec>(c->blocks), dev<TreeWork>(c->trees), dev<BlockInfo>(c->info), strategy, level);
     mark(11);
-    hipLaunchKernelGGL(zs_offsets_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, d_sd, d_st, dev<BlockRec>(c->blocks),
+    hipLaunchKernelGGL(zs_offsets_kernel, dim3((unsigned)n), dim3(256), 0, stream, d_sd, d_st, dev<BlockRec>(c->blocks),
                        dev<BlockInfo>(c->info), dev<uint32_t>(c->pieces), level, n);
     mark(12);
     hipLaunchKernelGGL(zs_emit_bits_kernel, dim3((unsigned)pl.w_blocks.size()), dim3(256), 0, stream, d_sd, d_st, d_work + o_blocks,

@@ -35,7 +35,7 @@ __device__ __forceinline__ void load_crc_tab(uint32_t *tab, const uint32_t *g) {
 // ------------------------------------------------------------------ K0
 __global__ void zs_clear_kernel(const StreamDesc *sd, const uint2 *work) {
     uint2 w = work[blockIdx.x];
-    const StreamDesc &s = sd[w.x];
+    const StreamDesc s = sd[w.x];
     int64_t beg = (int64_t)w.y * 65536, end = beg + 65536;
     if (end > s.out_cap) end = s.out_cap;
     uint8_t *o = s.out;
@@ -61,7 +61,7 @@ __global__ __launch_bounds__(64) void zs_links_kernel(const StreamDesc *sd, cons
     __shared__ uint32_t tab[1024];
     const int lane = lane_id();
     uint2 w = work[blockIdx.x];
-    const StreamDesc &s = sd[w.x];
+    const StreamDesc s = sd[w.x];
     const uint8_t *in = s.in;
     const int64_t t0 = (int64_t)w.y * kLinkTile;
     const int64_t qend_stream = (int64_t)s.n - 5;  // positions q with q + 5 < n
@@ -74,24 +74,30 @@ __global__ __launch_bounds__(64) void zs_links_kernel(const StreamDesc *sd, cons
     int64_t tend = t0 + kLinkTile;
     if (tend > qend_stream) tend = qend_stream;
     uint16_t *lk = link + s.pos_off;
-    // software pipeline: the 4 input bytes of the next group are in flight while this one is processed
-    uint32_t vnext = (w0 + lane < tend) ? *(const u32u *)(in + w0 + lane + 2) : 0;
+    // Software pipeline, two groups deep: the 4 input bytes of group g+2 and the bucket of group g+1 are in flight
+    // while group g goes through the head table, so an iteration costs one LDS round trip, not three.
+    auto load4 = [&](int64_t q) -> uint32_t { return q < tend ? *(const u32u *)(in + q + 2) : 0u; };
+    uint32_t v1 = load4(w0 + lane);           // bytes of the group after the current one
+    uint32_t hcur = dev_bucket(tab, v1, hash_variant);
+    v1 = load4(w0 + 64 + lane);
     for (int64_t g = w0; g < tend; g += 64) {
         const int64_t q = g + lane;
         const bool valid = q < tend;
-        const uint32_t vcur = vnext;
-        vnext = (q + 64 < tend) ? *(const u32u *)(in + q + 64 + 2) : 0;
-        uint32_t h = 0xFFFFFFFFu;
-        if (valid) h = dev_bucket(tab, vcur, hash_variant);
+        const uint32_t h = valid ? hcur : 0xFFFFFFFFu;
+        const uint32_t vnext = v1;
+        v1 = load4(q + 128);
+        hcur = dev_bucket(tab, vnext, hash_variant);  // bucket of group g+1: its table reads are issued before the head ops below
         const uint32_t rel = (uint32_t)(q - w0 + 1);  // 1..65280
-        uint32_t prevrel = 0;
+        uint32_t prevrel = 0, rb = 0;
         if (valid) {
-            prevrel = head[h];
-            head[h] = (uint16_t)rel;
+            // lanes of one wave execute DS ops in order: every lane reads the old head before any lane's store, and
+            // the read-back after the stores shows which lane won each bucket
+            // (volatile: other lanes store to the same entry, the read-back must not be forwarded from this lane's store)
+            volatile uint16_t *vh = head;
+            prevrel = vh[h];
+            vh[h] = (uint16_t)rel;
+            rb = vh[h];
         }
-        // lanes of one wave execute DS ops in order: every lane read the old
-        // head before any lane's store; now find the lanes that lost a store race
-        uint32_t rb = valid ? head[h] : 0;
         uint64_t lost = __ballot(valid && rb != rel);
         while (lost) {  // one round per bucket hit by more than one lane
             int leader = __builtin_ctzll(lost);
@@ -125,7 +131,7 @@ __global__ __launch_bounds__(1024) void zs_match_kernel(const StreamDesc *sd, co
     uint8_t *wb = smem;
     uint16_t *wl = (uint16_t *)(smem + kMatchLdsBytes);
     uint2 w = work[blockIdx.x];
-    const StreamDesc &s = sd[w.x];
+    const StreamDesc s = sd[w.x];
     const int64_t t0 = (int64_t)w.y * kMatchTile;
     const int64_t n = s.n;
     if (t0 > s.body_end) return;
@@ -363,7 +369,7 @@ __global__ __launch_bounds__(512) void zs_chunkmap_kernel(const StreamDesc *sd, 
     __shared__ uint32_t tbl[kNodeExit];
     __shared__ uint32_t tab[1024];
     uint2 w = work[blockIdx.x];
-    const StreamDesc &s = sd[w.x];
+    const StreamDesc s = sd[w.x];
     const int c = (int)w.y;
     stage_chunk_matches(s, c, mm, strategy, fk, fk4);
     const ChunkGeo g = chunk_geo(c);
@@ -400,7 +406,7 @@ __global__ __launch_bounds__(512) void zs_chunkmap_kernel(const StreamDesc *sd, 
 __global__ __launch_bounds__(320) void zs_segmap_kernel(const StreamDesc *sd, const uint2 *work, const uint32_t *maps,
                                                         uint2 *segmap) {
     uint2 w = work[blockIdx.x];
-    const StreamDesc &s = sd[w.x];
+    const StreamDesc s = sd[w.x];
     const int seg = (int)w.y;
     int slot = threadIdx.x;
     if (slot >= kSlots) return;
@@ -418,6 +424,7 @@ __global__ __launch_bounds__(320) void zs_segmap_kernel(const StreamDesc *sd, co
     segmap[((int64_t)s.seg_off + seg) * kSlots + entry_slot] = make_uint2((uint32_t)slot | flags, total);
 }
 
+constexpr int kSegBatch = 16;
 // ------------------------------------------------------------------ K4
 // One workgroup per stream.  Thread 0 follows the true parse path through the segment
 // maps (one dependent lookup per 32 Ki positions).  At a refill loop-top s_k whose bucket
@@ -434,7 +441,7 @@ __global__ __launch_bounds__(256) void zs_resolve_kernel(const StreamDesc *sd, S
     __shared__ uint32_t tab[1024];
     __shared__ int sh_seg, sh_slot, sh_scan, sh_kfired, sh_preins;
     __shared__ uint32_t sh_total;
-    const StreamDesc &s = sd[blockIdx.x];
+    const StreamDesc s = sd[blockIdx.x];
     StreamState &ss = st[blockIdx.x];
     load_crc_tab(tab, crc_tab_g);
     if (threadIdx.x == 0) sh_seg = 0, sh_slot = 0, sh_total = 0, sh_kfired = 0, sh_preins = -1, sh_scan = 0;
@@ -447,16 +454,25 @@ __global__ __launch_bounds__(256) void zs_resolve_kernel(const StreamDesc *sd, S
     uint2 *a = mm + s.pos_off;
     GlobalAcc acc{s.in, a, tab, strategy, hash_variant};
     const int nseg = s.nsegs, nch = s.nchunks;
+    __shared__ uint2 rows[kSegBatch * kSlots];  // segment-map rows of the current batch (33 KiB)
+    __shared__ uint8_t row_stale[kSegBatch];
     for (;;) {
-        // ---- thread 0 runs ahead until a refill needs the workgroup (or the end) ----
+        // ---- stage the next kSegBatch segment-map rows (coalesced), then thread 0 follows the path through them;
+        //      it stops early when a refill needs the whole workgroup ----
+        const int seg0 = sh_seg;
+        int nrow = nseg - seg0;
+        if (nrow > kSegBatch) nrow = kSegBatch;
+        for (int i = threadIdx.x; i < nrow * kSlots; i += blockDim.x) rows[i] = segmap[((int64_t)s.seg_off + seg0) * kSlots + i];
+        if (threadIdx.x < nrow) row_stale[threadIdx.x] = seg_stale[s.seg_off + seg0 + threadIdx.x];
+        __syncthreads();
         if (threadIdx.x == 0) {
-            int seg = sh_seg, slot = sh_slot;
+            int seg = seg0, slot = sh_slot;
             uint32_t total = sh_total;
             bool scanned = sh_scan != 0;  // the pending segment's cut has just been applied
             sh_scan = 0;
-            while (seg < nseg) {
+            while (seg < seg0 + nrow) {
                 const int c0 = seg_first_chunk(seg);
-                const uint2 v = segmap[((int64_t)s.seg_off + seg) * kSlots + slot];
+                const uint2 v = rows[(seg - seg0) * kSlots + slot];
                 if (seg >= 1 && seg <= s.kl) {
                     int64_t e = slot <= 256 ? chunk_geo(c0).cs + slot : chunk_geo(c0).cs;
                     if (e <= s.body_end) {
@@ -470,7 +486,7 @@ __global__ __launch_bounds__(256) void zs_resolve_kernel(const StreamDesc *sd, S
                 scanned = false;
                 seg_entry[s.seg_off + seg] = (uint16_t)slot;
                 seg_symbase[s.seg_off + seg] = total;
-                if (seg_stale[s.seg_off + seg]) {
+                if (row_stale[seg - seg0]) {
                     int c1 = seg_first_chunk(seg + 1);
                     if (c1 > nch) c1 = nch;
                     for (int cc = c0; cc < c1; cc++) {
@@ -494,7 +510,10 @@ __global__ __launch_bounds__(256) void zs_resolve_kernel(const StreamDesc *sd, S
             sh_seg = seg, sh_slot = slot, sh_total = total;
         }
         __syncthreads();
-        if (!sh_scan) break;
+        if (!sh_scan) {
+            if (sh_seg >= nseg) break;
+            continue;
+        }
         // ---- equal-bucket refill at the head of segment sh_seg: cut and repair ----
         {
             const int c0 = seg_first_chunk(sh_seg);
@@ -560,7 +579,7 @@ __global__ __launch_bounds__(64) void zs_expand_kernel(const StreamDesc *sd, con
     int i = blockIdx.x * 64 + threadIdx.x;
     if (i >= nwork) return;
     uint2 w = work[i];
-    const StreamDesc &s = sd[w.x];
+    const StreamDesc s = sd[w.x];
     const int seg = (int)w.y;
     GlobalAcc acc{s.in, mm + s.pos_off, crc_tab_g, strategy, hash_variant};
     int slot = seg_entry[s.seg_off + seg];
@@ -629,7 +648,7 @@ __global__ __launch_bounds__(256) void zs_emit_syms_kernel(const StreamDesc *sd,
     uint8_t *lb = (uint8_t *)(cp_idx + (kMaxCheckpoints + 8));  // kChunk + 8
     __shared__ int sh_ncp, sh_cnt;
     uint2 w = work[blockIdx.x];
-    const StreamDesc &s = sd[w.x];
+    const StreamDesc s = sd[w.x];
     const int c = (int)w.y;
     const ChunkGeo g = chunk_geo(c);
     stage_chunk_matches(s, c, mm, strategy, fk, fk4);
@@ -697,7 +716,7 @@ __global__ __launch_bounds__(1024) void zs_tail_kernel(const StreamDesc *sd, Str
                                                      const int32_t *blk_end, const int32_t *blk_top, BlockRec *blocks,
                                                      uint8_t *scratch, const uint32_t *crc_tab_g, LevelCfg lv, int strategy,
                                                      int hash_variant, int level) {
-    const StreamDesc &s = sd[blockIdx.x];
+    const StreamDesc s = sd[blockIdx.x];
     StreamState &ss = st[blockIdx.x];
     const int tid = threadIdx.x, nth = blockDim.x;  // all threads restore; wave 0 then runs the engine
     uint8_t *sc = scratch + (int64_t)blockIdx.x * kScratchBytes;
@@ -781,7 +800,7 @@ __global__ __launch_bounds__(256) void zs_trees_kernel(const StreamDesc *sd, con
     __shared__ TreeWork tw;
     __shared__ uint32_t hl[kLCodes], hd[kDCodes];
     uint2 w = work[blockIdx.x];
-    const StreamDesc &s = sd[w.x];
+    const StreamDesc s = sd[w.x];
     const int b = (int)w.y;
     if (b >= st[w.x].nblocks) return;
     const BlockRec r = blocks[s.blk_off + b];
@@ -828,43 +847,85 @@ __global__ __launch_bounds__(256) void zs_trees_kernel(const StreamDesc *sd, con
 }
 
 // ------------------------------------------------------------------ K8
-// One thread per stream: bit offset of every block (Send_bits is a pure
-// concatenation; stored blocks and the last block align to a byte), zlib
-// header, Adler-32 trailer, total length.
-__global__ void zs_offsets_kernel(const StreamDesc *sd, StreamState *st, const BlockRec *blocks, BlockInfo *info,
-                                  const uint32_t *adler_pieces, int level, int nstreams) {
-    int si = blockIdx.x * blockDim.x + threadIdx.x;
-    if (si >= nstreams) return;
-    const StreamDesc &s = sd[si];
+// One workgroup per stream: bit offset of every block (Send_bits is a pure concatenation; stored blocks and
+// the last block align to a byte), zlib header, Adler-32 trailer, total length.  The scan over blocks is
+// sequential (alignment depends on the absolute bit position) but runs out of LDS; the Adler pieces are
+// combined by a tree.
+__global__ __launch_bounds__(256) void zs_offsets_kernel(const StreamDesc *sd, StreamState *st, const BlockRec *blocks,
+                                                         BlockInfo *info, const uint32_t *adler_pieces, int level, int nstreams) {
+    __shared__ int32_t sh_type[1024], sh_bits[1024], sh_len[1024], sh_eof[1024];
+    __shared__ int64_t sh_start[1024];
+    __shared__ uint32_t ad_v[256];
+    __shared__ uint64_t ad_len[256];
+    __shared__ int64_t sh_pos;
+    __shared__ int sh_bad;
+    const int si = blockIdx.x;
+    const StreamDesc s = sd[si];
     StreamState &ss = st[si];
-    int64_t pos = 16;
-    bool bad = false;
-    for (int b = 0; b < ss.nblocks; b++) {
-        BlockInfo &bi = info[s.blk_off + b];
-        const BlockRec &r = blocks[s.blk_off + b];
-        bi.bit_start = pos;
-        if (bi.type == 0) {
-            // the reference copies a stored block through its pending buffer (64 KiB; 32 KiB at level 0) and
-            // throws when it does not fit (Deflate.cs:710-722, 757-761): report instead of emitting a stream it cannot produce
-            if (r.stored_len + 5 > (level == 0 ? 32768 : 65536)) bad = true;
-            pos += 3;
-            pos = (pos + 7) & ~7LL;
-            pos += 32 + 8LL * r.stored_len;
-        } else {
-            pos += bi.bits;
+    const int nb = ss.nblocks;
+    if (threadIdx.x == 0) sh_pos = 16, sh_bad = 0;
+    __syncthreads();
+    for (int b0 = 0; b0 < nb; b0 += 1024) {
+        int cnt = nb - b0 < 1024 ? nb - b0 : 1024;
+        for (int i = threadIdx.x; i < cnt; i += 256) {
+            const BlockInfo bi = info[s.blk_off + b0 + i];
+            const BlockRec r = blocks[s.blk_off + b0 + i];
+            sh_type[i] = bi.type, sh_bits[i] = bi.bits, sh_len[i] = r.stored_len, sh_eof[i] = r.eof;
         }
-        if (r.eof) pos = (pos + 7) & ~7LL;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int64_t pos = sh_pos;
+            for (int i = 0; i < cnt; i++) {
+                sh_start[i] = pos;
+                if (sh_type[i] == 0) {
+                    // the reference copies a stored block through its pending buffer (64 KiB; 32 KiB at level 0) and throws
+                    // when it does not fit (Deflate.cs:710-722, 757-761): report instead of emitting what it cannot produce
+                    if (sh_len[i] + 5 > (level == 0 ? 32768 : 65536)) sh_bad = 1;
+                    pos += 3;
+                    pos = (pos + 7) & ~7LL;
+                    pos += 32 + 8LL * sh_len[i];
+                } else {
+                    pos += sh_bits[i];
+                }
+                if (sh_eof[i]) pos = (pos + 7) & ~7LL;
+            }
+            sh_pos = pos;
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < cnt; i += 256) info[s.blk_off + b0 + i].bit_start = sh_start[i];
+        __syncthreads();
     }
-    uint32_t ad = 1;
-    for (int i = 0; i < s.n_adler; i++) {
-        int64_t len = (int64_t)s.n - (int64_t)i * kAdlerPiece;
-        if (len > kAdlerPiece) len = kAdlerPiece;
-        ad = adler_combine(ad, adler_pieces[s.adler_off + i], (uint64_t)len);
+    // Adler-32 of the whole input: tree combine of the 64 KiB pieces (adler_combine is associative)
+    uint32_t acc = 1;   // adler of the empty string
+    uint64_t acc_len = 0;
+    {
+        // thread t folds pieces [t*per, (t+1)*per) left to right
+        const int per = (s.n_adler + 255) / 256;
+        for (int k = 0; k < per; k++) {
+            int i = threadIdx.x * per + k;
+            if (i >= s.n_adler) break;
+            int64_t len = (int64_t)s.n - (int64_t)i * kAdlerPiece;
+            if (len > kAdlerPiece) len = kAdlerPiece;
+            acc = adler_combine(acc, adler_pieces[s.adler_off + i], (uint64_t)len);
+            acc_len += (uint64_t)len;
+        }
+        ad_v[threadIdx.x] = acc, ad_len[threadIdx.x] = acc_len;
     }
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        if ((threadIdx.x & (2 * off - 1)) == 0) {
+            ad_v[threadIdx.x] = adler_combine(ad_v[threadIdx.x], ad_v[threadIdx.x + off], ad_len[threadIdx.x + off]);
+            ad_len[threadIdx.x] += ad_len[threadIdx.x + off];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x != 0) return;
+    const uint32_t ad = ad_v[0];
+    const int64_t pos = sh_pos;
     ss.adler = ad;
     int64_t total = pos / 8 + 4;
     ss.out_len = total;
-    if (bad) {
+    if (sh_bad) {
         ss.status = -2;  // ZS_STREAM_ERROR
         return;
     }
@@ -922,7 +983,7 @@ __global__ __launch_bounds__(256) void zs_emit_bits_kernel(const StreamDesc *sd,
     __shared__ uint32_t scan[256];
     __shared__ int64_t sh_body;
     uint2 w = work[blockIdx.x];
-    const StreamDesc &s = sd[w.x];
+    const StreamDesc s = sd[w.x];
     const int b = (int)w.y;
     if (b >= st[w.x].nblocks || st[w.x].status != 0) return;
     const BlockRec r = blocks[s.blk_off + b];
@@ -1008,7 +1069,7 @@ __global__ __launch_bounds__(256) void zs_emit_bits_kernel(const StreamDesc *sd,
 __global__ __launch_bounds__(256) void zs_adler_kernel(const StreamDesc *sd, const uint2 *work, uint32_t *pieces) {
     __shared__ uint64_t ra[256], rb[256];
     uint2 w = work[blockIdx.x];
-    const StreamDesc &s = sd[w.x];
+    const StreamDesc s = sd[w.x];
     int64_t beg = (int64_t)w.y * kAdlerPiece;
     int64_t len = (int64_t)s.n - beg;
     if (len > kAdlerPiece) len = kAdlerPiece;
