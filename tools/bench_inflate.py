@@ -30,6 +30,7 @@ stream = torch.cuda.current_stream().cuda_stream
 def step():
     return eng.inflate_batch_device([z.data_ptr() for z in d_z], z_len, [o.data_ptr() for o in outs], [a.size] * a.streams, stream=stream)
 step()
+eng.set_profiling(True)
 torch.cuda.synchronize(); t0 = time.perf_counter()
 for _ in range(a.steps):
     lens = step()
@@ -37,4 +38,5 @@ torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / a.steps
 ok = all(lens[i] == a.size and torch.equal(outs[i], d_in[i]) for i in range(a.streams))
 print(json.dumps({"metric": "inflate MB/s (output), level-6 streams", "value": round(a.streams * a.size / dt / 1e6, 2), "unit": "MB/s",
                   "streams": a.streams, "bytes_per_stream": a.size, "ms_per_step": round(dt * 1e3, 2), "bit_exact_roundtrip": ok,
-                  "compressed_bytes": sum(z_len), "note": "stream-parallel only: one wave per stream"}))
+                  "compressed_bytes": sum(z_len), "stage_ms": {k: round(v, 3) for k, v in eng.stage_ms().items() if k},
+                  "note": "block-parallel decode (finder + per-block waves + window propagation); includes the Adler-32 check"}))

@@ -11,7 +11,7 @@
 
 #include "../../include/zsgpu.h"
 #include "zs_kernels.hip"
-#include "zs_inflate.hip"
+#include "zs_inflate_par.hip"
 
 using namespace zs;
 
@@ -36,11 +36,13 @@ struct zs_ctx {
     hipStream_t stream = nullptr;
     std::string err;
     bool profiling = false;
+    int last_op = 0;  // 0: deflate stages, 1: block-parallel inflate stages (for zs_ctx_stage_name)
     hipEvent_t ev[kStCount + 1] = {};
     double stage_ms[kStCount] = {};
     uint32_t *crc_tab = nullptr;
     DevBuf sd, st, work, link, mm, maps, segmap, seg_entry, seg_symbase, seg_stale, entry, symbase, stale, syms, blk_end, blk_top, blocks, trees, info, pieces, scratch,
-        stage_in, stage_out, wr, inf_desc, inf_state;
+        stage_in, stage_out, wr, inf_desc, inf_state, par_ps, par_st, par_work, par_cbits, par_ccnt, par_cands, par_blocks, par_cells,
+        par_windows, par_fail;
     void *pinned = nullptr;
     size_t pinned_cap = 0;
 };
@@ -252,6 +254,7 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
     StreamState *hst = (StreamState *)c->pinned;
     ZS_HIP(c, hipMemcpyAsync(hst, d_st, sizeof(StreamState) * (size_t)n, hipMemcpyDeviceToHost, stream));
     ZS_HIP(c, hipStreamSynchronize(stream));
+    c->last_op = 0;
     if (prof)
         for (int i = 0; i < kStCount; i++) {
             float ms = 0;
@@ -321,7 +324,8 @@ void zs_ctx_destroy(zs_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     DevBuf *bufs[] = {&c->sd, &c->st, &c->work, &c->link, &c->mm, &c->maps, &c->segmap, &c->seg_entry, &c->seg_symbase, &c->seg_stale, &c->entry, &c->symbase, &c->stale, &c->syms,
-                      &c->blk_end, &c->blk_top, &c->blocks, &c->trees, &c->info, &c->pieces, &c->scratch, &c->stage_in, &c->stage_out, &c->wr, &c->inf_desc, &c->inf_state};
+                      &c->blk_end, &c->blk_top, &c->blocks, &c->trees, &c->info, &c->pieces, &c->scratch, &c->stage_in, &c->stage_out, &c->wr, &c->inf_desc, &c->inf_state, &c->par_ps, &c->par_st, &c->par_work, &c->par_cbits, &c->par_ccnt,
+                      &c->par_cands, &c->par_blocks, &c->par_cells, &c->par_windows, &c->par_fail};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     if (c->crc_tab) (void)hipFree(c->crc_tab);
@@ -340,7 +344,11 @@ void zs_ctx_set_profiling(zs_ctx *c, int enable) {
     if (c) c->profiling = enable != 0;
 }
 int zs_ctx_stage_count(const zs_ctx *) { return kStCount; }
-const char *zs_ctx_stage_name(const zs_ctx *, int s) { return s >= 0 && s < kStCount ? kStageNames[s] : ""; }
+const char *zs_ctx_stage_name(const zs_ctx *c, int s) {
+    static const char *const inf_names[6] = {"inf_find", "inf_measure", "inf_chain", "inf_decode", "inf_windows", "inf_resolve"};
+    if (c && c->last_op == 1) return s >= 0 && s < 6 ? inf_names[s] : "";
+    return s >= 0 && s < kStCount ? kStageNames[s] : "";
+}
 double zs_ctx_stage_ms(const zs_ctx *c, int s) { return c && s >= 0 && s < kStCount ? c->stage_ms[s] : 0.0; }
 
 int zs_deflate_batch_device(zs_ctx *c, int n, const void *const *in, const int64_t *in_len, void *const *out,
@@ -440,7 +448,7 @@ const char *const kInfMessages[kInfMsgCount] = {
     "incomplete literal/length tree", "oversubscribed distance tree", "incomplete distance tree", "empty distance tree with lengths",
     "invalid literal/length code", "invalid distance code", "buffer error", "buffer error", "incorrect data check"};
 
-bool run_inflate(zs_ctx *c, int n, const void *const *in, const int64_t *in_len, void *const *out, const int64_t *out_cap,
+bool run_inflate_seq(zs_ctx *c, int n, const void *const *in, const int64_t *in_len, void *const *out, const int64_t *out_cap,
                  int64_t *out_len, int *status, hipStream_t stream) {
     std::vector<InfDesc> d((size_t)n);
     for (int i = 0; i < n; i++) d[(size_t)i] = {(const uint8_t *)in[i], (uint8_t *)out[i], in_len[i], out_cap[i]};
@@ -479,6 +487,155 @@ bool run_inflate(zs_ctx *c, int n, const void *const *in, const int64_t *in_len,
         }
     }
     return all_ok;
+}
+
+constexpr int64_t kParMinInput = 256 * 1024;  // shorter streams go straight to the one-wave decoder
+
+// Block-parallel path for the streams listed in `idx`; streams it cannot handle are appended to `rest`.
+bool run_inflate_par(zs_ctx *c, const std::vector<int> &idx, const void *const *in, const int64_t *in_len, void *const *out,
+                     const int64_t *out_cap, int64_t *out_len, int *status, hipStream_t stream, std::vector<int> &rest) {
+    const int m = (int)idx.size();
+    if (m == 0) return true;
+    std::vector<ParStream> ps((size_t)m);
+    int64_t nchunks = 0, ncand = 0, nblk = 0, ncells = 0;
+    std::vector<uint2> w_find;
+    for (int j = 0; j < m; j++) {
+        const int i = idx[(size_t)j];
+        ParStream &p = ps[(size_t)j];
+        p.in = (const uint8_t *)in[i], p.out = (uint8_t *)out[i], p.in_len = in_len[i], p.out_cap = out_cap[i];
+        p.chunk_off = (int32_t)nchunks, p.nchunks = (int32_t)((in_len[i] + kFindChunk - 1) / kFindChunk);
+        nchunks += p.nchunks;
+        p.cand_off = (int32_t)ncand, p.max_cand = (int32_t)(in_len[i] / 1024 + 64);
+        ncand += p.max_cand;
+        p.blk_off = (int32_t)nblk, p.max_blk = (int32_t)(in_len[i] / 256 + 64);
+        nblk += p.max_blk;
+        p.cell_off = ncells;
+        ncells += (out_cap[i] + 63) & ~63LL;
+        for (int k = 0; k < p.nchunks; k++) w_find.push_back(make_uint2((unsigned)j, (unsigned)k));
+    }
+    if (!ensure(c, c->par_ps, sizeof(ParStream) * (size_t)m) || !ensure(c, c->par_st, sizeof(ParState) * (size_t)m) ||
+        !ensure(c, c->par_work, sizeof(uint2) * (size_t)std::max<int64_t>(std::max<int64_t>(nchunks, ncand), nblk) + 64) ||
+        !ensure(c, c->par_cbits, 8 * (size_t)nchunks * kFindMaxCand + 64) || !ensure(c, c->par_ccnt, 4 * (size_t)nchunks + 64) ||
+        !ensure(c, c->par_cands, sizeof(ParCand) * (size_t)ncand) || !ensure(c, c->par_blocks, sizeof(ParBlock) * (size_t)nblk) ||
+        !ensure(c, c->par_cells, 2 * (size_t)ncells + 64) || !ensure(c, c->par_fail, 4 * (size_t)m + 64))
+        return false;
+    std::vector<ParState> st((size_t)m);
+    ZS_HIP(c, hipMemcpyAsync(c->par_ps.p, ps.data(), sizeof(ParStream) * (size_t)m, hipMemcpyHostToDevice, stream));
+    ZS_HIP(c, hipMemcpyAsync(c->par_work.p, w_find.data(), sizeof(uint2) * w_find.size(), hipMemcpyHostToDevice, stream));
+    ZS_HIP(c, hipMemsetAsync(c->par_fail.p, 0, 4 * (size_t)m + 64, stream));
+    ZS_HIP(c, hipStreamSynchronize(stream));  // ps / w_find are pageable
+    const ParStream *d_ps = dev<ParStream>(c->par_ps);
+    ParState *d_st = dev<ParState>(c->par_st);
+    const bool prof = c->profiling;
+    auto mark = [&](int k) {
+        if (prof) (void)hipEventRecord(c->ev[k], stream);
+    };
+    mark(0);
+    hipLaunchKernelGGL(zs_inf_find_kernel, dim3((unsigned)w_find.size()), dim3(256), 0, stream, d_ps, dev<uint2>(c->par_work),
+                       dev<int64_t>(c->par_cbits), dev<int32_t>(c->par_ccnt));
+    hipLaunchKernelGGL(zs_inf_flatten_kernel, dim3((unsigned)((m + 63) / 64)), dim3(64), 0, stream, d_ps, d_st, dev<int64_t>(c->par_cbits),
+                       dev<int32_t>(c->par_ccnt), dev<ParCand>(c->par_cands), m);
+    mark(1);
+    ZS_HIP(c, hipMemcpyAsync(st.data(), d_st, sizeof(ParState) * (size_t)m, hipMemcpyDeviceToHost, stream));
+    ZS_HIP(c, hipStreamSynchronize(stream));
+    std::vector<uint2> w;
+    for (int j = 0; j < m; j++)
+        for (int k = 0; k < st[(size_t)j].ncand; k++) w.push_back(make_uint2((unsigned)j, (unsigned)k));
+    if (!w.empty()) {
+        ZS_HIP(c, hipMemcpyAsync(c->par_work.p, w.data(), sizeof(uint2) * w.size(), hipMemcpyHostToDevice, stream));
+        ZS_HIP(c, hipStreamSynchronize(stream));
+        hipLaunchKernelGGL(zs_inf_measure_kernel, dim3((unsigned)w.size()), dim3(64), 0, stream, d_ps, d_st, dev<uint2>(c->par_work),
+                           dev<ParCand>(c->par_cands));
+    }
+    mark(2);
+    hipLaunchKernelGGL(zs_inf_chain_kernel, dim3((unsigned)m), dim3(64), 0, stream, d_ps, d_st, dev<ParCand>(c->par_cands),
+                       dev<ParBlock>(c->par_blocks));
+    mark(3);
+    ZS_HIP(c, hipMemcpyAsync(st.data(), d_st, sizeof(ParState) * (size_t)m, hipMemcpyDeviceToHost, stream));
+    ZS_HIP(c, hipStreamSynchronize(stream));
+    w.clear();
+    int64_t total_blk = 0;
+    for (int j = 0; j < m; j++)
+        if (st[(size_t)j].ok) {
+            for (int k = 0; k < st[(size_t)j].nblk; k++) w.push_back(make_uint2((unsigned)j, (unsigned)k));
+            total_blk = std::max<int64_t>(total_blk, (int64_t)ps[(size_t)j].blk_off + st[(size_t)j].nblk);
+        }
+    std::vector<int32_t> bfail((size_t)m, 0);
+    if (!w.empty()) {
+        if (!ensure(c, c->par_windows, (size_t)total_blk * kWSize + 64)) return false;
+        ZS_HIP(c, hipMemcpyAsync(c->par_work.p, w.data(), sizeof(uint2) * w.size(), hipMemcpyHostToDevice, stream));
+        ZS_HIP(c, hipStreamSynchronize(stream));
+        hipLaunchKernelGGL(zs_inf_decode_kernel, dim3((unsigned)w.size()), dim3(64), 0, stream, d_ps, d_st, dev<uint2>(c->par_work),
+                           dev<ParBlock>(c->par_blocks), dev<uint16_t>(c->par_cells), dev<int32_t>(c->par_fail));
+        mark(4);
+        hipLaunchKernelGGL(zs_inf_window_kernel, dim3((unsigned)m), dim3(1024), 0, stream, d_ps, d_st, dev<ParBlock>(c->par_blocks),
+                           dev<uint16_t>(c->par_cells), dev<uint8_t>(c->par_windows));
+        mark(5);
+        hipLaunchKernelGGL(zs_inf_resolve_kernel, dim3((unsigned)w.size()), dim3(256), 0, stream, d_ps, d_st, dev<uint2>(c->par_work),
+                           dev<ParBlock>(c->par_blocks), dev<uint16_t>(c->par_cells), dev<uint8_t>(c->par_windows));
+        mark(6);
+        ZS_HIP(c, hipGetLastError());
+        ZS_HIP(c, hipMemcpyAsync(bfail.data(), c->par_fail.p, 4 * (size_t)m, hipMemcpyDeviceToHost, stream));
+        ZS_HIP(c, hipStreamSynchronize(stream));
+        if (prof) {
+            c->last_op = 1;
+            for (double &v : c->stage_ms) v = 0;
+            for (int k = 0; k < 6; k++) {
+                float ms = 0;
+                (void)hipEventElapsedTime(&ms, c->ev[k], c->ev[k + 1]);
+                c->stage_ms[k] = ms;  // stages 0..5 of an inflate call: find, measure, chain, decode, windows, resolve
+            }
+        }
+    }
+    for (int j = 0; j < m; j++) {
+        const int i = idx[(size_t)j];
+        const ParState &q = st[(size_t)j];
+        if (!q.ok || bfail[(size_t)j]) {
+            rest.push_back(i);
+            continue;
+        }
+        // Adler-32 trailer after the last block, byte aligned (Inflate.cs:300-345)
+        const int64_t tb = (q.end_bit + 7) >> 3;
+        if (tb + 4 > in_len[i]) {
+            rest.push_back(i);  // truncated: let the sequential decoder classify it
+            continue;
+        }
+        uint8_t tr[4];
+        ZS_HIP(c, hipMemcpyAsync(tr, (const uint8_t *)in[i] + tb, 4, hipMemcpyDeviceToHost, stream));
+        ZS_HIP(c, hipStreamSynchronize(stream));
+        uint32_t want = ((uint32_t)tr[0] << 24) | ((uint32_t)tr[1] << 16) | ((uint32_t)tr[2] << 8) | tr[3], ad = 1;
+        if (zs_adler32_device(c, out[i], q.out_len, 1, &ad, stream) != ZS_OK) return false;
+        out_len[i] = q.out_len;
+        status[i] = ZS_STREAM_END;
+        if (ad != want) {
+            status[i] = ZS_DATA_ERROR;
+            c->err = kInfMessages[kInfBadCheck];
+        }
+    }
+    return true;
+}
+
+bool run_inflate(zs_ctx *c, int n, const void *const *in, const int64_t *in_len, void *const *out, const int64_t *out_cap,
+                 int64_t *out_len, int *status, hipStream_t stream) {
+    std::vector<int> par, seq;
+    for (int i = 0; i < n; i++) (in_len[i] >= kParMinInput ? par : seq).push_back(i);
+    std::vector<int> st((size_t)n, 0);
+    if (!run_inflate_par(c, par, in, in_len, out, out_cap, out_len, st.data(), stream, seq)) return false;
+    bool ok = true;
+    for (int i : par)
+        if (std::find(seq.begin(), seq.end(), i) == seq.end() && st[(size_t)i] != ZS_STREAM_END) ok = false;
+    if (!seq.empty()) {
+        const int m = (int)seq.size();
+        std::vector<const void *> sin((size_t)m);
+        std::vector<void *> sout((size_t)m);
+        std::vector<int64_t> slen((size_t)m), scap((size_t)m), solen((size_t)m);
+        std::vector<int> sst((size_t)m);
+        for (int j = 0; j < m; j++) sin[(size_t)j] = in[seq[(size_t)j]], sout[(size_t)j] = out[seq[(size_t)j]], slen[(size_t)j] = in_len[seq[(size_t)j]], scap[(size_t)j] = out_cap[seq[(size_t)j]];
+        if (!run_inflate_seq(c, m, sin.data(), slen.data(), sout.data(), scap.data(), solen.data(), sst.data(), stream)) ok = false;
+        for (int j = 0; j < m; j++) out_len[seq[(size_t)j]] = solen[(size_t)j], st[(size_t)seq[(size_t)j]] = sst[(size_t)j];
+    }
+    if (status) memcpy(status, st.data(), sizeof(int) * (size_t)n);
+    return ok;
 }
 }  // namespace
 

@@ -46,7 +46,7 @@ struct InfTables {
     uint16_t lsym[288], dsym[32];
 };
 
-constexpr int kInfInBuf = 8192;  // LDS window over the compressed bytes [ibase, ibase + kInfInBuf)
+constexpr int kInfInBuf = 2048;  // LDS window over the compressed bytes [ibase, ibase + kInfInBuf)
 struct InfBits {
     const uint8_t *in;
     int64_t n, pos;  // next byte to load
@@ -55,9 +55,9 @@ struct InfBits {
     bool bad;  // a read ran past the end of the input
     uint8_t *ibuf;
     int64_t ibase;
-    // every lane calls this (wave-uniform): slide the LDS window so that [pos, pos + 2 KiB) is resident
+    // every lane calls this (wave-uniform): slide the LDS window so that [pos, pos + 64) is resident
     __device__ void stage() {
-        if (pos - ibase < kInfInBuf - 2048 && ibase >= 0) return;
+        if (pos - ibase < kInfInBuf - 64 && ibase >= 0) return;
         const int lane = threadIdx.x & 63;
         ibase = pos & ~(int64_t)15;
         for (int o = lane * 16; o < kInfInBuf; o += 64 * 16) {

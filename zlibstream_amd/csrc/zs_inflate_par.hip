@@ -1,0 +1,572 @@
+// zs_inflate_par.hip -- block-parallel inflate (BASELINE config 5).
+//
+// A deflate stream is bit-serial and every block may reference the 32 KiB before it, so
+// one stream decoded front to back keeps one wave busy (zs_inflate.hip).  This path finds
+// parallelism inside a stream the way pugz / rapidgzip do on CPUs:
+//
+//   F  find     every bit offset at which a *dynamic-Huffman block header* validates
+//               completely (BTYPE, HLIT/HDIST ranges, a complete bit-length code, complete
+//               literal/length and distance codes with an end-of-block code) is a candidate
+//               block start; a random position passes with negligible probability.
+//   D1 measure  one wave per candidate decodes its block without output: end bit offset,
+//               output size, BFINAL, validity.
+//   C  chain    one wave per stream walks from the real first block (bit 16) through the
+//               candidates (end of block i = start of block i+1); blocks the finder cannot
+//               see (stored / fixed) are measured on the spot.  Output offsets follow.
+//   D2 decode   one wave per block decodes again into 16-bit cells: a literal byte, or a
+//               marker 0x8000 | i for "byte i of the 32 KiB window before this block"
+//               (copies of markers stay markers), so blocks decode independently.
+//   W  windows  per stream, block by block: the resolved last 32 KiB after each block.
+//   R  resolve  every cell of every block -> byte, in parallel.
+//
+// Any irregularity (no chain, overflow of a fixed-size table, an undecodable block) makes the
+// host fall back to the sequential kernel for that stream, so the result is always that of
+// a conformant decode (Inflate.cs / InflateBlocks.cs / InfCodes.cs / InfTree.cs).
+#include <hip/hip_runtime.h>
+
+#include "zs_inflate.hip"
+
+namespace zs {
+
+constexpr int kFindChunk = 4096;     // input bytes per finder workgroup
+constexpr int kFindMaxCand = 12;     // candidates kept per chunk
+constexpr int kParMaxBlocks = 1 << 16;
+
+struct ParStream {
+    const uint8_t *in;
+    uint8_t *out;
+    int64_t in_len, out_cap;
+    int32_t chunk_off, nchunks;   // finder chunks
+    int32_t cand_off, max_cand;   // flattened candidate list
+    int32_t blk_off, max_blk;     // chain blocks
+    int64_t cell_off;             // u16 cells of this stream's output
+};
+struct ParCand {
+    int64_t bit;       // block header bit offset
+    int64_t end_bit;   // bit offset after the block's EOB
+    int64_t out_bytes;
+    int32_t bfinal, ok;
+};
+struct ParBlock {
+    int64_t bit, out_off, out_bytes;
+};
+struct ParState {
+    int32_t ncand, nblk;
+    int32_t ok;        // 1: block-parallel path valid for this stream
+    int32_t pad_;
+    int64_t out_len, end_bit;
+};
+
+// ---- shared block decoder (wave-uniform) ----
+// MODE 0: measure only.  MODE 1: write 16-bit cells at o16[0 ..) (block-relative).
+struct BlockOut {
+    int64_t out_bytes, end_bit;
+    int bfinal, err;
+};
+
+__device__ __forceinline__ void inf_seek(InfBits &b, int64_t bit) {
+    b.pos = bit >> 3;
+    b.buf = 0;
+    b.cnt = 0;
+    b.bad = false;
+    b.ibase = -1;
+    b.fill();
+    b.drop((int)(bit & 7));
+}
+__device__ __forceinline__ int64_t inf_tell(const InfBits &b) { return b.pos * 8 - b.cnt; }
+
+__device__ __forceinline__ uint16_t cell_load(const uint16_t *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // L2-coherent read of the wave's own earlier stores
+}
+
+constexpr int kParMaxSyms = 1 << 20;  // no encoder emits blocks this long; bounds the work a false candidate can cause
+
+// abs_off: output position of the block's first byte in the stream (a match may not reach before 0)
+template <int MODE>
+__device__ BlockOut inf_block(InfBits &b, InfTables &T, uint8_t *lens, uint8_t *ll, uint16_t *o16, int64_t max_out, int64_t abs_off = 0) {
+    const int lane = threadIdx.x & 63;
+    BlockOut r{0, 0, 0, 0};
+    b.fill();
+    if (b.cnt < 3) {
+        r.err = 1;
+        return r;
+    }
+    r.bfinal = (int)b.take(1);
+    const unsigned type = b.take(2);
+    int64_t pos = 0;
+    if (type == 3) {
+        r.err = 1;
+        return r;
+    }
+    if (type == 0) {
+        b.drop(b.cnt & 7);
+        b.fill();
+        if (b.cnt < 32) {
+            r.err = 1;
+            return r;
+        }
+        unsigned len = b.take(16), nlen = b.take(16);
+        int64_t src = b.pos - (b.cnt >> 3);
+        if (len != (~nlen & 0xFFFF) || src + len > b.n || (int64_t)len > max_out) {
+            r.err = 1;
+            return r;
+        }
+        if (MODE == 1)
+            for (unsigned i = lane; i < len; i += 64) o16[i] = b.in[src + i];
+        b.pos = src + len;
+        b.buf = 0, b.cnt = 0, b.ibase = -1;
+        r.out_bytes = len;
+        r.end_bit = b.pos * 8;
+        return r;
+    }
+    if (type == 1) {
+        for (int i = lane; i < 288; i += 64) lens[i] = (uint8_t)static_llen(i);
+        __syncthreads();
+        inf_build(lens, 288, T.lit, kInfLitBits, T.lcount, T.lsym);
+        for (int i = lane; i < 32; i += 64) lens[i] = 5;
+        __syncthreads();
+        inf_build(lens, 30, T.dist, kInfDistBits, T.dcount, T.dsym);
+    } else {
+        b.fill();
+        if (b.cnt < 14) {
+            r.err = 1;
+            return r;
+        }
+        const int nlen = (int)b.take(5) + 257, ndist = (int)b.take(5) + 1, ncode = (int)b.take(4) + 4;
+        if (nlen > 286 || ndist > 30) {
+            r.err = 1;
+            return r;
+        }
+        for (int i = lane; i < 320; i += 64) lens[i] = 0;
+        __syncthreads();
+        for (int i = 0; i < ncode; i++) {
+            b.fill();
+            unsigned v = b.take(3);
+            if (lane == 0) lens[bl_order(i)] = (uint8_t)v;
+        }
+        __syncthreads();
+        if (b.bad || inf_build(lens, 19, T.lit, 7, T.lcount, T.lsym) != 0) {
+            r.err = 1;
+            return r;
+        }
+        __syncthreads();
+        uint8_t prev = 0;
+        int idx = 0;
+        while (idx < nlen + ndist) {
+            b.fill();
+            uint16_t e = T.lit[b.peek(7)];
+            if (b.bad || e == kInfEsc || (int)(e & 15) > b.cnt) {
+                r.err = 1;
+                return r;
+            }
+            b.drop(e & 15);
+            int sym = e >> 4;
+            if (sym < 16) {
+                if (lane == 0) ll[idx] = (uint8_t)sym;
+                prev = (uint8_t)sym;
+                idx++;
+            } else {
+                int rep;
+                uint8_t val = 0;
+                if (sym == 16) {
+                    if (idx == 0) {
+                        r.err = 1;
+                        return r;
+                    }
+                    val = prev;
+                    rep = 3 + (int)b.take(2);
+                } else if (sym == 17) {
+                    rep = 3 + (int)b.take(3);
+                } else {
+                    rep = 11 + (int)b.take(7);
+                }
+                if (idx + rep > nlen + ndist) {
+                    r.err = 1;
+                    return r;
+                }
+                if (lane < rep) ll[idx + lane] = val;
+                if (lane + 64 < rep) ll[idx + lane + 64] = val;
+                if (lane + 128 < rep) ll[idx + lane + 128] = val;
+                prev = val;
+                idx += rep;
+            }
+        }
+        __syncthreads();
+        for (int i = lane; i < 320; i += 64) lens[i] = i < nlen + ndist ? ll[i] : 0;
+        __syncthreads();
+        int q = inf_build(lens, nlen, T.lit, kInfLitBits, T.lcount, T.lsym);
+        if (q < 0 || (q > 0 && nlen - T.lcount[0] != 1) || lens[256] == 0) {
+            r.err = 1;
+            return r;
+        }
+        q = inf_build(lens + nlen, ndist, T.dist, kInfDistBits, T.dcount, T.dsym);
+        if (q < 0 || (q > 0 && ndist - T.dcount[0] > 1)) {
+            r.err = 1;
+            return r;
+        }
+    }
+    __syncthreads();
+    for (int nsym = 0;; nsym++) {
+        if (b.bad || nsym > kParMaxSyms) {
+            r.err = 1;
+            return r;
+        }
+        b.fill();
+        int sym, clen;
+        {
+            uint16_t e = T.lit[b.peek(kInfLitBits)];
+            if (e != kInfEsc) sym = e >> 4, clen = e & 15;
+            else sym = inf_slow(b, T.lcount, T.lsym, clen);
+        }
+        if (sym < 0 || clen > b.cnt) {
+            r.err = 1;
+            return r;
+        }
+        b.drop(clen);
+        if (sym < 256) {
+            if (pos >= max_out) {
+                r.err = 2;
+                return r;
+            }
+            if (MODE == 1 && lane == 0) o16[pos] = (uint16_t)sym;
+            pos++;
+        } else if (sym == 256) {
+            break;
+        } else {
+            sym -= 257;
+            if (sym >= 29) {
+                r.err = 1;
+                return r;
+            }
+            const int mlen = (sym == 28 ? 258 : base_length(sym) + 3) + (int)b.take(extra_lbits(sym));
+            b.fill();
+            int ds, dl;
+            {
+                uint16_t e = T.dist[b.peek(kInfDistBits)];
+                if (e != kInfEsc) ds = e >> 4, dl = e & 15;
+                else ds = inf_slow(b, T.dcount, T.dsym, dl);
+            }
+            if (ds < 0 || ds >= 30 || dl > b.cnt) {
+                r.err = 1;
+                return r;
+            }
+            b.drop(dl);
+            const int dist = base_dist(ds) + 1 + (int)b.take(extra_dbits(ds));
+            if (pos + mlen > max_out) {
+                r.err = 2;
+                return r;
+            }
+            if (MODE == 1) {
+                if (abs_off + pos - dist < 0) {  // before the start of the stream: "invalid distance" (InfCodes.cs:294)
+                    r.err = 1;
+                    return r;
+                }
+                // the wave's earlier cell stores must have reached L2 (vmcnt) before they are read back past L1 (sc1 loads)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                for (int i = lane; i < mlen; i += 64) {
+                    const int srcoff = dist >= mlen ? i : i % dist;
+                    const int64_t sp = pos - dist + srcoff;  // block-relative source position
+                    // before the block: byte (32768 + sp) of the window that precedes the block
+                    const uint16_t v = sp >= 0 ? cell_load(o16 + sp) : (uint16_t)(0x8000u | (uint32_t)(kWSize + sp));
+                    o16[pos + i] = v;
+                }
+            }
+            pos += mlen;
+        }
+    }
+    r.out_bytes = pos;
+    r.end_bit = inf_tell(b);
+    return r;
+}
+
+struct ParLds {
+    InfTables T;
+    uint8_t lens[320], ll[320 + 64];
+    uint8_t ibuf[kInfInBuf + 64];
+};
+
+// ------------------------------------------------------------------ F
+// 256 threads per 4 KiB of input; each thread tests the 128 bit offsets of its 16 bytes.
+__device__ bool find_check_header(const uint8_t *in, int64_t n, int64_t bit) {
+    // enough bits for the fixed part: 3 + 14 + 19 * 3 = 74 bits
+    auto bits_at = [&](int64_t bp, int k) -> uint32_t {  // k <= 25
+        int64_t byte = bp >> 3;
+        uint64_t v = 0;
+        for (int i = 0; i < 5; i++)
+            if (byte + i < n) v |= (uint64_t)in[byte + i] << (8 * i);
+        return (uint32_t)((v >> (bp & 7)) & ((1u << k) - 1));
+    };
+    if (bit + 17 > n * 8) return false;
+    const uint32_t h = bits_at(bit, 17);
+    if (((h >> 1) & 3) != 2) return false;
+    const int nlen = (int)((h >> 3) & 31) + 257, ndist = (int)((h >> 8) & 31) + 1, ncode = (int)((h >> 13) & 15) + 4;
+    if (nlen > 286 || ndist > 30) return false;
+    if (bit + 17 + 3 * ncode > n * 8) return false;
+    // bit-length code: must be complete (Kraft sum exactly 1 in units of 2^-7)
+    uint8_t bl[19];
+    for (int i = 0; i < 19; i++) bl[i] = 0;
+    int kraft = 0;
+    for (int i = 0; i < ncode; i++) {
+        int v = (int)bits_at(bit + 17 + 3 * i, 3);
+        bl[bl_order(i)] = (uint8_t)v;
+        if (v) kraft += 128 >> v;
+    }
+    if (kraft != 128) return false;
+    // canonical codes of the bit-length alphabet
+    int count[8] = {0, 0, 0, 0, 0, 0, 0, 0}, next[8];
+    for (int i = 0; i < 19; i++) count[bl[i]]++;
+    count[0] = 0;
+    int code = 0;
+    for (int l = 1; l <= 7; l++) {
+        code = (code + count[l - 1]) << 1;
+        next[l] = code;
+    }
+    uint8_t dec[128];  // 7-bit lookup: sym << 3 | len
+    for (int s = 0; s < 19; s++) {
+        int l = bl[s];
+        if (!l) continue;
+        unsigned rev = bit_reverse((unsigned)next[l]++, l);
+        for (unsigned r2 = rev; r2 < 128; r2 += 1u << l) dec[r2] = (uint8_t)((s << 3) | l);
+    }
+    // decode nlen + ndist code lengths, accumulate Kraft sums of both alphabets (units of 2^-15)
+    int64_t bp = bit + 17 + 3 * ncode;
+    int idx = 0, prev = 0, klit = 0, kdist = 0, nz_dist = 0, eob_len = 0;
+    auto account = [&](int at, int len) {
+        if (!len) return;
+        if (at < nlen) {
+            klit += 32768 >> len;
+            if (at == 256) eob_len = len;
+        } else {
+            kdist += 32768 >> len;
+            nz_dist++;
+        }
+    };
+    while (idx < nlen + ndist) {
+        if (bp + 14 > n * 8) return false;
+        uint32_t w = bits_at(bp, 14);
+        uint8_t e = dec[w & 127];
+        int l = e & 7, s = e >> 3;
+        bp += l;
+        w >>= l;
+        if (s < 16) {
+            account(idx, s);
+            prev = s;
+            idx++;
+        } else {
+            int rep, val = 0;
+            if (s == 16) {
+                if (idx == 0) return false;
+                val = prev;
+                rep = 3 + (int)(w & 3);
+                bp += 2;
+            } else if (s == 17) {
+                rep = 3 + (int)(w & 7);
+                bp += 3;
+            } else {
+                rep = 11 + (int)(w & 127);
+                bp += 7;
+            }
+            if (idx + rep > nlen + ndist) return false;
+            for (int k = 0; k < rep; k++) account(idx + k, val);
+            prev = val;
+            idx += rep;
+        }
+    }
+    if (!eob_len) return false;
+    if (klit != 32768) return false;                       // an encoder's literal/length code is complete
+    if (!(kdist == 32768 || nz_dist <= 1)) return false;  // distance code: complete, or at most one code
+    return true;
+}
+
+__global__ __launch_bounds__(256) void zs_inf_find_kernel(const ParStream *ps, const uint2 *work, int64_t *cand_bits, int32_t *cand_cnt) {
+    __shared__ int64_t found[kFindMaxCand];
+    __shared__ int nfound;
+    const uint2 w = work[blockIdx.x];
+    const ParStream s = ps[w.x];
+    const int chunk = (int)w.y;
+    if (threadIdx.x == 0) nfound = 0;
+    __syncthreads();
+    const int64_t byte0 = (int64_t)chunk * kFindChunk + (int64_t)threadIdx.x * 16;
+    for (int k = 0; k < 128; k++) {
+        const int64_t bit = byte0 * 8 + k;
+        if (bit < 16 || bit + 17 > s.in_len * 8) continue;
+        // cheap prefilter on the first 13 header bits before the full check
+        const int64_t by = bit >> 3;
+        uint32_t v = (uint32_t)s.in[by] | ((by + 1 < s.in_len ? (uint32_t)s.in[by + 1] : 0u) << 8) |
+                     ((by + 2 < s.in_len ? (uint32_t)s.in[by + 2] : 0u) << 16);
+        v >>= (bit & 7);
+        if (((v >> 1) & 3) != 2 || ((v >> 3) & 31) > 29 || ((v >> 8) & 31) > 29) continue;
+        if (find_check_header(s.in, s.in_len, bit)) {
+            int at = atomicAdd(&nfound, 1);
+            if (at < kFindMaxCand) found[at] = bit;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int n = nfound < kFindMaxCand ? nfound : kFindMaxCand;
+        for (int i = 1; i < n; i++) {  // insertion sort: a handful of entries
+            int64_t v = found[i];
+            int j = i - 1;
+            while (j >= 0 && found[j] > v) found[j + 1] = found[j], j--;
+            found[j + 1] = v;
+        }
+        const int64_t base = ((int64_t)s.chunk_off + chunk) * kFindMaxCand;
+        for (int i = 0; i < n; i++) cand_bits[base + i] = found[i];
+        cand_cnt[s.chunk_off + chunk] = nfound;  // > kFindMaxCand flags an overflow
+    }
+}
+
+// flatten the per-chunk lists into one ordered list per stream (one thread per stream)
+__global__ void zs_inf_flatten_kernel(const ParStream *ps, ParState *st, const int64_t *cand_bits, const int32_t *cand_cnt, ParCand *cands,
+                                      int nstreams) {
+    int si = blockIdx.x * blockDim.x + threadIdx.x;
+    if (si >= nstreams) return;
+    const ParStream s = ps[si];
+    int n = 0, ok = 1;
+    for (int c = 0; c < s.nchunks && ok; c++) {
+        int k = cand_cnt[s.chunk_off + c];
+        if (k > kFindMaxCand) ok = 0;
+        for (int i = 0; i < k && i < kFindMaxCand; i++) {
+            if (n >= s.max_cand) {
+                ok = 0;
+                break;
+            }
+            ParCand &d = cands[s.cand_off + n++];
+            d.bit = cand_bits[((int64_t)s.chunk_off + c) * kFindMaxCand + i];
+            d.end_bit = 0, d.out_bytes = 0, d.bfinal = 0, d.ok = 0;
+        }
+    }
+    st[si].ncand = n;
+    st[si].ok = ok;
+    st[si].nblk = 0;
+    st[si].out_len = 0;
+    st[si].end_bit = 0;
+}
+
+// ------------------------------------------------------------------ D1
+__global__ __launch_bounds__(64) void zs_inf_measure_kernel(const ParStream *ps, const ParState *st, const uint2 *work, ParCand *cands) {
+    __shared__ ParLds L;
+    const uint2 w = work[blockIdx.x];
+    const ParStream s = ps[w.x];
+    if ((int)w.y >= st[w.x].ncand) return;
+    ParCand &c = cands[s.cand_off + w.y];
+    InfBits b{s.in, s.in_len, 0, 0, 0, false, L.ibuf, -1};
+    inf_seek(b, c.bit);
+    BlockOut r = inf_block<0>(b, L.T, L.lens, L.ll, nullptr, (int64_t)1 << 40);
+    if (threadIdx.x == 0) {
+        c.end_bit = r.end_bit;
+        c.out_bytes = r.out_bytes;
+        c.bfinal = r.bfinal;
+        c.ok = r.err == 0;
+    }
+}
+
+// ------------------------------------------------------------------ C
+__global__ __launch_bounds__(64) void zs_inf_chain_kernel(const ParStream *ps, ParState *st, const ParCand *cands, ParBlock *blocks) {
+    __shared__ ParLds L;
+    const ParStream s = ps[blockIdx.x];
+    ParState &ss = st[blockIdx.x];
+    if (!ss.ok) return;
+    const ParCand *cd = cands + s.cand_off;
+    ParBlock *bl = blocks + s.blk_off;
+    const int ncand = ss.ncand;
+    int64_t cur = 16, out = 0;
+    int nb = 0, ok = 1, ci = 0;
+    // zlib header (Inflate.cs:120-170): anything unusual goes to the sequential decoder, which reports it
+    if (s.in_len < 6 || (s.in[0] & 0x0F) != 8 || (s.in[0] >> 4) > 7 || (((unsigned)s.in[0] << 8) + s.in[1]) % 31 != 0 || (s.in[1] & 0x20)) ok = 0;
+    InfBits b{s.in, s.in_len, 0, 0, 0, false, L.ibuf, -1};
+    while (ok) {
+        while (ci < ncand && cd[ci].bit < cur) ci++;
+        int64_t end, nbytes;
+        int bfinal;
+        if (ci < ncand && cd[ci].bit == cur && cd[ci].ok) {
+            end = cd[ci].end_bit, nbytes = cd[ci].out_bytes, bfinal = cd[ci].bfinal;
+        } else {
+            // a block the finder does not report (stored / fixed codes): measure it here
+            inf_seek(b, cur);
+            BlockOut r = inf_block<0>(b, L.T, L.lens, L.ll, nullptr, (int64_t)1 << 40);
+            if (r.err) {
+                ok = 0;
+                break;
+            }
+            end = r.end_bit, nbytes = r.out_bytes, bfinal = r.bfinal;
+        }
+        if (nb >= s.max_blk || out + nbytes > s.out_cap) {
+            ok = 0;
+            break;
+        }
+        if (threadIdx.x == 0) bl[nb] = {cur, out, nbytes};
+        nb++;
+        out += nbytes;
+        cur = end;
+        if (bfinal) break;
+    }
+    if (threadIdx.x == 0) {
+        ss.ok = ok;
+        ss.nblk = nb;
+        ss.out_len = out;
+        ss.end_bit = cur;
+    }
+}
+
+// ------------------------------------------------------------------ D2
+__global__ __launch_bounds__(64) void zs_inf_decode_kernel(const ParStream *ps, const ParState *st, const uint2 *work, const ParBlock *blocks,
+                                                           uint16_t *cells, int32_t *fail) {
+    __shared__ ParLds L;
+    const uint2 w = work[blockIdx.x];
+    const ParStream s = ps[w.x];
+    if (!st[w.x].ok || (int)w.y >= st[w.x].nblk) return;
+    const ParBlock k = blocks[s.blk_off + w.y];
+    InfBits b{s.in, s.in_len, 0, 0, 0, false, L.ibuf, -1};
+    inf_seek(b, k.bit);
+    BlockOut r = inf_block<1>(b, L.T, L.lens, L.ll, cells + s.cell_off + k.out_off, k.out_bytes, k.out_off);
+    if (threadIdx.x == 0 && (r.err || r.out_bytes != k.out_bytes)) fail[w.x] = 1;
+}
+
+// ------------------------------------------------------------------ W
+// One workgroup per stream, block by block: win[k] = the 32 KiB of resolved output that end with block k.
+__global__ __launch_bounds__(1024) void zs_inf_window_kernel(const ParStream *ps, const ParState *st, const ParBlock *blocks,
+                                                             const uint16_t *cells, uint8_t *windows) {
+    const ParStream s = ps[blockIdx.x];
+    const ParState ss = st[blockIdx.x];
+    if (!ss.ok) return;
+    const uint16_t *cl = cells + s.cell_off;
+    uint8_t *win = windows + (int64_t)s.blk_off * kWSize;
+    for (int k = 0; k < ss.nblk; k++) {
+        const ParBlock bk = blocks[s.blk_off + k];
+        const uint8_t *pw = k ? win + (int64_t)(k - 1) * kWSize : nullptr;  // window before block k
+        uint8_t *cw = win + (int64_t)k * kWSize;
+        const int64_t end = bk.out_off + bk.out_bytes;
+        for (int i = threadIdx.x; i < kWSize; i += 1024) {
+            const int64_t p = end - kWSize + i;  // absolute output position of window byte i
+            uint8_t v = 0;
+            if (p >= bk.out_off) {
+                const uint16_t c = cl[p];
+                v = (c & 0x8000) ? (pw ? pw[c & 0x7FFF] : 0) : (uint8_t)c;
+            } else if (p >= 0) {
+                v = pw ? pw[i + bk.out_bytes] : 0;  // p = (end_prev - 32768) + (i + out_bytes)
+            }
+            cw[i] = v;
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------ R
+__global__ __launch_bounds__(256) void zs_inf_resolve_kernel(const ParStream *ps, const ParState *st, const uint2 *work, const ParBlock *blocks,
+                                                             const uint16_t *cells, const uint8_t *windows) {
+    const uint2 w = work[blockIdx.x];
+    const ParStream s = ps[w.x];
+    if (!st[w.x].ok || (int)w.y >= st[w.x].nblk) return;
+    const ParBlock k = blocks[s.blk_off + w.y];
+    const uint8_t *pw = w.y ? windows + ((int64_t)s.blk_off + w.y - 1) * kWSize : nullptr;
+    const uint16_t *cl = cells + s.cell_off + k.out_off;
+    uint8_t *o = s.out + k.out_off;
+    for (int64_t i = threadIdx.x; i < k.out_bytes; i += 256) {
+        const uint16_t c = cl[i];
+        o[i] = (c & 0x8000) ? (pw ? pw[c & 0x7FFF] : 0) : (uint8_t)c;
+    }
+}
+
+}  // namespace zs
