@@ -30,6 +30,7 @@ namespace zs {
 
 constexpr int kFindChunk = 4096;     // input bytes per finder workgroup
 constexpr int kFindMaxCand = 12;     // candidates kept per chunk
+constexpr int kFindMaxSurv = 2048;   // prefilter survivors per chunk (32768 bit offsets; ~0.5 % survive on random data)
 constexpr int kParMaxBlocks = 1 << 16;
 
 struct ParStream {
@@ -287,13 +288,18 @@ struct ParLds {
 
 // ------------------------------------------------------------------ F
 // 256 threads per 4 KiB of input; each thread tests the 128 bit offsets of its 16 bytes.
-__device__ bool find_check_header(const uint8_t *in, int64_t n, int64_t bit) {
-    // enough bits for the fixed part: 3 + 14 + 19 * 3 = 74 bits
+// `dec`: 128 bytes of LDS private to the calling thread (a runtime-indexed private array would be kept in
+// registers and indexed through select chains -- hundreds of instructions per access).
+__device__ bool find_check_header(const uint8_t *in, int64_t n, int64_t bit, uint8_t *dec) {
     auto bits_at = [&](int64_t bp, int k) -> uint32_t {  // k <= 25
         int64_t byte = bp >> 3;
         uint64_t v = 0;
-        for (int i = 0; i < 5; i++)
-            if (byte + i < n) v |= (uint64_t)in[byte + i] << (8 * i);
+        if (byte + 8 <= n) {
+            v = *(const uint64_t __attribute__((aligned(1))) *)(in + byte);
+        } else {
+            for (int i = 0; i < 5; i++)
+                if (byte + i < n) v |= (uint64_t)in[byte + i] << (8 * i);
+        }
         return (uint32_t)((v >> (bp & 7)) & ((1u << k) - 1));
     };
     if (bit + 17 > n * 8) return false;
@@ -302,31 +308,31 @@ __device__ bool find_check_header(const uint8_t *in, int64_t n, int64_t bit) {
     const int nlen = (int)((h >> 3) & 31) + 257, ndist = (int)((h >> 8) & 31) + 1, ncode = (int)((h >> 13) & 15) + 4;
     if (nlen > 286 || ndist > 30) return false;
     if (bit + 17 + 3 * ncode > n * 8) return false;
-    // bit-length code: must be complete (Kraft sum exactly 1 in units of 2^-7)
-    uint8_t bl[19];
-    for (int i = 0; i < 19; i++) bl[i] = 0;
+    // bit-length code lengths, packed 3 bits per symbol; per-length counters packed 8 bits per length
+    uint64_t bl = 0, cnt = 0;
     int kraft = 0;
     for (int i = 0; i < ncode; i++) {
-        int v = (int)bits_at(bit + 17 + 3 * i, 3);
-        bl[bl_order(i)] = (uint8_t)v;
-        if (v) kraft += 128 >> v;
+        const uint64_t v = bits_at(bit + 17 + 3 * i, 3);
+        bl |= v << (3 * bl_order(i));
+        if (v) kraft += 128 >> v, cnt += 1ull << (8 * v);
     }
     if (kraft != 128) return false;
-    // canonical codes of the bit-length alphabet
-    int count[8] = {0, 0, 0, 0, 0, 0, 0, 0}, next[8];
-    for (int i = 0; i < 19; i++) count[bl[i]]++;
-    count[0] = 0;
-    int code = 0;
-    for (int l = 1; l <= 7; l++) {
-        code = (code + count[l - 1]) << 1;
-        next[l] = code;
+    // canonical codes: next[l] packed 8 bits per length (codes of length <= 7 are < 128)
+    uint64_t next = 0;
+    {
+        int code = 0;
+        for (int l = 1; l <= 7; l++) {
+            code = (code + (int)((cnt >> (8 * (l - 1))) & 0xFF) * (l > 1)) << 1;
+            next |= (uint64_t)(code & 0xFF) << (8 * l);
+        }
     }
-    uint8_t dec[128];  // 7-bit lookup: sym << 3 | len
-    for (int s = 0; s < 19; s++) {
-        int l = bl[s];
+    for (int sy = 0; sy < 19; sy++) {
+        const int l = (int)((bl >> (3 * sy)) & 7);
         if (!l) continue;
-        unsigned rev = bit_reverse((unsigned)next[l]++, l);
-        for (unsigned r2 = rev; r2 < 128; r2 += 1u << l) dec[r2] = (uint8_t)((s << 3) | l);
+        const unsigned code = (unsigned)((next >> (8 * l)) & 0xFF);
+        next += 1ull << (8 * l);
+        const unsigned rev = bit_reverse(code, l);
+        for (unsigned r2 = rev; r2 < 128; r2 += 1u << l) dec[r2] = (uint8_t)((sy << 3) | l);
     }
     // decode nlen + ndist code lengths, accumulate Kraft sums of both alphabets (units of 2^-15)
     int64_t bp = bit + 17 + 3 * ncode;
@@ -342,6 +348,7 @@ __device__ bool find_check_header(const uint8_t *in, int64_t n, int64_t bit) {
         }
     };
     while (idx < nlen + ndist) {
+        if (klit > 32768 || kdist > 32768) return false;  // oversubscribed already: random data dies here within a few symbols
         if (bp + 14 > n * 8) return false;
         uint32_t w = bits_at(bp, 14);
         uint8_t e = dec[w & 127];
@@ -380,29 +387,75 @@ __device__ bool find_check_header(const uint8_t *in, int64_t n, int64_t bit) {
 
 __global__ __launch_bounds__(256) void zs_inf_find_kernel(const ParStream *ps, const uint2 *work, int64_t *cand_bits, int32_t *cand_cnt) {
     __shared__ int64_t found[kFindMaxCand];
-    __shared__ int nfound;
+    __shared__ int nfound, nsurv;
+    __shared__ int32_t surv[kFindMaxSurv];  // bit offsets (chunk-relative) that passed the register prefilter
+    __shared__ uint8_t dec_lds[256 * 128];   // one 7-bit decode table per thread for the full header check
     const uint2 w = work[blockIdx.x];
     const ParStream s = ps[w.x];
     const int chunk = (int)w.y;
-    if (threadIdx.x == 0) nfound = 0;
+    if (threadIdx.x == 0) nfound = 0, nsurv = 0;
     __syncthreads();
+    // the thread's 16 bytes plus the 16 that follow, as four 64-bit words (zero past the end of the stream)
     const int64_t byte0 = (int64_t)chunk * kFindChunk + (int64_t)threadIdx.x * 16;
-    for (int k = 0; k < 128; k++) {
-        const int64_t bit = byte0 * 8 + k;
-        if (bit < 16 || bit + 17 > s.in_len * 8) continue;
-        // cheap prefilter on the first 13 header bits before the full check
-        const int64_t by = bit >> 3;
-        uint32_t v = (uint32_t)s.in[by] | ((by + 1 < s.in_len ? (uint32_t)s.in[by + 1] : 0u) << 8) |
-                     ((by + 2 < s.in_len ? (uint32_t)s.in[by + 2] : 0u) << 16);
-        v >>= (bit & 7);
-        if (((v >> 1) & 3) != 2 || ((v >> 3) & 31) > 29 || ((v >> 8) & 31) > 29) continue;
-        if (find_check_header(s.in, s.in_len, bit)) {
+    // 32 bytes as eight 32-bit words (64-bit shifts are quarter rate; v_alignbit_b32 is full rate)
+    uint32_t bw[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (byte0 + 32 <= s.in_len && (((uintptr_t)(s.in + byte0)) & 15) == 0) {
+        const uint4 *p16 = (const uint4 *)(s.in + byte0);
+        const uint4 u = p16[0], v = p16[1];
+        bw[0] = u.x, bw[1] = u.y, bw[2] = u.z, bw[3] = u.w, bw[4] = v.x, bw[5] = v.y, bw[6] = v.z, bw[7] = v.w;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 32; k++) {
+            const int64_t a = byte0 + k;
+            if (a < s.in_len) bw[k >> 2] |= (uint32_t)s.in[a] << (8 * (k & 3));
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {  // compile-time word index: bw[] stays in registers
+        const uint32_t c0 = bw[j], c1 = bw[j + 1], c2 = bw[j + 2], c3 = bw[j + 3];
+        for (int r = 0; r < 32; r++) {
+            const int64_t bit = byte0 * 8 + j * 32 + r;
+            if (bit < 16 || bit + 17 > s.in_len * 8) continue;
+            // 96 bits starting at bit offset r of (c0, c1, c2, c3)
+            const uint32_t x0 = __builtin_amdgcn_alignbit(c1, c0, r), x1 = __builtin_amdgcn_alignbit(c2, c1, r),
+                           x2 = __builtin_amdgcn_alignbit(c3, c2, r);
+            // BTYPE == 2, HLIT <= 29, HDIST <= 29
+            if (((x0 >> 1) & 3) != 2 || ((x0 >> 3) & 31) > 29 || ((x0 >> 8) & 31) > 29) continue;
+            // bit-length code lengths: (HCLEN + 4) 3-bit fields from bit 17; the code must be complete (Kraft sum 1)
+            const int ncode = (int)((x0 >> 13) & 15) + 4;
+            uint32_t g0 = (x0 >> 17) | (x1 << 15);  // bits 17..48: fields 0..9
+            uint32_t g1 = (x1 >> 15) | (x2 << 17);  // bits 47..78: fields 10..18
+            int kraft = 0;
+#pragma unroll
+            for (int i = 0; i < 10; i++) {
+                const int v = (int)(g0 & 7);
+                g0 >>= 3;
+                kraft += (i < ncode && v) ? 128 >> v : 0;
+            }
+#pragma unroll
+            for (int i = 10; i < 19; i++) {
+                const int v = (int)(g1 & 7);
+                g1 >>= 3;
+                kraft += (i < ncode && v) ? 128 >> v : 0;
+            }
+            if (kraft != 128) continue;
+            int at = atomicAdd(&nsurv, 1);
+            if (at < kFindMaxSurv) surv[at] = (int32_t)(bit - (int64_t)chunk * kFindChunk * 8);
+        }
+    }
+    __syncthreads();
+    // full header check of the survivors, one per thread (instead of one lane of a wave at a time)
+    const int ns = nsurv < kFindMaxSurv ? nsurv : kFindMaxSurv;
+    for (int i = threadIdx.x; i < ns; i += 256) {
+        const int64_t bit = (int64_t)chunk * kFindChunk * 8 + surv[i];
+        if (find_check_header(s.in, s.in_len, bit, dec_lds + threadIdx.x * 128)) {
             int at = atomicAdd(&nfound, 1);
             if (at < kFindMaxCand) found[at] = bit;
         }
     }
     __syncthreads();
     if (threadIdx.x == 0) {
+        if (nsurv > kFindMaxSurv) nfound = kFindMaxCand + 1;  // survivor list overflow: give the stream to the sequential decoder
         int n = nfound < kFindMaxCand ? nfound : kFindMaxCand;
         for (int i = 1; i < n; i++) {  // insertion sort: a handful of entries
             int64_t v = found[i];
@@ -525,31 +578,45 @@ __global__ __launch_bounds__(64) void zs_inf_decode_kernel(const ParStream *ps, 
 
 // ------------------------------------------------------------------ W
 // One workgroup per stream, block by block: win[k] = the 32 KiB of resolved output that end with block k.
+// The previous and the current window live in LDS (2 x 32 KiB); each finished window is also written to HBM
+// for the resolve kernel.
 __global__ __launch_bounds__(1024) void zs_inf_window_kernel(const ParStream *ps, const ParState *st, const ParBlock *blocks,
                                                              const uint16_t *cells, uint8_t *windows) {
+    __shared__ __attribute__((aligned(16))) uint8_t wl[2][kWSize];
     const ParStream s = ps[blockIdx.x];
     const ParState ss = st[blockIdx.x];
     if (!ss.ok) return;
     const uint16_t *cl = cells + s.cell_off;
     uint8_t *win = windows + (int64_t)s.blk_off * kWSize;
+    for (int i = threadIdx.x; i < kWSize; i += 1024) wl[0][i] = 0;
+    __syncthreads();
+    int cur = 1;
     for (int k = 0; k < ss.nblk; k++) {
         const ParBlock bk = blocks[s.blk_off + k];
-        const uint8_t *pw = k ? win + (int64_t)(k - 1) * kWSize : nullptr;  // window before block k
-        uint8_t *cw = win + (int64_t)k * kWSize;
+        const uint8_t *pw = wl[cur ^ 1];
+        uint8_t *cw = wl[cur];
         const int64_t end = bk.out_off + bk.out_bytes;
-        for (int i = threadIdx.x; i < kWSize; i += 1024) {
+        // cells first (independent global loads), then the LDS gathers
+        uint16_t c[kWSize / 1024];
+#pragma unroll
+        for (int j = 0; j < kWSize / 1024; j++) {
+            const int64_t p = end - kWSize + threadIdx.x + j * 1024;
+            c[j] = p >= bk.out_off ? cl[p] : 0;
+        }
+#pragma unroll
+        for (int j = 0; j < kWSize / 1024; j++) {
+            const int i = threadIdx.x + j * 1024;
             const int64_t p = end - kWSize + i;  // absolute output position of window byte i
-            uint8_t v = 0;
-            if (p >= bk.out_off) {
-                const uint16_t c = cl[p];
-                v = (c & 0x8000) ? (pw ? pw[c & 0x7FFF] : 0) : (uint8_t)c;
-            } else if (p >= 0) {
-                v = pw ? pw[i + bk.out_bytes] : 0;  // p = (end_prev - 32768) + (i + out_bytes)
-            }
+            uint8_t v;
+            if (p >= bk.out_off) v = (c[j] & 0x8000) ? pw[c[j] & 0x7FFF] : (uint8_t)c[j];
+            else v = pw[i + bk.out_bytes];  // p = (end of the previous block - 32768) + (i + out_bytes); zero before the stream
             cw[i] = v;
         }
-        __threadfence_block();
         __syncthreads();
+        uint4 *dst = (uint4 *)(win + (int64_t)k * kWSize);
+        const uint4 *src = (const uint4 *)cw;
+        for (int i = threadIdx.x; i < kWSize / 16; i += 1024) dst[i] = src[i];
+        cur ^= 1;
     }
 }
 
