@@ -339,6 +339,7 @@ static void parse_chunked(Model &m, int64_t &p_out, int &kind_out, uint32_t &pen
 static void run_tail(Model &m, int64_t p, int kind, uint32_t pend, int k_done, int64_t preins) {
     LitEngine e;
     memset(&e, 0, sizeof e);
+    le_defaults(e);
     std::vector<uint8_t> window(kWindowSize + 512);
     std::vector<uint16_t> head(kHashSize), prev(kWSize);
     e.window = window.data();

@@ -289,3 +289,20 @@ def test_cpp_host_mirror(tmp_path):
                    check=True)
     r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "PASS" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_fast_levels_large_streams_speculative_runs(engine, oracle):
+    """Levels 1-3 on streams >= 1 MiB take the speculative chunk-run path (verified hand-over states, sequential
+    fallback when a run does not verify): text, sparse rows, periodic data that resists re-synchronisation, zeros."""
+    rng = np.random.default_rng(9)
+    cases = {
+        "english4m": datagen.english(4 << 20),
+        "sparse4m": datagen.sparse(1024, 1024),
+        "period": (bytes(range(256)) * 8192)[:(1 << 21) + 12345],
+        "zeros": bytes((1 << 20) + 7),
+        "lowent": rng.choice(np.array([0, 0, 0, 0, 1, 2, 255], dtype=np.uint8), (1 << 20) + 999).tobytes(),
+        "mixed": datagen.english(1 << 20) + datagen.sparse(512, 256) + oracle_binding.corpus("kennedy.xls"),
+    }
+    for name, d in cases.items():
+        for lvl in (1, 2, 3):
+            assert engine.deflate_batch([d], level=lvl)[0] == oracle.compress(d, lvl), (name, lvl)

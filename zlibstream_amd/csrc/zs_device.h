@@ -42,6 +42,8 @@ struct StreamDesc {
     int32_t max_blocks;
     int32_t adler_off; // index of piece 0 in adler pieces
     int32_t n_adler;
+    int32_t fast_runs; // > 0: DeflateFast by speculative chunk runs (zs_fast_run_kernel); the tail kernel skips the stream
+    int32_t run_off;   // index of run 0 in the run arrays
     int32_t seg_off;   // index of parse segment 0 in segmap / seg_entry / seg_symbase / seg_stale
     int32_t nsegs;
     int32_t n_wr;            // > 1: several Writes -> the whole stream runs on the literal engine
@@ -61,6 +63,24 @@ struct StreamState {
     int64_t out_len;
     uint32_t adler;
     int32_t status;
+};
+
+// DeflateFast (levels 1-3) as speculative chunk runs: run j re-parses kFastWarm bytes before its chunk with an
+// "everything inserted" history, then its chunk; it is exact iff its state at the first loop-top of the chunk
+// (position + set of inserted strings in the 32 KiB before it) equals the previous run's final state.
+constexpr int kFastChunk = 262144;
+constexpr int kFastWarm = 65536;
+constexpr int kFastMinInput = 1 << 20;
+constexpr int64_t kFastRunSyms = kFastWarm + kFastChunk + 1024;             // symbol slots per run
+constexpr int64_t kFastRunBitWords = (kFastWarm + kFastChunk + 2048) / 32;  // inserted-position bitmap words per run
+constexpr int64_t kFastRunScratch = 2 * kHashSize + 4 * kHashSize;          // u16 head + u32 head32
+struct FastRunOut {
+    int64_t mark_pos, mark_nsyms;  // first loop-top inside the run's own chunk, symbols emitted before it
+    int64_t end_pos, nsyms;        // loop-top at which the run stopped (n for the last run), symbols emitted
+    int64_t final_base;            // window base at the end (last run: decides whether the last block may be stored)
+    int64_t sym_dst;               // where the run's own symbols go in the stream's symbol array (set by the stitch kernel)
+    int64_t ev[16];                // loop-tops of the refills the run performed
+    int32_t ok, n_ev;
 };
 
 struct BlockInfo {

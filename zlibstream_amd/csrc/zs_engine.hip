@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -36,13 +37,14 @@ struct zs_ctx {
     hipStream_t stream = nullptr;
     std::string err;
     bool profiling = false;
+    int fast_fallbacks = 0;  // speculative DeflateFast batches that had to be redone sequentially
     int last_op = 0;  // 0: deflate stages, 1: block-parallel inflate stages (for zs_ctx_stage_name)
     hipEvent_t ev[kStCount + 1] = {};
     double stage_ms[kStCount] = {};
     uint32_t *crc_tab = nullptr;
     DevBuf sd, st, work, link, mm, maps, segmap, seg_entry, seg_symbase, seg_stale, entry, symbase, stale, syms, blk_end, blk_top, blocks, trees, info, pieces, scratch,
         stage_in, stage_out, wr, inf_desc, inf_state, par_ps, par_st, par_work, par_cbits, par_ccnt, par_cands, par_blocks, par_cells,
-        par_windows, par_fail;
+        par_windows, par_fail, run_syms, run_bits, run_scratch, run_outs, run_fail;
     void *pinned = nullptr;
     size_t pinned_cap = 0;
 };
@@ -81,9 +83,9 @@ bool ensure_pinned(zs_ctx *c, size_t bytes) {
 
 struct Plan {
     std::vector<StreamDesc> sd;
-    std::vector<uint2> w_clear, w_adler, w_links, w_match, w_chunks, w_segs, w_blocks;
+    std::vector<uint2> w_clear, w_adler, w_links, w_match, w_chunks, w_segs, w_blocks, w_runs;
     int64_t n_pos = 0, n_syms = 0;
-    int64_t n_chunks = 0, n_segs = 0, n_blocks = 0, n_pieces = 0;
+    int64_t n_chunks = 0, n_segs = 0, n_blocks = 0, n_pieces = 0, n_runs = 0;
 };
 
 template <class T>
@@ -94,7 +96,7 @@ T *dev(DevBuf &b) {
 // `writes` (optional, one stream only): cumulative Write ends of a multi-Write stream
 bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len, void *const *out, const int64_t *out_cap,
                   int64_t *out_len, int *status, int level, int strategy, int hash_variant, hipStream_t stream,
-                  const std::vector<int64_t> *writes = nullptr) {
+                  const std::vector<int64_t> *writes = nullptr, bool force_seq = false) {
     if (level == -1) level = 6;
     LevelCfg lv = level_cfg(level);
     Plan pl;
@@ -121,6 +123,12 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
         s.seg_off = (int32_t)pl.n_segs;
         s.nsegs = num_segs(s.nchunks);
         pl.n_segs += s.nsegs;
+        // levels 1-3, one Write, large enough: speculative chunk runs instead of one sequential engine
+        const bool fast_par = lv.func == 1 && strategy != kRle && !multi && !force_seq && len >= kFastMinInput;
+        s.fast_runs = fast_par ? (int32_t)((len + kFastChunk - 1) / kFastChunk) : 0;
+        s.run_off = (int32_t)pl.n_runs;
+        pl.n_runs += s.fast_runs;
+        for (int k = 0; k < s.fast_runs; k++) pl.w_runs.push_back(make_uint2((unsigned)i, (unsigned)k));
         s.blk_off = (int32_t)pl.n_blocks;
         s.max_blocks = (int32_t)(level == 0 ? len / 8191 + len / 32506 + 4 : len / kBlockSyms + 2);
         pl.n_blocks += s.max_blocks;
@@ -129,8 +137,9 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
         pl.n_pieces += s.n_adler;
         for (int64_t k = 0; k * 65536 < s.out_cap; k++) pl.w_clear.push_back(make_uint2((unsigned)i, (unsigned)k));
         for (int k = 0; k < s.n_adler; k++) pl.w_adler.push_back(make_uint2((unsigned)i, (unsigned)k));
-        if (s.body_end >= 0) {
+        if (s.body_end >= 0 || s.fast_runs > 0)
             for (int64_t t = 0; t * kLinkTile < len - 5; t++) pl.w_links.push_back(make_uint2((unsigned)i, (unsigned)t));
+        if (s.body_end >= 0) {
             for (int64_t t = 0; t * kMatchTile <= s.body_end; t++) pl.w_match.push_back(make_uint2((unsigned)i, (unsigned)t));
             for (int k = 0; k < s.nchunks; k++) pl.w_chunks.push_back(make_uint2((unsigned)i, (unsigned)k));
             for (int k = 0; k < s.nsegs; k++) pl.w_segs.push_back(make_uint2((unsigned)i, (unsigned)k));
@@ -139,7 +148,7 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
     }
     // ---- workspace ----
     size_t n_work = pl.w_clear.size() + pl.w_adler.size() + pl.w_links.size() + pl.w_match.size() + pl.w_chunks.size() +
-                    pl.w_segs.size() + pl.w_blocks.size();
+                    pl.w_segs.size() + pl.w_blocks.size() + pl.w_runs.size();
     if (!ensure(c, c->sd, sizeof(StreamDesc) * (size_t)n) || !ensure(c, c->st, sizeof(StreamState) * (size_t)n) ||
         !ensure(c, c->work, sizeof(uint2) * (n_work + 1)) || !ensure(c, c->link, 2 * (size_t)pl.n_pos + 64) ||
         !ensure(c, c->mm, 8 * (size_t)pl.n_pos + 64) ||
@@ -151,6 +160,11 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
         !ensure(c, c->blk_top, 4 * (size_t)pl.n_blocks + 64) || !ensure(c, c->blocks, sizeof(BlockRec) * (size_t)pl.n_blocks) ||
         !ensure(c, c->trees, sizeof(TreeWork) * (size_t)pl.n_blocks) || !ensure(c, c->info, sizeof(BlockInfo) * (size_t)pl.n_blocks) ||
         !ensure(c, c->pieces, 4 * (size_t)pl.n_pieces + 64) || !ensure(c, c->scratch, (size_t)kScratchBytes * (size_t)n))
+        return false;
+    if (pl.n_runs &&
+        (!ensure(c, c->run_syms, 4 * (size_t)pl.n_runs * kFastRunSyms) || !ensure(c, c->run_bits, 4 * (size_t)pl.n_runs * kFastRunBitWords) ||
+         !ensure(c, c->run_scratch, (size_t)pl.n_runs * kFastRunScratch) || !ensure(c, c->run_outs, sizeof(FastRunOut) * (size_t)pl.n_runs) ||
+         !ensure(c, c->run_fail, 4 * (size_t)n + 64)))
         return false;
     if (writes && writes->size() > 1) {
         if (!ensure(c, c->wr, sizeof(int64_t) * writes->size())) return false;
@@ -164,7 +178,7 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
     uint8_t *hp = (uint8_t *)c->pinned;
     memcpy(hp, pl.sd.data(), sizeof(StreamDesc) * (size_t)n);
     uint2 *hw = (uint2 *)(hp + sizeof(StreamDesc) * (size_t)n);
-    size_t o_clear = 0, o_adler, o_links, o_match, o_chunks, o_segs, o_blocks;
+    size_t o_clear = 0, o_adler, o_links, o_match, o_chunks, o_segs, o_blocks, o_runs;
     auto put = [&](const std::vector<uint2> &v, size_t &off, size_t at) {
         off = at;
         if (!v.empty()) memcpy(hw + at, v.data(), sizeof(uint2) * v.size());
@@ -177,6 +191,7 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
     at = put(pl.w_chunks, o_chunks, at);
     at = put(pl.w_segs, o_segs, at);
     at = put(pl.w_blocks, o_blocks, at);
+    at = put(pl.w_runs, o_runs, at);
     ZS_HIP(c, hipMemcpyAsync(c->sd.p, hp, sizeof(StreamDesc) * (size_t)n, hipMemcpyHostToDevice, stream));
     if (n_work) ZS_HIP(c, hipMemcpyAsync(c->work.p, hw, sizeof(uint2) * n_work, hipMemcpyHostToDevice, stream));
     ZS_HIP(c, hipMemsetAsync(c->link.p, 0, 2 * (size_t)pl.n_pos + 64, stream));
@@ -240,6 +255,39 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
     hipLaunchKernelGGL(zs_tail_kernel, dim3((unsigned)n), dim3(1024), kTailLds, stream, d_sd, d_st, dev<uint16_t>(c->link),
                        dev<uint32_t>(c->syms), dev<int32_t>(c->blk_end), dev<int32_t>(c->blk_top), dev<BlockRec>(c->blocks),
                        dev<uint8_t>(c->scratch), c->crc_tab, lv, strategy, hash_variant, level);
+    if (pl.n_runs) {
+        // DeflateFast by speculative chunk runs; a run whose hand-over state does not verify sends the batch to the
+        // sequential engine (the result is the reference's bytes either way)
+        ZS_HIP(c, hipMemsetAsync(c->run_fail.p, 0, 4 * (size_t)n + 64, stream));
+        hipLaunchKernelGGL(zs_fast_run_kernel, dim3((unsigned)pl.n_runs), dim3(1024), kTailLds, stream, d_sd, d_work + o_runs,
+                           dev<uint16_t>(c->link), dev<uint32_t>(c->run_syms), dev<uint32_t>(c->run_bits), dev<uint8_t>(c->run_scratch),
+                           dev<FastRunOut>(c->run_outs), c->crc_tab, lv, strategy, hash_variant);
+        hipLaunchKernelGGL(zs_fast_verify_kernel, dim3((unsigned)pl.n_runs), dim3(256), 0, stream, d_sd, d_work + o_runs,
+                           dev<uint32_t>(c->run_bits), dev<FastRunOut>(c->run_outs), dev<int32_t>(c->run_fail));
+        std::vector<int32_t> rfail((size_t)n, 0);
+        ZS_HIP(c, hipMemcpyAsync(rfail.data(), c->run_fail.p, 4 * (size_t)n, hipMemcpyDeviceToHost, stream));
+        ZS_HIP(c, hipStreamSynchronize(stream));
+        for (int i = 0; i < n; i++)
+            if (rfail[(size_t)i]) {
+                c->fast_fallbacks++;
+                if (getenv("ZS_DEBUG")) {
+                    std::vector<FastRunOut> ro((size_t)pl.n_runs);
+                    (void)hipMemcpy(ro.data(), c->run_outs.p, sizeof(FastRunOut) * ro.size(), hipMemcpyDeviceToHost);
+                    for (int j = 0; j < pl.sd[(size_t)i].fast_runs; j++) {
+                        const FastRunOut &o = ro[(size_t)pl.sd[(size_t)i].run_off + j];
+                        fprintf(stderr, "zs: stream %d run %d ok=%d mark=%lld (+%lld syms) end=%lld nsyms=%lld n_ev=%d\n", i, j, o.ok,
+                                (long long)o.mark_pos, (long long)o.mark_nsyms, (long long)o.end_pos, (long long)o.nsyms, o.n_ev);
+                    }
+                }
+                return run_pipeline(c, n, in, in_len, out, out_cap, out_len, status, level, strategy, hash_variant, stream, writes, true);
+            }
+        hipLaunchKernelGGL(zs_fast_plan_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, d_sd, d_st, dev<FastRunOut>(c->run_outs), n);
+        hipLaunchKernelGGL(zs_fast_stitch_kernel, dim3((unsigned)pl.n_runs), dim3(256), 0, stream, d_sd, d_work + o_runs,
+                           dev<uint32_t>(c->run_syms), dev<FastRunOut>(c->run_outs), dev<uint32_t>(c->syms), dev<int32_t>(c->blk_end),
+                           dev<int32_t>(c->blk_top));
+        hipLaunchKernelGGL(zs_fast_blocks_kernel, dim3((unsigned)n), dim3(64), 0, stream, d_sd, d_st, dev<FastRunOut>(c->run_outs),
+                           dev<int32_t>(c->blk_end), dev<int32_t>(c->blk_top), dev<BlockRec>(c->blocks), n);
+    }
     mark(10);
     hipLaunchKernelGGL(zs_trees_kernel, dim3((unsigned)pl.w_blocks.size()), dim3(256), 0, stream, d_sd, d_st, d_work + o_blocks,
                        dev<uint32_t>(c->syms), dev<BlockRec>(c->blocks), dev<TreeWork>(c->trees), dev<BlockInfo>(c->info), strategy, level);
@@ -312,6 +360,7 @@ int zs_ctx_create(int device, zs_ctx **out) {
         hipFuncSetAttribute((const void *)zs_match_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kMatchLds) != hipSuccess ||
         hipFuncSetAttribute((const void *)zs_emit_syms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kEmitLds) != hipSuccess ||
         hipFuncSetAttribute((const void *)zs_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kTailLds) != hipSuccess ||
+        hipFuncSetAttribute((const void *)zs_fast_run_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kTailLds) != hipSuccess ||
         hipFuncSetAttribute((const void *)zs_inflate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kInfLds) != hipSuccess) {
         zs_ctx_destroy(c);
         return ZS_MEM_ERROR;
@@ -325,7 +374,8 @@ void zs_ctx_destroy(zs_ctx *c) {
     (void)hipSetDevice(c->device);
     DevBuf *bufs[] = {&c->sd, &c->st, &c->work, &c->link, &c->mm, &c->maps, &c->segmap, &c->seg_entry, &c->seg_symbase, &c->seg_stale, &c->entry, &c->symbase, &c->stale, &c->syms,
                       &c->blk_end, &c->blk_top, &c->blocks, &c->trees, &c->info, &c->pieces, &c->scratch, &c->stage_in, &c->stage_out, &c->wr, &c->inf_desc, &c->inf_state, &c->par_ps, &c->par_st, &c->par_work, &c->par_cbits, &c->par_ccnt,
-                      &c->par_cands, &c->par_blocks, &c->par_cells, &c->par_windows, &c->par_fail};
+                      &c->par_cands, &c->par_blocks, &c->par_cells, &c->par_windows, &c->par_fail, &c->run_syms, &c->run_bits,
+                      &c->run_scratch, &c->run_outs, &c->run_fail};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     if (c->crc_tab) (void)hipFree(c->crc_tab);

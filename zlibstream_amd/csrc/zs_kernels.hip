@@ -717,6 +717,7 @@ __global__ __launch_bounds__(1024) void zs_tail_kernel(const StreamDesc *sd, Str
                                                      uint8_t *scratch, const uint32_t *crc_tab_g, LevelCfg lv, int strategy,
                                                      int hash_variant, int level) {
     const StreamDesc s = sd[blockIdx.x];
+    if (s.fast_runs > 0) return;  // handled by zs_fast_run_kernel / zs_fast_stitch_kernel
     StreamState &ss = st[blockIdx.x];
     const int tid = threadIdx.x, nth = blockDim.x;  // all threads restore; wave 0 then runs the engine
     uint8_t *sc = scratch + (int64_t)blockIdx.x * kScratchBytes;
@@ -740,6 +741,7 @@ __global__ __launch_bounds__(1024) void zs_tail_kernel(const StreamDesc *sd, Str
     // window and prev live in LDS (129 KiB: the engine is latency-bound on them), head in HBM scratch
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     LitEngine e;
+    le_defaults(e);
     e.window = smem;
     e.head = (uint16_t *)(sc + kScratchHead);
     e.prev = (uint16_t *)(smem + kScratchHead);
@@ -790,6 +792,203 @@ __global__ __launch_bounds__(1024) void zs_tail_kernel(const StreamDesc *sd, Str
 }
 
 constexpr int kTailLds = (int)kScratchHead + 2 * kWSize;
+
+// ------------------------------------------------------------------ KF: DeflateFast by speculative chunk runs
+// One workgroup per run (1024 threads restore the engine state, wave 0 runs Deflate.Fast.cs:20-128 literally).
+__global__ __launch_bounds__(1024) void zs_fast_run_kernel(const StreamDesc *sd, const uint2 *work, const uint16_t *link,
+                                                           uint32_t *run_syms, uint32_t *run_bits, uint8_t *run_scratch,
+                                                           FastRunOut *outs, const uint32_t *crc_tab_g, LevelCfg lv, int strategy,
+                                                           int hash_variant) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    __shared__ BlockRec dummy_blk[2];
+    const uint2 w = work[blockIdx.x];
+    const StreamDesc s = sd[w.x];
+    const int j = (int)w.y;
+    const int64_t run = (int64_t)s.run_off + j;
+    const int tid = threadIdx.x, nth = blockDim.x;
+    const int64_t cj = (int64_t)j * kFastChunk;
+    const bool last = j + 1 == s.fast_runs;
+    int64_t x = cj - kFastWarm;
+    if (x < 0) x = 0;
+    uint8_t *sc = run_scratch + run * kFastRunScratch;
+    uint32_t *bits = run_bits + run * kFastRunBitWords;
+    for (int64_t i = tid; i < kFastRunBitWords; i += nth) bits[i] = 0;
+    LitEngine e;
+    le_defaults(e);
+    e.window = smem;
+    e.prev = (uint16_t *)(smem + kScratchHead);
+    e.head = (uint16_t *)sc;
+    uint32_t *head32 = (uint32_t *)(sc + 2 * kHashSize);
+    e.crc_tab = crc_tab_g;
+    e.data = s.in;
+    e.n = s.n;
+    e.lv = lv;
+    e.strategy = strategy;
+    e.hash_variant = hash_variant;
+    e.syms = run_syms + run * kFastRunSyms;
+    e.blocks = dummy_blk;
+    e.no_blocks = 1;
+    e.stop_abs = last ? -1 : cj + kFastChunk;
+    e.mark_abs = cj;
+    e.ins_bits = bits;
+    e.ins_base = x;
+    e.ev_log = outs[run].ev;
+    const uint16_t *lk = link + s.pos_off;
+    const int k_done = x == 0 ? 0 : refills_fired_at(x, s.kl);
+    le_restore(e, x, k_done, kR, 0, lk, -1, tid, nth);
+    for (int i = tid; i < kHashSize; i += nth) head32[i] = 0;
+    __syncthreads();
+    if (e.avail_end > 0) {
+        int64_t lo = x - (kWSize - 1);
+        if (lo < e.base) lo = e.base;
+        if (lo < 0) lo = 0;
+        for (int64_t q = lo + tid; q < x; q += nth) {
+            le_restore_prev(e, q, lk);
+            atomicMax(&head32[le_bucket(e, q)], (uint32_t)(q - e.base) + 1u);
+        }
+        __syncthreads();
+        for (int i = tid; i < kHashSize; i += nth) e.head[i] = (uint16_t)(head32[i] ? head32[i] - 1 : 0);
+    }
+    __syncthreads();
+    if (tid >= 64) return;
+    le_run_fast(e, tid, 64);
+    if (tid == 0) {
+        FastRunOut &o = outs[run];
+        o.mark_pos = e.mark_pos, o.mark_nsyms = e.mark_nsyms;
+        o.end_pos = (e.stop_abs >= 0 && e.lookahead > 0) ? e.base + e.strstart : (int64_t)s.n;
+        if (e.stop_abs >= 0 && e.base + e.strstart < e.stop_abs) o.end_pos = -1;  // ran out of input before its stop: not a valid hand-over
+        o.nsyms = e.nsyms;
+        o.final_base = e.base;
+        o.sym_dst = 0;
+        o.ok = 1, o.n_ev = e.n_ev;
+        if (j == 0) o.mark_pos = 0, o.mark_nsyms = 0;
+    }
+}
+
+// run j (j >= 1) is exact iff it entered its chunk where run j-1 stopped, with the same strings inserted in the
+// 32 KiB before that loop-top (chain walks never look further back)
+__global__ __launch_bounds__(256) void zs_fast_verify_kernel(const StreamDesc *sd, const uint2 *work, const uint32_t *run_bits,
+                                                             FastRunOut *outs, int32_t *stream_fail) {
+    __shared__ int bad;
+    const uint2 w = work[blockIdx.x];
+    const StreamDesc s = sd[w.x];
+    const int j = (int)w.y;
+    if (j == 0) return;
+    const int64_t run = (int64_t)s.run_off + j;
+    const FastRunOut a = outs[run - 1], b = outs[run];
+    if (threadIdx.x == 0) bad = (b.mark_pos < 0 || b.mark_pos != a.end_pos);
+    __syncthreads();
+    if (!bad) {
+        const int64_t xa = (j - 1) * (int64_t)kFastChunk - kFastWarm < 0 ? 0 : (j - 1) * (int64_t)kFastChunk - kFastWarm;
+        const int64_t xb = (int64_t)j * kFastChunk - kFastWarm < 0 ? 0 : (int64_t)j * kFastChunk - kFastWarm;
+        const uint32_t *ba = run_bits + (run - 1) * kFastRunBitWords, *bb = run_bits + run * kFastRunBitWords;
+        int64_t lo = b.mark_pos - kWSize;
+        if (lo < 0) lo = 0;
+        int mism = 0;
+        for (int64_t p = lo + threadIdx.x; p < b.mark_pos; p += 256) {
+            const int64_t ia = p - xa, ib = p - xb;
+            const uint32_t va = (ba[ia >> 5] >> (ia & 31)) & 1u;
+            const uint32_t vb = ib >= 0 ? (bb[ib >> 5] >> (ib & 31)) & 1u : va;  // before run j's start: restored as inserted; require run j-1 agrees
+            const uint32_t want = ib >= 0 ? vb : 1u;
+            mism |= (va != want);
+        }
+        if (mism) bad = 1;
+        // refills inside the compared window must have happened at the same loop-tops (the string they pre-insert
+        // and the prev[] 2-cycle they can leave are not visible in the bitmap)
+        if (threadIdx.x == 0) {
+            for (int u = 0; u < a.n_ev; u++) {
+                if (a.ev[u] < lo - 1 || a.ev[u] > b.mark_pos) continue;
+                bool found = false;
+                for (int v = 0; v < b.n_ev; v++) found |= b.ev[v] == a.ev[u];
+                if (!found) bad = 1;
+            }
+            for (int v = 0; v < b.n_ev; v++) {
+                if (b.ev[v] < lo - 1 || b.ev[v] > b.mark_pos) continue;
+                bool found = false;
+                for (int u = 0; u < a.n_ev; u++) found |= a.ev[u] == b.ev[v];
+                if (!found) bad = 1;
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && bad) {
+        outs[run].ok = 0;
+        stream_fail[w.x] = 1;
+    }
+}
+
+// per stream: where each run's own symbols go; block cuts every kBlockSyms symbols
+__global__ __launch_bounds__(64) void zs_fast_plan_kernel(const StreamDesc *sd, StreamState *st, FastRunOut *outs, int nstreams) {
+    const int si = blockIdx.x * 64 + threadIdx.x;
+    if (si >= nstreams) return;
+    const StreamDesc s = sd[si];
+    if (s.fast_runs <= 0) return;
+    int64_t total = 0;
+    for (int j = 0; j < s.fast_runs; j++) {
+        FastRunOut &o = outs[s.run_off + j];
+        o.sym_dst = total;
+        total += o.nsyms - o.mark_nsyms;
+    }
+    st[si].nsyms = (uint32_t)total;
+    st[si].nblocks = (int32_t)(total / kBlockSyms) + 1;
+    // a stream whose symbol count is a multiple of kBlockSyms ends with an empty last block, like the reference
+}
+
+// one workgroup per run: copy the run's own symbols into place; thread 0 re-walks them to find the byte positions of
+// the block cuts that fall inside the run
+__global__ __launch_bounds__(256) void zs_fast_stitch_kernel(const StreamDesc *sd, const uint2 *work, const uint32_t *run_syms,
+                                                             const FastRunOut *outs, uint32_t *syms, int32_t *blk_end,
+                                                             int32_t *blk_top) {
+    const uint2 w = work[blockIdx.x];
+    const StreamDesc s = sd[w.x];
+    const int64_t run = (int64_t)s.run_off + w.y;
+    const FastRunOut o = outs[run];
+    const uint32_t *src = run_syms + run * kFastRunSyms + o.mark_nsyms;
+    uint32_t *dst = syms + s.sym_off + o.sym_dst;
+    const int64_t cnt = o.nsyms - o.mark_nsyms;
+    for (int64_t i = threadIdx.x; i < cnt; i += 256) dst[i] = src[i];
+    if (threadIdx.x == 0) {
+        int64_t pos = o.mark_pos;
+        for (int64_t i = 0; i < cnt; i++) {
+            const uint32_t v = src[i];
+            const int64_t start = pos;
+            pos += (v >> 16) ? (int64_t)(v & 0xFFFF) + 3 : 1;
+            const int64_t g = o.sym_dst + i;
+            if ((g + 1) % kBlockSyms == 0) {
+                blk_end[s.blk_off + g / kBlockSyms] = (int32_t)pos;
+                blk_top[s.blk_off + g / kBlockSyms] = (int32_t)start;  // DeflateFast flushes at the loop-top that emitted the symbol
+            }
+        }
+    }
+}
+
+// per stream: block records from the cuts (Flush_block_only, Deflate.cs:951-956)
+__global__ __launch_bounds__(64) void zs_fast_blocks_kernel(const StreamDesc *sd, const StreamState *st, const FastRunOut *outs,
+                                                            const int32_t *blk_end, const int32_t *blk_top, BlockRec *blocks,
+                                                            int nstreams) {
+    const int si = blockIdx.x;
+    const StreamDesc s = sd[si];
+    if (s.fast_runs <= 0) return;
+    const int nb = st[si].nblocks;
+    const int64_t total = st[si].nsyms;
+    for (int b = threadIdx.x; b < nb; b += 64) {
+        BlockRec r;
+        r.start = b ? blk_end[s.blk_off + b - 1] : 0;
+        r.sym_start = (int64_t)b * kBlockSyms;
+        if (b + 1 < nb) {
+            r.stored_len = (int32_t)(blk_end[s.blk_off + b] - r.start);
+            r.nsyms = kBlockSyms;
+            r.can_store = r.start >= (int64_t)kWSize * refills_fired_at(blk_top[s.blk_off + b], s.kl);
+            r.eof = 0;
+        } else {
+            r.stored_len = (int32_t)((int64_t)s.n - r.start);
+            r.nsyms = (int32_t)(total - r.sym_start);
+            r.can_store = r.start >= outs[s.run_off + s.fast_runs - 1].final_base;
+            r.eof = 1;
+        }
+        blocks[s.blk_off + b] = r;
+    }
+}
 
 // ------------------------------------------------------------------ K7
 // One workgroup per block: histogram the block's symbols (Tr_tally_*), then

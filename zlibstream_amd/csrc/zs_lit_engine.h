@@ -63,12 +63,31 @@ struct LitEngine {
     int64_t block_start_abs;
     int64_t block_sym_start;  // symbols emitted before the current block
     int block_syms;           // litBufsize - 1: 16383, or 8191 at level 0 (memLevel 7, Deflate.cs:246-249,298)
+    // speculative chunk runs of DeflateFast (zs_kernels.hip, zs_fast_run_kernel); all off by default
+    int64_t stop_abs;         // stop at the first loop-top >= this (no final flush); < 0: run to the end
+    int64_t mark_abs;         // record the first loop-top >= this ...
+    int64_t mark_pos, mark_nsyms;  // ... its position and the symbols emitted before it (-1 until reached)
+    uint32_t *ins_bits;       // bitmap of inserted positions, bit (abs - ins_base); nullptr: not tracked
+    int64_t ins_base;
+    int no_blocks;            // do not cut blocks (the caller does it after stitching the runs)
+    int64_t *ev_log;          // loop-tops at which a refill read happened (the pre-insert positions - 1), up to 16
+    int n_ev;
     // outputs
     uint32_t *syms;     // symbol i: dist << 16 | lc  (dist 0 = literal)
     int64_t nsyms;      // symbols emitted so far in this stream (body + tail)
     BlockRec *blocks;
     int nblocks;
 };
+
+// the optional features are off unless a caller turns them on
+ZS_HD void le_defaults(LitEngine &e) {
+    e.wr_end = nullptr, e.n_wr = 1, e.cur_wr = 0;
+    e.stop_abs = -1, e.mark_abs = -1, e.mark_pos = -1, e.mark_nsyms = 0;
+    e.ins_bits = nullptr, e.ins_base = 0, e.no_blocks = 0;
+    e.ev_log = nullptr, e.n_ev = 0;
+    e.block_syms = kBlockSyms, e.block_sym_start = 0, e.block_start_abs = 0;
+    e.nsyms = 0, e.nblocks = 0;
+}
 
 ZS_HD uint32_t le_hash(const LitEngine &e, uint32_t v) {
     if (e.hash_variant == kHashMul) return hash_mul(v) & kHashMask;
@@ -81,6 +100,10 @@ ZS_HD uint32_t le_load32(const uint8_t *p) {
 
 // Deflate.cs:866-877
 ZS_HD int le_insert(LitEngine &e, int str) {
+    if (e.ins_bits) {
+        const int64_t i = e.base + str - e.ins_base;
+        e.ins_bits[i >> 5] |= 1u << (i & 31);  // every lane writes the same word: benign
+    }
     uint32_t h = le_hash(e, le_load32(e.window + str + 2));
     int cur = e.head[h];
     if (cur != str) {
@@ -118,6 +141,10 @@ ZS_HD_NOINLINE inline void le_fill_window(LitEngine &e, int lane, int nlanes) {
         ZS_WAVE_SYNC();
         e.avail_end += cnt;
         e.lookahead += cnt;
+        if (e.ev_log && e.n_ev < 16) {
+            if (lane == 0) e.ev_log[e.n_ev] = e.base + e.strstart;
+            e.n_ev++;
+        }
         if (e.lookahead >= kMinMatch) le_insert(e, e.strstart + 1);
     } while (e.lookahead < kMinLookahead && e.avail_end < ((e.wr_end && e.cur_wr < e.n_wr) ? e.wr_end[e.cur_wr] : e.n));
 }
@@ -183,7 +210,7 @@ ZS_HD void le_flush_block(LitEngine &e, bool eof, int lane) {
 ZS_HD bool le_tally(LitEngine &e, int dist, int lc, int lane) {
     if (lane == 0) e.syms[e.nsyms] = ((uint32_t)dist << 16) | (uint32_t)lc;
     e.nsyms++;
-    return (e.nsyms - e.block_sym_start) == e.block_syms;
+    return !e.no_blocks && (e.nsyms - e.block_sym_start) == e.block_syms;
 }
 
 // Deflate.Slow.cs:18-159 with flush == Finish, run to the end of the stream.
@@ -242,6 +269,8 @@ ZS_HD_NOINLINE inline void le_run_fast(LitEngine &e, int lane, int nlanes) {
             le_refill(e, lane, nlanes, dummy);
             if (e.lookahead == 0) break;
         }
+        if (e.mark_abs >= 0 && e.mark_pos < 0 && e.base + e.strstart >= e.mark_abs) e.mark_pos = e.base + e.strstart, e.mark_nsyms = e.nsyms;
+        if (e.stop_abs >= 0 && e.base + e.strstart >= e.stop_abs) return;  // a speculative run ends at a loop-top, nothing is flushed
         int hash_head = 0;
         if (e.lookahead >= kMinMatch) hash_head = le_insert(e, e.strstart);
         if (hash_head != 0 && e.strstart - hash_head <= kMaxDist) {
