@@ -21,6 +21,18 @@ namespace zs {
 
 typedef uint32_t __attribute__((aligned(1))) u32u;
 typedef uint64_t __attribute__((aligned(1))) u64u;
+// Unaligned 4 / 8 bytes out of an LDS byte array (16-byte aligned base, readable one dword past the last index
+// used): aligned dword reads + v_alignbyte.  A ds_read whose address is not a multiple of its size is legal but
+// the LDS pipe handles the misaligned lanes of a wave one at a time.
+__device__ __forceinline__ uint32_t lds_u32(const uint8_t *base, int idx) {
+    const uint32_t *q = (const uint32_t *)(base + (idx & ~3));
+    return __builtin_amdgcn_alignbyte(q[1], q[0], (uint32_t)idx & 3u);
+}
+__device__ __forceinline__ uint64_t lds_u64(const uint8_t *base, int idx) {
+    const uint32_t *q = (const uint32_t *)(base + (idx & ~3));
+    const uint32_t a = q[0], b = q[1], c = q[2], sh = (uint32_t)idx & 3u;
+    return (uint64_t)__builtin_amdgcn_alignbyte(b, a, sh) | ((uint64_t)__builtin_amdgcn_alignbyte(c, b, sh) << 32);
+}
 
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 __device__ __forceinline__ uint64_t lanemask_lt() { return (1ull << lane_id()) - 1ull; }
@@ -171,7 +183,21 @@ __global__ __launch_bounds__(1024) void zs_match_kernel(const StreamDesc *sd, co
                 }
                 v = make_uint4(t[0], t[1], t[2], t[3]);
             }
-            ((uint4 *)wl)[i] = v;
+            // LDS form of a link: 0xFFFF = none (a step over it lands beyond kMaxDist, so the walk needs no
+            // separate test); a link onto position 0 is none too (Longest_match never visits position 0)
+            uint32_t t[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t nz = (((t[k] & 0x7FFF7FFFu) + 0x7FFF7FFFu) | t[k]) & 0x80008000u;  // bit 15 of each non-zero half
+                t[k] |= ((nz ^ 0x80008000u) >> 15) * 0xFFFFu;
+            }
+            if (a <= kMaxDist && a + 7 >= 1) {
+                for (int k = 0; k < 8; k++) {
+                    const uint32_t d = (t[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
+                    if ((int64_t)d == a + k) t[k >> 1] |= 0xFFFFu << (16 * (k & 1));
+                }
+            }
+            ((uint4 *)wl)[i] = make_uint4(t[0], t[1], t[2], t[3]);
         }
     }
     __syncthreads();
@@ -188,117 +214,112 @@ __global__ __launch_bounds__(1024) void zs_match_kernel(const StreamDesc *sd, co
     uint2 *om = mm + s.pos_off;
     const int K = lv.chain, K4 = lv.chain >> 2, nice = lv.nice;
 
-    // Two independent walks per lane (A and B): with one 1024-thread workgroup per CU
-    // there are only 4 waves per SIMD, so a single dependent chain per lane
-    // (link -> candidate bytes -> compare -> next link) leaves the LDS latency exposed;
-    // two chains per lane overlap their LDS round trips.  Each iteration does, for each
-    // walk: phase 1 (issue the link read and the 4-byte prefilter read of the current
-    // candidate), phase 2 (rare: 8 bytes of a real compare), phase 3 (bookkeeping with
-    // selects, move to the next candidate or finish).
-    struct Walk {
-        int st;  // 0 idle, 1 at a candidate, 2 inside a long compare
-        int p, c, best, bdist, n_eval, cl, snapped;
-        uint32_t snap, scan_end;  // scan_end = bytes p+best-3 .. p+best
-    };
-#ifndef ZS_NW
-#define ZS_NW 2
+    // Every lane owns one walk at a time, in one of four states:
+    //   1 stepping   at a candidate that has not been looked at yet
+    //   2 comparing  the candidate passed the 4-byte prefilter and needs a real compare (cl bytes done so far)
+    //   3 finished   result to be stored, then the lane pulls the next position from the wave cursor
+    //   0 idle       the cursor is exhausted
+    // The kernel is bound by vector-instruction issue (a wave64 instruction holds its SIMD for 4 cycles), and a wave
+    // pays for every path any of its lanes takes.  The common step (read the link and 4 prefilter bytes of the
+    // candidate, move on) is ~20 instructions without branches; the compare and finish paths are several times
+    // that, and with 64 walks per wave some lane needs one of them in nearly every round.  So the stepping phase
+    // keeps going with the lanes still in state 1 and lets the others wait until as many lanes wait as step
+    // (kWaitNum / kWaitDen), and only then runs the compare and finish phases once for all of them.
+#ifndef ZS_WQ
+#define ZS_WQ 1
 #endif
-    constexpr int NW = ZS_NW;  // independent walks per lane
-    Walk W[NW];
-#pragma unroll
-    for (int k = 0; k < NW; k++) W[k] = {0, 8, 8, 3, 0, 0, 0, 0, 0, 0};
-    const int lo32 = (int)lo;  // |lo| < 2^31 (streams are < 2 GiB)
+#ifndef ZS_WD
+#define ZS_WD 1
+#endif
+    constexpr int kWaitNum = ZS_WQ, kWaitDen = ZS_WD;
+    int st = 3, p = -1, c = 8, best = 2, bdist = 0, n_eval = 0, cl = 0;
+    uint32_t snap = 0;       // record for the K>>2 budget once it is known to differ from the final one, else 0
+    int snapped = 0;
+    uint32_t scan_end = 0, mask = 0;  // scan_end = bytes p+best-3 .. p+best; mask drops the byte before p when best == 2
     int nexti = (int)(next - lo), wendi = (int)(wend - lo);  // wave-uniform, LDS-relative
-    auto start = [&](Walk &w, int mine) {
-        const int l = wl[mine];
-        const bool has = l != 0 && (mine - l) + lo32 >= 1;  // link distances are already <= kMaxDist
-        if (!has) om[(int64_t)mine + lo] = make_uint2(kNoMatch, kNoMatch);
-        w.p = mine, w.c = mine - l, w.st = has ? 1 : 0;
-        w.best = 2, w.bdist = 0, w.n_eval = 0, w.snapped = 0, w.cl = 0;
-        w.scan_end = *(const u32u *)(wb + mine - 1);
-    };
-    auto compare8 = [&](Walk &w, int &len, int &adv) {  // phase 2: up to 32 bytes per call
-        int off = w.st == 2 ? w.cl : 0;
-        for (int r = 0; r < 4; r++) {
-            const uint64_t x = *(const u64u *)(wb + w.p + off) ^ *(const u64u *)(wb + w.c + off);
-            if (x) {
-                len = off + (int)(__builtin_ctzll(x) >> 3);
-                len = len > kMaxMatch ? kMaxMatch : len;
-                return;
-            }
-            off += 8;
-            if (off >= kMaxMatch) {
-                len = kMaxMatch;
-                return;
-            }
-        }
-        w.cl = off, w.st = 2, adv = 0;
-    };
-    auto finish_step = [&](Walk &w, int l, int len, int adv) {  // phase 3
-        const int better = adv & (len > w.best);
-        w.best = better ? len : w.best;
-        w.bdist = better ? w.p - w.c : w.bdist;
-        const int nice_hit = better & (len >= nice);
-        if (better) w.scan_end = *(const u32u *)(wb + w.p + w.best - 3);
-        w.n_eval += adv;
-        const int do_snap = adv & !w.snapped & ((w.n_eval == K4) | nice_hit);
-        const uint32_t rec = w.best >= kMinMatch ? pack_match(w.best, w.bdist) : kNoMatch;
-        w.snap = do_snap ? rec : w.snap;
-        w.snapped |= do_snap;
-        // next candidate: `cur_match > limit` (distance < kMaxDist), never position 0
-        const int nc = w.c - l;
-        const int stop = nice_hit | (w.n_eval >= K) | (l == 0) | (w.p - nc >= kMaxDist) | (nc + lo32 < 1);
-        const int done = adv & stop;
-        w.c = (adv & !stop) ? nc : w.c;
-        w.st = done ? 0 : (adv ? 1 : w.st);
-        if (done) {
-            om[(int64_t)w.p + lo] = make_uint2(rec, w.snapped ? w.snap : rec);
-        }
-    };
     for (;;) {
-        uint64_t need[NW], any_need = 0, all_need = ~0ull;
-#pragma unroll
-        for (int k = 0; k < NW; k++) {
-            need[k] = __ballot(W[k].st == 0);
-            any_need |= need[k];
-            all_need &= need[k];
+        // ---- finish phase: store results, pull new positions (a position without a usable link is done at once)
+        if (st == 3 && p >= 0) {
+            const uint32_t rec = best >= kMinMatch ? pack_match(best, bdist) : kNoMatch;
+            om[(int64_t)p + lo] = make_uint2(rec, snapped ? snap : rec);
         }
-        if (any_need) {
-            if (nexti < wendi) {
-#pragma unroll
-                for (int k = 0; k < NW; k++) {
-                    if (need[k] && nexti < wendi) {
-                        const int mine = nexti + __builtin_popcountll(need[k] & lanemask_lt());
-                        nexti += __builtin_popcountll(need[k]);
-                        if (W[k].st == 0 && mine < wendi) start(W[k], mine);
-                    }
-                }
-            } else if (all_need == ~0ull) {
+        uint64_t need = __ballot(st == 3);
+        while (need) {
+            if (nexti >= wendi) {
+                if (st == 3) st = 0, p = -1;
                 break;
             }
+            const int mine = nexti + __builtin_popcountll(need & lanemask_lt());
+            nexti += __builtin_popcountll(need);
+            if (st == 3) {
+                if (mine < wendi) {
+                    const int l = wl[mine];
+                    const bool has = l != 0xFFFF;  // link distances are already <= kMaxDist
+                    if (!has) om[(int64_t)mine + lo] = make_uint2(kNoMatch, kNoMatch);
+                    p = has ? mine : -1, c = mine - (has ? l : 0), st = has ? 1 : 3;
+                    best = 2, bdist = 0, n_eval = 0, snapped = 0, cl = 0;
+                    scan_end = lds_u32(wb, mine - 1);
+                    mask = 0xFFFFFF00u;
+                } else {
+                    st = 0, p = -1;
+                }
+            }
+            need = __ballot(st == 3);
         }
-        // phase 1: all walks' reads in flight together (idle walks read their stale, in-range c)
-        int l[NW], pass[NW], len[NW], adv[NW];
-        uint32_t e[NW];
-#pragma unroll
-        for (int k = 0; k < NW; k++) {
-            l[k] = wl[W[k].c];
-            e[k] = *(const u32u *)(wb + W[k].c + W[k].best - 3);
+        if (!__ballot(st != 0)) break;
+        // ---- stepping phase (branch-free; lanes not in state 1 read their stale, in-range candidate)
+        for (;;) {
+            const int nact = __builtin_popcountll(__ballot(st == 1));
+            const int nwait = __builtin_popcountll(__ballot(st >= 2));
+            if (nact == 0 || nwait * kWaitNum >= nact * kWaitDen) break;
+            const int l = wl[c];
+            const uint32_t e = lds_u32(wb, c + best - 3);
+            // a candidate can only beat `best` if bytes [best-3 .. best] match too (bytes [0 .. 2] when best == 2)
+            const int pass = ((e ^ scan_end) & mask) == 0;
+            const int go = (st == 1) & !pass;
+            // leave the candidate: count it and follow its link; `cur_match > limit` is distance < kMaxDist
+            const int ne = n_eval + 1, nc = c - l;
+            const int stop = (ne >= K) | (p - nc >= kMaxDist);
+            n_eval = go ? ne : n_eval;
+            c = (go & !stop) ? nc : c;
+            st = (st == 1) ? (pass ? 2 : (stop ? 3 : 1)) : st;
         }
-        // a candidate can only beat `best` if bytes [best-3 .. best] match too (bytes [0 .. 2]
-        // when best == 2: the byte before the strings is masked out)
-#pragma unroll
-        for (int k = 0; k < NW; k++) {
-            pass[k] = (W[k].st == 2) |
-                      ((W[k].st == 1) & (((e[k] ^ W[k].scan_end) & (W[k].best == 2 ? 0xFFFFFF00u : 0xFFFFFFFFu)) == 0));
-            len[k] = 0;
-            adv[k] = W[k].st != 0;
+        // ---- compare phase: up to 32 bytes per visit
+        if (st == 2) {
+            int off = cl, len = -1;
+            for (int r = 0; r < 4; r++) {
+                const uint64_t x = lds_u64(wb, p + off) ^ lds_u64(wb, c + off);
+                if (x) {
+                    len = off + (int)(__builtin_ctzll(x) >> 3);
+                    break;
+                }
+                off += 8;
+                if (off >= kMaxMatch) break;
+            }
+            if (len < 0 && off >= kMaxMatch) len = kMaxMatch;
+            if (len < 0) {
+                cl = off;  // still equal: continue at the next visit
+            } else {
+                len = len > kMaxMatch ? kMaxMatch : len;
+                int nice_hit = 0;
+                if (len > best) {
+                    // the record for budget K>>2 is the state after candidate number K>>2: an improvement by a
+                    // later candidate freezes the record as it was
+                    if (n_eval >= K4 && !snapped) snapped = 1, snap = best >= kMinMatch ? pack_match(best, bdist) : kNoMatch;
+                    best = len;
+                    bdist = p - c;
+                    scan_end = lds_u32(wb, p + len - 3);
+                    mask = 0xFFFFFFFFu;
+                    nice_hit = len >= nice;
+                }
+                cl = 0;
+                n_eval++;
+                const int nc = c - wl[c];
+                const int stop = nice_hit | (n_eval >= K) | (p - nc >= kMaxDist);
+                c = stop ? c : nc;
+                st = stop ? 3 : 1;
+            }
         }
-#pragma unroll
-        for (int k = 0; k < NW; k++)
-            if (pass[k]) compare8(W[k], len[k], adv[k]);
-#pragma unroll
-        for (int k = 0; k < NW; k++) finish_step(W[k], l[k], len[k], adv[k]);
     }
 }
 
