@@ -730,6 +730,79 @@ __global__ __launch_bounds__(256) void zs_emit_syms_kernel(const StreamDesc *sd,
     for (int i = threadIdx.x; i < sh_cnt; i += 256) o[i] = sbuf[i];
 }
 
+// K5, lane-per-chunk form: every lane walks one chunk from its entry node straight out of HBM (a lane's reads
+// run along consecutive positions, so each 128-byte line of `mm` serves 16 steps out of L1/L2) and writes its
+// symbols in place.  All chunks of the batch walk at once, so the ~1000 dependent steps of a chunk are paid
+// once per launch, not once per workgroup.
+struct GlobalSymSink {
+    uint32_t *out;   // the chunk's first symbol
+    uint32_t base;   // its stream-global index
+    int32_t *blk_end, *blk_top;
+    __device__ void operator()(int i, uint32_t sym, int64_t end, int64_t top) {
+        out[i] = sym;
+        uint32_t idx = base + (uint32_t)i;
+        if ((idx + 1) % kBlockSyms == 0) {
+            uint32_t bi = idx / kBlockSyms;
+            blk_end[bi] = (int32_t)end;
+            blk_top[bi] = (int32_t)top;
+        }
+    }
+};
+__global__ __launch_bounds__(64) void zs_emit_syms_lane_kernel(const StreamDesc *sd, const uint2 *work, int nwork, const uint2 *mm,
+                                                               const uint16_t *entry, const uint32_t *symbase, uint32_t *syms,
+                                                               int32_t *blk_end, int32_t *blk_top, const uint32_t *crc_tab_g,
+                                                               LevelCfg lv, int strategy, int hash_variant) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= nwork) return;
+    const uint2 w = work[i];
+    const StreamDesc s = sd[w.x];
+    const int c = (int)w.y;
+    GlobalAcc acc{s.in, mm + s.pos_off, crc_tab_g, strategy, hash_variant};
+    const uint32_t base = symbase[s.chunk_off + c];
+    GlobalSymSink sink{syms + s.sym_off + base, base, blk_end + s.blk_off, blk_top + s.blk_off};
+    // the refill-rule prefix (first chunks of segments) by the shared code, then plain automaton steps
+    int kind, ns;
+    int64_t p;
+    bool equal;
+    chunk_special_prefix(acc, sink, c, (int)entry[s.chunk_off + c], s.kl, s.body_end, lv, strategy, kind, p, ns, equal);
+    const ChunkGeo g = chunk_geo(c);
+    int64_t ce = g.ce;
+    if (ce > (int64_t)s.body_end + 1) ce = (int64_t)s.body_end + 1;
+    if (p >= ce) return;
+    // A step's successor is p+1 or, when the pending match is emitted, p-1+len(pend): both records (and the
+    // literal byte a step at p+1 may emit) are requested one step ahead, so the dependent chain sees the load
+    // latency of a step only where it exceeds the arithmetic of the step before.
+    const uint2 *a = acc.mm;
+    const int64_t last = (int64_t)s.n - 1;
+    uint32_t pend = kNoMatch;
+    if (kind == kXK) pend = acc.mK(p - 1);
+    else if (kind == kXK4) pend = acc.mK4(p - 1);
+    uint2 cur = a[p];
+    uint8_t lit = p >= 1 ? s.in[p - 1] : 0;
+    while (p < ce) {
+        int64_t qa = p + 1, qb = pend ? p - 1 + match_len(pend) : qa;
+        if (qa > last) qa = last;
+        if (qb > last) qb = last;
+        const uint2 na = a[qa], nb = a[qb];
+        const uint8_t nlit = s.in[p];
+        uint32_t cK = acc.flt(cur.x), cK4 = acc.flt(cur.y);
+        if (p == 0) cK = cK4 = kNoMatch;
+        const Step st = lazy_step(kind, p, pend, cK, cK4, lv);
+        if (st.emit) {
+            const uint32_t sym = st.emit == 1 ? (uint32_t)lit : (((uint32_t)st.dist << 16) | (uint32_t)(st.len - 3));
+            sink(ns, sym, st.emit == 1 ? p : p - 1 + st.len, p);
+            ns++;
+        }
+        if (st.kind == kXK) pend = cK;
+        else if (st.kind == kXK4) pend = cK4;
+        else pend = kNoMatch;
+        kind = st.kind;
+        cur = st.pos == p + 1 ? na : nb;
+        lit = nlit;
+        p = st.pos;
+    }
+}
+
 // ------------------------------------------------------------------ K6
 // One wave per stream; all lanes run the engine uniformly.  Also turns the
 // block cuts recorded by K5 into BlockRec entries.
