@@ -101,6 +101,11 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
     LevelCfg lv = level_cfg(level);
     Plan pl;
     pl.sd.resize((size_t)n);
+    // positions per workgroup of the link kernel (each replays 32 Ki positions of warm-up first): long spans for a
+    // big batch, shorter ones when that is what it takes to give every CU a workgroup
+    int64_t total_len = 0;
+    for (int i = 0; i < n; i++) total_len += in_len[i];
+    const int64_t link_span = total_len >= (48ll << 20) ? 262144 : total_len >= (24ll << 20) ? 131072 : 65536;
     for (int i = 0; i < n; i++) {
         StreamDesc &s = pl.sd[(size_t)i];
         int64_t len = in_len[i];
@@ -138,7 +143,7 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
         for (int64_t k = 0; k * 65536 < s.out_cap; k++) pl.w_clear.push_back(make_uint2((unsigned)i, (unsigned)k));
         for (int k = 0; k < s.n_adler; k++) pl.w_adler.push_back(make_uint2((unsigned)i, (unsigned)k));
         if (s.body_end >= 0 || s.fast_runs > 0)
-            for (int64_t t = 0; t * kLinkTile < len - 5; t++) pl.w_links.push_back(make_uint2((unsigned)i, (unsigned)t));
+            for (int64_t t = 0; t * link_span < len - 5; t++) pl.w_links.push_back(make_uint2((unsigned)i, (unsigned)t));
         if (s.body_end >= 0) {
             for (int64_t t = 0; t * kMatchTile <= s.body_end; t++) pl.w_match.push_back(make_uint2((unsigned)i, (unsigned)t));
             for (int k = 0; k < s.nchunks; k++) pl.w_chunks.push_back(make_uint2((unsigned)i, (unsigned)k));
@@ -215,8 +220,8 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
                            dev<uint32_t>(c->pieces));
     mark(2);
     if (!pl.w_links.empty())
-        hipLaunchKernelGGL(zs_links_kernel, dim3((unsigned)pl.w_links.size()), dim3(64), 0, stream, d_sd, d_work + o_links,
-                           dev<uint16_t>(c->link), c->crc_tab, hash_variant);
+        hipLaunchKernelGGL(zs_links_kernel, dim3((unsigned)pl.w_links.size()), dim3(1024), kLkLds, stream, d_sd, d_work + o_links,
+                           dev<uint16_t>(c->link), c->crc_tab, hash_variant, (int)link_span);
     mark(3);
     if (strategy == kHuffmanOnly) {
         // Longest_match is never called (Deflate.Slow.cs:66-71): every position has no match
@@ -367,6 +372,7 @@ int zs_ctx_create(int device, zs_ctx **out) {
         hipMemcpy(c->crc_tab, tab.data(), 4096, hipMemcpyHostToDevice) != hipSuccess ||
         hipFuncSetAttribute((const void *)zs_match_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kMatchLds) != hipSuccess ||
         hipFuncSetAttribute((const void *)zs_emit_syms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kEmitLds) != hipSuccess ||
+        hipFuncSetAttribute((const void *)zs_links_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLkLds) != hipSuccess ||
         hipFuncSetAttribute((const void *)zs_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kTailLds) != hipSuccess ||
         hipFuncSetAttribute((const void *)zs_fast_run_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kTailLds) != hipSuccess ||
         hipFuncSetAttribute((const void *)zs_inflate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kInfLds) != hipSuccess) {

@@ -63,70 +63,166 @@ __global__ void zs_clear_kernel(const StreamDesc *sd, const uint2 *work) {
 }
 
 // ------------------------------------------------------------------ K1
-// One wave per 32 Ki-position tile.  The wave replays InsertString over
-// [t0 - kLinkWarm, t0 + kLinkTile) 64 positions at a time with the 32 Ki-entry
-// head table in LDS; positions inside the tile get link = distance to the
-// previous position of the same bucket (0 if none within kMaxDist).
-__global__ __launch_bounds__(64) void zs_links_kernel(const StreamDesc *sd, const uint2 *work, uint16_t *link,
-                                                      const uint32_t *crc_tab_g, int hash_variant) {
-    __shared__ uint16_t head[kHashSize];
-    __shared__ uint32_t tab[1024];
-    const int lane = lane_id();
-    uint2 w = work[blockIdx.x];
+// InsertString replayed in absolute coordinates: link[q] = distance from q to the previous position of q's
+// bucket (0 if none within kMaxDist).  The replay is sequential only within a bucket, so a 1024-thread workgroup
+// takes its span 16 Ki positions at a time and splits every tile by bucket class (h & 15): phase 1 hashes the
+// tile and ranks every position inside its (wave, class) cell with ballots, phase 2 turns the 16 x 16 cell counts
+// into offsets, phase 3 scatters (h, index) into 16 position-ordered class lists in LDS, and in phase 4 wave k
+// replays list k against the shared 32 Ki-entry head table, 64 entries per step: lanes of one wave execute DS
+// operations in lane order, so every lane reads the old head before any lane's store and a read-back shows which
+// lane won a bucket; buckets hit by several lanes of a step are then linked lane to lane.  The head table lives in
+// LDS for the whole span (entries are positions relative to a base that moves with the tile, re-based by 16 Ki per
+// tile like SlideHash), after 32 Ki positions of warm-up before the span.
+constexpr int kLkTile = 16384;
+constexpr int kLkWarm = 32768;  // >= kMaxDist, multiple of kLkTile
+constexpr int kLkLds = 2 * kHashSize + 4 * kLkTile + 4096 + 2 * 16 * 16 * 2 + 64 * 4;
+__global__ __launch_bounds__(1024) void zs_links_kernel(const StreamDesc *sd, const uint2 *work, uint16_t *link,
+                                                        const uint32_t *crc_tab_g, int hash_variant, int span) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint16_t *head = (uint16_t *)smem;                         // kHashSize, 0xFFFF = empty
+    uint32_t *list = (uint32_t *)(smem + 2 * kHashSize);       // kLkTile: (h << 16) | index in tile, grouped by class
+    uint32_t *tab = list + kLkTile;                            // 1024
+    uint16_t *cntw = (uint16_t *)(tab + 1024);                 // [wave][class]
+    uint16_t *coff = cntw + 256;                               // [class][wave] start of the cell in `list`
+    uint32_t *cstart = (uint32_t *)(coff + 256);               // [17] start of each class list
+    const int tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
+    const uint2 w = work[blockIdx.x];
     const StreamDesc s = sd[w.x];
     const uint8_t *in = s.in;
-    const int64_t t0 = (int64_t)w.y * kLinkTile;
-    const int64_t qend_stream = (int64_t)s.n - 5;  // positions q with q + 5 < n
-    if (t0 >= qend_stream) return;
-    for (int i = lane; i < kHashSize / 2; i += 64) ((uint32_t *)head)[i] = 0;
-    load_crc_tab(tab, crc_tab_g);
-    __syncthreads();
-    int64_t w0 = t0 - kLinkWarm;
+    const int64_t qend = (int64_t)s.n - 5;  // positions q with q + 5 < n are inserted
+    const int64_t span0 = (int64_t)w.y * span;
+    if (span0 >= qend) return;
+    int64_t span_end = span0 + span;
+    if (span_end > qend) span_end = qend;
+    int64_t w0 = span0 - kLkWarm;
     if (w0 < 0) w0 = 0;
-    int64_t tend = t0 + kLinkTile;
-    if (tend > qend_stream) tend = qend_stream;
+    for (int i = tid; i < kHashSize / 2; i += 1024) ((uint32_t *)head)[i] = 0xFFFFFFFFu;
+    load_crc_tab(tab, crc_tab_g);
     uint16_t *lk = link + s.pos_off;
-    // Software pipeline, two groups deep: the 4 input bytes of group g+2 and the bucket of group g+1 are in flight
-    // while group g goes through the head table, so an iteration costs one LDS round trip, not three.
-    auto load4 = [&](int64_t q) -> uint32_t { return q < tend ? *(const u32u *)(in + q + 2) : 0u; };
-    uint32_t v1 = load4(w0 + lane);           // bytes of the group after the current one
-    uint32_t hcur = dev_bucket(tab, v1, hash_variant);
-    v1 = load4(w0 + 64 + lane);
-    for (int64_t g = w0; g < tend; g += 64) {
-        const int64_t q = g + lane;
-        const bool valid = q < tend;
-        const uint32_t h = valid ? hcur : 0xFFFFFFFFu;
-        const uint32_t vnext = v1;
-        v1 = load4(q + 128);
-        hcur = dev_bucket(tab, vnext, hash_variant);  // bucket of group g+1: its table reads are issued before the head ops below
-        const uint32_t rel = (uint32_t)(q - w0 + 1);  // 1..65280
-        uint32_t prevrel = 0, rb = 0;
-        if (valid) {
-            // lanes of one wave execute DS ops in order: every lane reads the old head before any lane's store, and
-            // the read-back after the stores shows which lane won each bucket
-            // (volatile: other lanes store to the same entry, the read-back must not be forwarded from this lane's store)
-            volatile uint16_t *vh = head;
-            prevrel = vh[h];
-            vh[h] = (uint16_t)rel;
-            rb = vh[h];
-        }
-        uint64_t lost = __ballot(valid && rb != rel);
-        while (lost) {  // one round per bucket hit by more than one lane
-            int leader = __builtin_ctzll(lost);
-            uint32_t hb = (uint32_t)__shfl((int)h, leader);
-            uint64_t grp = __ballot(valid && h == hb);
-            if (valid && h == hb) {
-                uint64_t lower = grp & lanemask_lt();
-                if (lower) prevrel = rel - (uint32_t)(lane - (63 - __builtin_clzll(lower)));
-                if ((grp >> lane) == 1ull) head[h] = (uint16_t)rel;  // highest lane of the group
+    constexpr uint32_t kRel0 = 32768;  // position t0 + i is stored as kRel0 + i
+    for (int64_t t0 = w0; t0 < span_end; t0 += kLkTile) {
+        if (t0 != w0) {
+            // re-base the table by one tile; entries further back than 32 Ki positions drop out
+            for (int i = tid; i < kHashSize / 2; i += 1024) {
+                const uint32_t v = ((uint32_t *)head)[i];
+                uint32_t lo = v & 0xFFFFu, hi = v >> 16;
+                lo = (lo == 0xFFFFu || lo < (uint32_t)kLkTile) ? 0xFFFFu : lo - kLkTile;
+                hi = (hi == 0xFFFFu || hi < (uint32_t)kLkTile) ? 0xFFFFu : hi - kLkTile;
+                ((uint32_t *)head)[i] = lo | (hi << 16);
             }
-            lost &= ~grp;
         }
-        if (valid && q >= t0) {
-            uint32_t d = prevrel ? rel - prevrel : 0;
-            if (d > (uint32_t)kMaxDist) d = 0;
-            lk[q] = (uint16_t)d;
+        int64_t tend = t0 + kLkTile;
+        if (tend > span_end) tend = span_end;
+        const int tlen = (int)(tend - t0);
+        // ---- phase 1: buckets, and the rank of every position inside its (wave, class) cell
+        uint32_t hh[16];  // bucket, 0xFFFF0000 | .. when the position is past the end
+        uint16_t rk[16];
+        uint32_t run[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) run[k] = 0;
+#pragma unroll
+        for (int g = 0; g < 16; g++) {
+            const int idx = wave * 1024 + g * 64 + lane;
+            const bool valid = idx < tlen;
+            uint32_t h = 0;
+            if (valid) h = dev_bucket(tab, *(const u32u *)(in + t0 + idx + 2), hash_variant);
+            const int cls = valid ? (int)(h & 15u) : 16;
+            uint32_t r = 0;
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const uint64_t b = __ballot(cls == k);
+                const uint32_t below = (uint32_t)__builtin_popcountll(b & lanemask_lt());
+                r = cls == k ? run[k] + below : r;
+                run[k] += (uint32_t)__builtin_popcountll(b);  // wave-uniform
+            }
+            hh[g] = valid ? h : 0xFFFFFFFFu;
+            rk[g] = (uint16_t)r;
         }
+#pragma unroll
+        for (int k = 0; k < 16; k++)
+            if (lane == k) cntw[wave * 16 + k] = (uint16_t)run[k];
+        __syncthreads();
+        // ---- phase 2: cell offsets (class-major, waves in order inside a class)
+        if (tid < 256) {
+            const int k = tid >> 4, ww = tid & 15;
+            uint32_t off = 0;
+            for (int k2 = 0; k2 < k; k2++)
+                for (int w2 = 0; w2 < 16; w2++) off += cntw[w2 * 16 + k2];
+            if (ww == 0) cstart[k] = off;
+            for (int w2 = 0; w2 < ww; w2++) off += cntw[w2 * 16 + k];
+            coff[k * 16 + ww] = (uint16_t)off;
+            if (tid == 255) cstart[16] = off + cntw[15 * 16 + 15];
+        }
+        __syncthreads();
+        // ---- phase 3: scatter into the class lists
+#pragma unroll
+        for (int g = 0; g < 16; g++) {
+            if (hh[g] != 0xFFFFFFFFu) {
+                const uint32_t h = hh[g];
+                list[(uint32_t)coff[(h & 15u) * 16 + wave] + rk[g]] = (h << 16) | (uint32_t)(wave * 1024 + g * 64 + lane);
+            }
+        }
+        __syncthreads();
+        // ---- phase 4: wave k replays class k
+        {
+            const uint32_t cb = cstart[wave], ce = cstart[wave + 1];
+            const bool store = t0 >= span0;
+            volatile uint16_t *vh = head;
+            for (uint32_t i0 = cb; i0 < ce; i0 += 64) {
+                const uint32_t i = i0 + (uint32_t)lane;
+                const bool valid = i < ce;
+                const uint32_t e = valid ? list[i] : 0xFFFFFFFFu;
+                const uint32_t h = e >> 16, idx = e & 0x3FFFu;
+                const uint32_t rel = kRel0 + idx;
+                // Lanes of one wave execute DS operations in lane order: every lane reads the old head before any
+                // lane's store, and after the stores the highest lane of each bucket reads back its own value ("won").
+                // Its predecessor and those of the lanes that lost are found in one of two ways.  (a) One bucket per
+                // round with ballots only: the lanes of the leader's bucket link to each other by lane order (rounds =
+                // buckets hit more than once; one round for a run of equal bytes).  (b) All buckets together: the lanes
+                // that lost store again, the new winner of a bucket is the predecessor of the lane that won it the
+                // round before, which sees that in its own read-back (rounds = most lanes sharing a bucket; periodic
+                // data has many buckets a few times each).  (a) runs first and hands over to (b) when many lanes remain.
+                // (volatile: other lanes store to the same entries, nothing may be forwarded from this lane's stores)
+                const uint32_t hx = valid ? h : 0;  // in-range index for lanes past the end (they never store)
+                const uint32_t old = vh[hx];
+                if (valid) vh[hx] = (uint16_t)rel;
+                uint32_t rb = vh[hx];
+                const bool won = valid && rb == rel;
+                bool active = valid && !won, waiting = won;
+                uint32_t prevrel = old;
+                uint64_t lost = __ballot(active);
+                for (int it = 0; lost && (it == 0 || __builtin_popcountll(lost) < 36); it++) {
+                    const int leader = __builtin_ctzll(lost);
+                    const uint32_t hb = (uint32_t)__shfl((int)h, leader);
+                    const bool mine = valid && h == hb;
+                    const uint64_t grp = __ballot(mine);
+                    const uint64_t lower = grp & lanemask_lt();
+                    const int src = lower ? 63 - __builtin_clzll(lower) : lane;
+                    const uint32_t below = (uint32_t)__shfl((int)rel, src);
+                    if (mine) {
+                        if (lower) prevrel = below;
+                        active = false, waiting = false;
+                    }
+                    lost &= ~grp;
+                }
+                if (lost) {
+                    for (;;) {
+                        if (active) vh[hx] = (uint16_t)rel;
+                        rb = vh[hx];
+                        if (waiting && rb != rel) prevrel = rb, waiting = false;  // this round's winner is right below me
+                        if (active && rb == rel) active = false, waiting = true, prevrel = old;
+                        if (!__ballot(active)) break;
+                    }
+                    if (won) vh[hx] = (uint16_t)rel;  // the later rounds overwrote the final head
+                }
+                if (valid && store) {
+                    uint32_t d = prevrel != 0xFFFFu ? rel - prevrel : 0;
+                    if (d > (uint32_t)kMaxDist) d = 0;
+                    lk[t0 + idx] = (uint16_t)d;
+                }
+            }
+        }
+        __syncthreads();
     }
 }
 
