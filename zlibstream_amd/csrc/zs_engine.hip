@@ -239,7 +239,7 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
         hipLaunchKernelGGL(zs_segmap_kernel, dim3((unsigned)pl.w_segs.size()), dim3(320), 0, stream, d_sd, d_work + o_segs,
                            dev<uint32_t>(c->maps), dev<uint2>(c->segmap));
     mark(6);
-    hipLaunchKernelGGL(zs_resolve_kernel, dim3((unsigned)n), dim3(256), 0, stream, d_sd, d_st, dev<uint16_t>(c->link),
+    hipLaunchKernelGGL(zs_resolve_kernel, dim3((unsigned)n), dim3(1024), kResolveLds, stream, d_sd, d_st, dev<uint16_t>(c->link),
                        dev<uint2>(c->mm), dev<uint32_t>(c->maps), dev<uint2>(c->segmap),
                        dev<uint16_t>(c->seg_entry), dev<uint32_t>(c->seg_symbase), dev<uint8_t>(c->stale),
                        dev<uint8_t>(c->seg_stale), c->crc_tab, lv, strategy, hash_variant);
@@ -372,6 +372,7 @@ int zs_ctx_create(int device, zs_ctx **out) {
         hipMemcpy(c->crc_tab, tab.data(), 4096, hipMemcpyHostToDevice) != hipSuccess ||
         hipFuncSetAttribute((const void *)zs_match_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kMatchLds) != hipSuccess ||
         hipFuncSetAttribute((const void *)zs_emit_syms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kEmitLds) != hipSuccess ||
+        hipFuncSetAttribute((const void *)zs_resolve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kResolveLds) != hipSuccess ||
         hipFuncSetAttribute((const void *)zs_links_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLkLds) != hipSuccess ||
         hipFuncSetAttribute((const void *)zs_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kTailLds) != hipSuccess ||
         hipFuncSetAttribute((const void *)zs_fast_run_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kTailLds) != hipSuccess ||

@@ -541,7 +541,8 @@ __global__ __launch_bounds__(320) void zs_segmap_kernel(const StreamDesc *sd, co
     segmap[((int64_t)s.seg_off + seg) * kSlots + entry_slot] = make_uint2((uint32_t)slot | flags, total);
 }
 
-constexpr int kSegBatch = 16;
+constexpr int kSegBatch = 64;
+constexpr int kResolveLds = kSegBatch * kSlots * 8 + 4096 + kSegBatch * 8;
 // ------------------------------------------------------------------ K4
 // One workgroup per stream.  Thread 0 follows the true parse path through the segment
 // maps (one dependent lookup per 32 Ki positions).  At a refill loop-top s_k whose bucket
@@ -550,12 +551,18 @@ constexpr int kSegBatch = 16;
 // bucket: the workgroup cuts link[s_k], re-walks the positions whose recorded winner lies
 // behind the cut, and marks the chunks whose matches changed; segments holding such
 // chunks are then followed chunk by chunk, stale chunks by a direct walk.
-__global__ __launch_bounds__(256) void zs_resolve_kernel(const StreamDesc *sd, StreamState *st, uint16_t *link, uint2 *mm,
+__global__ __launch_bounds__(1024) void zs_resolve_kernel(const StreamDesc *sd, StreamState *st, uint16_t *link, uint2 *mm,
                                                          const uint32_t *maps, const uint2 *segmap,
                                                          uint16_t *seg_entry, uint32_t *seg_symbase, uint8_t *stale,
                                                          uint8_t *seg_stale, const uint32_t *crc_tab_g, LevelCfg lv,
                                                          int strategy, int hash_variant) {
-    __shared__ uint32_t tab[1024];
+    // > 64 KiB of LDS: dynamic allocation, carved by hand
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint2 *rows = (uint2 *)smem;                                  // segment-map rows of the current batch (130 KiB)
+    uint32_t *tab = (uint32_t *)(smem + kSegBatch * kSlots * 8);   // 1024
+    uint32_t *out_base = tab + 1024;                              // per segment of the batch: first-symbol index,
+    uint16_t *out_slot = (uint16_t *)(out_base + kSegBatch);      // entry slot,
+    uint8_t *row_stale = (uint8_t *)(out_slot + kSegBatch);       // stale flag
     __shared__ int sh_seg, sh_slot, sh_scan, sh_kfired, sh_preins;
     __shared__ uint32_t sh_total;
     const StreamDesc s = sd[blockIdx.x];
@@ -571,15 +578,17 @@ __global__ __launch_bounds__(256) void zs_resolve_kernel(const StreamDesc *sd, S
     uint2 *a = mm + s.pos_off;
     GlobalAcc acc{s.in, a, tab, strategy, hash_variant};
     const int nseg = s.nsegs, nch = s.nchunks;
-    __shared__ uint2 rows[kSegBatch * kSlots];  // segment-map rows of the current batch (33 KiB)
-    __shared__ uint8_t row_stale[kSegBatch];
     for (;;) {
-        // ---- stage the next kSegBatch segment-map rows (coalesced), then thread 0 follows the path through them;
-        //      it stops early when a refill needs the whole workgroup ----
+        // ---- stage the next kSegBatch segment-map rows (coalesced), then thread 0 follows the path through them
+        //      (one LDS lookup per segment; its per-segment results go out coalesced afterwards); it stops early
+        //      when a refill needs the whole workgroup ----
         const int seg0 = sh_seg;
         int nrow = nseg - seg0;
         if (nrow > kSegBatch) nrow = kSegBatch;
-        for (int i = threadIdx.x; i < nrow * kSlots; i += blockDim.x) rows[i] = segmap[((int64_t)s.seg_off + seg0) * kSlots + i];
+        {
+            const uint4 *src = (const uint4 *)(segmap + ((int64_t)s.seg_off + seg0) * kSlots);  // kSlots is even: 16-byte aligned
+            for (int i = threadIdx.x; i < nrow * kSlots / 2; i += blockDim.x) ((uint4 *)rows)[i] = src[i];
+        }
         if (threadIdx.x < nrow) row_stale[threadIdx.x] = seg_stale[s.seg_off + seg0 + threadIdx.x];
         __syncthreads();
         if (threadIdx.x == 0) {
@@ -587,11 +596,12 @@ __global__ __launch_bounds__(256) void zs_resolve_kernel(const StreamDesc *sd, S
             uint32_t total = sh_total;
             bool scanned = sh_scan != 0;  // the pending segment's cut has just been applied
             sh_scan = 0;
+            const int last_event_seg = s.kl < seg0 + nrow - 1 ? s.kl : seg0 + nrow - 1;
             while (seg < seg0 + nrow) {
-                const int c0 = seg_first_chunk(seg);
                 const uint2 v = rows[(seg - seg0) * kSlots + slot];
-                if (seg >= 1 && seg <= s.kl) {
-                    int64_t e = slot <= 256 ? chunk_geo(c0).cs + slot : chunk_geo(c0).cs;
+                if (seg >= 1 && seg <= last_event_seg) {
+                    const int64_t cs = (int64_t)kSeg0 + (int64_t)(seg - 1) * kWSize;  // segment_start(seg)
+                    const int64_t e = slot <= 256 ? cs + slot : cs;
                     if (e <= s.body_end) {
                         sh_kfired = seg, sh_preins = (int)(e + 1);
                         if ((v.x & kMapEqualBit) && strategy != kHuffmanOnly && !scanned) {
@@ -601,9 +611,10 @@ __global__ __launch_bounds__(256) void zs_resolve_kernel(const StreamDesc *sd, S
                     }
                 }
                 scanned = false;
-                seg_entry[s.seg_off + seg] = (uint16_t)slot;
-                seg_symbase[s.seg_off + seg] = total;
+                out_slot[seg - seg0] = (uint16_t)slot;
+                out_base[seg - seg0] = total;
                 if (row_stale[seg - seg0]) {
+                    const int c0 = seg_first_chunk(seg);
                     int c1 = seg_first_chunk(seg + 1);
                     if (c1 > nch) c1 = nch;
                     for (int cc = c0; cc < c1; cc++) {
@@ -627,6 +638,10 @@ __global__ __launch_bounds__(256) void zs_resolve_kernel(const StreamDesc *sd, S
             sh_seg = seg, sh_slot = slot, sh_total = total;
         }
         __syncthreads();
+        for (int i = threadIdx.x; i < sh_seg - seg0; i += blockDim.x) {
+            seg_entry[s.seg_off + seg0 + i] = out_slot[i];
+            seg_symbase[s.seg_off + seg0 + i] = out_base[i];
+        }
         if (!sh_scan) {
             if (sh_seg >= nseg) break;
             continue;

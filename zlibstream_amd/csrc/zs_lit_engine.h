@@ -113,6 +113,32 @@ ZS_HD int le_insert(LitEngine &e, int str) {
     return cur;
 }
 
+// The slide of Fill_window (Deflate.cs:979-999: BlockCopy of the upper window half, SlideHash over head and
+// prev).  kWSize is bit 15, so `v >= WSIZE ? v - WSIZE : 0` is "keep the low 15 bits where bit 15 is set"; on the
+// device the three arrays (16-byte aligned) move 16 bytes per lane and step.
+ZS_HD void le_slide(LitEngine &e, int lane, int nlanes) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    struct V4 { uint32_t x[4]; };
+    auto slide16 = [&](uint16_t *a, int count) {
+        V4 *v = (V4 *)a;
+        for (int i = lane; i < count / 8; i += nlanes) {
+            V4 t = v[i];
+#pragma unroll
+            for (int k = 0; k < 4; k++) t.x[k] = t.x[k] & 0x7FFF7FFFu & (((t.x[k] >> 15) & 0x00010001u) * 0xFFFFu);
+            v[i] = t;
+        }
+    };
+    V4 *w = (V4 *)e.window;
+    for (int i = lane; i < kWSize / 16; i += nlanes) w[i] = w[i + kWSize / 16];
+    slide16(e.head, kHashSize);
+    slide16(e.prev, kWSize);
+#else
+    for (int i = lane; i < kWSize; i += nlanes) e.window[i] = e.window[i + kWSize];
+    for (int i = lane; i < kHashSize; i += nlanes) e.head[i] = (uint16_t)(e.head[i] >= kWSize ? e.head[i] - kWSize : 0);
+    for (int i = lane; i < kWSize; i += nlanes) e.prev[i] = (uint16_t)(e.prev[i] >= kWSize ? e.prev[i] - kWSize : 0);
+#endif
+}
+
 // Deflate.cs:967-1019.  The whole remaining input is available (single Write
 // already issued, flush == Finish).
 ZS_HD_NOINLINE inline void le_fill_window(LitEngine &e, int lane, int nlanes) {
@@ -121,9 +147,7 @@ ZS_HD_NOINLINE inline void le_fill_window(LitEngine &e, int lane, int nlanes) {
         if (e.strstart >= kSlideAt) {
             ZS_WAVE_SYNC();
             // lane-strided: each i is read and written by one lane only
-            for (int i = lane; i < kWSize; i += nlanes) e.window[i] = e.window[i + kWSize];
-            for (int i = lane; i < kHashSize; i += nlanes) e.head[i] = (uint16_t)(e.head[i] >= kWSize ? e.head[i] - kWSize : 0);
-            for (int i = lane; i < kWSize; i += nlanes) e.prev[i] = (uint16_t)(e.prev[i] >= kWSize ? e.prev[i] - kWSize : 0);
+            le_slide(e, lane, nlanes);
             ZS_WAVE_SYNC();
             e.match_start -= kWSize;
             e.strstart -= kWSize;
