@@ -1376,16 +1376,36 @@ struct LdsTree {
         return {(uint16_t)v, (uint16_t)(v >> 16)};
     }
 };
-// One workgroup per block.  Each thread owns a contiguous run of the block's
-// symbols: pass 1 sums the run's bit lengths, a workgroup scan turns the sums
-// into bit offsets, pass 2 packs the run through a 64-bit accumulator and ORs
-// whole words into the (pre-zeroed) output.
+// One workgroup per block.  The block's bit string is assembled in LDS and leaves as whole 32-bit words: thread 0
+// puts the block header (and the dynamic trees) at the front; then, 2048 symbols at a time, every thread takes 8
+// consecutive symbols, a workgroup scan of their code lengths gives each thread its bit offset, the codes are
+// OR-ed into the LDS words (ds_or), and the complete words are stored coalesced.  The partial word at the end of a
+// tile is carried into the next tile; only the first and the last word of a block can be shared with its
+// neighbours, and only those go out with atomicOr (the output was zeroed by K0).
+constexpr int kEbTile = 2048;                            // symbols per tile
+constexpr int kEbWords = kEbTile * 48 / 32 + 256;        // worst case 48 bits per symbol + dynamic header (<= 141 words) + carry
+struct LdsBitPut {
+    uint32_t *w;   // zeroed words
+    uint32_t pos;  // bit position
+    __device__ void put64(uint64_t v, int nbits) {  // nbits <= 57
+        if (nbits == 0) return;
+        const uint32_t k = pos >> 5, sh = pos & 31;
+        const uint64_t lo = v << sh;
+        const uint32_t w0 = (uint32_t)lo, w1 = (uint32_t)(lo >> 32), w2 = sh ? (uint32_t)(v >> (64 - sh)) : 0;
+        if (w0) atomicOr(&w[k], w0);
+        if (w1) atomicOr(&w[k + 1], w1);
+        if (w2) atomicOr(&w[k + 2], w2);
+        pos += (uint32_t)nbits;
+    }
+    __device__ void operator()(unsigned value, int nbits) { put64(value, nbits); }
+};
 __global__ __launch_bounds__(256) void zs_emit_bits_kernel(const StreamDesc *sd, const StreamState *st, const uint2 *work,
                                                            const uint32_t *syms, const BlockRec *blocks, const TreeWork *trees,
                                                            const BlockInfo *info) {
     __shared__ uint32_t lt[kLCodes], dt[kDCodes];
-    __shared__ uint32_t scan[256];
-    __shared__ int64_t sh_body;
+    __shared__ uint32_t obuf[kEbWords];
+    __shared__ uint32_t wsum[4];
+    __shared__ uint32_t sh_bits;
     uint2 w = work[blockIdx.x];
     const StreamDesc s = sd[w.x];
     const int b = (int)w.y;
@@ -1393,78 +1413,126 @@ __global__ __launch_bounds__(256) void zs_emit_bits_kernel(const StreamDesc *sd,
     const BlockRec r = blocks[s.blk_off + b];
     const BlockInfo bi = info[s.blk_off + b];
     uint8_t *out = s.out;
+    const int tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
     if (bi.type == 0) {
         int64_t pos = bi.bit_start;
-        if (threadIdx.x == 0) or_bits(out, pos, (uint64_t)(r.eof ? 1 : 0), 3);
+        if (tid == 0) or_bits(out, pos, (uint64_t)(r.eof ? 1 : 0), 3);
         int64_t byte = (pos + 3 + 7) >> 3;
-        if (threadIdx.x == 0) {
+        if (tid == 0) {
             unsigned len = (unsigned)r.stored_len;
             out[byte] = (uint8_t)len, out[byte + 1] = (uint8_t)(len >> 8);
             out[byte + 2] = (uint8_t)~len, out[byte + 3] = (uint8_t)(~len >> 8);
         }
         const uint8_t *src = s.in + r.start;
         uint8_t *dst = out + byte + 4;
-        for (int i = threadIdx.x; i < r.stored_len; i += 256) dst[i] = src[i];
+        for (int i = tid; i < r.stored_len; i += 256) dst[i] = src[i];
         return;
     }
     const TreeWork &tw = trees[s.blk_off + b];
     if (bi.type == 2) {
-        for (int i = threadIdx.x; i < kLCodes; i += 256) lt[i] = (uint32_t)tw.ltree[i].fc | ((uint32_t)tw.ltree[i].dl << 16);
-        if (threadIdx.x < kDCodes) dt[threadIdx.x] = (uint32_t)tw.dtree[threadIdx.x].fc | ((uint32_t)tw.dtree[threadIdx.x].dl << 16);
+        for (int i = tid; i < kLCodes; i += 256) lt[i] = (uint32_t)tw.ltree[i].fc | ((uint32_t)tw.ltree[i].dl << 16);
+        if (tid < kDCodes) dt[tid] = (uint32_t)tw.dtree[tid].fc | ((uint32_t)tw.dtree[tid].dl << 16);
     } else {
-        for (int i = threadIdx.x; i < kLCodes; i += 256) lt[i] = static_lcode(i) | ((uint32_t)static_llen(i) << 16);
-        if (threadIdx.x < kDCodes) dt[threadIdx.x] = bit_reverse((unsigned)threadIdx.x, 5) | (5u << 16);
+        for (int i = tid; i < kLCodes; i += 256) lt[i] = static_lcode(i) | ((uint32_t)static_llen(i) << 16);
+        if (tid < kDCodes) dt[tid] = bit_reverse((unsigned)tid, 5) | (5u << 16);
     }
-    if (threadIdx.x == 0) {
-        OrPut put{out, bi.bit_start};
+    for (int i = tid; i < kEbWords; i += 256) obuf[i] = 0;
+    __syncthreads();
+    // global bit cursor, relative to the 4-byte aligned word at or below `out`
+    uint32_t *const W = (uint32_t *)((uintptr_t)out & ~(uintptr_t)3);
+    int64_t cur = bi.bit_start + (int64_t)(((uintptr_t)out & 3) << 3);
+    if (tid == 0) {
+        LdsBitPut put{obuf, (uint32_t)(cur & 31)};
         put((unsigned)(bi.type << 1) + (r.eof ? 1u : 0u), 3);
         if (bi.type == 2) emit_dyn_header(tw, put);
-        sh_body = put.pos;
+        sh_bits = put.pos - (uint32_t)(cur & 31);
     }
     __syncthreads();
     LdsTree L{lt}, D{dt};
     const uint32_t *sy = syms + s.sym_off + r.sym_start;
-    const int per = (r.nsyms + 255) / 256;
-    int i0 = threadIdx.x * per, i1 = i0 + per;
-    if (i0 > r.nsyms) i0 = r.nsyms;
-    if (i1 > r.nsyms) i1 = r.nsyms;
-    uint32_t mybits = 0;
-    for (int i = i0; i < i1; i++) {
-        uint32_t v = sy[i];
-        uint64_t bits;
-        mybits += (uint32_t)encode_symbol(L, D, (int)(v >> 16), (int)(v & 0xFFFF), bits);
-    }
-    scan[threadIdx.x] = mybits;
-    __syncthreads();
-    for (int off = 1; off < 256; off <<= 1) {
-        uint32_t t = threadIdx.x >= off ? scan[threadIdx.x - off] : 0;
+    const int total = r.nsyms + 1;  // + END_BLOCK
+    bool first = true;              // the next flush starts with the block's first word
+    uint32_t pending = sh_bits;     // bits already in obuf behind (cur & 31)
+    // flush `nb` bits that sit in obuf from bit (cur & 31): complete words out, the partial one carried to obuf[0]
+    auto flush = [&](uint32_t nb, bool last) {
+        const uint32_t end = (uint32_t)(cur & 31) + nb;
+        const uint32_t nfull = end >> 5;
+        uint32_t *g = W + (cur >> 5);
+        const uint32_t carry = obuf[nfull];
         __syncthreads();
-        scan[threadIdx.x] += t;
-        __syncthreads();
-    }
-    int64_t pos = sh_body + (int64_t)(scan[threadIdx.x] - mybits);
-    // pack the run: `acc` holds `fill` pending bits starting at bit position `pos`
-    uint64_t acc = 0;
-    int fill = 0;
-    for (int i = i0; i < i1; i++) {
-        uint32_t v = sy[i];
-        uint64_t bits;
-        int nb = encode_symbol(L, D, (int)(v >> 16), (int)(v & 0xFFFF), bits);
-        acc |= bits << fill;  // nb <= 48, fill <= 15 after a flush
-        fill += nb;
-        if (fill >= 16) {
-            int flush = fill & ~7;
-            if (flush > 56) flush = 56;
-            or_bits(out, pos, acc & ((flush == 64) ? ~0ull : ((1ull << flush) - 1)), flush);
-            pos += flush;
-            acc >>= flush;
-            fill -= flush;
+        for (uint32_t k = tid; k < nfull; k += 256) {
+            const uint32_t v = obuf[k];
+            if (k == 0 && first) {
+                if (v) atomicOr(g, v);
+            } else {
+                g[k] = v;
+            }
+            obuf[k] = 0;
         }
-    }
-    if (fill) or_bits(out, pos, acc, fill), pos += fill;
-    if (threadIdx.x == 255) {
-        LdsTree::E eob = L[kEndBlock];
-        or_bits(out, sh_body + (int64_t)scan[255], eob.fc, eob.dl);
+        if (tid == 0) {
+            obuf[nfull] = 0;
+            if (last) {
+                if (carry) atomicOr(g + nfull, carry);
+            } else {
+                obuf[0] = carry;
+            }
+        }
+        if (nfull) first = false;
+        cur += nb;
+        __syncthreads();
+    };
+    for (int t0 = 0; t0 < total; t0 += kEbTile) {
+        // ---- this thread's 8 symbols (END_BLOCK is symbol number nsyms)
+        const int i0 = t0 + tid * 8;
+        uint32_t v[8];
+        uint32_t mybits = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const int i = i0 + k;
+            v[k] = i < r.nsyms ? sy[i] : (uint32_t)kEndBlock;
+            uint64_t bits;
+            if (i < total) mybits += (uint32_t)encode_symbol(L, D, (int)(v[k] >> 16), (int)(v[k] & 0xFFFF), bits);
+        }
+        // ---- exclusive scan over the workgroup
+        uint32_t inc = mybits;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t o = (uint32_t)__shfl_up((int)inc, off);
+            if (lane >= off) inc += o;
+        }
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        uint32_t before = 0, tile_bits = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint32_t x = wsum[k];
+            if (k < wave) before += x;
+            tile_bits += x;
+        }
+        // ---- pack
+        LdsBitPut put{obuf, (uint32_t)(cur & 31) + pending + before + inc - mybits};
+        uint64_t acc = 0;
+        int fill = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            if (i0 + k < total) {
+                uint64_t bits;
+                const int nb = encode_symbol(L, D, (int)(v[k] >> 16), (int)(v[k] & 0xFFFF), bits);
+                acc |= bits << fill;  // nb <= 48, fill <= 15 after a flush
+                fill += nb;
+                if (fill >= 16) {
+                    int fl = fill & ~7;
+                    if (fl > 56) fl = 56;
+                    put.put64(acc & ((1ull << fl) - 1), fl);
+                    acc >>= fl;
+                    fill -= fl;
+                }
+            }
+        }
+        if (fill) put.put64(acc, fill);
+        __syncthreads();
+        flush(pending + tile_bits, t0 + kEbTile >= total);
+        pending = 0;
     }
 }
 
