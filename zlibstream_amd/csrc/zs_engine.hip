@@ -35,6 +35,8 @@ const char *const kStageNames[kStCount] = {"clear", "adler", "links", "match", "
 struct zs_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t aux = nullptr;  // second stream: tree building of the finished blocks runs beside the tail engine
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::string err;
     bool profiling = false;
     int fast_fallbacks = 0;  // speculative DeflateFast batches that had to be redone sequentially
@@ -265,6 +267,14 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
                                c->crc_tab, lv, strategy, hash_variant);
     }
     mark(9);
+    hipLaunchKernelGGL(zs_body_blocks_kernel, dim3((unsigned)n), dim3(256), 0, stream, d_sd, d_st, dev<int32_t>(c->blk_end),
+                       dev<int32_t>(c->blk_top), dev<BlockRec>(c->blocks));
+    // fork: Build_tree of the blocks that are already complete is independent of the (sequential) tail engine
+    ZS_HIP(c, hipEventRecord(c->ev_fork, stream));
+    ZS_HIP(c, hipStreamWaitEvent(c->aux, c->ev_fork, 0));
+    hipLaunchKernelGGL(zs_trees_kernel, dim3((unsigned)pl.w_blocks.size()), dim3(256), 0, c->aux, d_sd, d_st, d_work + o_blocks,
+                       dev<uint32_t>(c->syms), dev<BlockRec>(c->blocks), dev<TreeWork>(c->trees), dev<BlockInfo>(c->info), strategy, level, 0);
+    ZS_HIP(c, hipEventRecord(c->ev_join, c->aux));
     hipLaunchKernelGGL(zs_tail_kernel, dim3((unsigned)n), dim3(1024), kTailLds, stream, d_sd, d_st, dev<uint16_t>(c->link),
                        dev<uint32_t>(c->syms), dev<int32_t>(c->blk_end), dev<int32_t>(c->blk_top), dev<BlockRec>(c->blocks),
                        dev<uint8_t>(c->scratch), c->crc_tab, lv, strategy, hash_variant, level);
@@ -282,6 +292,7 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
         ZS_HIP(c, hipStreamSynchronize(stream));
         for (int i = 0; i < n; i++)
             if (rfail[(size_t)i]) {
+                ZS_HIP(c, hipStreamSynchronize(c->aux));  // the forked tree pass reads the workspace that is about to be reused
                 c->fast_fallbacks++;
                 if (getenv("ZS_DEBUG")) {
                     std::vector<FastRunOut> ro((size_t)pl.n_runs);
@@ -302,8 +313,9 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
                            dev<int32_t>(c->blk_end), dev<int32_t>(c->blk_top), dev<BlockRec>(c->blocks), n);
     }
     mark(10);
+    ZS_HIP(c, hipStreamWaitEvent(stream, c->ev_join, 0));
     hipLaunchKernelGGL(zs_trees_kernel, dim3((unsigned)pl.w_blocks.size()), dim3(256), 0, stream, d_sd, d_st, d_work + o_blocks,
-                       dev<uint32_t>(c->syms), dev<BlockRec>(c->blocks), dev<TreeWork>(c->trees), dev<BlockInfo>(c->info), strategy, level);
+                       dev<uint32_t>(c->syms), dev<BlockRec>(c->blocks), dev<TreeWork>(c->trees), dev<BlockInfo>(c->info), strategy, level, 1);
     mark(11);
     hipLaunchKernelGGL(zs_offsets_kernel, dim3((unsigned)n), dim3(256), 0, stream, d_sd, d_st, dev<BlockRec>(c->blocks),
                        dev<BlockInfo>(c->info), dev<uint32_t>(c->pieces), level, n);
@@ -365,6 +377,12 @@ int zs_ctx_create(int device, zs_ctx **out) {
         return ZS_MEM_ERROR;
     }
     for (auto &e : c->ev) (void)hipEventCreate(&e);
+    if (hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
+        delete c;
+        return ZS_MEM_ERROR;
+    }
     std::vector<uint32_t> tab(1024);
     for (int t = 0; t < 4; t++)
         for (int i = 0; i < 256; i++) tab[(size_t)t * 256 + i] = crc32c_table_entry(t, (uint32_t)i);
@@ -397,6 +415,9 @@ void zs_ctx_destroy(zs_ctx *c) {
     if (c->pinned) (void)hipHostFree(c->pinned);
     for (auto &e : c->ev)
         if (e) (void)hipEventDestroy(e);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->aux) (void)hipStreamDestroy(c->aux);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }

@@ -914,6 +914,30 @@ __global__ __launch_bounds__(64) void zs_emit_syms_lane_kernel(const StreamDesc 
     }
 }
 
+// ------------------------------------------------------------------ K5b
+// The block cuts recorded by K5 become BlockRec entries (the blocks that end inside the bulk parse).
+__global__ __launch_bounds__(256) void zs_body_blocks_kernel(const StreamDesc *sd, const StreamState *st, const int32_t *blk_end,
+                                                             const int32_t *blk_top, BlockRec *blocks) {
+    const StreamDesc s = sd[blockIdx.x];
+    if (s.fast_runs > 0) return;
+    const int nb_body = (int)(st[blockIdx.x].body_syms / kBlockSyms);
+    BlockRec *blk = blocks + s.blk_off;
+    // start = end of the previous block; stored blocks are allowed only while blockStart has not slid out of the
+    // window (Deflate.cs:953)
+    for (int i = threadIdx.x; i < nb_body; i += blockDim.x) {
+        int64_t start = i ? blk_end[s.blk_off + i - 1] : 0;
+        int64_t end = blk_end[s.blk_off + i];
+        BlockRec r;
+        r.start = start;
+        r.sym_start = (int64_t)i * kBlockSyms;
+        r.stored_len = (int32_t)(end - start);
+        r.nsyms = kBlockSyms;
+        r.can_store = start >= (int64_t)kWSize * refills_fired_at(blk_top[s.blk_off + i], s.kl);
+        r.eof = 0;
+        blk[i] = r;
+    }
+}
+
 // ------------------------------------------------------------------ K6
 // One wave per stream; all lanes run the engine uniformly.  Also turns the
 // block cuts recorded by K5 into BlockRec entries.
@@ -928,21 +952,7 @@ __global__ __launch_bounds__(1024) void zs_tail_kernel(const StreamDesc *sd, Str
     uint8_t *sc = scratch + (int64_t)blockIdx.x * kScratchBytes;
     BlockRec *blk = blocks + s.blk_off;
     const uint32_t body_syms = ss.body_syms;
-    const int nb_body = (int)(body_syms / kBlockSyms);
-    // body blocks: start = end of the previous one; stored blocks are allowed
-    // only while blockStart has not slid out of the window (Deflate.cs:953)
-    for (int i = tid; i < nb_body; i += nth) {
-        int64_t start = i ? blk_end[s.blk_off + i - 1] : 0;
-        int64_t end = blk_end[s.blk_off + i];
-        BlockRec r;
-        r.start = start;
-        r.sym_start = (int64_t)i * kBlockSyms;
-        r.stored_len = (int32_t)(end - start);
-        r.nsyms = kBlockSyms;
-        r.can_store = start >= (int64_t)kWSize * refills_fired_at(blk_top[s.blk_off + i], s.kl);
-        r.eof = 0;
-        blk[i] = r;
-    }
+    const int nb_body = (int)(body_syms / kBlockSyms);  // their BlockRecs come from zs_body_blocks_kernel
     // window and prev live in LDS (129 KiB: the engine is latency-bound on them), head in HBM scratch
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     LitEngine e;
@@ -951,7 +961,9 @@ __global__ __launch_bounds__(1024) void zs_tail_kernel(const StreamDesc *sd, Str
     e.head = (uint16_t *)(sc + kScratchHead);
     e.prev = (uint16_t *)(smem + kScratchHead);
     uint32_t *head32 = (uint32_t *)(sc + kScratchHead32);
-    e.crc_tab = crc_tab_g;
+    uint32_t *tabl = (uint32_t *)(smem + kScratchHead + 2 * kWSize);  // the hash of every insert goes through these
+    load_crc_tab(tabl, crc_tab_g);
+    e.crc_tab = tabl;
     e.data = s.in;
     e.n = s.n;
     e.wr_end = s.n_wr > 1 ? s.wr_end : nullptr;
@@ -996,7 +1008,7 @@ __global__ __launch_bounds__(1024) void zs_tail_kernel(const StreamDesc *sd, Str
     }
 }
 
-constexpr int kTailLds = (int)kScratchHead + 2 * kWSize;
+constexpr int kTailLds = (int)kScratchHead + 2 * kWSize + 4096;  // window, prev, CRC tables
 
 // ------------------------------------------------------------------ KF: DeflateFast by speculative chunk runs
 // One workgroup per run (1024 threads restore the engine state, wave 0 runs Deflate.Fast.cs:20-128 literally).
@@ -1024,7 +1036,9 @@ __global__ __launch_bounds__(1024) void zs_fast_run_kernel(const StreamDesc *sd,
     e.prev = (uint16_t *)(smem + kScratchHead);
     e.head = (uint16_t *)sc;
     uint32_t *head32 = (uint32_t *)(sc + 2 * kHashSize);
-    e.crc_tab = crc_tab_g;
+    uint32_t *tabl = (uint32_t *)(smem + kScratchHead + 2 * kWSize);
+    load_crc_tab(tabl, crc_tab_g);
+    e.crc_tab = tabl;
     e.data = s.in;
     e.n = s.n;
     e.lv = lv;
@@ -1200,13 +1214,15 @@ __global__ __launch_bounds__(64) void zs_fast_blocks_kernel(const StreamDesc *sd
 // thread 0 replays Build_tree x3 exactly and picks the block type.
 __global__ __launch_bounds__(256) void zs_trees_kernel(const StreamDesc *sd, const StreamState *st, const uint2 *work,
                                                        const uint32_t *syms, const BlockRec *blocks, TreeWork *trees,
-                                                       BlockInfo *info, int strategy, int level) {
+                                                       BlockInfo *info, int strategy, int level, int phase) {
     __shared__ TreeWork tw;
     __shared__ uint32_t hl[kLCodes], hd[kDCodes];
     uint2 w = work[blockIdx.x];
     const StreamDesc s = sd[w.x];
     const int b = (int)w.y;
-    if (b >= st[w.x].nblocks) return;
+    // phase 0 (may run beside the tail kernel): the blocks that end inside the bulk parse; phase 1: the rest
+    const int nb_body = s.fast_runs > 0 ? 0 : (int)(st[w.x].body_syms / kBlockSyms);
+    if (phase == 0 ? b >= nb_body : (b < nb_body || b >= st[w.x].nblocks)) return;
     const BlockRec r = blocks[s.blk_off + b];
     for (int i = threadIdx.x; i < kLCodes; i += 256) hl[i] = 0;
     if (threadIdx.x < kDCodes) hd[threadIdx.x] = 0;
