@@ -246,6 +246,14 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
                        dev<uint16_t>(c->seg_entry), dev<uint32_t>(c->seg_symbase), dev<uint8_t>(c->stale),
                        dev<uint8_t>(c->seg_stale), c->crc_tab, lv, strategy, hash_variant);
     mark(7);
+    // fork: the tail engine (sequential, one workgroup per stream) needs only what the resolve kernel left, so it runs
+    // on the second stream beside the symbol kernels
+    ZS_HIP(c, hipEventRecord(c->ev_fork, stream));
+    ZS_HIP(c, hipStreamWaitEvent(c->aux, c->ev_fork, 0));
+    hipLaunchKernelGGL(zs_tail_kernel, dim3((unsigned)n), dim3(1024), kTailLds, c->aux, d_sd, d_st, dev<uint16_t>(c->link),
+                       dev<uint32_t>(c->syms), dev<int32_t>(c->blk_end), dev<int32_t>(c->blk_top), dev<BlockRec>(c->blocks),
+                       dev<uint8_t>(c->scratch), c->crc_tab, lv, strategy, hash_variant, level);
+    ZS_HIP(c, hipEventRecord(c->ev_join, c->aux));
     if (!pl.w_segs.empty())
         hipLaunchKernelGGL(zs_expand_kernel, dim3((unsigned)((pl.w_segs.size() + 63) / 64)), dim3(64), 0, stream, d_sd,
                            d_work + o_segs, (int)pl.w_segs.size(), dev<uint2>(c->mm),
@@ -267,17 +275,9 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
                                c->crc_tab, lv, strategy, hash_variant);
     }
     mark(9);
+    ZS_HIP(c, hipStreamWaitEvent(stream, c->ev_join, 0));
     hipLaunchKernelGGL(zs_body_blocks_kernel, dim3((unsigned)n), dim3(256), 0, stream, d_sd, d_st, dev<int32_t>(c->blk_end),
                        dev<int32_t>(c->blk_top), dev<BlockRec>(c->blocks));
-    // fork: Build_tree of the blocks that are already complete is independent of the (sequential) tail engine
-    ZS_HIP(c, hipEventRecord(c->ev_fork, stream));
-    ZS_HIP(c, hipStreamWaitEvent(c->aux, c->ev_fork, 0));
-    hipLaunchKernelGGL(zs_trees_kernel, dim3((unsigned)pl.w_blocks.size()), dim3(256), 0, c->aux, d_sd, d_st, d_work + o_blocks,
-                       dev<uint32_t>(c->syms), dev<BlockRec>(c->blocks), dev<TreeWork>(c->trees), dev<BlockInfo>(c->info), strategy, level, 0);
-    ZS_HIP(c, hipEventRecord(c->ev_join, c->aux));
-    hipLaunchKernelGGL(zs_tail_kernel, dim3((unsigned)n), dim3(1024), kTailLds, stream, d_sd, d_st, dev<uint16_t>(c->link),
-                       dev<uint32_t>(c->syms), dev<int32_t>(c->blk_end), dev<int32_t>(c->blk_top), dev<BlockRec>(c->blocks),
-                       dev<uint8_t>(c->scratch), c->crc_tab, lv, strategy, hash_variant, level);
     if (pl.n_runs) {
         // DeflateFast by speculative chunk runs; a run whose hand-over state does not verify sends the batch to the
         // sequential engine (the result is the reference's bytes either way)
@@ -313,9 +313,8 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
                            dev<int32_t>(c->blk_end), dev<int32_t>(c->blk_top), dev<BlockRec>(c->blocks), n);
     }
     mark(10);
-    ZS_HIP(c, hipStreamWaitEvent(stream, c->ev_join, 0));
     hipLaunchKernelGGL(zs_trees_kernel, dim3((unsigned)pl.w_blocks.size()), dim3(256), 0, stream, d_sd, d_st, d_work + o_blocks,
-                       dev<uint32_t>(c->syms), dev<BlockRec>(c->blocks), dev<TreeWork>(c->trees), dev<BlockInfo>(c->info), strategy, level, 1);
+                       dev<uint32_t>(c->syms), dev<BlockRec>(c->blocks), dev<TreeWork>(c->trees), dev<BlockInfo>(c->info), strategy, level, 2);
     mark(11);
     hipLaunchKernelGGL(zs_offsets_kernel, dim3((unsigned)n), dim3(256), 0, stream, d_sd, d_st, dev<BlockRec>(c->blocks),
                        dev<BlockInfo>(c->info), dev<uint32_t>(c->pieces), level, n);

@@ -936,6 +936,17 @@ __global__ __launch_bounds__(256) void zs_body_blocks_kernel(const StreamDesc *s
         r.eof = 0;
         blk[i] = r;
     }
+    // the first block flushed by the tail engine (which ran beside K5) starts where the last finished block ends
+    if (threadIdx.x == 0 && nb_body > 0) {
+        BlockRec r = blk[nb_body];
+        if (r.can_store < 0) {
+            const int64_t base = (int64_t)(-r.can_store - 1) * kWSize, start = blk_end[s.blk_off + nb_body - 1];
+            r.start = start;
+            r.stored_len -= (int32_t)start;
+            r.can_store = start >= base;
+            blk[nb_body] = r;
+        }
+    }
 }
 
 // ------------------------------------------------------------------ K6
@@ -976,7 +987,10 @@ __global__ __launch_bounds__(1024) void zs_tail_kernel(const StreamDesc *sd, Str
     e.nsyms = body_syms;
     e.blocks = blk;
     e.nblocks = nb_body;
-    e.block_start_abs = nb_body ? blk_end[s.blk_off + nb_body - 1] : 0;
+    // this kernel runs beside K5, which records where the last finished block ends: the first block flushed here
+    // gets its start from zs_body_blocks_kernel afterwards
+    e.block_start_abs = 0;
+    e.defer_start = nb_body > 0;
     e.block_sym_start = (int64_t)nb_body * kBlockSyms;
     e.block_syms = level == 0 ? (kLitBufsize / 2) - 1 : kBlockSyms;
     const uint16_t *lk = link + s.pos_off;
@@ -1220,9 +1234,9 @@ __global__ __launch_bounds__(256) void zs_trees_kernel(const StreamDesc *sd, con
     uint2 w = work[blockIdx.x];
     const StreamDesc s = sd[w.x];
     const int b = (int)w.y;
-    // phase 0 (may run beside the tail kernel): the blocks that end inside the bulk parse; phase 1: the rest
+    // phase 0: the blocks that end inside the bulk parse; phase 1: the rest; 2: all
     const int nb_body = s.fast_runs > 0 ? 0 : (int)(st[w.x].body_syms / kBlockSyms);
-    if (phase == 0 ? b >= nb_body : (b < nb_body || b >= st[w.x].nblocks)) return;
+    if (phase == 0 ? b >= nb_body : ((phase == 1 && b < nb_body) || b >= st[w.x].nblocks)) return;
     const BlockRec r = blocks[s.blk_off + b];
     for (int i = threadIdx.x; i < kLCodes; i += 256) hl[i] = 0;
     if (threadIdx.x < kDCodes) hd[threadIdx.x] = 0;

@@ -61,6 +61,7 @@ struct LitEngine {
     int64_t avail_end;  // absolute end of the input already copied into the window
     int strstart, lookahead, match_length, match_start, match_available, prev_length, prev_match;
     int64_t block_start_abs;
+    int defer_start;  // device tail: the start of the first block flushed is filled in later (see zs_body_blocks_kernel)
     int64_t block_sym_start;  // symbols emitted before the current block
     int block_syms;           // litBufsize - 1: 16383, or 8191 at level 0 (memLevel 7, Deflate.cs:246-249,298)
     // speculative chunk runs of DeflateFast (zs_kernels.hip, zs_fast_run_kernel); all off by default
@@ -85,7 +86,7 @@ ZS_HD void le_defaults(LitEngine &e) {
     e.stop_abs = -1, e.mark_abs = -1, e.mark_pos = -1, e.mark_nsyms = 0;
     e.ins_bits = nullptr, e.ins_base = 0, e.no_blocks = 0;
     e.ev_log = nullptr, e.n_ev = 0;
-    e.block_syms = kBlockSyms, e.block_sym_start = 0, e.block_start_abs = 0;
+    e.block_syms = kBlockSyms, e.block_sym_start = 0, e.block_start_abs = 0, e.defer_start = 0;
     e.nsyms = 0, e.nblocks = 0;
 }
 
@@ -223,10 +224,12 @@ ZS_HD void le_flush_block(LitEngine &e, bool eof, int lane) {
         b.stored_len = (int32_t)(end_abs - e.block_start_abs);
         b.nsyms = (int32_t)(e.nsyms - e.block_sym_start);
         b.can_store = e.block_start_abs >= e.base;
+        if (e.defer_start) b.can_store = -(1 + (int32_t)(e.base / kWSize));  // start unknown here: leave the window base
         b.eof = eof;
     }
     e.nblocks++;
     e.block_start_abs = end_abs;
+    e.defer_start = 0;
     e.block_sym_start = e.nsyms;
 }
 
