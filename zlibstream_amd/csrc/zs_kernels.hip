@@ -1231,6 +1231,7 @@ __global__ __launch_bounds__(256) void zs_trees_kernel(const StreamDesc *sd, con
                                                        BlockInfo *info, int strategy, int level, int phase) {
     __shared__ TreeWork tw;
     __shared__ uint32_t hl[kLCodes], hd[kDCodes];
+    __shared__ uint32_t hk[kHeapSize + 1];  // Build_tree's priority queue
     uint2 w = work[blockIdx.x];
     const StreamDesc s = sd[w.x];
     const int b = (int)w.y;
@@ -1264,7 +1265,7 @@ __global__ __launch_bounds__(256) void zs_trees_kernel(const StreamDesc *sd, con
     __syncthreads();
     if (threadIdx.x == 0) {
         tw.ltree[kEndBlock].fc = 1;
-        int type = build_block_trees(tw, r.stored_len, r.can_store != 0, strategy);
+        int type = build_block_trees(tw, hk, r.stored_len, r.can_store != 0, strategy);
         // level 0 skips the tree comparison: opt_lenb = static_lenb = stored_len + 5, i.e. stored when the block
         // start is still in the window, else static trees (Trees.cs:601-620)
         if (level == 0) type = r.can_store ? 0 : 1;
