@@ -21,6 +21,16 @@ namespace zs {
 
 typedef uint32_t __attribute__((aligned(1))) u32u;
 typedef uint64_t __attribute__((aligned(1))) u64u;
+// The stream buffers are reached through pointers stored in StreamDesc, which the compiler has to treat as generic
+// addresses: flat loads, which count on the LDS counter as well and so make every wait for an LDS read a wait for
+// all outstanding global loads.  They are global memory: say so.
+typedef const __attribute__((address_space(1))) uint8_t *gcbytes;
+typedef __attribute__((address_space(1))) uint8_t *gbytes_w;
+__device__ __forceinline__ gcbytes as_global(const uint8_t *p) { return (gcbytes)(uintptr_t)p; }
+__device__ __forceinline__ gbytes_w as_global(uint8_t *p) { return (gbytes_w)(uintptr_t)p; }
+typedef const __attribute__((address_space(1))) uint32_t __attribute__((aligned(1))) *gcu32u;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(1))) u32x4 *gcu32x4;
 // Unaligned 4 / 8 bytes out of an LDS byte array (16-byte aligned base, readable one dword past the last index
 // used): aligned dword reads + v_alignbyte.  A ds_read whose address is not a multiple of its size is legal but
 // the LDS pipe handles the misaligned lanes of a wave one at a time.
@@ -88,7 +98,7 @@ __global__ __launch_bounds__(1024) void zs_links_kernel(const StreamDesc *sd, co
     const int tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
     const uint2 w = work[blockIdx.x];
     const StreamDesc s = sd[w.x];
-    const uint8_t *in = s.in;
+    const gcbytes in = as_global(s.in);
     const int64_t qend = (int64_t)s.n - 5;  // positions q with q + 5 < n are inserted
     const int64_t span0 = (int64_t)w.y * span;
     if (span0 >= qend) return;
@@ -125,7 +135,7 @@ __global__ __launch_bounds__(1024) void zs_links_kernel(const StreamDesc *sd, co
             const int idx = wave * 1024 + g * 64 + lane;
             const bool valid = idx < tlen;
             uint32_t h = 0;
-            if (valid) h = dev_bucket(tab, *(const u32u *)(in + t0 + idx + 2), hash_variant);
+            if (valid) h = dev_bucket(tab, *(gcu32u)(in + t0 + idx + 2), hash_variant);
             const int cls = valid ? (int)(h & 15u) : 16;
             uint32_t r = 0;
 #pragma unroll
@@ -244,7 +254,7 @@ __global__ __launch_bounds__(1024) void zs_match_kernel(const StreamDesc *sd, co
     const int64_t n = s.n;
     if (t0 > s.body_end) return;
     const int64_t lo = t0 - kMatchBack;
-    const uint8_t *in = s.in;
+    const gcbytes in = as_global(s.in);
     // ---- stage bytes (dword granularity, zero outside [0, n)) ----
     {
         // 16 bytes per lane (lo is a multiple of 16; the caller's buffer and the link array are 16-byte aligned
@@ -254,7 +264,8 @@ __global__ __launch_bounds__(1024) void zs_match_kernel(const StreamDesc *sd, co
             int64_t a = lo + (int64_t)i * 16;
             uint4 v = make_uint4(0, 0, 0, 0);
             if (a >= 0 && a + 15 < n && aligned) {
-                v = *(const uint4 *)(in + a);
+                const u32x4 t = *(gcu32x4)(in + a);
+                v = make_uint4(t[0], t[1], t[2], t[3]);
             } else if (a + 15 >= 0 && a < n) {
                 uint32_t t[4] = {0, 0, 0, 0};
                 for (int k = 0; k < 16; k++) {
@@ -421,7 +432,7 @@ __global__ __launch_bounds__(1024) void zs_match_kernel(const StreamDesc *sd, co
 
 // ------------------------------------------------------------------ K3 / K4 / K5 accessors
 struct GlobalAcc {
-    const uint8_t *in;
+    gcbytes in;
     const uint2 *mm;  // already offset to the stream's position 0
     const uint32_t *tab;
     int strategy, hash_variant;
@@ -429,7 +440,7 @@ struct GlobalAcc {
     __device__ uint32_t mK(int64_t p) const { return flt(mm[p].x); }
     __device__ uint32_t mK4(int64_t p) const { return flt(mm[p].y); }
     __device__ uint8_t byte(int64_t p) const { return in[p]; }
-    __device__ uint32_t bucket(int64_t p) const { return dev_bucket(tab, *(const u32u *)(in + p + 2), hash_variant); }
+    __device__ uint32_t bucket(int64_t p) const { return dev_bucket(tab, *(gcu32u)(in + p + 2), hash_variant); }
     __device__ int run1(int64_t p) const {
         int len = 0;
         while (len < kMaxMatch && in[p + len] == in[p - 1 + len]) len++;
@@ -438,7 +449,7 @@ struct GlobalAcc {
 };
 // matches staged (already filtered) in LDS for one chunk: index p - (cs - 1)
 struct LdsAcc {
-    const uint8_t *in;
+    gcbytes in;
     const uint32_t *fk, *fk4;
     int64_t org;  // cs - 1
     const uint32_t *tab;
@@ -447,7 +458,7 @@ struct LdsAcc {
     __device__ uint32_t mK(int64_t p) const { return fk[p - org]; }
     __device__ uint32_t mK4(int64_t p) const { return fk4[p - org]; }
     __device__ uint8_t byte(int64_t p) const { return lbytes ? lbytes[p - org] : in[p]; }
-    __device__ uint32_t bucket(int64_t p) const { return dev_bucket(tab, *(const u32u *)(in + p + 2), hash_variant); }
+    __device__ uint32_t bucket(int64_t p) const { return dev_bucket(tab, *(gcu32u)(in + p + 2), hash_variant); }
     __device__ int run1(int64_t p) const {
         int len = 0;
         while (len < kMaxMatch && in[p + len] == in[p - 1 + len]) len++;
@@ -496,7 +507,7 @@ __global__ __launch_bounds__(512) void zs_chunkmap_kernel(const StreamDesc *sd, 
     int64_t ce = g.ce;
     if (ce > (int64_t)s.body_end + 1) ce = (int64_t)s.body_end + 1;
     const int len = (int)(ce - g.cs);
-    LdsAcc acc{s.in, fk, fk4, g.cs - 1, tab, hash_variant};
+    LdsAcc acc{as_global(s.in), fk, fk4, g.cs - 1, tab, hash_variant};
     for (int i = threadIdx.x; i < 4 * kChunk; i += 512) {
         int kind = i >> 11, off = i & (kChunk - 1);
         if (off < len) tbl[i] = node_step(acc, kind, g.cs + off, g.cs, ce, lv);
@@ -576,7 +587,7 @@ __global__ __launch_bounds__(1024) void zs_resolve_kernel(const StreamDesc *sd, 
     }
     uint16_t *lk = link + s.pos_off;
     uint2 *a = mm + s.pos_off;
-    GlobalAcc acc{s.in, a, tab, strategy, hash_variant};
+    GlobalAcc acc{as_global(s.in), a, tab, strategy, hash_variant};
     const int nseg = s.nsegs, nch = s.nchunks;
     for (;;) {
         // ---- stage the next kSegBatch segment-map rows (coalesced), then thread 0 follows the path through them
@@ -664,7 +675,7 @@ __global__ __launch_bounds__(1024) void zs_resolve_kernel(const StreamDesc *sd, 
                 bool dirty = (x && p - match_dist(x) < e) || (y && p - match_dist(y) < e);
                 if (!dirty) continue;
                 auto lkf = [lk](int64_t q) { return (int)lk[q]; };
-                const uint8_t *in = s.in;
+                const gcbytes in = as_global(s.in);
                 auto lcp = [in](int64_t u, int64_t v) {
                     int len = 0;
                     while (len < kMaxMatch && in[u + len] == in[v + len]) len++;
@@ -713,7 +724,7 @@ __global__ __launch_bounds__(64) void zs_expand_kernel(const StreamDesc *sd, con
     uint2 w = work[i];
     const StreamDesc s = sd[w.x];
     const int seg = (int)w.y;
-    GlobalAcc acc{s.in, mm + s.pos_off, crc_tab_g, strategy, hash_variant};
+    GlobalAcc acc{as_global(s.in), mm + s.pos_off, crc_tab_g, strategy, hash_variant};
     int slot = seg_entry[s.seg_off + seg];
     uint32_t total = seg_symbase[s.seg_off + seg];
     const int c0 = seg_first_chunk(seg);
@@ -788,13 +799,13 @@ __global__ __launch_bounds__(256) void zs_emit_syms_kernel(const StreamDesc *sd,
     const int64_t org = g.cs - 1;
     for (int i = threadIdx.x; i < kChunk + 1; i += 256) {
         int64_t p = org + i;
-        lb[i] = (p >= 0 && p < s.n) ? s.in[p] : 0;
+        lb[i] = (p >= 0 && p < s.n) ? as_global(s.in)[p] : 0;
     }
     __syncthreads();
     int64_t ce = g.ce;
     if (ce > (int64_t)s.body_end + 1) ce = (int64_t)s.body_end + 1;
     const int len = (int)(ce - g.cs);
-    LdsAcc acc{s.in, fk, fk4, org, tab, hash_variant, lb};
+    LdsAcc acc{as_global(s.in), fk, fk4, org, tab, hash_variant, lb};
     for (int i = threadIdx.x; i < 4 * kChunk; i += 256) {
         int kind = i >> 11, off = i & (kChunk - 1);
         if (off < len) {
@@ -868,7 +879,7 @@ __global__ __launch_bounds__(64) void zs_emit_syms_lane_kernel(const StreamDesc 
     const uint2 w = work[i];
     const StreamDesc s = sd[w.x];
     const int c = (int)w.y;
-    GlobalAcc acc{s.in, mm + s.pos_off, crc_tab_g, strategy, hash_variant};
+    GlobalAcc acc{as_global(s.in), mm + s.pos_off, crc_tab_g, strategy, hash_variant};
     const uint32_t base = symbase[s.chunk_off + c];
     GlobalSymSink sink{syms + s.sym_off + base, base, blk_end + s.blk_off, blk_top + s.blk_off};
     // the refill-rule prefix (first chunks of segments) by the shared code, then plain automaton steps
@@ -884,18 +895,19 @@ __global__ __launch_bounds__(64) void zs_emit_syms_lane_kernel(const StreamDesc 
     // literal byte a step at p+1 may emit) are requested one step ahead, so the dependent chain sees the load
     // latency of a step only where it exceeds the arithmetic of the step before.
     const uint2 *a = acc.mm;
+    const gcbytes gin = acc.in;
     const int64_t last = (int64_t)s.n - 1;
     uint32_t pend = kNoMatch;
     if (kind == kXK) pend = acc.mK(p - 1);
     else if (kind == kXK4) pend = acc.mK4(p - 1);
     uint2 cur = a[p];
-    uint8_t lit = p >= 1 ? s.in[p - 1] : 0;
+    uint8_t lit = p >= 1 ? gin[p - 1] : 0;
     while (p < ce) {
         int64_t qa = p + 1, qb = pend ? p - 1 + match_len(pend) : qa;
         if (qa > last) qa = last;
         if (qb > last) qb = last;
         const uint2 na = a[qa], nb = a[qb];
-        const uint8_t nlit = s.in[p];
+        const uint8_t nlit = gin[p];
         uint32_t cK = acc.flt(cur.x), cK4 = acc.flt(cur.y);
         if (p == 0) cK = cK4 = kNoMatch;
         const Step st = lazy_step(kind, p, pend, cK, cK4, lv);
@@ -1576,7 +1588,7 @@ __global__ __launch_bounds__(256) void zs_adler_kernel(const StreamDesc *sd, con
     int64_t beg = (int64_t)w.y * kAdlerPiece;
     int64_t len = (int64_t)s.n - beg;
     if (len > kAdlerPiece) len = kAdlerPiece;
-    const uint8_t *p = s.in + beg;
+    const gcbytes p = as_global(s.in) + beg;
     // thread t covers bytes [t*256, t*256+256): A_t = sum d, B_t = sum (L_t - j) d_j
     int64_t o = (int64_t)threadIdx.x * 256;
     int64_t lt = len - o;
@@ -1585,11 +1597,11 @@ __global__ __launch_bounds__(256) void zs_adler_kernel(const StreamDesc *sd, con
     uint64_t a = 0, bsum = 0;
     if (lt == 256 && (((uintptr_t)(p + o)) & 15) == 0) {
         // 16 x 16-byte loads; within a 16-byte group byte j has weight (256 - 16 g - j)
-        const uint4 *v = (const uint4 *)(p + o);
+        const gcu32x4 v = (gcu32x4)(p + o);
 #pragma unroll 4
         for (int g = 0; g < 16; g++) {
-            const uint4 q = v[g];
-            const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+            const u32x4 q = v[g];
+            const uint32_t w[4] = {q[0], q[1], q[2], q[3]};
             uint32_t ga = 0, gb = 0;  // sum of the 16 bytes, sum of j * byte
 #pragma unroll
             for (int k = 0; k < 4; k++) {
