@@ -376,6 +376,23 @@ int zs_ctx_create(int device, zs_ctx **out) {
         return ZS_MEM_ERROR;
     }
     for (auto &e : c->ev) (void)hipEventCreate(&e);
+    {
+        // the link kernel relies on the LDS applying the lanes of one DS_MSKOR_RTN_B32 in lane order: check it here
+        int *d_ok = nullptr, ok = 0;
+        if (hipMalloc((void **)&d_ok, sizeof(int)) != hipSuccess) {
+            delete c;
+            return ZS_MEM_ERROR;
+        }
+        hipLaunchKernelGGL(zs_lds_order_kernel, dim3(1), dim3(64), 0, c->stream, d_ok);
+        const bool copied = hipMemcpyAsync(&ok, d_ok, sizeof(int), hipMemcpyDeviceToHost, c->stream) == hipSuccess &&
+                            hipStreamSynchronize(c->stream) == hipSuccess;
+        (void)hipFree(d_ok);
+        if (!copied || !ok) {
+            fprintf(stderr, "zsgpu: LDS lane-order self-test failed on device %d; this build cannot run there\n", device);
+            zs_ctx_destroy(c);
+            return ZS_STREAM_ERROR;
+        }
+    }
     if (hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {

@@ -72,17 +72,49 @@ __global__ void zs_clear_kernel(const StreamDesc *sd, const uint2 *work) {
     for (int64_t i = ab + nvec * 16 + threadIdx.x; i < end; i += blockDim.x) o[i] = 0;
 }
 
+// DS_MSKOR_RTN_B32: word = (word & ~mask) | bits, returns the old word (an atomic exchange of part of a dword).
+__device__ __forceinline__ uint32_t lds_mskor_rtn(uint32_t *lds_word, uint32_t mask, uint32_t bits) {
+    const uint32_t addr = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)lds_word;
+    uint32_t old;
+    asm volatile("ds_mskor_rtn_b32 %0, %1, %2, %3\n\ts_waitcnt lgkmcnt(0)" : "=v"(old) : "v"(addr), "v"(mask), "v"(bits) : "memory");
+    return old;
+}
+// Self-test of the property K1 builds on: the 64 lanes of one DS_MSKOR_RTN_B32 are applied in lane order, whether they
+// hit the same half of a word, the other half, or other words.  ok[0] = 1 when every lane saw its predecessor.
+__global__ __launch_bounds__(64) void zs_lds_order_kernel(int *ok) {
+    __shared__ uint32_t w[64];
+    const int lane = threadIdx.x;
+    w[lane] = 0xFFFFFFFFu;
+    __syncthreads();
+    bool good = true;
+    for (int pat = 0; pat < 4; pat++) {
+        // pattern 0: all lanes one half-word; 1: alternate halves of one word; 2: groups of 4 lanes per half-word;
+        // 3: lane-dependent scatter over 8 half-words
+        const uint32_t slot = pat == 0 ? 0u : pat == 1 ? (uint32_t)(lane & 1) : pat == 2 ? (uint32_t)(lane >> 2) : (uint32_t)((lane * 5) & 7);
+        const uint32_t sh = (slot & 1u) * 16u, val = (uint32_t)(pat * 64 + lane + 1);
+        const uint32_t oldw = lds_mskor_rtn(&w[8 * pat + (slot >> 1)], 0xFFFFu << sh, val << sh);
+        const uint32_t got = (oldw >> sh) & 0xFFFFu;
+        // expected: the value of the nearest lower lane with the same slot, else the initial 0xFFFF
+        uint32_t want = 0xFFFFu;
+        for (int l = 0; l < lane; l++) {
+            const uint32_t sl = pat == 0 ? 0u : pat == 1 ? (uint32_t)(l & 1) : pat == 2 ? (uint32_t)(l >> 2) : (uint32_t)((l * 5) & 7);
+            if (sl == slot) want = (uint32_t)(pat * 64 + l + 1);
+        }
+        good = good && got == want;
+    }
+    const uint64_t all = __ballot(good);
+    if (lane == 0) ok[0] = all == ~0ull ? 1 : 0;
+}
+
 // ------------------------------------------------------------------ K1
 // InsertString replayed in absolute coordinates: link[q] = distance from q to the previous position of q's
 // bucket (0 if none within kMaxDist).  The replay is sequential only within a bucket, so a 1024-thread workgroup
 // takes its span 16 Ki positions at a time and splits every tile by bucket class (h & 15): phase 1 hashes the
 // tile and ranks every position inside its (wave, class) cell with ballots, phase 2 turns the 16 x 16 cell counts
 // into offsets, phase 3 scatters (h, index) into 16 position-ordered class lists in LDS, and in phase 4 wave k
-// replays list k against the shared 32 Ki-entry head table, 64 entries per step: lanes of one wave execute DS
-// operations in lane order, so every lane reads the old head before any lane's store and a read-back shows which
-// lane won a bucket; buckets hit by several lanes of a step are then linked lane to lane.  The head table lives in
-// LDS for the whole span (entries are positions relative to a base that moves with the tile, re-based by 16 Ki per
-// tile like SlideHash), after 32 Ki positions of warm-up before the span.
+// replays list k against the shared 32 Ki-entry head table, 64 entries per step, with one returning masked-OR per
+// lane (phase 4 below).  The head table lives in LDS for the whole span (entries are positions relative to a base that
+// moves with the tile, re-based by 16 Ki per tile like SlideHash), after 32 Ki positions of warm-up before the span.
 constexpr int kLkTile = 16384;
 constexpr int kLkWarm = 32768;  // >= kMaxDist, multiple of kLkTile
 constexpr int kLkLds = 2 * kHashSize + 4 * kLkTile + 4096 + 2 * 16 * 16 * 2 + 64 * 4;
@@ -92,9 +124,10 @@ __global__ __launch_bounds__(1024) void zs_links_kernel(const StreamDesc *sd, co
     uint16_t *head = (uint16_t *)smem;                         // kHashSize, 0xFFFF = empty
     uint32_t *list = (uint32_t *)(smem + 2 * kHashSize);       // kLkTile: (h << 16) | index in tile, grouped by class
     uint32_t *tab = list + kLkTile;                            // 1024
-    uint16_t *cntw = (uint16_t *)(tab + 1024);                 // [wave][class]
+    uint16_t *cntw = (uint16_t *)(tab + 1024);                 // [class][wave]
     uint16_t *coff = cntw + 256;                               // [class][wave] start of the cell in `list`
     uint32_t *cstart = (uint32_t *)(coff + 256);               // [17] start of each class list
+    __shared__ uint32_t wsum4[4];
     const int tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
     const uint2 w = work[blockIdx.x];
     const StreamDesc s = sd[w.x];
@@ -124,12 +157,12 @@ __global__ __launch_bounds__(1024) void zs_links_kernel(const StreamDesc *sd, co
         int64_t tend = t0 + kLkTile;
         if (tend > span_end) tend = span_end;
         const int tlen = (int)(tend - t0);
-        // ---- phase 1: buckets, and the rank of every position inside its (wave, class) cell
-        uint32_t hh[16];  // bucket, 0xFFFF0000 | .. when the position is past the end
+        // ---- phase 1: buckets, and the rank of every position inside its (wave, class) cell.  Lane k of the wave
+        //      carries the running count of class k (a shuffle fetches a lane's own class count: keeping 16 wave-uniform
+        //      counters in scalar registers next to 16 ballot masks spilled)
+        uint32_t hh[16];  // bucket, 0xFFFFFFFF when the position is past the end
         uint16_t rk[16];
-        uint32_t run[16];
-#pragma unroll
-        for (int k = 0; k < 16; k++) run[k] = 0;
+        uint32_t run_v = 0;
 #pragma unroll
         for (int g = 0; g < 16; g++) {
             const int idx = wave * 1024 + g * 64 + lane;
@@ -137,31 +170,42 @@ __global__ __launch_bounds__(1024) void zs_links_kernel(const StreamDesc *sd, co
             uint32_t h = 0;
             if (valid) h = dev_bucket(tab, *(gcu32u)(in + t0 + idx + 2), hash_variant);
             const int cls = valid ? (int)(h & 15u) : 16;
-            uint32_t r = 0;
+            uint32_t below = 0, cnt_v = 0;
 #pragma unroll
             for (int k = 0; k < 16; k++) {
                 const uint64_t b = __ballot(cls == k);
-                const uint32_t below = (uint32_t)__builtin_popcountll(b & lanemask_lt());
-                r = cls == k ? run[k] + below : r;
-                run[k] += (uint32_t)__builtin_popcountll(b);  // wave-uniform
+                const uint32_t bl = (uint32_t)__builtin_popcountll(b & lanemask_lt());
+                below = cls == k ? bl : below;
+                cnt_v = lane == k ? (uint32_t)__builtin_popcountll(b) : cnt_v;
             }
+            const uint32_t base = (uint32_t)__shfl((int)run_v, cls & 15);
             hh[g] = valid ? h : 0xFFFFFFFFu;
-            rk[g] = (uint16_t)r;
+            rk[g] = (uint16_t)(base + below);
+            run_v += cnt_v;
         }
-#pragma unroll
-        for (int k = 0; k < 16; k++)
-            if (lane == k) cntw[wave * 16 + k] = (uint16_t)run[k];
+        if (lane < 16) cntw[lane * 16 + wave] = (uint16_t)run_v;  // [class][wave]
         __syncthreads();
-        // ---- phase 2: cell offsets (class-major, waves in order inside a class)
+        // ---- phase 2: cell offsets = exclusive scan of the 256 counts in class-major order
         if (tid < 256) {
-            const int k = tid >> 4, ww = tid & 15;
-            uint32_t off = 0;
-            for (int k2 = 0; k2 < k; k2++)
-                for (int w2 = 0; w2 < 16; w2++) off += cntw[w2 * 16 + k2];
-            if (ww == 0) cstart[k] = off;
-            for (int w2 = 0; w2 < ww; w2++) off += cntw[w2 * 16 + k];
-            coff[k * 16 + ww] = (uint16_t)off;
-            if (tid == 255) cstart[16] = off + cntw[15 * 16 + 15];
+            const uint32_t cnt = cntw[tid];
+            uint32_t inc = cnt;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t x = (uint32_t)__shfl_up((int)inc, o);
+                if (lane >= o) inc += x;
+            }
+            if (lane == 63) wsum4[wave] = inc;
+            __syncthreads();
+            uint32_t before = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (k < wave) before += wsum4[k];
+            const uint32_t off = before + inc - cnt;
+            coff[tid] = (uint16_t)off;
+            if ((tid & 15) == 0) cstart[tid >> 4] = off;
+            if (tid == 255) cstart[16] = off + cnt;
+        } else {
+            __syncthreads();
         }
         __syncthreads();
         // ---- phase 3: scatter into the class lists
@@ -173,62 +217,28 @@ __global__ __launch_bounds__(1024) void zs_links_kernel(const StreamDesc *sd, co
             }
         }
         __syncthreads();
-        // ---- phase 4: wave k replays class k
+        // ---- phase 4: wave k replays class k, 64 entries per step.  One DS_MSKOR_RTN_B32 per step writes the lane's
+        //      position into its bucket's 16-bit half of the head word and returns what was there: the LDS applies the
+        //      lanes of one instruction in lane order, so a lane gets the position left by the nearest lower lane of the
+        //      same bucket, or the head from earlier steps -- exactly InsertString's `prev[str] = head[h]; head[h] = str`
+        //      in stream order, with no separate pass for buckets hit several times in one step.  (zs_ctx_create checks
+        //      the lane order on the device with zs_lds_order_kernel.)
         {
             const uint32_t cb = cstart[wave], ce = cstart[wave + 1];
             const bool store = t0 >= span0;
-            volatile uint16_t *vh = head;
             for (uint32_t i0 = cb; i0 < ce; i0 += 64) {
                 const uint32_t i = i0 + (uint32_t)lane;
-                const bool valid = i < ce;
-                const uint32_t e = valid ? list[i] : 0xFFFFFFFFu;
-                const uint32_t h = e >> 16, idx = e & 0x3FFFu;
-                const uint32_t rel = kRel0 + idx;
-                // Lanes of one wave execute DS operations in lane order: every lane reads the old head before any
-                // lane's store, and after the stores the highest lane of each bucket reads back its own value ("won").
-                // Its predecessor and those of the lanes that lost are found in one of two ways.  (a) One bucket per
-                // round with ballots only: the lanes of the leader's bucket link to each other by lane order (rounds =
-                // buckets hit more than once; one round for a run of equal bytes).  (b) All buckets together: the lanes
-                // that lost store again, the new winner of a bucket is the predecessor of the lane that won it the
-                // round before, which sees that in its own read-back (rounds = most lanes sharing a bucket; periodic
-                // data has many buckets a few times each).  (a) runs first and hands over to (b) when many lanes remain.
-                // (volatile: other lanes store to the same entries, nothing may be forwarded from this lane's stores)
-                const uint32_t hx = valid ? h : 0;  // in-range index for lanes past the end (they never store)
-                const uint32_t old = vh[hx];
-                if (valid) vh[hx] = (uint16_t)rel;
-                uint32_t rb = vh[hx];
-                const bool won = valid && rb == rel;
-                bool active = valid && !won, waiting = won;
-                uint32_t prevrel = old;
-                uint64_t lost = __ballot(active);
-                for (int it = 0; lost && (it == 0 || __builtin_popcountll(lost) < 36); it++) {
-                    const int leader = __builtin_ctzll(lost);
-                    const uint32_t hb = (uint32_t)__shfl((int)h, leader);
-                    const bool mine = valid && h == hb;
-                    const uint64_t grp = __ballot(mine);
-                    const uint64_t lower = grp & lanemask_lt();
-                    const int src = lower ? 63 - __builtin_clzll(lower) : lane;
-                    const uint32_t below = (uint32_t)__shfl((int)rel, src);
-                    if (mine) {
-                        if (lower) prevrel = below;
-                        active = false, waiting = false;
+                if (i < ce) {
+                    const uint32_t e = list[i];
+                    const uint32_t h = e >> 16, idx = e & 0x3FFFu;
+                    const uint32_t rel = kRel0 + idx, sh = (h & 1u) * 16u;
+                    const uint32_t oldw = lds_mskor_rtn((uint32_t *)head + (h >> 1), 0xFFFFu << sh, rel << sh);
+                    const uint32_t prevrel = (oldw >> sh) & 0xFFFFu;
+                    if (store) {
+                        uint32_t d = prevrel != 0xFFFFu ? rel - prevrel : 0;
+                        if (d > (uint32_t)kMaxDist) d = 0;
+                        lk[t0 + idx] = (uint16_t)d;
                     }
-                    lost &= ~grp;
-                }
-                if (lost) {
-                    for (;;) {
-                        if (active) vh[hx] = (uint16_t)rel;
-                        rb = vh[hx];
-                        if (waiting && rb != rel) prevrel = rb, waiting = false;  // this round's winner is right below me
-                        if (active && rb == rel) active = false, waiting = true, prevrel = old;
-                        if (!__ballot(active)) break;
-                    }
-                    if (won) vh[hx] = (uint16_t)rel;  // the later rounds overwrote the final head
-                }
-                if (valid && store) {
-                    uint32_t d = prevrel != 0xFFFFu ? rel - prevrel : 0;
-                    if (d > (uint32_t)kMaxDist) d = 0;
-                    lk[t0 + idx] = (uint16_t)d;
                 }
             }
         }
