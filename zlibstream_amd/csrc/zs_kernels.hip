@@ -102,6 +102,12 @@ __global__ __launch_bounds__(64) void zs_lds_order_kernel(int *ok) {
         }
         good = good && got == want;
     }
+    // the returning add K1 ranks positions with: lanes sharing a counter must get consecutive values in lane order
+    __shared__ uint32_t ctr[4];
+    if (lane < 4) ctr[lane] = 0;
+    __syncthreads();
+    const uint32_t rank = atomicAdd(&ctr[lane & 3], 1u);
+    good = good && rank == (uint32_t)(lane >> 2);
     const uint64_t all = __ballot(good);
     if (lane == 0) ok[0] = all == ~0ull ? 1 : 0;
 }
@@ -124,10 +130,10 @@ __global__ __launch_bounds__(1024) void zs_links_kernel(const StreamDesc *sd, co
     uint16_t *head = (uint16_t *)smem;                         // kHashSize, 0xFFFF = empty
     uint32_t *list = (uint32_t *)(smem + 2 * kHashSize);       // kLkTile: (h << 16) | index in tile, grouped by class
     uint32_t *tab = list + kLkTile;                            // 1024
-    uint16_t *cntw = (uint16_t *)(tab + 1024);                 // [class][wave]
-    uint16_t *coff = cntw + 256;                               // [class][wave] start of the cell in `list`
+    uint16_t *coff = (uint16_t *)(tab + 1024) + 256;           // [class][wave] start of the cell in `list`
     uint32_t *cstart = (uint32_t *)(coff + 256);               // [17] start of each class list
     __shared__ uint32_t wsum4[4];
+    __shared__ uint32_t cell[256];  // [class][wave] positions counted so far in the tile
     const int tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
     const uint2 w = work[blockIdx.x];
     const StreamDesc s = sd[w.x];
@@ -140,7 +146,9 @@ __global__ __launch_bounds__(1024) void zs_links_kernel(const StreamDesc *sd, co
     int64_t w0 = span0 - kLkWarm;
     if (w0 < 0) w0 = 0;
     for (int i = tid; i < kHashSize / 2; i += 1024) ((uint32_t *)head)[i] = 0xFFFFFFFFu;
+    if (tid < 256) cell[tid] = 0;
     load_crc_tab(tab, crc_tab_g);
+    __syncthreads();
     uint16_t *lk = link + s.pos_off;
     constexpr uint32_t kRel0 = 32768;  // position t0 + i is stored as kRel0 + i
     for (int64_t t0 = w0; t0 < span_end; t0 += kLkTile) {
@@ -157,37 +165,26 @@ __global__ __launch_bounds__(1024) void zs_links_kernel(const StreamDesc *sd, co
         int64_t tend = t0 + kLkTile;
         if (tend > span_end) tend = span_end;
         const int tlen = (int)(tend - t0);
-        // ---- phase 1: buckets, and the rank of every position inside its (wave, class) cell.  Lane k of the wave
-        //      carries the running count of class k (a shuffle fetches a lane's own class count: keeping 16 wave-uniform
-        //      counters in scalar registers next to 16 ballot masks spilled)
+        // ---- phase 1: buckets, and the rank of every position inside its (wave, class) cell: one returning LDS add per
+        //      position on the cell's counter (lane order again: ranks follow the positions)
         uint32_t hh[16];  // bucket, 0xFFFFFFFF when the position is past the end
         uint16_t rk[16];
-        uint32_t run_v = 0;
 #pragma unroll
         for (int g = 0; g < 16; g++) {
             const int idx = wave * 1024 + g * 64 + lane;
-            const bool valid = idx < tlen;
-            uint32_t h = 0;
-            if (valid) h = dev_bucket(tab, *(gcu32u)(in + t0 + idx + 2), hash_variant);
-            const int cls = valid ? (int)(h & 15u) : 16;
-            uint32_t below = 0, cnt_v = 0;
-#pragma unroll
-            for (int k = 0; k < 16; k++) {
-                const uint64_t b = __ballot(cls == k);
-                const uint32_t bl = (uint32_t)__builtin_popcountll(b & lanemask_lt());
-                below = cls == k ? bl : below;
-                cnt_v = lane == k ? (uint32_t)__builtin_popcountll(b) : cnt_v;
+            uint32_t h = 0xFFFFFFFFu, r = 0;
+            if (idx < tlen) {
+                h = dev_bucket(tab, *(gcu32u)(in + t0 + idx + 2), hash_variant);
+                r = atomicAdd(&cell[(h & 15u) * 16 + wave], 1u);
             }
-            const uint32_t base = (uint32_t)__shfl((int)run_v, cls & 15);
-            hh[g] = valid ? h : 0xFFFFFFFFu;
-            rk[g] = (uint16_t)(base + below);
-            run_v += cnt_v;
+            hh[g] = h;
+            rk[g] = (uint16_t)r;
         }
-        if (lane < 16) cntw[lane * 16 + wave] = (uint16_t)run_v;  // [class][wave]
         __syncthreads();
         // ---- phase 2: cell offsets = exclusive scan of the 256 counts in class-major order
         if (tid < 256) {
-            const uint32_t cnt = cntw[tid];
+            const uint32_t cnt = cell[tid];
+            cell[tid] = 0;  // for the next tile
             uint32_t inc = cnt;
 #pragma unroll
             for (int o = 1; o < 64; o <<= 1) {
