@@ -520,11 +520,17 @@ __global__ __launch_bounds__(512) void zs_chunkmap_kernel(const StreamDesc *sd, 
         if (off < len) tbl[i] = node_step(acc, kind, g.cs + off, g.cs, ce, lv);
     }
     __syncthreads();
-    for (int r = 0; r < kJumpRounds; r++) {
+    // two dependent lookups per pass: after pass r every entry jumps >= 3^r steps or reaches its exit (a step advances
+    // at least one position, a chunk has 2048: 3^7 = 2187)
+    for (int r = 0; r < 7; r++) {
         for (int i = threadIdx.x; i < 4 * kChunk; i += 512) {
             if ((i & (kChunk - 1)) >= len) continue;
             uint32_t v = tbl[i];
-            if (node_succ(v) < kNodeExit) tbl[i] = node_jump(v, tbl[node_succ(v)]);
+            if (node_succ(v) < kNodeExit) {
+                v = node_jump(v, tbl[node_succ(v)]);
+                if (node_succ(v) < kNodeExit) v = node_jump(v, tbl[node_succ(v)]);
+                tbl[i] = v;
+            }
         }
         __syncthreads();
     }
@@ -867,13 +873,16 @@ struct GlobalSymSink {
     uint32_t *out;   // the chunk's first symbol
     uint32_t base;   // its stream-global index
     int32_t *blk_end, *blk_top;
+    uint32_t next_cut;  // index (in the chunk) of the next symbol that completes a block
+    __device__ GlobalSymSink(uint32_t *o, uint32_t b, int32_t *be, int32_t *bt)
+        : out(o), base(b), blk_end(be), blk_top(bt), next_cut((b / kBlockSyms + 1) * kBlockSyms - 1 - b) {}
     __device__ void operator()(int i, uint32_t sym, int64_t end, int64_t top) {
         out[i] = sym;
-        uint32_t idx = base + (uint32_t)i;
-        if ((idx + 1) % kBlockSyms == 0) {
-            uint32_t bi = idx / kBlockSyms;
+        if ((uint32_t)i == next_cut) {
+            const uint32_t bi = (base + (uint32_t)i) / kBlockSyms;
             blk_end[bi] = (int32_t)end;
             blk_top[bi] = (int32_t)top;
+            next_cut += kBlockSyms;
         }
     }
 };
@@ -888,7 +897,7 @@ __global__ __launch_bounds__(64) void zs_emit_syms_lane_kernel(const StreamDesc 
     const int c = (int)w.y;
     GlobalAcc acc{as_global(s.in), mm + s.pos_off, crc_tab_g, strategy, hash_variant};
     const uint32_t base = symbase[s.chunk_off + c];
-    GlobalSymSink sink{syms + s.sym_off + base, base, blk_end + s.blk_off, blk_top + s.blk_off};
+    GlobalSymSink sink(syms + s.sym_off + base, base, blk_end + s.blk_off, blk_top + s.blk_off);
     // the refill-rule prefix (first chunks of segments) by the shared code, then plain automaton steps
     int kind, ns;
     int64_t p;
