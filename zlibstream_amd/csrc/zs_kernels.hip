@@ -340,45 +340,67 @@ __global__ __launch_bounds__(1024) void zs_match_kernel(const StreamDesc *sd, co
     // keeps going with the lanes still in state 1 and lets the others wait until as many lanes wait as step
     // (kWaitNum / kWaitDen), and only then runs the compare and finish phases once for all of them.
 #ifndef ZS_WQ
-#define ZS_WQ 1
+#define ZS_WQ 3
 #endif
 #ifndef ZS_WD
-#define ZS_WD 1
+#define ZS_WD 2
 #endif
     constexpr int kWaitNum = ZS_WQ, kWaitDen = ZS_WD;
     int st = 3, p = -1, c = 8, best = 2, bdist = 0, n_eval = 0, cl = 0;
     uint32_t snap = 0;       // record for the K>>2 budget once it is known to differ from the final one, else 0
     int snapped = 0;
     uint32_t scan_end = 0, mask = 0;  // scan_end = bytes p+best-3 .. p+best; mask drops the byte before p when best == 2
+    uint32_t sc0 = 0, sc1 = 0;        // bytes p .. p+7 (the first 8 bytes of every compare)
     int nexti = (int)(next - lo), wendi = (int)(wend - lo);  // wave-uniform, LDS-relative
+    // after a finished compare of `len` bytes against candidate c: take the improvement, count the candidate, move on
+    auto after_compare = [&](int len) {
+        len = len > kMaxMatch ? kMaxMatch : len;
+        const int better = len > best;
+        // the record for budget K>>2 is the state after candidate number K>>2: an improvement by a later candidate
+        // freezes the record as it was
+        const int freeze = better & (n_eval >= K4) & !snapped;
+        snap = freeze ? (best >= kMinMatch ? pack_match(best, bdist) : kNoMatch) : snap;
+        snapped |= freeze;
+        best = better ? len : best;
+        bdist = better ? p - c : bdist;
+        if (better) scan_end = lds_u32(wb, p + len - 3);
+        mask = better ? 0xFFFFFFFFu : mask;
+        const int nice_hit = better & (len >= nice);
+        cl = 0;
+        n_eval++;
+        const int nc = c - wl[c];
+        const int stop = nice_hit | (n_eval >= K) | (p - nc >= kMaxDist);
+        c = stop ? c : nc;
+        st = stop ? 3 : 1;
+    };
     for (;;) {
-        // ---- finish phase: store results, pull new positions (a position without a usable link is done at once)
+        // ---- finish phase: store results, pull new positions (written with selects: every lane runs every line)
         if (st == 3 && p >= 0) {
             const uint32_t rec = best >= kMinMatch ? pack_match(best, bdist) : kNoMatch;
             om[(int64_t)p + lo] = make_uint2(rec, snapped ? snap : rec);
         }
-        uint64_t need = __ballot(st == 3);
-        while (need) {
-            if (nexti >= wendi) {
-                if (st == 3) st = 0, p = -1;
-                break;
-            }
+        p = st == 3 ? -1 : p;
+#pragma unroll
+        for (int rep = 0; rep < 2; rep++) {  // a position without a usable link is done at once: its lane pulls again
+            const uint64_t need = __ballot(st == 3);
+            if (!need) break;
             const int mine = nexti + __builtin_popcountll(need & lanemask_lt());
             nexti += __builtin_popcountll(need);
-            if (st == 3) {
-                if (mine < wendi) {
-                    const int l = wl[mine];
-                    const bool has = l != 0xFFFF;  // link distances are already <= kMaxDist
-                    if (!has) om[(int64_t)mine + lo] = make_uint2(kNoMatch, kNoMatch);
-                    p = has ? mine : -1, c = mine - (has ? l : 0), st = has ? 1 : 3;
-                    best = 2, bdist = 0, n_eval = 0, snapped = 0, cl = 0;
-                    scan_end = lds_u32(wb, mine - 1);
-                    mask = 0xFFFFFF00u;
-                } else {
-                    st = 0, p = -1;
-                }
-            }
-            need = __ballot(st == 3);
+            nexti = nexti > wendi ? wendi : nexti;
+            const bool take = st == 3 && mine < wendi, dry = st == 3 && mine >= wendi;
+            const int q = take ? mine : 8;  // lanes that take nothing read an in-range dummy
+            const int l = wl[q];
+            const uint64_t first8 = lds_u64(wb, q);
+            const bool has = l != 0xFFFF;  // link distances are already <= kMaxDist
+            if (take && !has) om[(int64_t)mine + lo] = make_uint2(kNoMatch, kNoMatch);
+            p = take && has ? mine : p;
+            c = take ? mine - (has ? l : 0) : c;
+            st = take ? (has ? 1 : 3) : (dry ? 0 : st);
+            best = take ? 2 : best, bdist = take ? 0 : bdist, n_eval = take ? 0 : n_eval, snapped = take ? 0 : snapped;
+            cl = take ? 0 : cl;
+            scan_end = take ? (uint32_t)first8 << 8 : scan_end;  // bytes p-1 .. p+2; the mask drops the byte before p
+            mask = take ? 0xFFFFFF00u : mask;
+            sc0 = take ? (uint32_t)first8 : sc0, sc1 = take ? (uint32_t)(first8 >> 32) : sc1;
         }
         if (!__ballot(st != 0)) break;
         // ---- stepping phase (branch-free; lanes not in state 1 read their stale, in-range candidate)
@@ -398,40 +420,22 @@ __global__ __launch_bounds__(1024) void zs_match_kernel(const StreamDesc *sd, co
             c = (go & !stop) ? nc : c;
             st = (st == 1) ? (pass ? 2 : (stop ? 3 : 1)) : st;
         }
-        // ---- compare phase: up to 32 bytes per visit
-        if (st == 2) {
-            int off = cl, len = -1;
-            for (int r = 0; r < 4; r++) {
-                const uint64_t x = lds_u64(wb, p + off) ^ lds_u64(wb, c + off);
+        // ---- compare phase.  First 8 bytes of every compare against the cached bytes of p (most end here) ...
+        if (st == 2 && cl == 0) {
+            const uint64_t x = lds_u64(wb, c) ^ ((uint64_t)sc0 | ((uint64_t)sc1 << 32));
+            if (x) after_compare((int)(__builtin_ctzll(x) >> 3));
+            else cl = 8;
+        }
+        // ... then up to 32 more per visit for the lanes inside a long match (skipped by the wave when there is none)
+        for (int r = 0; r < 4 && __ballot(st == 2 && cl != 0); r++) {
+            if (st == 2 && cl != 0) {
+                const uint64_t x = lds_u64(wb, p + cl) ^ lds_u64(wb, c + cl);
                 if (x) {
-                    len = off + (int)(__builtin_ctzll(x) >> 3);
-                    break;
+                    after_compare(cl + (int)(__builtin_ctzll(x) >> 3));
+                } else {
+                    cl += 8;
+                    if (cl >= kMaxMatch) after_compare(kMaxMatch);
                 }
-                off += 8;
-                if (off >= kMaxMatch) break;
-            }
-            if (len < 0 && off >= kMaxMatch) len = kMaxMatch;
-            if (len < 0) {
-                cl = off;  // still equal: continue at the next visit
-            } else {
-                len = len > kMaxMatch ? kMaxMatch : len;
-                int nice_hit = 0;
-                if (len > best) {
-                    // the record for budget K>>2 is the state after candidate number K>>2: an improvement by a
-                    // later candidate freezes the record as it was
-                    if (n_eval >= K4 && !snapped) snapped = 1, snap = best >= kMinMatch ? pack_match(best, bdist) : kNoMatch;
-                    best = len;
-                    bdist = p - c;
-                    scan_end = lds_u32(wb, p + len - 3);
-                    mask = 0xFFFFFFFFu;
-                    nice_hit = len >= nice;
-                }
-                cl = 0;
-                n_eval++;
-                const int nc = c - wl[c];
-                const int stop = nice_hit | (n_eval >= K) | (p - nc >= kMaxDist);
-                c = stop ? c : nc;
-                st = stop ? 3 : 1;
             }
         }
     }
