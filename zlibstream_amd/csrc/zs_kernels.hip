@@ -520,7 +520,7 @@ __global__ __launch_bounds__(512) void zs_chunkmap_kernel(const StreamDesc *sd, 
     const int len = (int)(ce - g.cs);
     LdsAcc acc{as_global(s.in), fk, fk4, g.cs - 1, tab, hash_variant};
     for (int i = threadIdx.x; i < 4 * kChunk; i += 512) {
-        int kind = i >> 11, off = i & (kChunk - 1);
+        int kind = i >> kChunkBits, off = i & (kChunk - 1);
         if (off < len) tbl[i] = node_step(acc, kind, g.cs + off, g.cs, ce, lv);
     }
     __syncthreads();
@@ -824,7 +824,7 @@ __global__ __launch_bounds__(256) void zs_emit_syms_kernel(const StreamDesc *sd,
     const int len = (int)(ce - g.cs);
     LdsAcc acc{as_global(s.in), fk, fk4, org, tab, hash_variant, lb};
     for (int i = threadIdx.x; i < 4 * kChunk; i += 256) {
-        int kind = i >> 11, off = i & (kChunk - 1);
+        int kind = i >> kChunkBits, off = i & (kChunk - 1);
         if (off < len) {
             uint32_t v = node_step(acc, kind, g.cs + off, g.cs, ce, lv);
             J[i] = v;
