@@ -37,7 +37,7 @@ def oracle_lib():
     return L
 
 
-def cpu_baseline(data, level, budget_s=20.0):
+def cpu_baseline(data, level, budget_s=20.0, name="english64"):
     L = oracle_lib()
     cap = len(data) + len(data) // 8 + 1024
     out = ctypes.create_string_buffer(cap)
@@ -57,8 +57,8 @@ def cpu_baseline(data, level, budget_s=20.0):
         n = L.zso_compress_stream(sample, len(sample), None, 0, level, 0, 0, 0, out, cap, None)
     dt = (time.perf_counter() - t) / iters
     return {"value": round(len(sample) / dt / 1e6, 2), "unit": "MB/s", "cores": 1, "kind": "port",
-            "sample": "first %d bytes of the english64 buffer, level %d, 1 thread, 1 warm-up + %d timed passes"
-                      % (len(sample), level, iters)}, out.raw[:n], len(sample)
+            "sample": "first %d bytes of the %s buffer, level %d, 1 thread, 1 warm-up + %d timed passes"
+                      % (len(sample), name, level, iters)}, out.raw[:n], len(sample)
 
 
 def pmc_traffic(kernel, args):
@@ -83,6 +83,7 @@ def main():
     ap.add_argument("--workload", default="english64", choices=["english64", "sparse64", "batch"])
     ap.add_argument("--buffers", type=int, default=128, help="--workload batch: buffers per GPU (1 MiB each by default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--inflight", type=int, default=3, help="contexts in flight for the secondary `pipelined` figure (1 = skip)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -142,6 +143,33 @@ def main():
         dt = float(t.item())
     eng.set_profiling(False)
 
+    # Secondary figure, not `value`: the same steps with several engine contexts in flight (one host thread each), which
+    # fills the device during the single-workgroup phases of a lone stream (resolve, tree building, block offsets).
+    pipelined = None
+    if world == 1 and args.inflight > 1:
+        import threading
+        engs = [eng] + [Engine(local_rank) for _ in range(args.inflight - 1)]
+        outs2 = [d_outs] + [[torch.empty(c, dtype=torch.uint8, device=dev) for c in caps] for _ in range(args.inflight - 1)]
+        per = max(2, args.steps // args.inflight)
+
+        def worker(j, reps):
+            ptrs = [t.data_ptr() for t in outs2[j]]
+            for _ in range(reps):
+                engs[j].deflate_batch_device(in_ptrs, in_lens, ptrs, caps, level=args.level)
+
+        for j in range(1, args.inflight):
+            worker(j, 1)  # workspace allocation outside the timed region
+        torch.cuda.synchronize()
+        tp = time.perf_counter()
+        th = [threading.Thread(target=worker, args=(j, per)) for j in range(args.inflight)]
+        [x.start() for x in th]
+        [x.join() for x in th]
+        torch.cuda.synchronize()
+        dtp = time.perf_counter() - tp
+        pipelined = {"contexts_in_flight": args.inflight, "steps": per * args.inflight,
+                     "value": round(n * per * args.inflight / dtp / 1e6, 2), "unit": "MB/s"}
+        del engs[1:], outs2[1:]
+
     # correctness of what was timed: the stream must inflate back to the input
     import zlib
     z = d_out[:out_len].cpu().numpy().tobytes()
@@ -180,8 +208,10 @@ def main():
                          "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": round(stage_ms[dom], 4)},
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
         }
+        if pipelined:
+            line["pipelined"] = pipelined
         if not args.no_cpu_baseline:
-            cb, ref, sample_len = cpu_baseline(data, args.level)
+            cb, ref, sample_len = cpu_baseline(data, args.level, name=args.workload)
             line["cpu_baseline"] = cb
             if sample_len == n and len(datas) == 1:
                 line["compressed_size_delta_vs_cpu"] = out_len - len(ref)
