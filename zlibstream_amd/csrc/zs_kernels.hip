@@ -570,7 +570,7 @@ __global__ __launch_bounds__(320) void zs_segmap_kernel(const StreamDesc *sd, co
 }
 
 constexpr int kSegBatch = 64;
-constexpr int kResolveLds = kSegBatch * kSlots * 8 + 4096 + kSegBatch * 8;
+constexpr int kResolveLds = kSegBatch * kSlots * 8 + 4096 + kSegBatch * 12;
 // ------------------------------------------------------------------ K4
 // One workgroup per stream.  Thread 0 follows the true parse path through the segment
 // maps (one dependent lookup per 32 Ki positions).  At a refill loop-top s_k whose bucket
@@ -590,7 +590,7 @@ __global__ __launch_bounds__(1024) void zs_resolve_kernel(const StreamDesc *sd, 
     uint32_t *tab = (uint32_t *)(smem + kSegBatch * kSlots * 8);   // 1024
     uint32_t *out_base = tab + 1024;                              // per segment of the batch: first-symbol index,
     uint16_t *out_slot = (uint16_t *)(out_base + kSegBatch);      // entry slot,
-    uint8_t *row_stale = (uint8_t *)(out_slot + kSegBatch);       // stale flag
+    uint32_t *row_meta = (uint32_t *)(out_slot + kSegBatch);      // flags and entry limit per row
     __shared__ int sh_seg, sh_slot, sh_scan, sh_kfired, sh_preins;
     __shared__ uint32_t sh_total;
     const StreamDesc s = sd[blockIdx.x];
@@ -617,31 +617,40 @@ __global__ __launch_bounds__(1024) void zs_resolve_kernel(const StreamDesc *sd, 
             const uint4 *src = (const uint4 *)(segmap + ((int64_t)s.seg_off + seg0) * kSlots);  // kSlots is even: 16-byte aligned
             for (int i = threadIdx.x; i < nrow * kSlots / 2; i += blockDim.x) ((uint4 *)rows)[i] = src[i];
         }
-        if (threadIdx.x < nrow) row_stale[threadIdx.x] = seg_stale[s.seg_off + seg0 + threadIdx.x];
+        if (threadIdx.x < nrow) {
+            // per row: bit 0 = the segment starts with a refill (segments 1 .. kl), bit 1 = it holds stale chunks,
+            // bits 2.. = largest entry offset that is still a loop-top of the body (only the last segment limits it)
+            const int seg = seg0 + (int)threadIdx.x;
+            const int64_t cs = seg >= 1 ? (int64_t)kSeg0 + (int64_t)(seg - 1) * kWSize : 0;  // segment_start(seg)
+            int64_t lim = (int64_t)s.body_end - cs;
+            lim = lim > 511 ? 511 : lim;
+            uint32_t m = (seg >= 1 && seg <= s.kl && lim >= 0) ? 1u : 0u;
+            if (seg_stale[s.seg_off + seg]) m |= 2u;
+            row_meta[threadIdx.x] = m | ((uint32_t)(lim < 0 ? 0 : lim) << 2);
+        }
         __syncthreads();
         if (threadIdx.x == 0) {
             int seg = seg0, slot = sh_slot;
             uint32_t total = sh_total;
             bool scanned = sh_scan != 0;  // the pending segment's cut has just been applied
-            sh_scan = 0;
-            const int last_event_seg = s.kl < seg0 + nrow - 1 ? s.kl : seg0 + nrow - 1;
+            int kf = -1, kslot = 0;       // last refill that fired in this batch
+            const bool cuts = strategy != kHuffmanOnly;
+            bool stop = false;
             while (seg < seg0 + nrow) {
-                const uint2 v = rows[(seg - seg0) * kSlots + slot];
-                if (seg >= 1 && seg <= last_event_seg) {
-                    const int64_t cs = (int64_t)kSeg0 + (int64_t)(seg - 1) * kWSize;  // segment_start(seg)
-                    const int64_t e = slot <= 256 ? cs + slot : cs;
-                    if (e <= s.body_end) {
-                        sh_kfired = seg, sh_preins = (int)(e + 1);
-                        if ((v.x & kMapEqualBit) && strategy != kHuffmanOnly && !scanned) {
-                            sh_scan = 1;
-                            break;
-                        }
+                const int i = seg - seg0;
+                const uint2 v = rows[i * kSlots + slot];
+                const uint32_t m = row_meta[i];
+                if ((m & 1u) && (uint32_t)(slot <= 256 ? slot : 0) <= (m >> 2)) {
+                    kf = seg, kslot = slot;
+                    if ((v.x & kMapEqualBit) && cuts && !scanned) {
+                        stop = true;
+                        break;
                     }
                 }
                 scanned = false;
-                out_slot[seg - seg0] = (uint16_t)slot;
-                out_base[seg - seg0] = total;
-                if (row_stale[seg - seg0]) {
+                out_slot[i] = (uint16_t)slot;
+                out_base[i] = total;
+                if (m & 2u) {
                     const int c0 = seg_first_chunk(seg);
                     int c1 = seg_first_chunk(seg + 1);
                     if (c1 > nch) c1 = nch;
@@ -651,8 +660,8 @@ __global__ __launch_bounds__(1024) void zs_resolve_kernel(const StreamDesc *sd, 
                             NullSink ns;
                             walk_chunk(acc, ns, cc, slot, s.kl, s.body_end, lv, strategy, ex, cnt);
                         } else {
-                            uint32_t m = maps[((int64_t)s.chunk_off + cc) * kSlots + slot];
-                            ex = map_exit(m), cnt = map_count(m);
+                            uint32_t mp = maps[((int64_t)s.chunk_off + cc) * kSlots + slot];
+                            ex = map_exit(mp), cnt = map_count(mp);
                         }
                         slot = ex;
                         total += (uint32_t)cnt;
@@ -663,6 +672,11 @@ __global__ __launch_bounds__(1024) void zs_resolve_kernel(const StreamDesc *sd, 
                 }
                 seg++;
             }
+            if (kf >= 0) {
+                const int64_t cs = (int64_t)kSeg0 + (int64_t)(kf - 1) * kWSize;
+                sh_kfired = kf, sh_preins = (int)((kslot <= 256 ? cs + kslot : cs) + 1);
+            }
+            sh_scan = stop ? 1 : 0;
             sh_seg = seg, sh_slot = slot, sh_total = total;
         }
         __syncthreads();
