@@ -570,7 +570,8 @@ __global__ __launch_bounds__(320) void zs_segmap_kernel(const StreamDesc *sd, co
 }
 
 constexpr int kSegBatch = 64;
-constexpr int kResolveLds = kSegBatch * kSlots * 8 + 4096 + kSegBatch * 12;
+constexpr int kSegGroup = 8;  // rows composed in parallel before the sequential walk
+constexpr int kResolveLds = kSegBatch * kSlots * 8 + 4096 + kSegBatch * 12 + (kSegBatch / kSegGroup) * kSlots * 8;
 // ------------------------------------------------------------------ K4
 // One workgroup per stream.  Thread 0 follows the true parse path through the segment
 // maps (one dependent lookup per 32 Ki positions).  At a refill loop-top s_k whose bucket
@@ -591,6 +592,10 @@ __global__ __launch_bounds__(1024) void zs_resolve_kernel(const StreamDesc *sd, 
     uint32_t *out_base = tab + 1024;                              // per segment of the batch: first-symbol index,
     uint16_t *out_slot = (uint16_t *)(out_base + kSegBatch);      // entry slot,
     uint32_t *row_meta = (uint32_t *)(out_slot + kSegBatch);      // flags and entry limit per row
+    uint2 *gmap = (uint2 *)(row_meta + kSegBatch);                // per group of kSegGroup rows: composed map of every slot
+    __shared__ int g_slot[kSegBatch / kSegGroup], g_kf[kSegBatch / kSegGroup], g_ks[kSegBatch / kSegGroup], g_fast[kSegBatch / kSegGroup];
+    __shared__ uint32_t g_base[kSegBatch / kSegGroup];
+    __shared__ int sh_kf, sh_ks;
     __shared__ int sh_seg, sh_slot, sh_scan, sh_kfired, sh_preins;
     __shared__ uint32_t sh_total;
     const StreamDesc s = sd[blockIdx.x];
@@ -629,15 +634,51 @@ __global__ __launch_bounds__(1024) void zs_resolve_kernel(const StreamDesc *sd, 
             row_meta[threadIdx.x] = m | ((uint32_t)(lim < 0 ? 0 : lim) << 2);
         }
         __syncthreads();
+        // ---- compose every group of kSegGroup rows for all slots in parallel: exit slot, symbols, and whether the
+        //      path from that slot meets anything the sequential walk must look at (an equal-bucket refill, a stale row)
+        const int ngroup = (nrow + kSegGroup - 1) / kSegGroup;
+        for (int t = threadIdx.x; t < ngroup * kSlots; t += blockDim.x) {
+            const int g = t / kSlots;
+            int cur = t - g * kSlots;
+            uint32_t cnt = 0, flag = 0;
+            for (int r = 0; r < kSegGroup; r++) {
+                const int i = g * kSegGroup + r;
+                if (i >= nrow) break;
+                const uint2 v = rows[i * kSlots + cur];
+                const uint32_t m = row_meta[i];
+                const bool fires = (m & 1u) && (uint32_t)(cur <= 256 ? cur : 0) <= (m >> 2);
+                flag |= (m & 2u) | ((fires && (v.x & kMapEqualBit)) ? 1u : 0u);
+                cur = (int)(v.x & 0x1FF);
+                cnt += v.y;
+            }
+            gmap[t] = make_uint2((uint32_t)cur | (flag ? 0x8000u : 0u), cnt);
+        }
+        __syncthreads();
+        if (threadIdx.x < kSegBatch / kSegGroup) g_fast[threadIdx.x] = 0;
+        __syncthreads();
         if (threadIdx.x == 0) {
             int seg = seg0, slot = sh_slot;
             uint32_t total = sh_total;
             bool scanned = sh_scan != 0;  // the pending segment's cut has just been applied
-            int kf = -1, kslot = 0;       // last refill that fired in this batch
+            int kf = -1, kslot = 0;       // last refill that fired among the rows walked one by one
             const bool cuts = strategy != kHuffmanOnly;
             bool stop = false;
             while (seg < seg0 + nrow) {
                 const int i = seg - seg0;
+                if (!scanned && i % kSegGroup == 0) {
+                    // a whole group at once when nothing on the path from `slot` needs attention; its per-row results are
+                    // filled in afterwards, one lane per group
+                    const int g = i / kSegGroup;
+                    const uint2 e = gmap[g * kSlots + slot];
+                    if (!(e.x & 0x8000u)) {
+                        g_slot[g] = slot, g_base[g] = total, g_fast[g] = 1;
+                        slot = (int)(e.x & 0x1FF);
+                        total += e.y;
+                        seg += kSegGroup;
+                        if (seg > seg0 + nrow) seg = seg0 + nrow;
+                        continue;
+                    }
+                }
                 const uint2 v = rows[i * kSlots + slot];
                 const uint32_t m = row_meta[i];
                 if ((m & 1u) && (uint32_t)(slot <= 256 ? slot : 0) <= (m >> 2)) {
@@ -672,12 +713,38 @@ __global__ __launch_bounds__(1024) void zs_resolve_kernel(const StreamDesc *sd, 
                 }
                 seg++;
             }
-            if (kf >= 0) {
-                const int64_t cs = (int64_t)kSeg0 + (int64_t)(kf - 1) * kWSize;
-                sh_kfired = kf, sh_preins = (int)((kslot <= 256 ? cs + kslot : cs) + 1);
-            }
+            sh_kf = kf, sh_ks = kslot;
             sh_scan = stop ? 1 : 0;
             sh_seg = seg, sh_slot = slot, sh_total = total;
+        }
+        __syncthreads();
+        if (threadIdx.x < kSegBatch / kSegGroup && g_fast[threadIdx.x]) {
+            const int g = threadIdx.x;
+            int cur = g_slot[g], kf = -1, ks = 0;
+            uint32_t total = g_base[g];
+            for (int r = 0; r < kSegGroup; r++) {
+                const int i = g * kSegGroup + r;
+                if (i >= nrow) break;
+                const uint2 v = rows[i * kSlots + cur];
+                const uint32_t m = row_meta[i];
+                if ((m & 1u) && (uint32_t)(cur <= 256 ? cur : 0) <= (m >> 2)) kf = seg0 + i, ks = cur;
+                out_slot[i] = (uint16_t)cur;
+                out_base[i] = total;
+                cur = (int)(v.x & 0x1FF);
+                total += v.y;
+            }
+            g_kf[g] = kf, g_ks[g] = ks;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            // the last refill that fired in this batch: among the rows walked one by one or inside a group
+            int kf = sh_kf, ks = sh_ks;
+            for (int g = 0; g < kSegBatch / kSegGroup; g++)
+                if (g_fast[g] && g_kf[g] > kf) kf = g_kf[g], ks = g_ks[g];
+            if (kf >= 0) {
+                const int64_t cs = (int64_t)kSeg0 + (int64_t)(kf - 1) * kWSize;
+                sh_kfired = kf, sh_preins = (int)((ks <= 256 ? cs + ks : cs) + 1);
+            }
         }
         __syncthreads();
         for (int i = threadIdx.x; i < sh_seg - seg0; i += blockDim.x) {
