@@ -1405,7 +1405,7 @@ __global__ __launch_bounds__(256) void zs_offsets_kernel(const StreamDesc *sd, S
     __shared__ int64_t sh_start[1024];
     __shared__ uint32_t ad_v[256];
     __shared__ uint64_t ad_len[256];
-    __shared__ int64_t sh_pos;
+    __shared__ int64_t sh_pos, sh_wsum[4];
     __shared__ int sh_bad;
     const int si = blockIdx.x;
     const StreamDesc s = sd[si];
@@ -1421,7 +1421,42 @@ __global__ __launch_bounds__(256) void zs_offsets_kernel(const StreamDesc *sd, S
             sh_type[i] = bi.type, sh_bits[i] = bi.bits, sh_len[i] = r.stored_len, sh_eof[i] = r.eof;
         }
         __syncthreads();
-        if (threadIdx.x == 0) {
+        // Send_bits is a concatenation: when no block of the batch needs byte alignment before its end (no stored block,
+        // end-of-stream only on the last one) the starts are a prefix sum; otherwise thread 0 walks the blocks
+        int irregular = 0;
+        for (int i = threadIdx.x; i < cnt; i += 256) irregular |= (sh_type[i] == 0) || (sh_eof[i] && i != cnt - 1);
+        irregular = __syncthreads_or(irregular);
+        if (!irregular) {
+            // thread t sums 4 consecutive blocks, then a scan over the 256 partial sums
+            const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+            int64_t b4[4], mine = 0;
+            for (int k = 0; k < 4; k++) {
+                const int i = threadIdx.x * 4 + k;
+                b4[k] = i < cnt ? sh_bits[i] : 0;
+                mine += b4[k];
+            }
+            int64_t inc = mine;
+            for (int o = 1; o < 64; o <<= 1) {
+                const int64_t x = __shfl_up(inc, o);
+                if (lane >= o) inc += x;
+            }
+            if (lane == 63) sh_wsum[wave] = inc;
+            __syncthreads();
+            int64_t before = sh_pos;
+            for (int k = 0; k < wave; k++) before += sh_wsum[k];
+            int64_t pos = before + inc - mine;
+            for (int k = 0; k < 4; k++) {
+                const int i = threadIdx.x * 4 + k;
+                if (i < cnt) sh_start[i] = pos;
+                pos += b4[k];
+            }
+            __syncthreads();
+            if (threadIdx.x == 255) {
+                int64_t end = pos;  // thread 255 holds the end of the last block of the batch
+                if (sh_eof[cnt - 1]) end = (end + 7) & ~7LL;
+                sh_pos = end;
+            }
+        } else if (threadIdx.x == 0) {
             int64_t pos = sh_pos;
             for (int i = 0; i < cnt; i++) {
                 sh_start[i] = pos;
