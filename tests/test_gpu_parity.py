@@ -306,3 +306,52 @@ def test_fast_levels_large_streams_speculative_runs(engine, oracle):
     for name, d in cases.items():
         for lvl in (1, 2, 3):
             assert engine.deflate_batch([d], level=lvl)[0] == oracle.compress(d, lvl), (name, lvl)
+
+
+def _fuzz_buffer(rng, i):
+    """Inputs that stress different parts of the pipeline: long zero / byte runs (equal-bucket refills, one hash class
+    getting every position), periodic data (many buckets a few times each), incompressible data (stored blocks, mid-stream
+    alignment), text with planted long repeats, and mixtures with abrupt changes."""
+    n = int(rng.integers(1, 3 << 20)) if i % 5 else int(rng.integers(1, 70000))
+    kind = i % 8
+    if kind == 0:
+        return bytes(n)
+    if kind == 1:
+        return rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+    if kind == 2:
+        per = rng.integers(0, 256, int(rng.integers(1, 700)), dtype=np.uint8).tobytes()
+        return (per * (n // len(per) + 1))[:n]
+    if kind == 3:
+        return np.repeat(rng.integers(0, 8, n // 4 + 1, dtype=np.uint8), rng.integers(1, 300, n // 4 + 1))[:n].tobytes()
+    if kind == 4:
+        return datagen.english(n, int(rng.integers(1, 1 << 30)))
+    if kind == 5:
+        t = bytearray(datagen.english(n, int(rng.integers(1, 1 << 30))))
+        for _ in range(20):  # planted repeats at distances around the window size
+            ln = int(rng.integers(3, 600))
+            src = int(rng.integers(0, max(1, n - ln)))
+            dst = src + int(rng.choice([1, 2, 255, 256, 4096, 32505, 32506, 32507, 32768, 40000]))
+            if dst + ln <= n:
+                t[dst:dst + ln] = t[src:src + ln]
+        return bytes(t)
+    if kind == 6:
+        parts, left = [], n
+        while left > 0:
+            m = min(left, int(rng.integers(1, 200000)))
+            parts.append(_fuzz_buffer(rng, int(rng.integers(0, 5)) * 8 + int(rng.integers(0, 5)))[:m])
+            left -= len(parts[-1])
+        return b"".join(parts)
+    return datagen.sparse(int(rng.integers(8, 700)), max(1, n // 2800), y0=int(rng.integers(0, 255)))[:n]
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_fuzz_mixed_inputs_all_slow_levels(engine, oracle, seed):
+    rng = np.random.default_rng(1000 + seed)
+    bufs = [_fuzz_buffer(rng, i) for i in range(24)]
+    for lvl in ((6, 9) if seed == 1 else (4, 7)):
+        got = engine.deflate_batch(bufs, level=lvl)
+        for i, (b, z) in enumerate(zip(bufs, got)):
+            assert z == oracle.compress(b, lvl), (seed, lvl, i, len(b))
+    got = engine.deflate_batch(bufs[:8], level=5, strategy=int(CompressionStrategy.Filtered))
+    for i, (b, z) in enumerate(zip(bufs[:8], got)):
+        assert z == oracle.compress(b, 5, int(CompressionStrategy.Filtered)), (seed, i)
