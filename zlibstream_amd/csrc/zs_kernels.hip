@@ -345,6 +345,9 @@ __global__ __launch_bounds__(1024) void zs_match_kernel(const StreamDesc *sd, co
 #ifndef ZS_WD
 #define ZS_WD 2
 #endif
+#ifndef ZS_STEP_UNROLL
+#define ZS_STEP_UNROLL 2
+#endif
     constexpr int kWaitNum = ZS_WQ, kWaitDen = ZS_WD;
     int st = 3, p = -1, c = 8, best = 2, bdist = 0, n_eval = 0, cl = 0;
     uint32_t snap = 0;       // record for the K>>2 budget once it is known to differ from the final one, else 0
@@ -408,17 +411,20 @@ __global__ __launch_bounds__(1024) void zs_match_kernel(const StreamDesc *sd, co
             const int nact = __builtin_popcountll(__ballot(st == 1));
             const int nwait = __builtin_popcountll(__ballot(st >= 2));
             if (nact == 0 || nwait * kWaitNum >= nact * kWaitDen) break;
-            const int l = wl[c];
-            const uint32_t e = lds_u32(wb, c + best - 3);
-            // a candidate can only beat `best` if bytes [best-3 .. best] match too (bytes [0 .. 2] when best == 2)
-            const int pass = ((e ^ scan_end) & mask) == 0;
-            const int go = (st == 1) & !pass;
-            // leave the candidate: count it and follow its link; `cur_match > limit` is distance < kMaxDist
-            const int ne = n_eval + 1, nc = c - l;
-            const int stop = (ne >= K) | (p - nc >= kMaxDist);
-            n_eval = go ? ne : n_eval;
-            c = (go & !stop) ? nc : c;
-            st = (st == 1) ? (pass ? 2 : (stop ? 3 : 1)) : st;
+#pragma unroll
+            for (int u = 0; u < ZS_STEP_UNROLL; u++) {  // steps per look at the lane counts
+                const int l = wl[c];
+                const uint32_t e = lds_u32(wb, c + best - 3);
+                // a candidate can only beat `best` if bytes [best-3 .. best] match too (bytes [0 .. 2] when best == 2)
+                const int pass = ((e ^ scan_end) & mask) == 0;
+                const int go = (st == 1) & !pass;
+                // leave the candidate: count it and follow its link; `cur_match > limit` is distance < kMaxDist
+                const int ne = n_eval + 1, nc = c - l;
+                const int stop = (ne >= K) | (p - nc >= kMaxDist);
+                n_eval = go ? ne : n_eval;
+                c = (go & !stop) ? nc : c;
+                st = (st == 1) ? (pass ? 2 : (stop ? 3 : 1)) : st;
+            }
         }
         // ---- compare phase.  First 8 bytes of every compare against the cached bytes of p (most end here) ...
         if (st == 2 && cl == 0) {
