@@ -321,10 +321,12 @@ __global__ __launch_bounds__(1024) void zs_match_kernel(const StreamDesc *sd, co
     int64_t pend = t0 + kMatchTile;
     if (pend > (int64_t)s.body_end + 1) pend = (int64_t)s.body_end + 1;
     const int wave = threadIdx.x >> 6, lane = lane_id();
-    const int64_t per = (pend - pbeg + 15) / 16;
-    int64_t next = pbeg + per * wave;  // wave-uniform cursor
-    int64_t wend = next + per;
-    if (wend > pend) wend = pend;
+    // one position cursor for the workgroup (an LDS counter): waves that run out of long walks early keep pulling, so
+    // the idle tail is that of the tile, not of 16 separate ranges
+    __shared__ int wg_cursor;
+    if (threadIdx.x == 0) wg_cursor = (int)(pbeg - lo);
+    __syncthreads();
+    const int wendi = (int)(pend - lo);  // LDS-relative end of the tile's positions
     uint2 *om = mm + s.pos_off;
     const int K = lv.chain, K4 = lv.chain >> 2, nice = lv.nice;
 
@@ -354,7 +356,6 @@ __global__ __launch_bounds__(1024) void zs_match_kernel(const StreamDesc *sd, co
     int snapped = 0;
     uint32_t scan_end = 0, mask = 0;  // scan_end = bytes p+best-3 .. p+best; mask drops the byte before p when best == 2
     uint32_t sc0 = 0, sc1 = 0;        // bytes p .. p+7 (the first 8 bytes of every compare)
-    int nexti = (int)(next - lo), wendi = (int)(wend - lo);  // wave-uniform, LDS-relative
     // after a finished compare of `len` bytes against candidate c: take the improvement, count the candidate, move on
     auto after_compare = [&](int len) {
         len = len > kMaxMatch ? kMaxMatch : len;
@@ -387,9 +388,14 @@ __global__ __launch_bounds__(1024) void zs_match_kernel(const StreamDesc *sd, co
         for (int rep = 0; rep < 2; rep++) {  // a position without a usable link is done at once: its lane pulls again
             const uint64_t need = __ballot(st == 3);
             if (!need) break;
-            const int mine = nexti + __builtin_popcountll(need & lanemask_lt());
-            nexti += __builtin_popcountll(need);
-            nexti = nexti > wendi ? wendi : nexti;
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&wg_cursor, (int)__builtin_popcountll(need));
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (base >= wendi) {  // nothing left in the tile
+                st = st == 3 ? 0 : st;
+                break;
+            }
+            const int mine = base + __builtin_popcountll(need & lanemask_lt());
             const bool take = st == 3 && mine < wendi, dry = st == 3 && mine >= wendi;
             const int q = take ? mine : 8;  // lanes that take nothing read an in-range dummy
             const int l = wl[q];
