@@ -83,7 +83,7 @@ def main():
     ap.add_argument("--workload", default="english64", choices=["english64", "sparse64", "batch"])
     ap.add_argument("--buffers", type=int, default=128, help="--workload batch: buffers per GPU (1 MiB each by default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--inflight", type=int, default=3, help="contexts in flight for the secondary `pipelined` figure (1 = skip)")
+    ap.add_argument("--inflight", type=int, default=1, help="> 1: also report the secondary `pipelined` figure with that many contexts in flight")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))

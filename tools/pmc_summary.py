@@ -48,7 +48,8 @@ if fetch or write:
                "kernels": ks}, open(os.path.join(dst, "%s_pmc_traffic_english64_L6.json" % tag), "w"), indent=1)
 for name, out in (("bench_english64.json", "bench_english64_L6.json"), ("bench_sparse64.json", "bench_sparse64_L6.json"),
                   ("bench_batch128.json", "bench_batch128x1MiB_L6.json"), ("bench_inflate.json", "bench_inflate1g.json"),
-                  ("time_levels.jsonl", "time_levels.jsonl")):
+                  ("time_levels.jsonl", "time_levels.jsonl"), ("host_path.jsonl", "host_path.jsonl"),
+                  ("bench_english64_pipelined.json", "bench_english64_L6_pipelined3.json")):
     p = os.path.join(src, name)
     if os.path.exists(p) and os.path.getsize(p) > 0:
         shutil.copy(p, os.path.join(dst, "%s_%s" % (tag, out)))
