@@ -355,3 +355,21 @@ def test_fuzz_mixed_inputs_all_slow_levels(engine, oracle, seed):
     got = engine.deflate_batch(bufs[:8], level=5, strategy=int(CompressionStrategy.Filtered))
     for i, (b, z) in enumerate(zip(bufs[:8], got)):
         assert z == oracle.compress(b, 5, int(CompressionStrategy.Filtered)), (seed, i)
+
+
+def test_streams_beyond_64_mib_bit_exact(engine, oracle):
+    """Single streams larger than the benchmark size, every byte against the oracle (position / symbol / bit offsets
+    that only grow past 2^26 .. 2^28): 256 MiB of sparse rows and 96 MiB of text."""
+    import torch
+    for name, data in (("sparse256", datagen.sparse(4096, 16384)), ("english96", datagen.english(96 << 20, 12345))):
+        n = len(data)
+        d_in = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
+        cap = deflate_bound(n)
+        d_out = torch.empty(cap, dtype=torch.uint8, device="cuda")
+        out_len = engine.deflate_batch_device([d_in.data_ptr()], [n], [d_out.data_ptr()], [cap], level=6,
+                                              stream=torch.cuda.current_stream().cuda_stream)[0]
+        z = d_out[:out_len].cpu().numpy().tobytes()
+        ref = oracle.compress(data, 6)
+        assert len(z) == len(ref), name
+        assert z == ref, name
+        del d_in, d_out
