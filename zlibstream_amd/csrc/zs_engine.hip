@@ -261,19 +261,11 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
                            dev<uint8_t>(c->stale), dev<uint16_t>(c->entry), dev<uint32_t>(c->symbase), c->crc_tab, lv, strategy,
                            hash_variant);
     mark(8);
-    if (!pl.w_chunks.empty()) {
-        static const bool wg_form = getenv("ZS_EMIT_WG") != nullptr;
-        if (wg_form)
-            hipLaunchKernelGGL(zs_emit_syms_kernel, dim3((unsigned)pl.w_chunks.size()), dim3(256), kEmitLds, stream, d_sd, d_work + o_chunks,
-                               dev<uint2>(c->mm), dev<uint16_t>(c->entry), dev<uint32_t>(c->symbase),
-                               dev<uint32_t>(c->syms), dev<int32_t>(c->blk_end), dev<int32_t>(c->blk_top), c->crc_tab, lv, strategy,
-                               hash_variant);
-        else
-            hipLaunchKernelGGL(zs_emit_syms_lane_kernel, dim3((unsigned)((pl.w_chunks.size() + 63) / 64)), dim3(64), 0, stream, d_sd,
-                               d_work + o_chunks, (int)pl.w_chunks.size(), dev<uint2>(c->mm), dev<uint16_t>(c->entry),
-                               dev<uint32_t>(c->symbase), dev<uint32_t>(c->syms), dev<int32_t>(c->blk_end), dev<int32_t>(c->blk_top),
-                               c->crc_tab, lv, strategy, hash_variant);
-    }
+    if (!pl.w_chunks.empty())
+        hipLaunchKernelGGL(zs_emit_syms_lane_kernel, dim3((unsigned)((pl.w_chunks.size() + 63) / 64)), dim3(64), 0, stream, d_sd,
+                           d_work + o_chunks, (int)pl.w_chunks.size(), dev<uint2>(c->mm), dev<uint16_t>(c->entry),
+                           dev<uint32_t>(c->symbase), dev<uint32_t>(c->syms), dev<int32_t>(c->blk_end), dev<int32_t>(c->blk_top),
+                           c->crc_tab, lv, strategy, hash_variant);
     mark(9);
     ZS_HIP(c, hipStreamWaitEvent(stream, c->ev_join, 0));
     hipLaunchKernelGGL(zs_body_blocks_kernel, dim3((unsigned)n), dim3(256), 0, stream, d_sd, d_st, dev<int32_t>(c->blk_end),
@@ -405,7 +397,6 @@ int zs_ctx_create(int device, zs_ctx **out) {
     if (hipMalloc((void **)&c->crc_tab, 4096) != hipSuccess ||
         hipMemcpy(c->crc_tab, tab.data(), 4096, hipMemcpyHostToDevice) != hipSuccess ||
         hipFuncSetAttribute((const void *)zs_match_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kMatchLds) != hipSuccess ||
-        hipFuncSetAttribute((const void *)zs_emit_syms_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kEmitLds) != hipSuccess ||
         hipFuncSetAttribute((const void *)zs_resolve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kResolveLds) != hipSuccess ||
         hipFuncSetAttribute((const void *)zs_links_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLkLds) != hipSuccess ||
         hipFuncSetAttribute((const void *)zs_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kTailLds) != hipSuccess ||

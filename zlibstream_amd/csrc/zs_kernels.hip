@@ -7,7 +7,7 @@
 //   K2 zs_match_kernel     per-position Longest_match for both chain budgets (Deflate.cs:1022-1100)
 //   K3 zs_chunkmap_kernel  lazy-parse transfer maps per 2 Ki-position chunk (Deflate.Slow.cs:34-145)
 //   K4 zs_resolve_kernel   compose the maps along the true path, refill quirk fix-ups (Deflate.cs:1010-1013)
-//   K5 zs_emit_syms_kernel symbols + block cuts along the true path (Tr_tally_*, Deflate.cs:910-948)
+//   K5 zs_emit_syms_lane_kernel symbols + block cuts along the true path (Tr_tally_*, Deflate.cs:910-948)
 //   K6 zs_tail_kernel      last <= 261 bytes by the literal engine (zs_lit_engine.h)
 //   K7 zs_trees_kernel     per-block histograms + exact Build_tree replay (Trees.cs:404-643)
 //   K8 zs_offsets_kernel   block bit offsets, zlib header / Adler trailer (Deflate.cs:464-493,627-635)
@@ -857,115 +857,11 @@ __global__ __launch_bounds__(64) void zs_expand_kernel(const StreamDesc *sd, con
 }
 
 // ------------------------------------------------------------------ K5
-// Symbols of one chunk along the true path.  The path is a chain through the chunk's
-// automaton; following it one lazy_step at a time on a single lane is ~1000 dependent
-// steps.  Instead: (1) every node's 1-step successor (J1, u16) and a jump table J
-// (kEmitRounds rounds of in-place squaring: every entry jumps >= 2^kEmitRounds steps and
-// carries its symbol count) are built by the whole workgroup; (2) lane 0 hops along J
-// from the entry node, recording checkpoints (node, symbol index); (3) each checkpoint
-// interval is expanded by one lane walking J1 and writing its symbols to LDS; (4) the
-// workgroup copies the symbols out coalesced.
-constexpr int kEmitRounds = 4;
-constexpr int kMaxCheckpoints = kChunk / (1 << kEmitRounds) + 8;
-constexpr int kEmitLds = 4 * (3 * (kChunk + 4) + kNodeExit + 1024) + 2 * (kNodeExit + 2 * (kMaxCheckpoints + 8)) + kChunk + 8;
-
-struct LdsSymSink {
-    uint32_t *buf;
-    uint32_t base;  // stream-global index of the chunk's first symbol
-    int32_t *blk_end, *blk_top;
-    __device__ void operator()(int i, uint32_t sym, int64_t end, int64_t top) {
-        buf[i] = sym;
-        uint32_t idx = base + (uint32_t)i;
-        if ((idx + 1) % kBlockSyms == 0) {
-            uint32_t bi = idx / kBlockSyms;
-            blk_end[bi] = (int32_t)end;
-            blk_top[bi] = (int32_t)top;
-        }
-    }
-};
-__global__ __launch_bounds__(256) void zs_emit_syms_kernel(const StreamDesc *sd, const uint2 *work, const uint2 *mm,
-                                                          const uint16_t *entry, const uint32_t *symbase,
-                                                          uint32_t *syms, int32_t *blk_end, int32_t *blk_top,
-                                                          const uint32_t *crc_tab_g, LevelCfg lv, int strategy,
-                                                          int hash_variant) {
-    // > 64 KiB of LDS: dynamic allocation (hipFuncAttributeMaxDynamicSharedMemorySize), carved by hand
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    uint32_t *fk = (uint32_t *)smem;                 // kChunk + 4
-    uint32_t *fk4 = fk + (kChunk + 4);               // kChunk + 4
-    uint32_t *J = fk4 + (kChunk + 4);                // kNodeExit
-    uint32_t *sbuf = J + kNodeExit;                  // kChunk + 4
-    uint32_t *tab = sbuf + (kChunk + 4);             // 1024
-    uint16_t *J1 = (uint16_t *)(tab + 1024);         // kNodeExit
-    uint16_t *cp_node = J1 + kNodeExit;              // kMaxCheckpoints + 8
-    uint16_t *cp_idx = cp_node + (kMaxCheckpoints + 8);
-    uint8_t *lb = (uint8_t *)(cp_idx + (kMaxCheckpoints + 8));  // kChunk + 8
-    __shared__ int sh_ncp, sh_cnt;
-    uint2 w = work[blockIdx.x];
-    const StreamDesc s = sd[w.x];
-    const int c = (int)w.y;
-    const ChunkGeo g = chunk_geo(c);
-    stage_chunk_matches(s, c, mm, strategy, fk, fk4);
-    if (g.first && g.seg <= s.kl) load_crc_tab(tab, crc_tab_g);
-    const int64_t org = g.cs - 1;
-    for (int i = threadIdx.x; i < kChunk + 1; i += 256) {
-        int64_t p = org + i;
-        lb[i] = (p >= 0 && p < s.n) ? as_global(s.in)[p] : 0;
-    }
-    __syncthreads();
-    int64_t ce = g.ce;
-    if (ce > (int64_t)s.body_end + 1) ce = (int64_t)s.body_end + 1;
-    const int len = (int)(ce - g.cs);
-    LdsAcc acc{as_global(s.in), fk, fk4, org, tab, hash_variant, lb};
-    for (int i = threadIdx.x; i < 4 * kChunk; i += 256) {
-        int kind = i >> kChunkBits, off = i & (kChunk - 1);
-        if (off < len) {
-            uint32_t v = node_step(acc, kind, g.cs + off, g.cs, ce, lv);
-            J[i] = v;
-            J1[i] = j1_pack(v);
-        }
-    }
-    __syncthreads();
-    for (int r = 0; r < kEmitRounds; r++) {
-        for (int i = threadIdx.x; i < 4 * kChunk; i += 256) {
-            if ((i & (kChunk - 1)) >= len) continue;
-            uint32_t v = J[i];
-            if (node_succ(v) < kNodeExit) J[i] = node_jump(v, J[node_succ(v)]);
-        }
-        __syncthreads();
-    }
-    const uint32_t base = symbase[s.chunk_off + c];
-    LdsSymSink sink{sbuf, base, blk_end + s.blk_off, blk_top + s.blk_off};
-    if (threadIdx.x == 0) {
-        int kind, ns;
-        int64_t p;
-        bool equal;
-        chunk_special_prefix(acc, sink, c, (int)entry[s.chunk_off + c], s.kl, s.body_end, lv, strategy, kind, p, ns, equal);
-        int ncp = 0;
-        int x = node_of(kind, p, g.cs, ce);
-        while (x < kNodeExit) {
-            cp_node[ncp] = (uint16_t)x;
-            cp_idx[ncp] = (uint16_t)ns;
-            ncp++;
-            uint32_t v = J[x];
-            x = node_succ(v);
-            ns += node_cnt(v);
-        }
-        cp_node[ncp] = (uint16_t)x;  // exit sentinel (>= kNodeExit never equals a node id)
-        cp_idx[ncp] = (uint16_t)ns;
-        sh_ncp = ncp;
-        sh_cnt = ns;
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < sh_ncp; i += 256) expand_interval(acc, J1, cp_node[i], cp_node[i + 1], cp_idx[i], g.cs, sink);
-    __syncthreads();
-    uint32_t *o = syms + s.sym_off + base;
-    for (int i = threadIdx.x; i < sh_cnt; i += 256) o[i] = sbuf[i];
-}
-
-// K5, lane-per-chunk form: every lane walks one chunk from its entry node straight out of HBM (a lane's reads
-// run along consecutive positions, so each 128-byte line of `mm` serves 16 steps out of L1/L2) and writes its
-// symbols in place.  All chunks of the batch walk at once, so the ~1000 dependent steps of a chunk are paid
-// once per launch, not once per workgroup.
+// Symbols + block cuts along the true path, one lane per chunk: every lane walks its chunk from its entry node
+// straight out of HBM (a lane's reads run along consecutive positions, so each 128-byte line of `mm` serves 16
+// steps out of L1/L2) and writes its symbols in place.  All chunks of the batch walk at once, so the ~1000
+// dependent steps of a chunk are paid once per launch.  (An earlier form built a jump table per chunk in LDS and
+// expanded checkpoint intervals with one workgroup per chunk: 2.5x slower.)
 struct GlobalSymSink {
     uint32_t *out;   // the chunk's first symbol
     uint32_t base;   // its stream-global index
