@@ -539,13 +539,30 @@ __global__ __launch_bounds__(512) void zs_chunkmap_kernel(const StreamDesc *sd, 
     // two dependent lookups per pass: after pass r every entry jumps >= 3^r steps or reaches its exit (a step advances
     // at least one position, a chunk has 2048: 3^7 = 2187)
     for (int r = 0; r < 7; r++) {
-        for (int i = threadIdx.x; i < 4 * kChunk; i += 512) {
-            if ((i & (kChunk - 1)) >= len) continue;
-            uint32_t v = tbl[i];
-            if (node_succ(v) < kNodeExit) {
-                v = node_jump(v, tbl[node_succ(v)]);
-                if (node_succ(v) < kNodeExit) v = node_jump(v, tbl[node_succ(v)]);
-                tbl[i] = v;
+        // four nodes per thread at a time, their lookups issued together (the LDS round trips overlap); a node past the
+        // end of the chunk or already at its exit looks itself up and stays as it is
+        for (int i0 = threadIdx.x; i0 < 4 * kChunk; i0 += 4 * 512) {
+            uint32_t v[4], w[4];
+            bool live[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int i = i0 + k * 512;
+                v[k] = tbl[i];
+                live[k] = (i & (kChunk - 1)) < len && node_succ(v[k]) < kNodeExit;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) w[k] = tbl[live[k] ? node_succ(v[k]) : 0];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (live[k]) v[k] = node_jump(v[k], w[k]);
+                live[k] = live[k] && node_succ(v[k]) < kNodeExit;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) w[k] = tbl[live[k] ? node_succ(v[k]) : 0];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (live[k]) v[k] = node_jump(v[k], w[k]);
+                if ((i0 + k * 512 & (kChunk - 1)) < len) tbl[i0 + k * 512] = v[k];
             }
         }
         __syncthreads();
