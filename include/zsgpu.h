@@ -135,6 +135,20 @@ ZS_API int zs_deflate(zs_deflate_stream *s, const uint8_t *next_in, int32_t *ava
 ZS_API void zs_deflate_end(zs_deflate_stream *s);
 ZS_API const char *zs_last_message(const zs_deflate_stream *s);
 
+/* zs_inflate_init <- Inflate..ctor (Inflate.cs:76-96); only window_bits 15 (zlib-wrapped) runs on the device: NULL otherwise.
+ * zs_inflate      <- Inflate.Decompress (Inflate.cs:103-357) as ZLibStream.Inflate(FlushMode) calls it
+ *   (ZlibStream.cs:119-122), driven by ZlibInputStream.ReadCore (ZlibInputStream.cs:133-186).  Same cursor convention as
+ *   zs_deflate.  The engine decodes whole streams: calls that bring input return ZS_OK after taking it; the first call
+ *   with *avail_in == 0 (BaseStream is exhausted) decodes on the GPU and output is served from then on, ZS_STREAM_END
+ *   with the last byte.  An incomplete stream at that point is ZS_BUF_ERROR; corrupt data gives ZS_DATA_ERROR with the
+ *   reference's message (zs_inflate_message). */
+typedef struct zs_inflate_stream zs_inflate_stream;
+ZS_API zs_inflate_stream *zs_inflate_init(zs_ctx *ctx, int window_bits);
+ZS_API int zs_inflate(zs_inflate_stream *s, const uint8_t *next_in, int32_t *avail_in, uint8_t *next_out, int32_t *avail_out,
+                      int flush, uint32_t *adler, int64_t *total_in, int64_t *total_out);
+ZS_API void zs_inflate_end(zs_inflate_stream *s);
+ZS_API const char *zs_inflate_message(const zs_inflate_stream *s);
+
 /* Adler32.Calculate (Adler32.cs:61-78) on the GPU, for a device-resident
  * buffer; result returned to the host. */
 ZS_API int zs_adler32_device(zs_ctx *ctx, const void *d_buf, int64_t len, uint32_t seed, uint32_t *out, void *hip_stream);

@@ -149,19 +149,43 @@ private:
 // first Read drains the base stream, inflates it on the GPU and later Reads are served from the result.
 class ZlibInputStream {
 public:
-    explicit ZlibInputStream(std::istream &input, zs_ctx *ctx = nullptr) : BaseStream(input), ctx_(ctx ? ctx : GpuContext::Shared()) {}
+    // ZlibInputStream.cs:29-76: 8 KiB chunk buffer, inflate mode
+    explicit ZlibInputStream(std::istream &input, zs_ctx *ctx = nullptr)
+        : BaseStream(input), ctx_(ctx ? ctx : GpuContext::Shared()), z_(zs_inflate_init(ctx_, 15)), chunk_(8192) {
+        if (!z_) throw std::out_of_range("windowBits");
+    }
+    ~ZlibInputStream() { zs_inflate_end(z_); }
+    ZlibInputStream(const ZlibInputStream &) = delete;
+    ZlibInputStream &operator=(const ZlibInputStream &) = delete;
     std::istream &BaseStream;
     bool CanRead() const { return true; }
     bool CanWrite() const { return false; }
+    int64_t TotalIn() const { return totalIn_; }
+    int64_t TotalOut() const { return totalOut_; }
 
-    // returns the number of bytes read, 0 at the end of the stream
+    // ReadCore (ZlibInputStream.cs:133-186): refill the chunk buffer when it is empty, call Inflate while the caller's
+    // buffer has room and the state is ZOK.  Returns the number of bytes read, 0 at the end of the stream.
     int Read(uint8_t *buffer, int offset, int count) {
-        if (!decoded_) Decode();
-        size_t n = data_.size() - pos_;
-        if (n > (size_t)count) n = (size_t)count;
-        std::copy(data_.begin() + (long)pos_, data_.begin() + (long)(pos_ + n), buffer + offset);
-        pos_ += n;
-        return (int)n;
+        if (count == 0) return 0;
+        int32_t availOut = count;
+        uint8_t *nextOut = buffer + offset;
+        int state;
+        do {
+            if (availIn_ == 0 && !noMoreInput_) {
+                BaseStream.read(reinterpret_cast<char *>(chunk_.data()), (std::streamsize)chunk_.size());
+                availIn_ = (int32_t)BaseStream.gcount();
+                nextIn_ = 0;
+            }
+            const int32_t inBefore = availIn_, outBefore = availOut;
+            state = zs_inflate(z_, chunk_.data() + nextIn_, &availIn_, nextOut, &availOut, ZS_NO_FLUSH, &adler_, &totalIn_, &totalOut_);
+            nextIn_ += inBefore - availIn_;
+            nextOut += outBefore - availOut;
+            if (state != ZS_OK && state != ZS_STREAM_END) {
+                const char *m = zs_inflate_message(z_);
+                throw ZlibStreamException(std::string("inflating: ") + (m ? m : ""));  // ThrowHelper.cs:21-23
+            }
+        } while (availOut > 0 && state == ZS_OK);
+        return count - availOut;
     }
     int ReadByte() {
         uint8_t b;
@@ -169,33 +193,13 @@ public:
     }
 
 private:
-    void Decode() {
-        std::vector<uint8_t> z((std::istreambuf_iterator<char>(BaseStream)), std::istreambuf_iterator<char>());
-        int64_t cap = (int64_t)z.size() * 4 + 65536;
-        for (;;) {
-            data_.resize((size_t)cap);
-            const void *in = z.data();
-            void *out = data_.data();
-            int64_t inLen = (int64_t)z.size(), outLen = 0;
-            int status = 0;
-            int rc = zs_inflate_batch(ctx_, 1, &in, &inLen, &out, &cap, &outLen, &status);
-            if (rc == ZS_OK) {
-                data_.resize((size_t)outLen);
-                break;
-            }
-            std::string m = zs_ctx_last_error(ctx_);
-            if (status == ZS_BUF_ERROR && m == "buffer error" && outLen >= cap && cap < (1LL << 31)) {
-                cap *= 4;  // the output did not fit: retry with a larger buffer
-                continue;
-            }
-            throw ZlibStreamException("inflating: " + m);  // ThrowHelper.cs:21-23
-        }
-        decoded_ = true;
-    }
     zs_ctx *ctx_;
-    std::vector<uint8_t> data_;
-    size_t pos_ = 0;
-    bool decoded_ = false;
+    zs_inflate_stream *z_;
+    std::vector<uint8_t> chunk_;
+    int32_t availIn_ = 0, nextIn_ = 0;
+    bool noMoreInput_ = false;
+    uint32_t adler_ = 1;
+    int64_t totalIn_ = 0, totalOut_ = 0;
 };
 
 }  // namespace ZlibStream

@@ -264,6 +264,32 @@ def test_zlib_input_stream_mirror(engine):
     s = ZlibInputStream(io.BytesIO(z), engine=engine)
     assert s.read(1000) == d[:1000]
     assert s.read() == d[1000:]
+    assert s.TotalIn == len(z) and s.TotalOut == len(d) and s.Adler == zlib.adler32(d)
+    assert s.read(10) == b""  # past the end of the stream
+
+
+def test_zs_inflate_stream_protocol(engine):
+    """zs_inflate under the ReadCore cadence (8 KiB input chunks, caller-sized output): several sizes incl. a stream
+    that expands ~1000x (output buffer grown on the device side), a truncated stream (ZBUFERROR, as the managed engine
+    reports when it cannot make progress) and a corrupted one (ZDATAERROR with the reference's message)."""
+    from zlibstream_amd import ZlibInputStream
+    for d in (b"", b"a", oracle_binding.corpus("fields.c"), bytes(5 << 20), datagen.english(3 << 20)):
+        z = zlib.compress(d, 6)
+        s = ZlibInputStream(io.BytesIO(z), engine=engine)
+        got = bytearray()
+        while True:
+            part = s.read(70000)
+            if not part:
+                break
+            got += part
+        assert bytes(got) == d, len(d)
+    z = zlib.compress(oracle_binding.corpus("alice29.txt"), 6)
+    with pytest.raises(ZlibStreamException, match="inflating: buffer error"):
+        ZlibInputStream(io.BytesIO(z[:len(z) // 2]), engine=engine).read()
+    bad = bytearray(z)
+    bad[-1] ^= 0x55
+    with pytest.raises(ZlibStreamException, match="inflating: incorrect data check"):
+        ZlibInputStream(io.BytesIO(bytes(bad)), engine=engine).read()
 
 
 def test_inflate_large_device_resident(engine):

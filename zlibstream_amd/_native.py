@@ -10,7 +10,7 @@ SYMBOLS = [
     "zs_ctx_create", "zs_ctx_destroy", "zs_ctx_last_error", "zs_deflate_bound", "zs_deflate_batch_device",
     "zs_deflate_batch", "zs_ctx_set_profiling", "zs_ctx_stage_count", "zs_ctx_stage_name", "zs_ctx_stage_ms",
     "zs_deflate_init", "zs_deflate", "zs_deflate_end", "zs_last_message", "zs_adler32_device",
-    "zs_inflate_batch_device", "zs_inflate_batch",
+    "zs_inflate_batch_device", "zs_inflate_batch", "zs_inflate_init", "zs_inflate", "zs_inflate_end", "zs_inflate_message",
 ]
 
 _lib = None
@@ -69,6 +69,14 @@ def lib():
     L.zs_deflate_end.argtypes = [vp]
     L.zs_last_message.restype = ctypes.c_char_p
     L.zs_last_message.argtypes = [vp]
+    L.zs_inflate_init.restype = vp
+    L.zs_inflate_init.argtypes = [vp, i32]
+    L.zs_inflate.restype = i32
+    L.zs_inflate.argtypes = [vp, vp, P(ctypes.c_int32), vp, P(ctypes.c_int32), i32, P(ctypes.c_uint32), P(i64), P(i64)]
+    L.zs_inflate_end.restype = None
+    L.zs_inflate_end.argtypes = [vp]
+    L.zs_inflate_message.restype = ctypes.c_char_p
+    L.zs_inflate_message.argtypes = [vp]
     L.zs_adler32_device.restype = i32
     L.zs_adler32_device.argtypes = [vp, vp, i64, ctypes.c_uint32, P(ctypes.c_uint32), vp]
     _lib = L

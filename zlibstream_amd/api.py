@@ -198,39 +198,74 @@ def compress(data, level=6, strategy=0, engine=None):
 class ZlibInputStream(io.RawIOBase):
     """ZlibInputStream.cs: a read-only stream that inflates `base_stream`.
 
-    The device decodes whole streams, so the first read drains the base stream, inflates it on the GPU
-    (growing the output buffer until it fits) and later reads are served from the decoded bytes.
+    Same loop as ReadCore (ZlibInputStream.cs:133-186): 8 KiB chunks of BaseStream go to `Inflate(flush)` while the
+    caller's buffer has room and the state is ZOK.  The device engine (zs_inflate) takes the chunks in, decodes the
+    whole stream on the GPU when a call arrives without input, and serves the output from then on.
     """
+
+    BUFFER_SIZE = 8192
 
     def __init__(self, base_stream, engine=None):
         super().__init__()
         self.BaseStream = base_stream
         self._engine = engine or default_engine()
-        self._data = None
-        self._pos = 0
+        self._lib = _native.lib()
+        self._z = self._lib.zs_inflate_init(self._engine.handle, 15)
+        if not self._z:
+            raise ValueError("zs_inflate_init")
+        self._chunk = b""
+        self._chunk_pos = 0
+        self._no_more_input = False
+        self.TotalIn = 0
+        self.TotalOut = 0
+        self.Adler = 1
 
     def readable(self):
         return True
 
-    def _decode(self):
-        z = self.BaseStream.read()
-        cap = max(4 * len(z), 1 << 16)
-        while True:
-            try:
-                self._data = self._engine.inflate_batch([z], [cap])[0]
-                return
-            except ZlibStreamException as e:
-                if "buffer error" in str(e) and cap < (1 << 31):
-                    cap *= 4
-                    continue
-                raise
+    def close(self):
+        if getattr(self, "_z", None):
+            self._lib.zs_inflate_end(self._z)
+            self._z = None
+        super().close()
+
+    def __del__(self):
+        try:
+            if getattr(self, "_z", None):
+                self._lib.zs_inflate_end(self._z)
+                self._z = None
+        except Exception:
+            pass
 
     def readinto(self, b):
-        if self._data is None:
-            self._decode()
-        n = min(len(b), len(self._data) - self._pos)
-        b[:n] = self._data[self._pos:self._pos + n]
-        self._pos += n
+        view = memoryview(b).cast("B")
+        if len(view) == 0:
+            return 0
+        out = (ctypes.c_uint8 * len(view))()
+        avail_out = ctypes.c_int32(len(view))
+        adler, tin, tout = ctypes.c_uint32(self.Adler), ctypes.c_int64(self.TotalIn), ctypes.c_int64(self.TotalOut)
+        out_index = 0
+        while True:
+            if self._chunk_pos == len(self._chunk) and not self._no_more_input:
+                self._chunk = self.BaseStream.read(self.BUFFER_SIZE) or b""
+                self._chunk_pos = 0
+            n_in = len(self._chunk) - self._chunk_pos
+            src = (ctypes.c_uint8 * max(1, n_in)).from_buffer_copy(self._chunk[self._chunk_pos:] or b"\0")
+            avail_in = ctypes.c_int32(n_in)
+            before_out = avail_out.value
+            state = self._lib.zs_inflate(self._z, ctypes.cast(src, ctypes.c_void_p), ctypes.byref(avail_in),
+                                         ctypes.c_void_p(ctypes.addressof(out) + out_index), ctypes.byref(avail_out), 0,
+                                         ctypes.byref(adler), ctypes.byref(tin), ctypes.byref(tout))
+            self._chunk_pos += n_in - avail_in.value
+            out_index += before_out - avail_out.value
+            if state not in (0, 1):
+                msg = (self._lib.zs_inflate_message(self._z) or b"").decode()
+                raise ZlibStreamException("inflating: " + msg)  # ThrowHelper.cs:21-23
+            if not (avail_out.value > 0 and state == 0):
+                break
+        self.Adler, self.TotalIn, self.TotalOut = adler.value, tin.value, tout.value
+        n = len(view) - avail_out.value
+        view[:n] = bytes(out)[:n]
         return n
 
 

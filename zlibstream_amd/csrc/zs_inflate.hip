@@ -312,7 +312,11 @@ __global__ __launch_bounds__(64) void zs_inflate_kernel(const InfDesc *descs, In
                 if (e != kInfEsc) sym = e >> 4, clen = e & 15;
                 else sym = inf_slow(b, T.lcount, T.lsym, clen);
             }
-            if (sym < 0 || clen > b.cnt) INF_FAIL(b.pos >= b.n && b.cnt < 15 ? ZS_BUF_ : ZS_DATA_, sym < 0 ? kInfBadLitCode : kInfTruncated);
+            if (sym < 0 || clen > b.cnt) {
+                // the bits ran out inside a code (the window is zero-padded past the end): not corrupt data, a truncated stream
+                const bool trunc = b.pos >= b.n && b.cnt < 15;
+                INF_FAIL(trunc ? ZS_BUF_ : ZS_DATA_, trunc || sym >= 0 ? kInfTruncated : kInfBadLitCode);
+            }
             b.drop(clen);
             if (sym < 256) {
                 if (pos >= d.out_cap) INF_FAIL(ZS_BUF_, kInfOutputFull);
@@ -331,9 +335,13 @@ __global__ __launch_bounds__(64) void zs_inflate_kernel(const InfDesc *descs, In
                     if (e != kInfEsc) ds = e >> 4, dl = e & 15;
                     else ds = inf_slow(b, T.dcount, T.dsym, dl);
                 }
-                if (ds < 0 || ds >= 30 || dl > b.cnt) INF_FAIL(b.pos >= b.n && b.cnt < 15 ? ZS_BUF_ : ZS_DATA_, kInfBadDistCode);
+                if (ds < 0 || ds >= 30 || dl > b.cnt) {
+                    const bool trunc = b.pos >= b.n && b.cnt < 15;
+                    INF_FAIL(trunc ? ZS_BUF_ : ZS_DATA_, trunc ? kInfTruncated : kInfBadDistCode);
+                }
                 b.drop(dl);
                 const int dist = base_dist(ds) + 1 + (int)b.take(extra_dbits(ds));
+                if (b.bad) INF_FAIL(ZS_BUF_, kInfTruncated);  // extra bits past the end of the input
                 if (dist > pos || dist > kWSize) INF_FAIL(ZS_DATA_, kInfBadDistCode);
                 if (pos + mlen > d.out_cap) INF_FAIL(ZS_BUF_, kInfOutputFull);
                 // one wave: DS operations execute in program order, so lane 0's literal stores are
