@@ -1261,15 +1261,171 @@ __global__ __launch_bounds__(64) void zs_fast_blocks_kernel(const StreamDesc *sd
     }
 }
 
+// Build_tree (Trees.cs:404-501) by one wave.  The priority queue is sifted by lane 0 exactly as the reference does
+// (zs_core.h build_tree: tie-breaking decides the tree); what surrounds it is data-parallel and costs as much as the
+// queue on blocks with a full alphabet (binary or image data: ~260 of 286 symbols in use):
+//   * the queue's initial contents: ballot-compaction of the symbols in use;
+//   * Gen_bitlen (Trees.cs:999-1109): a node's length is its depth -- pointer jumping over (parent, distance) words
+//     instead of one dependent lookup per node; any depth beyond max_length sends the tree to the reference's
+//     overflow repair (the sequential gen_bitlen, untouched);
+//   * Gen_codes (Trees.cs:1123-1151): `next_code[len]++` in symbol order is a returning LDS add per symbol (the LDS
+//     applies the lanes of one instruction in lane order, see K1).
+// `pd`: kHeapSize words, `nc`: 16 words of LDS scratch.  Every lane returns max_code.
+__device__ int build_tree_wave(TreeWork &w, uint32_t *hk, uint32_t *pd, uint32_t *nc, CtData *tree, const TreeDesc &d, int lane) {
+    int len = 0, max_code = -1;
+    for (int base = 0; base < d.elems; base += 64) {
+        const int n = base + lane;
+        const uint32_t f = n < d.elems ? tree[n].fc : 0;
+        const uint64_t nz = __ballot(f != 0);
+        if (f) hk[len + 1 + __builtin_popcountll(nz & lanemask_lt())] = hk_pack(f, 0, (uint32_t)n);
+        else if (n < d.elems) tree[n].dl = 0;
+        if (nz) max_code = base + 63 - __builtin_clzll(nz);
+        len += __builtin_popcountll(nz);
+    }
+    while (len < 2) {  // force at least two codes of non-zero frequency
+        const int node = max_code < 2 ? ++max_code : 0;
+        len++;
+        if (lane == 0) {
+            hk[len] = hk_pack(1, 0, (uint32_t)node);
+            tree[node].fc = 1;
+            w.opt_len--;
+            if (d.which != 2) w.static_len -= desc_static_len(d, node);
+        }
+    }
+    __threadfence_block();
+    if (lane == 0) {
+        w.heap_max = kHeapSize;
+        int hl = len;
+        for (int n = hl / 2; n >= 1; n--) pqdownheap_packed(hk, hl, n);
+        int node = d.elems;
+        do {
+            const uint32_t n = hk[1];
+            hk[1] = hk[hl--];
+            pqdownheap_packed(hk, hl, 1);
+            const uint32_t m = hk[1];
+            w.heap[--w.heap_max] = (uint16_t)(n & 1023u);
+            w.heap[--w.heap_max] = (uint16_t)(m & 1023u);
+            const uint32_t f = (n >> 16) + (m >> 16), dn = (n >> 10) & 63u, dm = (m >> 10) & 63u;
+            tree[node].fc = (uint16_t)f;
+            tree[n & 1023u].dl = tree[m & 1023u].dl = (uint16_t)node;
+            hk[1] = hk_pack(f, (dn >= dm ? dn : dm) + 1, (uint32_t)node);
+            node++;
+            pqdownheap_packed(hk, hl, 1);
+        } while (hl >= 2);
+        w.heap[--w.heap_max] = (uint16_t)(hk[1] & 1023u);
+        w.heap_len = hl;
+    }
+    __threadfence_block();
+    // ---- lengths = depths
+    const int hmax = w.heap_max, root = w.heap[hmax];
+    for (int h = hmax + lane; h < kHeapSize; h += 64) {
+        const int n = w.heap[h];
+        pd[n] = h == hmax ? ((uint32_t)n << 8) : (((uint32_t)tree[n].dl << 8) | 1u);
+    }
+    __threadfence_block();
+    for (int r = 0; r < 6; r++) {  // 2^6 >= any depth a tree over <= 65535 counts can have
+        for (int h = hmax + lane; h < kHeapSize; h += 64) {
+            const int n = w.heap[h];
+            const uint32_t v = pd[n], pv = pd[v >> 8];
+            pd[n] = (pv & ~0xFFu) | ((v & 0xFFu) + (pv & 0xFFu));  // one word: always a consistent (ancestor, distance) pair
+        }
+        __threadfence_block();
+    }
+    bool over = false;
+    for (int h = hmax + lane; h < kHeapSize; h += 64) over |= (int)(pd[w.heap[h]] & 0xFFu) > d.max_length;
+    (void)root;
+    if (__ballot(over)) {
+        if (lane == 0) gen_bitlen(w, tree, max_code, d);  // the reference's walk with its overflow repair
+        __threadfence_block();
+    } else {
+        if (lane < 16) nc[lane] = 0;
+        __threadfence_block();
+        int opt = 0, stat = 0;
+        for (int h = hmax + lane; h < kHeapSize; h += 64) {
+            const int n = w.heap[h];
+            const int bits = (int)(pd[n] & 0xFFu);
+            tree[n].dl = (uint16_t)bits;
+            if (n <= max_code) {
+                atomicAdd(&nc[bits], 1u);
+                const int xbits = desc_extra(d, n), f = tree[n].fc;
+                opt += f * (bits + xbits);
+                if (d.which != 2) stat += f * (desc_static_len(d, n) + xbits);
+            }
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) opt += __shfl_xor(opt, o), stat += __shfl_xor(stat, o);
+        __threadfence_block();
+        if (lane <= kMaxBits) w.bl_count[lane] = (uint16_t)nc[lane];
+        if (lane == 0) w.opt_len += opt, w.static_len += stat;
+        __threadfence_block();
+    }
+    // ---- codes
+    if (lane == 0) {
+        unsigned code = 0;
+        nc[0] = 0;
+        for (int bits = 1; bits <= kMaxBits; bits++) {
+            code = (code + w.bl_count[bits - 1]) << 1;
+            nc[bits] = code;
+        }
+    }
+    __threadfence_block();
+    for (int base = 0; base <= max_code; base += 64) {
+        const int n = base + lane;
+        const int l = n <= max_code ? (int)tree[n].dl : 0;
+        if (l) {
+            const uint32_t code = atomicAdd(&nc[l], 1u);  // lanes in order: the symbols of one length get consecutive codes
+            tree[n].fc = (uint16_t)(__brev(code) >> (32 - l));
+        }
+    }
+    __threadfence_block();
+    return max_code;
+}
+// Tr_flush_block's tree phase (zs_core.h build_block_trees) with the wave form of Build_tree; lane 0's return value counts.
+__device__ int build_block_trees_wave(TreeWork &w, uint32_t *hk, uint32_t *pd, uint32_t *nc, int stored_len, bool can_store,
+                                      int strategy, int lane) {
+    if (lane == 0) {
+        w.opt_len = w.static_len = 0;
+        for (int i = 0; i < kBlCodes; i++) w.bltree[i].fc = 0;
+    }
+    __threadfence_block();
+    const TreeDesc ld = {0, kLCodes, kMaxBits, kLiterals + 1};
+    const TreeDesc dd = {1, kDCodes, kMaxBits, 0};
+    const TreeDesc bd = {2, kBlCodes, kMaxBlBits, 0};
+    const int lmax = build_tree_wave(w, hk, pd, nc, w.ltree, ld, lane);
+    const int dmax = build_tree_wave(w, hk, pd, nc, w.dtree, dd, lane);
+    if (lane == 0) {
+        w.l_max_code = lmax, w.d_max_code = dmax;
+        scan_tree(w, w.ltree, lmax);
+        scan_tree(w, w.dtree, dmax);
+    }
+    __threadfence_block();
+    build_tree_wave(w, hk, pd, nc, w.bltree, bd, lane);
+    int type = 2;
+    if (lane == 0) {
+        int mb;
+        for (mb = kBlCodes - 1; mb >= 3; mb--)
+            if (w.bltree[bl_order(mb)].dl != 0) break;
+        w.max_blindex = mb;
+        w.opt_len += 3 * (mb + 1) + 5 + 5 + 4;
+        int opt_lenb = (w.opt_len + 3 + 7) >> 3;
+        const int static_lenb = (w.static_len + 3 + 7) >> 3;
+        if (static_lenb <= opt_lenb) opt_lenb = static_lenb;
+        if (stored_len + 4 <= opt_lenb && can_store) type = 0;
+        else if (strategy == kFixed || static_lenb == opt_lenb) type = 1;
+    }
+    return type;
+}
+
 // ------------------------------------------------------------------ K7
-// One workgroup per block: histogram the block's symbols (Tr_tally_*), then
-// thread 0 replays Build_tree x3 exactly and picks the block type.
+// One workgroup per block: histogram the block's symbols (Tr_tally_*), then wave 0 replays Build_tree x3 exactly
+// (build_tree_wave) and picks the block type.
 __global__ __launch_bounds__(256) void zs_trees_kernel(const StreamDesc *sd, const StreamState *st, const uint2 *work,
                                                        const uint32_t *syms, const BlockRec *blocks, TreeWork *trees,
                                                        BlockInfo *info, int strategy, int level, int phase) {
     __shared__ TreeWork tw;
     __shared__ uint32_t hl[kLCodes], hd[kDCodes];
     __shared__ uint32_t hk[kHeapSize + 1];  // Build_tree's priority queue
+    __shared__ uint32_t pd[kHeapSize + 1], nc[16];  // (ancestor, distance) words of the depth pass; per-length counters
     uint2 w = work[blockIdx.x];
     const StreamDesc s = sd[w.x];
     const int b = (int)w.y;
@@ -1301,9 +1457,11 @@ __global__ __launch_bounds__(256) void zs_trees_kernel(const StreamDesc *sd, con
     }
     if (threadIdx.x < 2 * kBlCodes + 1) tw.bltree[threadIdx.x].fc = 0, tw.bltree[threadIdx.x].dl = 0;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        tw.ltree[kEndBlock].fc = 1;
-        int type = build_block_trees(tw, hk, r.stored_len, r.can_store != 0, strategy);
+    if (threadIdx.x == 0) tw.ltree[kEndBlock].fc = 1;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        int type = build_block_trees_wave(tw, hk, pd, nc, r.stored_len, r.can_store != 0, strategy, (int)threadIdx.x);
+        if (threadIdx.x == 0) {
         // level 0 skips the tree comparison: opt_lenb = static_lenb = stored_len + 5, i.e. stored when the block
         // start is still in the window, else static trees (Trees.cs:601-620)
         if (level == 0) type = r.can_store ? 0 : 1;
@@ -1312,6 +1470,7 @@ __global__ __launch_bounds__(256) void zs_trees_kernel(const StreamDesc *sd, con
         bi.bits = type == 1 ? 3 + tw.static_len : type == 2 ? 3 + tw.opt_len : 0;
         bi.bit_start = 0;
         info[s.blk_off + b] = bi;
+        }
     }
     __syncthreads();
     uint32_t *dst = (uint32_t *)&trees[s.blk_off + b];
