@@ -415,7 +415,7 @@ static std::vector<uint8_t> emit_stream(Model &m) {
         }
         w.ltree[kEndBlock].fc = 1;
         so += m.blocks[b].nsyms;
-        std::vector<uint32_t> hk(kHeapSize + 1);
+        std::vector<uint32_t> hk(kHeapSize + 8);
         type[b] = build_block_trees(w, hk.data(), m.blocks[b].stored_len, m.blocks[b].can_store != 0, m.strategy);
         if (m.level == 0) type[b] = m.blocks[b].can_store ? 0 : 1;
         bits[b] = type[b] == 1 ? 3 + w.static_len : type[b] == 2 ? 3 + w.opt_len : 0;

@@ -1424,7 +1424,7 @@ __global__ __launch_bounds__(256) void zs_trees_kernel(const StreamDesc *sd, con
                                                        BlockInfo *info, int strategy, int level, int phase) {
     __shared__ TreeWork tw;
     __shared__ uint32_t hl[kLCodes], hd[kDCodes];
-    __shared__ uint32_t hk[kHeapSize + 1];  // Build_tree's priority queue
+    __shared__ uint32_t hk[kHeapSize + 8];  // Build_tree's priority queue (the sift reads a few entries past the end)
     __shared__ uint32_t pd[kHeapSize + 1], nc[16];  // (ancestor, distance) words of the depth pass; per-length counters
     uint2 w = work[blockIdx.x];
     const StreamDesc s = sd[w.x];
