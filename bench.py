@@ -210,7 +210,7 @@ def main():
         }
         if pipelined:
             line["pipelined"] = pipelined
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # the CPU leg runs on rank 0 of the single-GPU run only
             cb, ref, sample_len = cpu_baseline(data, args.level, name=args.workload)
             line["cpu_baseline"] = cb
             if sample_len == n and len(datas) == 1:
