@@ -98,6 +98,41 @@ ZS_HD uint32_t le_hash(const LitEngine &e, uint32_t v) {
 ZS_HD uint32_t le_load32(const uint8_t *p) {
     return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
 }
+// 8 bytes at any alignment, little-endian.  On the device three aligned dword loads and a funnel shift: the window is
+// in LDS behind a generic pointer, where byte loads cost a round trip each and misaligned wide loads are slow.
+ZS_HD uint64_t le_load64(const uint8_t *p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t *q = (const uint32_t *)((uintptr_t)p & ~(uintptr_t)3);
+    const uint32_t a = q[0], b = q[1], c = q[2], sh = ((uint32_t)(uintptr_t)p & 3u) * 8u;
+    const uint64_t lo = (uint64_t)a | ((uint64_t)b << 32);
+    return sh ? (lo >> sh) | ((uint64_t)c << (64 - sh)) : lo;
+#else
+    uint64_t v = 0;
+    for (int i = 0; i < 8; i++) v |= (uint64_t)p[i] << (8 * i);
+    return v;
+#endif
+}
+// number of equal leading bytes of a and b, at most kMaxMatch (Compare256 of the reference's Longest_match); reads up
+// to 10 bytes past a + kMaxMatch / b + kMaxMatch (the window carries 512 bytes of padding)
+ZS_HD int le_match_len(const uint8_t *a, const uint8_t *b) {
+    int len = 0;
+    while (len < kMaxMatch) {
+        const uint64_t x = le_load64(a + len) ^ le_load64(b + len);
+        if (x) {
+            int tz = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+            tz = (int)__builtin_ctzll(x);
+#else
+            uint64_t y = x;
+            while (!(y & 1)) y >>= 1, tz++;
+#endif
+            len += tz >> 3;
+            break;
+        }
+        len += 8;
+    }
+    return len < kMaxMatch ? len : kMaxMatch;
+}
 
 // Deflate.cs:866-877
 ZS_HD int le_insert(LitEngine &e, int str) {
@@ -203,8 +238,7 @@ ZS_HD_NOINLINE inline int le_longest_match(LitEngine &e, int cur_match) {
         const uint8_t *m = e.window + cur_match;
         if (m[best_len] != scan[best_len] || m[best_len - 1] != scan[best_len - 1] || m[0] != scan[0] || m[1] != scan[1])
             continue;
-        int len = 2;
-        while (len < kMaxMatch && scan[len] == m[len]) len++;
+        const int len = le_match_len(scan, m);  // bytes 0 and 1 are known to match
         if (len > best_len) {
             ms = cur_match;
             best_len = len;
@@ -365,8 +399,7 @@ ZS_HD_NOINLINE inline void le_run_rle(LitEngine &e, int lane, int nlanes) {
             const uint8_t *w = e.window + e.strstart;
             const uint8_t prev = w[-1];
             if (prev == w[0] && prev == w[1] && prev == w[2]) {
-                int len = 3;
-                while (len < kMaxMatch && w[len] == prev) len++;
+                const int len = le_match_len(w, w - 1);  // the run of `prev` = what w shares with itself one byte back
                 e.match_length = len < e.lookahead ? len : e.lookahead;
             }
         }
