@@ -1123,6 +1123,7 @@ __global__ __launch_bounds__(1024) void zs_fast_run_kernel(const StreamDesc *sd,
     __syncthreads();
     if (tid >= 64) return;
     le_run_fast(e, tid, 64);
+    le_flush_ins(e);
     if (tid == 0) {
         FastRunOut &o = outs[run];
         o.mark_pos = e.mark_pos, o.mark_nsyms = e.mark_nsyms;

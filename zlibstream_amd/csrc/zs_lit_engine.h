@@ -69,6 +69,8 @@ struct LitEngine {
     int64_t mark_abs;         // record the first loop-top >= this ...
     int64_t mark_pos, mark_nsyms;  // ... its position and the symbols emitted before it (-1 until reached)
     uint32_t *ins_bits;       // bitmap of inserted positions, bit (abs - ins_base); nullptr: not tracked
+    int64_t ins_word_idx;     // the bitmap word being filled (-1: none) and its bits so far; le_flush_ins() stores it
+    uint32_t ins_word;
     int64_t ins_base;
     int no_blocks;            // do not cut blocks (the caller does it after stitching the runs)
     int64_t *ev_log;          // loop-tops at which a refill read happened (the pre-insert positions - 1), up to 16
@@ -84,7 +86,7 @@ struct LitEngine {
 ZS_HD void le_defaults(LitEngine &e) {
     e.wr_end = nullptr, e.n_wr = 1, e.cur_wr = 0;
     e.stop_abs = -1, e.mark_abs = -1, e.mark_pos = -1, e.mark_nsyms = 0;
-    e.ins_bits = nullptr, e.ins_base = 0, e.no_blocks = 0;
+    e.ins_bits = nullptr, e.ins_base = 0, e.no_blocks = 0, e.ins_word_idx = -1, e.ins_word = 0;
     e.ev_log = nullptr, e.n_ev = 0;
     e.block_syms = kBlockSyms, e.block_sym_start = 0, e.block_start_abs = 0, e.defer_start = 0;
     e.nsyms = 0, e.nblocks = 0;
@@ -134,11 +136,27 @@ ZS_HD int le_match_len(const uint8_t *a, const uint8_t *b) {
     return len < kMaxMatch ? len : kMaxMatch;
 }
 
+ZS_HD void le_flush_ins(LitEngine &e) {
+    if (e.ins_bits && e.ins_word_idx >= 0) e.ins_bits[e.ins_word_idx] |= e.ins_word;
+    e.ins_word_idx = -1, e.ins_word = 0;
+}
+
 // Deflate.cs:866-877
 ZS_HD int le_insert(LitEngine &e, int str) {
     if (e.ins_bits) {
+        // positions arrive in (almost) increasing order: the current bitmap word is kept in a register and stored when
+        // the engine moves past it; only the refill pre-insert (s + 1 before s) can step back across a word boundary
         const int64_t i = e.base + str - e.ins_base;
-        e.ins_bits[i >> 5] |= 1u << (i & 31);  // every lane writes the same word: benign
+        const int64_t wi = i >> 5;
+        const uint32_t bit = 1u << (i & 31);
+        if (wi == e.ins_word_idx) {
+            e.ins_word |= bit;
+        } else if (wi > e.ins_word_idx) {
+            if (e.ins_word_idx >= 0) e.ins_bits[e.ins_word_idx] |= e.ins_word;  // every lane writes the same word: benign
+            e.ins_word_idx = wi, e.ins_word = bit;
+        } else {
+            e.ins_bits[wi] |= bit;
+        }
     }
     uint32_t h = le_hash(e, le_load32(e.window + str + 2));
     int cur = e.head[h];
