@@ -187,24 +187,24 @@ static void parse_chunked(Model &m, int64_t &p_out, int &kind_out, uint32_t &pen
     int nchunks = chunk_of(m.body_end) + 1;
     // K3: maps for every chunk and entry slot (embarrassingly parallel on the GPU)
     std::vector<uint32_t> maps((size_t)nchunks * kSlots);
-    std::vector<uint32_t> tbl(kNodeExit);
+    std::vector<uint32_t> tbl(kNodeExit3);
     ModelAcc macc{&m};
     for (int c = 0; c < nchunks; c++) {
-        // jump table of the chunk (the GPU builds it with 512 threads and in-place squaring rounds)
+        // jump table of the chunk, three rows (R, L-or-XK, XK4) as K3 builds it with 512 threads and in-place jumping passes
         ChunkGeo g = chunk_geo(c);
         int64_t ce = std::min<int64_t>(g.ce, m.body_end + 1);
-        for (int kind = 0; kind < 4; kind++)
-            for (int64_t p = g.cs; p < ce; p++) tbl[kind * kChunk + (int)(p - g.cs)] = node_step(macc, kind, p, g.cs, ce, m.lv);
+        for (int row = 0; row < 3; row++)
+            for (int64_t p = g.cs; p < ce; p++) tbl[row * kChunk + (int)(p - g.cs)] = node_step3(macc, row, p, g.cs, ce, m.lv);
         for (int r = 0; r < kJumpRounds; r++)
-            for (int kind = 0; kind < 4; kind++)
+            for (int row = 0; row < 3; row++)
                 for (int64_t p = g.cs; p < ce; p++) {
-                    int x = kind * kChunk + (int)(p - g.cs);
+                    int x = row * kChunk + (int)(p - g.cs);
                     uint32_t v = tbl[x];
-                    if (node_succ(v) < kNodeExit) tbl[x] = node_jump(v, tbl[node_succ(v)]);
+                    if (node_succ(v) < kNodeExit3) tbl[x] = node_jump(v, tbl[node_succ(v)]);
                 }
         for (int s = 0; s < kSlots; s++) {
             if (!slot_valid(c, s, m.body_end)) { maps[(size_t)c * kSlots + s] = 0; continue; }
-            uint32_t v = chunk_exit_by_table(macc, tbl, c, s, kl, m.body_end, m.lv, m.strategy);
+            uint32_t v = chunk_exit_by_table3(macc, tbl, c, s, kl, m.body_end, m.lv, m.strategy);
             int ex, ns;
             chunk_walk(m, c, s, kl, ex, ns, nullptr);  // cross-check against the plain walk
             if (map_exit(v) != ex || map_count(v) != ns) {
@@ -268,51 +268,13 @@ static void parse_chunked(Model &m, int64_t &p_out, int &kind_out, uint32_t &pen
     m.syms.assign((size_t)total, 0);
     size_t nb = (size_t)(total / kBlockSyms);
     std::vector<int64_t> blk_end(nb), blk_top(nb);
-    std::vector<uint16_t> J1(kNodeExit);
-    std::vector<uint32_t> ref_syms;
     for (int c = 0; c < nchunks; c++) {
-        // the way K5 does it: 1-step table J1, jump table J (4 squaring rounds), checkpoints, expansion
-        ChunkGeo g = chunk_geo(c);
-        int64_t ce = std::min<int64_t>(g.ce, m.body_end + 1);
-        for (int kind = 0; kind < 4; kind++)
-            for (int64_t p = g.cs; p < ce; p++) {
-                int x = kind * kChunk + (int)(p - g.cs);
-                tbl[x] = node_step(macc, kind, p, g.cs, ce, m.lv);
-                J1[x] = j1_pack(tbl[x]);
-            }
-        for (int r = 0; r < 4; r++)
-            for (int kind = 0; kind < 4; kind++)
-                for (int64_t p = g.cs; p < ce; p++) {
-                    int x = kind * kChunk + (int)(p - g.cs);
-                    uint32_t v = tbl[x];
-                    if (node_succ(v) < kNodeExit) tbl[x] = node_jump(v, tbl[node_succ(v)]);
-                }
+        // the way K5 does it: every chunk on its own from its true entry (the refill-rule prefix, then plain steps)
         Sink sk{symbase[c], &m.syms, &blk_end, &blk_top};
-        int kind, ns;
-        int64_t p;
-        bool equal;
-        chunk_special_prefix(macc, sk, c, entry[c], kl, m.body_end, m.lv, m.strategy, kind, p, ns, equal);
-        std::vector<int> cpn, cpi;
-        int x = node_of(kind, p, g.cs, ce);
-        while (x < kNodeExit) {
-            cpn.push_back(x), cpi.push_back(ns);
-            uint32_t v = tbl[x];
-            x = node_succ(v);
-            ns += node_cnt(v);
-        }
-        cpn.push_back(x), cpi.push_back(ns);
-        for (size_t i = 0; i + 1 < cpn.size(); i++) expand_interval(macc, J1, cpn[i], cpn[i + 1], cpi[i], g.cs, sk);
-        // cross-check against the plain walk
+        int ex, ns;
+        chunk_walk(m, c, entry[c], kl, ex, ns, &sk);
         int64_t nxt = c + 1 < nchunks ? symbase[c + 1] : total;
-        if (symbase[c] + ns != nxt) { printf("chunk %d: checkpoint count %d vs %ld\n", c, ns, (long)(nxt - symbase[c])); exit(1); }
-        ref_syms.assign((size_t)ns + 4, 0);
-        std::vector<int64_t> be(nb + 1), bt(nb + 1);
-        std::vector<uint32_t> tmp((size_t)total + 4);
-        Sink sk2{symbase[c], &tmp, &be, &bt};
-        int ex, ns2;
-        chunk_walk(m, c, entry[c], kl, ex, ns2, &sk2);
-        for (int i = 0; i < ns; i++)
-            if (tmp[(size_t)symbase[c] + i] != m.syms[(size_t)symbase[c] + i]) { printf("chunk %d sym %d differs\n", c, i); exit(1); }
+        if (symbase[c] + ns != nxt) { printf("chunk %d: %d symbols, maps said %ld\n", c, ns, (long)(nxt - symbase[c])); exit(1); }
     }
     int64_t bs = 0;
     for (size_t b = 0; b < nb; b++) {

@@ -509,15 +509,15 @@ __device__ __forceinline__ void stage_chunk_matches(const StreamDesc &s, int c, 
 }
 
 // ------------------------------------------------------------------ K3
-// Transfer map of one chunk for all 260 entry slots.  512 threads: one lazy_step per
-// automaton node (4 states x 2048 positions) builds the 1-step table in LDS, in-place
-// squaring rounds turn it into node -> (exit slot, symbols), then one lane per slot reads
-// its entry (the refill-rule positions of segment-first chunks are stepped explicitly).
+// Transfer map of one chunk for all 260 entry slots.  512 threads: one lazy_step per table node (3 rows x 2048
+// positions: R, L-or-XK, XK4 -- zs_core.h node_step3) builds the 1-step table in LDS, in-place jumping passes turn it
+// into node -> (exit slot, symbols), then one lane per slot reads its entry (the refill-rule positions of
+// segment-first chunks are stepped explicitly).
 __global__ __launch_bounds__(512) void zs_chunkmap_kernel(const StreamDesc *sd, const uint2 *work, const uint2 *mm,
                                                           uint32_t *maps, const uint32_t *crc_tab_g,
                                                           LevelCfg lv, int strategy, int hash_variant) {
     __shared__ uint32_t fk[kChunk + 1], fk4[kChunk + 1];
-    __shared__ uint32_t tbl[kNodeExit];
+    __shared__ uint32_t tbl[kNodeExit3];
     __shared__ uint32_t tab[1024];
     uint2 w = work[blockIdx.x];
     const StreamDesc s = sd[w.x];
@@ -531,9 +531,9 @@ __global__ __launch_bounds__(512) void zs_chunkmap_kernel(const StreamDesc *sd, 
     if (ce > (int64_t)s.body_end + 1) ce = (int64_t)s.body_end + 1;
     const int len = (int)(ce - g.cs);
     LdsAcc acc{as_global(s.in), fk, fk4, g.cs - 1, tab, hash_variant};
-    for (int i = threadIdx.x; i < 4 * kChunk; i += 512) {
-        int kind = i >> kChunkBits, off = i & (kChunk - 1);
-        if (off < len) tbl[i] = node_step(acc, kind, g.cs + off, g.cs, ce, lv);
+    for (int i = threadIdx.x; i < 3 * kChunk; i += 512) {
+        const int row = i >> kChunkBits, off = i & (kChunk - 1);
+        if (off < len) tbl[i] = node_step3(acc, row, g.cs + off, g.cs, ce, lv);
     }
     __syncthreads();
     // two dependent lookups per pass: after pass r every entry jumps >= 3^r steps or reaches its exit (a step advances
@@ -541,21 +541,21 @@ __global__ __launch_bounds__(512) void zs_chunkmap_kernel(const StreamDesc *sd, 
     for (int r = 0; r < 7; r++) {
         // four nodes per thread at a time, their lookups issued together (the LDS round trips overlap); a node past the
         // end of the chunk or already at its exit looks itself up and stays as it is
-        for (int i0 = threadIdx.x; i0 < 4 * kChunk; i0 += 4 * 512) {
+        for (int i0 = threadIdx.x; i0 < 3 * kChunk; i0 += 4 * 512) {
             uint32_t v[4], w[4];
             bool live[4];
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 const int i = i0 + k * 512;
                 v[k] = tbl[i];
-                live[k] = (i & (kChunk - 1)) < len && node_succ(v[k]) < kNodeExit;
+                live[k] = (i & (kChunk - 1)) < len && node_succ(v[k]) < kNodeExit3;
             }
 #pragma unroll
             for (int k = 0; k < 4; k++) w[k] = tbl[live[k] ? node_succ(v[k]) : 0];
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 if (live[k]) v[k] = node_jump(v[k], w[k]);
-                live[k] = live[k] && node_succ(v[k]) < kNodeExit;
+                live[k] = live[k] && node_succ(v[k]) < kNodeExit3;
             }
 #pragma unroll
             for (int k = 0; k < 4; k++) w[k] = tbl[live[k] ? node_succ(v[k]) : 0];
@@ -570,7 +570,7 @@ __global__ __launch_bounds__(512) void zs_chunkmap_kernel(const StreamDesc *sd, 
     const int slot = threadIdx.x;
     if (slot >= kSlots) return;
     uint32_t out = 0;
-    if (slot_valid(c, slot, s.body_end)) out = chunk_exit_by_table(acc, tbl, c, slot, s.kl, s.body_end, lv, strategy);
+    if (slot_valid(c, slot, s.body_end)) out = chunk_exit_by_table3(acc, tbl, c, slot, s.kl, s.body_end, lv, strategy);
     maps[((int64_t)s.chunk_off + c) * kSlots + slot] = out;
 }
 
