@@ -44,6 +44,11 @@ __device__ __forceinline__ uint64_t lds_u64(const uint8_t *base, int idx) {
     return (uint64_t)__builtin_amdgcn_alignbyte(b, a, sh) | ((uint64_t)__builtin_amdgcn_alignbyte(c, b, sh) << 32);
 }
 
+// Match records in `mm` (uint2 per position): x = record for budget K, y = for budget K >> 2, each dist | (len-3) << 16
+// (zs_core.h pack_match); bits 24..31 of x carry the input byte of the position, so that the symbol kernel gets its
+// literals with the records it reads anyway.
+constexpr uint32_t kRecMask = 0x00FFFFFFu;
+
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 __device__ __forceinline__ uint64_t lanemask_lt() { return (1ull << lane_id()) - 1ull; }
 
@@ -327,6 +332,7 @@ __global__ __launch_bounds__(1024) void zs_match_kernel(const StreamDesc *sd, co
     if (threadIdx.x == 0) wg_cursor = (int)(pbeg - lo);
     __syncthreads();
     const int wendi = (int)(pend - lo);  // LDS-relative end of the tile's positions
+    if (t0 == 0 && threadIdx.x == 0) mm[s.pos_off] = make_uint2((uint32_t)wb[0 - lo] << 24, kNoMatch);  // position 0 is never searched
     uint2 *om = mm + s.pos_off;
     const int K = lv.chain, K4 = lv.chain >> 2, nice = lv.nice;
 
@@ -381,7 +387,7 @@ __global__ __launch_bounds__(1024) void zs_match_kernel(const StreamDesc *sd, co
         // ---- finish phase: store results, pull new positions (written with selects: every lane runs every line)
         if (st == 3 && p >= 0) {
             const uint32_t rec = best >= kMinMatch ? pack_match(best, bdist) : kNoMatch;
-            om[(int64_t)p + lo] = make_uint2(rec, snapped ? snap : rec);
+            om[(int64_t)p + lo] = make_uint2(rec | (sc0 << 24), snapped ? snap : rec);  // sc0's low byte is the byte at p
         }
         p = st == 3 ? -1 : p;
 #pragma unroll
@@ -401,7 +407,7 @@ __global__ __launch_bounds__(1024) void zs_match_kernel(const StreamDesc *sd, co
             const int l = wl[q];
             const uint64_t first8 = lds_u64(wb, q);
             const bool has = l != 0xFFFF;  // link distances are already <= kMaxDist
-            if (take && !has) om[(int64_t)mine + lo] = make_uint2(kNoMatch, kNoMatch);
+            if (take && !has) om[(int64_t)mine + lo] = make_uint2((uint32_t)first8 << 24, kNoMatch);
             p = take && has ? mine : p;
             c = take ? mine - (has ? l : 0) : c;
             st = take ? (has ? 1 : 3) : (dry ? 0 : st);
@@ -459,7 +465,10 @@ struct GlobalAcc {
     const uint2 *mm;  // already offset to the stream's position 0
     const uint32_t *tab;
     int strategy, hash_variant;
-    __device__ uint32_t flt(uint32_t m) const { return m ? filter_match(match_len(m), match_dist(m), strategy) : kNoMatch; }
+    __device__ uint32_t flt(uint32_t m) const {
+        m &= kRecMask;
+        return m ? filter_match(match_len(m), match_dist(m), strategy) : kNoMatch;
+    }
     __device__ uint32_t mK(int64_t p) const { return flt(mm[p].x); }
     __device__ uint32_t mK4(int64_t p) const { return flt(mm[p].y); }
     __device__ uint8_t byte(int64_t p) const { return in[p]; }
@@ -499,7 +508,7 @@ __device__ __forceinline__ void stage_chunk_matches(const StreamDesc &s, int c, 
         uint32_t x = 0, y = 0;
         if (p >= 1 && p <= s.body_end) {
             const uint2 v = a[p];
-            x = v.x, y = v.y;
+            x = v.x & kRecMask, y = v.y;
             x = x ? filter_match(match_len(x), match_dist(x), strategy) : kNoMatch;
             y = y ? filter_match(match_len(y), match_dist(y), strategy) : kNoMatch;
         }
@@ -798,7 +807,7 @@ __global__ __launch_bounds__(1024) void zs_resolve_kernel(const StreamDesc *sd, 
             for (int64_t p = e + 1 + threadIdx.x; p <= hi; p += blockDim.x) {
                 if (acc.bucket(p) != B) continue;
                 const uint2 old = a[p];
-                uint32_t x = old.x, y = old.y;
+                uint32_t x = old.x & kRecMask, y = old.y;
                 bool dirty = (x && p - match_dist(x) < e) || (y && p - match_dist(y) < e);
                 if (!dirty) continue;
                 auto lkf = [lk](int64_t q) { return (int)lk[q]; };
@@ -811,7 +820,7 @@ __global__ __launch_bounds__(1024) void zs_resolve_kernel(const StreamDesc *sd, 
                 uint32_t nx, ny;
                 walk_matches(lkf, lcp, p, lv, nx, ny);
                 if (nx != x || ny != y) {
-                    a[p] = make_uint2(nx, ny);
+                    a[p] = make_uint2(nx | (old.x & ~kRecMask), ny);
                     int cp = chunk_of(p);
                     stale[s.chunk_off + cp] = 1;
                     seg_stale[s.seg_off + seg_of_chunk(cp)] = 1;
@@ -928,12 +937,13 @@ __global__ __launch_bounds__(64) void zs_emit_syms_lane_kernel(const StreamDesc 
     else if (kind == kXK4) pend = acc.mK4(p - 1);
     uint2 cur = a[p];
     uint8_t lit = p >= 1 ? gin[p - 1] : 0;
+    const bool rec_lits = strategy != kHuffmanOnly;  // HuffmanOnly has no match pass: its records are zero-filled
     while (p < ce) {
         int64_t qa = p + 1, qb = pend ? p - 1 + match_len(pend) : qa;
         if (qa > last) qa = last;
         if (qb > last) qb = last;
         const uint2 na = a[qa], nb = a[qb];
-        const uint8_t nlit = gin[p];
+        const uint8_t nlit = rec_lits ? (uint8_t)(cur.x >> 24) : gin[p];
         uint32_t cK = acc.flt(cur.x), cK4 = acc.flt(cur.y);
         if (p == 0) cK = cK4 = kNoMatch;
         const Step st = lazy_step(kind, p, pend, cK, cK4, lv);
