@@ -6,9 +6,6 @@
 
 namespace zs {
 
-// Link tile: positions per workgroup of the bucket-link kernel.
-constexpr int kLinkTile = 32768;
-constexpr int kLinkWarm = 32512;  // >= kMaxDist, multiple of 64: history replayed before a tile
 // Match tile: positions per workgroup of the match kernel; its LDS holds the
 // input bytes [t0 - kMatchBack, t0 + kMatchTile + kMatchFwd) and the links of
 // [t0 - kMatchBack, t0 + kMatchTile).
