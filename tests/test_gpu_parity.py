@@ -399,3 +399,10 @@ def test_streams_beyond_64_mib_bit_exact(engine, oracle):
         assert len(z) == len(ref), name
         assert z == ref, name
         del d_in, d_out
+
+
+@pytest.mark.parametrize("level,strategy", [(4, 0), (8, 0), (9, 0), (5, int(CompressionStrategy.Filtered)), (7, int(CompressionStrategy.Fixed))])
+def test_other_levels_at_32_mib_bit_exact(engine, oracle, level, strategy):
+    """The levels the headline run does not use, on a stream long enough for hundreds of refills and blocks."""
+    data = datagen.english(32 << 20, 777 + level)
+    assert engine.deflate_batch([data], level=level, strategy=strategy)[0] == oracle.compress(data, level, strategy)
