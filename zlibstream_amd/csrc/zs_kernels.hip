@@ -1444,11 +1444,11 @@ __global__ __launch_bounds__(256) void zs_trees_kernel(const StreamDesc *sd, con
     const int nb_body = s.fast_runs > 0 ? 0 : (int)(st[w.x].body_syms / kBlockSyms);
     if (phase == 0 ? b >= nb_body : ((phase == 1 && b < nb_body) || b >= st[w.x].nblocks)) return;
     const BlockRec r = blocks[s.blk_off + b];
-    for (int i = threadIdx.x; i < kLCodes; i += 256) hl[i] = 0;
-    if (threadIdx.x < kDCodes) hd[threadIdx.x] = 0;
+    for (int i = threadIdx.x; i < kLCodes; i += blockDim.x) hl[i] = 0;
+    for (int i = threadIdx.x; i < kDCodes; i += blockDim.x) hd[i] = 0;
     __syncthreads();
     const uint32_t *sy = syms + s.sym_off + r.sym_start;
-    for (int i = threadIdx.x; i < r.nsyms; i += 256) {
+    for (int i = threadIdx.x; i < r.nsyms; i += blockDim.x) {
         uint32_t v = sy[i];
         int dist = (int)(v >> 16), lc = (int)(v & 0xFFFF);
         if (dist == 0) atomicAdd(&hl[lc], 1u);
@@ -1458,15 +1458,15 @@ __global__ __launch_bounds__(256) void zs_trees_kernel(const StreamDesc *sd, con
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < kHeapSize; i += 256) {
+    for (int i = threadIdx.x; i < kHeapSize; i += blockDim.x) {
         tw.ltree[i].fc = i < kLCodes ? (uint16_t)hl[i] : 0;
         tw.ltree[i].dl = 0;
     }
-    if (threadIdx.x < 2 * kDCodes + 1) {
-        tw.dtree[threadIdx.x].fc = threadIdx.x < kDCodes ? (uint16_t)hd[threadIdx.x] : 0;
-        tw.dtree[threadIdx.x].dl = 0;
+    for (int i = threadIdx.x; i < 2 * kDCodes + 1; i += blockDim.x) {
+        tw.dtree[i].fc = i < kDCodes ? (uint16_t)hd[i] : 0;
+        tw.dtree[i].dl = 0;
     }
-    if (threadIdx.x < 2 * kBlCodes + 1) tw.bltree[threadIdx.x].fc = 0, tw.bltree[threadIdx.x].dl = 0;
+    for (int i = threadIdx.x; i < 2 * kBlCodes + 1; i += blockDim.x) tw.bltree[i].fc = 0, tw.bltree[i].dl = 0;
     __syncthreads();
     if (threadIdx.x == 0) tw.ltree[kEndBlock].fc = 1;
     __syncthreads();
@@ -1486,7 +1486,7 @@ __global__ __launch_bounds__(256) void zs_trees_kernel(const StreamDesc *sd, con
     __syncthreads();
     uint32_t *dst = (uint32_t *)&trees[s.blk_off + b];
     const uint32_t *src = (const uint32_t *)&tw;
-    for (int i = threadIdx.x; i < (int)(sizeof(TreeWork) / 4); i += 256) dst[i] = src[i];
+    for (int i = threadIdx.x; i < (int)(sizeof(TreeWork) / 4); i += blockDim.x) dst[i] = src[i];
 }
 
 // ------------------------------------------------------------------ K8
