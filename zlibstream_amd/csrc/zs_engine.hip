@@ -45,7 +45,7 @@ struct zs_ctx {
     double stage_ms[kStCount] = {};
     uint32_t *crc_tab = nullptr;
     DevBuf sd, st, work, link, mm, maps, segmap, seg_entry, seg_symbase, seg_stale, entry, symbase, stale, syms, blk_end, blk_top, blocks, trees, info, pieces, scratch,
-        stage_in, stage_out, wr, inf_desc, inf_state, par_ps, par_st, par_work, par_cbits, par_ccnt, par_cands, par_blocks, par_cells,
+        stage_in, stage_out, wr, inf_desc, inf_state, par_ps, par_st, par_work, par_cbits, par_ccnt, par_cands, par_tabs, par_blocks, par_cells,
         par_windows, par_fail, run_syms, run_bits, run_scratch, run_outs, run_fail;
     void *pinned = nullptr;
     size_t pinned_cap = 0;
@@ -417,7 +417,7 @@ void zs_ctx_destroy(zs_ctx *c) {
     (void)hipSetDevice(c->device);
     DevBuf *bufs[] = {&c->sd, &c->st, &c->work, &c->link, &c->mm, &c->maps, &c->segmap, &c->seg_entry, &c->seg_symbase, &c->seg_stale, &c->entry, &c->symbase, &c->stale, &c->syms,
                       &c->blk_end, &c->blk_top, &c->blocks, &c->trees, &c->info, &c->pieces, &c->scratch, &c->stage_in, &c->stage_out, &c->wr, &c->inf_desc, &c->inf_state, &c->par_ps, &c->par_st, &c->par_work, &c->par_cbits, &c->par_ccnt,
-                      &c->par_cands, &c->par_blocks, &c->par_cells, &c->par_windows, &c->par_fail, &c->run_syms, &c->run_bits,
+                      &c->par_cands, &c->par_tabs, &c->par_blocks, &c->par_cells, &c->par_windows, &c->par_fail, &c->run_syms, &c->run_bits,
                       &c->run_scratch, &c->run_outs, &c->run_fail};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
@@ -640,8 +640,17 @@ bool run_inflate_par(zs_ctx *c, const std::vector<int> &idx, const void *const *
     if (!w.empty()) {
         ZS_HIP(c, hipMemcpyAsync(c->par_work.p, w.data(), sizeof(uint2) * w.size(), hipMemcpyHostToDevice, stream));
         ZS_HIP(c, hipStreamSynchronize(stream));
-        hipLaunchKernelGGL(zs_inf_measure_kernel, dim3((unsigned)w.size()), dim3(64), 0, stream, d_ps, d_st, dev<uint2>(c->par_work),
-                           dev<ParCand>(c->par_cands));
+        // one wave per candidate is the faster chain while all of them are resident at once (256 CUs x 24 workgroups of
+        // 6.6 KiB LDS); beyond that the waves queue up in rounds and the lane form, all candidates at once, wins
+        if (w.size() <= 6144) {
+            hipLaunchKernelGGL(zs_inf_measure_kernel, dim3((unsigned)w.size()), dim3(64), 0, stream, d_ps, d_st, dev<uint2>(c->par_work),
+                               dev<ParCand>(c->par_cands));
+        } else if (!ensure(c, c->par_tabs, sizeof(LaneTabs) * w.size())) {
+            return false;
+        } else
+        hipLaunchKernelGGL(zs_inf_measure_lane_kernel, dim3((unsigned)((w.size() + kLaneLanes - 1) / kLaneLanes)), dim3(kLaneLanes),
+                           kLaneLitLds, stream, d_ps, d_st, dev<uint2>(c->par_work), (int)w.size(), dev<ParCand>(c->par_cands),
+                           dev<LaneTabs>(c->par_tabs));
     }
     mark(2);
     hipLaunchKernelGGL(zs_inf_chain_kernel, dim3((unsigned)m), dim3(64), 0, stream, d_ps, d_st, dev<ParCand>(c->par_cands),

@@ -496,7 +496,8 @@ __global__ void zs_inf_flatten_kernel(const ParStream *ps, ParState *st, const i
     st[si].end_bit = 0;
 }
 
-// ------------------------------------------------------------------ D1
+// ------------------------------------------------------------------ D1, wave form: one wave per candidate (fastest chain per block;
+// used while every candidate of the batch gets a wave at once)
 __global__ __launch_bounds__(64) void zs_inf_measure_kernel(const ParStream *ps, const ParState *st, const uint2 *work, ParCand *cands) {
     __shared__ ParLds L;
     const uint2 w = work[blockIdx.x];
@@ -512,6 +513,231 @@ __global__ __launch_bounds__(64) void zs_inf_measure_kernel(const ParStream *ps,
         c.bfinal = r.bfinal;
         c.ok = r.err == 0;
     }
+}
+
+// ------------------------------------------------------------------ D1, lane form
+// Measuring a candidate is a decode without output, and a block's decode is one dependency chain (~2 us per symbol here):
+// the pass lasts as long as the longest block however many waves work on it.  One wave per candidate executes that chain
+// with 63 lanes idle and, at 20 000+ candidates, in several rounds; here every lane takes a candidate of its own, a few
+// lanes per workgroup so that every candidate of the batch is resident at once.  The literal/length table (one lookup
+// per symbol) is a lane-private column in LDS, the rest of the tables a private slab of HBM (they stay in L2), the bit
+// buffer is filled straight from the input.  Only dynamic blocks come out of the finder, so this is the dynamic-block
+// path alone; whatever it does not accept (ok = 0) the chain kernel measures with the wave decoder, and every accepted
+// size is checked again by the decode pass and the Adler-32.
+constexpr int kLaneLanes = 8;
+constexpr int kLaneLitLds = (1 << kInfLitBits) * kLaneLanes * 2;
+struct LaneTabs {
+    uint16_t dist[1 << kInfDistBits];
+    uint16_t lcount[16], dcount[16];
+    uint16_t lsym[288], dsym[32];
+    uint8_t lens[384];  // [0, 19): bit-length code lengths; [32, 32 + nlen + ndist): literal/length and distance code lengths
+    uint8_t blt[128];   // bit-length code: sym << 3 | len, 0 = invalid
+};
+struct LaneBits {
+    const __attribute__((address_space(1))) uint8_t *in;  // the stream's input (global memory: no flat loads)
+    int64_t n, pos;
+    uint64_t buf;
+    int cnt;
+    bool bad;
+    __device__ void fill() {
+        if (cnt > 40) return;  // a symbol needs at most 15 + 5 + 15 + 13 bits; every load is on the decode's dependency chain
+        if (pos + 8 <= n) {
+            buf |= *(const __attribute__((address_space(1))) uint64_t __attribute__((aligned(1))) *)(in + pos) << cnt;
+            const int adv = (63 - cnt) >> 3;
+            pos += adv;
+            cnt += adv * 8;
+        } else {
+            while (cnt <= 56 && pos < n) {
+                buf |= (uint64_t)in[pos] << cnt;
+                pos++;
+                cnt += 8;
+            }
+        }
+    }
+    __device__ uint32_t peek(int k) const { return (uint32_t)(buf & ((1ull << k) - 1)); }
+    __device__ void drop(int k) {
+        if (k > cnt) bad = true, k = cnt;
+        buf >>= k;
+        cnt -= k;
+    }
+    __device__ uint32_t take(int k) {
+        const uint32_t v = peek(k);
+        drop(k);
+        return v;
+    }
+};
+// canonical tables from code lengths, one lane on its own (inf_build's result).  `primary` is indexed with stride `ps`
+// (1: a private array; kLaneLanes: the lane's column of the workgroup's table in LDS)
+__device__ int lane_build(const uint8_t *lens, int n, uint16_t *primary, int ps, int pbits, uint16_t *count, uint16_t *symtab) {
+    uint16_t offs[16];
+    for (int i = 0; i < 16; i++) count[i] = 0;
+    for (int i = 0; i < n; i++) count[lens[i]]++;
+    int left = 1;
+    for (int len = 1; len <= 15; len++) {
+        left <<= 1;
+        left -= count[len];
+        if (left < 0) return left;
+    }
+    offs[1] = 0;
+    for (int len = 1; len < 15; len++) offs[len + 1] = (uint16_t)(offs[len] + count[len]);
+    for (int i = 0; i < n; i++)
+        if (lens[i]) symtab[offs[lens[i]]++] = (uint16_t)i;
+    for (int i = 0; i < (1 << pbits); i++) primary[i * ps] = kInfEsc;
+    unsigned code = 0;
+    int index = 0;
+    for (int len = 1; len <= pbits; len++) {
+        for (int k = 0; k < count[len]; k++) {
+            const unsigned rev = __brev(code) >> (32 - len);
+            const uint16_t e = (uint16_t)((symtab[index] << 4) | len);
+            for (unsigned r = rev; r < (1u << pbits); r += 1u << len) primary[r * ps] = e;
+            code++;
+            index++;
+        }
+        code <<= 1;
+    }
+    return left;
+}
+__device__ int lane_slow(const LaneBits &b, const uint16_t *count, const uint16_t *symtab, int &len_out) {
+    int code = 0, first = 0, index = 0;
+    uint64_t bits = b.buf;
+    for (int len = 1; len <= 15; len++) {
+        code |= (int)(bits & 1);
+        bits >>= 1;
+        const int c = count[len];
+        if (code - c < first) {
+            len_out = len;
+            return symtab[index + (code - first)];
+        }
+        index += c;
+        first += c;
+        first <<= 1;
+        code <<= 1;
+    }
+    len_out = 0;
+    return -1;
+}
+__global__ __launch_bounds__(kLaneLanes) void zs_inf_measure_lane_kernel(const ParStream *ps, const ParState *st, const uint2 *work,
+                                                                         int nwork, ParCand *cands, LaneTabs *tabs) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint16_t *lit = (uint16_t *)smem + threadIdx.x;  // this lane's column: entry e at lit[e * kLaneLanes]
+    const int gi = blockIdx.x * kLaneLanes + threadIdx.x;
+    if (gi >= nwork) return;
+    const uint2 w = work[gi];
+    const ParStream s = ps[w.x];
+    if ((int)w.y >= st[w.x].ncand) return;
+    ParCand &c = cands[s.cand_off + w.y];
+    LaneTabs &T = tabs[gi];
+    c.ok = 0;
+    LaneBits b{(const __attribute__((address_space(1))) uint8_t *)(uintptr_t)s.in, s.in_len, c.bit >> 3, 0, 0, false};
+    b.fill();
+    b.drop((int)(c.bit & 7));
+    b.fill();
+    if (b.cnt < 17) return;
+    const int bfinal = (int)b.take(1);
+    if (b.take(2) != 2) return;
+    const int nlen = (int)b.take(5) + 257, ndist = (int)b.take(5) + 1, ncode = (int)b.take(4) + 4;
+    if (nlen > 286 || ndist > 30) return;
+    for (int i = 0; i < 19; i++) T.lens[i] = 0;
+    for (int i = 0; i < ncode; i++) {
+        b.fill();
+        T.lens[bl_order(i)] = (uint8_t)b.take(3);
+    }
+    if (b.bad) return;
+    {
+        // the bit-length code must be complete (the finder checked this offset already; this is the decoder's own check)
+        uint16_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int i = 0; i < 19; i++) cnt[T.lens[i]]++;
+        int left = 1;
+        for (int len = 1; len <= 7; len++) {
+            left <<= 1;
+            left -= cnt[len];
+        }
+        if (left != 0) return;
+        for (int i = 0; i < 128; i++) T.blt[i] = 0;
+        unsigned code = 0;
+        for (int len = 1; len <= 7; len++) {
+            for (int sy = 0; sy < 19; sy++)
+                if (T.lens[sy] == len) {
+                    const unsigned rev = __brev(code) >> (32 - len);
+                    for (unsigned r = rev; r < 128; r += 1u << len) T.blt[r] = (uint8_t)((sy << 3) | len);
+                    code++;
+                }
+            code <<= 1;
+        }
+    }
+    uint8_t *ll = T.lens + 32;
+    int idx = 0;
+    uint8_t prev = 0;
+    while (idx < nlen + ndist) {
+        b.fill();
+        const uint8_t e = T.blt[b.peek(7)];
+        if (b.bad || e == 0 || (int)(e & 7) > b.cnt) return;
+        b.drop(e & 7);
+        const int sym = e >> 3;
+        if (sym < 16) {
+            ll[idx++] = (uint8_t)sym;
+            prev = (uint8_t)sym;
+        } else {
+            int rep;
+            uint8_t val = 0;
+            if (sym == 16) {
+                if (idx == 0) return;
+                val = prev;
+                rep = 3 + (int)b.take(2);
+            } else if (sym == 17) {
+                rep = 3 + (int)b.take(3);
+            } else {
+                rep = 11 + (int)b.take(7);
+            }
+            if (idx + rep > nlen + ndist) return;
+            for (int k = 0; k < rep; k++) ll[idx + k] = val;
+            prev = val;
+            idx += rep;
+        }
+    }
+    if (b.bad || ll[256] == 0) return;
+    int q = lane_build(ll, nlen, lit, kLaneLanes, kInfLitBits, T.lcount, T.lsym);
+    if (q < 0 || (q > 0 && nlen - T.lcount[0] != 1)) return;
+    q = lane_build(ll + nlen, ndist, T.dist, 1, kInfDistBits, T.dcount, T.dsym);
+    if (q < 0 || (q > 0 && ndist - T.dcount[0] > 1)) return;
+    int64_t pos = 0;
+    for (int nsym = 0;; nsym++) {
+        if (b.bad || nsym > kParMaxSyms) return;
+        b.fill();
+        int sym, clen;
+        {
+            const uint16_t e = lit[b.peek(kInfLitBits) * kLaneLanes];
+            if (e != kInfEsc) sym = e >> 4, clen = e & 15;
+            else sym = lane_slow(b, T.lcount, T.lsym, clen);
+        }
+        if (sym < 0 || clen > b.cnt) return;
+        b.drop(clen);
+        if (sym < 256) {
+            pos++;
+        } else if (sym == 256) {
+            break;
+        } else {
+            sym -= 257;
+            if (sym >= 29) return;
+            const int mlen = (sym == 28 ? 258 : base_length(sym) + 3) + (int)b.take(extra_lbits(sym));
+            b.fill();
+            int ds, dl;
+            {
+                const uint16_t e = T.dist[b.peek(kInfDistBits)];
+                if (e != kInfEsc) ds = e >> 4, dl = e & 15;
+                else ds = lane_slow(b, T.dcount, T.dsym, dl);
+            }
+            if (ds < 0 || ds >= 30 || dl > b.cnt) return;
+            b.drop(dl);
+            (void)b.take(extra_dbits(ds));
+            pos += mlen;
+        }
+    }
+    if (b.bad) return;
+    c.end_bit = b.pos * 8 - b.cnt;
+    c.out_bytes = pos;
+    c.bfinal = bfinal;
+    c.ok = 1;
 }
 
 // ------------------------------------------------------------------ C
