@@ -389,7 +389,7 @@ __global__ __launch_bounds__(256) void zs_inf_find_kernel(const ParStream *ps, c
     __shared__ int64_t found[kFindMaxCand];
     __shared__ int nfound, nsurv;
     __shared__ int32_t surv[kFindMaxSurv];  // bit offsets (chunk-relative) that passed the register prefilter
-    __shared__ uint8_t dec_lds[256 * 128];   // one 7-bit decode table per thread for the full header check
+    __shared__ uint8_t dec_lds[64 * 128];    // one 7-bit decode table per lane of the wave that runs the full header checks
     const uint2 w = work[blockIdx.x];
     const ParStream s = ps[w.x];
     const int chunk = (int)w.y;
@@ -446,7 +446,9 @@ __global__ __launch_bounds__(256) void zs_inf_find_kernel(const ParStream *ps, c
     __syncthreads();
     // full header check of the survivors, one per thread (instead of one lane of a wave at a time)
     const int ns = nsurv < kFindMaxSurv ? nsurv : kFindMaxSurv;
-    for (int i = threadIdx.x; i < ns; i += 256) {
+    // (a chunk has a few dozen survivors: one wave takes them, and the small LDS footprint lets more chunks overlap --
+    // a check is a chain of a few hundred dependent steps)
+    for (int i = threadIdx.x; i < ns && threadIdx.x < 64; i += 64) {
         const int64_t bit = (int64_t)chunk * kFindChunk * 8 + surv[i];
         if (find_check_header(s.in, s.in_len, bit, dec_lds + threadIdx.x * 128)) {
             int at = atomicAdd(&nfound, 1);
