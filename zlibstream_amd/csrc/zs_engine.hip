@@ -45,7 +45,7 @@ struct zs_ctx {
     double stage_ms[kStCount] = {};
     uint32_t *crc_tab = nullptr;
     DevBuf sd, st, work, link, mm, maps, segmap, seg_entry, seg_symbase, seg_stale, entry, symbase, stale, syms, blk_end, blk_top, blocks, trees, info, pieces, scratch,
-        stage_in, stage_out, wr, inf_desc, inf_state, par_ps, par_st, par_work, par_cbits, par_ccnt, par_cands, par_tabs, par_blocks, par_cells,
+        stage_in, stage_out, wr, inf_desc, inf_state, par_ps, par_st, par_work, par_cbits, par_ccnt, par_surv, par_scnt, par_cands, par_tabs, par_blocks, par_cells,
         par_windows, par_fail, run_syms, run_bits, run_scratch, run_outs, run_fail;
     void *pinned = nullptr;
     size_t pinned_cap = 0;
@@ -416,7 +416,7 @@ void zs_ctx_destroy(zs_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     DevBuf *bufs[] = {&c->sd, &c->st, &c->work, &c->link, &c->mm, &c->maps, &c->segmap, &c->seg_entry, &c->seg_symbase, &c->seg_stale, &c->entry, &c->symbase, &c->stale, &c->syms,
-                      &c->blk_end, &c->blk_top, &c->blocks, &c->trees, &c->info, &c->pieces, &c->scratch, &c->stage_in, &c->stage_out, &c->wr, &c->inf_desc, &c->inf_state, &c->par_ps, &c->par_st, &c->par_work, &c->par_cbits, &c->par_ccnt,
+                      &c->blk_end, &c->blk_top, &c->blocks, &c->trees, &c->info, &c->pieces, &c->scratch, &c->stage_in, &c->stage_out, &c->wr, &c->inf_desc, &c->inf_state, &c->par_ps, &c->par_st, &c->par_work, &c->par_cbits, &c->par_ccnt, &c->par_surv, &c->par_scnt,
                       &c->par_cands, &c->par_tabs, &c->par_blocks, &c->par_cells, &c->par_windows, &c->par_fail, &c->run_syms, &c->run_bits,
                       &c->run_scratch, &c->run_outs, &c->run_fail};
     for (DevBuf *b : bufs)
@@ -612,6 +612,7 @@ bool run_inflate_par(zs_ctx *c, const std::vector<int> &idx, const void *const *
     if (!ensure(c, c->par_ps, sizeof(ParStream) * (size_t)m) || !ensure(c, c->par_st, sizeof(ParState) * (size_t)m) ||
         !ensure(c, c->par_work, sizeof(uint2) * (size_t)std::max<int64_t>(std::max<int64_t>(nchunks, ncand), nblk) + 64) ||
         !ensure(c, c->par_cbits, 8 * (size_t)nchunks * kFindMaxCand + 64) || !ensure(c, c->par_ccnt, 4 * (size_t)nchunks + 64) ||
+        !ensure(c, c->par_surv, 4 * (size_t)nchunks * kFindMaxSurv + 64) || !ensure(c, c->par_scnt, 4 * (size_t)nchunks + 64) ||
         !ensure(c, c->par_cands, sizeof(ParCand) * (size_t)ncand) || !ensure(c, c->par_blocks, sizeof(ParBlock) * (size_t)nblk) ||
         !ensure(c, c->par_cells, 2 * (size_t)ncells + 64) || !ensure(c, c->par_fail, 4 * (size_t)m + 64))
         return false;
@@ -627,8 +628,10 @@ bool run_inflate_par(zs_ctx *c, const std::vector<int> &idx, const void *const *
         if (prof) (void)hipEventRecord(c->ev[k], stream);
     };
     mark(0);
-    hipLaunchKernelGGL(zs_inf_find_kernel, dim3((unsigned)w_find.size()), dim3(256), 0, stream, d_ps, dev<uint2>(c->par_work),
-                       dev<int64_t>(c->par_cbits), dev<int32_t>(c->par_ccnt));
+    hipLaunchKernelGGL(zs_inf_prefilter_kernel, dim3((unsigned)w_find.size()), dim3(256), 0, stream, d_ps, dev<uint2>(c->par_work),
+                       dev<int32_t>(c->par_surv), dev<int32_t>(c->par_scnt));
+    hipLaunchKernelGGL(zs_inf_check_kernel, dim3((unsigned)w_find.size()), dim3(64), 0, stream, d_ps, dev<uint2>(c->par_work),
+                       dev<int32_t>(c->par_surv), dev<int32_t>(c->par_scnt), dev<int64_t>(c->par_cbits), dev<int32_t>(c->par_ccnt));
     hipLaunchKernelGGL(zs_inf_flatten_kernel, dim3((unsigned)((m + 63) / 64)), dim3(64), 0, stream, d_ps, d_st, dev<int64_t>(c->par_cbits),
                        dev<int32_t>(c->par_ccnt), dev<ParCand>(c->par_cands), m);
     mark(1);

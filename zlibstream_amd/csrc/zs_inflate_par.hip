@@ -30,7 +30,7 @@ namespace zs {
 
 constexpr int kFindChunk = 4096;     // input bytes per finder workgroup
 constexpr int kFindMaxCand = 12;     // candidates kept per chunk
-constexpr int kFindMaxSurv = 2048;   // prefilter survivors per chunk (32768 bit offsets; ~0.5 % survive on random data)
+constexpr int kFindMaxSurv = 512;    // prefilter survivors per chunk (32768 bit offsets; ~0.5 % survive on random data)
 constexpr int kParMaxBlocks = 1 << 16;
 
 struct ParStream {
@@ -385,15 +385,13 @@ __device__ bool find_check_header(const uint8_t *in, int64_t n, int64_t bit, uin
     return true;
 }
 
-__global__ __launch_bounds__(256) void zs_inf_find_kernel(const ParStream *ps, const uint2 *work, int64_t *cand_bits, int32_t *cand_cnt) {
-    __shared__ int64_t found[kFindMaxCand];
-    __shared__ int nfound, nsurv;
+__global__ __launch_bounds__(256) void zs_inf_prefilter_kernel(const ParStream *ps, const uint2 *work, int32_t *surv_g, int32_t *surv_cnt) {
+    __shared__ int nsurv;
     __shared__ int32_t surv[kFindMaxSurv];  // bit offsets (chunk-relative) that passed the register prefilter
-    __shared__ uint8_t dec_lds[64 * 128];    // one 7-bit decode table per lane of the wave that runs the full header checks
     const uint2 w = work[blockIdx.x];
     const ParStream s = ps[w.x];
     const int chunk = (int)w.y;
-    if (threadIdx.x == 0) nfound = 0, nsurv = 0;
+    if (threadIdx.x == 0) nsurv = 0;
     __syncthreads();
     // the thread's 16 bytes plus the 16 that follow, as four 64-bit words (zero past the end of the stream)
     const int64_t byte0 = (int64_t)chunk * kFindChunk + (int64_t)threadIdx.x * 16;
@@ -444,11 +442,29 @@ __global__ __launch_bounds__(256) void zs_inf_find_kernel(const ParStream *ps, c
         }
     }
     __syncthreads();
-    // full header check of the survivors, one per thread (instead of one lane of a wave at a time)
+    // the survivors go out for the header-check kernel (a count above kFindMaxSurv flags the overflow)
     const int ns = nsurv < kFindMaxSurv ? nsurv : kFindMaxSurv;
-    // (a chunk has a few dozen survivors: one wave takes them, and the small LDS footprint lets more chunks overlap --
-    // a check is a chain of a few hundred dependent steps)
-    for (int i = threadIdx.x; i < ns && threadIdx.x < 64; i += 64) {
+    int32_t *dst = surv_g + (int64_t)blockIdx.x * kFindMaxSurv;
+    for (int i = threadIdx.x; i < ns; i += 256) dst[i] = surv[i];
+    if (threadIdx.x == 0) surv_cnt[blockIdx.x] = nsurv;
+}
+
+// Full header check of a chunk's survivors: one lane each (a check is a chain of a few hundred dependent steps, so what
+// matters is how many chunks are in flight: one wave and 8 KiB of decode tables per chunk).
+__global__ __launch_bounds__(64) void zs_inf_check_kernel(const ParStream *ps, const uint2 *work, const int32_t *surv_g,
+                                                          const int32_t *surv_cnt, int64_t *cand_bits, int32_t *cand_cnt) {
+    __shared__ int64_t found[kFindMaxCand];
+    __shared__ int nfound;
+    __shared__ uint8_t dec_lds[64 * 128];  // one 7-bit decode table per lane
+    const uint2 w = work[blockIdx.x];
+    const ParStream s = ps[w.x];
+    const int chunk = (int)w.y;
+    const int nsurv = surv_cnt[blockIdx.x];
+    const int32_t *surv = surv_g + (int64_t)blockIdx.x * kFindMaxSurv;
+    if (threadIdx.x == 0) nfound = 0;
+    __syncthreads();
+    const int ns = nsurv < kFindMaxSurv ? nsurv : kFindMaxSurv;
+    for (int i = threadIdx.x; i < ns; i += 64) {
         const int64_t bit = (int64_t)chunk * kFindChunk * 8 + surv[i];
         if (find_check_header(s.in, s.in_len, bit, dec_lds + threadIdx.x * 128)) {
             int at = atomicAdd(&nfound, 1);
