@@ -298,9 +298,26 @@ def test_inflate_large_device_resident(engine):
     z = engine.deflate_batch([data], level=6)[0]
     d_in = torch.frombuffer(bytearray(z), dtype=torch.uint8).cuda()
     d_out = torch.empty(len(data), dtype=torch.uint8, device="cuda")
+    engine.set_profiling(True)
     n = engine.inflate_batch_device([d_in.data_ptr()], [len(z)], [d_out.data_ptr()], [len(data)],
                                     stream=torch.cuda.current_stream().cuda_stream)[0]
+    stages = engine.stage_ms()
+    engine.set_profiling(False)
     assert n == len(data) and d_out.cpu().numpy().tobytes() == data
+    # the block-parallel path must have done it: a regular stream that silently falls back to the one-wave decoder is a bug
+    assert stages.get("inf_decode", 0) > 0 and stages.get("inf_measure", 0) > 0, stages
+    # many streams at once: enough candidates for the lane form of the measure pass
+    zs = [engine.deflate_batch([datagen.english(6 << 20, 50 + i)], level=6)[0] for i in range(2)] * 32  # ~8000 candidates
+    srcs = [torch.frombuffer(bytearray(x), dtype=torch.uint8).cuda() for x in zs]
+    outs = [torch.empty(6 << 20, dtype=torch.uint8, device="cuda") for _ in zs]
+    engine.set_profiling(True)
+    lens = engine.inflate_batch_device([t.data_ptr() for t in srcs], [len(x) for x in zs], [o.data_ptr() for o in outs],
+                                       [6 << 20] * len(zs), stream=torch.cuda.current_stream().cuda_stream)
+    stages = engine.stage_ms()
+    engine.set_profiling(False)
+    assert stages.get("inf_decode", 0) > 0, stages
+    for i, o in enumerate(outs):
+        assert lens[i] == 6 << 20 and zlib.adler32(o.cpu().numpy().tobytes()) == int.from_bytes(zs[i][-4:], "big")
 
 
 def test_cpp_host_mirror(tmp_path):
