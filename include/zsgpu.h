@@ -120,10 +120,18 @@ ZS_API double zs_ctx_stage_ms(const zs_ctx *ctx, int stage);
  * zs_deflate       <- Deflate.Compress (Deflate.cs:436-636).  The cursor fields
  *   of ZLibStream (ZlibStream.cs:34-94) are passed explicitly: *avail_in /
  *   *avail_out are decremented, *total_in / *total_out advanced, *adler
- *   updated.  Input is copied during the call.  Under ZS_NO_FLUSH the engine
- *   buffers input and records the Write boundary; compression runs on the GPU
+ *   updated.  Input is copied during the call.  The engine buffers input and
+ *   records the Write boundary and its flush mode; compression runs on the GPU
  *   when ZS_FINISH arrives, after which output is handed out avail_out bytes
  *   at a time exactly like Flush_pending (Deflate.cs:828-854).
+ *   ZS_PARTIAL_FLUSH / ZS_SYNC_FLUSH / ZS_FULL_FLUSH (Deflate.cs:583-613): the
+ *   final bytes are the reference's for a caller that runs
+ *   ZlibOutputStream.WriteCore's loop (ZlibOutputStream.cs:125-168: a fresh
+ *   output chunk of the same size for every call -- the size is taken from
+ *   the first call), i.e. block end + Tr_align / empty stored block after every
+ *   Write, FullFlush forgetting the hash heads, and the extra empty blocks of
+ *   flushes that fill the chunk exactly; they are delivered at ZS_FINISH, not
+ *   at the flush call.
  * zs_deflate_end   <- Deflate.Dispose.
  * zs_last_message  <- ZLibStream.Message. */
 typedef struct zs_deflate_stream zs_deflate_stream;

@@ -74,17 +74,43 @@ int main() {
         for (int i = 0; i < count; i += chunk) CHECK(inflate.Read(actual.data(), i, chunk) == chunk);
         CHECK(actual == expected);
     }
-    // error behaviour: flush modes other than NoFlush / Finish are outside the device path -> ZlibStreamException("deflating: ...")
+    // ZlibOptions.FlushMode Partial / Sync / Full: every Write closes its block and is followed by the flush marker
+    // (Deflate.cs:583-613); bytes checked against the oracle's literal 512-byte WriteCore loop
+    for (FlushMode mode : {FlushMode::PartialFlush, FlushMode::SyncFlush, FlushMode::FullFlush}) {
+        for (CompressionLevel level : {CompressionLevel::NoCompression, CompressionLevel::Level1, CompressionLevel::Level6}) {
+            std::stringstream compressed;
+            {
+                ZlibOptions options;
+                options.CompressionLevel_ = level;
+                options.FlushMode_ = mode;
+                ZlibOutputStream deflate(compressed, options);
+                for (int i = 0; i < count; i += chunk) deflate.Write(expected.data(), i, chunk);
+            }
+            std::string z = compressed.str();
+            std::vector<uint8_t> ref(zso_compress_bound(expected.size()) + 256);
+            const size_t chunks[4] = {(size_t)chunk, (size_t)chunk, (size_t)chunk, (size_t)chunk};
+            ref.resize(zso_compress_stream(expected.data(), expected.size(), chunks, 4, (int)level, 0, (int)mode, 0, ref.data(), ref.size(), nullptr));
+            CHECK(z.size() == ref.size() && memcmp(z.data(), ref.data(), ref.size()) == 0);
+            std::vector<uint8_t> actual((size_t)count);
+            ZlibInputStream inflate(compressed);
+            CHECK(inflate.Read(actual.data(), 0, count) == count);
+            CHECK(actual == expected);
+        }
+    }
+    // error behaviour: what is outside the device path -> ZlibStreamException("deflating: ...")
     try {
-        std::stringstream s;
-        ZlibOptions options;
-        options.CompressionLevel_ = CompressionLevel::Level6;
-        options.FlushMode_ = FlushMode::SyncFlush;
-        ZlibOutputStream deflate(s, options);
-        deflate.Write(expected.data(), 0, 10);
-        CHECK(!"expected ZlibStreamException");
+        zs_ctx *ctx = nullptr;
+        CHECK(zs_ctx_create(0, &ctx) == 0);
+        zs_deflate_stream *d = zs_deflate_init(ctx, 6, 0, 12, 8, 0);  // windowBits 12
+        CHECK(d != nullptr);
+        uint8_t outb[512];
+        int32_t availIn = 10, availOut = 512;
+        int rc = zs_deflate(d, expected.data(), &availIn, outb, &availOut, 0, nullptr, nullptr, nullptr);
+        CHECK(rc == -2 && zs_last_message(d) != nullptr);
+        zs_deflate_end(d);
+        zs_ctx_destroy(ctx);
     } catch (const ZlibStreamException &e) {
-        CHECK(std::string(e.what()).rfind("deflating: ", 0) == 0);
+        CHECK(!"unexpected exception");
     }
     // corrupt trailer -> "inflating: incorrect data check" (Inflate.cs:339)
     try {

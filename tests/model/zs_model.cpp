@@ -53,6 +53,9 @@ struct Model {
     std::vector<int64_t> events;  // s_k for k = 1..
     int64_t body_end;             // last body loop-top position (n - 262), or -1
     std::vector<int64_t> wr_end;
+    int flush_mode = 0;            // ZlibOptions.FlushMode of every Write
+    std::vector<uint8_t> wr_flush;
+    std::vector<int32_t> wr_blk;
 
     uint32_t bucket(int64_t p) const {
         uint32_t v = (uint32_t)data[p + 2] | ((uint32_t)data[p + 3] << 8) | ((uint32_t)data[p + 4] << 16) | ((uint32_t)data[p + 5] << 24);
@@ -313,15 +316,18 @@ static void run_tail(Model &m, int64_t p, int kind, uint32_t pend, int k_done, i
     e.lv = m.lv;
     e.strategy = m.strategy;
     e.hash_variant = kHashCrc32c;
-    e.wr_end = m.wr_end.size() > 1 ? m.wr_end.data() : nullptr;
+    e.wr_end = (m.wr_end.size() > 1 || m.flush_mode) ? m.wr_end.data() : nullptr;
     e.n_wr = (int)m.wr_end.size();
     e.cur_wr = 0;
+    m.wr_flush.assign(m.wr_end.size(), (uint8_t)m.flush_mode);
+    m.wr_blk.assign(m.wr_end.size(), 0);
+    if (m.flush_mode) e.wr_flush = m.wr_flush.data(), e.wr_blk = m.wr_blk.data();
     size_t body_syms = m.syms.size();
     m.syms.resize(body_syms + 2 * kMinLookahead + 600 + (m.body_end < 0 ? (size_t)m.n : 0));
     e.syms = m.syms.data();
     e.nsyms = (int64_t)body_syms;
     size_t body_blocks = m.blocks.size();
-    m.blocks.resize(body_blocks + 8 + (m.body_end < 0 ? (size_t)m.n / 8000 : 0));
+    m.blocks.resize(body_blocks + 8 + m.wr_end.size() + (m.body_end < 0 ? (size_t)m.n / 8000 : 0));
     e.blocks = m.blocks.data();
     e.nblocks = (int)body_blocks;
     e.block_start_abs = body_blocks ? m.blocks[body_blocks - 1].start + m.blocks[body_blocks - 1].stored_len : 0;
@@ -383,24 +389,44 @@ static std::vector<uint8_t> emit_stream(Model &m) {
         bits[b] = type[b] == 1 ? 3 + w.static_len : type[b] == 2 ? 3 + w.opt_len : 0;
     }
     int64_t pos = 16;  // after the 2-byte zlib header
-    for (size_t b = 0; b < nb; b++) {  // K8: sequential per stream
-        bit_start[b] = pos;
-        if (type[b] == 0) {
-            pos += 3;
-            pos = (pos + 7) & ~7LL;
-            pos += 32 + 8LL * m.blocks[b].stored_len;
-        } else {
-            pos += bits[b];
+    std::vector<uint8_t> out;
+    for (int pass = 0; pass < 2; pass++) {  // K8: sequential per stream; the second pass writes the flush markers
+        FlushAcct fa;
+        fa_init(fa, 512, m.level, false);
+        fa_enter(fa);
+        size_t w = 0;
+        auto put = [&](int64_t at, uint32_t v, int nbits) {
+            if (!pass) return;
+            BitOr o{&out, at};
+            o(v, nbits);
+        };
+        for (size_t b = 0; b < nb; b++) {
+            while (m.flush_mode && w + 1 < m.wr_blk.size() && (size_t)m.wr_blk[w + 1] <= b) w++, fa_enter(fa);
+            pos = fa.bits;
+            bit_start[b] = pos;
+            if (type[b] == 0) {
+                pos += 3;
+                pos = (pos + 7) & ~7LL;
+                pos += 32 + 8LL * m.blocks[b].stored_len;
+            } else {
+                pos += bits[b];
+            }
+            if (m.blocks[b].eof & 1) pos = (pos + 7) & ~7LL;
+            fa.bits = pos;
+            fa.last_eob_len = type[b] == 0 ? 8 : type[b] == 1 ? 7 : tw[b].ltree[kEndBlock].dl;
+            const int f = m.blocks[b].eof >> 1;
+            if (f) fa_end_of_write(fa, f, put);
+            else fa_after_block(fa);
         }
-        if (m.blocks[b].eof) pos = (pos + 7) & ~7LL;
+        pos = fa.bits;
+        if (!pass) out.assign((size_t)(pos / 8) + 4 + 8, 0);
     }
-    std::vector<uint8_t> out((size_t)(pos / 8) + 4 + 8, 0);
     unsigned hdr = zlib_header(m.level);
     out[0] = (uint8_t)(hdr >> 8);
     out[1] = (uint8_t)hdr;
     for (size_t b = 0; b < nb; b++) {  // K9: one workgroup per block
         BitOr put{&out, bit_start[b]};
-        put((unsigned)(type[b] << 1) + (m.blocks[b].eof ? 1u : 0u), 3);
+        put((unsigned)(type[b] << 1) + ((m.blocks[b].eof & 1) ? 1u : 0u), 3);
         if (type[b] == 0) {
             put.pos = (put.pos + 7) & ~7LL;
             unsigned len = (unsigned)m.blocks[b].stored_len;
@@ -451,6 +477,7 @@ int main(int argc, char **argv) {
     int strategy = argc > 3 ? atoi(argv[3]) : 0;
     std::string mode = argc > 4 ? argv[4] : "bulk";
     size_t wchunk = argc > 5 ? (size_t)atol(argv[5]) : 0;
+    int flush_mode = argc > 6 ? atoi(argv[6]) : 0;
     int64_t n = (int64_t)buf.size();
     buf.resize(buf.size() + 1024, 0);
 
@@ -461,7 +488,8 @@ int main(int argc, char **argv) {
     t.on_block = on_block;
     t.on_read = on_read;
     t.user = &tr;
-    std::vector<uint8_t> ref(zso_compress_bound((size_t)n));
+    // every Write that ends under a flush mode adds a block end, a marker and now and then an empty block
+    std::vector<uint8_t> ref(zso_compress_bound((size_t)n) + (wchunk ? 32 * ((size_t)n / wchunk + 2) : 64));
     std::vector<size_t> wlens;
     std::vector<int64_t> wends;
     if (wchunk) {
@@ -470,7 +498,8 @@ int main(int argc, char **argv) {
             wends.push_back((int64_t)(o + wlens.back()));
         }
     }
-    size_t ref_len = zso_compress_stream(buf.data(), (size_t)n, wlens.empty() ? nullptr : wlens.data(), wlens.size(), level, strategy, 0, 0,
+    if (flush_mode && wends.empty() && n > 0) wlens.push_back((size_t)n), wends.push_back(n);
+    size_t ref_len = zso_compress_stream(buf.data(), (size_t)n, wlens.empty() ? nullptr : wlens.data(), wlens.size(), level, strategy, flush_mode, 0,
                                          ref.data(), ref.size(), &t);
     if (ref_len == (size_t)-1) {
         printf("oracle failed\n");
@@ -488,6 +517,7 @@ int main(int argc, char **argv) {
         for (int i = 0; i < 256; i++) m.crc_tab[tt * 256 + i] = crc32c_table_entry(tt, (uint32_t)i);
     m.body_end = (m.lv.func == 2 && strategy != kRle && wends.size() <= 1) ? n - kMinLookahead : -1;
     m.wr_end = wends;
+    m.flush_mode = flush_mode;
     m.build_links();
     int64_t p;
     int kind, k_done;
@@ -510,7 +540,9 @@ int main(int argc, char **argv) {
             ok = false;
             break;
         }
-    if (m.blocks.size() != tr.blocks.size()) {
+    if (flush_mode) {
+        // the oracle's trace also holds the empty blocks of re-entered flushes; the bytes below cover the blocks
+    } else if (m.blocks.size() != tr.blocks.size()) {
         printf("block count %zu vs oracle %zu\n", m.blocks.size(), tr.blocks.size());
         ok = false;
     } else {

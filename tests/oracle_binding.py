@@ -42,7 +42,7 @@ class Oracle:
 
     def compress(self, data, level=6, strategy=0, chunks=None, hash_variant=0, flush=0):
         data = bytes(data)
-        cap = len(data) + len(data) // 8 + 1024
+        cap = len(data) + len(data) // 8 + 1024 + 48 * len(chunks or [])
         out = ctypes.create_string_buffer(cap)
         if chunks:
             arr = (ctypes.c_size_t * len(chunks))(*chunks)

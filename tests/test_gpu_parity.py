@@ -159,9 +159,14 @@ def test_stored_level_and_rle_strategy(engine, oracle):
 
 
 def test_stream_api_errors_and_unsupported(engine):
-    with pytest.raises(ZlibStreamException):  # flush modes other than NoFlush / Finish are not on the device path
-        with ZlibOutputStream(io.BytesIO(), ZlibOptions(CompressionLevel=CompressionLevel.Level6, FlushMode=2), engine=engine) as s:
-            s.write(b"abc")
+    import ctypes
+    L = engine._lib
+    d = L.zs_deflate_init(engine._h, 6, 0, 12, 8, 0)  # windowBits 12 is not on the device path: loud, no CPU fallback
+    assert d
+    ai, ao, out = ctypes.c_int32(3), ctypes.c_int32(512), ctypes.create_string_buffer(512)
+    assert L.zs_deflate(d, b"abc", ctypes.byref(ai), out, ctypes.byref(ao), 0, None, None, None) == -2
+    assert b"windowBits" in L.zs_last_message(d)
+    L.zs_deflate_end(d)
     with pytest.raises(ValueError):
         ZlibOutputStream(io.BytesIO(), 12, engine=engine)
     s = ZlibOutputStream(io.BytesIO(), CompressionLevel.Level6, engine=engine)
@@ -423,3 +428,43 @@ def test_other_levels_at_32_mib_bit_exact(engine, oracle, level, strategy):
     """The levels the headline run does not use, on a stream long enough for hundreds of refills and blocks."""
     data = datagen.english(32 << 20, 777 + level)
     assert engine.deflate_batch([data], level=level, strategy=strategy)[0] == oracle.compress(data, level, strategy)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flush", [1, 2, 3])
+def test_flush_modes_partial_sync_full(engine, oracle, flush):
+    """ZlibOptions.FlushMode Partial / Sync / Full (FlushMode.cs; Deflate.cs:583-613, Trees.cs:658-680): every Write
+    ends its block, then the marker; a flush that fills WriteCore's 512-byte chunk exactly re-enters the block function
+    and adds an empty block.  Bytes against the oracle's literal loop, for all block functions and Write patterns."""
+    alice = oracle_binding.corpus("alice29.txt")
+    rng = np.random.default_rng(flush)
+    low = rng.choice(np.array([0, 0, 0, 0, 1, 2, 255], dtype=np.uint8), 150000).tobytes()
+    cases = [(alice, [len(alice)]), (alice, [4000] * 37 + [481]), (alice * 2, [70000, 70000, 70000, 86962]),
+             (low, [8192] * 18 + [2544]), (alice[:30000], [100] * 300), (b"hello", [5]), (bytes(98305), [65536, 32769])]
+    for data, chunks in cases:
+        assert sum(chunks) == len(data)
+        for level, strategy in ((0, 0), (1, 0), (3, 0), (4, 0), (6, 0), (9, 0), (6, 3), (6, 2), (6, 4)):
+            out = io.BytesIO()
+            with ZlibOutputStream(out, ZlibOptions(CompressionLevel=CompressionLevel(level), CompressionStrategy=CompressionStrategy(strategy),
+                                                   FlushMode=flush), engine=engine) as s:
+                o = 0
+                for c in chunks:
+                    s.write(data[o:o + c])
+                    o += c
+            z = out.getvalue()
+            assert zlib.decompress(z) == data
+            assert z == oracle.compress(data, level, strategy, chunks=chunks, flush=flush), (len(data), chunks[:3], level, strategy)
+
+
+@pytest.mark.gpu
+def test_flush_mode_single_write_takes_the_bulk_path(engine, oracle):
+    """One Write under SyncFlush at level 6: the bulk pipeline runs (the tail engine closes the block, the offsets kernel
+    adds the marker and the re-entered empty block); 8 MiB so that the sequential engine would be visible in the time."""
+    d = datagen.english(8 << 20, datagen.GOLDEN)
+    for flush in (1, 2, 3):
+        out = io.BytesIO()
+        with ZlibOutputStream(out, ZlibOptions(CompressionLevel=CompressionLevel.Level6, FlushMode=flush), engine=engine) as s:
+            s.write(d)
+        z = out.getvalue()
+        assert zlib.decompress(z) == d
+        assert z == oracle.compress(d, 6, 0, chunks=[len(d)], flush=flush)

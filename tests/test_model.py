@@ -35,8 +35,8 @@ def model(tmp_path_factory):
     return files
 
 
-def run(path, level, strategy=0, mode="chunk", wchunk=None):
-    cmd = [EXE, path, str(level), str(strategy), mode] + ([str(wchunk)] if wchunk else [])
+def run(path, level, strategy=0, mode="chunk", wchunk=None, flush=0):
+    cmd = [EXE, path, str(level), str(strategy), mode, str(wchunk or 0), str(flush)]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0 and "PASS" in r.stdout, (cmd, r.stdout[-500:])
 
@@ -62,3 +62,15 @@ def test_multi_write_literal_engine(model):
         for w in (1, 100, 8192, 65536, 70000):
             for level in (1, 6):
                 run(model[name], level, 0, "chunk", w)
+
+
+def test_flush_modes_literal_engine_and_marker_accounting(model):
+    """FlushMode Partial / Sync / Full (Deflate.cs:583-613): the literal engine closes a block at every Write end and
+    the offsets stage replays Deflate.Compress's 512-byte chunk accounting for the markers and the extra empty blocks."""
+    for name in ("alice_98304", "lowent_65537", "zeros_98305", "alice_5", "alice_0"):
+        for flush in (1, 2, 3):
+            for w in (0, 100, 4000, 8192, 70000):
+                for level in (0, 1, 6):
+                    run(model[name], level, 0, "chunk" if level >= 4 else "seq", w, flush)
+            run(model[name], 6, 3, "chunk", 5000, flush)   # Rle
+            run(model[name], 9, 4, "chunk", 3137, flush)   # Fixed

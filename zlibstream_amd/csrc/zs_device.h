@@ -45,6 +45,12 @@ struct StreamDesc {
     int32_t nsegs;
     int32_t n_wr;            // > 1: several Writes -> the whole stream runs on the literal engine
     const int64_t *wr_end;   // device array of n_wr cumulative Write ends (or nullptr)
+    // FlushMode Partial / Sync / Full (nullptr: every Write is NoFlush): the mode of each Write, the number of blocks
+    // flushed before each Write began (written by the literal engine, read by the offsets kernel), the caller's output
+    // chunk (ZlibOutputStream's 512) and whether the stream is raw deflate (no header bytes were delivered)
+    const uint8_t *wr_flush;
+    int32_t *wr_blk;
+    int32_t out_chunk, raw;
 };
 
 struct StreamState {

@@ -95,10 +95,24 @@ T *dev(DevBuf &b) {
     return (T *)b.p;
 }
 
-// `writes` (optional, one stream only): cumulative Write ends of a multi-Write stream
+// The Writes of one stream (ZlibOutputStream.WriteCore): cumulative ends, the FlushMode of each, the caller's output
+// chunk size and whether the stream is raw deflate.
+struct WriteSpec {
+    std::vector<int64_t> ends;
+    std::vector<uint8_t> flush;
+    int chunk = 512;
+    bool raw = false;
+    bool flushing() const {
+        for (uint8_t f : flush)
+            if (f) return true;
+        return false;
+    }
+};
+
+// `writes` (optional, one stream only): the Writes of a multi-Write stream, or of one whose Writes carry a flush mode
 bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len, void *const *out, const int64_t *out_cap,
                   int64_t *out_len, int *status, int level, int strategy, int hash_variant, hipStream_t stream,
-                  const std::vector<int64_t> *writes = nullptr, bool force_seq = false) {
+                  const WriteSpec *writes = nullptr, bool force_seq = false) {
     if (level == -1) level = 6;
     LevelCfg lv = level_cfg(level);
     Plan pl;
@@ -115,10 +129,12 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
         s.out = (uint8_t *)out[i];
         s.out_cap = out_cap[i];
         s.n = (int32_t)len;
-        const bool multi = writes && writes->size() > 1;
+        const bool multi = writes && writes->ends.size() > 1;
+        const bool flushing = writes && writes->flushing();
         s.body_end = (lv.func == 2 && strategy != kRle && len >= kMinLookahead && !multi) ? (int32_t)(len - kMinLookahead) : -1;
-        s.n_wr = multi ? (int32_t)writes->size() : 1;
+        s.n_wr = (multi || flushing) ? (int32_t)writes->ends.size() : 1;
         s.wr_end = nullptr;
+        s.wr_flush = nullptr, s.wr_blk = nullptr, s.out_chunk = writes ? writes->chunk : 512, s.raw = writes && writes->raw;
         s.kl = num_refills(len);
         s.nchunks = s.body_end >= 0 ? chunk_of(s.body_end) + 1 : 0;
         s.pos_off = pl.n_pos;
@@ -131,13 +147,14 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
         s.nsegs = num_segs(s.nchunks);
         pl.n_segs += s.nsegs;
         // levels 1-3, one Write, large enough: speculative chunk runs instead of one sequential engine
-        const bool fast_par = lv.func == 1 && strategy != kRle && !multi && !force_seq && len >= kFastMinInput;
+        const bool fast_par = lv.func == 1 && strategy != kRle && !multi && !flushing && !force_seq && len >= kFastMinInput;
         s.fast_runs = fast_par ? (int32_t)((len + kFastChunk - 1) / kFastChunk) : 0;
         s.run_off = (int32_t)pl.n_runs;
         pl.n_runs += s.fast_runs;
         for (int k = 0; k < s.fast_runs; k++) pl.w_runs.push_back(make_uint2((unsigned)i, (unsigned)k));
         s.blk_off = (int32_t)pl.n_blocks;
         s.max_blocks = (int32_t)(level == 0 ? len / 8191 + len / 32506 + 4 : len / kBlockSyms + 2);
+        if (flushing) s.max_blocks += (int32_t)writes->ends.size() + 1;  // every Write under a flush mode closes a block
         pl.n_blocks += s.max_blocks;
         s.adler_off = (int32_t)pl.n_pieces;
         s.n_adler = (int32_t)((len + kAdlerPiece - 1) / kAdlerPiece);
@@ -173,11 +190,19 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
          !ensure(c, c->run_scratch, (size_t)pl.n_runs * kFastRunScratch) || !ensure(c, c->run_outs, sizeof(FastRunOut) * (size_t)pl.n_runs) ||
          !ensure(c, c->run_fail, 4 * (size_t)n + 64)))
         return false;
-    if (writes && writes->size() > 1) {
-        if (!ensure(c, c->wr, sizeof(int64_t) * writes->size())) return false;
-        ZS_HIP(c, hipMemcpyAsync(c->wr.p, writes->data(), sizeof(int64_t) * writes->size(), hipMemcpyHostToDevice, stream));
-        ZS_HIP(c, hipStreamSynchronize(stream));  // `writes` is caller-owned pageable memory
+    if (writes && (writes->ends.size() > 1 || writes->flushing())) {
+        // [ends: int64 x nw][blocks before each Write: int32 x nw][flush modes: u8 x nw]
+        const size_t nw = writes->ends.size();
+        if (!ensure(c, c->wr, 13 * nw + 64)) return false;
+        ZS_HIP(c, hipMemsetAsync(c->wr.p, 0, 13 * nw + 64, stream));
+        ZS_HIP(c, hipMemcpyAsync(c->wr.p, writes->ends.data(), sizeof(int64_t) * nw, hipMemcpyHostToDevice, stream));
         pl.sd[0].wr_end = (const int64_t *)c->wr.p;
+        if (writes->flushing()) {
+            ZS_HIP(c, hipMemcpyAsync((uint8_t *)c->wr.p + 12 * nw, writes->flush.data(), nw, hipMemcpyHostToDevice, stream));
+            pl.sd[0].wr_blk = (int32_t *)((uint8_t *)c->wr.p + 8 * nw);
+            pl.sd[0].wr_flush = (const uint8_t *)c->wr.p + 12 * nw;
+        }
+        ZS_HIP(c, hipStreamSynchronize(stream));  // `writes` is caller-owned pageable memory
     }
     // ---- upload descriptors and work lists (one pinned staging copy) ----
     size_t up_bytes = sizeof(StreamDesc) * (size_t)n + sizeof(uint2) * n_work;
@@ -312,7 +337,7 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
                        dev<uint32_t>(c->syms), dev<BlockRec>(c->blocks), dev<TreeWork>(c->trees), dev<BlockInfo>(c->info), strategy, level, 2);
     mark(11);
     hipLaunchKernelGGL(zs_offsets_kernel, dim3((unsigned)n), dim3(256), 0, stream, d_sd, d_st, dev<BlockRec>(c->blocks),
-                       dev<BlockInfo>(c->info), dev<uint32_t>(c->pieces), level, n);
+                       dev<BlockInfo>(c->info), dev<TreeWork>(c->trees), dev<uint32_t>(c->pieces), level, n);
     mark(12);
     hipLaunchKernelGGL(zs_emit_bits_kernel, dim3((unsigned)pl.w_blocks.size()), dim3(256), 0, stream, d_sd, d_st, d_work + o_blocks,
                        dev<uint32_t>(c->syms), dev<BlockRec>(c->blocks), dev<TreeWork>(c->trees), dev<BlockInfo>(c->info));

@@ -1025,9 +1025,11 @@ __global__ __launch_bounds__(1024) void zs_tail_kernel(const StreamDesc *sd, Str
     e.crc_tab = tabl;
     e.data = s.in;
     e.n = s.n;
-    e.wr_end = s.n_wr > 1 ? s.wr_end : nullptr;
+    e.wr_end = s.wr_end;  // set for several Writes and for any Write under a flush mode
     e.n_wr = s.n_wr;
     e.cur_wr = 0;
+    e.wr_flush = s.wr_flush;
+    e.wr_blk = s.wr_blk;
     e.lv = lv;
     e.strategy = strategy;
     e.hash_variant = hash_variant;
@@ -1494,19 +1496,48 @@ __global__ __launch_bounds__(256) void zs_trees_kernel(const StreamDesc *sd, con
 // the last block align to a byte), zlib header, Adler-32 trailer, total length.  The scan over blocks is
 // sequential (alignment depends on the absolute bit position) but runs out of LDS; the Adler pieces are
 // combined by a tree.
+// OR `nbits` (<= 57) of `v` into the zeroed output at bit position `pos`.
+__device__ __forceinline__ void or_bits(uint8_t *out, int64_t pos, uint64_t v, int nbits) {
+    if (nbits == 0) return;
+    uint32_t *w = (uint32_t *)((uintptr_t)(out + (pos >> 3)) & ~(uintptr_t)3);
+    int sh = (int)(pos - ((int64_t)((uint8_t *)w - out) << 3));  // 0..31
+    uint64_t lo = v << sh;
+    uint32_t w0 = (uint32_t)lo, w1 = (uint32_t)(lo >> 32);
+    uint32_t w2 = sh ? (uint32_t)(v >> (64 - sh)) : 0;
+    if (w0) atomicOr(w, w0);
+    if (w1) atomicOr(w + 1, w1);
+    if (w2) atomicOr(w + 2, w2);
+}
+struct OrBitsAt {  // FlushAcct's put: OR into the zeroed stream, never past the caller's capacity
+    uint8_t *out;
+    int64_t cap;
+    __device__ void operator()(int64_t pos, uint32_t v, int nbits) const {
+        if ((pos >> 3) + 12 <= cap) or_bits(out, pos, v, nbits);
+    }
+};
 __global__ __launch_bounds__(256) void zs_offsets_kernel(const StreamDesc *sd, StreamState *st, const BlockRec *blocks,
-                                                         BlockInfo *info, const uint32_t *adler_pieces, int level, int nstreams) {
+                                                         BlockInfo *info, const TreeWork *trees, const uint32_t *adler_pieces,
+                                                         int level, int nstreams) {
     __shared__ int32_t sh_type[1024], sh_bits[1024], sh_len[1024], sh_eof[1024];
     __shared__ int64_t sh_start[1024];
     __shared__ uint32_t ad_v[256];
     __shared__ uint64_t ad_len[256];
     __shared__ int64_t sh_pos, sh_wsum[4];
     __shared__ int sh_bad;
+    // FlushMode Partial / Sync / Full: thread 0 replays Deflate.Compress's chunk accounting (zs_core.h, FlushAcct)
+    FlushAcct fa;
+    int fa_w = 0;
+    const bool flushing = sd[blockIdx.x].wr_flush != nullptr;
     const int si = blockIdx.x;
     const StreamDesc s = sd[si];
     StreamState &ss = st[si];
     const int nb = ss.nblocks;
     if (threadIdx.x == 0) sh_pos = 16, sh_bad = 0;
+    const OrBitsAt fa_put{s.out, s.out_cap};
+    if (flushing) {
+        fa_init(fa, s.out_chunk, level, s.raw != 0);
+        fa_enter(fa);  // the first Deflate call delivers the header
+    }
     __syncthreads();
     for (int b0 = 0; b0 < nb; b0 += 1024) {
         int cnt = nb - b0 < 1024 ? nb - b0 : 1024;
@@ -1520,7 +1551,7 @@ __global__ __launch_bounds__(256) void zs_offsets_kernel(const StreamDesc *sd, S
         // end-of-stream only on the last one) the starts are a prefix sum; otherwise thread 0 walks the blocks
         int irregular = 0;
         for (int i = threadIdx.x; i < cnt; i += 256) irregular |= (sh_type[i] == 0) || (sh_eof[i] && i != cnt - 1);
-        irregular = __syncthreads_or(irregular);
+        irregular = __syncthreads_or(irregular | (int)flushing);
         if (!irregular) {
             // thread t sums 4 consecutive blocks, then a scan over the 256 partial sums
             const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1548,12 +1579,14 @@ __global__ __launch_bounds__(256) void zs_offsets_kernel(const StreamDesc *sd, S
             __syncthreads();
             if (threadIdx.x == 255) {
                 int64_t end = pos;  // thread 255 holds the end of the last block of the batch
-                if (sh_eof[cnt - 1]) end = (end + 7) & ~7LL;
+                if (sh_eof[cnt - 1] & 1) end = (end + 7) & ~7LL;
                 sh_pos = end;
             }
         } else if (threadIdx.x == 0) {
             int64_t pos = sh_pos;
             for (int i = 0; i < cnt; i++) {
+                if (flushing)  // Writes that began before this block was flushed: each is a new Deflate call
+                    while (fa_w + 1 < s.n_wr && s.wr_blk[fa_w + 1] <= b0 + i) fa_w++, fa_enter(fa);
                 sh_start[i] = pos;
                 if (sh_type[i] == 0) {
                     // the reference copies a stored block through its pending buffer (64 KiB; 32 KiB at level 0) and throws
@@ -1565,7 +1598,15 @@ __global__ __launch_bounds__(256) void zs_offsets_kernel(const StreamDesc *sd, S
                 } else {
                     pos += sh_bits[i];
                 }
-                if (sh_eof[i]) pos = (pos + 7) & ~7LL;
+                if (sh_eof[i] & 1) pos = (pos + 7) & ~7LL;
+                if (flushing) {
+                    fa.bits = pos;
+                    fa.last_eob_len = sh_type[i] == 0 ? 8 : sh_type[i] == 1 ? 7 : trees[s.blk_off + b0 + i].ltree[kEndBlock].dl;
+                    const int f = sh_eof[i] >> 1;
+                    if (f) fa_end_of_write(fa, f, fa_put);
+                    else fa_after_block(fa);
+                    pos = fa.bits;
+                }
             }
             sh_pos = pos;
         }
@@ -1620,18 +1661,6 @@ __global__ __launch_bounds__(256) void zs_offsets_kernel(const StreamDesc *sd, S
 }
 
 // ------------------------------------------------------------------ K9
-// OR `nbits` (<= 57) of `v` into the zeroed output at bit position `pos`.
-__device__ __forceinline__ void or_bits(uint8_t *out, int64_t pos, uint64_t v, int nbits) {
-    if (nbits == 0) return;
-    uint32_t *w = (uint32_t *)((uintptr_t)(out + (pos >> 3)) & ~(uintptr_t)3);
-    int sh = (int)(pos - ((int64_t)((uint8_t *)w - out) << 3));  // 0..31
-    uint64_t lo = v << sh;
-    uint32_t w0 = (uint32_t)lo, w1 = (uint32_t)(lo >> 32);
-    uint32_t w2 = sh ? (uint32_t)(v >> (64 - sh)) : 0;
-    if (w0) atomicOr(w, w0);
-    if (w1) atomicOr(w + 1, w1);
-    if (w2) atomicOr(w + 2, w2);
-}
 struct OrPut {
     uint8_t *out;
     int64_t pos;
@@ -1690,7 +1719,7 @@ __global__ __launch_bounds__(256) void zs_emit_bits_kernel(const StreamDesc *sd,
     const int tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
     if (bi.type == 0) {
         int64_t pos = bi.bit_start;
-        if (tid == 0) or_bits(out, pos, (uint64_t)(r.eof ? 1 : 0), 3);
+        if (tid == 0) or_bits(out, pos, (uint64_t)(r.eof & 1), 3);
         int64_t byte = (pos + 3 + 7) >> 3;
         if (tid == 0) {
             unsigned len = (unsigned)r.stored_len;
@@ -1717,7 +1746,7 @@ __global__ __launch_bounds__(256) void zs_emit_bits_kernel(const StreamDesc *sd,
     int64_t cur = bi.bit_start + (int64_t)(((uintptr_t)out & 3) << 3);
     if (tid == 0) {
         LdsBitPut put{obuf, (uint32_t)(cur & 31)};
-        put((unsigned)(bi.type << 1) + (r.eof ? 1u : 0u), 3);
+        put((unsigned)(bi.type << 1) + (unsigned)(r.eof & 1), 3);
         if (bi.type == 2) emit_dyn_header(tw, put);
         sh_bits = put.pos - (uint32_t)(cur & 31);
     }

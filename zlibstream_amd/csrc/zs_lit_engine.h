@@ -54,6 +54,11 @@ struct LitEngine {
     // means one Write of the whole buffer.
     const int64_t *wr_end;
     int n_wr, cur_wr;
+    // FlushMode of each Write (ZlibOptions.FlushMode; 0 NoFlush, 1 Partial, 2 Sync, 3 Full; nullptr: NoFlush).  A
+    // Write under a flush mode is parsed to its last byte and closes its block (Deflate.Slow.cs:38-46,147-158);
+    // wr_blk[i] (optional) receives the number of blocks flushed before Write i began.
+    const uint8_t *wr_flush;
+    int32_t *wr_blk;
     LevelCfg lv;
     int strategy, hash_variant;
     // reference state
@@ -84,7 +89,7 @@ struct LitEngine {
 
 // the optional features are off unless a caller turns them on
 ZS_HD void le_defaults(LitEngine &e) {
-    e.wr_end = nullptr, e.n_wr = 1, e.cur_wr = 0;
+    e.wr_end = nullptr, e.n_wr = 1, e.cur_wr = 0, e.wr_flush = nullptr, e.wr_blk = nullptr;
     e.stop_abs = -1, e.mark_abs = -1, e.mark_pos = -1, e.mark_nsyms = 0;
     e.ins_bits = nullptr, e.ins_base = 0, e.no_blocks = 0, e.ins_word_idx = -1, e.ins_word = 0;
     e.ev_log = nullptr, e.n_ev = 0;
@@ -235,7 +240,9 @@ ZS_HD_NOINLINE inline void le_refill(LitEngine &e, int lane, int nlanes, int &ha
     for (;;) {
         le_fill_window(e, lane, nlanes);
         if (e.lookahead >= enough || !e.wr_end || e.cur_wr + 1 >= e.n_wr) break;
+        if (e.wr_flush && e.wr_flush[e.cur_wr] != 0) break;  // flush != NoFlush: go on with what is there
         e.cur_wr++;
+        if (e.wr_blk && lane == 0) e.wr_blk[e.cur_wr] = e.nblocks;
         hash_head = 0;  // DeflateSlow's local is reset on every entry (Deflate.Slow.cs:20)
     }
 }
@@ -267,7 +274,7 @@ ZS_HD_NOINLINE inline int le_longest_match(LitEngine &e, int cur_match) {
     return best_len < e.lookahead ? best_len : e.lookahead;
 }
 
-ZS_HD void le_flush_block(LitEngine &e, bool eof, int lane) {
+ZS_HD void le_flush_block(LitEngine &e, bool eof, int lane, int flush = 0) {
     int64_t end_abs = e.base + e.strstart;
     if (lane == 0) {
         BlockRec &b = e.blocks[e.nblocks];
@@ -277,12 +284,28 @@ ZS_HD void le_flush_block(LitEngine &e, bool eof, int lane) {
         b.nsyms = (int32_t)(e.nsyms - e.block_sym_start);
         b.can_store = e.block_start_abs >= e.base;
         if (e.defer_start) b.can_store = -(1 + (int32_t)(e.base / kWSize));  // start unknown here: leave the window base
-        b.eof = eof;
+        b.eof = (eof ? 1 : 0) | (flush << 1);  // bit 0: last block; bits 1..2: the FlushMode marker that follows the block
     }
     e.nblocks++;
     e.block_start_abs = end_abs;
     e.defer_start = 0;
     e.block_sym_start = e.nsyms;
+}
+
+// lookahead == 0 with the current Write ending under FlushMode Partial / Sync / Full?
+ZS_HD bool le_write_flushes(const LitEngine &e) { return e.wr_flush && e.cur_wr < e.n_wr && e.wr_flush[e.cur_wr] != 0; }
+// The end of such a Write: Flush_block_only(false), BlockDone; Deflate.Compress then sends the marker and, for
+// FullFlush, forgets the hash heads (Deflate.cs:583-604).  The next Write (or Finish) enters the block function again.
+ZS_HD_NOINLINE inline void le_end_write(LitEngine &e, int lane, int nlanes) {
+    const int f = e.wr_flush[e.cur_wr];
+    le_flush_block(e, false, lane, f);
+    if (f == 3) {
+        ZS_WAVE_SYNC();
+        for (int i = lane; i < kHashSize; i += nlanes) e.head[i] = 0;
+        ZS_WAVE_SYNC();
+    }
+    e.cur_wr++;
+    if (e.wr_blk && e.cur_wr < e.n_wr && lane == 0) e.wr_blk[e.cur_wr] = e.nblocks;
 }
 
 // returns true when the block must be flushed (Deflate.cs:910-948)
@@ -298,7 +321,16 @@ ZS_HD_NOINLINE inline void le_run_slow(LitEngine &e, int lane, int nlanes) {
     for (;;) {
         if (e.lookahead < kMinLookahead) {
             le_refill(e, lane, nlanes, hash_head);
-            if (e.lookahead == 0) break;
+            if (e.lookahead == 0) {
+                if (!le_write_flushes(e)) break;
+                if (e.match_available != 0) {
+                    le_tally(e, 0, e.window[e.strstart - 1], lane);
+                    e.match_available = 0;
+                }
+                le_end_write(e, lane, nlanes);
+                hash_head = 0;
+                continue;
+            }
         }
         if (e.lookahead >= kMinMatch) hash_head = le_insert(e, e.strstart);
         e.prev_length = e.match_length;
@@ -346,7 +378,11 @@ ZS_HD_NOINLINE inline void le_run_fast(LitEngine &e, int lane, int nlanes) {
         if (e.lookahead < kMinLookahead) {
             int dummy = 0;
             le_refill(e, lane, nlanes, dummy);
-            if (e.lookahead == 0) break;
+            if (e.lookahead == 0) {
+                if (!le_write_flushes(e)) break;
+                le_end_write(e, lane, nlanes);
+                continue;
+            }
         }
         if (e.mark_abs >= 0 && e.mark_pos < 0 && e.base + e.strstart >= e.mark_abs) e.mark_pos = e.base + e.strstart, e.mark_nsyms = e.nsyms;
         if (e.stop_abs >= 0 && e.base + e.strstart >= e.stop_abs) return;  // a speculative run ends at a loop-top, nothing is flushed
@@ -388,7 +424,11 @@ ZS_HD_NOINLINE inline void le_run_stored(LitEngine &e, int lane, int nlanes) {
         if (e.lookahead <= 1) {
             int dummy = 0;
             le_refill(e, lane, nlanes, dummy, 1);  // NoFlush returns only while lookahead == 0
-            if (e.lookahead == 0) break;
+            if (e.lookahead == 0) {
+                if (!le_write_flushes(e)) break;
+                le_end_write(e, lane, nlanes);
+                continue;
+            }
         }
         e.strstart += e.lookahead;
         e.lookahead = 0;
@@ -411,7 +451,11 @@ ZS_HD_NOINLINE inline void le_run_rle(LitEngine &e, int lane, int nlanes) {
             int dummy = 0;
             le_refill(e, lane, nlanes, dummy, kMaxMatch + 1);
         }
-        if (e.lookahead == 0) break;
+        if (e.lookahead == 0) {
+            if (!le_write_flushes(e)) break;
+            le_end_write(e, lane, nlanes);
+            continue;
+        }
         e.match_length = 0;
         if (e.lookahead >= kMinMatch && e.strstart > 0) {
             const uint8_t *w = e.window + e.strstart;
