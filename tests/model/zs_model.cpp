@@ -53,6 +53,8 @@ struct Model {
     std::vector<int64_t> events;  // s_k for k = 1..
     int64_t body_end;             // last body loop-top position (n - 262), or -1
     std::vector<int64_t> wr_end;
+    std::vector<ReadEvent> rev;    // the stream's read events (zs_core.h build_read_events); rev[0] = the first read
+    std::vector<char> head;        // per chunk: a read event fires at its entry
     int flush_mode = 0;            // ZlibOptions.FlushMode of every Write
     std::vector<uint8_t> wr_flush;
     std::vector<int32_t> wr_blk;
@@ -99,12 +101,12 @@ static void parse_sequential(Model &m, bool on_demand, int64_t &p_out, int &kind
     int64_t p = 0;
     uint32_t pend = 0;
     int k_fired = 0;
-    int kl = num_refills(m.n);
+    int kl = (int)m.rev.size() - 1;
     int64_t killed_pos = -1;
     int64_t preins = -1;
     int64_t block_start = 0;
     while (p <= m.body_end) {
-        if (k_fired < kl && p >= segment_start(k_fired + 1)) {
+        if (k_fired < kl && p >= m.rev[(size_t)k_fired + 1].at - (kMinLookahead - 1)) {
             k_fired++;
             m.events.push_back(p);
             preins = p + 1;
@@ -131,7 +133,7 @@ static void parse_sequential(Model &m, bool on_demand, int64_t &p_out, int &kind
                 b.sym_start = (int64_t)m.syms.size() - kBlockSyms;
                 b.stored_len = (int32_t)(end - block_start);
                 b.nsyms = kBlockSyms;
-                b.can_store = block_start >= (int64_t)kWSize * k_fired;
+                b.can_store = block_start >= m.rev[(size_t)k_fired].base;
                 b.eof = 0;
                 m.blocks.push_back(b);
                 block_start = end;
@@ -174,17 +176,17 @@ struct ModelAcc {
     uint32_t bucket(int64_t p) const { return m->bucket(p); }
     int run1(int64_t p) const { return m->lcp(p, p - 1); }
 };
-static void chunk_walk(Model &m, int c, int slot, int kl, int &exit_slot, int &nsyms, Sink *sink) {
+static void chunk_walk(Model &m, int c, int slot, int &exit_slot, int &nsyms, Sink *sink) {
     ModelAcc acc{&m};
-    if (sink) walk_chunk(acc, *sink, c, slot, kl, m.body_end, m.lv, m.strategy, exit_slot, nsyms);
+    const bool ev = m.head[(size_t)c] != 0;
+    if (sink) walk_chunk(acc, *sink, c, slot, ev, m.body_end, m.lv, m.strategy, exit_slot, nsyms);
     else {
         NullSink ns;
-        walk_chunk(acc, ns, c, slot, kl, m.body_end, m.lv, m.strategy, exit_slot, nsyms);
+        walk_chunk(acc, ns, c, slot, ev, m.body_end, m.lv, m.strategy, exit_slot, nsyms);
     }
 }
 
 static void parse_chunked(Model &m, int64_t &p_out, int &kind_out, uint32_t &pend_out, int &kdone_out, int64_t &preins_out) {
-    int kl = num_refills(m.n);
     p_out = 0, kind_out = kR, pend_out = 0, kdone_out = 0, preins_out = -1;
     if (m.body_end < 0) return;
     int nchunks = chunk_of(m.body_end) + 1;
@@ -207,9 +209,9 @@ static void parse_chunked(Model &m, int64_t &p_out, int &kind_out, uint32_t &pen
                 }
         for (int s = 0; s < kSlots; s++) {
             if (!slot_valid(c, s, m.body_end)) { maps[(size_t)c * kSlots + s] = 0; continue; }
-            uint32_t v = chunk_exit_by_table3(macc, tbl, c, s, kl, m.body_end, m.lv, m.strategy);
+            uint32_t v = chunk_exit_by_table3(macc, tbl, c, s, m.head[(size_t)c] != 0, m.body_end, m.lv, m.strategy);
             int ex, ns;
-            chunk_walk(m, c, s, kl, ex, ns, nullptr);  // cross-check against the plain walk
+            chunk_walk(m, c, s, ex, ns, nullptr);  // cross-check against the plain walk
             if (map_exit(v) != ex || map_count(v) != ns) {
                 printf("chunk %d slot %d: table (%d,%d) walk (%d,%d)\n", c, s, map_exit(v), map_count(v), ex, ns);
                 exit(1);
@@ -227,7 +229,7 @@ static void parse_chunked(Model &m, int64_t &p_out, int &kind_out, uint32_t &pen
     for (int c = 0; c < nchunks; c++) {
         ChunkGeo g = chunk_geo(c);
         int64_t e = slot <= 256 ? g.cs + slot : g.cs;
-        if (g.first && g.seg <= kl && e <= m.body_end) {
+        if (m.head[(size_t)c] && e <= m.body_end) {
             k_fired++;
             m.events.push_back(e);
             preins = e + 1;
@@ -259,7 +261,7 @@ static void parse_chunked(Model &m, int64_t &p_out, int &kind_out, uint32_t &pen
         int ex, ns;
         if (stale[c]) {
             n_stale++;
-            chunk_walk(m, c, slot, kl, ex, ns, nullptr);
+            chunk_walk(m, c, slot, ex, ns, nullptr);
         } else {
             uint32_t v = maps[(size_t)c * kSlots + slot];
             ex = map_exit(v), ns = map_count(v);
@@ -275,7 +277,7 @@ static void parse_chunked(Model &m, int64_t &p_out, int &kind_out, uint32_t &pen
         // the way K5 does it: every chunk on its own from its true entry (the refill-rule prefix, then plain steps)
         Sink sk{symbase[c], &m.syms, &blk_end, &blk_top};
         int ex, ns;
-        chunk_walk(m, c, entry[c], kl, ex, ns, &sk);
+        chunk_walk(m, c, entry[c], ex, ns, &sk);
         int64_t nxt = c + 1 < nchunks ? symbase[c + 1] : total;
         if (symbase[c] + ns != nxt) { printf("chunk %d: %d symbols, maps said %ld\n", c, ns, (long)(nxt - symbase[c])); exit(1); }
     }
@@ -286,7 +288,7 @@ static void parse_chunked(Model &m, int64_t &p_out, int &kind_out, uint32_t &pen
         r.sym_start = (int64_t)b * kBlockSyms;
         r.stored_len = (int32_t)(blk_end[b] - bs);
         r.nsyms = kBlockSyms;
-        int fired = refills_fired_at(blk_top[b], kl);
+        int fired = refills_fired_at(blk_top[b], num_refills(m.n));
         r.can_store = bs >= (int64_t)kWSize * fired;
         r.eof = 0;
         m.blocks.push_back(r);
@@ -318,7 +320,6 @@ static void run_tail(Model &m, int64_t p, int kind, uint32_t pend, int k_done, i
     e.hash_variant = kHashCrc32c;
     e.wr_end = (m.wr_end.size() > 1 || m.flush_mode) ? m.wr_end.data() : nullptr;
     e.n_wr = (int)m.wr_end.size();
-    e.cur_wr = 0;
     m.wr_flush.assign(m.wr_end.size(), (uint8_t)m.flush_mode);
     m.wr_blk.assign(m.wr_end.size(), 0);
     if (m.flush_mode) e.wr_flush = m.wr_flush.data(), e.wr_blk = m.wr_blk.data();
@@ -333,7 +334,8 @@ static void run_tail(Model &m, int64_t p, int kind, uint32_t pend, int k_done, i
     e.block_start_abs = body_blocks ? m.blocks[body_blocks - 1].start + m.blocks[body_blocks - 1].stored_len : 0;
     e.block_sym_start = (int64_t)body_blocks * kBlockSyms;
     e.block_syms = m.level == 0 ? (kLitBufsize / 2) - 1 : kBlockSyms;
-    le_restore(e, p, k_done, kind, pend, m.link.data(), preins, 0, 1);
+    le_restore(e, p, m.rev.empty() ? 0 : m.rev[(size_t)k_done].base, m.rev.empty() ? 0 : m.rev[(size_t)k_done].after, kind, pend,
+               m.link.data(), preins, 0, 1);
     if (e.avail_end > 0) {
         int64_t lo = p - (kWSize - 1);
         if (lo < e.base) lo = e.base;
@@ -515,9 +517,18 @@ int main(int argc, char **argv) {
     m.crc_tab.resize(1024);
     for (int tt = 0; tt < 4; tt++)
         for (int i = 0; i < 256; i++) m.crc_tab[tt * 256 + i] = crc32c_table_entry(tt, (uint32_t)i);
-    m.body_end = (m.lv.func == 2 && strategy != kRle && wends.size() <= 1) ? n - kMinLookahead : -1;
     m.wr_end = wends;
     m.flush_mode = flush_mode;
+    // the bulk form needs a regular read schedule: one Write, or NoFlush Writes whose sizes are multiples of kChunk
+    bool regular = build_read_events(n, wends, m.rev) && (wends.size() <= 1 || flush_mode == 0);
+    m.body_end = (m.lv.func == 2 && strategy != kRle && regular) ? n - kMinLookahead : -1;
+    if (m.body_end >= 0) {
+        m.head.assign((size_t)chunk_of(m.body_end) + 2, 0);
+        for (size_t k = 1; k < m.rev.size(); k++) {
+            int64_t at = m.rev[k].at - (kMinLookahead - 1);
+            if (at <= m.body_end) m.head[(size_t)chunk_of(at)] = 1;
+        }
+    }
     m.build_links();
     int64_t p;
     int kind, k_done;

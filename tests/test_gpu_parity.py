@@ -468,3 +468,44 @@ def test_flush_mode_single_write_takes_the_bulk_path(engine, oracle):
         z = out.getvalue()
         assert zlib.decompress(z) == d
         assert z == oracle.compress(d, 6, 0, chunks=[len(d)], flush=flush)
+
+
+@pytest.mark.gpu
+def test_multi_write_streams_on_the_bulk_path(engine, oracle):
+    """Streams of several NoFlush Writes whose sizes are multiples of 2048 (Stream.CopyTo's 81920, 4 / 8 / 64 KiB buffers)
+    have a regular read schedule -- the window-full events of a single Write plus one event per Write end, all on the
+    chunk grid (zs_core.h build_read_events) -- and take the bulk pipeline; bytes against the oracle, which runs the
+    reference's WriteCore loop literally.  8 MiB of text in ~2 MB/s of the literal engine would take seconds: the time
+    bound shows which path ran."""
+    import time
+    text = datagen.english(8 << 20, datagen.GOLDEN)
+    low = np.random.default_rng(9).choice(np.array([0, 0, 0, 0, 1, 2, 255], dtype=np.uint8), 3 << 20).tobytes()
+    zeros = bytes(1 << 20)
+    for data, sizes in ((text, (81920, 4096, 65536, 2048, 1 << 20)), (low, (8192, 98304)), (zeros, (2048, 16384)),
+                        (text[:200000], (4096,)), (text[:65536 + 300], (32768,)), (text[:3 * 81920], (81920,))):
+        for size in sizes:
+            for level in (6, 4, 9) if len(data) <= (3 << 20) else (6,):
+                chunks = [min(size, len(data) - o) for o in range(0, len(data), size)]
+                out = io.BytesIO()
+                t0 = time.perf_counter()
+                with ZlibOutputStream(out, CompressionLevel(level), engine=engine) as s:
+                    o = 0
+                    for c in chunks:
+                        s.write(data[o:o + c])
+                        o += c
+                dt = time.perf_counter() - t0
+                z = out.getvalue()
+                assert z == oracle.compress(data, level, chunks=chunks), (len(data), size, level)
+                if len(data) >= (8 << 20):
+                    assert dt < 2.0, "8 MiB in %d-byte Writes took %.2f s: not the bulk path" % (size, dt)
+    # Write sizes off the grid, or under a flush mode, stay on the literal engine -- same bytes
+    d = text[:300000]
+    for size in (1000, 5000, 81921):
+        chunks = [min(size, len(d) - o) for o in range(0, len(d), size)]
+        out = io.BytesIO()
+        with ZlibOutputStream(out, CompressionLevel.Level6, engine=engine) as s:
+            o = 0
+            for c in chunks:
+                s.write(d[o:o + c])
+                o += c
+        assert out.getvalue() == oracle.compress(d, 6, chunks=chunks)

@@ -74,3 +74,18 @@ def test_flush_modes_literal_engine_and_marker_accounting(model):
                     run(model[name], level, 0, "chunk" if level >= 4 else "seq", w, flush)
             run(model[name], 6, 3, "chunk", 5000, flush)   # Rle
             run(model[name], 9, 4, "chunk", 3137, flush)   # Fixed
+
+
+def test_regular_multi_write_takes_the_chunked_form(model):
+    """NoFlush Writes whose sizes are multiples of the chunk size: read events at Write ends fall on the chunk grid
+    (zs_core.h build_read_events) and the chunked parse handles them like window-full refills -- including events
+    whose loop-top shares its bucket with the next position (zeros, runs)."""
+    for name in ("alice_98304", "alice_98305", "lowent_98043", "zeros_98305", "zeros_65541", "runs", "ptt5"):
+        for w in (2048, 4096, 8192, 32768, 65536, 81920):
+            for level in (4, 6, 9):
+                if level == 9 and name == "ptt5":
+                    continue
+                r = subprocess.run([EXE, model[name], str(level), "0", "chunk", str(w), "0"], capture_output=True, text=True)
+                assert r.returncode == 0 and "PASS" in r.stdout, (name, w, level, r.stdout[-400:])
+                if os.path.getsize(model[name]) > w + 600:
+                    assert "tail_from=0 " not in r.stdout + " ", (name, w, level)   # the bulk form really ran

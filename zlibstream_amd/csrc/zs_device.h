@@ -43,6 +43,10 @@ struct StreamDesc {
     int32_t run_off;   // index of run 0 in the run arrays
     int32_t seg_off;   // index of parse segment 0 in segmap / seg_entry / seg_symbase / seg_stale
     int32_t nsegs;
+    // parse segments (one per read event, zs_core.h build_read_events), already offset to this stream: first chunk of
+    // each, data end after its event's read, window base after it; and per chunk whether a read event fires at its entry
+    const int32_t *seg_c0, *seg_after, *seg_base;
+    const uint8_t *head;
     int32_t n_wr;            // > 1: several Writes -> the whole stream runs on the literal engine
     const int64_t *wr_end;   // device array of n_wr cumulative Write ends (or nullptr)
     // FlushMode Partial / Sync / Full (nullptr: every Write is NoFlush): the mode of each Write, the number of blocks

@@ -44,7 +44,7 @@ struct zs_ctx {
     hipEvent_t ev[kStCount + 1] = {};
     double stage_ms[kStCount] = {};
     uint32_t *crc_tab = nullptr;
-    DevBuf sd, st, work, link, mm, maps, segmap, seg_entry, seg_symbase, seg_stale, entry, symbase, stale, syms, blk_end, blk_top, blocks, trees, info, pieces, scratch,
+    DevBuf sd, st, work, geo, link, mm, maps, segmap, seg_entry, seg_symbase, seg_stale, entry, symbase, stale, syms, blk_end, blk_top, blocks, trees, info, pieces, scratch,
         stage_in, stage_out, wr, inf_desc, inf_state, par_ps, par_st, par_work, par_cbits, par_ccnt, par_surv, par_scnt, par_cands, par_tabs, par_blocks, par_cells,
         par_windows, par_fail, run_syms, run_bits, run_scratch, run_outs, run_fail;
     void *pinned = nullptr;
@@ -88,6 +88,8 @@ struct Plan {
     std::vector<uint2> w_clear, w_adler, w_links, w_match, w_chunks, w_segs, w_blocks, w_runs;
     int64_t n_pos = 0, n_syms = 0;
     int64_t n_chunks = 0, n_segs = 0, n_blocks = 0, n_pieces = 0, n_runs = 0;
+    std::vector<int32_t> seg_c0, seg_after, seg_base;  // per parse segment (all streams, in seg_off order)
+    std::vector<uint8_t> head;                         // per chunk (chunk_off order): a read event fires at its entry
 };
 
 template <class T>
@@ -131,7 +133,13 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
         s.n = (int32_t)len;
         const bool multi = writes && writes->ends.size() > 1;
         const bool flushing = writes && writes->flushing();
-        s.body_end = (lv.func == 2 && strategy != kRle && len >= kMinLookahead && !multi) ? (int32_t)(len - kMinLookahead) : -1;
+        // the bulk pipeline needs a regular read schedule (zs_core.h build_read_events): one Write, or NoFlush Writes
+        // whose ends fall on the chunk grid; other streams of several Writes run on the literal engine
+        std::vector<ReadEvent> rev;
+        const int64_t one_write[1] = {len};
+        const bool regular = multi ? (!flushing && build_read_events(len, writes->ends, rev))
+                                   : build_read_events(len, std::vector<int64_t>(one_write, one_write + 1), rev);
+        s.body_end = (lv.func == 2 && strategy != kRle && len >= kMinLookahead && regular) ? (int32_t)(len - kMinLookahead) : -1;
         s.n_wr = (multi || flushing) ? (int32_t)writes->ends.size() : 1;
         s.wr_end = nullptr;
         s.wr_flush = nullptr, s.wr_blk = nullptr, s.out_chunk = writes ? writes->chunk : 512, s.raw = writes && writes->raw;
@@ -144,7 +152,18 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
         s.chunk_off = (int32_t)pl.n_chunks;
         pl.n_chunks += s.nchunks;
         s.seg_off = (int32_t)pl.n_segs;
-        s.nsegs = num_segs(s.nchunks);
+        s.nsegs = 0;
+        pl.head.resize((size_t)pl.n_chunks, 0);
+        if (s.body_end >= 0)
+            for (size_t k = 0; k < rev.size(); k++) {
+                const int64_t at = k ? rev[k].at - (kMinLookahead - 1) : 0;  // where the segment starts
+                if (at > s.body_end) break;
+                const int c0 = chunk_of(at);
+                pl.seg_c0.push_back(c0), pl.seg_after.push_back((int32_t)rev[k].after), pl.seg_base.push_back((int32_t)rev[k].base);
+                if (k) pl.head[(size_t)s.chunk_off + (size_t)c0] = 1;
+                s.nsegs++;
+            }
+        s.seg_c0 = s.seg_after = s.seg_base = nullptr, s.head = nullptr;
         pl.n_segs += s.nsegs;
         // levels 1-3, one Write, large enough: speculative chunk runs instead of one sequential engine
         const bool fast_par = lv.func == 1 && strategy != kRle && !multi && !flushing && !force_seq && len >= kFastMinInput;
@@ -185,6 +204,15 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
         !ensure(c, c->trees, sizeof(TreeWork) * (size_t)pl.n_blocks) || !ensure(c, c->info, sizeof(BlockInfo) * (size_t)pl.n_blocks) ||
         !ensure(c, c->pieces, 4 * (size_t)pl.n_pieces + 64) || !ensure(c, c->scratch, (size_t)kScratchBytes * (size_t)n))
         return false;
+    // parse-segment tables: [seg_c0 | seg_after | seg_base : int32 x n_segs each][head : u8 x n_chunks]
+    const size_t geo_bytes = 12 * (size_t)pl.n_segs + (size_t)pl.n_chunks;
+    if (!ensure(c, c->geo, geo_bytes + 64)) return false;
+    for (int i = 0; i < n; i++) {
+        StreamDesc &s = pl.sd[(size_t)i];
+        const int32_t *g = (const int32_t *)c->geo.p;
+        s.seg_c0 = g + s.seg_off, s.seg_after = g + pl.n_segs + s.seg_off, s.seg_base = g + 2 * pl.n_segs + s.seg_off;
+        s.head = (const uint8_t *)c->geo.p + 12 * (size_t)pl.n_segs + (size_t)s.chunk_off;
+    }
     if (pl.n_runs &&
         (!ensure(c, c->run_syms, 4 * (size_t)pl.n_runs * kFastRunSyms) || !ensure(c, c->run_bits, 4 * (size_t)pl.n_runs * kFastRunBitWords) ||
          !ensure(c, c->run_scratch, (size_t)pl.n_runs * kFastRunScratch) || !ensure(c, c->run_outs, sizeof(FastRunOut) * (size_t)pl.n_runs) ||
@@ -205,7 +233,7 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
         ZS_HIP(c, hipStreamSynchronize(stream));  // `writes` is caller-owned pageable memory
     }
     // ---- upload descriptors and work lists (one pinned staging copy) ----
-    size_t up_bytes = sizeof(StreamDesc) * (size_t)n + sizeof(uint2) * n_work;
+    size_t up_bytes = sizeof(StreamDesc) * (size_t)n + sizeof(uint2) * n_work + geo_bytes + 16;
     if (!ensure_pinned(c, std::max(up_bytes, sizeof(StreamState) * (size_t)n))) return false;
     uint8_t *hp = (uint8_t *)c->pinned;
     memcpy(hp, pl.sd.data(), sizeof(StreamDesc) * (size_t)n);
@@ -224,6 +252,16 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
     at = put(pl.w_segs, o_segs, at);
     at = put(pl.w_blocks, o_blocks, at);
     at = put(pl.w_runs, o_runs, at);
+    if (geo_bytes) {
+        uint8_t *hg = hp + sizeof(StreamDesc) * (size_t)n + sizeof(uint2) * n_work;
+        if (pl.n_segs) {
+            memcpy(hg, pl.seg_c0.data(), 4 * (size_t)pl.n_segs);
+            memcpy(hg + 4 * (size_t)pl.n_segs, pl.seg_after.data(), 4 * (size_t)pl.n_segs);
+            memcpy(hg + 8 * (size_t)pl.n_segs, pl.seg_base.data(), 4 * (size_t)pl.n_segs);
+        }
+        if (pl.n_chunks) memcpy(hg + 12 * (size_t)pl.n_segs, pl.head.data(), (size_t)pl.n_chunks);
+        ZS_HIP(c, hipMemcpyAsync(c->geo.p, hg, geo_bytes, hipMemcpyHostToDevice, stream));
+    }
     ZS_HIP(c, hipMemcpyAsync(c->sd.p, hp, sizeof(StreamDesc) * (size_t)n, hipMemcpyHostToDevice, stream));
     if (n_work) ZS_HIP(c, hipMemcpyAsync(c->work.p, hw, sizeof(uint2) * n_work, hipMemcpyHostToDevice, stream));
     ZS_HIP(c, hipMemsetAsync(c->link.p, 0, 2 * (size_t)pl.n_pos + 64, stream));
@@ -440,7 +478,7 @@ int zs_ctx_create(int device, zs_ctx **out) {
 void zs_ctx_destroy(zs_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    DevBuf *bufs[] = {&c->sd, &c->st, &c->work, &c->link, &c->mm, &c->maps, &c->segmap, &c->seg_entry, &c->seg_symbase, &c->seg_stale, &c->entry, &c->symbase, &c->stale, &c->syms,
+    DevBuf *bufs[] = {&c->sd, &c->st, &c->work, &c->geo, &c->link, &c->mm, &c->maps, &c->segmap, &c->seg_entry, &c->seg_symbase, &c->seg_stale, &c->entry, &c->symbase, &c->stale, &c->syms,
                       &c->blk_end, &c->blk_top, &c->blocks, &c->trees, &c->info, &c->pieces, &c->scratch, &c->stage_in, &c->stage_out, &c->wr, &c->inf_desc, &c->inf_state, &c->par_ps, &c->par_st, &c->par_work, &c->par_cbits, &c->par_ccnt, &c->par_surv, &c->par_scnt,
                       &c->par_cands, &c->par_tabs, &c->par_blocks, &c->par_cells, &c->par_windows, &c->par_fail, &c->run_syms, &c->run_bits,
                       &c->run_scratch, &c->run_outs, &c->run_fail};

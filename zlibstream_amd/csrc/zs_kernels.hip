@@ -459,6 +459,18 @@ __global__ __launch_bounds__(1024) void zs_match_kernel(const StreamDesc *sd, co
     }
 }
 
+// ------------------------------------------------------------------ parse-segment tables (StreamDesc)
+__device__ __forceinline__ int seg_first(const StreamDesc &s, int seg) { return seg < s.nsegs ? s.seg_c0[seg] : s.nchunks; }
+__device__ __forceinline__ int seg_of(const StreamDesc &s, int c) {  // last segment whose first chunk is <= c
+    int lo = 0, hi = s.nsegs - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (s.seg_c0[mid] <= c) lo = mid;
+        else hi = mid - 1;
+    }
+    return lo;
+}
+
 // ------------------------------------------------------------------ K3 / K4 / K5 accessors
 struct GlobalAcc {
     gcbytes in;
@@ -533,7 +545,7 @@ __global__ __launch_bounds__(512) void zs_chunkmap_kernel(const StreamDesc *sd, 
     const int c = (int)w.y;
     stage_chunk_matches(s, c, mm, strategy, fk, fk4);
     const ChunkGeo g = chunk_geo(c);
-    const bool event_chunk = g.first && g.seg <= s.kl;
+    const bool event_chunk = s.head[c] != 0;
     if (event_chunk) load_crc_tab(tab, crc_tab_g);
     __syncthreads();
     int64_t ce = g.ce;
@@ -579,7 +591,7 @@ __global__ __launch_bounds__(512) void zs_chunkmap_kernel(const StreamDesc *sd, 
     const int slot = threadIdx.x;
     if (slot >= kSlots) return;
     uint32_t out = 0;
-    if (slot_valid(c, slot, s.body_end)) out = chunk_exit_by_table3(acc, tbl, c, slot, s.kl, s.body_end, lv, strategy);
+    if (slot_valid(c, slot, s.body_end)) out = chunk_exit_by_table3(acc, tbl, c, slot, event_chunk, s.body_end, lv, strategy);
     maps[((int64_t)s.chunk_off + c) * kSlots + slot] = out;
 }
 
@@ -593,9 +605,7 @@ __global__ __launch_bounds__(320) void zs_segmap_kernel(const StreamDesc *sd, co
     const int seg = (int)w.y;
     int slot = threadIdx.x;
     if (slot >= kSlots) return;
-    const int c0 = seg_first_chunk(seg);
-    int c1 = seg_first_chunk(seg + 1);
-    if (c1 > s.nchunks) c1 = s.nchunks;
+    const int c0 = seg_first(s, seg), c1 = seg_first(s, seg + 1);
     const int entry_slot = slot;
     uint32_t total = 0, flags = 0;
     for (int c = c0; c < c1; c++) {
@@ -664,10 +674,10 @@ __global__ __launch_bounds__(1024) void zs_resolve_kernel(const StreamDesc *sd, 
             // per row: bit 0 = the segment starts with a refill (segments 1 .. kl), bit 1 = it holds stale chunks,
             // bits 2.. = largest entry offset that is still a loop-top of the body (only the last segment limits it)
             const int seg = seg0 + (int)threadIdx.x;
-            const int64_t cs = seg >= 1 ? (int64_t)kSeg0 + (int64_t)(seg - 1) * kWSize : 0;  // segment_start(seg)
+            const int64_t cs = chunk_start(s.seg_c0[seg]);
             int64_t lim = (int64_t)s.body_end - cs;
             lim = lim > 511 ? 511 : lim;
-            uint32_t m = (seg >= 1 && seg <= s.kl && lim >= 0) ? 1u : 0u;
+            uint32_t m = (seg >= 1 && lim >= 0) ? 1u : 0u;
             if (seg_stale[s.seg_off + seg]) m |= 2u;
             row_meta[threadIdx.x] = m | ((uint32_t)(lim < 0 ? 0 : lim) << 2);
         }
@@ -730,14 +740,12 @@ __global__ __launch_bounds__(1024) void zs_resolve_kernel(const StreamDesc *sd, 
                 out_slot[i] = (uint16_t)slot;
                 out_base[i] = total;
                 if (m & 2u) {
-                    const int c0 = seg_first_chunk(seg);
-                    int c1 = seg_first_chunk(seg + 1);
-                    if (c1 > nch) c1 = nch;
+                    const int c0 = seg_first(s, seg), c1 = seg_first(s, seg + 1);
                     for (int cc = c0; cc < c1; cc++) {
                         int ex, cnt;
                         if (stale[s.chunk_off + cc]) {
                             NullSink ns;
-                            walk_chunk(acc, ns, cc, slot, s.kl, s.body_end, lv, strategy, ex, cnt);
+                            walk_chunk(acc, ns, cc, slot, s.head[cc] != 0, s.body_end, lv, strategy, ex, cnt);
                         } else {
                             uint32_t mp = maps[((int64_t)s.chunk_off + cc) * kSlots + slot];
                             ex = map_exit(mp), cnt = map_count(mp);
@@ -780,7 +788,7 @@ __global__ __launch_bounds__(1024) void zs_resolve_kernel(const StreamDesc *sd, 
             for (int g = 0; g < kSegBatch / kSegGroup; g++)
                 if (g_fast[g] && g_kf[g] > kf) kf = g_kf[g], ks = g_ks[g];
             if (kf >= 0) {
-                const int64_t cs = (int64_t)kSeg0 + (int64_t)(kf - 1) * kWSize;
+                const int64_t cs = chunk_start(s.seg_c0[kf]);
                 sh_kfired = kf, sh_preins = (int)((ks <= 256 ? cs + ks : cs) + 1);
             }
         }
@@ -795,9 +803,9 @@ __global__ __launch_bounds__(1024) void zs_resolve_kernel(const StreamDesc *sd, 
         }
         // ---- equal-bucket refill at the head of segment sh_seg: cut and repair ----
         {
-            const int c0 = seg_first_chunk(sh_seg);
+            const int c0 = s.seg_c0[sh_seg];
             const int slot = sh_slot;
-            const int64_t e = slot <= 256 ? chunk_geo(c0).cs + slot : chunk_geo(c0).cs;
+            const int64_t e = slot <= 256 ? chunk_start(c0) + slot : chunk_start(c0);
             const uint32_t B = acc.bucket(e);
             if (threadIdx.x == 0) lk[e] = 0;
             __threadfence_block();
@@ -823,10 +831,10 @@ __global__ __launch_bounds__(1024) void zs_resolve_kernel(const StreamDesc *sd, 
                     a[p] = make_uint2(nx | (old.x & ~kRecMask), ny);
                     int cp = chunk_of(p);
                     stale[s.chunk_off + cp] = 1;
-                    seg_stale[s.seg_off + seg_of_chunk(cp)] = 1;
+                    seg_stale[s.seg_off + seg_of(s, cp)] = 1;
                     if (p + 1 == chunk_geo(cp).ce && cp + 1 < nch) {
                         stale[s.chunk_off + cp + 1] = 1;
-                        seg_stale[s.seg_off + seg_of_chunk(cp + 1)] = 1;
+                        seg_stale[s.seg_off + seg_of(s, cp + 1)] = 1;
                     }
                 }
             }
@@ -863,16 +871,14 @@ __global__ __launch_bounds__(64) void zs_expand_kernel(const StreamDesc *sd, con
     GlobalAcc acc{as_global(s.in), mm + s.pos_off, crc_tab_g, strategy, hash_variant};
     int slot = seg_entry[s.seg_off + seg];
     uint32_t total = seg_symbase[s.seg_off + seg];
-    const int c0 = seg_first_chunk(seg);
-    int c1 = seg_first_chunk(seg + 1);
-    if (c1 > s.nchunks) c1 = s.nchunks;
+    const int c0 = seg_first(s, seg), c1 = seg_first(s, seg + 1);
     for (int c = c0; c < c1; c++) {
         entry[s.chunk_off + c] = (uint16_t)slot;
         symbase[s.chunk_off + c] = total;
         int ex, cnt;
         if (stale[s.chunk_off + c]) {
             NullSink ns;
-            walk_chunk(acc, ns, c, slot, s.kl, s.body_end, lv, strategy, ex, cnt);
+            walk_chunk(acc, ns, c, slot, s.head[c] != 0, s.body_end, lv, strategy, ex, cnt);
         } else {
             uint32_t m = maps[((int64_t)s.chunk_off + c) * kSlots + slot];
             ex = map_exit(m), cnt = map_count(m);
@@ -921,7 +927,7 @@ __global__ __launch_bounds__(64) void zs_emit_syms_lane_kernel(const StreamDesc 
     int kind, ns;
     int64_t p;
     bool equal;
-    chunk_special_prefix(acc, sink, c, (int)entry[s.chunk_off + c], s.kl, s.body_end, lv, strategy, kind, p, ns, equal);
+    chunk_special_prefix(acc, sink, c, (int)entry[s.chunk_off + c], s.head[c] != 0, s.body_end, lv, strategy, kind, p, ns, equal);
     const ChunkGeo g = chunk_geo(c);
     int64_t ce = g.ce;
     if (ce > (int64_t)s.body_end + 1) ce = (int64_t)s.body_end + 1;
@@ -1045,7 +1051,10 @@ __global__ __launch_bounds__(1024) void zs_tail_kernel(const StreamDesc *sd, Str
     e.block_syms = level == 0 ? (kLitBufsize / 2) - 1 : kBlockSyms;
     const uint16_t *lk = link + s.pos_off;
     const int64_t p = ss.tail_p;
-    le_restore(e, p, ss.k_done, ss.tail_kind, ss.tail_pend, lk, ss.preins, tid, nth);
+    // ss.k_done is the parse segment of the last read event that fired before p
+    const bool have_seg = s.nsegs > 0;
+    le_restore(e, p, have_seg ? s.seg_base[ss.k_done] : 0, have_seg ? s.seg_after[ss.k_done] : 0, ss.tail_kind, ss.tail_pend, lk,
+               ss.preins, tid, nth);
     for (int i = tid; i < kHashSize; i += nth) head32[i] = 0;
     __syncthreads();
     if (e.avail_end > 0) {
@@ -1118,7 +1127,7 @@ __global__ __launch_bounds__(1024) void zs_fast_run_kernel(const StreamDesc *sd,
     e.ev_log = outs[run].ev;
     const uint16_t *lk = link + s.pos_off;
     const int k_done = x == 0 ? 0 : refills_fired_at(x, s.kl);
-    le_restore(e, x, k_done, kR, 0, lk, -1, tid, nth);
+    le_restore(e, x, (int64_t)kWSize * k_done, read_end_before(k_done + 1), kR, 0, lk, -1, tid, nth);
     for (int i = tid; i < kHashSize; i += nth) head32[i] = 0;
     __syncthreads();
     if (e.avail_end > 0) {

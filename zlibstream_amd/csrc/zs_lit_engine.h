@@ -489,27 +489,32 @@ ZS_HD void le_run(LitEngine &e, int level, int lane, int nlanes) {
     else le_run_slow(e, lane, nlanes);
 }
 
-// Rebuild the reference state at absolute loop-top `p` of a single-Write
-// stream whose first `k_done` refills (reads k = 1..k_done, each preceded by a
-// slide) have happened, from the bulk arrays:
+// Rebuild the reference state at absolute loop-top `p` of a stream whose read
+// events so far have left the window at absolute position `base` and the data
+// read up to `avail_end` (both 0 when nothing has been read yet: the engine
+// then performs the first read itself), from the bulk arrays:
 //   link[q]  distance from q to the previous position in q's hash bucket
 //            (0 = none within 32767), valid for q <= n - 6, with link[s] = 0 at
 //            every resolved equal-bucket refill position s;
 //   kind / pend  the lazy-parse node at p (zs_core.h) and its pending match;
 //   preins  the position that the last refill pre-inserted (s_k + 1) or -1.
 // `lane`/`nlanes` split the copy loops across a wave on the device.
-ZS_HD_NOINLINE inline void le_restore(LitEngine &e, int64_t p, int k_done, int kind, uint32_t pend, const uint16_t *link,
-                                      int64_t preins, int lane, int nlanes) {
-    e.base = (int64_t)kWSize * k_done;
-    e.avail_end = read_end_before(k_done + 1);
+ZS_HD_NOINLINE inline void le_restore(LitEngine &e, int64_t p, int64_t base, int64_t avail_end, int kind, uint32_t pend,
+                                      const uint16_t *link, int64_t preins, int lane, int nlanes) {
+    e.base = base;
+    e.avail_end = avail_end;
     if (e.avail_end > e.n) e.avail_end = e.n;
-    bool started = (p > 0 || k_done > 0 || kind != kR);
+    bool started = (p > 0 || base > 0 || kind != kR);
     if (!started) e.avail_end = 0;  // nothing read yet: the engine performs read 0 itself
+    // the Write whose data the next Fill_window continues with
+    e.cur_wr = 0;
+    if (e.wr_end)
+        while (e.cur_wr + 1 < e.n_wr && e.wr_end[e.cur_wr] < e.avail_end) e.cur_wr++;
     int64_t valid = e.avail_end - e.base;
     for (int w = lane; w < kWindowSize + 512; w += nlanes) {
         uint8_t v = 0;
         if (w < valid) v = e.data[e.base + w];
-        else if (k_done >= 1 && w < kWindowSize) v = e.data[e.base + w - kWSize];  // stale upper half
+        else if (e.base >= kWSize && w < kWindowSize) v = e.data[e.base + w - kWSize];  // stale upper half
         e.window[w] = v;
     }
     for (int i = lane; i < kHashSize; i += nlanes) e.head[i] = 0;
