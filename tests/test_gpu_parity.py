@@ -509,3 +509,49 @@ def test_multi_write_streams_on_the_bulk_path(engine, oracle):
                 s.write(d[o:o + c])
                 o += c
         assert out.getvalue() == oracle.compress(d, 6, chunks=chunks)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [11, 12, 13])
+def test_fuzz_stream_protocol_writes_and_flush_modes(engine, oracle, seed):
+    """Random streams through the ZlibOutputStream mirror: data kind, level 0-9, strategy, Write sizes (on and off the
+    chunk grid, tiny ones included) and FlushMode drawn at random; bytes against the oracle's literal WriteCore loop."""
+    rng = np.random.default_rng(seed)
+    alice = oracle_binding.corpus("alice29.txt")
+    for case in range(14):
+        n = int(rng.choice([0, 1, 300, 5000, 70000, 200000, 400000]))
+        n += int(rng.integers(0, 3000)) if n > 300 else 0
+        kind = int(rng.integers(0, 4))
+        if kind == 0:
+            data = (alice * 4)[:n]
+        elif kind == 1:
+            data = rng.choice(np.array([0, 0, 0, 0, 1, 2, 255], dtype=np.uint8), n).tobytes()
+        elif kind == 2:
+            data = bytes(n)
+        else:
+            data = np.repeat(rng.integers(0, 4, n // 8 + 1, dtype=np.uint8), rng.integers(1, 30, n // 8 + 1))[:n].tobytes()
+            n = len(data)
+        level = int(rng.integers(0, 10))
+        strategy = int(rng.choice([0, 0, 0, 1, 2, 3, 4]))
+        flush = int(rng.choice([0, 0, 0, 1, 2, 3]))
+        unit = int(rng.choice([2048, 4096, 81920, 1000, 333, 65536, 7]))
+        chunks, left = [], n
+        while left > 0:
+            c = unit if rng.random() < 0.8 else int(rng.integers(1, 2 * unit + 1))
+            if unit == 7 and n > 5000:
+                c = int(rng.integers(1, 4000))
+            c = min(c, left)
+            chunks.append(c)
+            left -= c
+        try:
+            want = oracle.compress(data, level, strategy, chunks=chunks or None, flush=flush)
+        except RuntimeError:
+            continue  # level 0 + Rle overflow of the reference's pending buffer: covered elsewhere
+        out = io.BytesIO()
+        with ZlibOutputStream(out, ZlibOptions(CompressionLevel=CompressionLevel(level), CompressionStrategy=CompressionStrategy(strategy),
+                                               FlushMode=flush), engine=engine) as s:
+            o = 0
+            for c in chunks:
+                s.write(data[o:o + c])
+                o += c
+        assert out.getvalue() == want, (seed, case, n, kind, level, strategy, flush, unit, chunks[:4])
