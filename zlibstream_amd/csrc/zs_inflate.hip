@@ -46,7 +46,7 @@ struct InfTables {
     uint16_t lsym[288], dsym[32];
 };
 
-constexpr int kInfInBuf = 2048;  // LDS window over the compressed bytes [ibase, ibase + kInfInBuf)
+constexpr int kInfInBuf = 512;   // LDS window over the compressed bytes [ibase, ibase + kInfInBuf): small, so that 32 decoder waves fit a CU
 struct InfBits {
     const uint8_t *in;
     int64_t n, pos;  // next byte to load
