@@ -719,8 +719,10 @@ bool run_inflate_par(zs_ctx *c, const std::vector<int> &idx, const void *const *
                            dev<LaneTabs>(c->par_tabs));
     }
     mark(2);
+    // blocks measured by the lane kernel carry checkpoints: they are decoded by sub-blocks, one lane each
+    const bool lane_decode = w.size() > 6144 && !getenv("ZS_INF_WAVE_DECODE");
     hipLaunchKernelGGL(zs_inf_chain_kernel, dim3((unsigned)m), dim3(64), 0, stream, d_ps, d_st, dev<ParCand>(c->par_cands),
-                       dev<ParBlock>(c->par_blocks));
+                       dev<ParBlock>(c->par_blocks), lane_decode ? 1 : 0);
     mark(3);
     ZS_HIP(c, hipMemcpyAsync(st.data(), d_st, sizeof(ParState) * (size_t)m, hipMemcpyDeviceToHost, stream));
     ZS_HIP(c, hipStreamSynchronize(stream));
@@ -736,8 +738,15 @@ bool run_inflate_par(zs_ctx *c, const std::vector<int> &idx, const void *const *
         if (!ensure(c, c->par_windows, (size_t)total_blk * kWSize + 64)) return false;
         ZS_HIP(c, hipMemcpyAsync(c->par_work.p, w.data(), sizeof(uint2) * w.size(), hipMemcpyHostToDevice, stream));
         ZS_HIP(c, hipStreamSynchronize(stream));
+        if (lane_decode)
+            hipLaunchKernelGGL(zs_inf_decode_lane_kernel, dim3((unsigned)((w.size() + kDecBlocks - 1) / kDecBlocks)), dim3(64), 0, stream, d_ps,
+                               d_st, dev<uint2>(c->par_work), (int)w.size(), dev<ParBlock>(c->par_blocks), dev<LaneTabs>(c->par_tabs),
+                               dev<uint16_t>(c->par_cells), dev<int32_t>(c->par_fail));
         hipLaunchKernelGGL(zs_inf_decode_kernel, dim3((unsigned)w.size()), dim3(64), 0, stream, d_ps, d_st, dev<uint2>(c->par_work),
                            dev<ParBlock>(c->par_blocks), dev<uint16_t>(c->par_cells), dev<int32_t>(c->par_fail));
+        if (lane_decode)
+            hipLaunchKernelGGL(zs_inf_cellflat_kernel, dim3((unsigned)w.size()), dim3(256), 0, stream, d_ps, d_st, dev<uint2>(c->par_work),
+                               dev<ParBlock>(c->par_blocks), dev<LaneTabs>(c->par_tabs), dev<uint16_t>(c->par_cells));
         mark(4);
         hipLaunchKernelGGL(zs_inf_window_kernel, dim3((unsigned)m), dim3(1024), 0, stream, d_ps, d_st, dev<ParBlock>(c->par_blocks),
                            dev<uint16_t>(c->par_cells), dev<uint8_t>(c->par_windows));

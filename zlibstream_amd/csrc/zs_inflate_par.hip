@@ -47,9 +47,11 @@ struct ParCand {
     int64_t end_bit;   // bit offset after the block's EOB
     int64_t out_bytes;
     int32_t bfinal, ok;
+    int32_t tab, pad_;  // >= 0: measured by the lane kernel, with tables and checkpoints in tabs[tab] (see zs_inf_decode_lane_kernel)
 };
 struct ParBlock {
     int64_t bit, out_off, out_bytes;
+    int32_t tab, pad_;  // >= 0: decoded by sub-blocks from tabs[tab]; -1: by the wave decoder
 };
 struct ParState {
     int32_t ncand, nblk;
@@ -504,7 +506,7 @@ __global__ void zs_inf_flatten_kernel(const ParStream *ps, ParState *st, const i
             }
             ParCand &d = cands[s.cand_off + n++];
             d.bit = cand_bits[((int64_t)s.chunk_off + c) * kFindMaxCand + i];
-            d.end_bit = 0, d.out_bytes = 0, d.bfinal = 0, d.ok = 0;
+            d.end_bit = 0, d.out_bytes = 0, d.bfinal = 0, d.ok = 0, d.tab = -1, d.pad_ = 0;
         }
     }
     st[si].ncand = n;
@@ -544,13 +546,20 @@ __global__ __launch_bounds__(64) void zs_inf_measure_kernel(const ParStream *ps,
 // size is checked again by the decode pass and the Adler-32.
 constexpr int kLaneLanes = 8;
 constexpr int kLaneLitLds = (1 << kInfLitBits) * kLaneLanes * 2;
+constexpr int kCkSyms = 2048;  // the lane measure pass leaves a checkpoint (bit position, output position) every so many symbols
+constexpr int kCkMax = 32;     // checkpoints kept per block (a zlib block has 16 Ki symbols: 8); longer blocks go to the wave decoder
 struct LaneTabs {
+    uint16_t lit[1 << kInfLitBits];  // the literal/length primary table, kept for the sub-block decode pass
+    uint32_t ck_bit[kCkMax + 1];     // checkpoint k: bit position relative to the block header, before symbol k * kCkSyms
+    uint32_t ck_out[kCkMax + 1];     //               block-relative output position; entry nsub = the block's end
+    int32_t nsub, pad_;
     uint16_t dist[1 << kInfDistBits];
     uint16_t lcount[16], dcount[16];
     uint16_t lsym[288], dsym[32];
     uint8_t lens[384];  // [0, 19): bit-length code lengths; [32, 32 + nlen + ndist): literal/length and distance code lengths
     uint8_t blt[128];   // bit-length code: sym << 3 | len, 0 = invalid
 };
+static_assert(sizeof(LaneTabs) % 16 == 0, "the table at the head of every LaneTabs is copied with 16-byte loads");
 struct LaneBits {
     const __attribute__((address_space(1))) uint8_t *in;  // the stream's input (global memory: no flat loads)
     int64_t n, pos;
@@ -719,8 +728,14 @@ __global__ __launch_bounds__(kLaneLanes) void zs_inf_measure_lane_kernel(const P
     q = lane_build(ll + nlen, ndist, T.dist, 1, kInfDistBits, T.dcount, T.dsym);
     if (q < 0 || (q > 0 && ndist - T.dcount[0] > 1)) return;
     int64_t pos = 0;
-    for (int nsym = 0;; nsym++) {
+    T.nsub = 0;
+    int nsym = 0;
+    for (;; nsym++) {
         if (b.bad || nsym > kParMaxSyms) return;
+        if ((nsym & (kCkSyms - 1)) == 0 && nsym / kCkSyms < kCkMax) {
+            T.ck_bit[nsym / kCkSyms] = (uint32_t)(b.pos * 8 - b.cnt - c.bit);
+            T.ck_out[nsym / kCkSyms] = (uint32_t)pos;
+        }
         b.fill();
         int sym, clen;
         {
@@ -756,10 +771,20 @@ __global__ __launch_bounds__(kLaneLanes) void zs_inf_measure_lane_kernel(const P
     c.out_bytes = pos;
     c.bfinal = bfinal;
     c.ok = 1;
+    // sub-blocks for the decode pass: nsym symbols before END_BLOCK, one checkpoint per kCkSyms of them
+    const int nsub = nsym / kCkSyms + 1;
+    if (nsub <= kCkMax && pos < ((int64_t)1 << 31)) {
+        T.ck_out[nsub] = (uint32_t)pos;
+        T.ck_bit[nsub] = (uint32_t)(c.end_bit - c.bit);
+        T.nsub = nsub;
+        for (int i = 0; i < (1 << kInfLitBits); i++) T.lit[i] = lit[i * kLaneLanes];
+        c.tab = gi;
+    }
 }
 
 // ------------------------------------------------------------------ C
-__global__ __launch_bounds__(64) void zs_inf_chain_kernel(const ParStream *ps, ParState *st, const ParCand *cands, ParBlock *blocks) {
+__global__ __launch_bounds__(64) void zs_inf_chain_kernel(const ParStream *ps, ParState *st, const ParCand *cands, ParBlock *blocks,
+                                                          int lane_decode) {
     __shared__ ParLds L;
     const ParStream s = ps[blockIdx.x];
     ParState &ss = st[blockIdx.x];
@@ -775,9 +800,10 @@ __global__ __launch_bounds__(64) void zs_inf_chain_kernel(const ParStream *ps, P
     while (ok) {
         while (ci < ncand && cd[ci].bit < cur) ci++;
         int64_t end, nbytes;
-        int bfinal;
+        int bfinal, tab = -1;
         if (ci < ncand && cd[ci].bit == cur && cd[ci].ok) {
             end = cd[ci].end_bit, nbytes = cd[ci].out_bytes, bfinal = cd[ci].bfinal;
+            tab = lane_decode ? cd[ci].tab : -1;
         } else {
             // a block the finder does not report (stored / fixed codes): measure it here
             inf_seek(b, cur);
@@ -792,7 +818,7 @@ __global__ __launch_bounds__(64) void zs_inf_chain_kernel(const ParStream *ps, P
             ok = 0;
             break;
         }
-        if (threadIdx.x == 0) bl[nb] = {cur, out, nbytes};
+        if (threadIdx.x == 0) bl[nb] = {cur, out, nbytes, tab, 0};
         nb++;
         out += nbytes;
         cur = end;
@@ -814,10 +840,179 @@ __global__ __launch_bounds__(64) void zs_inf_decode_kernel(const ParStream *ps, 
     const ParStream s = ps[w.x];
     if (!st[w.x].ok || (int)w.y >= st[w.x].nblk) return;
     const ParBlock k = blocks[s.blk_off + w.y];
+    if (k.tab >= 0) return;  // decoded by sub-blocks (zs_inf_decode_lane_kernel)
     InfBits b{s.in, s.in_len, 0, 0, 0, false, L.ibuf, -1};
     inf_seek(b, k.bit);
     BlockOut r = inf_block<1>(b, L.T, L.lens, L.ll, cells + s.cell_off + k.out_off, k.out_bytes, k.out_off);
     if (threadIdx.x == 0 && (r.err || r.out_bytes != k.out_bytes)) fail[w.x] = 1;
+}
+
+// ------------------------------------------------------------------ D2, lane form
+// The wave decoder spends ~130 instructions of a whole wave on every symbol, and a CU issues about one per cycle: the
+// pass is bound by instruction issue with 63 of 64 lanes doing nothing useful.  Here every lane decodes something of
+// its own: the measure pass left a checkpoint every kCkSyms symbols, so a block falls into sub-blocks that decode
+// independently -- eight blocks per workgroup, one lane per sub-block, the eight literal/length tables in LDS (copied
+// from the measure pass), the other tables in their HBM slab.
+// Cells: a byte; 0x8000 | i = byte i of the 32 KiB before the *block* (as the wave decoder writes them); and, new,
+// 0x100 + (d - 1) = the cell d positions before the start of this lane's *sub-block* (d <= 32512; a source further
+// back inside the block fails the stream over to the sequential decoder -- zlib's MAX_DIST is 32506).  Copies of
+// markers stay markers; zs_inf_cellflat_kernel then follows the sub-block markers, so that the window and resolve
+// passes see the wave decoder's two kinds only.
+constexpr int kSubMarkBase = 0x100, kSubMarkMax = 0x8000 - kSubMarkBase;  // 32512 distances
+constexpr int kDecBlocks = 8;  // blocks per workgroup
+constexpr int kDecCopy = 8;    // cells of a match copied per round trip
+__global__ __launch_bounds__(64) void zs_inf_decode_lane_kernel(const ParStream *ps, const ParState *st, const uint2 *work, int nwork,
+                                                                const ParBlock *blocks, const LaneTabs *tabs, uint16_t *cells,
+                                                                int32_t *fail) {
+    __shared__ __attribute__((aligned(16))) uint16_t lit_s[kDecBlocks][1 << kInfLitBits];
+    const int grp = threadIdx.x >> 3, sub0 = threadIdx.x & 7;
+    const int wi = blockIdx.x * kDecBlocks + grp;
+    bool live = wi < nwork;
+    uint2 w = make_uint2(0, 0);
+    if (live) w = work[wi];
+    ParStream s = ps[w.x];
+    live = live && st[w.x].ok && (int)w.y < st[w.x].nblk;
+    ParBlock k = {0, 0, 0, -1, 0};
+    if (live) k = blocks[s.blk_off + w.y];
+    live = live && k.tab >= 0;
+    const LaneTabs *T = tabs + (live ? k.tab : 0);
+    if (live) {
+        const uint4 *src = (const uint4 *)T->lit;  // LaneTabs starts with the table: 16-byte aligned
+        uint4 *dst = (uint4 *)lit_s[grp];
+        for (int i = sub0; i < (1 << kInfLitBits) * 2 / 16; i += 8) dst[i] = src[i];
+    }
+    __syncthreads();
+    if (!live) return;
+    const uint16_t *lit = lit_s[grp];
+    uint16_t *o16 = cells + s.cell_off + k.out_off;
+    const int nsub = T->nsub;
+    bool bad = false;
+    for (int sub = sub0; sub < nsub && !bad; sub += 8) {
+        const int64_t bit0 = k.bit + T->ck_bit[sub];
+        const int64_t S = T->ck_out[sub], E = T->ck_out[sub + 1];
+        LaneBits b{(const __attribute__((address_space(1))) uint8_t *)(uintptr_t)s.in, s.in_len, bit0 >> 3, 0, 0, false};
+        b.fill();
+        b.drop((int)(bit0 & 7));
+        int64_t pos = S;
+        bool eob = false;
+        for (int ns = 0; ns < kCkSyms; ns++) {
+            b.fill();
+            int sym, clen;
+            {
+                const uint16_t e = lit[b.peek(kInfLitBits)];
+                if (e != kInfEsc) sym = e >> 4, clen = e & 15;
+                else sym = lane_slow(b, T->lcount, T->lsym, clen);
+            }
+            if (sym < 0 || clen > b.cnt) {
+                bad = true;
+                break;
+            }
+            b.drop(clen);
+            if (sym < 256) {
+                if (pos >= E) {
+                    bad = true;
+                    break;
+                }
+                o16[pos++] = (uint16_t)sym;
+                continue;
+            }
+            if (sym == 256) {
+                eob = true;
+                break;
+            }
+            sym -= 257;
+            if (sym >= 29) {
+                bad = true;
+                break;
+            }
+            const int mlen = (sym == 28 ? 258 : base_length(sym) + 3) + (int)b.take(extra_lbits(sym));
+            b.fill();
+            int ds, dl;
+            {
+                const uint16_t e = T->dist[b.peek(kInfDistBits)];
+                if (e != kInfEsc) ds = e >> 4, dl = e & 15;
+                else ds = lane_slow(b, T->dcount, T->dsym, dl);
+            }
+            if (ds < 0 || ds >= 30 || dl > b.cnt) {
+                bad = true;
+                break;
+            }
+            b.drop(dl);
+            const int dist = base_dist(ds) + 1 + (int)b.take(extra_dbits(ds));
+            const int64_t sp0 = pos - dist;  // block-relative source of the first byte
+            if (b.bad || pos + mlen > E || k.out_off + sp0 < 0) {
+                bad = true;
+                break;
+            }
+            // sources are older than this match (offset i mod dist); the lane's own cells are read back from L2 once its
+            // stores have landed, kDecCopy at a time (the wave goes round as often as its longest match needs)
+            if (sp0 + (dist < mlen ? dist : mlen) > S) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            int off = 0;
+            for (int i = 0; i < mlen; i += kDecCopy) {
+                uint16_t v[kDecCopy];
+#pragma unroll
+                for (int u = 0; u < kDecCopy; u++) {
+                    const int64_t sp = sp0 + off;
+                    v[u] = 0;
+                    if (i + u < mlen) {
+                        v[u] = sp >= S ? cell_load(o16 + sp)
+                                       : sp < 0 ? (uint16_t)(0x8000u | (uint32_t)(kWSize + sp)) : (uint16_t)(kSubMarkBase + (S - sp - 1));
+                        if (sp >= 0 && S - sp > kSubMarkMax) bad = true;  // further back inside the block than a cell can say
+                    }
+                    off = off + 1 == dist ? 0 : off + 1;
+                }
+#pragma unroll
+                for (int u = 0; u < kDecCopy; u++)
+                    if (i + u < mlen) o16[pos + i + u] = v[u];
+            }
+            pos += mlen;
+        }
+        // a sub-block ends where the next checkpoint says (the last one at END_BLOCK)
+        const bool last = sub + 1 == nsub;
+        if (bad || b.bad || pos != E || (last ? !eob : (eob || (uint32_t)(b.pos * 8 - b.cnt - k.bit) != T->ck_bit[sub + 1]))) bad = true;
+    }
+    if (bad) fail[w.x] = 1;
+}
+
+// Follow the sub-block markers of the lane decoder: every such cell becomes a byte or a block marker.  In place: a cell
+// read while another thread rewrites it holds either form, and both say the same thing.
+__global__ __launch_bounds__(256) void zs_inf_cellflat_kernel(const ParStream *ps, const ParState *st, const uint2 *work,
+                                                              const ParBlock *blocks, const LaneTabs *tabs, uint16_t *cells) {
+    __shared__ uint32_t ck[kCkMax + 1];
+    const uint2 w = work[blockIdx.x];
+    const ParStream s = ps[w.x];
+    if (!st[w.x].ok || (int)w.y >= st[w.x].nblk) return;
+    const ParBlock k = blocks[s.blk_off + w.y];
+    if (k.tab < 0) return;
+    const LaneTabs &T = tabs[k.tab];
+    const int nsub = T.nsub;
+    for (int i = threadIdx.x; i <= nsub; i += 256) ck[i] = T.ck_out[i];
+    __syncthreads();
+    uint16_t *cl = cells + s.cell_off + k.out_off;
+    auto sub_start = [&](uint32_t p) {  // start of the sub-block that holds block-relative position p
+        int lo = 0, hi = nsub - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (ck[mid] <= p) lo = mid;
+            else hi = mid - 1;
+        }
+        return ck[lo];
+    };
+    for (int64_t i = threadIdx.x; i < k.out_bytes; i += 256) {
+        uint16_t c = cl[i];
+        if (c < kSubMarkBase || c >= 0x8000) continue;
+        uint32_t p = (uint32_t)i;
+        do {
+            const uint32_t S = sub_start(p), d = (uint32_t)(c - kSubMarkBase + 1);
+            if (d > S) {  // not something the lane decoder writes: its stream has failed over already
+                c = 0;
+                break;
+            }
+            p = S - d;
+            c = cell_load(cl + p);
+        } while (c >= kSubMarkBase && c < 0x8000);
+        cl[i] = c;
+    }
 }
 
 // ------------------------------------------------------------------ W
