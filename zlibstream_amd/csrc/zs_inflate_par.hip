@@ -546,8 +546,11 @@ __global__ __launch_bounds__(64) void zs_inf_measure_kernel(const ParStream *ps,
 // size is checked again by the decode pass and the Adler-32.
 constexpr int kLaneLanes = 8;
 constexpr int kLaneLitLds = (1 << kInfLitBits) * kLaneLanes * 2;
-constexpr int kCkSyms = 2048;  // the lane measure pass leaves a checkpoint (bit position, output position) every so many symbols
-constexpr int kCkMax = 32;     // checkpoints kept per block (a zlib block has 16 Ki symbols: 8); longer blocks go to the wave decoder
+#ifndef ZS_CK_SYMS
+#define ZS_CK_SYMS 1024
+#endif
+constexpr int kCkSyms = ZS_CK_SYMS;  // the lane measure pass leaves a checkpoint (bit position, output position) every so many symbols
+constexpr int kCkMax = 64;           // checkpoints kept per block (a zlib block has 16 Ki symbols); longer blocks go to the wave decoder
 struct LaneTabs {
     uint16_t lit[1 << kInfLitBits];  // the literal/length primary table, kept for the sub-block decode pass
     uint32_t ck_bit[kCkMax + 1];     // checkpoint k: bit position relative to the block header, before symbol k * kCkSyms
@@ -851,7 +854,7 @@ __global__ __launch_bounds__(64) void zs_inf_decode_kernel(const ParStream *ps, 
 // The wave decoder spends ~130 instructions of a whole wave on every symbol, and a CU issues about one per cycle: the
 // pass is bound by instruction issue with 63 of 64 lanes doing nothing useful.  Here every lane decodes something of
 // its own: the measure pass left a checkpoint every kCkSyms symbols, so a block falls into sub-blocks that decode
-// independently -- eight blocks per workgroup, one lane per sub-block, the eight literal/length tables in LDS (copied
+// independently -- kDecBlocks blocks per workgroup, one lane per sub-block, their literal/length tables in LDS (copied
 // from the measure pass), the other tables in their HBM slab.
 // Cells: a byte; 0x8000 | i = byte i of the 32 KiB before the *block* (as the wave decoder writes them); and, new,
 // 0x100 + (d - 1) = the cell d positions before the start of this lane's *sub-block* (d <= 32512; a source further
@@ -859,13 +862,14 @@ __global__ __launch_bounds__(64) void zs_inf_decode_kernel(const ParStream *ps, 
 // markers stay markers; zs_inf_cellflat_kernel then follows the sub-block markers, so that the window and resolve
 // passes see the wave decoder's two kinds only.
 constexpr int kSubMarkBase = 0x100, kSubMarkMax = 0x8000 - kSubMarkBase;  // 32512 distances
-constexpr int kDecBlocks = 8;  // blocks per workgroup
+constexpr int kDecSubLanes = 16384 / kCkSyms;      // lanes per block: the sub-blocks of a zlib block
+constexpr int kDecBlocks = 64 / kDecSubLanes;      // blocks per workgroup
 constexpr int kDecCopy = 8;    // cells of a match copied per round trip
 __global__ __launch_bounds__(64) void zs_inf_decode_lane_kernel(const ParStream *ps, const ParState *st, const uint2 *work, int nwork,
                                                                 const ParBlock *blocks, const LaneTabs *tabs, uint16_t *cells,
                                                                 int32_t *fail) {
     __shared__ __attribute__((aligned(16))) uint16_t lit_s[kDecBlocks][1 << kInfLitBits];
-    const int grp = threadIdx.x >> 3, sub0 = threadIdx.x & 7;
+    const int grp = threadIdx.x / kDecSubLanes, sub0 = threadIdx.x % kDecSubLanes;
     const int wi = blockIdx.x * kDecBlocks + grp;
     bool live = wi < nwork;
     uint2 w = make_uint2(0, 0);
@@ -879,7 +883,7 @@ __global__ __launch_bounds__(64) void zs_inf_decode_lane_kernel(const ParStream 
     if (live) {
         const uint4 *src = (const uint4 *)T->lit;  // LaneTabs starts with the table: 16-byte aligned
         uint4 *dst = (uint4 *)lit_s[grp];
-        for (int i = sub0; i < (1 << kInfLitBits) * 2 / 16; i += 8) dst[i] = src[i];
+        for (int i = sub0; i < (1 << kInfLitBits) * 2 / 16; i += kDecSubLanes) dst[i] = src[i];
     }
     __syncthreads();
     if (!live) return;
@@ -887,7 +891,7 @@ __global__ __launch_bounds__(64) void zs_inf_decode_lane_kernel(const ParStream 
     uint16_t *o16 = cells + s.cell_off + k.out_off;
     const int nsub = T->nsub;
     bool bad = false;
-    for (int sub = sub0; sub < nsub && !bad; sub += 8) {
+    for (int sub = sub0; sub < nsub && !bad; sub += kDecSubLanes) {
         const int64_t bit0 = k.bit + T->ck_bit[sub];
         const int64_t S = T->ck_out[sub], E = T->ck_out[sub + 1];
         LaneBits b{(const __attribute__((address_space(1))) uint8_t *)(uintptr_t)s.in, s.in_len, bit0 >> 3, 0, 0, false};
