@@ -701,26 +701,28 @@ bool run_inflate_par(zs_ctx *c, const std::vector<int> &idx, const void *const *
     ZS_HIP(c, hipMemcpyAsync(st.data(), d_st, sizeof(ParState) * (size_t)m, hipMemcpyDeviceToHost, stream));
     ZS_HIP(c, hipStreamSynchronize(stream));
     std::vector<uint2> w;
+    bool wave_measure = false;
     for (int j = 0; j < m; j++)
         for (int k = 0; k < st[(size_t)j].ncand; k++) w.push_back(make_uint2((unsigned)j, (unsigned)k));
     if (!w.empty()) {
         ZS_HIP(c, hipMemcpyAsync(c->par_work.p, w.data(), sizeof(uint2) * w.size(), hipMemcpyHostToDevice, stream));
         ZS_HIP(c, hipStreamSynchronize(stream));
-        // one wave per candidate is the faster chain while all of them are resident at once (256 CUs x 24 workgroups of
-        // 6.6 KiB LDS); beyond that the waves queue up in rounds and the lane form, all candidates at once, wins
-        if (w.size() <= 6144) {
+        // one wave per candidate, its lanes on subsequences of the block (self-synchronising decode); ZS_INF_WAVE_MEASURE
+        // selects the plain wave decoder (one dependency chain per block) for comparison
+        if (getenv("ZS_INF_WAVE_MEASURE")) {
+            wave_measure = true;
             hipLaunchKernelGGL(zs_inf_measure_kernel, dim3((unsigned)w.size()), dim3(64), 0, stream, d_ps, d_st, dev<uint2>(c->par_work),
                                dev<ParCand>(c->par_cands));
         } else if (!ensure(c, c->par_tabs, sizeof(LaneTabs) * w.size())) {
             return false;
-        } else
-        hipLaunchKernelGGL(zs_inf_measure_lane_kernel, dim3((unsigned)((w.size() + kLaneLanes - 1) / kLaneLanes)), dim3(kLaneLanes),
-                           kLaneLitLds, stream, d_ps, d_st, dev<uint2>(c->par_work), (int)w.size(), dev<ParCand>(c->par_cands),
-                           dev<LaneTabs>(c->par_tabs));
+        } else {
+            hipLaunchKernelGGL(zs_inf_measure_sync_kernel, dim3((unsigned)w.size()), dim3(64), 0, stream, d_ps, d_st, dev<uint2>(c->par_work),
+                               dev<ParCand>(c->par_cands), dev<LaneTabs>(c->par_tabs));
+        }
     }
     mark(2);
-    // blocks measured by the lane kernel carry checkpoints: they are decoded by sub-blocks, one lane each
-    const bool lane_decode = w.size() > 6144 && !getenv("ZS_INF_WAVE_DECODE");
+    // measured blocks carry checkpoints: they are decoded by sub-blocks, one lane each
+    const bool lane_decode = !w.empty() && !wave_measure && !getenv("ZS_INF_WAVE_DECODE");
     hipLaunchKernelGGL(zs_inf_chain_kernel, dim3((unsigned)m), dim3(64), 0, stream, d_ps, d_st, dev<ParCand>(c->par_cands),
                        dev<ParBlock>(c->par_blocks), lane_decode ? 1 : 0);
     mark(3);

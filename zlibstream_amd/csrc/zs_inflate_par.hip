@@ -82,6 +82,82 @@ __device__ __forceinline__ uint16_t cell_load(const uint16_t *p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // L2-coherent read of the wave's own earlier stores
 }
 
+// dynamic block header after BTYPE (wave-uniform): HLIT / HDIST / HCLEN, the bit-length code, the code lengths and both
+// decode tables (InflateBlocks.cs:237-420, InfTree.cs:377-427).  Returns 0, or 1 for anything a conformant decoder rejects.
+__device__ int inf_dyn_tables(InfBits &b, InfTables &T, uint8_t *lens, uint8_t *ll) {
+    const int lane = threadIdx.x & 63;
+    b.fill();
+    if (b.cnt < 14) {
+        return 1;
+    }
+    const int nlen = (int)b.take(5) + 257, ndist = (int)b.take(5) + 1, ncode = (int)b.take(4) + 4;
+    if (nlen > 286 || ndist > 30) {
+        return 1;
+    }
+    for (int i = lane; i < 320; i += 64) lens[i] = 0;
+    __syncthreads();
+    for (int i = 0; i < ncode; i++) {
+        b.fill();
+        unsigned v = b.take(3);
+        if (lane == 0) lens[bl_order(i)] = (uint8_t)v;
+    }
+    __syncthreads();
+    if (b.bad || inf_build(lens, 19, T.lit, 7, T.lcount, T.lsym) != 0) {
+        return 1;
+    }
+    __syncthreads();
+    uint8_t prev = 0;
+    int idx = 0;
+    while (idx < nlen + ndist) {
+        b.fill();
+        uint16_t e = T.lit[b.peek(7)];
+        if (b.bad || e == kInfEsc || (int)(e & 15) > b.cnt) {
+            return 1;
+        }
+        b.drop(e & 15);
+        int sym = e >> 4;
+        if (sym < 16) {
+            if (lane == 0) ll[idx] = (uint8_t)sym;
+            prev = (uint8_t)sym;
+            idx++;
+        } else {
+            int rep;
+            uint8_t val = 0;
+            if (sym == 16) {
+                if (idx == 0) {
+                    return 1;
+                }
+                val = prev;
+                rep = 3 + (int)b.take(2);
+            } else if (sym == 17) {
+                rep = 3 + (int)b.take(3);
+            } else {
+                rep = 11 + (int)b.take(7);
+            }
+            if (idx + rep > nlen + ndist) {
+                return 1;
+            }
+            if (lane < rep) ll[idx + lane] = val;
+            if (lane + 64 < rep) ll[idx + lane + 64] = val;
+            if (lane + 128 < rep) ll[idx + lane + 128] = val;
+            prev = val;
+            idx += rep;
+        }
+    }
+    __syncthreads();
+    for (int i = lane; i < 320; i += 64) lens[i] = i < nlen + ndist ? ll[i] : 0;
+    __syncthreads();
+    int q = inf_build(lens, nlen, T.lit, kInfLitBits, T.lcount, T.lsym);
+    if (q < 0 || (q > 0 && nlen - T.lcount[0] != 1) || lens[256] == 0) {
+        return 1;
+    }
+    q = inf_build(lens + nlen, ndist, T.dist, kInfDistBits, T.dcount, T.dsym);
+    if (q < 0 || (q > 0 && ndist - T.dcount[0] > 1)) {
+        return 1;
+    }
+    return 0;
+}
+
 constexpr int kParMaxSyms = 1 << 20;  // no encoder emits blocks this long; bounds the work a false candidate can cause
 
 // abs_off: output position of the block's first byte in the stream (a match may not reach before 0)
@@ -129,84 +205,9 @@ __device__ BlockOut inf_block(InfBits &b, InfTables &T, uint8_t *lens, uint8_t *
         for (int i = lane; i < 32; i += 64) lens[i] = 5;
         __syncthreads();
         inf_build(lens, 30, T.dist, kInfDistBits, T.dcount, T.dsym);
-    } else {
-        b.fill();
-        if (b.cnt < 14) {
-            r.err = 1;
-            return r;
-        }
-        const int nlen = (int)b.take(5) + 257, ndist = (int)b.take(5) + 1, ncode = (int)b.take(4) + 4;
-        if (nlen > 286 || ndist > 30) {
-            r.err = 1;
-            return r;
-        }
-        for (int i = lane; i < 320; i += 64) lens[i] = 0;
-        __syncthreads();
-        for (int i = 0; i < ncode; i++) {
-            b.fill();
-            unsigned v = b.take(3);
-            if (lane == 0) lens[bl_order(i)] = (uint8_t)v;
-        }
-        __syncthreads();
-        if (b.bad || inf_build(lens, 19, T.lit, 7, T.lcount, T.lsym) != 0) {
-            r.err = 1;
-            return r;
-        }
-        __syncthreads();
-        uint8_t prev = 0;
-        int idx = 0;
-        while (idx < nlen + ndist) {
-            b.fill();
-            uint16_t e = T.lit[b.peek(7)];
-            if (b.bad || e == kInfEsc || (int)(e & 15) > b.cnt) {
-                r.err = 1;
-                return r;
-            }
-            b.drop(e & 15);
-            int sym = e >> 4;
-            if (sym < 16) {
-                if (lane == 0) ll[idx] = (uint8_t)sym;
-                prev = (uint8_t)sym;
-                idx++;
-            } else {
-                int rep;
-                uint8_t val = 0;
-                if (sym == 16) {
-                    if (idx == 0) {
-                        r.err = 1;
-                        return r;
-                    }
-                    val = prev;
-                    rep = 3 + (int)b.take(2);
-                } else if (sym == 17) {
-                    rep = 3 + (int)b.take(3);
-                } else {
-                    rep = 11 + (int)b.take(7);
-                }
-                if (idx + rep > nlen + ndist) {
-                    r.err = 1;
-                    return r;
-                }
-                if (lane < rep) ll[idx + lane] = val;
-                if (lane + 64 < rep) ll[idx + lane + 64] = val;
-                if (lane + 128 < rep) ll[idx + lane + 128] = val;
-                prev = val;
-                idx += rep;
-            }
-        }
-        __syncthreads();
-        for (int i = lane; i < 320; i += 64) lens[i] = i < nlen + ndist ? ll[i] : 0;
-        __syncthreads();
-        int q = inf_build(lens, nlen, T.lit, kInfLitBits, T.lcount, T.lsym);
-        if (q < 0 || (q > 0 && nlen - T.lcount[0] != 1) || lens[256] == 0) {
-            r.err = 1;
-            return r;
-        }
-        q = inf_build(lens + nlen, ndist, T.dist, kInfDistBits, T.dcount, T.dsym);
-        if (q < 0 || (q > 0 && ndist - T.dcount[0] > 1)) {
-            r.err = 1;
-            return r;
-        }
+    } else if (inf_dyn_tables(b, T, lens, ll)) {
+        r.err = 1;
+        return r;
     }
     __syncthreads();
     for (int nsym = 0;; nsym++) {
@@ -535,34 +536,36 @@ __global__ __launch_bounds__(64) void zs_inf_measure_kernel(const ParStream *ps,
     }
 }
 
-// ------------------------------------------------------------------ D1, lane form
-// Measuring a candidate is a decode without output, and a block's decode is one dependency chain (~2 us per symbol here):
-// the pass lasts as long as the longest block however many waves work on it.  One wave per candidate executes that chain
-// with 63 lanes idle and, at 20 000+ candidates, in several rounds; here every lane takes a candidate of its own, a few
-// lanes per workgroup so that every candidate of the batch is resident at once.  The literal/length table (one lookup
-// per symbol) is a lane-private column in LDS, the rest of the tables a private slab of HBM (they stay in L2), the bit
-// buffer is filled straight from the input.  Only dynamic blocks come out of the finder, so this is the dynamic-block
-// path alone; whatever it does not accept (ok = 0) the chain kernel measures with the wave decoder, and every accepted
-// size is checked again by the decode pass and the Adler-32.
-constexpr int kLaneLanes = 8;
-constexpr int kLaneLitLds = (1 << kInfLitBits) * kLaneLanes * 2;
-#ifndef ZS_CK_SYMS
-#define ZS_CK_SYMS 1024
+// ------------------------------------------------------------------ D1, self-synchronising form
+// Measuring a candidate is a decode without output, and a block's decode is one dependency chain of ~16 Ki symbols.  A
+// Huffman bit stream decoded from a wrong bit offset falls into step with the true symbol boundaries after a few dozen
+// symbols, so the chain can be cut: the block's bits are divided into 64 subsequences of S bits (S from the distance to
+// the next candidate), lane j decodes subsequence j from its nominal first bit until it crosses into subsequence j + 1
+// and reports the symbol boundary it arrived at (its exit).  Lane 0 starts at the true first symbol; every other lane
+// whose entry differs from its predecessor's exit decodes again from that exit, all of them at once, until the chain of
+// exits = entries is unbroken from lane 0 on -- each pass extends the proven prefix by at least one lane, so the result
+// is that of the sequential decode however badly a subsequence synchronises (typically two or three passes in all).
+// One wave per candidate, the block's tables in LDS shared by its lanes.  The entry of every subsequence (bit position,
+// output position) is a checkpoint for the decode pass, which decodes the subsequences independently the same way.
+// Only dynamic blocks come out of the finder; whatever this kernel does not accept (ok = 0) the chain kernel measures
+// with the wave decoder, and every accepted size is checked again by the decode pass and the Adler-32.
+#ifndef ZS_SUB_MIN
+#define ZS_SUB_MIN 1024
 #endif
-constexpr int kCkSyms = ZS_CK_SYMS;  // the lane measure pass leaves a checkpoint (bit position, output position) every so many symbols
-constexpr int kCkMax = 64;           // checkpoints kept per block (a zlib block has 16 Ki symbols); longer blocks go to the wave decoder
+constexpr int kSubMinBits = ZS_SUB_MIN, kSubMaxBits = 16384;  // subsequence length: a multiple of 64 bits in this range
+constexpr int kCkMax = 256;  // checkpoints kept per block; a block with more subsequences goes to the wave decoder
 struct LaneTabs {
-    uint16_t lit[1 << kInfLitBits];  // the literal/length primary table, kept for the sub-block decode pass
-    uint32_t ck_bit[kCkMax + 1];     // checkpoint k: bit position relative to the block header, before symbol k * kCkSyms
-    uint32_t ck_out[kCkMax + 1];     //               block-relative output position; entry nsub = the block's end
-    int32_t nsub, pad_;
+    // the block's decode tables exactly as InfTables lays them out (copied with 16-byte stores), kept for the decode pass
+    uint16_t lit[1 << kInfLitBits];
     uint16_t dist[1 << kInfDistBits];
     uint16_t lcount[16], dcount[16];
     uint16_t lsym[288], dsym[32];
-    uint8_t lens[384];  // [0, 19): bit-length code lengths; [32, 32 + nlen + ndist): literal/length and distance code lengths
-    uint8_t blt[128];   // bit-length code: sym << 3 | len, 0 = invalid
+    int32_t nsub, pad_;
+    uint32_t ck_bit[kCkMax + 1];  // checkpoint k: bit position relative to the block header, at the first symbol of subsequence k
+    uint32_t ck_out[kCkMax + 1];  //               block-relative output position; entry nsub = the block's end
 };
-static_assert(sizeof(LaneTabs) % 16 == 0, "the table at the head of every LaneTabs is copied with 16-byte loads");
+static_assert(sizeof(InfTables) % 16 == 0 && sizeof(LaneTabs) % 16 == 0 && offsetof(LaneTabs, nsub) == sizeof(InfTables),
+              "LaneTabs begins with an InfTables image copied with 16-byte stores");
 struct LaneBits {
     const __attribute__((address_space(1))) uint8_t *in;  // the stream's input (global memory: no flat loads)
     int64_t n, pos;
@@ -584,6 +587,12 @@ struct LaneBits {
             }
         }
     }
+    __device__ void seek(int64_t bit) {
+        pos = bit >> 3, buf = 0, cnt = 0, bad = false;
+        fill();
+        drop((int)(bit & 7));
+    }
+    __device__ int64_t tell() const { return pos * 8 - cnt; }
     __device__ uint32_t peek(int k) const { return (uint32_t)(buf & ((1ull << k) - 1)); }
     __device__ void drop(int k) {
         if (k > cnt) bad = true, k = cnt;
@@ -596,37 +605,6 @@ struct LaneBits {
         return v;
     }
 };
-// canonical tables from code lengths, one lane on its own (inf_build's result).  `primary` is indexed with stride `ps`
-// (1: a private array; kLaneLanes: the lane's column of the workgroup's table in LDS)
-__device__ int lane_build(const uint8_t *lens, int n, uint16_t *primary, int ps, int pbits, uint16_t *count, uint16_t *symtab) {
-    uint16_t offs[16];
-    for (int i = 0; i < 16; i++) count[i] = 0;
-    for (int i = 0; i < n; i++) count[lens[i]]++;
-    int left = 1;
-    for (int len = 1; len <= 15; len++) {
-        left <<= 1;
-        left -= count[len];
-        if (left < 0) return left;
-    }
-    offs[1] = 0;
-    for (int len = 1; len < 15; len++) offs[len + 1] = (uint16_t)(offs[len] + count[len]);
-    for (int i = 0; i < n; i++)
-        if (lens[i]) symtab[offs[lens[i]]++] = (uint16_t)i;
-    for (int i = 0; i < (1 << pbits); i++) primary[i * ps] = kInfEsc;
-    unsigned code = 0;
-    int index = 0;
-    for (int len = 1; len <= pbits; len++) {
-        for (int k = 0; k < count[len]; k++) {
-            const unsigned rev = __brev(code) >> (32 - len);
-            const uint16_t e = (uint16_t)((symtab[index] << 4) | len);
-            for (unsigned r = rev; r < (1u << pbits); r += 1u << len) primary[r * ps] = e;
-            code++;
-            index++;
-        }
-        code <<= 1;
-    }
-    return left;
-}
 __device__ int lane_slow(const LaneBits &b, const uint16_t *count, const uint16_t *symtab, int &len_out) {
     int code = 0, first = 0, index = 0;
     uint64_t bits = b.buf;
@@ -646,115 +624,39 @@ __device__ int lane_slow(const LaneBits &b, const uint16_t *count, const uint16_
     len_out = 0;
     return -1;
 }
-__global__ __launch_bounds__(kLaneLanes) void zs_inf_measure_lane_kernel(const ParStream *ps, const ParState *st, const uint2 *work,
-                                                                         int nwork, ParCand *cands, LaneTabs *tabs) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    uint16_t *lit = (uint16_t *)smem + threadIdx.x;  // this lane's column: entry e at lit[e * kLaneLanes]
-    const int gi = blockIdx.x * kLaneLanes + threadIdx.x;
-    if (gi >= nwork) return;
-    const uint2 w = work[gi];
-    const ParStream s = ps[w.x];
-    if ((int)w.y >= st[w.x].ncand) return;
-    ParCand &c = cands[s.cand_off + w.y];
-    LaneTabs &T = tabs[gi];
-    c.ok = 0;
-    LaneBits b{(const __attribute__((address_space(1))) uint8_t *)(uintptr_t)s.in, s.in_len, c.bit >> 3, 0, 0, false};
-    b.fill();
-    b.drop((int)(c.bit & 7));
-    b.fill();
-    if (b.cnt < 17) return;
-    const int bfinal = (int)b.take(1);
-    if (b.take(2) != 2) return;
-    const int nlen = (int)b.take(5) + 257, ndist = (int)b.take(5) + 1, ncode = (int)b.take(4) + 4;
-    if (nlen > 286 || ndist > 30) return;
-    for (int i = 0; i < 19; i++) T.lens[i] = 0;
-    for (int i = 0; i < ncode; i++) {
-        b.fill();
-        T.lens[bl_order(i)] = (uint8_t)b.take(3);
-    }
-    if (b.bad) return;
-    {
-        // the bit-length code must be complete (the finder checked this offset already; this is the decoder's own check)
-        uint16_t cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (int i = 0; i < 19; i++) cnt[T.lens[i]]++;
-        int left = 1;
-        for (int len = 1; len <= 7; len++) {
-            left <<= 1;
-            left -= cnt[len];
-        }
-        if (left != 0) return;
-        for (int i = 0; i < 128; i++) T.blt[i] = 0;
-        unsigned code = 0;
-        for (int len = 1; len <= 7; len++) {
-            for (int sy = 0; sy < 19; sy++)
-                if (T.lens[sy] == len) {
-                    const unsigned rev = __brev(code) >> (32 - len);
-                    for (unsigned r = rev; r < 128; r += 1u << len) T.blt[r] = (uint8_t)((sy << 3) | len);
-                    code++;
-                }
-            code <<= 1;
-        }
-    }
-    uint8_t *ll = T.lens + 32;
-    int idx = 0;
-    uint8_t prev = 0;
-    while (idx < nlen + ndist) {
-        b.fill();
-        const uint8_t e = T.blt[b.peek(7)];
-        if (b.bad || e == 0 || (int)(e & 7) > b.cnt) return;
-        b.drop(e & 7);
-        const int sym = e >> 3;
-        if (sym < 16) {
-            ll[idx++] = (uint8_t)sym;
-            prev = (uint8_t)sym;
-        } else {
-            int rep;
-            uint8_t val = 0;
-            if (sym == 16) {
-                if (idx == 0) return;
-                val = prev;
-                rep = 3 + (int)b.take(2);
-            } else if (sym == 17) {
-                rep = 3 + (int)b.take(3);
-            } else {
-                rep = 11 + (int)b.take(7);
-            }
-            if (idx + rep > nlen + ndist) return;
-            for (int k = 0; k < rep; k++) ll[idx + k] = val;
-            prev = val;
-            idx += rep;
-        }
-    }
-    if (b.bad || ll[256] == 0) return;
-    int q = lane_build(ll, nlen, lit, kLaneLanes, kInfLitBits, T.lcount, T.lsym);
-    if (q < 0 || (q > 0 && nlen - T.lcount[0] != 1)) return;
-    q = lane_build(ll + nlen, ndist, T.dist, 1, kInfDistBits, T.dcount, T.dsym);
-    if (q < 0 || (q > 0 && ndist - T.dcount[0] > 1)) return;
-    int64_t pos = 0;
-    T.nsub = 0;
-    int nsym = 0;
-    for (;; nsym++) {
-        if (b.bad || nsym > kParMaxSyms) return;
-        if ((nsym & (kCkSyms - 1)) == 0 && nsym / kCkSyms < kCkMax) {
-            T.ck_bit[nsym / kCkSyms] = (uint32_t)(b.pos * 8 - b.cnt - c.bit);
-            T.ck_out[nsym / kCkSyms] = (uint32_t)pos;
-        }
+// One lane decodes (without output) from bit `entry` to the first symbol boundary at or after `gend`, or to END_BLOCK.
+// flags: 0 = crossed gend, 1 = END_BLOCK (exit_bit is the bit after it), 2 = not decodable from here.
+__device__ __forceinline__ void sub_measure(const __attribute__((address_space(1))) uint8_t *in, int64_t n, const InfTables &T, int64_t entry,
+                                            int64_t gend, int64_t &exit_bit, int &nout, int &nsym, int &flags) {
+    LaneBits b{in, n, 0, 0, 0, false};
+    b.seek(entry);
+    int out = 0, ns = 0, fl = 0;
+    int64_t cur = entry;
+    while (cur < gend) {
         b.fill();
         int sym, clen;
         {
-            const uint16_t e = lit[b.peek(kInfLitBits) * kLaneLanes];
+            const uint16_t e = T.lit[b.peek(kInfLitBits)];
             if (e != kInfEsc) sym = e >> 4, clen = e & 15;
             else sym = lane_slow(b, T.lcount, T.lsym, clen);
         }
-        if (sym < 0 || clen > b.cnt) return;
+        if (sym < 0 || clen > b.cnt) {
+            fl = 2;
+            break;
+        }
         b.drop(clen);
         if (sym < 256) {
-            pos++;
+            out++;
         } else if (sym == 256) {
+            fl = 1;
+            cur = b.tell();
             break;
         } else {
             sym -= 257;
-            if (sym >= 29) return;
+            if (sym >= 29) {
+                fl = 2;
+                break;
+            }
             const int mlen = (sym == 28 ? 258 : base_length(sym) + 3) + (int)b.take(extra_lbits(sym));
             b.fill();
             int ds, dl;
@@ -763,25 +665,139 @@ __global__ __launch_bounds__(kLaneLanes) void zs_inf_measure_lane_kernel(const P
                 if (e != kInfEsc) ds = e >> 4, dl = e & 15;
                 else ds = lane_slow(b, T.dcount, T.dsym, dl);
             }
-            if (ds < 0 || ds >= 30 || dl > b.cnt) return;
+            if (ds < 0 || ds >= 30 || dl > b.cnt) {
+                fl = 2;
+                break;
+            }
             b.drop(dl);
             (void)b.take(extra_dbits(ds));
-            pos += mlen;
+            out += mlen;
+        }
+        if (b.bad) {
+            fl = 2;
+            break;
+        }
+        ns++;
+        cur = b.tell();
+    }
+    exit_bit = cur, nout = out, nsym = ns, flags = fl;
+}
+__global__ __launch_bounds__(64) void zs_inf_measure_sync_kernel(const ParStream *ps, const ParState *st, const uint2 *work, ParCand *cands,
+                                                                 LaneTabs *tabs) {
+    __shared__ __attribute__((aligned(16))) ParLds L;
+    const uint2 w = work[blockIdx.x];
+    const ParStream s = ps[w.x];
+    const int ncand = st[w.x].ncand;
+    if ((int)w.y >= ncand) return;
+    ParCand &c = cands[s.cand_off + w.y];
+    const int lane = threadIdx.x;
+    const int64_t cbit = c.bit, nbits = s.in_len * 8;
+    // the block most likely ends where the next candidate begins (candidate bits are final since the flatten pass)
+    const int64_t hint = (int)w.y + 1 < ncand ? cands[s.cand_off + w.y + 1].bit : nbits;
+    InfBits hb{s.in, s.in_len, 0, 0, 0, false, L.ibuf, -1};
+    inf_seek(hb, cbit);
+    hb.fill();
+    int bfinal = 0;
+    bool ok = hb.cnt >= 3;
+    if (ok) {
+        bfinal = (int)hb.take(1);
+        ok = hb.take(2) == 2;
+    }
+    ok = ok && inf_dyn_tables(hb, L.T, L.lens, L.ll) == 0;
+    __syncthreads();
+    if (!ok) {
+        if (lane == 0) c.ok = 0;
+        return;
+    }
+    const int64_t b0 = inf_tell(hb);  // first symbol of the block
+    int S = kSubMinBits;
+    if (hint > b0) {
+        const int64_t per = ((hint - b0 + 63) / 64 + 63) & ~(int64_t)63;
+        S = per < kSubMinBits ? kSubMinBits : per > kSubMaxBits ? kSubMaxBits : (int)per;
+    }
+    const __attribute__((address_space(1))) uint8_t *gin = (const __attribute__((address_space(1))) uint8_t *)(uintptr_t)s.in;
+    LaneTabs &T = tabs[blockIdx.x];
+    int64_t entry0 = b0, out_base = 0, total_syms = 0, end_bit = 0;
+    int nck = 0, result = 0;  // result: 1 = END_BLOCK reached on the proven chain, 2 = not decodable
+    bool store = true, hint_ok = true;
+    for (int round = 0; result == 0; round++) {
+        const int64_t g = b0 + ((int64_t)round * 64 + lane) * S, gend = g + S;
+        int64_t entry = lane == 0 ? entry0 : g, exit_bit = -1;
+        int nout = 0, nsym = 0, flags = 0, nvalid = 0, lf = 0;
+        bool spec = false;  // this lane has decoded its subsequence (from `entry`)
+        bool run = lane == 0 || (g < nbits && (g < hint || !hint_ok));
+        for (;;) {
+            if (run) {
+                sub_measure(gin, s.in_len, L.T, entry, gend, exit_bit, nout, nsym, flags);
+                spec = true;
+            }
+            const int64_t pe = __shfl_up(exit_bit, 1);
+            const int pf = __shfl_up(flags, 1);
+            const bool pspec = __shfl_up((int)spec, 1) != 0;
+            const bool link = lane == 0 || (pspec && pf == 0 && spec && entry == pe);
+            const uint64_t m = __ballot(link);
+            nvalid = m == ~0ull ? 64 : (int)__builtin_ctzll(~m);  // lanes [0, nvalid) are proven
+            lf = __shfl(flags, nvalid - 1);
+            if (nvalid == 64 || lf != 0) break;
+            // lane nvalid decodes from a proven exit; the lanes behind it whose entry no longer fits their predecessor's exit
+            // go again too (their predecessor's exit is usually right already: that is the self-synchronisation)
+            run = lane >= nvalid && pspec && pf == 0 && (!spec || entry != pe);
+            if (run) entry = pe;
+            // the chain has walked past the hint: it was not the block's end, so everyone behind speculates as well
+            if (__shfl((int)spec, nvalid) == 0) hint_ok = false;
+            if (!hint_ok && !spec && !run && lane > nvalid && g < nbits) run = true;
+        }
+        // checkpoints of the proven lanes
+        const bool valid = lane < nvalid;
+        int incl = valid ? nout : 0;
+        for (int d = 1; d < 64; d <<= 1) {
+            const int t = __shfl_up(incl, d);
+            if (lane >= d) incl += t;
+        }
+        int sy = valid ? nsym : 0;
+        for (int d = 32; d; d >>= 1) sy += __shfl_xor(sy, d);
+        if (store && nck + nvalid <= kCkMax) {
+            if (valid) {
+                T.ck_bit[nck + lane] = (uint32_t)(entry - cbit);
+                T.ck_out[nck + lane] = (uint32_t)(out_base + incl - nout);
+            }
+        } else {
+            store = false;
+        }
+        nck += nvalid;
+        out_base += __shfl(incl, 63);
+        total_syms += sy;
+        if (lf == 1) {
+            end_bit = __shfl(exit_bit, nvalid - 1);
+            result = 1;
+        } else if (lf == 2 || total_syms > kParMaxSyms || out_base >= ((int64_t)1 << 31)) {
+            result = 2;
+        } else {
+            entry0 = __shfl(exit_bit, 63);
+            if (entry0 - cbit >= ((int64_t)1 << 32)) result = 2;
         }
     }
-    if (b.bad) return;
-    c.end_bit = b.pos * 8 - b.cnt;
-    c.out_bytes = pos;
-    c.bfinal = bfinal;
-    c.ok = 1;
-    // sub-blocks for the decode pass: nsym symbols before END_BLOCK, one checkpoint per kCkSyms of them
-    const int nsub = nsym / kCkSyms + 1;
-    if (nsub <= kCkMax && pos < ((int64_t)1 << 31)) {
-        T.ck_out[nsub] = (uint32_t)pos;
-        T.ck_bit[nsub] = (uint32_t)(c.end_bit - c.bit);
-        T.nsub = nsub;
-        for (int i = 0; i < (1 << kInfLitBits); i++) T.lit[i] = lit[i * kLaneLanes];
-        c.tab = gi;
+    if (result != 1) {
+        if (lane == 0) c.ok = 0;
+        return;
+    }
+    if (store && end_bit - cbit < ((int64_t)1 << 32)) {
+        // the decode pass takes the block by subsequences: tables and checkpoints
+        const uint4 *src = (const uint4 *)&L.T;
+        uint4 *dst = (uint4 *)&T;
+        for (int i = lane; i < (int)(sizeof(InfTables) / 16); i += 64) dst[i] = src[i];
+        if (lane == 0) {
+            T.ck_bit[nck] = (uint32_t)(end_bit - cbit);
+            T.ck_out[nck] = (uint32_t)out_base;
+            T.nsub = nck;
+            c.tab = (int32_t)blockIdx.x;
+        }
+    }
+    if (lane == 0) {
+        c.end_bit = end_bit;
+        c.out_bytes = out_base;
+        c.bfinal = bfinal;
+        c.ok = 1;
     }
 }
 
@@ -853,16 +869,19 @@ __global__ __launch_bounds__(64) void zs_inf_decode_kernel(const ParStream *ps, 
 // ------------------------------------------------------------------ D2, lane form
 // The wave decoder spends ~130 instructions of a whole wave on every symbol, and a CU issues about one per cycle: the
 // pass is bound by instruction issue with 63 of 64 lanes doing nothing useful.  Here every lane decodes something of
-// its own: the measure pass left a checkpoint every kCkSyms symbols, so a block falls into sub-blocks that decode
-// independently -- kDecBlocks blocks per workgroup, one lane per sub-block, their literal/length tables in LDS (copied
-// from the measure pass), the other tables in their HBM slab.
+// its own: the measure pass left a checkpoint at the first symbol of every subsequence, so a block falls into
+// sub-blocks that decode independently -- kDecBlocks blocks per workgroup, kDecSubLanes lanes per block taking its
+// sub-blocks in turn, the literal/length tables in LDS (copied from the measure pass), the other tables in their HBM slab.
 // Cells: a byte; 0x8000 | i = byte i of the 32 KiB before the *block* (as the wave decoder writes them); and, new,
 // 0x100 + (d - 1) = the cell d positions before the start of this lane's *sub-block* (d <= 32512; a source further
 // back inside the block fails the stream over to the sequential decoder -- zlib's MAX_DIST is 32506).  Copies of
 // markers stay markers; zs_inf_cellflat_kernel then follows the sub-block markers, so that the window and resolve
 // passes see the wave decoder's two kinds only.
 constexpr int kSubMarkBase = 0x100, kSubMarkMax = 0x8000 - kSubMarkBase;  // 32512 distances
-constexpr int kDecSubLanes = 16384 / kCkSyms;      // lanes per block: the sub-blocks of a zlib block
+#ifndef ZS_DEC_SUBLANES
+#define ZS_DEC_SUBLANES 16
+#endif
+constexpr int kDecSubLanes = ZS_DEC_SUBLANES;      // lanes per block
 constexpr int kDecBlocks = 64 / kDecSubLanes;      // blocks per workgroup
 constexpr int kDecCopy = 8;    // cells of a match copied per round trip
 __global__ __launch_bounds__(64) void zs_inf_decode_lane_kernel(const ParStream *ps, const ParState *st, const uint2 *work, int nwork,
@@ -894,12 +913,12 @@ __global__ __launch_bounds__(64) void zs_inf_decode_lane_kernel(const ParStream 
     for (int sub = sub0; sub < nsub && !bad; sub += kDecSubLanes) {
         const int64_t bit0 = k.bit + T->ck_bit[sub];
         const int64_t S = T->ck_out[sub], E = T->ck_out[sub + 1];
-        LaneBits b{(const __attribute__((address_space(1))) uint8_t *)(uintptr_t)s.in, s.in_len, bit0 >> 3, 0, 0, false};
-        b.fill();
-        b.drop((int)(bit0 & 7));
+        const int64_t bit1 = k.bit + T->ck_bit[sub + 1];  // the next sub-block's first symbol, or the bit after END_BLOCK
+        LaneBits b{(const __attribute__((address_space(1))) uint8_t *)(uintptr_t)s.in, s.in_len, 0, 0, 0, false};
+        b.seek(bit0);
         int64_t pos = S;
         bool eob = false;
-        for (int ns = 0; ns < kCkSyms; ns++) {
+        while (b.tell() < bit1) {
             b.fill();
             int sym, clen;
             {
@@ -973,7 +992,7 @@ __global__ __launch_bounds__(64) void zs_inf_decode_lane_kernel(const ParStream 
         }
         // a sub-block ends where the next checkpoint says (the last one at END_BLOCK)
         const bool last = sub + 1 == nsub;
-        if (bad || b.bad || pos != E || (last ? !eob : (eob || (uint32_t)(b.pos * 8 - b.cnt - k.bit) != T->ck_bit[sub + 1]))) bad = true;
+        if (bad || b.bad || pos != E || eob != last || b.tell() != bit1) bad = true;
     }
     if (bad) fail[w.x] = 1;
 }
