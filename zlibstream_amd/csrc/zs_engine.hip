@@ -467,6 +467,7 @@ int zs_ctx_create(int device, zs_ctx **out) {
         hipFuncSetAttribute((const void *)zs_links_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLkLds) != hipSuccess ||
         hipFuncSetAttribute((const void *)zs_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kTailLds) != hipSuccess ||
         hipFuncSetAttribute((const void *)zs_fast_run_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kTailLds) != hipSuccess ||
+        hipFuncSetAttribute((const void *)zs_inf_window_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kWinLds) != hipSuccess ||
         hipFuncSetAttribute((const void *)zs_inflate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kInfLds) != hipSuccess) {
         zs_ctx_destroy(c);
         return ZS_MEM_ERROR;
@@ -695,7 +696,7 @@ bool run_inflate_par(zs_ctx *c, const std::vector<int> &idx, const void *const *
                        dev<int32_t>(c->par_surv), dev<int32_t>(c->par_scnt));
     hipLaunchKernelGGL(zs_inf_check_kernel, dim3((unsigned)w_find.size()), dim3(64), 0, stream, d_ps, dev<uint2>(c->par_work),
                        dev<int32_t>(c->par_surv), dev<int32_t>(c->par_scnt), dev<int64_t>(c->par_cbits), dev<int32_t>(c->par_ccnt));
-    hipLaunchKernelGGL(zs_inf_flatten_kernel, dim3((unsigned)((m + 63) / 64)), dim3(64), 0, stream, d_ps, d_st, dev<int64_t>(c->par_cbits),
+    hipLaunchKernelGGL(zs_inf_flatten_kernel, dim3((unsigned)m), dim3(256), 0, stream, d_ps, d_st, dev<int64_t>(c->par_cbits),
                        dev<int32_t>(c->par_ccnt), dev<ParCand>(c->par_cands), m);
     mark(1);
     ZS_HIP(c, hipMemcpyAsync(st.data(), d_st, sizeof(ParState) * (size_t)m, hipMemcpyDeviceToHost, stream));
@@ -750,7 +751,7 @@ bool run_inflate_par(zs_ctx *c, const std::vector<int> &idx, const void *const *
             hipLaunchKernelGGL(zs_inf_cellflat_kernel, dim3((unsigned)w.size()), dim3(256), 0, stream, d_ps, d_st, dev<uint2>(c->par_work),
                                dev<ParBlock>(c->par_blocks), dev<LaneTabs>(c->par_tabs), dev<uint16_t>(c->par_cells));
         mark(4);
-        hipLaunchKernelGGL(zs_inf_window_kernel, dim3((unsigned)m), dim3(1024), 0, stream, d_ps, d_st, dev<ParBlock>(c->par_blocks),
+        hipLaunchKernelGGL(zs_inf_window_kernel, dim3((unsigned)m), dim3(1024), kWinLds, stream, d_ps, d_st, dev<ParBlock>(c->par_blocks),
                            dev<uint16_t>(c->par_cells), dev<uint8_t>(c->par_windows));
         mark(5);
         hipLaunchKernelGGL(zs_inf_resolve_kernel, dim3((unsigned)w.size()), dim3(256), 0, stream, d_ps, d_st, dev<uint2>(c->par_work),

@@ -414,34 +414,39 @@ __global__ __launch_bounds__(256) void zs_inf_prefilter_kernel(const ParStream *
 #pragma unroll
     for (int j = 0; j < 4; j++) {  // compile-time word index: bw[] stays in registers
         const uint32_t c0 = bw[j], c1 = bw[j + 1], c2 = bw[j + 2], c3 = bw[j + 3];
-        for (int r = 0; r < 32; r++) {
-            const int64_t bit = byte0 * 8 + j * 32 + r;
-            if (bit < 16 || bit + 17 > s.in_len * 8) continue;
+        // First test, the word's 32 bit offsets at once (bit r of sh(k) is stream bit r + k): BTYPE == 2 is bit 1 clear and
+        // bit 2 set; HLIT > 29 is bits 4..7 all set, HDIST > 29 bits 9..12.  About a fifth of all offsets pass.
+        auto sh = [&](int k) { return __builtin_amdgcn_alignbit(c1, c0, k); };
+        uint32_t m = ~sh(1) & sh(2);
+        m &= ~(sh(4) & sh(5) & sh(6) & sh(7));
+        m &= ~(sh(9) & sh(10) & sh(11) & sh(12));
+        const int64_t base = byte0 * 8 + j * 32;
+        if (base < 16) m &= ~((1u << (16 - base)) - 1u);         // the zlib header is no block
+        const int64_t last = s.in_len * 8 - 17 - base;            // last offset with 17 header bits inside the stream
+        if (last < 31) m = last < 0 ? 0u : m & ((2u << last) - 1u);
+        // Second test, one passing offset per trip (a wave goes round as often as its fullest lane needs): the bit-length code
+        // -- (HCLEN + 4) 3-bit fields from bit 17 -- must be complete (Kraft sum 1)
+        while (m) {
+            const int r = __builtin_ctz(m);
+            m &= m - 1;
             // 96 bits starting at bit offset r of (c0, c1, c2, c3)
             const uint32_t x0 = __builtin_amdgcn_alignbit(c1, c0, r), x1 = __builtin_amdgcn_alignbit(c2, c1, r),
                            x2 = __builtin_amdgcn_alignbit(c3, c2, r);
-            // BTYPE == 2, HLIT <= 29, HDIST <= 29
-            if (((x0 >> 1) & 3) != 2 || ((x0 >> 3) & 31) > 29 || ((x0 >> 8) & 31) > 29) continue;
-            // bit-length code lengths: (HCLEN + 4) 3-bit fields from bit 17; the code must be complete (Kraft sum 1)
             const int ncode = (int)((x0 >> 13) & 15) + 4;
-            uint32_t g0 = (x0 >> 17) | (x1 << 15);  // bits 17..48: fields 0..9
+            uint32_t g0 = (x0 >> 17) | (x1 << 15);  // bits 17..48: fields 0..9 (and two bits of field 10)
             uint32_t g1 = (x1 >> 15) | (x2 << 17);  // bits 47..78: fields 10..18
-            int kraft = 0;
+            // fields at and beyond HCLEN + 4 count as length 0
+            const int nb = 3 * ncode;
+            g0 = nb < 30 ? g0 & ((1u << nb) - 1u) : g0;
+            g1 = nb <= 30 ? 0u : g1 & ((1u << (nb - 30)) - 1u);
+            int kraft = 0;  // units of 2^-7: a length v > 0 adds 128 >> v, which is (128 >> v) & 127 for every v
 #pragma unroll
-            for (int i = 0; i < 10; i++) {
-                const int v = (int)(g0 & 7);
-                g0 >>= 3;
-                kraft += (i < ncode && v) ? 128 >> v : 0;
-            }
+            for (int i = 0; i < 10; i++) kraft += (int)((0x80u >> ((g0 >> (3 * i)) & 7)) & 0x7Fu);
 #pragma unroll
-            for (int i = 10; i < 19; i++) {
-                const int v = (int)(g1 & 7);
-                g1 >>= 3;
-                kraft += (i < ncode && v) ? 128 >> v : 0;
-            }
+            for (int i = 0; i < 9; i++) kraft += (int)((0x80u >> ((g1 >> (3 * i)) & 7)) & 0x7Fu);
             if (kraft != 128) continue;
             int at = atomicAdd(&nsurv, 1);
-            if (at < kFindMaxSurv) surv[at] = (int32_t)(bit - (int64_t)chunk * kFindChunk * 8);
+            if (at < kFindMaxSurv) surv[at] = (int32_t)(base + r - (int64_t)chunk * kFindChunk * 8);
         }
     }
     __syncthreads();
@@ -490,31 +495,50 @@ __global__ __launch_bounds__(64) void zs_inf_check_kernel(const ParStream *ps, c
     }
 }
 
-// flatten the per-chunk lists into one ordered list per stream (one thread per stream)
-__global__ void zs_inf_flatten_kernel(const ParStream *ps, ParState *st, const int64_t *cand_bits, const int32_t *cand_cnt, ParCand *cands,
-                                      int nstreams) {
-    int si = blockIdx.x * blockDim.x + threadIdx.x;
+// flatten the per-chunk lists into one ordered list per stream: one workgroup per stream, 256 chunks per step
+// (a workgroup-wide prefix sum of the counts places every chunk's candidates)
+__global__ __launch_bounds__(256) void zs_inf_flatten_kernel(const ParStream *ps, ParState *st, const int64_t *cand_bits, const int32_t *cand_cnt, ParCand *cands,
+                                                             int nstreams) {
+    __shared__ int sc[256];
+    __shared__ int s_ok;
+    const int si = blockIdx.x, tid = threadIdx.x;
     if (si >= nstreams) return;
     const ParStream s = ps[si];
-    int n = 0, ok = 1;
-    for (int c = 0; c < s.nchunks && ok; c++) {
-        int k = cand_cnt[s.chunk_off + c];
-        if (k > kFindMaxCand) ok = 0;
-        for (int i = 0; i < k && i < kFindMaxCand; i++) {
-            if (n >= s.max_cand) {
-                ok = 0;
+    if (tid == 0) s_ok = 1;
+    __syncthreads();
+    int base = 0;
+    for (int c0 = 0; c0 < s.nchunks; c0 += 256) {
+        const int c = c0 + tid;
+        int k = c < s.nchunks ? cand_cnt[s.chunk_off + c] : 0;
+        if (k > kFindMaxCand) s_ok = 0, k = kFindMaxCand;  // a chunk's list overflowed
+        sc[tid] = k;
+        __syncthreads();
+        for (int d = 1; d < 256; d <<= 1) {
+            const int t = tid >= d ? sc[tid - d] : 0;
+            __syncthreads();
+            sc[tid] += t;
+            __syncthreads();
+        }
+        const int at = base + sc[tid] - k;
+        for (int i = 0; i < k; i++) {
+            if (at + i >= s.max_cand) {
+                s_ok = 0;
                 break;
             }
-            ParCand &d = cands[s.cand_off + n++];
+            ParCand &d = cands[s.cand_off + at + i];
             d.bit = cand_bits[((int64_t)s.chunk_off + c) * kFindMaxCand + i];
             d.end_bit = 0, d.out_bytes = 0, d.bfinal = 0, d.ok = 0, d.tab = -1, d.pad_ = 0;
         }
+        base += sc[255];
+        __syncthreads();
     }
-    st[si].ncand = n;
-    st[si].ok = ok;
-    st[si].nblk = 0;
-    st[si].out_len = 0;
-    st[si].end_bit = 0;
+    if (tid == 0) {
+        st[si].ncand = base < s.max_cand ? base : s.max_cand;
+        st[si].ok = s_ok;
+        st[si].nblk = 0;
+        st[si].out_len = 0;
+        st[si].end_bit = 0;
+    }
 }
 
 // ------------------------------------------------------------------ D1, wave form: one wave per candidate (fastest chain per block;
@@ -879,7 +903,7 @@ __global__ __launch_bounds__(64) void zs_inf_decode_kernel(const ParStream *ps, 
 // passes see the wave decoder's two kinds only.
 constexpr int kSubMarkBase = 0x100, kSubMarkMax = 0x8000 - kSubMarkBase;  // 32512 distances
 #ifndef ZS_DEC_SUBLANES
-#define ZS_DEC_SUBLANES 16
+#define ZS_DEC_SUBLANES 64
 #endif
 constexpr int kDecSubLanes = ZS_DEC_SUBLANES;      // lanes per block
 constexpr int kDecBlocks = 64 / kDecSubLanes;      // blocks per workgroup
@@ -1039,45 +1063,89 @@ __global__ __launch_bounds__(256) void zs_inf_cellflat_kernel(const ParStream *p
 }
 
 // ------------------------------------------------------------------ W
-// One workgroup per stream, block by block: win[k] = the 32 KiB of resolved output that end with block k.
-// The previous and the current window live in LDS (2 x 32 KiB); each finished window is also written to HBM
-// for the resolve kernel.
+// One workgroup per stream, block by block: win[k] = the 32 KiB of resolved output that end with block k.  Copies of
+// markers are markers, so on text a byte's chain of sources runs back through block after block: the windows are the
+// one place where that chain is cut, and the pass is serial per stream -- a step has to be short.  It is bound by
+// instruction issue (16 waves on one CU), so the LDS image of a window is laid out such that a cell *is* its own gather
+// address: a 256-byte identity table at offset 0 (a literal cell b reads b), the window at offset 0x8000 (a marker
+// 0x8000 | i reads window byte i); two such 64 KiB images, the previous window and the one being built.  A thread owns
+// runs of 4 consecutive window bytes: cells requested a block ahead (two aligned 8-byte loads and a funnel shift), four
+// byte gathers, one LDS dword and one HBM dword written.
+constexpr int kWinImage = 0x10000;
+constexpr int kWinLds = 2 * kWinImage;
 __global__ __launch_bounds__(1024) void zs_inf_window_kernel(const ParStream *ps, const ParState *st, const ParBlock *blocks,
                                                              const uint16_t *cells, uint8_t *windows) {
-    __shared__ __attribute__((aligned(16))) uint8_t wl[2][kWSize];
+    extern __shared__ __attribute__((aligned(16))) uint8_t wl[];  // [2][kWinImage]
     const ParStream s = ps[blockIdx.x];
     const ParState ss = st[blockIdx.x];
     if (!ss.ok) return;
     const uint16_t *cl = cells + s.cell_off;
     uint8_t *win = windows + (int64_t)s.blk_off * kWSize;
-    for (int i = threadIdx.x; i < kWSize; i += 1024) wl[0][i] = 0;
+    for (int i = threadIdx.x; i < kWSize; i += 1024) wl[0x8000 + i] = 0;  // before the stream: zeros
+    if (threadIdx.x < 256) wl[threadIdx.x] = (uint8_t)threadIdx.x, wl[kWinImage + threadIdx.x] = (uint8_t)threadIdx.x;
     __syncthreads();
+    constexpr int kRuns = kWSize / 4096;  // runs of 4 window bytes per thread
     int cur = 1;
-    for (int k = 0; k < ss.nblk; k++) {
-        const ParBlock bk = blocks[s.blk_off + k];
-        const uint8_t *pw = wl[cur ^ 1];
-        uint8_t *cw = wl[cur];
-        const int64_t end = bk.out_off + bk.out_bytes;
-        // cells first (independent global loads), then the LDS gathers
-        uint16_t c[kWSize / 1024];
+    uint2 c[kRuns], r0[kRuns], r1[kRuns];
+    ParBlock bk = {0, 0, 0, -1, 0}, bn = bk;
+    // The 4 cells of window bytes [i, i + 4) of a block's window.  The window's first cell is not 8-byte aligned in general:
+    // two aligned 8-byte loads (request: unconditional, from clamped addresses, so that the loads of a step are all in
+    // flight together, a block ahead of their use) and a funnel shift by the block's wave-uniform misalignment (finish).
+    // Where the window reaches back beyond the block the "cell" is the marker of the same byte in the previous window,
+    // 0x8000 | (i + out_bytes).
+    auto request = [&](const ParBlock &q) {
+        const int64_t org = q.out_off + q.out_bytes - kWSize;
+        const int off = (int)(org & 3);
 #pragma unroll
-        for (int j = 0; j < kWSize / 1024; j++) {
-            const int64_t p = end - kWSize + threadIdx.x + j * 1024;
-            c[j] = p >= bk.out_off ? cl[p] : 0;
+        for (int j = 0; j < kRuns; j++) {
+            const int64_t a = org - off + (threadIdx.x + j * 1024) * 4;  // a multiple of 4 cells (cell_off is one of 64, the array 16-byte aligned)
+            // cells before position 0 do not exist; what is loaded in their place is replaced in finish()
+            r0[j] = *(const uint2 *)(cl + (a < 0 ? 0 : a));
+            r1[j] = *(const uint2 *)(cl + (a + 4 < 0 ? 0 : a + 4));
         }
+    };
+    auto finish = [&](const ParBlock &q) {
+        const int64_t org = q.out_off + q.out_bytes - kWSize;
+        const int off = (int)(org & 3), ws = off >> 1, bs = (off & 1) * 16;
 #pragma unroll
-        for (int j = 0; j < kWSize / 1024; j++) {
-            const int i = threadIdx.x + j * 1024;
-            const int64_t p = end - kWSize + i;  // absolute output position of window byte i
-            uint8_t v;
-            if (p >= bk.out_off) v = (c[j] & 0x8000) ? pw[c[j] & 0x7FFF] : (uint8_t)c[j];
-            else v = pw[i + bk.out_bytes];  // p = (end of the previous block - 32768) + (i + out_bytes); zero before the stream
-            cw[i] = v;
+        for (int j = 0; j < kRuns; j++) {
+            const uint32_t w0 = ws ? r0[j].y : r0[j].x, w1 = ws ? r1[j].x : r0[j].y, w2 = ws ? r1[j].y : r1[j].x;
+            c[j] = make_uint2(__builtin_amdgcn_alignbit(w1, w0, bs), __builtin_amdgcn_alignbit(w2, w1, bs));
+        }
+        if (q.out_bytes < kWSize) {  // wave-uniform
+#pragma unroll
+            for (int j = 0; j < kRuns; j++) {
+                const int i = (threadIdx.x + j * 1024) * 4;
+                uint32_t v[4] = {c[j].x & 0xFFFFu, c[j].x >> 16, c[j].y & 0xFFFFu, c[j].y >> 16};
+#pragma unroll
+                for (int u = 0; u < 4; u++) v[u] = org + i + u >= q.out_off ? v[u] : 0x8000u | (uint32_t)(i + u + q.out_bytes);
+                c[j] = make_uint2(v[0] | (v[1] << 16), v[2] | (v[3] << 16));
+            }
+        }
+    };
+    if (ss.nblk > 0) {
+        bn = blocks[s.blk_off];
+        request(bn);
+    }
+    for (int k = 0; k < ss.nblk; k++) {
+        bk = bn;
+        finish(bk);
+        if (k + 1 < ss.nblk) {
+            bn = blocks[s.blk_off + k + 1];
+            request(bn);
+        }
+        const uint8_t *pw = wl + (cur ^ 1) * kWinImage;
+        uint8_t *cw = wl + cur * kWinImage + 0x8000;
+        uint32_t *dst = (uint32_t *)(win + (int64_t)k * kWSize);
+#pragma unroll
+        for (int j = 0; j < kRuns; j++) {
+            const int i = (threadIdx.x + j * 1024) * 4;
+            const uint32_t b0 = pw[c[j].x & 0xFFFFu], b1 = pw[c[j].x >> 16], b2 = pw[c[j].y & 0xFFFFu], b3 = pw[c[j].y >> 16];
+            const uint32_t word = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
+            *(uint32_t *)(cw + i) = word;
+            dst[i >> 2] = word;
         }
         __syncthreads();
-        uint4 *dst = (uint4 *)(win + (int64_t)k * kWSize);
-        const uint4 *src = (const uint4 *)cw;
-        for (int i = threadIdx.x; i < kWSize / 16; i += 1024) dst[i] = src[i];
         cur ^= 1;
     }
 }
