@@ -290,101 +290,164 @@ struct ParLds {
 };
 
 // ------------------------------------------------------------------ F
-// 256 threads per 4 KiB of input; each thread tests the 128 bit offsets of its 16 bytes.
-// `dec`: 128 bytes of LDS private to the calling thread (a runtime-indexed private array would be kept in
-// registers and indexed through select chains -- hundreds of instructions per access).
-__device__ bool find_check_header(const uint8_t *in, int64_t n, int64_t bit, uint8_t *dec) {
-    auto bits_at = [&](int64_t bp, int k) -> uint32_t {  // k <= 25
-        int64_t byte = bp >> 3;
-        uint64_t v = 0;
-        if (byte + 8 <= n) {
-            v = *(const uint64_t __attribute__((aligned(1))) *)(in + byte);
+// 256 threads per 4 KiB of input; each thread tests the 128 bit offsets of its 16 bytes (prefilter), the survivors get
+// the full header check, one lane each.
+//
+// The check is written for a wave whose lanes are all somewhere else in their headers: no tables in memory, no loops
+// whose trip count differs from lane to lane except the one over the code-length symbols.  The bit-length code (<= 19
+// symbols, <= 7 bits, complete) is decoded from three packed registers: lim (byte l = the left-aligned code value at
+// which lengths > l begin, i.e. the Kraft sum of the lengths <= l in units of 2^-7), base (byte l = number of symbols
+// shorter than l) and the symbols sorted by (length, symbol), 6 bits each.  With rv = the next 7 bits, first bit on top,
+// the code length is 1 + #{l < 7 : rv >= lim[l]} and the symbol is entry base[l] + ((rv - lim[l - 1]) >> (7 - l)).
+// Runs (symbols 16-18) are accounted in closed form.
+struct LaneBits {
+    const __attribute__((address_space(1))) uint8_t *in;  // the stream's input (global memory: no flat loads)
+    int64_t n, pos;
+    uint64_t buf;
+    int cnt;
+    bool bad;
+    __device__ void fill() {
+        if (cnt > 40) return;  // a symbol needs at most 15 + 5 + 15 + 13 bits; every load is on the decode's dependency chain
+        if (pos + 8 <= n) {
+            buf |= *(const __attribute__((address_space(1))) uint64_t __attribute__((aligned(1))) *)(in + pos) << cnt;
+            const int adv = (63 - cnt) >> 3;
+            pos += adv;
+            cnt += adv * 8;
         } else {
-            for (int i = 0; i < 5; i++)
-                if (byte + i < n) v |= (uint64_t)in[byte + i] << (8 * i);
+            while (cnt <= 56 && pos < n) {
+                buf |= (uint64_t)in[pos] << cnt;
+                pos++;
+                cnt += 8;
+            }
         }
-        return (uint32_t)((v >> (bp & 7)) & ((1u << k) - 1));
-    };
+    }
+    __device__ void seek(int64_t bit) {
+        pos = bit >> 3, buf = 0, cnt = 0, bad = false;
+        fill();
+        drop((int)(bit & 7));
+    }
+    __device__ int64_t tell() const { return pos * 8 - cnt; }
+    __device__ uint32_t peek(int k) const { return (uint32_t)(buf & ((1ull << k) - 1)); }
+    __device__ void drop(int k) {
+        if (k > cnt) bad = true, k = cnt;
+        buf >>= k;
+        cnt -= k;
+    }
+    __device__ uint32_t take(int k) {
+        const uint32_t v = peek(k);
+        drop(k);
+        return v;
+    }
+};
+__device__ int lane_slow(const LaneBits &b, const uint16_t *count, const uint16_t *symtab, int &len_out) {
+    int code = 0, first = 0, index = 0;
+    uint64_t bits = b.buf;
+    for (int len = 1; len <= 15; len++) {
+        code |= (int)(bits & 1);
+        bits >>= 1;
+        const int c = count[len];
+        if (code - c < first) {
+            len_out = len;
+            return symtab[index + (code - first)];
+        }
+        index += c;
+        first += c;
+        first <<= 1;
+        code <<= 1;
+    }
+    len_out = 0;
+    return -1;
+}
+__device__ bool find_check_header(const __attribute__((address_space(1))) uint8_t *in, int64_t n, int64_t bit) {
     if (bit + 17 > n * 8) return false;
-    const uint32_t h = bits_at(bit, 17);
+    LaneBits b{in, n, 0, 0, 0, false};
+    b.seek(bit);
+    const uint32_t h = b.take(17);
     if (((h >> 1) & 3) != 2) return false;
     const int nlen = (int)((h >> 3) & 31) + 257, ndist = (int)((h >> 8) & 31) + 1, ncode = (int)((h >> 13) & 15) + 4;
     if (nlen > 286 || ndist > 30) return false;
-    if (bit + 17 + 3 * ncode > n * 8) return false;
-    // bit-length code lengths, packed 3 bits per symbol; per-length counters packed 8 bits per length
-    uint64_t bl = 0, cnt = 0;
-    int kraft = 0;
-    for (int i = 0; i < ncode; i++) {
-        const uint64_t v = bits_at(bit + 17 + 3 * i, 3);
-        bl |= v << (3 * bl_order(i));
-        if (v) kraft += 128 >> v, cnt += 1ull << (8 * v);
+    // (HCLEN + 4) 3-bit lengths in bl_order; the fields beyond count as 0
+    b.fill();
+    const int nb = 3 * ncode;
+    uint32_t g0 = b.peek(30);
+    b.drop(nb < 30 ? nb : 30);
+    b.fill();
+    uint32_t g1 = b.peek(27);
+    b.drop(nb > 30 ? nb - 30 : 0);
+    if (b.bad) return false;
+    g0 = nb < 30 ? g0 & ((1u << nb) - 1u) : g0;
+    g1 = nb <= 30 ? 0u : g1 & ((1u << (nb - 30)) - 1u);
+    uint64_t bl = 0;  // 3 bits per symbol, in symbol order
+#pragma unroll
+    for (int i = 0; i < 19; i++) {
+        const uint32_t v = i < 10 ? (g0 >> (3 * i)) & 7u : (g1 >> (3 * (i - 10))) & 7u;
+        bl |= (uint64_t)v << (3 * bl_order(i));
     }
-    if (kraft != 128) return false;
-    // canonical codes: next[l] packed 8 bits per length (codes of length <= 7 are < 128)
-    uint64_t next = 0;
+    // symbols per length: bit-sliced compare of all 19 fields with l, then a population count
+    const uint64_t ones = 0x0249249249249249ull;  // bit 0 of each of the 19 fields
+    const uint64_t s0 = bl & ones, s1 = (bl >> 1) & ones, s2 = (bl >> 2) & ones;
+    uint64_t lim = 0, base = 0, offs = 0;
     {
-        int code = 0;
+        int cum = 0, nsym = 0;
+#pragma unroll
         for (int l = 1; l <= 7; l++) {
-            code = (code + (int)((cnt >> (8 * (l - 1))) & 0xFF) * (l > 1)) << 1;
-            next |= (uint64_t)(code & 0xFF) << (8 * l);
+            const uint64_t eq = ((l & 1) ? s0 : ~s0) & ((l & 2) ? s1 : ~s1) & ((l & 4) ? s2 : ~s2) & ones;
+            const int c = __builtin_popcountll(eq);
+            base |= (uint64_t)nsym << (8 * l);
+            nsym += c;
+            cum += c << (7 - l);
+            lim |= (uint64_t)(cum > 255 ? 255 : cum) << (8 * l);
         }
+        if (cum != 128) return false;  // the bit-length code must be complete
+        offs = base;
     }
+    uint64_t tab_lo = 0, tab_hi = 0;  // sorted symbols, 6 bits each: entries 0..9 and 10..18
+#pragma unroll
     for (int sy = 0; sy < 19; sy++) {
         const int l = (int)((bl >> (3 * sy)) & 7);
-        if (!l) continue;
-        const unsigned code = (unsigned)((next >> (8 * l)) & 0xFF);
-        next += 1ull << (8 * l);
-        const unsigned rev = bit_reverse(code, l);
-        for (unsigned r2 = rev; r2 < 128; r2 += 1u << l) dec[r2] = (uint8_t)((sy << 3) | l);
+        const int pos = (int)((offs >> (8 * l)) & 0xFF);
+        offs += l ? 1ull << (8 * l) : 0ull;
+        const uint64_t e = l ? (uint64_t)sy << (6 * (pos < 10 ? pos : pos - 10)) : 0ull;
+        tab_lo |= pos < 10 ? e : 0ull;
+        tab_hi |= pos < 10 ? 0ull : e;
     }
+    const uint32_t lim_lo = (uint32_t)lim, lim_hi = (uint32_t)(lim >> 32);
     // decode nlen + ndist code lengths, accumulate Kraft sums of both alphabets (units of 2^-15)
-    int64_t bp = bit + 17 + 3 * ncode;
-    int idx = 0, prev = 0, klit = 0, kdist = 0, nz_dist = 0, eob_len = 0;
-    auto account = [&](int at, int len) {
-        if (!len) return;
-        if (at < nlen) {
-            klit += 32768 >> len;
-            if (at == 256) eob_len = len;
-        } else {
-            kdist += 32768 >> len;
-            nz_dist++;
+    const int total = nlen + ndist;
+    int idx = 0, prev = 0, nz_dist = 0, eob_len = 0;
+    uint32_t klit = 0, kdist = 0;
+    while (idx < total) {
+        if (klit > 32768u || kdist > 32768u) return false;  // oversubscribed already: random data dies here within a few symbols
+        b.fill();
+        const uint32_t rv = __brev(b.peek(7)) >> 25;
+        const int l = 1 + (int)(rv >= ((lim_lo >> 8) & 0xFF)) + (int)(rv >= ((lim_lo >> 16) & 0xFF)) + (int)(rv >= (lim_lo >> 24)) +
+                      (int)(rv >= (lim_hi & 0xFF)) + (int)(rv >= ((lim_hi >> 8) & 0xFF)) + (int)(rv >= ((lim_hi >> 16) & 0xFF));
+        const uint32_t fa = (uint32_t)(lim >> (8 * (l - 1))) & 0xFF;
+        const int pos = (int)((base >> (8 * l)) & 0xFF) + (int)((rv - fa) >> (7 - l));
+        const int sym = (int)(((pos < 10 ? tab_lo : tab_hi) >> (6 * (pos < 10 ? pos : pos - 10))) & 63);
+        b.drop(l);
+        if (sym == 16 && idx == 0) return false;
+        const int eb = sym < 16 ? 0 : sym == 16 ? 2 : sym == 17 ? 3 : 7;
+        const int rep = (sym < 16 ? 1 : sym == 18 ? 11 : 3) + (int)b.take(eb);
+        const int val = sym < 16 ? sym : sym == 16 ? prev : 0;
+        if (b.bad || idx + rep > total) return false;
+        // positions [idx, idx + rep): those below nlen belong to the literal/length code
+        int nl = (idx + rep < nlen ? idx + rep : nlen) - idx;
+        nl = nl < 0 ? 0 : nl;
+        const int nd = rep - nl;
+        if (val) {
+            const uint32_t wgt = 32768u >> val;
+            klit += (uint32_t)nl * wgt;
+            kdist += (uint32_t)nd * wgt;
+            nz_dist += nd;
+            if (idx <= 256 && idx + rep > 256) eob_len = val;
         }
-    };
-    while (idx < nlen + ndist) {
-        if (klit > 32768 || kdist > 32768) return false;  // oversubscribed already: random data dies here within a few symbols
-        if (bp + 14 > n * 8) return false;
-        uint32_t w = bits_at(bp, 14);
-        uint8_t e = dec[w & 127];
-        int l = e & 7, s = e >> 3;
-        bp += l;
-        w >>= l;
-        if (s < 16) {
-            account(idx, s);
-            prev = s;
-            idx++;
-        } else {
-            int rep, val = 0;
-            if (s == 16) {
-                if (idx == 0) return false;
-                val = prev;
-                rep = 3 + (int)(w & 3);
-                bp += 2;
-            } else if (s == 17) {
-                rep = 3 + (int)(w & 7);
-                bp += 3;
-            } else {
-                rep = 11 + (int)(w & 127);
-                bp += 7;
-            }
-            if (idx + rep > nlen + ndist) return false;
-            for (int k = 0; k < rep; k++) account(idx + k, val);
-            prev = val;
-            idx += rep;
-        }
+        prev = val;
+        idx += rep;
     }
     if (!eob_len) return false;
-    if (klit != 32768) return false;                       // an encoder's literal/length code is complete
-    if (!(kdist == 32768 || nz_dist <= 1)) return false;  // distance code: complete, or at most one code
+    if (klit != 32768u) return false;                       // an encoder's literal/length code is complete
+    if (!(kdist == 32768u || nz_dist <= 1)) return false;  // distance code: complete, or at most one code
     return true;
 }
 
@@ -457,13 +520,11 @@ __global__ __launch_bounds__(256) void zs_inf_prefilter_kernel(const ParStream *
     if (threadIdx.x == 0) surv_cnt[blockIdx.x] = nsurv;
 }
 
-// Full header check of a chunk's survivors: one lane each (a check is a chain of a few hundred dependent steps, so what
-// matters is how many chunks are in flight: one wave and 8 KiB of decode tables per chunk).
+// Full header check of a chunk's survivors: one lane each, one wave per chunk.
 __global__ __launch_bounds__(64) void zs_inf_check_kernel(const ParStream *ps, const uint2 *work, const int32_t *surv_g,
                                                           const int32_t *surv_cnt, int64_t *cand_bits, int32_t *cand_cnt) {
     __shared__ int64_t found[kFindMaxCand];
     __shared__ int nfound;
-    __shared__ uint8_t dec_lds[64 * 128];  // one 7-bit decode table per lane
     const uint2 w = work[blockIdx.x];
     const ParStream s = ps[w.x];
     const int chunk = (int)w.y;
@@ -474,7 +535,7 @@ __global__ __launch_bounds__(64) void zs_inf_check_kernel(const ParStream *ps, c
     const int ns = nsurv < kFindMaxSurv ? nsurv : kFindMaxSurv;
     for (int i = threadIdx.x; i < ns; i += 64) {
         const int64_t bit = (int64_t)chunk * kFindChunk * 8 + surv[i];
-        if (find_check_header(s.in, s.in_len, bit, dec_lds + threadIdx.x * 128)) {
+        if (find_check_header((const __attribute__((address_space(1))) uint8_t *)(uintptr_t)s.in, s.in_len, bit)) {
             int at = atomicAdd(&nfound, 1);
             if (at < kFindMaxCand) found[at] = bit;
         }
@@ -590,64 +651,6 @@ struct LaneTabs {
 };
 static_assert(sizeof(InfTables) % 16 == 0 && sizeof(LaneTabs) % 16 == 0 && offsetof(LaneTabs, nsub) == sizeof(InfTables),
               "LaneTabs begins with an InfTables image copied with 16-byte stores");
-struct LaneBits {
-    const __attribute__((address_space(1))) uint8_t *in;  // the stream's input (global memory: no flat loads)
-    int64_t n, pos;
-    uint64_t buf;
-    int cnt;
-    bool bad;
-    __device__ void fill() {
-        if (cnt > 40) return;  // a symbol needs at most 15 + 5 + 15 + 13 bits; every load is on the decode's dependency chain
-        if (pos + 8 <= n) {
-            buf |= *(const __attribute__((address_space(1))) uint64_t __attribute__((aligned(1))) *)(in + pos) << cnt;
-            const int adv = (63 - cnt) >> 3;
-            pos += adv;
-            cnt += adv * 8;
-        } else {
-            while (cnt <= 56 && pos < n) {
-                buf |= (uint64_t)in[pos] << cnt;
-                pos++;
-                cnt += 8;
-            }
-        }
-    }
-    __device__ void seek(int64_t bit) {
-        pos = bit >> 3, buf = 0, cnt = 0, bad = false;
-        fill();
-        drop((int)(bit & 7));
-    }
-    __device__ int64_t tell() const { return pos * 8 - cnt; }
-    __device__ uint32_t peek(int k) const { return (uint32_t)(buf & ((1ull << k) - 1)); }
-    __device__ void drop(int k) {
-        if (k > cnt) bad = true, k = cnt;
-        buf >>= k;
-        cnt -= k;
-    }
-    __device__ uint32_t take(int k) {
-        const uint32_t v = peek(k);
-        drop(k);
-        return v;
-    }
-};
-__device__ int lane_slow(const LaneBits &b, const uint16_t *count, const uint16_t *symtab, int &len_out) {
-    int code = 0, first = 0, index = 0;
-    uint64_t bits = b.buf;
-    for (int len = 1; len <= 15; len++) {
-        code |= (int)(bits & 1);
-        bits >>= 1;
-        const int c = count[len];
-        if (code - c < first) {
-            len_out = len;
-            return symtab[index + (code - first)];
-        }
-        index += c;
-        first += c;
-        first <<= 1;
-        code <<= 1;
-    }
-    len_out = 0;
-    return -1;
-}
 // One lane decodes (without output) from bit `entry` to the first symbol boundary at or after `gend`, or to END_BLOCK.
 // flags: 0 = crossed gend, 1 = END_BLOCK (exit_bit is the bit after it), 2 = not decodable from here.
 __device__ __forceinline__ void sub_measure(const __attribute__((address_space(1))) uint8_t *in, int64_t n, const InfTables &T, int64_t entry,
