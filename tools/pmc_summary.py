@@ -3,6 +3,7 @@
 
   profiles/rNN_english64_L6_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary (zs_* kernels)
   profiles/rNN_pmc_traffic_english64_L6.json   FETCH_SIZE / WRITE_SIZE per launch, corrected as MI355X_MICROARCH.md says
+  profiles/rNN_inflate1g_kernel_stats.csv      the same for tools/bench_inflate.py (zs_inf_* kernels)
   profiles/rNN_bench_*.json                    the bench lines of the same run
 """
 import csv, glob, json, os, shutil, sys
@@ -24,6 +25,16 @@ if st:
         w.writerow(rows[0])
         for r in rows[1:]:
             if "zs_" in r[0]:
+                w.writerow([short(r[0])] + r[1:])
+
+sti = glob.glob(os.path.join(src, "stats_inflate", "**", "*kernel_stats.csv"), recursive=True)
+if sti:
+    rows = list(csv.reader(open(sti[0])))
+    with open(os.path.join(dst, "%s_inflate1g_kernel_stats.csv" % tag), "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(rows[0])
+        for r in rows[1:]:
+            if "zs_inf" in r[0] or "zs_adler" in r[0]:
                 w.writerow([short(r[0])] + r[1:])
 
 def counter(dirname, cname):
@@ -49,7 +60,8 @@ if fetch or write:
 for name, out in (("bench_english64.json", "bench_english64_L6.json"), ("bench_sparse64.json", "bench_sparse64_L6.json"),
                   ("bench_batch128.json", "bench_batch128x1MiB_L6.json"), ("bench_inflate.json", "bench_inflate1g.json"),
                   ("time_levels.jsonl", "time_levels.jsonl"), ("host_path.jsonl", "host_path.jsonl"),
-                  ("bench_english64_pipelined.json", "bench_english64_L6_pipelined3.json")):
+                  ("bench_english64_pipelined.json", "bench_english64_L6_pipelined3.json"),
+                  ("bench_inflate_single.json", "bench_inflate_single64.json")):
     p = os.path.join(src, name)
     if os.path.exists(p) and os.path.getsize(p) > 0:
         shutil.copy(p, os.path.join(dst, "%s_%s" % (tag, out)))

@@ -15,6 +15,8 @@ python3 $R/tools/bench_inflate.py > $O/bench_inflate.json 2> $O/bench_inflate.er
 python3 $R/tools/time_levels.py > $O/time_levels.jsonl 2> $O/time_levels.err
 python3 $R/tools/bench_host_path.py > $O/host_path.jsonl 2> $O/host_path.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o run -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline > $O/stats_bench.json 2> $O/stats.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_inflate -o run -- python3 $R/tools/bench_inflate.py > $O/stats_bench_inflate.json 2> $O/stats_inflate.err
+python3 $R/tools/bench_inflate.py --streams 1 > $O/bench_inflate_single.json 2> $O/bench_inflate_single.err
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o run -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> $O/pmc_fetch.err
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o run -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> $O/pmc_write.err
 find $O -name "*.csv" -size +20M -delete
