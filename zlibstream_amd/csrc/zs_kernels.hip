@@ -558,8 +558,12 @@ __global__ __launch_bounds__(512) void zs_chunkmap_kernel(const StreamDesc *sd, 
     }
     __syncthreads();
     // two dependent lookups per pass: after pass r every entry jumps >= 3^r steps or reaches its exit (a step advances
-    // at least one position, a chunk has 2048: 3^7 = 2187)
-    for (int r = 0; r < 7; r++) {
+    // at least one position, a chunk has 2048: 3^7 = 2187 would finish every entry).  The passes stop earlier: the 260
+    // slot lookups below follow unfinished entries (<= 2048 / 3^r lookups each), which costs less than the passes saved.
+#ifndef ZS_JUMP_PASSES
+#define ZS_JUMP_PASSES 3
+#endif
+    for (int r = 0; r < ZS_JUMP_PASSES; r++) {
         // four nodes per thread at a time, their lookups issued together (the LDS round trips overlap); a node past the
         // end of the chunk or already at its exit looks itself up and stays as it is
         for (int i0 = threadIdx.x; i0 < 3 * kChunk; i0 += 4 * 512) {
