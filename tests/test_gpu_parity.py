@@ -325,6 +325,44 @@ def test_inflate_large_device_resident(engine):
         assert lens[i] == 6 << 20 and zlib.adler32(o.cpu().numpy().tobytes()) == int.from_bytes(zs[i][-4:], "big")
 
 
+def test_inflate_block_parallel_path_on_foreign_large_streams(engine):
+    """Large streams from another encoder through the block-parallel path: blocks the finder cannot see (stored, fixed)
+    between dynamic ones, empty stored blocks from flushes (the next candidate is then not the block's end), tiny and huge
+    blocks (zeros: 4 MiB of output per block; level 1: other block lengths), data that does not compress (stored only:
+    the one-wave decoder takes it).  Bytes and lengths must be those of zlib."""
+    rng = np.random.default_rng(11)
+    text = datagen.english(3 << 20, 77)
+    noise = rng.integers(0, 256, 1 << 20, dtype=np.uint8).tobytes()
+    zeros = bytes(24 << 20)
+    cases = []
+    for lvl in (1, 6, 9):
+        cases.append(zlib.compress(text, lvl))
+    cases.append(zlib.compress(zeros, 6))
+    cases.append(zlib.compress(noise, 6))                       # stored blocks only
+    cases.append(zlib.compress(text[:1 << 20] + noise + text[1 << 20:] + zeros[:1 << 20], 6))  # dynamic / stored / dynamic
+    co = zlib.compressobj(6)
+    parts = []
+    for off in range(0, len(text), 300000):                     # sync / full flushes: empty stored blocks between the dynamic ones
+        parts.append(co.compress(text[off:off + 300000]))
+        parts.append(co.flush(zlib.Z_FULL_FLUSH if (off // 300000) % 2 else zlib.Z_SYNC_FLUSH))
+    parts.append(co.flush())
+    cases.append(b"".join(parts))
+    co = zlib.compressobj(6, zlib.DEFLATED, 15, 8, zlib.Z_FIXED)  # fixed blocks only: measured by the chain kernel, wave decoder
+    cases.append(co.compress(text[:1 << 20]) + co.flush())
+    co = zlib.compressobj(9, zlib.DEFLATED, 15, 9)
+    cases.append(co.compress(datagen.sparse(1024, 1024)) + co.flush())
+    want = [zlib.decompress(z) for z in cases]
+    got = engine.inflate_batch(cases, [len(w) for w in want])
+    for i, (g_, w_) in enumerate(zip(got, want)):
+        assert g_ == w_, (i, len(g_), len(w_))
+    # a corrupted byte in the middle of a large stream is a data error here as it is in zlib (message classes are covered
+    # by test_inflate_errors_match_reference_messages)
+    bad = bytearray(cases[1])
+    bad[len(bad) // 2] ^= 0x10
+    with pytest.raises(ZlibStreamException):
+        engine.inflate_batch([bytes(bad)], [len(want[1])])
+
+
 def test_cpp_host_mirror(tmp_path):
     """The C++ host-side mirror of ZlibOutputStream / ZlibInputStream (include/zsgpu.hpp) replays the reference's
     EncodeDecode / EncodeDecodePerChunk tests through the C ABI; bytes are checked against the oracle."""

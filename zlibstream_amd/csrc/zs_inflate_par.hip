@@ -939,83 +939,97 @@ __global__ __launch_bounds__(64) void zs_inf_decode_lane_kernel(const ParStream 
     bool bad = false;
     for (int sub = sub0; sub < nsub && !bad; sub += kDecSubLanes) {
         const int64_t bit0 = k.bit + T->ck_bit[sub];
-        const int64_t S = T->ck_out[sub], E = T->ck_out[sub + 1];
+        const int S = (int)T->ck_out[sub], E = (int)T->ck_out[sub + 1];  // block-relative, < 2^31 (measure pass)
         const int64_t bit1 = k.bit + T->ck_bit[sub + 1];  // the next sub-block's first symbol, or the bit after END_BLOCK
         LaneBits b{(const __attribute__((address_space(1))) uint8_t *)(uintptr_t)s.in, s.in_len, 0, 0, 0, false};
         b.seek(bit0);
-        int64_t pos = S;
-        bool eob = false;
-        while (b.tell() < bit1) {
-            b.fill();
-            int sym, clen;
-            {
-                const uint16_t e = lit[b.peek(kInfLitBits)];
-                if (e != kInfEsc) sym = e >> 4, clen = e & 15;
-                else sym = lane_slow(b, T->lcount, T->lsym, clen);
-            }
-            if (sym < 0 || clen > b.cnt) {
-                bad = true;
-                break;
-            }
-            b.drop(clen);
-            if (sym < 256) {
-                if (pos >= E) {
+        int pos = S;
+        bool eob = false, fin = false;
+        // A lane is either decoding its next symbol or copying the match it decoded, kDecCopy cells per trip: a long match
+        // keeps its own lane busy for several trips while the other lanes decode on (a wave pays for a trip once, however
+        // many of its lanes take it; as a loop inside the match it ran as often as the wave's longest match needed).
+        int cp_left = 0, cp_sp0 = 0, cp_off = 0, cp_dist = 1;
+        const int sub_mark = kSubMarkBase - 1 + S;  // sub-block marker of source position sp: sub_mark - sp
+        while (!bad && (!fin || cp_left > 0)) {
+            if (cp_left == 0) {
+                if (b.tell() >= bit1) {
+                    fin = true;
+                    continue;
+                }
+                b.fill();
+                int sym, clen;
+                {
+                    const uint16_t e = lit[b.peek(kInfLitBits)];
+                    if (e != kInfEsc) sym = e >> 4, clen = e & 15;
+                    else sym = lane_slow(b, T->lcount, T->lsym, clen);
+                }
+                if (sym < 0 || clen > b.cnt) {
                     bad = true;
                     break;
                 }
-                o16[pos++] = (uint16_t)sym;
-                continue;
+                b.drop(clen);
+                if (sym < 256) {
+                    if (pos >= E) {
+                        bad = true;
+                        break;
+                    }
+                    o16[pos++] = (uint16_t)sym;
+                    continue;
+                }
+                if (sym == 256) {
+                    eob = true;
+                    fin = true;
+                    continue;
+                }
+                sym -= 257;
+                if (sym >= 29) {
+                    bad = true;
+                    break;
+                }
+                const int mlen = (sym == 28 ? 258 : base_length(sym) + 3) + (int)b.take(extra_lbits(sym));
+                b.fill();
+                int ds, dl;
+                {
+                    const uint16_t e = T->dist[b.peek(kInfDistBits)];
+                    if (e != kInfEsc) ds = e >> 4, dl = e & 15;
+                    else ds = lane_slow(b, T->dcount, T->dsym, dl);
+                }
+                if (ds < 0 || ds >= 30 || dl > b.cnt) {
+                    bad = true;
+                    break;
+                }
+                b.drop(dl);
+                const int dist = base_dist(ds) + 1 + (int)b.take(extra_dbits(ds));
+                const int sp0 = pos - dist;  // block-relative source of the first byte
+                // a source cell inside the block but further before S than a sub-block marker can say fails the stream over
+                const int span = dist < mlen ? dist : mlen, lo = sp0 < 0 ? 0 : sp0;  // source cells sp0 .. sp0 + span - 1
+                if (b.bad || pos + mlen > E || k.out_off + sp0 < 0 || (lo < S && lo < sp0 + span && S - lo > kSubMarkMax)) {
+                    bad = true;
+                    break;
+                }
+                cp_left = mlen, cp_sp0 = sp0, cp_off = 0, cp_dist = dist;
+                // sources are older than this match (offset i mod dist); the lane's own cells are read back from L2 once
+                // its stores have landed
+                if (sp0 + span > S) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
-            if (sym == 256) {
-                eob = true;
-                break;
-            }
-            sym -= 257;
-            if (sym >= 29) {
-                bad = true;
-                break;
-            }
-            const int mlen = (sym == 28 ? 258 : base_length(sym) + 3) + (int)b.take(extra_lbits(sym));
-            b.fill();
-            int ds, dl;
-            {
-                const uint16_t e = T->dist[b.peek(kInfDistBits)];
-                if (e != kInfEsc) ds = e >> 4, dl = e & 15;
-                else ds = lane_slow(b, T->dcount, T->dsym, dl);
-            }
-            if (ds < 0 || ds >= 30 || dl > b.cnt) {
-                bad = true;
-                break;
-            }
-            b.drop(dl);
-            const int dist = base_dist(ds) + 1 + (int)b.take(extra_dbits(ds));
-            const int64_t sp0 = pos - dist;  // block-relative source of the first byte
-            if (b.bad || pos + mlen > E || k.out_off + sp0 < 0) {
-                bad = true;
-                break;
-            }
-            // sources are older than this match (offset i mod dist); the lane's own cells are read back from L2 once its
-            // stores have landed, kDecCopy at a time (the wave goes round as often as its longest match needs)
-            if (sp0 + (dist < mlen ? dist : mlen) > S) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            int off = 0;
-            for (int i = 0; i < mlen; i += kDecCopy) {
-                uint16_t v[kDecCopy];
+            if (cp_left > 0) {
+                uint32_t v[kDecCopy];
 #pragma unroll
                 for (int u = 0; u < kDecCopy; u++) {
-                    const int64_t sp = sp0 + off;
-                    v[u] = 0;
-                    if (i + u < mlen) {
-                        v[u] = sp >= S ? cell_load(o16 + sp)
-                                       : sp < 0 ? (uint16_t)(0x8000u | (uint32_t)(kWSize + sp)) : (uint16_t)(kSubMarkBase + (S - sp - 1));
-                        if (sp >= 0 && S - sp > kSubMarkMax) bad = true;  // further back inside the block than a cell can say
-                    }
-                    off = off + 1 == dist ? 0 : off + 1;
+                    const int sp = cp_sp0 + cp_off;
+                    // before the block: marker of byte 32768 + sp of the window (0x8000 | (32768 + sp) is sp's low 16 bits);
+                    // before the sub-block: its distance from S; else the cell itself
+                    v[u] = sp < 0 ? (uint32_t)sp : (uint32_t)(sub_mark - sp);
+                    if (u < cp_left && sp >= S) v[u] = cell_load(o16 + sp);
+                    cp_off = cp_off + 1 == cp_dist ? 0 : cp_off + 1;
                 }
 #pragma unroll
                 for (int u = 0; u < kDecCopy; u++)
-                    if (i + u < mlen) o16[pos + i + u] = v[u];
+                    if (u < cp_left) o16[pos + u] = (uint16_t)v[u];
+                const int n = cp_left < kDecCopy ? cp_left : kDecCopy;
+                pos += n;
+                cp_left -= n;
             }
-            pos += mlen;
         }
         // a sub-block ends where the next checkpoint says (the last one at END_BLOCK)
         const bool last = sub + 1 == nsub;
