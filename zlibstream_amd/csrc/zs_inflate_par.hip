@@ -914,7 +914,9 @@ constexpr int kDecCopy = 8;    // cells of a match copied per round trip
 __global__ __launch_bounds__(64) void zs_inf_decode_lane_kernel(const ParStream *ps, const ParState *st, const uint2 *work, int nwork,
                                                                 const ParBlock *blocks, const LaneTabs *tabs, uint16_t *cells,
                                                                 int32_t *fail) {
-    __shared__ __attribute__((aligned(16))) uint16_t lit_s[kDecBlocks][1 << kInfLitBits];
+    // the block's decode tables, all of them: a code longer than the primary index is rare for a lane but not for a wave,
+    // and its canonical walk is up to 15 dependent lookups
+    __shared__ __attribute__((aligned(16))) InfTables tab_s[kDecBlocks];
     const int grp = threadIdx.x / kDecSubLanes, sub0 = threadIdx.x % kDecSubLanes;
     const int wi = blockIdx.x * kDecBlocks + grp;
     bool live = wi < nwork;
@@ -927,13 +929,14 @@ __global__ __launch_bounds__(64) void zs_inf_decode_lane_kernel(const ParStream 
     live = live && k.tab >= 0;
     const LaneTabs *T = tabs + (live ? k.tab : 0);
     if (live) {
-        const uint4 *src = (const uint4 *)T->lit;  // LaneTabs starts with the table: 16-byte aligned
-        uint4 *dst = (uint4 *)lit_s[grp];
-        for (int i = sub0; i < (1 << kInfLitBits) * 2 / 16; i += kDecSubLanes) dst[i] = src[i];
+        const uint4 *src = (const uint4 *)T;  // LaneTabs starts with an InfTables image: 16-byte aligned
+        uint4 *dst = (uint4 *)&tab_s[grp];
+        for (int i = sub0; i < (int)(sizeof(InfTables) / 16); i += kDecSubLanes) dst[i] = src[i];
     }
     __syncthreads();
     if (!live) return;
-    const uint16_t *lit = lit_s[grp];
+    const InfTables &L = tab_s[grp];
+    const uint16_t *lit = L.lit;
     uint16_t *o16 = cells + s.cell_off + k.out_off;
     const int nsub = T->nsub;
     bool bad = false;
@@ -961,7 +964,7 @@ __global__ __launch_bounds__(64) void zs_inf_decode_lane_kernel(const ParStream 
                 {
                     const uint16_t e = lit[b.peek(kInfLitBits)];
                     if (e != kInfEsc) sym = e >> 4, clen = e & 15;
-                    else sym = lane_slow(b, T->lcount, T->lsym, clen);
+                    else sym = lane_slow(b, L.lcount, L.lsym, clen);
                 }
                 if (sym < 0 || clen > b.cnt) {
                     bad = true;
@@ -990,9 +993,9 @@ __global__ __launch_bounds__(64) void zs_inf_decode_lane_kernel(const ParStream 
                 b.fill();
                 int ds, dl;
                 {
-                    const uint16_t e = T->dist[b.peek(kInfDistBits)];
+                    const uint16_t e = L.dist[b.peek(kInfDistBits)];
                     if (e != kInfEsc) ds = e >> 4, dl = e & 15;
-                    else ds = lane_slow(b, T->dcount, T->dsym, dl);
+                    else ds = lane_slow(b, L.dcount, L.dsym, dl);
                 }
                 if (ds < 0 || ds >= 30 || dl > b.cnt) {
                     bad = true;
@@ -1014,18 +1017,50 @@ __global__ __launch_bounds__(64) void zs_inf_decode_lane_kernel(const ParStream 
             }
             if (cp_left > 0) {
                 uint32_t v[kDecCopy];
+                const int first = cp_sp0 + cp_off;
+                if (cp_off + kDecCopy <= cp_dist && first >= S) {
+                    // 8 consecutive cells of the lane's own sub-block: one 16-byte load past L1 (what lies beyond the match's
+                    // last source cell is not used)
+                    u32x4 r;
+                    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(r) : "v"(o16 + first) : "memory");
 #pragma unroll
-                for (int u = 0; u < kDecCopy; u++) {
-                    const int sp = cp_sp0 + cp_off;
-                    // before the block: marker of byte 32768 + sp of the window (0x8000 | (32768 + sp) is sp's low 16 bits);
-                    // before the sub-block: its distance from S; else the cell itself
-                    v[u] = sp < 0 ? (uint32_t)sp : (uint32_t)(sub_mark - sp);
-                    if (u < cp_left && sp >= S) v[u] = cell_load(o16 + sp);
-                    cp_off = cp_off + 1 == cp_dist ? 0 : cp_off + 1;
+                    for (int u = 0; u < kDecCopy; u++) v[u] = (r[u >> 1] >> (16 * (u & 1))) & 0xFFFFu;
+                    cp_off = cp_off + kDecCopy == cp_dist ? 0 : cp_off + kDecCopy;
+                } else {
+                    // cell by cell (a source that wraps inside the trip, or straddles S).  Before the block: marker of byte
+                    // 32768 + sp of the window (0x8000 | (32768 + sp) is sp's low 16 bits); before the sub-block: its
+                    // distance from S; else the cell itself, read past L1 -- the loads are issued together and waited for once
+                    uint32_t ld[kDecCopy];
+                    bool own[kDecCopy];
+#pragma unroll
+                    for (int u = 0; u < kDecCopy; u++) {
+                        const int sp = cp_sp0 + cp_off;
+                        v[u] = sp < 0 ? (uint32_t)sp : (uint32_t)(sub_mark - sp);
+                        own[u] = u < cp_left && sp >= S;
+                        ld[u] = 0;
+                        if (own[u]) asm volatile("global_load_ushort %0, %1, off sc1" : "=v"(ld[u]) : "v"(o16 + sp) : "memory");
+                        cp_off = cp_off + 1 == cp_dist ? 0 : cp_off + 1;
+                    }
+                    asm volatile("s_waitcnt vmcnt(0)"
+                                 : "+v"(ld[0]), "+v"(ld[1]), "+v"(ld[2]), "+v"(ld[3]), "+v"(ld[4]), "+v"(ld[5]), "+v"(ld[6]), "+v"(ld[7])
+                                 :
+                                 : "memory");
+#pragma unroll
+                    for (int u = 0; u < kDecCopy; u++) v[u] = own[u] ? ld[u] : v[u];
                 }
+                // One 16-byte store (at 2-byte alignment) for the trip's 8 cells while that stays inside the lane's own
+                // sub-block: the cells beyond the match's end are the lane's to write anyway, and it writes them (again)
+                // before any of its later matches can read them.  The pass is bound by the count of vector-memory
+                // instructions, whatever their width or their active lanes.
+                if (pos + kDecCopy <= E) {
+                    static_assert(kDecCopy == 8, "one 16-byte store per trip");
+                    *(uint4 *)(o16 + pos) = make_uint4((v[0] & 0xFFFFu) | (v[1] << 16), (v[2] & 0xFFFFu) | (v[3] << 16),
+                                                       (v[4] & 0xFFFFu) | (v[5] << 16), (v[6] & 0xFFFFu) | (v[7] << 16));
+                } else {
 #pragma unroll
-                for (int u = 0; u < kDecCopy; u++)
-                    if (u < cp_left) o16[pos + u] = (uint16_t)v[u];
+                    for (int u = 0; u < kDecCopy; u++)
+                        if (u < cp_left) o16[pos + u] = (uint16_t)v[u];
+                }
                 const int n = cp_left < kDecCopy ? cp_left : kDecCopy;
                 pos += n;
                 cp_left -= n;
