@@ -258,18 +258,27 @@ ZS_HD_NOINLINE inline int le_longest_match(LitEngine &e, int cur_match) {
     if (best_len == 0) best_len = 1;
     if (e.prev_length >= e.lv.good) chain_length >>= 2;
     if (nice > e.lookahead) nice = e.lookahead;
+    // One candidate is one round trip: the four bytes the reference tests (Deflate.cs:1072-1078) and the candidate's link
+    // are requested together, the scan's own bytes are kept in registers (the engine is a single dependency chain of LDS
+    // round trips; the tests in sequence were four of them)
+    const uint8_t s0 = scan[0], s1 = scan[1];
+    uint8_t sb0 = scan[best_len - 1], sb1 = scan[best_len];
     do {
         if (cur_match >= e.strstart) break;
         const uint8_t *m = e.window + cur_match;
-        if (m[best_len] != scan[best_len] || m[best_len - 1] != scan[best_len - 1] || m[0] != scan[0] || m[1] != scan[1])
-            continue;
-        const int len = le_match_len(scan, m);  // bytes 0 and 1 are known to match
-        if (len > best_len) {
-            ms = cur_match;
-            best_len = len;
-            if (len >= nice) break;
+        const uint8_t mb1 = m[best_len], mb0 = m[best_len - 1], m0 = m[0], m1 = m[1];
+        const int next = e.prev[cur_match & kWMask];
+        if (!((mb1 ^ sb1) | (mb0 ^ sb0) | (m0 ^ s0) | (m1 ^ s1))) {
+            const int len = le_match_len(scan, m);  // bytes 0 and 1 are known to match
+            if (len > best_len) {
+                ms = cur_match;
+                best_len = len;
+                if (len >= nice) break;
+                sb0 = scan[best_len - 1], sb1 = scan[best_len];
+            }
         }
-    } while ((cur_match = e.prev[cur_match & kWMask]) > limit && --chain_length != 0);
+        cur_match = next;
+    } while (cur_match > limit && --chain_length != 0);
     e.match_start = ms;
     return best_len < e.lookahead ? best_len : e.lookahead;
 }
