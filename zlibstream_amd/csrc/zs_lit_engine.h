@@ -97,19 +97,30 @@ ZS_HD void le_defaults(LitEngine &e) {
     e.nsyms = 0, e.nblocks = 0;
 }
 
+// On the device the engine's window, prev and CRC tables are always LDS (zs_tail_kernel, zs_fast_run_kernel), but the
+// struct holds generic pointers: an access through one is a flat instruction, whose wait covers the vector-memory
+// counter as well -- i.e. the acknowledgement of the head / symbol stores the engine has just issued.  The hot accessors
+// say where the memory is.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define ZS_LDS_PTR(T, p) ((__attribute__((address_space(3))) T *)(p))
+#else
+#define ZS_LDS_PTR(T, p) (p)
+#endif
 ZS_HD uint32_t le_hash(const LitEngine &e, uint32_t v) {
     if (e.hash_variant == kHashMul) return hash_mul(v) & kHashMask;
-    if (e.crc_tab) return crc32c_u32_tab(e.crc_tab, v) & kHashMask;
+    if (e.crc_tab) return crc32c_u32_tab(ZS_LDS_PTR(const uint32_t, e.crc_tab), v) & kHashMask;
     return crc32c_u32_slow(v) & kHashMask;
 }
-ZS_HD uint32_t le_load32(const uint8_t *p) {
+ZS_HD uint32_t le_load32(const uint8_t *pg) {
+    auto p = ZS_LDS_PTR(const uint8_t, pg);
     return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
 }
+ZS_HD uint8_t le_wbyte(const LitEngine &e, int i) { return ZS_LDS_PTR(const uint8_t, e.window)[i]; }
 // 8 bytes at any alignment, little-endian.  On the device three aligned dword loads and a funnel shift: the window is
 // in LDS behind a generic pointer, where byte loads cost a round trip each and misaligned wide loads are slow.
 ZS_HD uint64_t le_load64(const uint8_t *p) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    const uint32_t *q = (const uint32_t *)((uintptr_t)p & ~(uintptr_t)3);
+    auto q = ZS_LDS_PTR(const uint32_t, (const uint32_t *)((uintptr_t)p & ~(uintptr_t)3));
     const uint32_t a = q[0], b = q[1], c = q[2], sh = ((uint32_t)(uintptr_t)p & 3u) * 8u;
     const uint64_t lo = (uint64_t)a | ((uint64_t)b << 32);
     return sh ? (lo >> sh) | ((uint64_t)c << (64 - sh)) : lo;
@@ -166,7 +177,7 @@ ZS_HD int le_insert(LitEngine &e, int str) {
     uint32_t h = le_hash(e, le_load32(e.window + str + 2));
     int cur = e.head[h];
     if (cur != str) {
-        e.prev[str & kWMask] = (uint16_t)cur;
+        ZS_LDS_PTR(uint16_t, e.prev)[str & kWMask] = (uint16_t)cur;
         e.head[h] = (uint16_t)str;
     }
     return cur;
@@ -261,20 +272,24 @@ ZS_HD_NOINLINE inline int le_longest_match(LitEngine &e, int cur_match) {
     // One candidate is one round trip: the four bytes the reference tests (Deflate.cs:1072-1078) and the candidate's link
     // are requested together, the scan's own bytes are kept in registers (the engine is a single dependency chain of LDS
     // round trips; the tests in sequence were four of them)
-    const uint8_t s0 = scan[0], s1 = scan[1];
-    uint8_t sb0 = scan[best_len - 1], sb1 = scan[best_len];
+    auto wl = ZS_LDS_PTR(const uint8_t, e.window);
+    auto pl = ZS_LDS_PTR(const uint16_t, e.prev);
+    auto sc = wl + e.strstart;
+    const uint8_t s0 = sc[0], s1 = sc[1];
+    uint8_t sb0 = sc[best_len - 1], sb1 = sc[best_len];
     do {
         if (cur_match >= e.strstart) break;
         const uint8_t *m = e.window + cur_match;
-        const uint8_t mb1 = m[best_len], mb0 = m[best_len - 1], m0 = m[0], m1 = m[1];
-        const int next = e.prev[cur_match & kWMask];
+        auto ml = wl + cur_match;
+        const uint8_t mb1 = ml[best_len], mb0 = ml[best_len - 1], m0 = ml[0], m1 = ml[1];
+        const int next = pl[cur_match & kWMask];
         if (!((mb1 ^ sb1) | (mb0 ^ sb0) | (m0 ^ s0) | (m1 ^ s1))) {
             const int len = le_match_len(scan, m);  // bytes 0 and 1 are known to match
             if (len > best_len) {
                 ms = cur_match;
                 best_len = len;
                 if (len >= nice) break;
-                sb0 = scan[best_len - 1], sb1 = scan[best_len];
+                sb0 = sc[best_len - 1], sb1 = sc[best_len];
             }
         }
         cur_match = next;
@@ -333,7 +348,7 @@ ZS_HD_NOINLINE inline void le_run_slow(LitEngine &e, int lane, int nlanes) {
             if (e.lookahead == 0) {
                 if (!le_write_flushes(e)) break;
                 if (e.match_available != 0) {
-                    le_tally(e, 0, e.window[e.strstart - 1], lane);
+                    le_tally(e, 0, le_wbyte(e, e.strstart - 1), lane);
                     e.match_available = 0;
                 }
                 le_end_write(e, lane, nlanes);
@@ -364,7 +379,7 @@ ZS_HD_NOINLINE inline void le_run_slow(LitEngine &e, int lane, int nlanes) {
             e.strstart++;
             if (bflush) le_flush_block(e, false, lane);
         } else if (e.match_available != 0) {
-            bool bflush = le_tally(e, 0, e.window[e.strstart - 1], lane);
+            bool bflush = le_tally(e, 0, le_wbyte(e, e.strstart - 1), lane);
             if (bflush) le_flush_block(e, false, lane);
             e.strstart++;
             e.lookahead--;
@@ -375,7 +390,7 @@ ZS_HD_NOINLINE inline void le_run_slow(LitEngine &e, int lane, int nlanes) {
         }
     }
     if (e.match_available != 0) {
-        le_tally(e, 0, e.window[e.strstart - 1], lane);
+        le_tally(e, 0, le_wbyte(e, e.strstart - 1), lane);
         e.match_available = 0;
     }
     le_flush_block(e, true, lane);
@@ -416,7 +431,7 @@ ZS_HD_NOINLINE inline void le_run_fast(LitEngine &e, int lane, int nlanes) {
                 e.match_length = 0;
             }
         } else {
-            bflush = le_tally(e, 0, e.window[e.strstart], lane);
+            bflush = le_tally(e, 0, le_wbyte(e, e.strstart), lane);
             e.lookahead--;
             e.strstart++;
         }
@@ -481,7 +496,7 @@ ZS_HD_NOINLINE inline void le_run_rle(LitEngine &e, int lane, int nlanes) {
             e.strstart += e.match_length;
             e.match_length = 0;
         } else {
-            bflush = le_tally(e, 0, e.window[e.strstart], lane);
+            bflush = le_tally(e, 0, le_wbyte(e, e.strstart), lane);
             e.lookahead--;
             e.strstart++;
         }
