@@ -9,13 +9,17 @@
 //               literal/length and distance codes with an end-of-block code) is a candidate
 //               block start; a random position passes with negligible probability.
 //   D1 measure  one wave per candidate decodes its block without output: end bit offset,
-//               output size, BFINAL, validity.
+//               output size, BFINAL, validity -- its 64 lanes on 64 subsequences of the block's
+//               bits (Huffman streams self-synchronise; exits are chained to a proven prefix),
+//               which also leaves a checkpoint (bit, output position) per subsequence.
 //   C  chain    one wave per stream walks from the real first block (bit 16) through the
 //               candidates (end of block i = start of block i+1); blocks the finder cannot
 //               see (stored / fixed) are measured on the spot.  Output offsets follow.
-//   D2 decode   one wave per block decodes again into 16-bit cells: a literal byte, or a
-//               marker 0x8000 | i for "byte i of the 32 KiB window before this block"
-//               (copies of markers stay markers), so blocks decode independently.
+//   D2 decode   one wave per block, one lane per subsequence, decodes again into 16-bit cells:
+//               a literal byte, a marker 0x8000 | i for "byte i of the 32 KiB window before this
+//               block", or a marker for "the cell d positions before this lane's subsequence"
+//               (copies of markers stay markers), so subsequences and blocks decode
+//               independently; a flatten pass removes the second kind.
 //   W  windows  per stream, block by block: the resolved last 32 KiB after each block.
 //   R  resolve  every cell of every block -> byte, in parallel.
 //
