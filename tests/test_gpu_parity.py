@@ -363,6 +363,49 @@ def test_inflate_block_parallel_path_on_foreign_large_streams(engine):
         engine.inflate_batch([bytes(bad)], [len(want[1])])
 
 
+@pytest.mark.parametrize("seed", [int(x) for x in os.environ.get("ZS_FUZZ_SEEDS", "2024,7").split(",")])
+def test_inflate_fuzz_foreign_streams(engine, seed):
+    """Randomised streams from another encoder (levels, strategies, window sizes, memLevels, flush points of every kind,
+    data of every compressibility), large enough for the block-parallel path and small enough for the one-wave decoder,
+    in one batch: bytes and lengths must be zlib's."""
+    rng = np.random.default_rng(seed)
+    text = datagen.english(2 << 20, 5)
+    def piece(n):
+        kind = int(rng.integers(0, 5))
+        if kind == 0:
+            o = int(rng.integers(0, len(text) - n))
+            return text[o:o + n]
+        if kind == 1:
+            return bytes(n)
+        if kind == 2:
+            return rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+        if kind == 3:
+            period = bytes(rng.integers(0, 256, int(rng.integers(1, 40000)), dtype=np.uint8))
+            return (period * (n // len(period) + 1))[:n]
+        return rng.integers(0, 4, n, dtype=np.uint8).tobytes()  # low entropy: long codes are short, blocks are long
+    cases, want = [], []
+    for i in range(28):
+        total = int(rng.integers(1000, 3 << 20)) if i % 4 else int(rng.integers(400000, 6 << 20))
+        data = b"".join(piece(int(rng.integers(1, 400000))) for _ in range(1 + total // 200000))[:total]
+        level = int(rng.integers(0, 10))
+        strategy = [zlib.Z_DEFAULT_STRATEGY, zlib.Z_FILTERED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE, zlib.Z_FIXED][int(rng.integers(0, 5))]
+        co = zlib.compressobj(level, zlib.DEFLATED, int(rng.integers(9, 16)), int(rng.integers(1, 10)), strategy)
+        parts, off = [], 0
+        while off < len(data):
+            n = int(rng.integers(1, 500000))
+            parts.append(co.compress(data[off:off + n]))
+            off += n
+            mode = int(rng.integers(0, 6))
+            if mode < 3 and off < len(data):
+                parts.append(co.flush([zlib.Z_SYNC_FLUSH, zlib.Z_FULL_FLUSH, zlib.Z_BLOCK][mode]))
+        parts.append(co.flush())
+        cases.append(b"".join(parts))
+        want.append(data)
+    got = engine.inflate_batch(cases, [len(w) for w in want])
+    for i, (g_, w_) in enumerate(zip(got, want)):
+        assert g_ == w_, (i, len(g_), len(w_), len(cases[i]))
+
+
 def test_cpp_host_mirror(tmp_path):
     """The C++ host-side mirror of ZlibOutputStream / ZlibInputStream (include/zsgpu.hpp) replays the reference's
     EncodeDecode / EncodeDecodePerChunk tests through the C ABI; bytes are checked against the oracle."""
