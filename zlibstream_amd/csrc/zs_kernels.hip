@@ -361,6 +361,7 @@ __global__ __launch_bounds__(1024) void zs_match_kernel(const StreamDesc *sd, co
     uint32_t snap = 0;       // record for the K>>2 budget once it is known to differ from the final one, else 0
     int snapped = 0;
     uint32_t scan_end = 0, mask = 0;  // scan_end = bytes p+best-3 .. p+best; mask drops the byte before p when best == 2
+    uint32_t fmask = 0;               // the candidate's first bytes must match too: 3 of them while best == 2, then 4
     uint32_t sc0 = 0, sc1 = 0;        // bytes p .. p+7 (the first 8 bytes of every compare)
     // after a finished compare of `len` bytes against candidate c: take the improvement, count the candidate, move on
     auto after_compare = [&](int len) {
@@ -375,6 +376,7 @@ __global__ __launch_bounds__(1024) void zs_match_kernel(const StreamDesc *sd, co
         bdist = better ? p - c : bdist;
         if (better) scan_end = lds_u32(wb, p + len - 3);
         mask = better ? 0xFFFFFFFFu : mask;
+        fmask = better ? 0xFFFFFFFFu : fmask;
         const int nice_hit = better & (len >= nice);
         cl = 0;
         n_eval++;
@@ -415,6 +417,7 @@ __global__ __launch_bounds__(1024) void zs_match_kernel(const StreamDesc *sd, co
             cl = take ? 0 : cl;
             scan_end = take ? (uint32_t)first8 << 8 : scan_end;  // bytes p-1 .. p+2; the mask drops the byte before p
             mask = take ? 0xFFFFFF00u : mask;
+            fmask = take ? 0x00FFFFFFu : fmask;
             sc0 = take ? (uint32_t)first8 : sc0, sc1 = take ? (uint32_t)(first8 >> 32) : sc1;
         }
         if (!__ballot(st != 0)) break;
@@ -427,8 +430,15 @@ __global__ __launch_bounds__(1024) void zs_match_kernel(const StreamDesc *sd, co
             for (int u = 0; u < ZS_STEP_UNROLL; u++) {  // steps per look at the lane counts
                 const int l = wl[c];
                 const uint32_t e = lds_u32(wb, c + best - 3);
-                // a candidate can only beat `best` if bytes [best-3 .. best] match too (bytes [0 .. 2] when best == 2)
+#ifndef ZS_NO_FRONT_CHECK
+                // a candidate can only beat `best` if bytes [best-3 .. best] match too (bytes [0 .. 2] when best == 2) -- and
+                // its first bytes: the chain is keyed on bytes 2 .. 5, so most candidates that agree with the scan around
+                // `best` differ from it in bytes 0 and 1, and each of those would cost a visit to the compare phase
+                const uint32_t f = lds_u32(wb, c);
+                const int pass = (((e ^ scan_end) & mask) | ((f ^ sc0) & fmask)) == 0;
+#else
                 const int pass = ((e ^ scan_end) & mask) == 0;
+#endif
                 const int go = (st == 1) & !pass;
                 // leave the candidate: count it and follow its link; `cur_match > limit` is distance < kMaxDist
                 const int ne = n_eval + 1, nc = c - l;
