@@ -345,16 +345,16 @@ __global__ __launch_bounds__(1024) void zs_match_kernel(const StreamDesc *sd, co
     // pays for every path any of its lanes takes.  The common step (read the link and 4 prefilter bytes of the
     // candidate, move on) is ~20 instructions without branches; the compare and finish paths are several times
     // that, and with 64 walks per wave some lane needs one of them in nearly every round.  So the stepping phase
-    // keeps going with the lanes still in state 1 and lets the others wait until as many lanes wait as step
-    // (kWaitNum / kWaitDen), and only then runs the compare and finish phases once for all of them.
+    // keeps going with the lanes still in state 1 and lets the others wait until half as many lanes wait as step
+    // (nwait * kWaitNum >= nact * kWaitDen), and only then runs the compare and finish phases once for all of them.
 #ifndef ZS_WQ
-#define ZS_WQ 3
+#define ZS_WQ 2
 #endif
 #ifndef ZS_WD
-#define ZS_WD 2
+#define ZS_WD 1
 #endif
 #ifndef ZS_STEP_UNROLL
-#define ZS_STEP_UNROLL 2
+#define ZS_STEP_UNROLL 4
 #endif
     constexpr int kWaitNum = ZS_WQ, kWaitDen = ZS_WD;
     int st = 3, p = -1, c = 8, best = 2, bdist = 0, n_eval = 0, cl = 0;
