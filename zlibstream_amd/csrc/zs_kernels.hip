@@ -353,6 +353,9 @@ __global__ __launch_bounds__(1024) void zs_match_kernel(const StreamDesc *sd, co
 #ifndef ZS_WD
 #define ZS_WD 1
 #endif
+#ifndef ZS_PULL_REPS
+#define ZS_PULL_REPS 1
+#endif
 #ifndef ZS_STEP_UNROLL
 #define ZS_STEP_UNROLL 4
 #endif
@@ -393,7 +396,8 @@ __global__ __launch_bounds__(1024) void zs_match_kernel(const StreamDesc *sd, co
         }
         p = st == 3 ? -1 : p;
 #pragma unroll
-        for (int rep = 0; rep < 2; rep++) {  // a position without a usable link is done at once: its lane pulls again
+        for (int rep = 0; rep < ZS_PULL_REPS; rep++) {  // a position without a usable link is done at once; its lane pulls again
+                                                     // at the next visit (an immediate second pull cost more than the idle lane)
             const uint64_t need = __ballot(st == 3);
             if (!need) break;
             int base = 0;
