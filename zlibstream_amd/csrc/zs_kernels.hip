@@ -248,124 +248,44 @@ __global__ __launch_bounds__(1024) void zs_links_kernel(const StreamDesc *sd, co
     }
 }
 
-// ------------------------------------------------------------------ K2
-// 1024 threads per 16 Ki-position tile; the tile's 48 KiB of input and 96 KiB
-// of links are staged in LDS once, then every lane walks hash chains for one
-// position at a time, pulling the next position from a per-wave cursor as soon
-// as its walk ends (lanes of a wave have very different chain lengths).
-// Per main-loop iteration a lane does one unit of work: test a candidate and
-// compare its first 8 bytes, or compare 8 more bytes of a long match.
-__global__ __launch_bounds__(1024) void zs_match_kernel(const StreamDesc *sd, const uint2 *work, const uint16_t *link,
-                                                        uint2 *mm, LevelCfg lv, int strategy) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    uint8_t *wb = smem;
-    uint16_t *wl = (uint16_t *)(smem + kMatchLdsBytes);
-    uint2 w = work[blockIdx.x];
-    const StreamDesc s = sd[w.x];
-    const int64_t t0 = (int64_t)w.y * kMatchTile;
-    const int64_t n = s.n;
-    if (t0 > s.body_end) return;
-    const int64_t lo = t0 - kMatchBack;
-    const gcbytes in = as_global(s.in);
-    // ---- stage bytes (dword granularity, zero outside [0, n)) ----
-    {
-        // 16 bytes per lane (lo is a multiple of 16; the caller's buffer and the link array are 16-byte aligned
-        // in the common case), scalar fallback at the edges of the stream
-        const bool aligned = (((uintptr_t)in) & 15) == 0;
-        for (int i = threadIdx.x; i < kMatchLdsBytes / 16; i += 1024) {
-            int64_t a = lo + (int64_t)i * 16;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (a >= 0 && a + 15 < n && aligned) {
-                const u32x4 t = *(gcu32x4)(in + a);
-                v = make_uint4(t[0], t[1], t[2], t[3]);
-            } else if (a + 15 >= 0 && a < n) {
-                uint32_t t[4] = {0, 0, 0, 0};
-                for (int k = 0; k < 16; k++) {
-                    int64_t b = a + k;
-                    if (b >= 0 && b < n) t[k >> 2] |= (uint32_t)in[b] << (8 * (k & 3));
-                }
-                v = make_uint4(t[0], t[1], t[2], t[3]);
-            }
-            ((uint4 *)wb)[i] = v;
-        }
-        const uint16_t *lk = link + s.pos_off;  // pos_off is a multiple of 64 and the array 16-byte aligned
-        for (int i = threadIdx.x; i < kMatchLdsLinks / 8; i += 1024) {
-            int64_t a = lo + (int64_t)i * 8;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (a >= 0 && a + 7 < n) {
-                v = *(const uint4 *)(lk + a);
-            } else if (a + 7 >= 0 && a < n) {
-                uint32_t t[4] = {0, 0, 0, 0};
-                for (int k = 0; k < 8; k++) {
-                    int64_t b = a + k;
-                    if (b >= 0 && b < n) t[k >> 1] |= (uint32_t)lk[b] << (16 * (k & 1));
-                }
-                v = make_uint4(t[0], t[1], t[2], t[3]);
-            }
-            // LDS form of a link: 0xFFFF = none (a step over it lands beyond kMaxDist, so the walk needs no
-            // separate test); a link onto position 0 is none too (Longest_match never visits position 0)
-            uint32_t t[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const uint32_t nz = (((t[k] & 0x7FFF7FFFu) + 0x7FFF7FFFu) | t[k]) & 0x80008000u;  // bit 15 of each non-zero half
-                t[k] |= ((nz ^ 0x80008000u) >> 15) * 0xFFFFu;
-            }
-            if (a <= kMaxDist && a + 7 >= 1) {
-                for (int k = 0; k < 8; k++) {
-                    const uint32_t d = (t[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
-                    if ((int64_t)d == a + k) t[k >> 1] |= 0xFFFFu << (16 * (k & 1));
-                }
-            }
-            ((uint4 *)wl)[i] = make_uint4(t[0], t[1], t[2], t[3]);
-        }
-    }
-    __syncthreads();
-
-    // ---- walk ----
-    int64_t pbeg = t0 < 1 ? 1 : t0;
-    int64_t pend = t0 + kMatchTile;
-    if (pend > (int64_t)s.body_end + 1) pend = (int64_t)s.body_end + 1;
-    const int wave = threadIdx.x >> 6, lane = lane_id();
-    // one position cursor for the workgroup (an LDS counter): waves that run out of long walks early keep pulling, so
-    // the idle tail is that of the tile, not of 16 separate ranges
-    __shared__ int wg_cursor;
-    if (threadIdx.x == 0) wg_cursor = (int)(pbeg - lo);
-    __syncthreads();
-    const int wendi = (int)(pend - lo);  // LDS-relative end of the tile's positions
-    if (t0 == 0 && threadIdx.x == 0) mm[s.pos_off] = make_uint2((uint32_t)wb[0 - lo] << 24, kNoMatch);  // position 0 is never searched
-    uint2 *om = mm + s.pos_off;
-    const int K = lv.chain, K4 = lv.chain >> 2, nice = lv.nice;
-
-    // Every lane owns one walk at a time, in one of four states:
-    //   1 stepping   at a candidate that has not been looked at yet
-    //   2 comparing  the candidate passed the 4-byte prefilter and needs a real compare (cl bytes done so far)
-    //   3 finished   result to be stored, then the lane pulls the next position from the wave cursor
-    //   0 idle       the cursor is exhausted
-    // The kernel is bound by vector-instruction issue (a wave64 instruction holds its SIMD for 4 cycles), and a wave
-    // pays for every path any of its lanes takes.  The common step (read the link and 4 prefilter bytes of the
-    // candidate, move on) is ~20 instructions without branches; the compare and finish paths are several times
-    // that, and with 64 walks per wave some lane needs one of them in nearly every round.  So the stepping phase
-    // keeps going with the lanes still in state 1 and lets the others wait until half as many lanes wait as step
-    // (nwait * kWaitNum >= nact * kWaitDen), and only then runs the compare and finish phases once for all of them.
+// Every lane owns one walk at a time, in one of four states:
+//   1 stepping   at a candidate that has not been looked at yet
+//   2 comparing  the candidate passed the 4-byte prefilter and needs a real compare (cl bytes done so far)
+//   3 finished   result to be stored, then the lane pulls the next position from the wave cursor
+//   0 idle       the cursor is exhausted
+// The kernel is bound by vector-instruction issue (a wave64 instruction holds its SIMD for 4 cycles), and a wave
+// pays for every path any of its lanes takes.  The common step (read the link and 4 prefilter bytes of the
+// candidate, move on) is ~20 instructions without branches; the compare and finish paths are several times
+// that, and with 64 walks per wave some lane needs one of them in nearly every round.  So the stepping phase
+// keeps going with the lanes still in state 1 and lets the others wait until half as many lanes wait as step
+// (nwait * kWaitNum >= nact * kWaitDen), and only then runs the compare and finish phases once for all of them.
 #ifndef ZS_WQ
 #define ZS_WQ 2
 #endif
 #ifndef ZS_WD
 #define ZS_WD 1
 #endif
-#ifndef ZS_PULL_REPS
-#define ZS_PULL_REPS 1
+#ifndef ZS_RUN
+#define ZS_RUN 2
 #endif
 #ifndef ZS_STEP_UNROLL
 #define ZS_STEP_UNROLL 4
 #endif
+// The walk of one tile by one wave's lanes (zs_match_kernel below).  RUNS: positions are handed out in runs of ZS_RUN
+// per lane instead of one at a time, and the match found at p bounds what the same distance gives at p + 1 (the hint).
+template <bool RUNS>
+__device__ __forceinline__ void match_walk(const uint8_t *wb, const uint16_t *wl, uint2 *om, int64_t lo, int wendi, int *wg_cursor,
+                                           int K, int K4, int nice, int lane) {
     constexpr int kWaitNum = ZS_WQ, kWaitDen = ZS_WD;
+    constexpr int kRun = RUNS ? ZS_RUN : 1;
     int st = 3, p = -1, c = 8, best = 2, bdist = 0, n_eval = 0, cl = 0;
     uint32_t snap = 0;       // record for the K>>2 budget once it is known to differ from the final one, else 0
     int snapped = 0;
     uint32_t scan_end = 0, mask = 0;  // scan_end = bytes p+best-3 .. p+best; mask drops the byte before p when best == 2
     uint32_t fmask = 0;               // the candidate's first bytes must match too: 3 of them while best == 2, then 4
     uint32_t sc0 = 0, sc1 = 0;        // bytes p .. p+7 (the first 8 bytes of every compare)
+    int run_next = 0, run_end = 0;    // the lane's run of positions: next one to take, end
+    int hint_l = 0, hint_d = 0;       // match found at the position just before p (0: none, or p does not follow it)
     // after a finished compare of `len` bytes against candidate c: take the improvement, count the candidate, move on
     auto after_compare = [&](int len) {
         len = len > kMaxMatch ? kMaxMatch : len;
@@ -389,31 +309,62 @@ __global__ __launch_bounds__(1024) void zs_match_kernel(const StreamDesc *sd, co
         st = stop ? 3 : 1;
     };
     for (;;) {
-        // ---- finish phase: store results, pull new positions (written with selects: every lane runs every line)
+        // ---- finish phase: store results, take new positions (written with selects: every lane runs every line).
+        // A lane takes runs of kRun consecutive positions: one counter update per run, and the match found at p bounds
+        // what the same distance gives at p + 1 from below (hint_l - 1 equal bytes are known before any compare) -- the
+        // long matches of image rows and runs are then compared over their last bytes only.
         if (st == 3 && p >= 0) {
             const uint32_t rec = best >= kMinMatch ? pack_match(best, bdist) : kNoMatch;
             om[(int64_t)p + lo] = make_uint2(rec | (sc0 << 24), snapped ? snap : rec);  // sc0's low byte is the byte at p
+            if constexpr (RUNS) hint_l = best >= kMinMatch ? best : 0, hint_d = bdist;
         }
         p = st == 3 ? -1 : p;
-#pragma unroll
-        for (int rep = 0; rep < ZS_PULL_REPS; rep++) {  // a position without a usable link is done at once; its lane pulls again
-                                                     // at the next visit (an immediate second pull cost more than the idle lane)
+        if constexpr (!RUNS) {
+            // one position per lane and visit, neighbouring lanes taking neighbouring positions
             const uint64_t need = __ballot(st == 3);
-            if (!need) break;
-            int base = 0;
-            if (lane == 0) base = atomicAdd(&wg_cursor, (int)__builtin_popcountll(need));
-            base = __builtin_amdgcn_readfirstlane(base);
-            if (base >= wendi) {  // nothing left in the tile
-                st = st == 3 ? 0 : st;
-                break;
+            if (need) {
+                int base = 0;
+                if (lane == 0) base = atomicAdd(wg_cursor, (int)__builtin_popcountll(need));
+                base = __builtin_amdgcn_readfirstlane(base);
+                const int mine = base + __builtin_popcountll(need & lanemask_lt());
+                const bool take = st == 3 && mine < wendi, dry = st == 3 && mine >= wendi;
+                const int q = take ? mine : 8;  // lanes that take nothing read an in-range dummy
+                const int l = wl[q];
+                const uint64_t first8 = lds_u64(wb, q);
+                const bool has = l != 0xFFFF;  // link distances are already <= kMaxDist
+                // a position without a usable link is done at once; its lane takes its next one at the next visit (an
+                // immediate second pull cost more than the idle lane)
+                if (take && !has) om[(int64_t)mine + lo] = make_uint2((uint32_t)first8 << 24, kNoMatch);
+                p = take && has ? mine : p;
+                c = take ? mine - (has ? l : 0) : c;
+                st = take ? (has ? 1 : 3) : (dry ? 0 : st);
+                best = take ? 2 : best, bdist = take ? 0 : bdist, n_eval = take ? 0 : n_eval, snapped = take ? 0 : snapped;
+                cl = take ? 0 : cl;
+                scan_end = take ? (uint32_t)first8 << 8 : scan_end;  // bytes p-1 .. p+2; the mask drops the byte before p
+                mask = take ? 0xFFFFFF00u : mask;
+                fmask = take ? 0x00FFFFFFu : fmask;
+                sc0 = take ? (uint32_t)first8 : sc0, sc1 = take ? (uint32_t)(first8 >> 32) : sc1;
             }
-            const int mine = base + __builtin_popcountll(need & lanemask_lt());
+        } else if (__ballot(st == 3)) {
+            const bool cont = st == 3 && run_next < run_end;  // the next position of the lane's own run
+            const uint64_t need = __ballot(st == 3 && !cont);
+            int base = 0;
+            if (need) {
+                if (lane == 0) base = atomicAdd(wg_cursor, kRun * (int)__builtin_popcountll(need));
+                base = __builtin_amdgcn_readfirstlane(base);
+            }
+            const int fresh = base + kRun * (int)__builtin_popcountll(need & lanemask_lt());
+            const int mine = cont ? run_next : fresh;
             const bool take = st == 3 && mine < wendi, dry = st == 3 && mine >= wendi;
+            if (st == 3 && !cont) run_end = fresh + kRun < wendi ? fresh + kRun : wendi, hint_l = 0;
+            run_next = st == 3 ? mine + 1 : run_next;
             const int q = take ? mine : 8;  // lanes that take nothing read an in-range dummy
             const int l = wl[q];
             const uint64_t first8 = lds_u64(wb, q);
             const bool has = l != 0xFFFF;  // link distances are already <= kMaxDist
+            // a position without a usable link is done at once; its lane takes its next one at the next visit
             if (take && !has) om[(int64_t)mine + lo] = make_uint2((uint32_t)first8 << 24, kNoMatch);
+            hint_l = take && !has ? 0 : hint_l;
             p = take && has ? mine : p;
             c = take ? mine - (has ? l : 0) : c;
             st = take ? (has ? 1 : 3) : (dry ? 0 : st);
@@ -454,9 +405,13 @@ __global__ __launch_bounds__(1024) void zs_match_kernel(const StreamDesc *sd, co
         }
         // ---- compare phase.  First 8 bytes of every compare against the cached bytes of p (most end here) ...
         if (st == 2 && cl == 0) {
-            const uint64_t x = lds_u64(wb, c) ^ ((uint64_t)sc0 | ((uint64_t)sc1 << 32));
-            if (x) after_compare((int)(__builtin_ctzll(x) >> 3));
-            else cl = 8;
+            if (RUNS && hint_l > 16 && p - c == hint_d) {
+                cl = (hint_l - 1) & ~7;  // the same distance matched hint_l bytes one position earlier
+            } else {
+                const uint64_t x = lds_u64(wb, c) ^ ((uint64_t)sc0 | ((uint64_t)sc1 << 32));
+                if (x) after_compare((int)(__builtin_ctzll(x) >> 3));
+                else cl = 8;
+            }
         }
         // ... then up to 32 more per visit for the lanes inside a long match (skipped by the wave when there is none)
         for (int r = 0; r < 4 && __ballot(st == 2 && cl != 0); r++) {
@@ -471,6 +426,110 @@ __global__ __launch_bounds__(1024) void zs_match_kernel(const StreamDesc *sd, co
             }
         }
     }
+}
+
+// ------------------------------------------------------------------ K2
+// 1024 threads per 16 Ki-position tile; the tile's 48 KiB of input and 96 KiB
+// of links are staged in LDS once, then every lane walks hash chains for one
+// position at a time, pulling the next position from a per-wave cursor as soon
+// as its walk ends (lanes of a wave have very different chain lengths).
+// Per main-loop iteration a lane does one unit of work: test a candidate and
+// compare its first 8 bytes, or compare 8 more bytes of a long match.
+__global__ __launch_bounds__(1024) void zs_match_kernel(const StreamDesc *sd, const uint2 *work, const uint16_t *link,
+                                                        uint2 *mm, LevelCfg lv, int strategy) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint8_t *wb = smem;
+    uint16_t *wl = (uint16_t *)(smem + kMatchLdsBytes);
+    uint2 w = work[blockIdx.x];
+    const StreamDesc s = sd[w.x];
+    const int64_t t0 = (int64_t)w.y * kMatchTile;
+    const int64_t n = s.n;
+    if (t0 > s.body_end) return;
+    __shared__ int wg_same;
+    if (threadIdx.x == 0) wg_same = 0;
+    __syncthreads();
+    const int64_t lo = t0 - kMatchBack;
+    const gcbytes in = as_global(s.in);
+    // ---- stage bytes (dword granularity, zero outside [0, n)) ----
+    {
+        // 16 bytes per lane (lo is a multiple of 16; the caller's buffer and the link array are 16-byte aligned
+        // in the common case), scalar fallback at the edges of the stream
+        const bool aligned = (((uintptr_t)in) & 15) == 0;
+        for (int i = threadIdx.x; i < kMatchLdsBytes / 16; i += 1024) {
+            int64_t a = lo + (int64_t)i * 16;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (a >= 0 && a + 15 < n && aligned) {
+                const u32x4 t = *(gcu32x4)(in + a);
+                v = make_uint4(t[0], t[1], t[2], t[3]);
+            } else if (a + 15 >= 0 && a < n) {
+                uint32_t t[4] = {0, 0, 0, 0};
+                for (int k = 0; k < 16; k++) {
+                    int64_t b = a + k;
+                    if (b >= 0 && b < n) t[k >> 2] |= (uint32_t)in[b] << (8 * (k & 3));
+                }
+                v = make_uint4(t[0], t[1], t[2], t[3]);
+            }
+            ((uint4 *)wb)[i] = v;
+        }
+        const uint16_t *lk = link + s.pos_off;  // pos_off is a multiple of 64 and the array 16-byte aligned
+        int n_same = 0;
+        for (int i = threadIdx.x; i < kMatchLdsLinks / 8; i += 1024) {
+            int64_t a = lo + (int64_t)i * 8;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (a >= 0 && a + 7 < n) {
+                v = *(const uint4 *)(lk + a);
+            } else if (a + 7 >= 0 && a < n) {
+                uint32_t t[4] = {0, 0, 0, 0};
+                for (int k = 0; k < 8; k++) {
+                    int64_t b = a + k;
+                    if (b >= 0 && b < n) t[k >> 1] |= (uint32_t)lk[b] << (16 * (k & 1));
+                }
+                v = make_uint4(t[0], t[1], t[2], t[3]);
+            }
+            // eight positions in a row whose previous occurrence lies at one and the same distance: the inside of a long
+            // match (image rows, runs); counted to choose how positions are handed out (below)
+            n_same += v.x != 0 && v.x == v.y && v.y == v.z && v.z == v.w && (v.x >> 16) == (v.x & 0xFFFFu);
+            // LDS form of a link: 0xFFFF = none (a step over it lands beyond kMaxDist, so the walk needs no
+            // separate test); a link onto position 0 is none too (Longest_match never visits position 0)
+            uint32_t t[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t nz = (((t[k] & 0x7FFF7FFFu) + 0x7FFF7FFFu) | t[k]) & 0x80008000u;  // bit 15 of each non-zero half
+                t[k] |= ((nz ^ 0x80008000u) >> 15) * 0xFFFFu;
+            }
+            if (a <= kMaxDist && a + 7 >= 1) {
+                for (int k = 0; k < 8; k++) {
+                    const uint32_t d = (t[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
+                    if ((int64_t)d == a + k) t[k >> 1] |= 0xFFFFu << (16 * (k & 1));
+                }
+            }
+            ((uint4 *)wl)[i] = make_uint4(t[0], t[1], t[2], t[3]);
+        }
+        if (n_same) atomicAdd(&wg_same, n_same);
+    }
+    __syncthreads();
+
+    // ---- walk ----
+    int64_t pbeg = t0 < 1 ? 1 : t0;
+    int64_t pend = t0 + kMatchTile;
+    if (pend > (int64_t)s.body_end + 1) pend = (int64_t)s.body_end + 1;
+    const int wave = threadIdx.x >> 6, lane = lane_id();
+    // one position cursor for the workgroup (an LDS counter): waves that run out of long walks early keep pulling, so
+    // the idle tail is that of the tile, not of 16 separate ranges
+    __shared__ int wg_cursor;
+    if (threadIdx.x == 0) wg_cursor = (int)(pbeg - lo);
+    __syncthreads();
+    const int wendi = (int)(pend - lo);  // LDS-relative end of the tile's positions
+    if (t0 == 0 && threadIdx.x == 0) mm[s.pos_off] = make_uint2((uint32_t)wb[0 - lo] << 24, kNoMatch);  // position 0 is never searched
+    uint2 *om = mm + s.pos_off;
+    const int K = lv.chain, K4 = lv.chain >> 2, nice = lv.nice;
+
+    // Positions are handed out one at a time -- neighbouring lanes then walk neighbouring positions, whose candidates are
+    // neighbours too: their LDS reads fall into the same words -- unless the tile is mostly the inside of long matches
+    // (image rows, runs): then in runs per lane, for the sake of the hint.  Two instances of the walk, so that a text tile
+    // pays nothing for the other kind.
+    if (wg_same * 4 > kMatchLdsLinks / 8) match_walk<true>(wb, wl, om, lo, wendi, &wg_cursor, K, K4, nice, lane);
+    else match_walk<false>(wb, wl, om, lo, wendi, &wg_cursor, K, K4, nice, lane);
 }
 
 // ------------------------------------------------------------------ parse-segment tables (StreamDesc)
