@@ -198,8 +198,14 @@ static void parse_chunked(Model &m, int64_t &p_out, int &kind_out, uint32_t &pen
         // jump table of the chunk, three rows (R, L-or-XK, XK4) as K3 builds it with 512 threads and in-place jumping passes
         ChunkGeo g = chunk_geo(c);
         int64_t ce = std::min<int64_t>(g.ce, m.body_end + 1);
-        for (int row = 0; row < 3; row++)
-            for (int64_t p = g.cs; p < ce; p++) tbl[row * kChunk + (int)(p - g.cs)] = node_step3(macc, row, p, g.cs, ce, m.lv);
+        for (int64_t p = g.cs; p < ce; p++) {
+            uint32_t r[3];
+            node_step3_all(macc, p, g.cs, ce, m.lv, r[0], r[1], r[2]);  // what K3 runs; must agree with the per-node form
+            for (int row = 0; row < 3; row++) {
+                if (r[row] != node_step3(macc, row, p, g.cs, ce, m.lv)) { printf("node_step3_all differs at %ld row %d\n", (long)p, row); exit(1); }
+                tbl[row * kChunk + (int)(p - g.cs)] = r[row];
+            }
+        }
         for (int r = 0; r < 4; r++)  // deliberately unfinished: chunk_exit_by_table3 must not depend on finished entries
             for (int row = 0; row < 3; row++)
                 for (int64_t p = g.cs; p < ce; p++) {

@@ -625,9 +625,10 @@ __global__ __launch_bounds__(512) void zs_chunkmap_kernel(const StreamDesc *sd, 
     if (ce > (int64_t)s.body_end + 1) ce = (int64_t)s.body_end + 1;
     const int len = (int)(ce - g.cs);
     LdsAcc acc{as_global(s.in), fk, fk4, g.cs - 1, tab, hash_variant};
-    for (int i = threadIdx.x; i < 3 * kChunk; i += 512) {
-        const int row = i >> kChunkBits, off = i & (kChunk - 1);
-        if (off < len) tbl[i] = node_step3(acc, row, g.cs + off, g.cs, ce, lv);
+    for (int off = threadIdx.x; off < len; off += 512) {
+        uint32_t r0, r1, r2;
+        node_step3_all(acc, g.cs + off, g.cs, ce, lv, r0, r1, r2);
+        tbl[off] = r0, tbl[kChunk + off] = r1, tbl[2 * kChunk + off] = r2;
     }
     __syncthreads();
     // two dependent lookups per pass: after pass r every entry jumps >= 3^r steps or reaches its exit (a step advances
