@@ -694,7 +694,7 @@ bool run_inflate_par(zs_ctx *c, const std::vector<int> &idx, const void *const *
     mark(0);
     hipLaunchKernelGGL(zs_inf_prefilter_kernel, dim3((unsigned)w_find.size()), dim3(256), 0, stream, d_ps, dev<uint2>(c->par_work),
                        dev<int32_t>(c->par_surv), dev<int32_t>(c->par_scnt));
-    hipLaunchKernelGGL(zs_inf_check_kernel, dim3((unsigned)w_find.size()), dim3(64), 0, stream, d_ps, dev<uint2>(c->par_work),
+    hipLaunchKernelGGL(zs_inf_check_kernel, dim3((unsigned)((w_find.size() + 1) / 2)), dim3(64), 0, stream, d_ps, dev<uint2>(c->par_work), (int)w_find.size(),
                        dev<int32_t>(c->par_surv), dev<int32_t>(c->par_scnt), dev<int64_t>(c->par_cbits), dev<int32_t>(c->par_ccnt));
     hipLaunchKernelGGL(zs_inf_flatten_kernel, dim3((unsigned)m), dim3(256), 0, stream, d_ps, d_st, dev<int64_t>(c->par_cbits),
                        dev<int32_t>(c->par_ccnt), dev<ParCand>(c->par_cands), m);

@@ -525,38 +525,44 @@ __global__ __launch_bounds__(256) void zs_inf_prefilter_kernel(const ParStream *
 }
 
 // Full header check of a chunk's survivors: one lane each, one wave per chunk.
-__global__ __launch_bounds__(64) void zs_inf_check_kernel(const ParStream *ps, const uint2 *work, const int32_t *surv_g,
+// (a chunk has ~30 survivors: two chunks share a wave, 32 lanes each)
+__global__ __launch_bounds__(64) void zs_inf_check_kernel(const ParStream *ps, const uint2 *work, int nwork, const int32_t *surv_g,
                                                           const int32_t *surv_cnt, int64_t *cand_bits, int32_t *cand_cnt) {
-    __shared__ int64_t found[kFindMaxCand];
-    __shared__ int nfound;
-    const uint2 w = work[blockIdx.x];
+    __shared__ int64_t found[2][kFindMaxCand];
+    __shared__ int nfound[2];
+    const int half = threadIdx.x >> 5, hl = threadIdx.x & 31;
+    const int wi = blockIdx.x * 2 + half;
+    const bool live = wi < nwork;
+    const uint2 w = work[live ? wi : 0];
     const ParStream s = ps[w.x];
     const int chunk = (int)w.y;
-    const int nsurv = surv_cnt[blockIdx.x];
-    const int32_t *surv = surv_g + (int64_t)blockIdx.x * kFindMaxSurv;
-    if (threadIdx.x == 0) nfound = 0;
+    const int nsurv = live ? surv_cnt[wi] : 0;
+    const int32_t *surv = surv_g + (int64_t)wi * kFindMaxSurv;
+    if (hl == 0) nfound[half] = 0;
     __syncthreads();
     const int ns = nsurv < kFindMaxSurv ? nsurv : kFindMaxSurv;
-    for (int i = threadIdx.x; i < ns; i += 64) {
+    for (int i = hl; i < ns; i += 32) {
         const int64_t bit = (int64_t)chunk * kFindChunk * 8 + surv[i];
         if (find_check_header((const __attribute__((address_space(1))) uint8_t *)(uintptr_t)s.in, s.in_len, bit)) {
-            int at = atomicAdd(&nfound, 1);
-            if (at < kFindMaxCand) found[at] = bit;
+            int at = atomicAdd(&nfound[half], 1);
+            if (at < kFindMaxCand) found[half][at] = bit;
         }
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        if (nsurv > kFindMaxSurv) nfound = kFindMaxCand + 1;  // survivor list overflow: give the stream to the sequential decoder
-        int n = nfound < kFindMaxCand ? nfound : kFindMaxCand;
+    if (hl == 0 && live) {
+        int nf = nfound[half];
+        if (nsurv > kFindMaxSurv) nf = kFindMaxCand + 1;  // survivor list overflow: give the stream to the sequential decoder
+        int n = nf < kFindMaxCand ? nf : kFindMaxCand;
+        int64_t *fd = found[half];
         for (int i = 1; i < n; i++) {  // insertion sort: a handful of entries
-            int64_t v = found[i];
+            int64_t v = fd[i];
             int j = i - 1;
-            while (j >= 0 && found[j] > v) found[j + 1] = found[j], j--;
-            found[j + 1] = v;
+            while (j >= 0 && fd[j] > v) fd[j + 1] = fd[j], j--;
+            fd[j + 1] = v;
         }
         const int64_t base = ((int64_t)s.chunk_off + chunk) * kFindMaxCand;
-        for (int i = 0; i < n; i++) cand_bits[base + i] = found[i];
-        cand_cnt[s.chunk_off + chunk] = nfound;  // > kFindMaxCand flags an overflow
+        for (int i = 0; i < n; i++) cand_bits[base + i] = fd[i];
+        cand_cnt[s.chunk_off + chunk] = nf;  // > kFindMaxCand flags an overflow
     }
 }
 
