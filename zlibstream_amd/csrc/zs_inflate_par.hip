@@ -853,13 +853,40 @@ __global__ __launch_bounds__(64) void zs_inf_chain_kernel(const ParStream *ps, P
     // zlib header (Inflate.cs:120-170): anything unusual goes to the sequential decoder, which reports it
     if (s.in_len < 6 || (s.in[0] & 0x0F) != 8 || (s.in[0] >> 4) > 7 || (((unsigned)s.in[0] << 8) + s.in[1]) % 31 != 0 || (s.in[1] & 0x20)) ok = 0;
     InfBits b{s.in, s.in_len, 0, 0, 0, false, L.ibuf, -1};
+    // The walk is one dependency chain over the stream's blocks; its candidates come 64 at a time into the lanes'
+    // registers (lane l holds candidate cbase + l) and are read with wave-uniform shuffles, so that a step is not a chain
+    // of dependent loads.
+    int cbase = -(1 << 30);
+    int64_t m_bit = 0, m_end = 0, m_out = 0;
+    int m_ok = 0, m_bfinal = 0, m_tab = -1;
+    auto at = [&](int i) {  // make candidate i (wave-uniform, < ncand) resident; returns its lane
+        if (i < cbase || i >= cbase + 64) {
+            cbase = i;
+            const int idx = i + (int)threadIdx.x;
+            if (idx < ncand) {
+                const ParCand q = cd[idx];
+                m_bit = q.bit, m_end = q.end_bit, m_out = q.out_bytes, m_ok = q.ok, m_bfinal = q.bfinal, m_tab = q.tab;
+            }
+        }
+        return i - cbase;
+    };
+    // the lane index is wave-uniform: v_readlane, not a permute through the LDS
+    auto rl = [](int v, int k) { return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(k)); };
+    auto rl64 = [&](int64_t v, int k) {
+        return (int64_t)(((uint64_t)(uint32_t)rl((int)(v >> 32), k) << 32) | (uint32_t)rl((int)(uint32_t)v, k));
+    };
     while (ok) {
-        while (ci < ncand && cd[ci].bit < cur) ci++;
+        while (ci < ncand) {
+            const int kk = at(ci);  // (first: it may reload the registers that are read)
+            if (rl64(m_bit, kk) >= cur) break;
+            ci++;
+        }
         int64_t end, nbytes;
         int bfinal, tab = -1;
-        if (ci < ncand && cd[ci].bit == cur && cd[ci].ok) {
-            end = cd[ci].end_bit, nbytes = cd[ci].out_bytes, bfinal = cd[ci].bfinal;
-            tab = lane_decode ? cd[ci].tab : -1;
+        const int k = ci < ncand ? at(ci) : 0;
+        if (ci < ncand && rl64(m_bit, k) == cur && rl(m_ok, k)) {
+            end = rl64(m_end, k), nbytes = rl64(m_out, k), bfinal = rl(m_bfinal, k);
+            tab = lane_decode ? rl(m_tab, k) : -1;
         } else {
             // a block the finder does not report (stored / fixed codes): measure it here
             inf_seek(b, cur);
