@@ -1,18 +1,27 @@
 #!/usr/bin/env python3
 """bench.py -- deflate MB/s (input) at level 6 on 64 MiB buffers, one MI355X per rank.
 
-Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it
-is launched under torch.distributed.run, one rank per GPU.  A step is one pass
-of the hot path (zs_deflate_batch_device) over one 64 MiB pseudo-random-English
-buffer that is already resident in HBM; ranks compress independent buffers
-(no collective in the data path: BASELINE.json north_star), so scaling is weak.
-Rank 0 prints ONE JSON line.
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched under
+torch.distributed.run, one rank per GPU.  Rank 0 prints ONE JSON line.
+
+N = 1 (the default): `value` is BASELINE config 2 -- one 64 MiB pseudo-random-English buffer, level 6, resident in HBM
+when the timed region starts; a step is one pass of the hot path (zs_deflate_batch_device) over it.  The same run
+also measures the other BASELINE configs and the caller-visible paths and reports them under `secondary`:
+    sparse64_L1 / _L6 / _L9   config 3: 4096 x 4096 RGBA of the reference's GetImageBytes (DeflateSparseBenchmark.cs:53-99)
+    batch1024_L6              config 4 on one GPU: 1024 x 1 MiB buffers (the N = 1 point of the scaling workload)
+    inflate1g                 config 5: 16 x 64 MiB level-6 streams (seeds 0..15) -> 1 GiB, compared on the device
+    host_path                 H2D + pipeline + D2H through zs_deflate_batch, pageable and pinned host memory
+    stream_api                the C++ mirror of ZlibOutputStream / ZlibInputStream with the reference's 512-byte loop
+N > 1: config 4 -- the 1024 x 1 MiB batch is partitioned over the ranks (zs_partition, the library's own; no
+collective in the data path) and `value` is total input bytes / max-over-ranks time: strong scaling.
 """
 import argparse
 import ctypes
 import json
 import os
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -22,28 +31,47 @@ import torch  # noqa: E402  (must precede the engine: shared HIP runtime, see _n
 import torch.distributed as dist  # noqa: E402
 
 from zlibstream_amd import Engine, datagen, deflate_bound  # noqa: E402
+from zlibstream_amd.shard import partition  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+BATCH_BUFFERS = 1024   # BASELINE config 4
+BATCH_BYTES = 1 << 20
 
 
+# ---------------------------------------------------------------- CPU legs (the oracle is only ever the baseline / checker)
 def oracle_lib():
-    """CPU baseline leg only: the oracle (bit-exact restatement of the reference's managed path)."""
     from zlibstream_amd import build
     L = ctypes.CDLL(build.build_oracle())
     L.zso_compress_stream.restype = ctypes.c_size_t
     L.zso_compress_stream.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int,
                                       ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_char_p, ctypes.c_size_t,
                                       ctypes.c_void_p]
+    L.zso_inflate_oneshot.restype = ctypes.c_int
+    L.zso_inflate_oneshot.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t,
+                                      ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t),
+                                      ctypes.POINTER(ctypes.c_char_p)]
     return L
 
 
-def cpu_baseline(data, level, budget_s=20.0, name="english64"):
+def cpu_info():
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"cpu_model": model, "nproc": os.cpu_count(), "usable_cores": len(os.sched_getaffinity(0))}
+
+
+def cpu_baseline(data, level, budget_s=15.0, name="english64"):
+    """The bit-exact C restatement of the reference's managed path (oracle/, -O2), 1 thread, on a bounded sample."""
     L = oracle_lib()
     cap = len(data) + len(data) // 8 + 1024
     out = ctypes.create_string_buffer(cap)
     sample = data
-    # one untimed pass on 4 MiB to size the sample for ~budget_s of CPU work
-    probe = data[:4 << 20]
+    probe = data[:4 << 20]  # one untimed pass on 4 MiB sizes the sample for ~budget_s of CPU work
     t = time.perf_counter()
     L.zso_compress_stream(probe, len(probe), None, 0, level, 0, 0, 0, out, cap, None)
     rate = len(probe) / (time.perf_counter() - t)
@@ -56,21 +84,208 @@ def cpu_baseline(data, level, budget_s=20.0, name="english64"):
     for _ in range(iters):
         n = L.zso_compress_stream(sample, len(sample), None, 0, level, 0, 0, 0, out, cap, None)
     dt = (time.perf_counter() - t) / iters
-    return {"value": round(len(sample) / dt / 1e6, 2), "unit": "MB/s", "cores": 1, "kind": "port",
-            "sample": "first %d bytes of the %s buffer, level %d, 1 thread, 1 warm-up + %d timed passes"
-                      % (len(sample), name, level, iters)}, out.raw[:n], len(sample)
+    res = {"value": round(len(sample) / dt / 1e6, 2), "unit": "MB/s", "cores": 1, "kind": "port",
+           "sample": "first %d bytes of the %s buffer, level %d, 1 thread, 1 warm-up + %d timed passes (Config.cs:51 uses 3 + 3)"
+                     % (len(sample), name, level, iters)}
+    res.update(cpu_info())
+    return res, out.raw[:n], len(sample)
 
 
-def pmc_traffic(kernel, args):
-    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/), for the workload they were taken on."""
-    if args.workload != "english64" or args.level != 6 or args.size != 64 << 20:
-        return None
+def cpu_inflate_baseline(z, out_len):
+    """oracle/zs_inflate_oracle.c (the restated managed inflater), 1 thread, one whole stream, 1 warm-up + 2 timed passes."""
+    L = oracle_lib()
+    out = ctypes.create_string_buffer(out_len)
+    olen, used, msg = ctypes.c_size_t(0), ctypes.c_size_t(0), ctypes.c_char_p()
+
+    def once():
+        rc = L.zso_inflate_oneshot(z, len(z), out, out_len, ctypes.byref(olen), ctypes.byref(used), ctypes.byref(msg))
+        assert rc == 1 and olen.value == out_len, (rc, olen.value, msg.value)  # 1 = ZSTREAMEND
+    once()
+    t = time.perf_counter()
+    for _ in range(2):
+        once()
+    dt = (time.perf_counter() - t) / 2
+    return {"value": round(out_len / dt / 1e6, 2), "unit": "MB/s (output)", "cores": 1, "kind": "port",
+            "sample": "one %d-byte level-6 stream -> %d bytes, 1 thread, 1 warm-up + 2 timed passes" % (len(z), out_len)}
+
+
+def pmc_traffic(kernel, tag):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/*pmc_traffic_<tag>.json), if any."""
     pdir = os.path.join(ROOT, "profiles")
-    cands = sorted(f for f in os.listdir(pdir) if "pmc_traffic_english64_L6" in f) if os.path.isdir(pdir) else []
+    cands = sorted(f for f in os.listdir(pdir) if f.endswith("pmc_traffic_%s.json" % tag)) if os.path.isdir(pdir) else []
     if not cands:
         return None
     k = json.load(open(os.path.join(pdir, cands[-1])))["kernels"].get(kernel)
     return k["hbm_bytes_corrected"] if k else None
+
+
+# ---------------------------------------------------------------- device legs
+class DeviceBatch:
+    """Buffers resident in HBM + their output buffers, and a timed loop over zs_deflate_batch_device."""
+
+    def __init__(self, eng, dev, datas):
+        self.eng, self.datas = eng, datas
+        self.n = sum(len(d) for d in datas)
+        self.d_ins = [torch.frombuffer(bytearray(d), dtype=torch.uint8).to(dev) for d in datas]
+        self.caps = [deflate_bound(len(d)) for d in datas]
+        self.d_outs = [torch.empty(c, dtype=torch.uint8, device=dev) for c in self.caps]
+        self.in_ptrs = [t.data_ptr() for t in self.d_ins]
+        self.in_lens = [len(d) for d in datas]
+        self.out_ptrs = [t.data_ptr() for t in self.d_outs]
+        self.out_lens = []
+
+    def step(self, level):
+        self.out_lens = self.eng.deflate_batch_device(self.in_ptrs, self.in_lens, self.out_ptrs, self.caps, level=level,
+                                                      stream=torch.cuda.current_stream().cuda_stream)
+
+    def timed(self, level, steps, warmup, barrier=lambda: None):
+        for _ in range(warmup):
+            self.step(level)
+        self.eng.set_profiling(True)
+        stage_sum = {}
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.step(level)
+            for k, v in self.eng.stage_ms().items():
+                if k:
+                    stage_sum[k] = stage_sum.get(k, 0.0) + v
+        torch.cuda.synchronize()
+        barrier()
+        dt = time.perf_counter() - t0
+        self.eng.set_profiling(False)
+        return dt, {k: v / steps for k, v in stage_sum.items()}
+
+    def stream_bytes(self, i):
+        return self.d_outs[i][:self.out_lens[i]].cpu().numpy().tobytes()
+
+    def check_roundtrip(self, every=1):
+        import zlib
+        for i in range(0, len(self.datas), every):
+            assert zlib.decompress(self.stream_bytes(i)) == self.datas[i], "device output %d does not inflate to its input" % i
+
+
+def roofline(stage_ms, alg_bytes, traffic=None):
+    dom = max(stage_ms, key=stage_ms.get)
+    achieved = alg_bytes / (stage_ms[dom] * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": "zs_%s_kernel" % dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
+            "kernel_ms": round(stage_ms[dom], 4)}
+
+
+def secondary_deflate(eng, dev, name, datas, level, steps, check_every=1):
+    b = DeviceBatch(eng, dev, datas)
+    dt, stage_ms = b.timed(level, steps, 1)
+    b.check_roundtrip(check_every)
+    total_out = sum(b.out_lens)
+    res = {"workload": name, "level": level, "buffers": len(datas), "input_bytes": b.n, "compressed_bytes": total_out,
+           "value": round(b.n * steps / dt / 1e6, 2), "unit": "MB/s", "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps,
+           "roundtrip": True, "roofline": roofline(stage_ms, b.n + total_out),
+           "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()}}
+    return res, b
+
+
+def secondary_inflate(eng, dev, steps, streams=16, size=64 << 20):
+    """BASELINE config 5: `streams` level-6 streams of english64-style buffers (seeds 0..streams-1) -> streams x size bytes."""
+    cap = deflate_bound(size)
+    d_in, d_z, z_len = [], [], []
+    for i in range(streams):
+        t = torch.frombuffer(bytearray(datagen.english(size, (datagen.GOLDEN + i) & datagen.MASK)), dtype=torch.uint8).to(dev)
+        z = torch.empty(cap, dtype=torch.uint8, device=dev)
+        n = eng.deflate_batch_device([t.data_ptr()], [size], [z.data_ptr()], [cap], level=6)[0]
+        d_in.append(t), d_z.append(z[:n].clone()), z_len.append(n)
+        del z
+    outs = [torch.empty(size, dtype=torch.uint8, device=dev) for _ in range(streams)]
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        return eng.inflate_batch_device([z.data_ptr() for z in d_z], z_len, [o.data_ptr() for o in outs], [size] * streams, stream=stream)
+    step()
+    eng.set_profiling(True)
+    stage_sum = {}
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        lens = step()
+        for k, v in eng.stage_ms().items():
+            if k:
+                stage_sum[k] = stage_sum.get(k, 0.0) + v
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    eng.set_profiling(False)
+    ok = all(lens[i] == size and torch.equal(outs[i], d_in[i]) for i in range(streams))
+    stage_ms = {k: v / steps for k, v in stage_sum.items()}
+    # a single stream alone (what one ZlibInputStream sees once its input is complete)
+    one = [d_z[0].data_ptr()], [z_len[0]], [outs[0].data_ptr()], [size]
+    eng.inflate_batch_device(*one, stream=stream)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(steps):
+        eng.inflate_batch_device(*one, stream=stream)
+    torch.cuda.synchronize()
+    dt1 = (time.perf_counter() - t1) / steps
+    z0 = d_z[0].cpu().numpy().tobytes()
+    return {"workload": "inflate1g: %d level-6 zlib streams of english64-style buffers (seeds 0..%d), %d bytes each -> %d bytes"
+                        % (streams, streams - 1, size, streams * size),
+            "value": round(streams * size / dt / 1e6, 2), "unit": "MB/s (output)", "ms_per_step": round(dt * 1e3, 3), "steps": steps,
+            "compressed_bytes": sum(z_len), "bit_exact_roundtrip_on_device": bool(ok),
+            "single_stream": {"value": round(size / dt1 / 1e6, 2), "unit": "MB/s (output)", "ms": round(dt1 * 1e3, 3)},
+            "roofline": roofline(stage_ms, sum(z_len) + streams * size, pmc_traffic("zs_%s_kernel" % max(stage_ms, key=stage_ms.get), "inflate1g")),
+            "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
+            "cpu_baseline": cpu_inflate_baseline(z0, size)}
+
+
+def secondary_host_path(eng, data, level, reps=3):
+    """zs_deflate_batch: host pointers in and out, so H2D of the input and D2H of the stream are inside the timed region."""
+    import numpy as np
+    L, H = eng._lib, eng._h
+    cap = deflate_bound(len(data))
+    VP, I64, I32 = ctypes.c_void_p * 1, ctypes.c_int64 * 1, ctypes.c_int * 1
+    out_len, status = I64(), I32()
+    res = {}
+    for kind in ("pageable", "pinned"):
+        if kind == "pageable":
+            src = np.frombuffer(data, dtype=np.uint8).copy()
+            dst = np.empty(cap, dtype=np.uint8)
+            sp, dp = src.ctypes.data, dst.ctypes.data
+        else:
+            src_t = torch.frombuffer(bytearray(data), dtype=torch.uint8).pin_memory()
+            dst_t = torch.empty(cap, dtype=torch.uint8).pin_memory()
+            sp, dp = src_t.data_ptr(), dst_t.data_ptr()
+
+        def call():
+            rc = L.zs_deflate_batch(H, 1, VP(sp), I64(len(data)), VP(dp), I64(cap), out_len, status, level, 0, 0)
+            assert rc == 0
+        call()
+        t = time.perf_counter()
+        for _ in range(reps):
+            call()
+        dt = (time.perf_counter() - t) / reps
+        res[kind] = {"value": round(len(data) / dt / 1e6, 1), "unit": "MB/s", "ms": round(dt * 1e3, 2)}
+    res["workload"] = "english64 level %d through zs_deflate_batch (H2D + pipeline + D2H)" % level
+    return res
+
+
+def secondary_stream_api(data, level, reps=2):
+    from zlibstream_amd import build
+    exe = build.build_tools()
+    with tempfile.NamedTemporaryFile(suffix=".bin", delete=False) as f:
+        f.write(data)
+        path = f.name
+    try:
+        out = {}
+        for label, wr in (("one_write", 0), ("writes_of_1MiB", 1 << 20)):
+            r = subprocess.run([exe, path, str(level), str(reps), str(wr)], capture_output=True, text=True, timeout=600)
+            if r.returncode != 0:
+                out[label] = {"error": (r.stderr or r.stdout)[-300:]}
+            else:
+                out[label] = json.loads(r.stdout.strip().splitlines()[-1])
+        out["workload"] = ("english64 level %d through the C++ mirror of ZlibOutputStream / ZlibInputStream (include/zsgpu.hpp): "
+                           "512-byte Deflate chunks, 8 KiB Inflate chunks, host memory" % level)
+        return out
+    finally:
+        os.unlink(path)
 
 
 def main():
@@ -80,10 +295,13 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--level", type=int, default=6)
     ap.add_argument("--size", type=int, default=64 << 20)
-    ap.add_argument("--workload", default="english64", choices=["english64", "sparse64", "batch"])
-    ap.add_argument("--buffers", type=int, default=128, help="--workload batch: buffers per GPU (1 MiB each by default)")
+    ap.add_argument("--workload", default=None, choices=["english64", "sparse64", "batch"],
+                    help="default: english64 at --gpus 1, the sharded 1024 x 1 MiB batch at --gpus N > 1")
+    ap.add_argument("--buffers", type=int, default=BATCH_BUFFERS, help="--workload batch: buffers in the whole job")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--inflight", type=int, default=1, help="> 1: also report the secondary `pipelined` figure with that many contexts in flight")
+    ap.add_argument("--no-secondary", action="store_true", help="headline only")
+    ap.add_argument("--secondary-steps", type=int, default=3)
+    ap.add_argument("--inflight", type=int, default=1, help="> 1: also report the `pipelined` figure with that many contexts in flight")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -93,69 +311,58 @@ def main():
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-
-    if args.workload == "english64":
-        datas = [datagen.english(args.size, (datagen.GOLDEN + rank) & datagen.MASK)]
-    elif args.workload == "sparse64":
-        side = int((args.size // 4) ** 0.5)
-        datas = [datagen.sparse(side, args.size // (4 * side), y0=rank)]
-    else:  # BASELINE config 4 shape: independent 1 MiB buffers, even = english, odd = sparse rows
-        if args.size == 64 << 20:
-            args.size = 1 << 20
-        datas = [datagen.batch_buffer(rank * args.buffers + i, args.size) for i in range(args.buffers)]
-    data = datas[0]
-    n = sum(len(d) for d in datas)
-    eng = Engine(local_rank)
-    d_ins = [torch.frombuffer(bytearray(d), dtype=torch.uint8).to(dev) for d in datas]
-    caps = [deflate_bound(len(d)) for d in datas]
-    d_outs = [torch.empty(c, dtype=torch.uint8, device=dev) for c in caps]
-    d_out = d_outs[0]
-    stream = torch.cuda.current_stream().cuda_stream
-    in_ptrs, in_lens, out_ptrs = [t.data_ptr() for t in d_ins], [len(d) for d in datas], [t.data_ptr() for t in d_outs]
-    out_lens = []
-
-    def step():
-        out_lens[:] = eng.deflate_batch_device(in_ptrs, in_lens, out_ptrs, caps, level=args.level, stream=stream)
-        return out_lens[0]
-
-    for _ in range(args.warmup):
-        out_len = step()
+    workload = args.workload or ("english64" if world == 1 else "batch")
 
     def barrier():
         if world > 1:
             dist.barrier()
 
-    eng.set_profiling(True)
-    stage_sum = {}
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out_len = step()
-        for k, v in eng.stage_ms().items():
-            stage_sum[k] = stage_sum.get(k, 0.0) + v
-    torch.cuda.synchronize()
-    barrier()
-    dt = time.perf_counter() - t0
+    shard_note = None
+    if workload == "english64":
+        datas = [datagen.english(args.size, (datagen.GOLDEN + rank) & datagen.MASK)]
+    elif workload == "sparse64":
+        side = int((args.size // 4) ** 0.5)
+        datas = [datagen.sparse(side, args.size // (4 * side), y0=rank)]
+    else:
+        # BASELINE config 4: the whole job is `--buffers` independent 1 MiB buffers (even: english, odd: sparse rows); every
+        # rank derives the same partition from the sizes alone and generates only its own buffers
+        size = BATCH_BYTES if args.size == 64 << 20 else args.size
+        mine = partition([size] * args.buffers, world)[rank]
+        datas = [datagen.batch_buffer(i, size) for i in mine]
+        shard_note = {"buffers_total": args.buffers, "buffer_bytes": size, "buffers_this_rank": len(mine)}
+    eng = Engine(local_rank)
+    main_batch = DeviceBatch(eng, dev, datas)
+    n = main_batch.n
+    dt, stage_ms = main_batch.timed(args.level, args.steps, args.warmup, barrier)
+    total_n, total_out = n, sum(main_batch.out_lens)
+    per_rank_bytes = [n]
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    eng.set_profiling(False)
+        g = torch.zeros(world, dtype=torch.int64, device=dev)
+        g[rank] = n
+        dist.all_reduce(g)  # control plane only: per-rank input bytes for the report
+        per_rank_bytes = [int(x) for x in g.tolist()]
+        total_n = sum(per_rank_bytes)
+        o = torch.tensor([total_out], dtype=torch.int64, device=dev)
+        dist.all_reduce(o)
+        total_out = int(o.item())
+    main_batch.check_roundtrip(max(1, len(datas) // 8))
 
-    # Secondary figure, not `value`: the same steps with several engine contexts in flight (one host thread each), which
-    # fills the device during the single-workgroup phases of a lone stream (resolve, tree building, block offsets).
     pipelined = None
     if world == 1 and args.inflight > 1:
+        # the same steps with several engine contexts in flight (one host thread each): fills the device during the
+        # single-workgroup phases of a lone stream; never `value`
         import threading
         engs = [eng] + [Engine(local_rank) for _ in range(args.inflight - 1)]
-        outs2 = [d_outs] + [[torch.empty(c, dtype=torch.uint8, device=dev) for c in caps] for _ in range(args.inflight - 1)]
+        outs2 = [main_batch.d_outs] + [[torch.empty(c, dtype=torch.uint8, device=dev) for c in main_batch.caps] for _ in range(args.inflight - 1)]
         per = max(2, args.steps // args.inflight)
 
         def worker(j, reps):
             ptrs = [t.data_ptr() for t in outs2[j]]
             for _ in range(reps):
-                engs[j].deflate_batch_device(in_ptrs, in_lens, ptrs, caps, level=args.level)
+                engs[j].deflate_batch_device(main_batch.in_ptrs, main_batch.in_lens, ptrs, main_batch.caps, level=args.level)
 
         for j in range(1, args.inflight):
             worker(j, 1)  # workspace allocation outside the timed region
@@ -170,52 +377,70 @@ def main():
                      "value": round(n * per * args.inflight / dtp / 1e6, 2), "unit": "MB/s"}
         del engs[1:], outs2[1:]
 
-    # correctness of what was timed: the stream must inflate back to the input
-    import zlib
-    z = d_out[:out_len].cpu().numpy().tobytes()
-    assert zlib.decompress(z) == data, "device output does not inflate to the input"
-    for i in range(1, len(datas), max(1, len(datas) // 8)):
-        assert zlib.decompress(d_outs[i][:out_lens[i]].cpu().numpy().tobytes()) == datas[i]
-    total_out = sum(out_lens)
-
     if rank == 0:
-        stage_ms = {k: v / args.steps for k, v in stage_sum.items()}
-        dom = max(stage_ms, key=stage_ms.get)
-        alg_bytes = n + total_out  # one read of the input + one write of the stream, per buffer
-        achieved = alg_bytes / (stage_ms[dom] * 1e-3) / 1e9
+        kind = {"english64": "pseudo-random-English (Zipf words of alice29.txt)", "sparse64": "sparse RGBA image (reference GetImageBytes)",
+                "batch": "alternating english / sparse-row"}[workload]
+        if workload == "batch":
+            wl = ("batch%d: %d x %d-byte %s buffers partitioned over %d GPU(s) by size (zs_partition), level %d, zlib framing, "
+                  "inputs resident in HBM" % (args.buffers, args.buffers, shard_note["buffer_bytes"], kind, world, args.level))
+            metric = "deflate MB/s (input) at level %d, %d x %d-byte buffers" % (args.level, args.buffers, shard_note["buffer_bytes"])
+        else:
+            wl = ("%s: 1 x %d-byte %s buffer per GPU, level %d, zlib framing, inputs resident in HBM" % (workload, len(datas[0]), kind, args.level))
+            metric = "deflate MB/s (input) at level %d, 64 MiB buffers" % args.level
         line = {
-            "metric": "deflate MB/s (input) at level %d, %s" % (args.level, "64 MiB buffers" if args.workload != "batch"
-                                                                      else "%d x %d-byte buffers" % (len(datas), args.size)),
-            "value": round(world * n * args.steps / dt / 1e6, 2),
+            "metric": metric,
+            "value": round((total_n if workload == "batch" else world * n) * args.steps / dt / 1e6, 2),
             "unit": "MB/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if workload == "batch" else "weak",
             "vs_baseline": None,
             "dtype": "u8",
             "data": "synthetic",
-            "config": {"workload": "%s: %d x %d-byte %s buffer(s) per GPU, level %d, zlib framing, inputs resident in HBM"
-                                   % (args.workload, len(datas), len(data), {"english64": "pseudo-random-English (Zipf words of alice29.txt)",
-                                      "sparse64": "sparse RGBA image (reference GetImageBytes)",
-                                      "batch": "alternating english / sparse-row"}[args.workload], args.level),
-                       "level": args.level, "buffer_bytes": len(data), "buffers_per_gpu": len(datas), "compressed_bytes": total_out,
-                       "parallelism": "independent buffers, %d GPU(s), no collective" % world},
-            "roofline": {"bound": "hbm", "kernel": "zs_%s_kernel" % dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": pmc_traffic("zs_%s_kernel" % dom, args),
-                         "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": round(stage_ms[dom], 4)},
+            "config": {"workload": wl, "level": args.level, "buffer_bytes": len(datas[0]) if datas else 0, "buffers_per_gpu": len(datas),
+                       "compressed_bytes": total_out, "input_bytes_per_rank": per_rank_bytes,
+                       "parallelism": "independent buffers, %d GPU(s), no collective in the data path" % world},
+            "roofline": roofline(stage_ms, n + sum(main_batch.out_lens),
+                                 pmc_traffic("zs_%s_kernel" % max(stage_ms, key=stage_ms.get), "english64_L6")
+                                 if workload == "english64" and args.level == 6 and args.size == 64 << 20 else None),
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
         }
+        if shard_note:
+            line["config"]["shard"] = shard_note
         if pipelined:
             line["pipelined"] = pipelined
-        if not args.no_cpu_baseline and world == 1:  # the CPU leg runs on rank 0 of the single-GPU run only
-            cb, ref, sample_len = cpu_baseline(data, args.level, name=args.workload)
-            line["cpu_baseline"] = cb
-            if sample_len == n and len(datas) == 1:
-                line["compressed_size_delta_vs_cpu"] = out_len - len(ref)
-                line["bit_identical_to_cpu"] = bool(z == ref)
+        if world == 1:
+            data = datas[0]
+            if not args.no_cpu_baseline:  # the CPU leg runs on rank 0 of the single-GPU run only
+                cb, ref, sample_len = cpu_baseline(data, args.level, name=workload)
+                line["cpu_baseline"] = cb
+                if sample_len == n and len(datas) == 1:
+                    z = main_batch.stream_bytes(0)
+                    line["compressed_size_delta_vs_cpu"] = len(z) - len(ref)
+                    line["bit_identical_to_cpu"] = bool(z == ref)
+            if not args.no_secondary and workload == "english64":
+                sec = {}
+                ks = args.secondary_steps
+                del main_batch
+                torch.cuda.empty_cache()
+                sp = datagen.sparse(4096, 4096)
+                for lvl in (1, 6, 9):
+                    sec["sparse64_L%d" % lvl], b = secondary_deflate(eng, dev, "sparse64: 4096 x 4096 RGBA of GetImageBytes, 1 x 64 MiB", [sp], lvl, ks)
+                    del b
+                bufs = [datagen.batch_buffer(i, BATCH_BYTES) for i in range(BATCH_BUFFERS)]
+                sec["batch1024_L6"], b = secondary_deflate(eng, dev, "batch1024: 1024 x 1 MiB alternating english / sparse-row buffers on ONE GPU "
+                                                           "(the N = 1 point of the --gpus N workload)", bufs, 6, ks, check_every=64)
+                del b, bufs
+                torch.cuda.empty_cache()
+                sec["inflate1g"] = secondary_inflate(eng, dev, ks)
+                torch.cuda.empty_cache()
+                sec["host_path"] = secondary_host_path(eng, data, args.level)
+                eng.close()  # the stream-API tool is its own process with its own context
+                sec["stream_api"] = secondary_stream_api(data, args.level)
+                line["secondary"] = sec
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

@@ -103,6 +103,23 @@ ZS_API int zs_inflate_batch_device(zs_ctx *ctx, int n, const void *const *in, co
 ZS_API int zs_inflate_batch(zs_ctx *ctx, int n, const void *const *in, const int64_t *in_len, void *const *out,
                             const int64_t *out_cap, int64_t *out_len, int *status);
 
+/* ------------------------------------------------------------------ */
+/* Multi-GPU batch entry points (SURVEY.md 8(b) "zs_deflate_batch(..., device_mask)", 8(e)): the n independent
+ * buffers are partitioned over n_ctx contexts -- normally one per GPU of the node, zs_ctx_create(0 .. count-1) --
+ * by size (longest-processing-time, zs_partition), each context's share runs on its own host thread through the
+ * host-pointer batch call above, and results land in input order.  No collective and no peer traffic: a zlib
+ * stream cannot be split bit-exactly, so the buffer is the unit (DeflateCorpusBenchmark.cs:86-100 compresses
+ * independent buffers the same way, one after the other).  Contexts must be distinct; several may name the same
+ * device.  Returns ZS_OK or the first failing context's code; per-buffer codes in status[i]. */
+ZS_API int zs_device_count(void);
+/* part_of[i] = context index of buffer i; deterministic (ties: earlier buffer first, lower context first). */
+ZS_API int zs_partition(const int64_t *sizes, int n, int n_parts, int *part_of);
+ZS_API int zs_deflate_batch_multi(zs_ctx *const *ctxs, int n_ctx, int n, const void *const *in, const int64_t *in_len,
+                                  void *const *out, const int64_t *out_cap, int64_t *out_len, int *status, int level,
+                                  int strategy, int hash_variant);
+ZS_API int zs_inflate_batch_multi(zs_ctx *const *ctxs, int n_ctx, int n, const void *const *in, const int64_t *in_len,
+                                  void *const *out, const int64_t *out_cap, int64_t *out_len, int *status);
+
 /* Stage timing of the last *_batch_device call, measured with hipEvents on
  * the stream the kernels ran on.  Enable before the call. */
 ZS_API void zs_ctx_set_profiling(zs_ctx *ctx, int enable);

@@ -195,7 +195,8 @@ int zso_inflate_oneshot(const uint8_t *in, size_t in_len, uint8_t *out, size_t o
             huff blh;
             int r = build_huff(&blh, lengths, 19);
             if (r < 0) BAIL(ZSO_DATA_ERROR, "oversubscribed dynamic bit lengths tree");
-            if (r > 0) BAIL(ZSO_DATA_ERROR, "incomplete dynamic bit lengths tree");
+            /* incomplete is accepted only for a single code of length 1 (Huft_build, InfTree.cs:364: y != 0 && g != 1) */
+            if (r > 0 && !(blh.count[1] == 1 && 19 - blh.count[0] == 1)) BAIL(ZSO_DATA_ERROR, "incomplete dynamic bit lengths tree");
             uint32_t idx = 0;
             uint8_t ll[320];
             while (idx < nlen + ndist) {
@@ -224,12 +225,15 @@ int zso_inflate_oneshot(const uint8_t *in, size_t in_len, uint8_t *out, size_t o
             }
             r = build_huff(&lh, ll, (int)nlen);
             if (r < 0) BAIL(ZSO_DATA_ERROR, "oversubscribed literal/length tree");
-            if (r > 0 && (int)nlen - lh.count[0] != 1) BAIL(ZSO_DATA_ERROR, "incomplete literal/length tree");
+            if (r > 0 && !(lh.count[1] == 1 && (int)nlen - lh.count[0] == 1)) BAIL(ZSO_DATA_ERROR, "incomplete literal/length tree");
             r = build_huff(&dh, ll + nlen, (int)ndist);
             if (r < 0) BAIL(ZSO_DATA_ERROR, "oversubscribed distance tree");
-            if (r > 0 && (int)ndist - dh.count[0] != 1) {
-                if ((int)ndist - dh.count[0] == 0 && nlen > 257) BAIL(ZSO_DATA_ERROR, "empty distance tree with lengths");
-                if ((int)ndist - dh.count[0] > 1) BAIL(ZSO_DATA_ERROR, "incomplete distance tree");
+            if (r > 0) {
+                if ((int)ndist - dh.count[0] == 0) {
+                    if (nlen > 257) BAIL(ZSO_DATA_ERROR, "empty distance tree with lengths");
+                } else if (!(dh.count[1] == 1 && (int)ndist - dh.count[0] == 1)) {
+                    BAIL(ZSO_DATA_ERROR, "incomplete distance tree");
+                }
             }
             if (inflate_codes(s, &lh, &dh)) BAIL(st.err, st.msg ? st.msg : "buffer error");
         } else {

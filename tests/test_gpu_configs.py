@@ -1,0 +1,251 @@
+"""-m gpu: BASELINE.json configs 3, 4 and 5 at their stated sizes, determinism, the multi-context batch entry and the
+limits of the C ABI.  Oracle comparisons are byte-exact; where the oracle would take minutes (full 64 MiB / 1 GiB
+sizes) the size-independent properties stand in: round trip through an independent decoder, the Adler-32 trailer, and
+`torch.equal` on the device for inflate."""
+import ctypes
+import hashlib
+import threading
+import zlib
+
+import pytest
+
+import oracle_binding
+from zlibstream_amd import (Engine, ZlibStreamException, datagen, deflate_batch_multi, deflate_bound, device_count,
+                            inflate_batch_multi)
+
+pytestmark = pytest.mark.gpu
+
+
+def _roundtrip_ok(z, data, header=None):
+    assert zlib.decompress(z) == data
+    assert int.from_bytes(z[-4:], "big") == zlib.adler32(data)
+    if header:
+        assert z[:2] == header
+
+
+# ---------------------------------------------------------------- config 4: 1024 x 1 MiB (datagen.batch_buffer)
+def test_config4_batch1024_first_128_bit_exact_all_1024_roundtrip(engine, oracle):
+    """Buffers 0..127 byte-exact against the oracle; all 1024 (one device batch, inputs resident in HBM) through round trip +
+    trailer.  Even buffers are english, odd ones sparse rows."""
+    import torch
+    bufs = [datagen.batch_buffer(i) for i in range(1024)]
+    assert all(len(b) == 1 << 20 for b in bufs)
+    d_ins = [torch.frombuffer(bytearray(b), dtype=torch.uint8).cuda() for b in bufs]
+    caps = [deflate_bound(len(b)) for b in bufs]
+    d_outs = [torch.empty(c, dtype=torch.uint8, device="cuda") for c in caps]
+    lens = engine.deflate_batch_device([t.data_ptr() for t in d_ins], [len(b) for b in bufs], [t.data_ptr() for t in d_outs], caps, level=6,
+                                       stream=torch.cuda.current_stream().cuda_stream)
+    for i, b in enumerate(bufs):
+        z = d_outs[i][:lens[i]].cpu().numpy().tobytes()
+        _roundtrip_ok(z, b, b"\x78\x9c")
+        if i < 128:
+            assert z == oracle.compress(b, 6), "buffer %d differs from the oracle" % i
+
+
+# ---------------------------------------------------------------- config 3: sparse64 at levels 1 and 9 (level 6 is in test_gpu_parity)
+@pytest.mark.parametrize("level,header", [(1, b"\x78\x01"), (9, b"\x78\xda")])
+def test_config3_sparse64_levels_1_and_9(engine, oracle, level, header):
+    import torch
+    data = datagen.sparse(4096, 4096)
+    n = len(data)
+    assert n == 64 << 20
+    d_in = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
+    cap = deflate_bound(n)
+    d_out = torch.empty(cap, dtype=torch.uint8, device="cuda")
+    m = engine.deflate_batch_device([d_in.data_ptr()], [n], [d_out.data_ptr()], [cap], level=level,
+                                    stream=torch.cuda.current_stream().cuda_stream)[0]
+    _roundtrip_ok(d_out[:m].cpu().numpy().tobytes(), data, header)
+    small = data[:4 << 20]
+    assert engine.deflate_batch([small], level=level)[0] == oracle.compress(small, level)
+
+
+def test_config2_english64_levels_1_and_9_sample_and_roundtrip(engine, oracle):
+    data = datagen.english(64 << 20)
+    for level in (9,):
+        z = engine.deflate_batch([data], level=level)[0]
+        _roundtrip_ok(z, data, b"\x78\xda")
+    small = data[:4 << 20]
+    for level in (1, 9):
+        assert engine.deflate_batch([small], level=level)[0] == oracle.compress(small, level)
+
+
+# ---------------------------------------------------------------- config 5: 16 x 64 MiB level-6 streams -> 1 GiB
+def test_config5_inflate_1gib_seeds_0_to_15_equal_on_device(engine):
+    import torch
+    size = 64 << 20
+    cap = deflate_bound(size)
+    d_in, d_z, z_len = [], [], []
+    for i in range(16):
+        t = torch.frombuffer(bytearray(datagen.english(size, (datagen.GOLDEN + i) & datagen.MASK)), dtype=torch.uint8).cuda()
+        z = torch.empty(cap, dtype=torch.uint8, device="cuda")
+        n = engine.deflate_batch_device([t.data_ptr()], [size], [z.data_ptr()], [cap], level=6)[0]
+        d_in.append(t), d_z.append(z[:n].clone()), z_len.append(n)
+        del z
+    outs = [torch.zeros(size, dtype=torch.uint8, device="cuda") for _ in range(16)]
+    lens = engine.inflate_batch_device([z.data_ptr() for z in d_z], z_len, [o.data_ptr() for o in outs], [size] * 16)
+    assert lens == [size] * 16
+    for i in range(16):
+        assert torch.equal(outs[i], d_in[i]), "stream %d" % i
+    # a flipped payload byte in one stream must surface as that stream's error, not as silence
+    bad = d_z[3].clone()
+    bad[z_len[3] // 2] ^= 0x10
+    with pytest.raises(ZlibStreamException):
+        engine.inflate_batch_device([bad.data_ptr()], [z_len[3]], [outs[3].data_ptr()], [size])
+
+
+# ---------------------------------------------------------------- determinism (the link kernel relies on LDS lane order)
+def test_determinism_repeats_and_concurrent_contexts():
+    """english64 level 6: 3 repeats on one context, then 2 more contexts concurrently (2 runs each): one distinct output."""
+    import torch
+    data = datagen.english(64 << 20)
+    n = len(data)
+    d_in = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
+    cap = deflate_bound(n)
+    res, errs = [], []
+
+    def work(reps):
+        try:
+            eng = Engine(0)
+            d_out = torch.empty(cap, dtype=torch.uint8, device="cuda")
+            for _ in range(reps):
+                m = eng.deflate_batch_device([d_in.data_ptr()], [n], [d_out.data_ptr()], [cap], level=6)[0]
+                res.append(hashlib.sha256(d_out[:m].cpu().numpy().tobytes()).hexdigest())
+            eng.close()
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+    work(3)
+    th = [threading.Thread(target=work, args=(2,)) for _ in range(2)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs
+    assert len(res) == 7 and len(set(res)) == 1, res
+
+
+# ---------------------------------------------------------------- multi-context batch entry (one GPU here, 8 on the node)
+def test_batch_multi_two_contexts_matches_single_context_and_oracle(engine, oracle):
+    assert device_count() >= 1
+    bufs = [datagen.batch_buffer(i, 256 << 10) for i in range(24)] + [b"", b"x", oracle_binding.corpus("kennedy.xls"),
+                                                                       datagen.english(3 << 20, 9)]
+    e2 = Engine(0)
+    try:
+        got = deflate_batch_multi([engine, e2], bufs, level=6)
+        assert got == engine.deflate_batch(bufs, level=6)
+        for i in (0, 1, 24, 25, 26):
+            assert got[i] == oracle.compress(bufs[i], 6)
+        back = inflate_batch_multi([engine, e2], got, [len(b) for b in bufs])
+        assert back == bufs
+        # three contexts, fewer buffers than contexts, and a failing buffer that leaves the others delivered
+        e3 = Engine(0)
+        assert deflate_batch_multi([engine, e2, e3], bufs[:2], level=9) == engine.deflate_batch(bufs[:2], level=9)
+        e3.close()
+    finally:
+        e2.close()
+
+
+def test_batch_reports_every_stream_when_one_fails(engine, oracle):
+    """One undersized output in a batch: that stream is ZBUFERROR, the others are delivered with their lengths."""
+    bufs = [oracle_binding.corpus("sum"), oracle_binding.corpus("kennedy.xls"), oracle_binding.corpus("cp.html")]
+    keep = [ctypes.create_string_buffer(b, len(b)) for b in bufs]
+    caps = [deflate_bound(len(bufs[0])), 100, deflate_bound(len(bufs[2]))]
+    outs = [ctypes.create_string_buffer(c) for c in caps]
+    rc, lens, status = engine._call_batch(engine._lib.zs_deflate_batch, [ctypes.addressof(k) for k in keep], [len(b) for b in bufs],
+                                          [ctypes.addressof(o) for o in outs], caps, 6, 0, 0)
+    assert rc == -5 and status == [0, -5, 0]
+    assert outs[0].raw[:lens[0]] == oracle.compress(bufs[0], 6)
+    assert outs[2].raw[:lens[2]] == oracle.compress(bufs[2], 6)
+
+
+# ---------------------------------------------------------------- Huft_build's "incomplete" rule (InfTree.cs:364)
+class _Bits:
+    def __init__(self):
+        self.v, self.n = 0, 0
+
+    def put(self, value, nbits):  # LSB-first fields
+        self.v |= value << self.n
+        self.n += nbits
+
+    def code(self, code, nbits):  # Huffman codes go out MSB first
+        for i in range(nbits - 1, -1, -1):
+            self.put((code >> i) & 1, 1)
+
+    def bytes(self):
+        return self.v.to_bytes((self.n + 7) // 8, "little")
+
+
+def _single_code_stream(lit_len, dist_len, payload):
+    """zlib stream with one dynamic block whose code lengths are: literal 'A' and END_BLOCK `lit_len` bits each... see below.
+    lit_len == 1: 'A' and END_BLOCK both 1 bit (complete).  lit_len == 0: only END_BLOCK, `dist_len` bits (incomplete).
+    The distance tree is one code of `dist_len` bits (incomplete; accepted by the reference only when dist_len == 1)."""
+    b = _Bits()
+    b.put(1, 1), b.put(2, 2)          # BFINAL, dynamic
+    b.put(0, 5), b.put(0, 5), b.put(14, 4)  # HLIT 257, HDIST 1, HCLEN 18
+    bl = {0: 1, 1: 2, 2: 3, 18: 3}    # bit-length code: 0 -> '0', 1 -> '10', 2 -> '110', 18 -> '111'
+    order = [16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15]
+    for s in order[:18]:
+        b.put(bl.get(s, 0), 3)
+    codes = {0: (0, 1), 1: (2, 2), 2: (6, 3), 18: (7, 3)}
+
+    def zeros(k):
+        while k:
+            r = min(k, 138)
+            assert r >= 11
+            b.code(*codes[18]), b.put(r - 11, 7)
+            k -= r
+    if lit_len == 1:
+        zeros(65), b.code(*codes[1]), zeros(190), b.code(*codes[1])   # 'A' = 65 and END_BLOCK = 256: 1 bit each
+    else:
+        zeros(138), zeros(118), b.code(*codes[dist_len])              # END_BLOCK alone
+    b.code(*codes[dist_len])                                          # the single distance code
+    if lit_len == 1:
+        for ch in payload:
+            assert ch == 65
+            b.put(0, 1)
+        b.put(1, 1)  # END_BLOCK
+    else:
+        b.put(0, dist_len)  # END_BLOCK = all-zero code
+    raw = b.bytes()
+    return b"\x78\x9c" + raw + zlib.adler32(payload).to_bytes(4, "big")
+
+
+@pytest.mark.parametrize("lit_len,dist_len,payload,want", [
+    (1, 1, b"AAA", None),                                   # single 1-bit distance code: accepted
+    (1, 2, b"AAA", "incomplete distance tree"),             # single 2-bit distance code: rejected by Huft_build
+    (0, 1, b"", None),                                      # END_BLOCK alone, 1 bit: accepted
+    (0, 2, b"", "incomplete literal/length tree"),
+])
+def test_inflate_incomplete_single_code_trees_follow_huft_build(engine, oracle, lit_len, dist_len, payload, want):
+    z = _single_code_stream(lit_len, dist_len, payload)
+    rc, out, msg = oracle.inflate(z, 16)
+    if want is None:
+        assert rc == 1 and out == payload
+        assert engine.inflate_batch([z], [16]) == [payload]
+    else:
+        assert rc == -3 and msg == want
+        with pytest.raises(ZlibStreamException) as ei:
+            engine.inflate_batch([z], [16])
+        assert str(ei.value) == "inflating: " + want
+
+
+# ---------------------------------------------------------------- limits of the stream entry points
+def test_zs_deflate_rejects_input_beyond_the_device_limit_cleanly(engine):
+    """Feeding more than 2 GiB - 1 KiB into one zs_deflate stream fails with ZMEMERROR and *avail_in untouched (no truncation)."""
+    lib = engine._lib
+    z = lib.zs_deflate_init(engine.handle, 6, 0, 15, 8, 0)
+    assert z
+    try:
+        piece = bytes(64 << 20)
+        src = ctypes.create_string_buffer(piece, len(piece))
+        out = ctypes.create_string_buffer(512)
+        adler, tin, tout = ctypes.c_uint32(1), ctypes.c_int64(0), ctypes.c_int64(0)
+        for k in range(32):
+            avail_in, avail_out = ctypes.c_int32(len(piece)), ctypes.c_int32(512)
+            rc = lib.zs_deflate(z, ctypes.addressof(src), ctypes.byref(avail_in), ctypes.addressof(out), ctypes.byref(avail_out), 0,
+                                ctypes.byref(adler), ctypes.byref(tin), ctypes.byref(tout))
+            if k < 31:
+                assert rc == 0 and avail_in.value == 0, k
+            else:
+                assert rc == -4 and avail_in.value == len(piece)
+                assert b"2 GiB" in lib.zs_last_message(z)
+        assert tin.value == 31 * len(piece)
+    finally:
+        lib.zs_deflate_end(z)

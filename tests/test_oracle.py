@@ -140,3 +140,18 @@ def test_generators_are_deterministic():
     assert hashlib.sha256(datagen.english(1 << 16)).hexdigest() == hashlib.sha256(a[:1 << 16]).hexdigest()
     s = datagen.sparse(8, 2)
     assert s[:8] == bytes([0, 0, 0, 255, 4, 0, 0, 255]) and s[32:36] == bytes([1, 0, 0, 255])
+
+
+def test_inflate_oracle_follows_huft_build_on_incomplete_single_code_trees(oracle):
+    """Huft_build accepts an incomplete code only when it is one code of length 1 (InfTree.cs:364, 378-431)."""
+    from test_gpu_configs import _single_code_stream
+    assert oracle.inflate(_single_code_stream(1, 1, b"AAA"), 16)[:2] == (1, b"AAA")
+    assert oracle.inflate(_single_code_stream(1, 2, b"AAA"), 16) == (-3, b"", "incomplete distance tree")
+    assert oracle.inflate(_single_code_stream(0, 1, b""), 16)[:2] == (1, b"")
+    assert oracle.inflate(_single_code_stream(0, 2, b""), 16) == (-3, b"", "incomplete literal/length tree")
+
+
+def test_english_generator_is_pinned():
+    """The chunked generator must keep producing the bytes the round-1 digests and benches were taken on."""
+    assert hashlib.sha256(datagen.english(1 << 20)).hexdigest() == hashlib.sha256(datagen.english(64 << 20)[:1 << 20]).hexdigest()
+    assert hashlib.sha256(datagen.english(64 << 20)).hexdigest() == "cd512dd3dd6a2448fbd2603c2434354d758470a43ca17346cbd9fac78f903633"

@@ -1,6 +1,9 @@
 """N > 1: independent buffers shard across ranks with no data-path collective.  World-size-2
-gloo run on CPU: both ranks derive the same partition, every buffer is owned exactly once,
-and the per-rank results gather back in input order."""
+gloo run on CPU of bench.py's control plane: both ranks derive the same partition from the
+library's zs_partition (zlibstream_amd.shard), every buffer is owned exactly once, each rank
+compresses only its own buffers (here with the CPU oracle standing in for the device call,
+which needs a GPU; tests/test_gpu_configs.py covers zs_deflate_batch_multi on the device) and
+the per-buffer results gather back in input order."""
 import os
 import socket
 
@@ -22,11 +25,15 @@ def _free_port():
 def _worker(rank, world, port, sizes, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import oracle_binding
+    from zlibstream_amd import datagen
+    oracle = oracle_binding.Oracle()
     mine = partition(sizes, world)[rank]
-    # stand-in for the device call: "compressed length" = size // 3 + index
     lens = torch.zeros(len(sizes), dtype=torch.int64)
-    for i in mine:
-        lens[i] = sizes[i] // 3 + i
+    for i in mine:  # the rank generates and compresses only its own buffers (as bench.py --gpus N does)
+        lens[i] = len(oracle.compress(datagen.batch_buffer(i, sizes[i]), 6))
     dist.all_reduce(lens)  # gather of per-buffer lengths (control plane only; payloads stay on their rank)
     total = torch.tensor([sum(sizes[i] for i in mine)], dtype=torch.int64)
     dist.all_reduce(total)
@@ -46,10 +53,16 @@ def test_partition_is_balanced_and_complete():
     loads = [sum(sizes[i] for i in p) for p in parts]
     assert max(loads) - min(loads) <= max(sizes)
     assert partition([], 4) == [[], [], [], []]
+    # deterministic tie-breaking: equal sizes go round the parts in input order
+    assert partition([7] * 5, 2) == [[0, 2, 4], [1, 3]]
 
 
 def test_two_rank_gloo_shards_and_gathers():
-    sizes = [(i * 7919) % 100000 + 1 for i in range(37)]
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import oracle_binding
+    from zlibstream_amd import datagen
+    sizes = [4096 * (1 + (i * 7919) % 13) for i in range(21)]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -60,5 +73,6 @@ def test_two_rank_gloo_shards_and_gathers():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert lens == [s // 3 + i for i, s in enumerate(sizes)]
+    oracle = oracle_binding.Oracle()
+    assert lens == [len(oracle.compress(datagen.batch_buffer(i, s), 6)) for i, s in enumerate(sizes)]
     assert total == sum(sizes)

@@ -6,4 +6,5 @@ ZlibStreamException) over the C ABI in include/zsgpu.h.  The compression path
 has no CPU fallback: it needs libzsgpu.so and an MI355X.
 """
 from .api import (CompressionLevel, CompressionState, CompressionStrategy, Engine, FlushMode, ZlibInputStream, ZlibOptions,  # noqa: F401
-                  ZlibOutputStream, ZlibStreamException, compress, deflate_bound)
+                  ZlibOutputStream, ZlibStreamException, compress, deflate_batch_multi, deflate_bound, device_count,
+                  inflate_batch_multi)

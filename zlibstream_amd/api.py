@@ -180,6 +180,52 @@ class Engine:
         return [outs[i].raw[:lens[i]] for i in range(n)]
 
 
+def deflate_batch_multi(engines, buffers, level=6, strategy=0, hash_variant=0):
+    """Host buffers sharded over several engines (one per GPU) by zs_deflate_batch_multi -> zlib streams in input order."""
+    lib = _native.lib()
+    bufs = [bytes(b) for b in buffers]
+    n = len(bufs)
+    if n == 0:
+        return []
+    keep = [ctypes.create_string_buffer(b, len(b)) if len(b) else ctypes.create_string_buffer(1) for b in bufs]
+    caps = [deflate_bound(len(b)) for b in bufs]
+    outs = [ctypes.create_string_buffer(c) for c in caps]
+    VP, I64, I32 = ctypes.c_void_p * n, ctypes.c_int64 * n, ctypes.c_int * n
+    out_len, status = I64(), I32()
+    ctxs = (ctypes.c_void_p * len(engines))(*[e.handle for e in engines])
+    rc = lib.zs_deflate_batch_multi(ctxs, len(engines), n, VP(*[ctypes.addressof(k) for k in keep]), I64(*[len(b) for b in bufs]),
+                                    VP(*[ctypes.addressof(o) for o in outs]), I64(*caps), out_len, status, int(level), int(strategy),
+                                    int(hash_variant))
+    if rc != 0:
+        bad = [e.last_error() for e in engines if e.last_error()]
+        raise ZlibStreamException("deflating: " + (bad[0] if bad else "error %d" % rc))
+    return [outs[i].raw[:out_len[i]] for i in range(n)]
+
+
+def inflate_batch_multi(engines, streams, out_sizes):
+    """zlib streams sharded over several engines by zs_inflate_batch_multi -> decoded bytes in input order."""
+    lib = _native.lib()
+    zs = [bytes(z) for z in streams]
+    n = len(zs)
+    if n == 0:
+        return []
+    keep = [ctypes.create_string_buffer(z, len(z)) if len(z) else ctypes.create_string_buffer(1) for z in zs]
+    outs = [ctypes.create_string_buffer(max(int(c), 1)) for c in out_sizes]
+    VP, I64, I32 = ctypes.c_void_p * n, ctypes.c_int64 * n, ctypes.c_int * n
+    out_len, status = I64(), I32()
+    ctxs = (ctypes.c_void_p * len(engines))(*[e.handle for e in engines])
+    rc = lib.zs_inflate_batch_multi(ctxs, len(engines), n, VP(*[ctypes.addressof(k) for k in keep]), I64(*[len(z) for z in zs]),
+                                    VP(*[ctypes.addressof(o) for o in outs]), I64(*[int(c) for c in out_sizes]), out_len, status)
+    if rc != 0:
+        bad = [e.last_error() for e in engines if e.last_error()]
+        raise ZlibStreamException("inflating: " + (bad[0] if bad else "error %d" % rc))
+    return [outs[i].raw[:out_len[i]] for i in range(n)]
+
+
+def device_count():
+    return int(_native.lib().zs_device_count())
+
+
 _default_engine = None
 
 

@@ -56,7 +56,22 @@ def build_oracle(force=False):
     return ORACLE_LIB
 
 
+def build_tools(force=False):
+    """tools/stream_api_bench: the C++ mirror of the Stream API (include/zsgpu.hpp) driven like the reference's benchmarks;
+    bench.py runs it for the `stream_api` figure."""
+    exe = os.path.join(ROOT, "build", "stream_api_bench")
+    srcs = [os.path.join(ROOT, "tools", "stream_api_bench.cpp"), os.path.join(ROOT, "include", "zsgpu.hpp"),
+            os.path.join(ROOT, "include", "zsgpu.h"), LIB]
+    if not force and not _newer(exe, srcs):
+        return exe
+    os.makedirs(os.path.dirname(exe), exist_ok=True)
+    subprocess.run(["g++", "-O2", "-std=c++17", "-o", exe, srcs[0], "-L" + PKG, "-lzsgpu", "-Wl,-rpath," + PKG,
+                    "-Wl,-rpath,/opt/rocm/lib"], check=True, cwd=ROOT)
+    return exe
+
+
 if __name__ == "__main__":
     build_engine(force="--force" in sys.argv, verbose=True)
     build_oracle(force="--force" in sys.argv)
+    build_tools(force="--force" in sys.argv)
     print("built", LIB, "and", ORACLE_LIB)

@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/zsgpu.h"
@@ -46,7 +47,7 @@ struct zs_ctx {
     uint32_t *crc_tab = nullptr;
     DevBuf sd, st, work, geo, link, mm, maps, segmap, seg_entry, seg_symbase, seg_stale, entry, symbase, stale, syms, blk_end, blk_top, blocks, trees, info, pieces, scratch,
         stage_in, stage_out, wr, inf_desc, inf_state, par_ps, par_st, par_work, par_cbits, par_ccnt, par_surv, par_scnt, par_cands, par_tabs, par_blocks, par_cells,
-        par_windows, par_fail, run_syms, run_bits, run_scratch, run_outs, run_fail;
+        par_windows, par_fail, run_syms, run_bits, run_scratch, run_outs, run_fail, adl_tr, adl_res;
     void *pinned = nullptr;
     size_t pinned_cap = 0;
 };
@@ -117,6 +118,10 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
                   const WriteSpec *writes = nullptr, bool force_seq = false) {
     if (level == -1) level = 6;
     LevelCfg lv = level_cfg(level);
+    for (int i = 0; i < n; i++) {  // what the caller sees if a HIP call fails before the results are known
+        out_len[i] = 0;
+        if (status) status[i] = ZS_STREAM_ERROR;
+    }
     Plan pl;
     pl.sd.resize((size_t)n);
     // positions per workgroup of the link kernel (each replays 32 Ki positions of warm-up first): long spans for a
@@ -391,14 +396,62 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
             (void)hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]);
             c->stage_ms[i] = ms;
         }
+    // every stream's length and code are reported; the first failing one sets the message and the return value
+    bool all_ok = true;
     for (int i = 0; i < n; i++) {
         out_len[i] = hst[i].out_len;
         if (status) status[i] = hst[i].status;
-        if (hst[i].status != 0) {
+        if (hst[i].status != 0 && all_ok) {
             c->err = hst[i].status == ZS_BUF_ERROR ? "buffer error"
                                                    : "stored block larger than the reference's pending buffer (the managed engine throws here)";
-            return false;
+            all_ok = false;
         }
+    }
+    return all_ok;
+}
+
+// Adler-32 (seed 1) of m device buffers in one pass: the piece kernel over all of them, one combining workgroup per
+// buffer, one copy back.  `trailers` (optional, device pointers or null entries): the 4 big-endian bytes each result is
+// compared with (the check of Inflate.cs:300-345); ok[i] = 1 when they agree.
+bool device_adlers(zs_ctx *c, int m, const void *const *bufs, const int64_t *lens, const void *const *trailers, uint32_t *adlers,
+                   int *ok, hipStream_t stream) {
+    if (m <= 0) return true;
+    std::vector<StreamDesc> sd((size_t)m);
+    std::vector<uint2> work;
+    int64_t n_pieces = 0;
+    for (int i = 0; i < m; i++) {
+        StreamDesc &s = sd[(size_t)i];
+        memset(&s, 0, sizeof s);
+        s.in = (const uint8_t *)bufs[i];
+        s.n = (int32_t)lens[i];
+        s.adler_off = (int32_t)n_pieces;
+        s.n_adler = (int32_t)((lens[i] + kAdlerPiece - 1) / kAdlerPiece);
+        n_pieces += s.n_adler;
+        for (int k = 0; k < s.n_adler; k++) work.push_back(make_uint2((unsigned)i, (unsigned)k));
+    }
+    const size_t b_sd = sizeof(StreamDesc) * (size_t)m, b_work = sizeof(uint2) * work.size(), b_tr = sizeof(void *) * (size_t)m;
+    if (!ensure(c, c->sd, b_sd) || !ensure(c, c->work, b_work + 16) || !ensure(c, c->pieces, 4 * (size_t)n_pieces + 64) ||
+        !ensure(c, c->adl_tr, b_tr) || !ensure(c, c->adl_res, sizeof(uint2) * (size_t)m) ||
+        !ensure_pinned(c, b_sd + b_work + b_tr + sizeof(uint2) * (size_t)m))
+        return false;
+    uint8_t *hp = (uint8_t *)c->pinned;
+    memcpy(hp, sd.data(), b_sd);
+    if (b_work) memcpy(hp + b_sd, work.data(), b_work);
+    if (trailers) memcpy(hp + b_sd + b_work, trailers, b_tr);
+    ZS_HIP(c, hipMemcpyAsync(c->sd.p, hp, b_sd, hipMemcpyHostToDevice, stream));
+    if (b_work) ZS_HIP(c, hipMemcpyAsync(c->work.p, hp + b_sd, b_work, hipMemcpyHostToDevice, stream));
+    if (trailers) ZS_HIP(c, hipMemcpyAsync(c->adl_tr.p, hp + b_sd + b_work, b_tr, hipMemcpyHostToDevice, stream));
+    if (!work.empty())
+        hipLaunchKernelGGL(zs_adler_kernel, dim3((unsigned)work.size()), dim3(256), 0, stream, dev<StreamDesc>(c->sd), dev<uint2>(c->work),
+                           dev<uint32_t>(c->pieces));
+    hipLaunchKernelGGL(zs_adler_finish_kernel, dim3((unsigned)m), dim3(256), 0, stream, dev<StreamDesc>(c->sd), dev<uint32_t>(c->pieces),
+                       trailers ? (const uint8_t *const *)c->adl_tr.p : nullptr, dev<uint2>(c->adl_res));
+    uint2 *hres = (uint2 *)(hp + b_sd + b_work + b_tr);
+    ZS_HIP(c, hipMemcpyAsync(hres, c->adl_res.p, sizeof(uint2) * (size_t)m, hipMemcpyDeviceToHost, stream));
+    ZS_HIP(c, hipStreamSynchronize(stream));
+    for (int i = 0; i < m; i++) {
+        if (adlers) adlers[i] = hres[i].x;
+        if (ok) ok[i] = (int)hres[i].y;
     }
     return true;
 }
@@ -482,7 +535,7 @@ void zs_ctx_destroy(zs_ctx *c) {
     DevBuf *bufs[] = {&c->sd, &c->st, &c->work, &c->geo, &c->link, &c->mm, &c->maps, &c->segmap, &c->seg_entry, &c->seg_symbase, &c->seg_stale, &c->entry, &c->symbase, &c->stale, &c->syms,
                       &c->blk_end, &c->blk_top, &c->blocks, &c->trees, &c->info, &c->pieces, &c->scratch, &c->stage_in, &c->stage_out, &c->wr, &c->inf_desc, &c->inf_state, &c->par_ps, &c->par_st, &c->par_work, &c->par_cbits, &c->par_ccnt, &c->par_surv, &c->par_scnt,
                       &c->par_cands, &c->par_tabs, &c->par_blocks, &c->par_cells, &c->par_windows, &c->par_fail, &c->run_syms, &c->run_bits,
-                      &c->run_scratch, &c->run_outs, &c->run_fail};
+                      &c->run_scratch, &c->run_outs, &c->run_fail, &c->adl_tr, &c->adl_res};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     if (c->crc_tab) (void)hipFree(c->crc_tab);
@@ -552,47 +605,30 @@ int zs_deflate_batch(zs_ctx *c, int n, const void *const *in, const int64_t *in_
         oi += ((size_t)in_len[i] + 255) & ~(size_t)255;
         oo += ((size_t)out_cap[i] + 255) & ~(size_t)255;
     }
-    if (!run_pipeline(c, n, din.data(), in_len, dout.data(), dcap.data(), out_len, status, level, strategy, hash_variant, c->stream))
-        return c->err == "buffer error" ? ZS_BUF_ERROR : ZS_STREAM_ERROR;
+    std::vector<int> st_local;
+    if (!status) st_local.assign((size_t)n, 0), status = st_local.data();
+    const bool ok = run_pipeline(c, n, din.data(), in_len, dout.data(), dcap.data(), out_len, status, level, strategy, hash_variant, c->stream);
+    const std::string first_err = c->err;
+    // streams that succeeded are delivered even when another stream of the batch failed (status[i] says which)
     for (int i = 0; i < n; i++)
-        if (!chk(hipMemcpyAsync(out[i], dout[(size_t)i], (size_t)out_len[i], hipMemcpyDeviceToHost, c->stream), "D2H"))
+        if (status[i] == 0 && out_len[i] > 0 && out_len[i] <= out_cap[i] &&
+            !chk(hipMemcpyAsync(out[i], dout[(size_t)i], (size_t)out_len[i], hipMemcpyDeviceToHost, c->stream), "D2H"))
             return ZS_STREAM_ERROR;
     if (!chk(hipStreamSynchronize(c->stream), "sync")) return ZS_STREAM_ERROR;
+    if (!ok) {
+        c->err = first_err;
+        return first_err == "buffer error" ? ZS_BUF_ERROR : ZS_STREAM_ERROR;
+    }
     return ZS_OK;
 }
 
 int zs_adler32_device(zs_ctx *c, const void *d_buf, int64_t len, uint32_t seed, uint32_t *out, void *hip_stream) {
-    if (!c || !out || len < 0) return ZS_STREAM_ERROR;
+    if (!c || !out || len < 0 || len > 0x7FFFFFFF - 1024) return ZS_STREAM_ERROR;
     if (hipSetDevice(c->device) != hipSuccess) return ZS_STREAM_ERROR;
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
-    StreamDesc sd;
-    memset(&sd, 0, sizeof sd);
-    sd.in = (const uint8_t *)d_buf;
-    sd.n = (int32_t)len;
-    sd.n_adler = (int32_t)((len + kAdlerPiece - 1) / kAdlerPiece);
-    std::vector<uint2> work;
-    for (int k = 0; k < sd.n_adler; k++) work.push_back(make_uint2(0, (unsigned)k));
-    if (!ensure(c, c->sd, sizeof sd) || !ensure(c, c->work, sizeof(uint2) * (work.size() + 1)) ||
-        !ensure(c, c->pieces, 4 * (size_t)sd.n_adler + 64))
-        return ZS_MEM_ERROR;
-    std::vector<uint32_t> pieces((size_t)sd.n_adler);
-    if (hipMemcpyAsync(c->sd.p, &sd, sizeof sd, hipMemcpyHostToDevice, s) != hipSuccess) return ZS_STREAM_ERROR;
-    if (sd.n_adler) {
-        if (hipMemcpyAsync(c->work.p, work.data(), sizeof(uint2) * work.size(), hipMemcpyHostToDevice, s) != hipSuccess)
-            return ZS_STREAM_ERROR;
-        hipLaunchKernelGGL(zs_adler_kernel, dim3((unsigned)sd.n_adler), dim3(256), 0, s, dev<StreamDesc>(c->sd), dev<uint2>(c->work),
-                           dev<uint32_t>(c->pieces));
-        if (hipMemcpyAsync(pieces.data(), c->pieces.p, 4 * (size_t)sd.n_adler, hipMemcpyDeviceToHost, s) != hipSuccess)
-            return ZS_STREAM_ERROR;
-    }
-    if (hipStreamSynchronize(s) != hipSuccess) return ZS_STREAM_ERROR;
-    uint32_t ad = seed;
-    for (int i = 0; i < sd.n_adler; i++) {
-        int64_t l = len - (int64_t)i * kAdlerPiece;
-        if (l > kAdlerPiece) l = kAdlerPiece;
-        ad = adler_combine(ad, pieces[(size_t)i], (uint64_t)l);
-    }
-    *out = ad;
+    uint32_t ad = 1;
+    if (!device_adlers(c, 1, &d_buf, &len, nullptr, &ad, nullptr, s)) return ZS_STREAM_ERROR;
+    *out = adler_combine(seed, ad, (uint64_t)len);
     return ZS_OK;
 }
 
@@ -609,7 +645,7 @@ const char *const kInfMessages[kInfMsgCount] = {
     "invalid literal/length code", "invalid distance code", "buffer error", "buffer error", "incorrect data check"};
 
 bool run_inflate_seq(zs_ctx *c, int n, const void *const *in, const int64_t *in_len, void *const *out, const int64_t *out_cap,
-                 int64_t *out_len, int *status, hipStream_t stream) {
+                 int64_t *out_len, int *status, hipStream_t stream, uint32_t *adler_out = nullptr) {
     std::vector<InfDesc> d((size_t)n);
     for (int i = 0; i < n; i++) d[(size_t)i] = {(const uint8_t *)in[i], (uint8_t *)out[i], in_len[i], out_cap[i]};
     if (!ensure(c, c->inf_desc, sizeof(InfDesc) * (size_t)n) || !ensure(c, c->inf_state, sizeof(InfState) * (size_t)n)) return false;
@@ -630,16 +666,24 @@ bool run_inflate_seq(zs_ctx *c, int n, const void *const *in, const int64_t *in_
         for (double &v : c->stage_ms) v = 0;
         c->stage_ms[0] = ms;  // reported under stage 0 for inflate calls
     }
+    // Adler-32 of the produced bytes against the stored trailer, on the device, all finished streams in one pass
+    // (Inflate.cs:300-345)
+    std::vector<const void *> abuf;
+    std::vector<int64_t> alen;
+    std::vector<int> aidx;
+    for (int i = 0; i < n; i++)
+        if (st[(size_t)i].status == ZS_STREAM_END) abuf.push_back(out[i]), alen.push_back(st[(size_t)i].out_len), aidx.push_back(i);
+    std::vector<uint32_t> ads(abuf.size(), 1u);
+    if (!device_adlers(c, (int)abuf.size(), abuf.data(), alen.data(), nullptr, ads.data(), nullptr, stream)) return false;
+    for (size_t k = 0; k < aidx.size(); k++) {
+        InfState &q = st[(size_t)aidx[k]];
+        if (ads[k] != q.adler_stored) q.status = ZS_DATA_ERROR, q.msg = kInfBadCheck;
+        else if (adler_out) adler_out[aidx[k]] = ads[k];
+    }
     bool all_ok = true;
     for (int i = 0; i < n; i++) {
         out_len[i] = st[(size_t)i].out_len;
-        int code = st[(size_t)i].status;
-        if (code == ZS_STREAM_END) {
-            // Adler-32 of the produced bytes, on the device (Inflate.cs:300-345)
-            uint32_t ad = 1;
-            if (zs_adler32_device(c, out[i], out_len[i], 1, &ad, stream) != ZS_OK) return false;
-            if (ad != st[(size_t)i].adler_stored) code = ZS_DATA_ERROR, st[(size_t)i].msg = kInfBadCheck;
-        }
+        const int code = st[(size_t)i].status;
         if (status) status[i] = code;
         if (code != ZS_STREAM_END) {
             if (all_ok) c->err = kInfMessages[st[(size_t)i].msg];
@@ -653,7 +697,8 @@ constexpr int64_t kParMinInput = 256 * 1024;  // shorter streams go straight to 
 
 // Block-parallel path for the streams listed in `idx`; streams it cannot handle are appended to `rest`.
 bool run_inflate_par(zs_ctx *c, const std::vector<int> &idx, const void *const *in, const int64_t *in_len, void *const *out,
-                     const int64_t *out_cap, int64_t *out_len, int *status, hipStream_t stream, std::vector<int> &rest) {
+                     const int64_t *out_cap, int64_t *out_len, int *status, hipStream_t stream, std::vector<int> &rest,
+                     uint32_t *adler_out = nullptr) {
     const int m = (int)idx.size();
     if (m == 0) return true;
     std::vector<ParStream> ps((size_t)m);
@@ -730,15 +775,23 @@ bool run_inflate_par(zs_ctx *c, const std::vector<int> &idx, const void *const *
     ZS_HIP(c, hipMemcpyAsync(st.data(), d_st, sizeof(ParState) * (size_t)m, hipMemcpyDeviceToHost, stream));
     ZS_HIP(c, hipStreamSynchronize(stream));
     w.clear();
+    // windows are laid out by the block counts the chain found (not by the per-stream bounds the other tables use)
     int64_t total_blk = 0;
     for (int j = 0; j < m; j++)
         if (st[(size_t)j].ok) {
             for (int k = 0; k < st[(size_t)j].nblk; k++) w.push_back(make_uint2((unsigned)j, (unsigned)k));
-            total_blk = std::max<int64_t>(total_blk, (int64_t)ps[(size_t)j].blk_off + st[(size_t)j].nblk);
+            st[(size_t)j].win_off = (int32_t)total_blk;
+            total_blk += st[(size_t)j].nblk;
         }
     std::vector<int32_t> bfail((size_t)m, 0);
     if (!w.empty()) {
-        if (!ensure(c, c->par_windows, (size_t)total_blk * kWSize + 64)) return false;
+        if (total_blk > 0x7FFFFFFF / 2 || !ensure(c, c->par_windows, (size_t)total_blk * kWSize + 64)) {
+            // no room for the windows (streams cut into very many small blocks): the one-wave decoder needs none
+            c->err.clear();
+            for (int j = 0; j < m; j++) rest.push_back(idx[(size_t)j]);
+            return true;
+        }
+        ZS_HIP(c, hipMemcpyAsync(d_st, st.data(), sizeof(ParState) * (size_t)m, hipMemcpyHostToDevice, stream));
         ZS_HIP(c, hipMemcpyAsync(c->par_work.p, w.data(), sizeof(uint2) * w.size(), hipMemcpyHostToDevice, stream));
         ZS_HIP(c, hipStreamSynchronize(stream));
         if (lane_decode)
@@ -770,27 +823,29 @@ bool run_inflate_par(zs_ctx *c, const std::vector<int> &idx, const void *const *
             }
         }
     }
+    // Adler-32 trailer after the last block, byte aligned (Inflate.cs:300-345): all streams in one device pass
+    std::vector<const void *> abuf, atr;
+    std::vector<int64_t> alen;
+    std::vector<int> aidx;
     for (int j = 0; j < m; j++) {
         const int i = idx[(size_t)j];
         const ParState &q = st[(size_t)j];
-        if (!q.ok || bfail[(size_t)j]) {
-            rest.push_back(i);
-            continue;
-        }
-        // Adler-32 trailer after the last block, byte aligned (Inflate.cs:300-345)
         const int64_t tb = (q.end_bit + 7) >> 3;
-        if (tb + 4 > in_len[i]) {
-            rest.push_back(i);  // truncated: let the sequential decoder classify it
+        if (!q.ok || bfail[(size_t)j] || tb + 4 > in_len[i]) {
+            rest.push_back(i);  // not decodable here, or truncated: the sequential decoder classifies it
             continue;
         }
-        uint8_t tr[4];
-        ZS_HIP(c, hipMemcpyAsync(tr, (const uint8_t *)in[i] + tb, 4, hipMemcpyDeviceToHost, stream));
-        ZS_HIP(c, hipStreamSynchronize(stream));
-        uint32_t want = ((uint32_t)tr[0] << 24) | ((uint32_t)tr[1] << 16) | ((uint32_t)tr[2] << 8) | tr[3], ad = 1;
-        if (zs_adler32_device(c, out[i], q.out_len, 1, &ad, stream) != ZS_OK) return false;
-        out_len[i] = q.out_len;
+        abuf.push_back(out[i]), alen.push_back(q.out_len), atr.push_back((const uint8_t *)in[i] + tb), aidx.push_back(j);
+    }
+    std::vector<uint32_t> ads(abuf.size(), 1u);
+    std::vector<int> aok(abuf.size(), 0);
+    if (!device_adlers(c, (int)abuf.size(), abuf.data(), alen.data(), atr.data(), ads.data(), aok.data(), stream)) return false;
+    for (size_t k = 0; k < aidx.size(); k++) {
+        const int j = aidx[k], i = idx[(size_t)j];
+        out_len[i] = st[(size_t)j].out_len;
         status[i] = ZS_STREAM_END;
-        if (ad != want) {
+        if (adler_out) adler_out[i] = ads[k];
+        if (!aok[k]) {
             status[i] = ZS_DATA_ERROR;
             c->err = kInfMessages[kInfBadCheck];
         }
@@ -799,11 +854,11 @@ bool run_inflate_par(zs_ctx *c, const std::vector<int> &idx, const void *const *
 }
 
 bool run_inflate(zs_ctx *c, int n, const void *const *in, const int64_t *in_len, void *const *out, const int64_t *out_cap,
-                 int64_t *out_len, int *status, hipStream_t stream) {
+                 int64_t *out_len, int *status, hipStream_t stream, uint32_t *adler_out = nullptr) {
     std::vector<int> par, seq;
     for (int i = 0; i < n; i++) (in_len[i] >= kParMinInput ? par : seq).push_back(i);
     std::vector<int> st((size_t)n, 0);
-    if (!run_inflate_par(c, par, in, in_len, out, out_cap, out_len, st.data(), stream, seq)) return false;
+    if (!run_inflate_par(c, par, in, in_len, out, out_cap, out_len, st.data(), stream, seq, adler_out)) return false;
     bool ok = true;
     for (int i : par)
         if (std::find(seq.begin(), seq.end(), i) == seq.end() && st[(size_t)i] != ZS_STREAM_END) ok = false;
@@ -813,9 +868,13 @@ bool run_inflate(zs_ctx *c, int n, const void *const *in, const int64_t *in_len,
         std::vector<void *> sout((size_t)m);
         std::vector<int64_t> slen((size_t)m), scap((size_t)m), solen((size_t)m);
         std::vector<int> sst((size_t)m);
+        std::vector<uint32_t> sad((size_t)m, 1u);
         for (int j = 0; j < m; j++) sin[(size_t)j] = in[seq[(size_t)j]], sout[(size_t)j] = out[seq[(size_t)j]], slen[(size_t)j] = in_len[seq[(size_t)j]], scap[(size_t)j] = out_cap[seq[(size_t)j]];
-        if (!run_inflate_seq(c, m, sin.data(), slen.data(), sout.data(), scap.data(), solen.data(), sst.data(), stream)) ok = false;
-        for (int j = 0; j < m; j++) out_len[seq[(size_t)j]] = solen[(size_t)j], st[(size_t)seq[(size_t)j]] = sst[(size_t)j];
+        if (!run_inflate_seq(c, m, sin.data(), slen.data(), sout.data(), scap.data(), solen.data(), sst.data(), stream, sad.data())) ok = false;
+        for (int j = 0; j < m; j++) {
+            out_len[seq[(size_t)j]] = solen[(size_t)j], st[(size_t)seq[(size_t)j]] = sst[(size_t)j];
+            if (adler_out) adler_out[seq[(size_t)j]] = sad[(size_t)j];
+        }
     }
     if (status) memcpy(status, st.data(), sizeof(int) * (size_t)n);
     return ok;
@@ -864,6 +923,95 @@ int zs_inflate_batch(zs_ctx *c, int n, const void *const *in, const int64_t *in_
             return ZS_STREAM_ERROR;
     if (hipStreamSynchronize(c->stream) != hipSuccess) return ZS_STREAM_ERROR;
     return rc;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------ multi-GPU batch entry points
+// BASELINE north_star: "independent input buffers shard embarrassingly across the 8 GPUs of one node (no RCCL needed)".
+// The unit of sharding is the buffer (a zlib stream cannot be split bit-exactly: 32 KiB history, sequential parse,
+// bit-contiguous blocks).  Longest-processing-time partition by size, one host thread and one context per device, results
+// in input order; no collective, no peer traffic.
+extern "C" {
+
+int zs_device_count(void) {
+    int count = 0;
+    return hipGetDeviceCount(&count) == hipSuccess ? count : 0;
+}
+
+int zs_partition(const int64_t *sizes, int n, int n_parts, int *part_of) {
+    if (!sizes || !part_of || n < 0 || n_parts <= 0) return ZS_STREAM_ERROR;
+    std::vector<int> order((size_t)n);
+    for (int i = 0; i < n; i++) order[(size_t)i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return sizes[a] > sizes[b]; });  // ties keep input order
+    std::vector<int64_t> load((size_t)n_parts, 0);
+    for (int i : order) {
+        int best = 0;
+        for (int k = 1; k < n_parts; k++)
+            if (load[(size_t)k] < load[(size_t)best]) best = k;  // ties go to the lowest part
+        part_of[i] = best;
+        load[(size_t)best] += sizes[i];
+    }
+    return ZS_OK;
+}
+
+}  // extern "C"
+
+namespace {
+template <class Fn>  // Fn(ctx, count, in, in_len, out, out_cap, out_len, status) -> code
+int run_multi(zs_ctx *const *ctxs, int n_ctx, int n, const void *const *in, const int64_t *in_len, void *const *out,
+              const int64_t *out_cap, int64_t *out_len, int *status, const int64_t *weights, Fn fn) {
+    if (!ctxs || n_ctx <= 0 || n < 0) return ZS_STREAM_ERROR;
+    for (int k = 0; k < n_ctx; k++)
+        if (!ctxs[k]) return ZS_STREAM_ERROR;
+    if (n == 0) return ZS_OK;
+    std::vector<int> part((size_t)n);
+    if (zs_partition(weights, n, n_ctx, part.data()) != ZS_OK) return ZS_STREAM_ERROR;
+    std::vector<std::vector<int>> idx((size_t)n_ctx);
+    for (int i = 0; i < n; i++) idx[(size_t)part[(size_t)i]].push_back(i);
+    std::vector<int> rc((size_t)n_ctx, ZS_OK);
+    std::vector<std::thread> th;
+    for (int k = 0; k < n_ctx; k++) {
+        if (idx[(size_t)k].empty()) continue;
+        th.emplace_back([&, k]() {
+            const std::vector<int> &ix = idx[(size_t)k];
+            const size_t m = ix.size();
+            std::vector<const void *> sin(m);
+            std::vector<void *> sout(m);
+            std::vector<int64_t> slen(m), scap(m), solen(m, 0);
+            std::vector<int> sst(m, ZS_STREAM_ERROR);
+            for (size_t j = 0; j < m; j++) sin[j] = in[ix[j]], sout[j] = out[ix[j]], slen[j] = in_len[ix[j]], scap[j] = out_cap[ix[j]];
+            rc[(size_t)k] = fn(ctxs[k], (int)m, sin.data(), slen.data(), sout.data(), scap.data(), solen.data(), sst.data());
+            for (size_t j = 0; j < m; j++) {
+                out_len[ix[j]] = solen[j];
+                if (status) status[ix[j]] = sst[j];
+            }
+        });
+    }
+    for (std::thread &t : th) t.join();
+    for (int k = 0; k < n_ctx; k++)
+        if (rc[(size_t)k] != ZS_OK) return rc[(size_t)k];
+    return ZS_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int zs_deflate_batch_multi(zs_ctx *const *ctxs, int n_ctx, int n, const void *const *in, const int64_t *in_len, void *const *out,
+                           const int64_t *out_cap, int64_t *out_len, int *status, int level, int strategy, int hash_variant) {
+    return run_multi(ctxs, n_ctx, n, in, in_len, out, out_cap, out_len, status, in_len,
+                     [=](zs_ctx *c, int m, const void *const *i, const int64_t *il, void *const *o, const int64_t *oc, int64_t *ol, int *st) {
+                         return zs_deflate_batch(c, m, i, il, o, oc, ol, st, level, strategy, hash_variant);
+                     });
+}
+
+int zs_inflate_batch_multi(zs_ctx *const *ctxs, int n_ctx, int n, const void *const *in, const int64_t *in_len, void *const *out,
+                           const int64_t *out_cap, int64_t *out_len, int *status) {
+    // balanced by output capacity: the decoded size is what an inflate costs
+    return run_multi(ctxs, n_ctx, n, in, in_len, out, out_cap, out_len, status, out_cap,
+                     [](zs_ctx *c, int m, const void *const *i, const int64_t *il, void *const *o, const int64_t *oc, int64_t *ol, int *st) {
+                         return zs_inflate_batch(c, m, i, il, o, oc, ol, st);
+                     });
 }
 
 }  // extern "C"

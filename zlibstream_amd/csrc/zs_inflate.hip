@@ -253,7 +253,9 @@ __global__ __launch_bounds__(64) void zs_inflate_kernel(const InfDesc *descs, In
             __syncthreads();
             int r = inf_build(lens, 19, T.lit, 7, T.lcount, T.lsym);  // bit-length code: <= 7 bits, fits the primary table
             if (r < 0) INF_FAIL(ZS_DATA_, kInfOverBl);
-            if (r > 0) INF_FAIL(ZS_DATA_, kInfIncompleteBl);
+            // an incomplete code is accepted only when it is a single code of length 1 (Huft_build: `y != 0 && g != 1`,
+            // InfTree.cs:364; Inflate_trees_bits :378-382)
+            if (r > 0 && !(T.lcount[1] == 1 && 19 - T.lcount[0] == 1)) INF_FAIL(ZS_DATA_, kInfIncompleteBl);
             __syncthreads();
             uint8_t prev = 0;
             int idx = 0;
@@ -293,12 +295,15 @@ __global__ __launch_bounds__(64) void zs_inflate_kernel(const InfDesc *descs, In
             __syncthreads();
             r = inf_build(lens, nlen, T.lit, kInfLitBits, T.lcount, T.lsym);
             if (r < 0) INF_FAIL(ZS_DATA_, kInfOverLit);
-            if (r > 0 && nlen - T.lcount[0] != 1) INF_FAIL(ZS_DATA_, kInfIncompleteLit);
+            if (r > 0 && !(T.lcount[1] == 1 && nlen - T.lcount[0] == 1)) INF_FAIL(ZS_DATA_, kInfIncompleteLit);  // InfTree.cs:364,397-410
             r = inf_build(lens + nlen, ndist, T.dist, kInfDistBits, T.dcount, T.dsym);
             if (r < 0) INF_FAIL(ZS_DATA_, kInfOverDist);
-            if (r > 0 && ndist - T.dcount[0] != 1) {
-                if (ndist - T.dcount[0] == 0 && nlen > 257) INF_FAIL(ZS_DATA_, kInfEmptyDist);
-                if (ndist - T.dcount[0] > 1) INF_FAIL(ZS_DATA_, kInfIncompleteDist);
+            if (r > 0) {  // InfTree.cs:364,413-431
+                if (ndist - T.dcount[0] == 0) {
+                    if (nlen > 257) INF_FAIL(ZS_DATA_, kInfEmptyDist);
+                } else if (!(T.dcount[1] == 1 && ndist - T.dcount[0] == 1)) {
+                    INF_FAIL(ZS_DATA_, kInfIncompleteDist);
+                }
             }
         }
         __syncthreads();

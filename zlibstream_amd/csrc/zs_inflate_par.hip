@@ -60,7 +60,7 @@ struct ParBlock {
 struct ParState {
     int32_t ncand, nblk;
     int32_t ok;        // 1: block-parallel path valid for this stream
-    int32_t pad_;
+    int32_t win_off;   // index of the stream's first window in `windows` (set by the host once the block counts are known)
     int64_t out_len, end_bit;
 };
 
@@ -152,11 +152,11 @@ __device__ int inf_dyn_tables(InfBits &b, InfTables &T, uint8_t *lens, uint8_t *
     for (int i = lane; i < 320; i += 64) lens[i] = i < nlen + ndist ? ll[i] : 0;
     __syncthreads();
     int q = inf_build(lens, nlen, T.lit, kInfLitBits, T.lcount, T.lsym);
-    if (q < 0 || (q > 0 && nlen - T.lcount[0] != 1) || lens[256] == 0) {
+    if (q < 0 || (q > 0 && !(T.lcount[1] == 1 && nlen - T.lcount[0] == 1)) || lens[256] == 0) {
         return 1;
     }
     q = inf_build(lens + nlen, ndist, T.dist, kInfDistBits, T.dcount, T.dsym);
-    if (q < 0 || (q > 0 && ndist - T.dcount[0] > 1)) {
+    if (q < 0 || (q > 0 && ndist - T.dcount[0] >= 1 && !(T.dcount[1] == 1 && ndist - T.dcount[0] == 1))) {
         return 1;
     }
     return 0;
@@ -1169,7 +1169,7 @@ __global__ __launch_bounds__(1024) void zs_inf_window_kernel(const ParStream *ps
     const ParState ss = st[blockIdx.x];
     if (!ss.ok) return;
     const uint16_t *cl = cells + s.cell_off;
-    uint8_t *win = windows + (int64_t)s.blk_off * kWSize;
+    uint8_t *win = windows + (int64_t)ss.win_off * kWSize;
     for (int i = threadIdx.x; i < kWSize; i += 1024) wl[0x8000 + i] = 0;  // before the stream: zeros
     if (threadIdx.x < 256) wl[threadIdx.x] = (uint8_t)threadIdx.x, wl[kWinImage + threadIdx.x] = (uint8_t)threadIdx.x;
     __syncthreads();
@@ -1246,7 +1246,7 @@ __global__ __launch_bounds__(256) void zs_inf_resolve_kernel(const ParStream *ps
     const ParStream s = ps[w.x];
     if (!st[w.x].ok || (int)w.y >= st[w.x].nblk) return;
     const ParBlock k = blocks[s.blk_off + w.y];
-    const uint8_t *pw = w.y ? windows + ((int64_t)s.blk_off + w.y - 1) * kWSize : nullptr;
+    const uint8_t *pw = w.y ? windows + ((int64_t)st[w.x].win_off + w.y - 1) * kWSize : nullptr;
     const uint16_t *cl = cells + s.cell_off + k.out_off;
     uint8_t *o = s.out + k.out_off;
     for (int64_t i = threadIdx.x; i < k.out_bytes; i += 256) {

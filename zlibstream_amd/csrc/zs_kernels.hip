@@ -1982,4 +1982,42 @@ __global__ __launch_bounds__(256) void zs_adler_kernel(const StreamDesc *sd, con
     }
 }
 
+// Adler-32 of whole buffers from their 64 KiB pieces, one workgroup per buffer, and -- for inflate -- the comparison with
+// the stream's trailer (Inflate.cs:300-345): `trailer[i]` points at the 4 big-endian bytes behind the last block, or is
+// null.  res[i] = (adler of the buffer, 1 when it equals the trailer / no trailer given).
+__global__ __launch_bounds__(256) void zs_adler_finish_kernel(const StreamDesc *sd, const uint32_t *pieces, const uint8_t *const *trailer,
+                                                              uint2 *res) {
+    __shared__ uint32_t ad_v[256];
+    __shared__ uint64_t ad_len[256];
+    const StreamDesc s = sd[blockIdx.x];
+    uint32_t acc = 1;
+    uint64_t acc_len = 0;
+    const int per = (s.n_adler + 255) / 256;
+    for (int k = 0; k < per; k++) {
+        const int i = threadIdx.x * per + k;
+        if (i >= s.n_adler) break;
+        int64_t len = (int64_t)s.n - (int64_t)i * kAdlerPiece;
+        if (len > kAdlerPiece) len = kAdlerPiece;
+        acc = adler_combine(acc, pieces[s.adler_off + i], (uint64_t)len);
+        acc_len += (uint64_t)len;
+    }
+    ad_v[threadIdx.x] = acc, ad_len[threadIdx.x] = acc_len;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {
+        if ((threadIdx.x & (2 * off - 1)) == 0) {
+            ad_v[threadIdx.x] = adler_combine(ad_v[threadIdx.x], ad_v[threadIdx.x + off], ad_len[threadIdx.x + off]);
+            ad_len[threadIdx.x] += ad_len[threadIdx.x + off];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x != 0) return;
+    uint32_t ok = 1;
+    if (trailer && trailer[blockIdx.x]) {
+        const uint8_t *t = trailer[blockIdx.x];
+        const uint32_t want = ((uint32_t)t[0] << 24) | ((uint32_t)t[1] << 16) | ((uint32_t)t[2] << 8) | t[3];
+        ok = want == ad_v[0];
+    }
+    res[blockIdx.x] = make_uint2(ad_v[0], ok);
+}
+
 }  // namespace zs

@@ -40,20 +40,31 @@ def _vocab():
     return _vocab_cache
 
 
+def _xorshift_blocks(seed, steps, block):
+    """xorshift64* run as _LANES interleaved generators: yields the draws of `block` steps at a time (step-major)."""
+    state = np.array([((seed + i * GOLDEN) & MASK) or 1 for i in range(_LANES)], dtype=np.uint64)
+    mul = np.uint64(0x2545F4914F6CDD1D)
+    done = 0
+    while done < steps:
+        k = min(block, steps - done)
+        out = np.empty((k, _LANES), dtype=np.uint64)
+        for t in range(k):
+            state ^= state >> np.uint64(12)
+            state ^= state << np.uint64(25)
+            state ^= state >> np.uint64(27)
+            out[t] = state * mul
+        done += k
+        yield out.reshape(-1)
+
+
 def _xorshift_lanes(seed, steps):
     """steps x _LANES uint64 draws of xorshift64* (one generator per lane)."""
-    state = np.array([((seed + i * GOLDEN) & MASK) or 1 for i in range(_LANES)], dtype=np.uint64)
-    out = np.empty((steps, _LANES), dtype=np.uint64)
-    mul = np.uint64(0x2545F4914F6CDD1D)
-    for t in range(steps):
-        state ^= state >> np.uint64(12)
-        state ^= state << np.uint64(25)
-        state ^= state >> np.uint64(27)
-        out[t] = state * mul
-    return out.reshape(-1)
+    return np.concatenate(list(_xorshift_blocks(seed, steps, max(steps, 1))))
 
 
 def english(n, seed=GOLDEN):
+    """The word sequence of one reseed round is fixed by (seed, number of steps); it is turned into bytes a block of
+    draws at a time so that the index arrays stay cache-sized (the byte-for-byte result does not depend on the block)."""
     blob, offs, lens, cdf = _vocab()
     if n == 0:
         return b""
@@ -65,30 +76,40 @@ def english(n, seed=GOLDEN):
     while filled < n:
         want = int((n - filled) / mean * 1.05) + _LANES
         steps = (want + _LANES - 1) // _LANES
-        u = _xorshift_lanes(rnd_seed, steps)
+        room = n - filled + 64   # words are kept while their end stays within this many bytes (at least one word)
+        used = 0                 # bytes this round has produced
+        first = True
+        for u in _xorshift_blocks(rnd_seed, steps, 64):
+            idx = np.searchsorted(cdf, (u >> np.uint64(11)).astype(np.float64) * (1.0 / (1 << 53)), side="right")
+            idx = np.minimum(idx, len(lens) - 1)
+            wl = lens[idx] + 1
+            ends = np.cumsum(wl)
+            keep = int(np.searchsorted(ends, room - used, side="right"))
+            if first:
+                keep = max(keep, 1)
+            first = False
+            stop = keep < len(idx)
+            if keep == 0:
+                break
+            idx, wl, ends = idx[:keep], wl[:keep], ends[:keep]
+            starts = ends - wl
+            total = int(ends[-1])
+            # source index of every output byte (separator slots fixed afterwards)
+            src = np.repeat(offs[idx] - starts, wl) + np.arange(total, dtype=np.int64)
+            sep = ends - 1
+            src[sep] = 0
+            piece = blob[src]
+            seps = np.full(keep, 32, dtype=np.uint8)
+            seps[(np.arange(word_no, word_no + keep) % 12) == 11] = 10
+            piece[sep] = seps
+            word_no += keep
+            take = min(total, n + 64 - filled)
+            out[filled:filled + take] = piece[:take]
+            filled += take
+            used += total
+            if stop or filled >= n + 64:
+                break
         rnd_seed = (rnd_seed + GOLDEN * 7919) & MASK
-        idx = np.searchsorted(cdf, (u >> np.uint64(11)).astype(np.float64) * (1.0 / (1 << 53)), side="right")
-        idx = np.minimum(idx, len(lens) - 1)
-        wl = lens[idx] + 1
-        ends = np.cumsum(wl)
-        keep = int(np.searchsorted(ends, n - filled + 64, side="right"))
-        keep = max(keep, 1)
-        idx, wl, ends = idx[:keep], wl[:keep], ends[:keep]
-        starts = ends - wl
-        total = int(ends[-1])
-        piece = np.empty(total, dtype=np.uint8)
-        # source index of every output byte (separator slots fixed afterwards)
-        src = np.repeat(offs[idx] - starts, wl) + np.arange(total, dtype=np.int64)
-        sep = ends - 1
-        src[sep] = 0
-        piece[:] = blob[src]
-        seps = np.full(keep, 32, dtype=np.uint8)
-        seps[(np.arange(word_no, word_no + keep) % 12) == 11] = 10
-        piece[sep] = seps
-        word_no += keep
-        take = min(total, n + 64 - filled)
-        out[filled:filled + take] = piece[:take]
-        filled += take
     return out[:n].tobytes()
 
 

@@ -2,20 +2,24 @@
 buffers shard embarrassingly across the 8 GPUs of one node (no RCCL needed)").
 
 A single zlib stream cannot be split across GPUs bit-exactly (32 KiB history, sequential lazy
-parse, bit-contiguous blocks), so the unit of sharding is the buffer.  Deterministic
-longest-processing-time assignment: every rank computes the same partition from the sizes
-alone, so no data-path collective is needed.
+parse, bit-contiguous blocks), so the unit of sharding is the buffer.  The partition is the
+library's own (`zs_partition`, include/zsgpu.h: longest-processing-time by size, deterministic),
+the one `zs_deflate_batch_multi` uses inside one process; `bench.py --gpus N` calls it on every
+rank with the same sizes, so ranks agree on who compresses what without a data-path collective.
 """
+import ctypes
+
+from . import _native
 
 
 def partition(sizes, world):
+    """-> list of `world` sorted index lists."""
+    n = len(sizes)
+    part = (ctypes.c_int * max(n, 1))()
+    rc = _native.lib().zs_partition((ctypes.c_int64 * max(n, 1))(*[int(x) for x in sizes]), n, int(world), part)
+    if rc != 0:
+        raise ValueError("zs_partition(%d sizes, %d parts) failed" % (n, world))
     parts = [[] for _ in range(world)]
-    loads = [0] * world
-    order = sorted(range(len(sizes)), key=lambda i: (-sizes[i], i))
-    for i in order:
-        r = min(range(world), key=lambda k: (loads[k], k))
-        parts[r].append(i)
-        loads[r] += sizes[i]
-    for p in parts:
-        p.sort()
+    for i in range(n):
+        parts[part[i]].append(i)
     return parts
