@@ -546,6 +546,30 @@ int main(int argc, char **argv) {
     run_tail(m, p, kind, pend, k_done, preins);
 
     bool ok = true;
+    if (level == 0 && strategy != kRle) {
+        // level 0 on the device: the block list comes from plan_stored_blocks (sizes only) instead of the literal engine;
+        // it must be the engine's list, block for block, and the Write -> block counts with it
+        std::vector<BlockRec> plan;
+        std::vector<int32_t> pwb(m.wr_end.size(), 0);
+        const bool wr = m.wr_end.size() > 1 || flush_mode;
+        const std::vector<int64_t> no_ends;
+        const std::vector<uint8_t> no_flush;
+        plan_stored_blocks(n, wr ? m.wr_end : no_ends, flush_mode ? m.wr_flush : no_flush,
+                           [&](int64_t start, int32_t blen, int can_store, int eof) { plan.push_back(BlockRec{start, 0, blen, 0, can_store, eof}); },
+                           [&](int w, int nb) { pwb[(size_t)w] = nb; });
+        if (plan.size() != m.blocks.size()) printf("stored plan: %zu blocks, engine %zu\n", plan.size(), m.blocks.size()), ok = false;
+        for (size_t i = 0; ok && i < plan.size(); i++) {
+            const BlockRec &a = plan[i], &b = m.blocks[i];
+            if (a.start != b.start || a.stored_len != b.stored_len || a.can_store != b.can_store || a.eof != b.eof || b.nsyms != 0) {
+                printf("stored plan block %zu: start %ld/%ld len %d/%d can %d/%d eof %d/%d\n", i, (long)a.start, (long)b.start, a.stored_len,
+                       b.stored_len, a.can_store, b.can_store, a.eof, b.eof);
+                ok = false;
+            }
+        }
+        if (flush_mode && pwb != m.wr_blk) printf("stored plan: wr_blk differs\n"), ok = false;
+        m.blocks = plan;  // the bytes below are assembled from the planned list
+        if (flush_mode) m.wr_blk = pwb;
+    }
     if (m.syms.size() != tr.syms.size()) {
         printf("symbol count %zu vs oracle %zu\n", m.syms.size(), tr.syms.size());
         ok = false;

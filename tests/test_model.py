@@ -89,3 +89,24 @@ def test_regular_multi_write_takes_the_chunked_form(model):
                 assert r.returncode == 0 and "PASS" in r.stdout, (name, w, level, r.stdout[-400:])
                 if os.path.getsize(model[name]) > w + 600:
                     assert "tail_from=0 " not in r.stdout + " ", (name, w, level)   # the bulk form really ran
+
+
+def test_level0_block_plan_equals_the_literal_engine(model, tmp_path):
+    """zs_core.h plan_stored_blocks (what the device uses at level 0: the blocks of DeflateStored from the sizes alone)
+    against the literal engine and the oracle's bytes: single Write, Writes on and off any grid, all flush modes, and
+    sizes around the window / block / slide boundaries."""
+    rng = np.random.default_rng(3)
+    for name in ("alice_0", "alice_1", "alice_5", "alice_600", "alice_65274", "alice_65536", "alice_65537", "alice_98304", "zeros_98305"):
+        run(model[name], 0, 0, "seq")
+    big = tmp_path / "big0"
+    big.write_bytes(rng.integers(0, 256, 700001, dtype=np.uint8).tobytes())
+    run(str(big), 0, 0, "seq")
+    for wchunk in (1, 7, 333, 32763, 32768, 65536, 81920, 100000):
+        if wchunk < 333:
+            run(model["alice_600"], 0, 0, "seq", wchunk)
+        else:
+            run(str(big), 0, 0, "seq", wchunk)
+        for flush in (1, 2, 3):
+            run(model["alice_98304"] if wchunk < 333 else str(big), 0, 0, "seq", max(wchunk, 100), flush)
+    for s in (2, 4):  # strategies other than Rle do not change DeflateStored
+        run(str(big), 0, s, "seq", 50000)

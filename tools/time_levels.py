@@ -24,3 +24,6 @@ for lvl in (6, 9, 1):
 en = datagen.english(8 << 20)
 for lvl in (1, 3):
     run("english8", en, lvl, reps=1)
+e64 = datagen.english(64 << 20)
+run("english64", e64, 0, reps=3)   # DeflateStored: host-planned blocks + copy kernel
+run("sparse64", sp, 0, reps=3)

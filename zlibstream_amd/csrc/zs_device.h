@@ -55,6 +55,10 @@ struct StreamDesc {
     const uint8_t *wr_flush;
     int32_t *wr_blk;
     int32_t out_chunk, raw;
+    // level 0 (DeflateStored): the block list is a function of the sizes alone and comes from the host
+    // (zs_core.h plan_stored_blocks); the literal engine is not run, the bytes are moved by the bit-emission kernel
+    const BlockRec *plan_blk;
+    int32_t plan_nblk, pad_;
 };
 
 struct StreamState {

@@ -47,7 +47,7 @@ struct zs_ctx {
     uint32_t *crc_tab = nullptr;
     DevBuf sd, st, work, geo, link, mm, maps, segmap, seg_entry, seg_symbase, seg_stale, entry, symbase, stale, syms, blk_end, blk_top, blocks, trees, info, pieces, scratch,
         stage_in, stage_out, wr, inf_desc, inf_state, par_ps, par_st, par_work, par_cbits, par_ccnt, par_surv, par_scnt, par_cands, par_tabs, par_blocks, par_cells,
-        par_windows, par_fail, run_syms, run_bits, run_scratch, run_outs, run_fail, adl_tr, adl_res;
+        par_windows, par_fail, run_syms, run_bits, run_scratch, run_outs, run_fail, adl_tr, adl_res, plan_blk;
     void *pinned = nullptr;
     size_t pinned_cap = 0;
 };
@@ -91,6 +91,8 @@ struct Plan {
     int64_t n_chunks = 0, n_segs = 0, n_blocks = 0, n_pieces = 0, n_runs = 0;
     std::vector<int32_t> seg_c0, seg_after, seg_base;  // per parse segment (all streams, in seg_off order)
     std::vector<uint8_t> head;                         // per chunk (chunk_off order): a read event fires at its entry
+    std::vector<BlockRec> plan_blk;                    // level 0: the stored blocks of every stream, stream after stream
+    std::vector<int32_t> plan_wr_blk;                  // level 0 under a flush mode: blocks flushed before each Write began
 };
 
 template <class T>
@@ -177,8 +179,27 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
         pl.n_runs += s.fast_runs;
         for (int k = 0; k < s.fast_runs; k++) pl.w_runs.push_back(make_uint2((unsigned)i, (unsigned)k));
         s.blk_off = (int32_t)pl.n_blocks;
-        s.max_blocks = (int32_t)(level == 0 ? len / 8191 + len / 32506 + 4 : len / kBlockSyms + 2);
+        s.max_blocks = (int32_t)(len / kBlockSyms + 2);
         if (flushing) s.max_blocks += (int32_t)writes->ends.size() + 1;  // every Write under a flush mode closes a block
+        s.plan_blk = nullptr, s.plan_nblk = 0, s.pad_ = 0;
+        if (level == 0 && strategy != kRle) {
+            // DeflateStored: block boundaries from the sizes alone (zs_core.h plan_stored_blocks); s.plan_blk holds the
+            // offset into the batch's list until the device address is known
+            const size_t first = pl.plan_blk.size();
+            const std::vector<int64_t> no_ends;
+            const std::vector<uint8_t> no_flush;
+            if (flushing) pl.plan_wr_blk.assign(writes->ends.size(), 0);
+            plan_stored_blocks(len, (multi || flushing) ? writes->ends : no_ends, flushing ? writes->flush : no_flush,
+                               [&](int64_t start, int32_t blen, int can_store, int eof) {
+                                   pl.plan_blk.push_back(BlockRec{start, 0, blen, 0, can_store, eof});
+                               },
+                               [&](int w, int nb) {
+                                   if (flushing) pl.plan_wr_blk[(size_t)w] = nb;
+                               });
+            s.plan_nblk = (int32_t)(pl.plan_blk.size() - first);
+            s.plan_blk = (const BlockRec *)(uintptr_t)first;
+            s.max_blocks = s.plan_nblk + 1;
+        }
         pl.n_blocks += s.max_blocks;
         s.adler_off = (int32_t)pl.n_pieces;
         s.n_adler = (int32_t)((len + kAdlerPiece - 1) / kAdlerPiece);
@@ -218,6 +239,11 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
         s.seg_c0 = g + s.seg_off, s.seg_after = g + pl.n_segs + s.seg_off, s.seg_base = g + 2 * pl.n_segs + s.seg_off;
         s.head = (const uint8_t *)c->geo.p + 12 * (size_t)pl.n_segs + (size_t)s.chunk_off;
     }
+    if (!pl.plan_blk.empty()) {
+        if (!ensure(c, c->plan_blk, sizeof(BlockRec) * pl.plan_blk.size())) return false;
+        for (int i = 0; i < n; i++)
+            if (pl.sd[(size_t)i].plan_nblk) pl.sd[(size_t)i].plan_blk = dev<BlockRec>(c->plan_blk) + (uintptr_t)pl.sd[(size_t)i].plan_blk;
+    }
     if (pl.n_runs &&
         (!ensure(c, c->run_syms, 4 * (size_t)pl.n_runs * kFastRunSyms) || !ensure(c, c->run_bits, 4 * (size_t)pl.n_runs * kFastRunBitWords) ||
          !ensure(c, c->run_scratch, (size_t)pl.n_runs * kFastRunScratch) || !ensure(c, c->run_outs, sizeof(FastRunOut) * (size_t)pl.n_runs) ||
@@ -235,7 +261,13 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
             pl.sd[0].wr_blk = (int32_t *)((uint8_t *)c->wr.p + 8 * nw);
             pl.sd[0].wr_flush = (const uint8_t *)c->wr.p + 12 * nw;
         }
+        if (!pl.plan_wr_blk.empty())
+            ZS_HIP(c, hipMemcpyAsync((uint8_t *)c->wr.p + 8 * nw, pl.plan_wr_blk.data(), 4 * nw, hipMemcpyHostToDevice, stream));
         ZS_HIP(c, hipStreamSynchronize(stream));  // `writes` is caller-owned pageable memory
+    }
+    if (!pl.plan_blk.empty()) {
+        ZS_HIP(c, hipMemcpyAsync(c->plan_blk.p, pl.plan_blk.data(), sizeof(BlockRec) * pl.plan_blk.size(), hipMemcpyHostToDevice, stream));
+        ZS_HIP(c, hipStreamSynchronize(stream));  // pageable source
     }
     // ---- upload descriptors and work lists (one pinned staging copy) ----
     size_t up_bytes = sizeof(StreamDesc) * (size_t)n + sizeof(uint2) * n_work + geo_bytes + 16;
@@ -535,7 +567,7 @@ void zs_ctx_destroy(zs_ctx *c) {
     DevBuf *bufs[] = {&c->sd, &c->st, &c->work, &c->geo, &c->link, &c->mm, &c->maps, &c->segmap, &c->seg_entry, &c->seg_symbase, &c->seg_stale, &c->entry, &c->symbase, &c->stale, &c->syms,
                       &c->blk_end, &c->blk_top, &c->blocks, &c->trees, &c->info, &c->pieces, &c->scratch, &c->stage_in, &c->stage_out, &c->wr, &c->inf_desc, &c->inf_state, &c->par_ps, &c->par_st, &c->par_work, &c->par_cbits, &c->par_ccnt, &c->par_surv, &c->par_scnt,
                       &c->par_cands, &c->par_tabs, &c->par_blocks, &c->par_cells, &c->par_windows, &c->par_fail, &c->run_syms, &c->run_bits,
-                      &c->run_scratch, &c->run_outs, &c->run_fail, &c->adl_tr, &c->adl_res};
+                      &c->run_scratch, &c->run_outs, &c->run_fail, &c->adl_tr, &c->adl_res, &c->plan_blk};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     if (c->crc_tab) (void)hipFree(c->crc_tab);

@@ -1092,6 +1092,12 @@ __global__ __launch_bounds__(1024) void zs_tail_kernel(const StreamDesc *sd, Str
     if (s.fast_runs > 0) return;  // handled by zs_fast_run_kernel / zs_fast_stitch_kernel
     StreamState &ss = st[blockIdx.x];
     const int tid = threadIdx.x, nth = blockDim.x;  // all threads restore; wave 0 then runs the engine
+    if (s.plan_nblk > 0) {
+        // level 0: the stored blocks were planned on the host from the sizes; nothing to parse
+        for (int i = tid; i < s.plan_nblk; i += nth) blocks[s.blk_off + i] = s.plan_blk[i];
+        if (tid == 0) ss.nsyms = 0, ss.nblocks = s.plan_nblk;
+        return;
+    }
     uint8_t *sc = scratch + (int64_t)blockIdx.x * kScratchBytes;
     BlockRec *blk = blocks + s.blk_off;
     const uint32_t body_syms = ss.body_syms;
@@ -1533,6 +1539,18 @@ __global__ __launch_bounds__(256) void zs_trees_kernel(const StreamDesc *sd, con
     const int nb_body = s.fast_runs > 0 ? 0 : (int)(st[w.x].body_syms / kBlockSyms);
     if (phase == 0 ? b >= nb_body : ((phase == 1 && b < nb_body) || b >= st[w.x].nblocks)) return;
     const BlockRec r = blocks[s.blk_off + b];
+    if (level == 0 && r.nsyms == 0 && s.plan_nblk > 0) {
+        // DeflateStored tallies nothing and level 0 skips the tree comparison (Trees.cs:601-620): stored while the block
+        // start is in the window, else an empty static block (3 header bits + END_BLOCK)
+        if (threadIdx.x == 0) {
+            BlockInfo bi;
+            bi.type = r.can_store ? 0 : 1;
+            bi.bits = r.can_store ? 0 : 10;
+            bi.bit_start = 0;
+            info[s.blk_off + b] = bi;
+        }
+        return;
+    }
     for (int i = threadIdx.x; i < kLCodes; i += blockDim.x) hl[i] = 0;
     for (int i = threadIdx.x; i < kDCodes; i += blockDim.x) hd[i] = 0;
     __syncthreads();
@@ -1813,9 +1831,14 @@ __global__ __launch_bounds__(256) void zs_emit_bits_kernel(const StreamDesc *sd,
             out[byte] = (uint8_t)len, out[byte + 1] = (uint8_t)(len >> 8);
             out[byte + 2] = (uint8_t)~len, out[byte + 3] = (uint8_t)(~len >> 8);
         }
-        const uint8_t *src = s.in + r.start;
-        uint8_t *dst = out + byte + 4;
-        for (int i = tid; i < r.stored_len; i += 256) dst[i] = src[i];
+        // Copy_block (Deflate.cs:710-722): 16 bytes per lane and trip (global memory takes them at any alignment), bytes at the end
+        const gcbytes src = as_global(s.in) + r.start;
+        const gbytes_w dst = as_global(out) + byte + 4;
+        typedef u32x4 __attribute__((aligned(1))) u32x4u;
+        const int nvec = r.stored_len >> 4;
+        for (int i = tid; i < nvec; i += 256)
+            *(__attribute__((address_space(1))) u32x4u *)(dst + 16 * i) = *(const __attribute__((address_space(1))) u32x4u *)(src + 16 * i);
+        for (int i = (nvec << 4) + tid; i < r.stored_len; i += 256) dst[i] = src[i];
         return;
     }
     const TreeWork &tw = trees[s.blk_off + b];
