@@ -179,7 +179,8 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
         pl.n_runs += s.fast_runs;
         for (int k = 0; k < s.fast_runs; k++) pl.w_runs.push_back(make_uint2((unsigned)i, (unsigned)k));
         s.blk_off = (int32_t)pl.n_blocks;
-        s.max_blocks = (int32_t)(len / kBlockSyms + 2);
+        // level 0 runs with memLevel 7: a block is flushed every 8191 symbols (only Rle tallies symbols there)
+        s.max_blocks = (int32_t)(level == 0 ? len / 8191 + len / 32506 + 4 : len / kBlockSyms + 2);
         if (flushing) s.max_blocks += (int32_t)writes->ends.size() + 1;  // every Write under a flush mode closes a block
         s.plan_blk = nullptr, s.plan_nblk = 0, s.pad_ = 0;
         if (level == 0 && strategy != kRle) {
