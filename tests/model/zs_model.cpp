@@ -58,6 +58,7 @@ struct Model {
     int flush_mode = 0;            // ZlibOptions.FlushMode of every Write
     std::vector<uint8_t> wr_flush;
     std::vector<int32_t> wr_blk;
+    bool incremental = false;  // mode "inc": the literal engine run Write by Write (suspend / re-enter)
 
     uint32_t bucket(int64_t p) const {
         uint32_t v = (uint32_t)data[p + 2] | ((uint32_t)data[p + 3] << 8) | ((uint32_t)data[p + 4] << 16) | ((uint32_t)data[p + 5] << 24);
@@ -352,7 +353,29 @@ static void run_tail(Model &m, int64_t p, int kind, uint32_t pend, int k_done, i
         }
         le_restore_finish(e, p, m.link.data(), preins);
     }
-    le_run(e, m.level, 0, 1);
+    if (m.incremental && !m.wr_end.empty()) {
+        // incremental stream: one run per Write (the engine suspends where Deflate.Compress returns for more input and is
+        // re-entered with the next Write), then the Finish call as a run of its own without input
+        for (size_t r = 0; r <= m.wr_end.size(); r++) {
+            const bool last = r == m.wr_end.size();
+            e.final_run = last ? 1 : 0;
+            e.suspended = 0;
+            e.cur_wr = 0;
+            if (last) {
+                e.wr_end = nullptr, e.n_wr = 1, e.wr_flush = nullptr, e.wr_blk = nullptr;
+            } else {
+                e.wr_end = m.wr_end.data() + r, e.n_wr = 1;
+                e.wr_flush = m.wr_flush.data() + r;  // a NoFlush Write has mode 0
+                e.wr_blk = m.wr_blk.data() + r;
+                m.wr_blk[r] = e.nblocks;
+                e.n = m.wr_end[r];
+            }
+            le_run(e, m.level, 0, 1);
+            if (!last && !e.suspended) printf("run %zu did not suspend\n", r);
+        }
+    } else {
+        le_run(e, m.level, 0, 1);
+    }
     m.syms.resize((size_t)e.nsyms);
     m.blocks.resize((size_t)e.nblocks);
 }
@@ -525,6 +548,7 @@ int main(int argc, char **argv) {
         for (int i = 0; i < 256; i++) m.crc_tab[tt * 256 + i] = crc32c_table_entry(tt, (uint32_t)i);
     m.wr_end = wends;
     m.flush_mode = flush_mode;
+    m.incremental = mode == "inc";
     // the bulk form needs a regular read schedule: one Write, or NoFlush Writes whose sizes are multiples of kChunk
     bool regular = build_read_events(n, wends, m.rev) && (wends.size() <= 1 || flush_mode == 0);
     m.body_end = (m.lv.func == 2 && strategy != kRle && regular) ? n - kMinLookahead : -1;

@@ -249,3 +249,60 @@ def test_zs_deflate_rejects_input_beyond_the_device_limit_cleanly(engine):
         assert tin.value == 31 * len(piece)
     finally:
         lib.zs_deflate_end(z)
+
+
+# ---------------------------------------------------------------- incremental streams: flushes deliver, memory stays bounded
+@pytest.mark.parametrize("level,flush", [(6, 2), (1, 2), (6, 1), (9, 3), (0, 2)])
+def test_flush_makes_the_data_readable_before_finish(engine, oracle, level, flush):
+    """Deflate.cs:583-613: after a Write under Partial / Sync / Full flush the reader can decode everything written so far
+    from the bytes delivered so far.  The stream's final bytes are the oracle's for the same Writes and mode."""
+    import io
+    from zlibstream_amd import CompressionLevel, FlushMode, ZlibOptions, ZlibOutputStream
+    text = datagen.english(700000, 31)
+    pieces = [text[:300000], text[300000:300007], text[300007:520000], text[520000:]]
+    out = io.BytesIO()
+    s = ZlibOutputStream(out, ZlibOptions(CompressionLevel=CompressionLevel(level), FlushMode=FlushMode(flush)), engine=engine)
+    done = b""
+    for p in pieces:
+        s.write(p)
+        done += p
+        d = zlib.decompressobj()
+        assert d.decompress(out.getvalue()) == done, "the data written so far is not readable after the flush"
+    s.close()
+    z = out.getvalue()
+    assert zlib.decompress(z) == text
+    assert z == oracle.compress(text, level, 0, chunks=[len(p) for p in pieces], flush=flush)
+
+
+def test_noflush_stream_that_outgrows_the_buffer_becomes_incremental(oracle):
+    """A NoFlush stream is buffered for the bulk pipeline only up to a limit (1 GiB; lowered here through the environment):
+    beyond it the stream turns incremental -- the buffered part through the bulk pipeline as a run that is not the end, the
+    rest continued from the suspended engine -- with bounded host memory and no length limit.  Bytes: the oracle's."""
+    import io
+    import os
+    import subprocess
+    import sys
+    code = r"""
+import io, sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import oracle_binding
+from zlibstream_amd import CompressionLevel, Engine, ZlibOptions, ZlibOutputStream, datagen
+eng = Engine(0)
+oracle = oracle_binding.Oracle()
+text = datagen.english(1500000, 77)
+for level, wsize in ((6, 81920), (6, 1000), (4, 65536), (1, 50000), (0, 81920)):
+    chunks = [min(wsize, len(text) - o) for o in range(0, len(text), wsize)]
+    out = io.BytesIO()
+    with ZlibOutputStream(out, ZlibOptions(CompressionLevel=CompressionLevel(level)), engine=eng) as s:
+        o = 0
+        early = 0
+        for c in chunks:
+            s.write(text[o:o + c]); o += c
+            early = max(early, len(out.getvalue()))
+    assert early > 1000, "nothing was delivered before Finish"
+    assert out.getvalue() == oracle.compress(text, level, 0, chunks=chunks), (level, wsize)
+print("OK")
+""" % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, ZS_INC_SWITCH_BYTES="300000")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0 and "OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])

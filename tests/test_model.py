@@ -110,3 +110,21 @@ def test_level0_block_plan_equals_the_literal_engine(model, tmp_path):
             run(model["alice_98304"] if wchunk < 333 else str(big), 0, 0, "seq", max(wchunk, 100), flush)
     for s in (2, 4):  # strategies other than Rle do not change DeflateStored
         run(str(big), 0, s, "seq", 50000)
+
+
+def test_incremental_runs_of_the_literal_engine(model, tmp_path):
+    """The engine run Write by Write -- suspended where Deflate.Compress returns for more input (NeedMore under NoFlush,
+    BlockDone after a flush), re-entered with the next Write, Finish as a last run without input -- gives the oracle's
+    bytes: every engine (stored, fast, slow, Rle), every flush mode, Writes longer and shorter than MIN_LOOKAHEAD."""
+    rng = np.random.default_rng(5)
+    mixed = tmp_path / "mixed"
+    alice = open(os.path.join(ROOT, "tests/golden/corpus/alice29.txt"), "rb").read()
+    mixed.write_bytes(alice[:90000] + bytes(40000) + rng.integers(0, 256, 50000, dtype=np.uint8).tobytes() + alice[:70000])
+    for level, strategy in ((0, 0), (1, 0), (3, 0), (4, 0), (6, 0), (9, 0), (6, 3), (6, 2)):  # level 0 + Rle overflows the reference's pending buffer on such data
+        for wchunk in (100, 261, 5000, 32768, 65536, 100000):
+            for flush in (0, 2) if wchunk in (261, 32768) else (0, 1, 2, 3):
+                run(str(mixed), level, strategy, "inc", wchunk, flush)
+    run(model["alice_600"], 6, 0, "inc", 1, 0)
+    run(model["alice_600"], 6, 0, "inc", 7, 2)
+    run(model["zeros_98305"], 6, 0, "inc", 4096, 1)
+    run(model["alice_0"], 6, 0, "inc", 0, 0)

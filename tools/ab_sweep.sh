@@ -1,0 +1,8 @@
+#!/bin/bash
+# A/B sweep: bench.py (headline only) with every library under build/variants/ in turn; one line per variant
+cp zlibstream_amd/libzsgpu.so /tmp/lib_orig.so
+for f in build/variants/*.so; do
+  cp "$f" zlibstream_amd/libzsgpu.so
+  timeout -k 5 120 python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-secondary "$@" 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$f', d['value'], d['ms_per_step'], 'match', d['stage_ms']['match'], 'syms', d['stage_ms']['emit_syms'], 'chunkmap', d['stage_ms']['chunkmap'])"
+done
+cp /tmp/lib_orig.so zlibstream_amd/libzsgpu.so

@@ -58,7 +58,32 @@ struct StreamDesc {
     // level 0 (DeflateStored): the block list is a function of the sizes alone and comes from the host
     // (zs_core.h plan_stored_blocks); the literal engine is not run, the bytes are moved by the bit-emission kernel
     const BlockRec *plan_blk;
-    int32_t plan_nblk, pad_;
+    int32_t plan_nblk;
+    // incremental streams (zs_stream_api.inc): the run is not the end of the stream (final_run == 0) and / or continues one
+    // whose engine state lives in `persist` (cont != 0: the input buffer holds only the bytes from absolute position abs_off
+    // on, nothing is parsed in bulk).  The Adler-32 of the whole stream is then the caller's (adler_stream).
+    int32_t final_run;
+    struct LitPersist *persist;
+    int64_t abs_off;
+    int32_t cont;
+    uint32_t adler_stream;
+    uint32_t carry_byte;  // cont: the bits of the stream's last, incomplete byte from the run before
+    int32_t pad_;
+};
+
+// What a suspended literal engine keeps between runs (device memory, one per zs_deflate stream): the reference's own state
+// -- window, prev, head, the Deflate fields (Deflate.cs:128-226) -- plus the symbols of the block in progress and the
+// chunk accounting of the output protocol (zs_core.h FlushAcct).
+struct LitPersist {
+    int64_t base, avail_end, block_start_abs;
+    int32_t strstart, lookahead, match_length, match_start, match_available, prev_length, prev_match;
+    int32_t pending_syms;
+    FlushAcct fa;
+    int32_t fa_valid, pad_;
+    uint8_t window[kWindowSize + 512];
+    uint16_t prev[kWSize];
+    uint16_t head[kHashSize];
+    uint32_t syms[kLitBufsize];
 };
 
 struct StreamState {
@@ -71,9 +96,10 @@ struct StreamState {
     uint32_t nsyms;
     int32_t nblocks;
     // written by the offsets kernel
-    int64_t out_len;
+    int64_t out_len;   // bytes of output; a run that is not the stream's end: complete bytes only
     uint32_t adler;
     int32_t status;
+    int64_t end_bits;  // bit position in the stream (zlib header included) behind the run's last block or marker
 };
 
 // DeflateFast (levels 1-3) as speculative chunk runs: run j re-parses kFastWarm bytes before its chunk with an

@@ -114,10 +114,22 @@ struct WriteSpec {
     }
 };
 
+// One run of an incremental stream (zs_stream_api.inc; one stream per call).  final_run == false: the stream goes on after
+// this run's Writes, the engine is left in `persist` (device memory) where Deflate.Compress would return to its caller, and
+// only what is final -- whole blocks and flush markers, complete bytes -- is output.  cont: the run continues from `persist`;
+// the input buffer then holds the new bytes only (absolute stream position abs_off on) and `writes` holds absolute ends.
+struct RunOpts {
+    bool final_run = true, cont = false;
+    LitPersist *persist = nullptr;
+    int64_t abs_off = 0;
+    uint32_t adler_stream = 1, carry_byte = 0;
+    int64_t end_bits = 0;  // out: stream bit position behind the run's last block or marker
+};
+
 // `writes` (optional, one stream only): the Writes of a multi-Write stream, or of one whose Writes carry a flush mode
 bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len, void *const *out, const int64_t *out_cap,
                   int64_t *out_len, int *status, int level, int strategy, int hash_variant, hipStream_t stream,
-                  const WriteSpec *writes = nullptr, bool force_seq = false) {
+                  const WriteSpec *writes = nullptr, bool force_seq = false, RunOpts *ro = nullptr) {
     if (level == -1) level = 6;
     LevelCfg lv = level_cfg(level);
     for (int i = 0; i < n; i++) {  // what the caller sees if a HIP call fails before the results are known
@@ -139,15 +151,19 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
         s.out_cap = out_cap[i];
         s.n = (int32_t)len;
         const bool multi = writes && writes->ends.size() > 1;
-        const bool flushing = writes && writes->flushing();
+        // an incremental run always takes the block-by-block output accounting (its state is carried from run to run)
+        const bool flushing = writes && (writes->flushing() || ro);
+        const bool cont = ro && ro->cont, final_run = !ro || ro->final_run;
         // the bulk pipeline needs a regular read schedule (zs_core.h build_read_events): one Write, or NoFlush Writes
         // whose ends fall on the chunk grid; other streams of several Writes run on the literal engine
         std::vector<ReadEvent> rev;
         const int64_t one_write[1] = {len};
-        const bool regular = multi ? (!flushing && build_read_events(len, writes->ends, rev))
-                                   : build_read_events(len, std::vector<int64_t>(one_write, one_write + 1), rev);
+        const bool real_flush = writes && writes->flushing();
+        const bool regular = cont ? false
+                             : multi ? (!real_flush && build_read_events(len, writes->ends, rev))
+                                     : build_read_events(len, std::vector<int64_t>(one_write, one_write + 1), rev);
         s.body_end = (lv.func == 2 && strategy != kRle && len >= kMinLookahead && regular) ? (int32_t)(len - kMinLookahead) : -1;
-        s.n_wr = (multi || flushing) ? (int32_t)writes->ends.size() : 1;
+        s.n_wr = (multi || flushing) ? (int32_t)writes->ends.size() : 1;  // 0: a run without input (Finish alone)
         s.wr_end = nullptr;
         s.wr_flush = nullptr, s.wr_blk = nullptr, s.out_chunk = writes ? writes->chunk : 512, s.raw = writes && writes->raw;
         s.kl = num_refills(len);
@@ -155,7 +171,7 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
         s.pos_off = pl.n_pos;
         pl.n_pos += (len + 64 + 63) & ~63LL;
         s.sym_off = pl.n_syms;
-        pl.n_syms += len + 64;
+        pl.n_syms += len + 64 + (ro ? kLitBufsize : 0);  // a continued run starts with the symbols of the block in progress
         s.chunk_off = (int32_t)pl.n_chunks;
         pl.n_chunks += s.nchunks;
         s.seg_off = (int32_t)pl.n_segs;
@@ -173,7 +189,7 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
         s.seg_c0 = s.seg_after = s.seg_base = nullptr, s.head = nullptr;
         pl.n_segs += s.nsegs;
         // levels 1-3, one Write, large enough: speculative chunk runs instead of one sequential engine
-        const bool fast_par = lv.func == 1 && strategy != kRle && !multi && !flushing && !force_seq && len >= kFastMinInput;
+        const bool fast_par = lv.func == 1 && strategy != kRle && !multi && !flushing && !force_seq && final_run && len >= kFastMinInput;
         s.fast_runs = fast_par ? (int32_t)((len + kFastChunk - 1) / kFastChunk) : 0;
         s.run_off = (int32_t)pl.n_runs;
         pl.n_runs += s.fast_runs;
@@ -183,7 +199,9 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
         s.max_blocks = (int32_t)(level == 0 ? len / 8191 + len / 32506 + 4 : len / kBlockSyms + 2);
         if (flushing) s.max_blocks += (int32_t)writes->ends.size() + 1;  // every Write under a flush mode closes a block
         s.plan_blk = nullptr, s.plan_nblk = 0, s.pad_ = 0;
-        if (level == 0 && strategy != kRle) {
+        s.final_run = final_run ? 1 : 0, s.cont = cont ? 1 : 0, s.persist = ro ? ro->persist : nullptr;
+        s.abs_off = ro ? ro->abs_off : 0, s.adler_stream = ro ? ro->adler_stream : 1, s.carry_byte = ro ? ro->carry_byte : 0;
+        if (level == 0 && strategy != kRle && !ro) {
             // DeflateStored: block boundaries from the sizes alone (zs_core.h plan_stored_blocks); s.plan_blk holds the
             // offset into the batch's list until the device address is known
             const size_t first = pl.plan_blk.size();
@@ -203,7 +221,7 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
         }
         pl.n_blocks += s.max_blocks;
         s.adler_off = (int32_t)pl.n_pieces;
-        s.n_adler = (int32_t)((len + kAdlerPiece - 1) / kAdlerPiece);
+        s.n_adler = ro ? 0 : (int32_t)((len + kAdlerPiece - 1) / kAdlerPiece);  // an incremental stream's checksum is its owner's
         pl.n_pieces += s.n_adler;
         for (int64_t k = 0; k * 65536 < s.out_cap; k++) pl.w_clear.push_back(make_uint2((unsigned)i, (unsigned)k));
         for (int k = 0; k < s.n_adler; k++) pl.w_adler.push_back(make_uint2((unsigned)i, (unsigned)k));
@@ -250,15 +268,15 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
          !ensure(c, c->run_scratch, (size_t)pl.n_runs * kFastRunScratch) || !ensure(c, c->run_outs, sizeof(FastRunOut) * (size_t)pl.n_runs) ||
          !ensure(c, c->run_fail, 4 * (size_t)n + 64)))
         return false;
-    if (writes && (writes->ends.size() > 1 || writes->flushing())) {
+    if (writes && (writes->ends.size() > 1 || writes->flushing() || ro)) {
         // [ends: int64 x nw][blocks before each Write: int32 x nw][flush modes: u8 x nw]
         const size_t nw = writes->ends.size();
         if (!ensure(c, c->wr, 13 * nw + 64)) return false;
         ZS_HIP(c, hipMemsetAsync(c->wr.p, 0, 13 * nw + 64, stream));
-        ZS_HIP(c, hipMemcpyAsync(c->wr.p, writes->ends.data(), sizeof(int64_t) * nw, hipMemcpyHostToDevice, stream));
+        if (nw) ZS_HIP(c, hipMemcpyAsync(c->wr.p, writes->ends.data(), sizeof(int64_t) * nw, hipMemcpyHostToDevice, stream));
         pl.sd[0].wr_end = (const int64_t *)c->wr.p;
-        if (writes->flushing()) {
-            ZS_HIP(c, hipMemcpyAsync((uint8_t *)c->wr.p + 12 * nw, writes->flush.data(), nw, hipMemcpyHostToDevice, stream));
+        if (writes->flushing() || ro) {
+            if (nw) ZS_HIP(c, hipMemcpyAsync((uint8_t *)c->wr.p + 12 * nw, writes->flush.data(), nw, hipMemcpyHostToDevice, stream));
             pl.sd[0].wr_blk = (int32_t *)((uint8_t *)c->wr.p + 8 * nw);
             pl.sd[0].wr_flush = (const uint8_t *)c->wr.p + 12 * nw;
         }
@@ -349,12 +367,15 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
     mark(7);
     // fork: the tail engine (sequential, one workgroup per stream) needs only what the resolve kernel left, so it runs
     // on the second stream beside the symbol kernels
-    ZS_HIP(c, hipEventRecord(c->ev_fork, stream));
-    ZS_HIP(c, hipStreamWaitEvent(c->aux, c->ev_fork, 0));
-    hipLaunchKernelGGL(zs_tail_kernel, dim3((unsigned)n), dim3(1024), kTailLds, c->aux, d_sd, d_st, dev<uint16_t>(c->link),
-                       dev<uint32_t>(c->syms), dev<int32_t>(c->blk_end), dev<int32_t>(c->blk_top), dev<BlockRec>(c->blocks),
-                       dev<uint8_t>(c->scratch), c->crc_tab, lv, strategy, hash_variant, level);
-    ZS_HIP(c, hipEventRecord(c->ev_join, c->aux));
+    const bool tail_late = ro && !ro->final_run;  // the engine is left for a later run: it needs K5's symbols and block ends
+    if (!tail_late) {
+        ZS_HIP(c, hipEventRecord(c->ev_fork, stream));
+        ZS_HIP(c, hipStreamWaitEvent(c->aux, c->ev_fork, 0));
+        hipLaunchKernelGGL(zs_tail_kernel, dim3((unsigned)n), dim3(1024), kTailLds, c->aux, d_sd, d_st, dev<uint16_t>(c->link),
+                           dev<uint32_t>(c->syms), dev<int32_t>(c->blk_end), dev<int32_t>(c->blk_top), dev<BlockRec>(c->blocks),
+                           dev<uint8_t>(c->scratch), c->crc_tab, lv, strategy, hash_variant, level);
+        ZS_HIP(c, hipEventRecord(c->ev_join, c->aux));
+    }
     if (!pl.w_segs.empty())
         hipLaunchKernelGGL(zs_expand_kernel, dim3((unsigned)((pl.w_segs.size() + 63) / 64)), dim3(64), 0, stream, d_sd,
                            d_work + o_segs, (int)pl.w_segs.size(), dev<uint2>(c->mm),
@@ -368,9 +389,13 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
                            dev<uint32_t>(c->symbase), dev<uint32_t>(c->syms), dev<int32_t>(c->blk_end), dev<int32_t>(c->blk_top),
                            c->crc_tab, lv, strategy, hash_variant);
     mark(9);
-    ZS_HIP(c, hipStreamWaitEvent(stream, c->ev_join, 0));
+    if (!tail_late) ZS_HIP(c, hipStreamWaitEvent(stream, c->ev_join, 0));
     hipLaunchKernelGGL(zs_body_blocks_kernel, dim3((unsigned)n), dim3(256), 0, stream, d_sd, d_st, dev<int32_t>(c->blk_end),
                        dev<int32_t>(c->blk_top), dev<BlockRec>(c->blocks));
+    if (tail_late)
+        hipLaunchKernelGGL(zs_tail_kernel, dim3((unsigned)n), dim3(1024), kTailLds, stream, d_sd, d_st, dev<uint16_t>(c->link),
+                           dev<uint32_t>(c->syms), dev<int32_t>(c->blk_end), dev<int32_t>(c->blk_top), dev<BlockRec>(c->blocks),
+                           dev<uint8_t>(c->scratch), c->crc_tab, lv, strategy, hash_variant, level);
     if (pl.n_runs) {
         // DeflateFast by speculative chunk runs; a run whose hand-over state does not verify sends the batch to the
         // sequential engine (the result is the reference's bytes either way)
@@ -396,7 +421,7 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
                                 (long long)o.mark_pos, (long long)o.mark_nsyms, (long long)o.end_pos, (long long)o.nsyms, o.n_ev);
                     }
                 }
-                return run_pipeline(c, n, in, in_len, out, out_cap, out_len, status, level, strategy, hash_variant, stream, writes, true);
+                return run_pipeline(c, n, in, in_len, out, out_cap, out_len, status, level, strategy, hash_variant, stream, writes, true, ro);
             }
         hipLaunchKernelGGL(zs_fast_plan_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, d_sd, d_st, dev<FastRunOut>(c->run_outs), n);
         hipLaunchKernelGGL(zs_fast_stitch_kernel, dim3((unsigned)pl.n_runs), dim3(256), 0, stream, d_sd, d_work + o_runs,
@@ -429,6 +454,7 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
             (void)hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]);
             c->stage_ms[i] = ms;
         }
+    if (ro) ro->end_bits = hst[0].end_bits;
     // every stream's length and code are reported; the first failing one sets the message and the return value
     bool all_ok = true;
     for (int i = 0; i < n; i++) {

@@ -1069,7 +1069,7 @@ __global__ __launch_bounds__(256) void zs_body_blocks_kernel(const StreamDesc *s
         blk[i] = r;
     }
     // the first block flushed by the tail engine (which ran beside K5) starts where the last finished block ends
-    if (threadIdx.x == 0 && nb_body > 0) {
+    if (threadIdx.x == 0 && nb_body > 0 && s.final_run) {
         BlockRec r = blk[nb_body];
         if (r.can_store < 0) {
             const int64_t base = (int64_t)(-r.can_store - 1) * kWSize, start = blk_end[s.blk_off + nb_body - 1];
@@ -1131,37 +1131,76 @@ __global__ __launch_bounds__(1024) void zs_tail_kernel(const StreamDesc *sd, Str
     // gets its start from zs_body_blocks_kernel afterwards
     e.block_start_abs = 0;
     e.defer_start = nb_body > 0;
+    if (!s.final_run && nb_body > 0) {
+        // a run that is not the stream's end runs behind K5 (the pending block's symbols and start must be final when the
+        // engine is left for the next run): the last finished block's end is known
+        e.block_start_abs = blk_end[s.blk_off + nb_body - 1];
+        e.defer_start = 0;
+    }
     e.block_sym_start = (int64_t)nb_body * kBlockSyms;
     e.block_syms = level == 0 ? (kLitBufsize / 2) - 1 : kBlockSyms;
     const uint16_t *lk = link + s.pos_off;
     const int64_t p = ss.tail_p;
-    // ss.k_done is the parse segment of the last read event that fired before p
-    const bool have_seg = s.nsegs > 0;
-    le_restore(e, p, have_seg ? s.seg_base[ss.k_done] : 0, have_seg ? s.seg_after[ss.k_done] : 0, ss.tail_kind, ss.tail_pend, lk,
-               ss.preins, tid, nth);
-    for (int i = tid; i < kHashSize; i += nth) head32[i] = 0;
-    __syncthreads();
-    if (e.avail_end > 0) {
-        int64_t lo = p - (kWSize - 1);
-        if (lo < e.base) lo = e.base;
-        if (lo < 0) lo = 0;
-        int64_t hi = p;
-        if (hi > (int64_t)s.n - 5) hi = (int64_t)s.n - 5;
-        for (int64_t q = lo + tid; q < hi; q += nth) {
-            le_restore_prev(e, q, lk);
-            atomicMax(&head32[le_bucket(e, q)], (uint32_t)(q - e.base) + 1u);
+    e.final_run = s.final_run;
+    LitPersist *ps = s.persist;
+    if (s.cont) {
+        // a later run of an incremental stream: the engine as the run before left it; the input buffer starts at absolute
+        // position abs_off (= everything read so far), the symbols of the block in progress go first
+        for (int i = tid * 16; i < kWindowSize + 512; i += nth * 16) *(uint4 *)(smem + i) = *(const uint4 *)(ps->window + i);
+        for (int i = tid * 8; i < kWSize; i += nth * 8) *(uint4 *)(e.prev + i) = *(const uint4 *)(ps->prev + i);
+        for (int i = tid; i < ps->pending_syms; i += nth) e.syms[i] = ps->syms[i];
+        e.head = ps->head;
+        e.data = s.in - s.abs_off;
+        e.n = s.abs_off + (int64_t)s.n;
+        e.base = ps->base, e.avail_end = ps->avail_end, e.block_start_abs = ps->block_start_abs;
+        e.strstart = ps->strstart, e.lookahead = ps->lookahead, e.match_length = ps->match_length, e.match_start = ps->match_start;
+        e.match_available = ps->match_available, e.prev_length = ps->prev_length, e.prev_match = ps->prev_match;
+        e.nsyms = ps->pending_syms, e.block_sym_start = 0, e.nblocks = 0, e.defer_start = 0;
+        __syncthreads();
+    } else {
+        // ss.k_done is the parse segment of the last read event that fired before p
+        const bool have_seg = s.nsegs > 0;
+        le_restore(e, p, have_seg ? s.seg_base[ss.k_done] : 0, have_seg ? s.seg_after[ss.k_done] : 0, ss.tail_kind, ss.tail_pend, lk,
+                   ss.preins, tid, nth);
+        for (int i = tid; i < kHashSize; i += nth) head32[i] = 0;
+        __syncthreads();
+        if (e.avail_end > 0) {
+            int64_t lo = p - (kWSize - 1);
+            if (lo < e.base) lo = e.base;
+            if (lo < 0) lo = 0;
+            int64_t hi = p;
+            if (hi > (int64_t)s.n - 5) hi = (int64_t)s.n - 5;
+            for (int64_t q = lo + tid; q < hi; q += nth) {
+                le_restore_prev(e, q, lk);
+                atomicMax(&head32[le_bucket(e, q)], (uint32_t)(q - e.base) + 1u);
+            }
+            __syncthreads();
+            for (int i = tid; i < kHashSize; i += nth) e.head[i] = (uint16_t)(head32[i] ? head32[i] - 1 : 0);
         }
         __syncthreads();
-        for (int i = tid; i < kHashSize; i += nth) e.head[i] = (uint16_t)(head32[i] ? head32[i] - 1 : 0);
     }
-    __syncthreads();
     if (tid >= 64) return;  // the engine is one wave, every lane running the same scalar code
-    if (e.avail_end > 0) le_restore_finish(e, p, lk, ss.preins);
+    if (!s.cont && e.avail_end > 0) le_restore_finish(e, p, lk, ss.preins);
     __syncthreads();
     le_run(e, level, tid, 64);
     if (tid == 0) {
         ss.nsyms = (uint32_t)e.nsyms;
         ss.nblocks = e.nblocks;
+    }
+    if (!ps || s.final_run) return;
+    // ---- the stream goes on: the wave leaves the engine for the next run (its lanes all hold the same scalars)
+    __syncthreads();
+    for (int i = tid * 16; i < kWindowSize + 512; i += 64 * 16) *(uint4 *)(ps->window + i) = *(const uint4 *)(smem + i);
+    for (int i = tid * 8; i < kWSize; i += 64 * 8) *(uint4 *)(ps->prev + i) = *(const uint4 *)(e.prev + i);
+    if (e.head != ps->head)
+        for (int i = tid * 8; i < kHashSize; i += 64 * 8) *(uint4 *)(ps->head + i) = *(const uint4 *)(e.head + i);
+    const int pending = (int)(e.nsyms - e.block_sym_start);
+    for (int i = tid; i < pending; i += 64) ps->syms[i] = e.syms[e.block_sym_start + i];
+    if (tid == 0) {
+        ps->base = e.base, ps->avail_end = e.avail_end, ps->block_start_abs = e.block_start_abs;
+        ps->strstart = e.strstart, ps->lookahead = e.lookahead, ps->match_length = e.match_length, ps->match_start = e.match_start;
+        ps->match_available = e.match_available, ps->prev_length = e.prev_length, ps->prev_match = e.prev_match;
+        ps->pending_syms = pending;
     }
 }
 
@@ -1616,7 +1655,9 @@ __device__ __forceinline__ void or_bits(uint8_t *out, int64_t pos, uint64_t v, i
 struct OrBitsAt {  // FlushAcct's put: OR into the zeroed stream, never past the caller's capacity
     uint8_t *out;
     int64_t cap;
+    int64_t bit_base;  // stream bit position of out[0] (0 unless the run continues an incremental stream)
     __device__ void operator()(int64_t pos, uint32_t v, int nbits) const {
+        pos -= bit_base;
         if ((pos >> 3) + 12 <= cap) or_bits(out, pos, v, nbits);
     }
 };
@@ -1637,12 +1678,19 @@ __global__ __launch_bounds__(256) void zs_offsets_kernel(const StreamDesc *sd, S
     const StreamDesc s = sd[si];
     StreamState &ss = st[si];
     const int nb = ss.nblocks;
-    if (threadIdx.x == 0) sh_pos = 16, sh_bad = 0;
-    const OrBitsAt fa_put{s.out, s.out_cap};
+    LitPersist *ps = s.persist;
+    // a run that continues an incremental stream starts where the run before stopped: `bit_base` is the stream bit position
+    // of this run's out[0], whose low bits (the stream's last, incomplete byte) come with the descriptor
+    const int64_t start_bits = s.cont ? ps->fa.bits : 16;
+    const int64_t bit_base = s.cont ? (start_bits & ~7LL) : 0;
+    if (threadIdx.x == 0) sh_pos = start_bits, sh_bad = 0;
+    const OrBitsAt fa_put{s.out, s.out_cap, bit_base};
     if (flushing) {
-        fa_init(fa, s.out_chunk, level, s.raw != 0);
-        fa_enter(fa);  // the first Deflate call delivers the header
+        if (s.cont) fa = ps->fa;
+        else fa_init(fa, s.out_chunk, level, s.raw != 0);
+        fa_enter(fa);  // the run's first Deflate call (of a stream: it delivers the header)
     }
+    if (threadIdx.x == 0 && s.cont && s.out_cap > 0) s.out[0] = (uint8_t)s.carry_byte;
     __syncthreads();
     for (int b0 = 0; b0 < nb; b0 += 1024) {
         int cnt = nb - b0 < 1024 ? nb - b0 : 1024;
@@ -1716,7 +1764,7 @@ __global__ __launch_bounds__(256) void zs_offsets_kernel(const StreamDesc *sd, S
             sh_pos = pos;
         }
         __syncthreads();
-        for (int i = threadIdx.x; i < cnt; i += 256) info[s.blk_off + b0 + i].bit_start = sh_start[i];
+        for (int i = threadIdx.x; i < cnt; i += 256) info[s.blk_off + b0 + i].bit_start = sh_start[i] - bit_base;
         __syncthreads();
     }
     // Adler-32 of the whole input: tree combine of the 64 KiB pieces (adler_combine is associative)
@@ -1744,10 +1792,19 @@ __global__ __launch_bounds__(256) void zs_offsets_kernel(const StreamDesc *sd, S
         __syncthreads();
     }
     if (threadIdx.x != 0) return;
-    const uint32_t ad = ad_v[0];
+    const uint32_t ad = ps ? s.adler_stream : ad_v[0];  // an incremental stream's checksum is kept by its owner
     const int64_t pos = sh_pos;
     ss.adler = ad;
-    int64_t total = pos / 8 + 4;
+    ss.end_bits = pos;
+    if (ps && !s.final_run) {
+        // the stream goes on: complete bytes are the run's output, the bits of the last one stay with the stream
+        if (flushing) fa.bits = pos, ps->fa = fa, ps->fa_valid = 1;
+        const int64_t bytes = (pos - bit_base) >> 3;
+        ss.out_len = bytes;
+        ss.status = sh_bad ? -2 : (bytes + 8 > s.out_cap ? -5 : 0);
+        return;
+    }
+    int64_t total = (pos - bit_base) / 8 + 4;
     ss.out_len = total;
     if (sh_bad) {
         ss.status = -2;  // ZS_STREAM_ERROR
@@ -1758,10 +1815,12 @@ __global__ __launch_bounds__(256) void zs_offsets_kernel(const StreamDesc *sd, S
         return;
     }
     ss.status = 0;
-    unsigned hdr = zlib_header(level);
-    s.out[0] = (uint8_t)(hdr >> 8);
-    s.out[1] = (uint8_t)hdr;
-    uint8_t *t = s.out + pos / 8;
+    if (!s.cont) {
+        unsigned hdr = zlib_header(level);
+        s.out[0] = (uint8_t)(hdr >> 8);
+        s.out[1] = (uint8_t)hdr;
+    }
+    uint8_t *t = s.out + (pos - bit_base) / 8;
     t[0] = (uint8_t)(ad >> 24), t[1] = (uint8_t)(ad >> 16), t[2] = (uint8_t)(ad >> 8), t[3] = (uint8_t)ad;
 }
 

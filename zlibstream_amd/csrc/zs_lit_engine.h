@@ -80,6 +80,11 @@ struct LitEngine {
     int no_blocks;            // do not cut blocks (the caller does it after stitching the runs)
     int64_t *ev_log;          // loop-tops at which a refill read happened (the pre-insert positions - 1), up to 16
     int n_ev;
+    // incremental streams (zs_stream_api.inc): a run holds the Writes that have arrived so far.  final_run == 0: the
+    // stream goes on after this run's last Write -- where Deflate.Compress would return to its caller for more input
+    // (NeedMore under NoFlush, Deflate.Slow.cs:38-46; BlockDone after a flush, Deflate.cs:583-613) the engine stops with
+    // `suspended` set, at a loop-top, and a later run re-enters the block function from there
+    int final_run, suspended;
     // outputs
     uint32_t *syms;     // symbol i: dist << 16 | lc  (dist 0 = literal)
     int64_t nsyms;      // symbols emitted so far in this stream (body + tail)
@@ -93,6 +98,7 @@ ZS_HD void le_defaults(LitEngine &e) {
     e.stop_abs = -1, e.mark_abs = -1, e.mark_pos = -1, e.mark_nsyms = 0;
     e.ins_bits = nullptr, e.ins_base = 0, e.no_blocks = 0, e.ins_word_idx = -1, e.ins_word = 0;
     e.ev_log = nullptr, e.n_ev = 0;
+    e.final_run = 1, e.suspended = 0;
     e.block_syms = kBlockSyms, e.block_sym_start = 0, e.block_start_abs = 0, e.defer_start = 0;
     e.nsyms = 0, e.nblocks = 0;
 }
@@ -250,8 +256,14 @@ ZS_HD_NOINLINE inline void le_fill_window(LitEngine &e, int lane, int nlanes) {
 ZS_HD_NOINLINE inline void le_refill(LitEngine &e, int lane, int nlanes, int &hash_head, int enough = kMinLookahead) {
     for (;;) {
         le_fill_window(e, lane, nlanes);
-        if (e.lookahead >= enough || !e.wr_end || e.cur_wr + 1 >= e.n_wr) break;
-        if (e.wr_flush && e.wr_flush[e.cur_wr] != 0) break;  // flush != NoFlush: go on with what is there
+        if (e.lookahead >= enough) break;
+        const bool flushes = e.wr_flush && e.cur_wr < e.n_wr && e.wr_flush[e.cur_wr] != 0;  // flush != NoFlush: go on with what is there
+        if (!e.wr_end || e.cur_wr + 1 >= e.n_wr) {
+            // no further Write in this run: Finish follows (final run), or the caller is asked for more input
+            if (!e.final_run && !flushes) e.suspended = 1;
+            break;
+        }
+        if (flushes) break;
         e.cur_wr++;
         if (e.wr_blk && lane == 0) e.wr_blk[e.cur_wr] = e.nblocks;
         hash_head = 0;  // DeflateSlow's local is reset on every entry (Deflate.Slow.cs:20)
@@ -345,6 +357,7 @@ ZS_HD_NOINLINE inline void le_run_slow(LitEngine &e, int lane, int nlanes) {
     for (;;) {
         if (e.lookahead < kMinLookahead) {
             le_refill(e, lane, nlanes, hash_head);
+            if (e.suspended) return;
             if (e.lookahead == 0) {
                 if (!le_write_flushes(e)) break;
                 if (e.match_available != 0) {
@@ -402,6 +415,7 @@ ZS_HD_NOINLINE inline void le_run_fast(LitEngine &e, int lane, int nlanes) {
         if (e.lookahead < kMinLookahead) {
             int dummy = 0;
             le_refill(e, lane, nlanes, dummy);
+            if (e.suspended) return;
             if (e.lookahead == 0) {
                 if (!le_write_flushes(e)) break;
                 le_end_write(e, lane, nlanes);
@@ -448,6 +462,7 @@ ZS_HD_NOINLINE inline void le_run_stored(LitEngine &e, int lane, int nlanes) {
         if (e.lookahead <= 1) {
             int dummy = 0;
             le_refill(e, lane, nlanes, dummy, 1);  // NoFlush returns only while lookahead == 0
+            if (e.suspended) return;
             if (e.lookahead == 0) {
                 if (!le_write_flushes(e)) break;
                 le_end_write(e, lane, nlanes);
@@ -474,6 +489,7 @@ ZS_HD_NOINLINE inline void le_run_rle(LitEngine &e, int lane, int nlanes) {
         if (e.lookahead <= kMaxMatch) {
             int dummy = 0;
             le_refill(e, lane, nlanes, dummy, kMaxMatch + 1);
+            if (e.suspended) return;
         }
         if (e.lookahead == 0) {
             if (!le_write_flushes(e)) break;
