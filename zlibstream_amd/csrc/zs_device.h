@@ -60,8 +60,8 @@ struct StreamDesc {
     const BlockRec *plan_blk;
     int32_t plan_nblk;
     // incremental streams (zs_stream_api.inc): the run is not the end of the stream (final_run == 0) and / or continues one
-    // whose engine state lives in `persist` (cont != 0: the input buffer holds only the bytes from absolute position abs_off
-    // on, nothing is parsed in bulk).  The Adler-32 of the whole stream is then the caller's (adler_stream).
+    // whose engine state lives in `persist` (cont != 0: the input buffer holds the stream from position abs_off on -- the
+    // last 64 KiB already read, then the new bytes -- and nothing is parsed in bulk).  The Adler-32 of the whole stream is then the caller's (adler_stream).
     int32_t final_run;
     struct LitPersist *persist;
     int64_t abs_off;

@@ -117,7 +117,8 @@ struct WriteSpec {
 // One run of an incremental stream (zs_stream_api.inc; one stream per call).  final_run == false: the stream goes on after
 // this run's Writes, the engine is left in `persist` (device memory) where Deflate.Compress would return to its caller, and
 // only what is final -- whole blocks and flush markers, complete bytes -- is output.  cont: the run continues from `persist`;
-// the input buffer then holds the new bytes only (absolute stream position abs_off on) and `writes` holds absolute ends.
+// the input buffer then holds the stream from position abs_off on (64 KiB already read, then the new bytes) and `writes`
+// holds absolute ends.
 struct RunOpts {
     bool final_run = true, cont = false;
     LitPersist *persist = nullptr;

@@ -1144,8 +1144,9 @@ __global__ __launch_bounds__(1024) void zs_tail_kernel(const StreamDesc *sd, Str
     e.final_run = s.final_run;
     LitPersist *ps = s.persist;
     if (s.cont) {
-        // a later run of an incremental stream: the engine as the run before left it; the input buffer starts at absolute
-        // position abs_off (= everything read so far), the symbols of the block in progress go first
+        // a later run of an incremental stream: the engine as the run before left it.  The input buffer starts at stream
+        // position abs_off: the last 64 KiB the engine has already read (a stored block is copied from there, like the
+        // reference copies it from its window) and then the new bytes; the symbols of the block in progress go first
         for (int i = tid * 16; i < kWindowSize + 512; i += nth * 16) *(uint4 *)(smem + i) = *(const uint4 *)(ps->window + i);
         for (int i = tid * 8; i < kWSize; i += nth * 8) *(uint4 *)(e.prev + i) = *(const uint4 *)(ps->prev + i);
         for (int i = tid; i < ps->pending_syms; i += nth) e.syms[i] = ps->syms[i];
@@ -1891,7 +1892,7 @@ __global__ __launch_bounds__(256) void zs_emit_bits_kernel(const StreamDesc *sd,
             out[byte + 2] = (uint8_t)~len, out[byte + 3] = (uint8_t)(~len >> 8);
         }
         // Copy_block (Deflate.cs:710-722): 16 bytes per lane and trip (global memory takes them at any alignment), bytes at the end
-        const gcbytes src = as_global(s.in) + r.start;
+        const gcbytes src = as_global(s.in) + (r.start - s.abs_off);  // abs_off: stream position of in[0] (0 unless the run continues a stream)
         const gbytes_w dst = as_global(out) + byte + 4;
         typedef u32x4 __attribute__((aligned(1))) u32x4u;
         const int nvec = r.stored_len >> 4;
