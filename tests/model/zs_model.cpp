@@ -20,6 +20,7 @@
 #include "../../oracle/zs_oracle.h"
 #include "../../zlibstream_amd/csrc/zs_core.h"
 #include "../../zlibstream_amd/csrc/zs_lit_engine.h"
+#include "../../zlibstream_amd/csrc/zs_fast_vec.h"
 
 using namespace zs;
 
@@ -59,6 +60,7 @@ struct Model {
     std::vector<uint8_t> wr_flush;
     std::vector<int32_t> wr_blk;
     bool incremental = false;  // mode "inc": the literal engine run Write by Write (suspend / re-enter)
+    std::vector<uint8_t> ins;  // mode "fvec" (DeflateFast for the lanes of a wave): the inserted positions
 
     uint32_t bucket(int64_t p) const {
         uint32_t v = (uint32_t)data[p + 2] | ((uint32_t)data[p + 3] << 8) | ((uint32_t)data[p + 4] << 16) | ((uint32_t)data[p + 5] << 24);
@@ -153,6 +155,77 @@ static void parse_sequential(Model &m, bool on_demand, int64_t &p_out, int &kind
     (void)block_start;
 }
 
+
+// ---- DeflateFast as the device runs it (zs_fast_vec.h): windows of 64 positions searched "in parallel" over the
+//      all-position chains filtered by the inserted set, then the hops followed through the lanes' results ----
+struct FvAcc {
+    const Model *m;
+    int link(int64_t c) const { return (int)m->link[(size_t)c]; }
+    bool ins(int64_t c) const { return m->ins[(size_t)c] != 0; }
+    int lcp(int64_t q, int64_t c) const { return m->lcp(q, c); }
+};
+static void parse_fast_vec(Model &m, int64_t &p_out, int &kdone_out, int64_t &preins_out) {
+    m.ins.assign((size_t)m.n + 128, 0);
+    FvAcc acc{&m};
+    const int kl = (int)m.rev.size() - 1;
+    FvState st{0, 0, kl >= 1 ? m.rev[1].at - (kMinLookahead - 1) : -1, 0, -1, 0};
+    int64_t block_start = 0;
+    const bool search = m.strategy != kHuffmanOnly;
+    long fv_windows = 0, fv_iters = 0, fv_max_iters = 0;
+    while (st.p <= m.body_end) {
+        const int64_t p0 = st.p;
+        bool dead0 = false, dead1 = false, only1 = false;
+        if (st.trigger >= 0 && p0 >= st.trigger) {
+            // the read event at loop-top p0: p0 + 1 is inserted first (Deflate.cs:1010-1013)
+            st.k_fired++;
+            m.events.push_back(p0);
+            st.preins = p0 + 1;
+            m.ins[(size_t)p0 + 1] = 1;
+            if (m.link[(size_t)p0 + 1] == 1) {
+                dead0 = true, only1 = true;
+                m.link[(size_t)p0] = 0;  // prev[p0] = p0 + 1, prev[p0 + 1] = p0: nothing older is reachable through them
+            } else {
+                dead1 = true;
+            }
+            st.trigger = st.k_fired < kl ? m.rev[(size_t)st.k_fired + 1].at - (kMinLookahead - 1) : -1;
+        }
+        int limit = kFvLanes;
+        if (m.body_end - p0 + 1 < limit) limit = (int)(m.body_end - p0 + 1);
+        FvResult res[kFvLanes];
+        for (int i = 0; i < limit; i++)
+            res[i] = fv_search(acc, p0 + i, p0, m.lv.chain, m.lv.nice, !search || (i == 0 && dead0) || (i == 1 && dead1), i == 1 && only1);
+        auto rf = [&](int i) { return res[i]; };
+        const FvWindow w = fv_resolve(rf, p0, limit, m.lv.lazy, st.trigger);
+        for (int i = 0; i < limit; i++) {
+            if (!((w.tops >> i) & 1)) continue;
+            const int64_t q = p0 + i;
+            const bool match = res[i].len >= kMinMatch;
+            m.syms.push_back(match ? (((uint32_t)res[i].dist << 16) | (uint32_t)(res[i].len - 3)) : (uint32_t)m.data[q]);
+            if (m.syms.size() % kBlockSyms == 0) {
+                const int64_t end = q + (match ? res[i].len : 1);
+                BlockRec b;
+                b.start = block_start;
+                b.sym_start = (int64_t)m.syms.size() - kBlockSyms;
+                b.stored_len = (int32_t)(end - block_start);
+                b.nsyms = kBlockSyms;
+                b.can_store = block_start >= m.rev[(size_t)st.k_fired].base;
+                b.eof = 0;
+                m.blocks.push_back(b);
+                block_start = end;
+            }
+        }
+        for (int k = 0; k < 64; k++)
+            if ((w.ins_lo >> k) & 1) m.ins[(size_t)p0 + k] = 1;
+        for (int k = 0; k < 32; k++)
+            if ((w.ins_hi >> k) & 1) m.ins[(size_t)p0 + 64 + k] = 1;
+        st.p = p0 + w.advance;
+        fv_windows++, fv_iters += fv_max_iters;
+    }
+    if (getenv("ZS_FV_STATS")) printf("fvec: %ld windows, %.1f positions per window\n", fv_windows, (double)st.p / (double)(fv_windows ? fv_windows : 1));
+    p_out = st.p;
+    kdone_out = st.k_fired;
+    preins_out = st.preins;
+}
 
 // ---- stage B: the chunked form the GPU runs ----
 struct Sink {
@@ -347,8 +420,14 @@ static void run_tail(Model &m, int64_t p, int kind, uint32_t pend, int k_done, i
         int64_t lo = p - (kWSize - 1);
         if (lo < e.base) lo = e.base;
         if (lo < 0) lo = 0;
+        auto insf = [&](int64_t c) { return m.ins[(size_t)c] != 0; };
         for (int64_t q = lo; q < p && q + 5 < m.n; q++) {
-            le_restore_prev(e, q, m.link.data());
+            if (!m.ins.empty()) {  // DeflateFast: only what was inserted is in the chains
+                if (!m.ins[(size_t)q]) continue;
+                le_restore_prev_ins(e, q, m.link.data(), insf);
+            } else {
+                le_restore_prev(e, q, m.link.data());
+            }
             e.head[le_bucket(e, q)] = (uint16_t)(q - e.base);  // increasing q: last writer = max
         }
         le_restore_finish(e, p, m.link.data(), preins);
@@ -565,7 +644,12 @@ int main(int argc, char **argv) {
     uint32_t pend;
     int64_t preins;
     if (mode == "bulk" || mode == "chunk") m.match_all();
-    if (mode == "chunk") parse_chunked(m, p, kind, pend, k_done, preins);
+    if (mode == "fvec") {
+        // DeflateFast, single Write: the vector form up to the last loop-top with a full lookahead, then the literal engine
+        m.body_end = (m.lv.func == 1 && strategy != kRle && wends.size() <= 1 && flush_mode == 0 && n >= kMinLookahead) ? n - kMinLookahead : -1;
+        kind = kR, pend = 0, p = 0, k_done = 0, preins = -1;
+        if (m.body_end >= 0) parse_fast_vec(m, p, k_done, preins);
+    } else if (mode == "chunk") parse_chunked(m, p, kind, pend, k_done, preins);
     else parse_sequential(m, mode != "bulk", p, kind, pend, k_done, preins);
     run_tail(m, p, kind, pend, k_done, preins);
 

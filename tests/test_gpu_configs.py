@@ -226,27 +226,45 @@ def test_inflate_incomplete_single_code_trees_follow_huft_build(engine, oracle, 
         assert str(ei.value) == "inflating: " + want
 
 
-# ---------------------------------------------------------------- limits of the stream entry points
-def test_zs_deflate_rejects_input_beyond_the_device_limit_cleanly(engine):
-    """Feeding more than 2 GiB - 1 KiB into one zs_deflate stream fails with ZMEMERROR and *avail_in untouched (no truncation)."""
+# ---------------------------------------------------------------- no length limit on a stream
+def test_zs_deflate_takes_streams_beyond_2_gib(engine):
+    """A run of the device pipeline indexes its input with 32-bit positions, a stream does not: past 1 GiB of buffered
+    NoFlush input the stream turns incremental (bounded host memory) and goes on.  34 Writes of 64 MiB at level 0 (the
+    reference handles unbounded streams; round 1 truncated the length): every byte comes back, TotalIn is 64-bit."""
     lib = engine._lib
-    z = lib.zs_deflate_init(engine.handle, 6, 0, 15, 8, 0)
+    z = lib.zs_deflate_init(engine.handle, 0, 0, 15, 8, 0)
     assert z
     try:
         piece = bytes(64 << 20)
         src = ctypes.create_string_buffer(piece, len(piece))
-        out = ctypes.create_string_buffer(512)
+        cap = 4 << 20
+        out = ctypes.create_string_buffer(cap)
         adler, tin, tout = ctypes.c_uint32(1), ctypes.c_int64(0), ctypes.c_int64(0)
-        for k in range(32):
-            avail_in, avail_out = ctypes.c_int32(len(piece)), ctypes.c_int32(512)
-            rc = lib.zs_deflate(z, ctypes.addressof(src), ctypes.byref(avail_in), ctypes.addressof(out), ctypes.byref(avail_out), 0,
-                                ctypes.byref(adler), ctypes.byref(tin), ctypes.byref(tout))
-            if k < 31:
-                assert rc == 0 and avail_in.value == 0, k
-            else:
-                assert rc == -4 and avail_in.value == len(piece)
-                assert b"2 GiB" in lib.zs_last_message(z)
-        assert tin.value == 31 * len(piece)
+        d = zlib.decompressobj()
+        decoded = 0
+
+        def call(n_in, flush):
+            nonlocal decoded
+            avail_in = ctypes.c_int32(n_in)
+            while True:
+                avail_out = ctypes.c_int32(cap)
+                off = len(piece) - avail_in.value if n_in else 0
+                rc = lib.zs_deflate(z, ctypes.addressof(src) + off, ctypes.byref(avail_in), ctypes.addressof(out), ctypes.byref(avail_out), flush,
+                                    ctypes.byref(adler), ctypes.byref(tin), ctypes.byref(tout))
+                assert rc in (0, 1), (rc, lib.zs_last_message(z))
+                got = cap - avail_out.value
+                if got:
+                    chunk = d.decompress(out.raw[:got])
+                    assert chunk.count(0) == len(chunk)
+                    decoded += len(chunk)
+                if rc == 1 or not (avail_in.value > 0 or avail_out.value == 0):
+                    return rc
+        n_writes = 34
+        for _ in range(n_writes):
+            assert call(len(piece), 0) == 0
+        assert call(0, 4) == 1
+        assert tin.value == n_writes * len(piece) > (1 << 31)
+        assert decoded == n_writes * len(piece) and d.eof
     finally:
         lib.zs_deflate_end(z)
 

@@ -576,6 +576,22 @@ ZS_HD void le_restore_prev(LitEngine &e, int64_t q, const uint16_t *link) {
     int64_t c = link[q] ? q - (int64_t)link[q] : -1;
     e.prev[w & kWMask] = (uint16_t)(c >= e.base ? c - e.base : 0);
 }
+// The same for DeflateFast, whose chains hold only the inserted positions (`ins(q)`, zs_fast_vec.h): prev[q] is the
+// nearest inserted position before q on the all-position chain.
+template <class Ins>
+ZS_HD void le_restore_prev_ins(LitEngine &e, int64_t q, const uint16_t *link, const Ins &ins) {
+    int64_t c = q;
+    for (;;) {
+        const int l = link[c];
+        if (!l) {
+            c = -1;
+            break;
+        }
+        c -= l;
+        if (c < e.base || ins(c)) break;
+    }
+    e.prev[(int)(q - e.base) & kWMask] = (uint16_t)(c >= e.base ? c - e.base : 0);
+}
 // bucket of an already-restored window position
 ZS_HD uint32_t le_bucket(const LitEngine &e, int64_t q) { return le_hash(e, le_load32(e.window + (q - e.base) + 2)); }
 
