@@ -3,6 +3,7 @@
 #pragma once
 #include "zs_core.h"
 #include "zs_lit_engine.h"
+#include "zs_fast_vec.h"
 
 namespace zs {
 
@@ -68,8 +69,20 @@ struct StreamDesc {
     int32_t cont;
     uint32_t adler_stream;
     uint32_t carry_byte;  // cont: the bits of the stream's last, incomplete byte from the run before
-    int32_t pad_;
+    // DeflateFast for the lanes of a wave (zs_fast_vec.h, zs_fast_vec_kernel): last loop-top it handles (n - 262), -1: not
+    // this stream; the stream's inserted-position bitmap (bit q of the array = position q)
+    int32_t fv_end;
+    uint32_t *ins_bits;
 };
+
+// zs_fast_vec_kernel's tile: the window [t0 - kFvBack, t0 + kFvTile + kFvFwd) in LDS as bytes, links and inserted bits
+constexpr int kFvTile = 16384;
+constexpr int kFvBack = 32512;  // >= kMaxDist, multiple of 32
+constexpr int kFvFwd = 272;     // >= kMaxMatch + 8, multiple of 16
+constexpr int kFvBytes = kFvBack + kFvTile + kFvFwd;
+constexpr int kFvLinks = kFvBack + kFvTile;
+constexpr int kFvBitWords = kFvLinks / 32 + 8;  // the tile may start 16 positions into a word, and short matches reach out of it
+constexpr int kFvLds = kFvBytes + 2 * kFvLinks + 4 * kFvBitWords;
 
 // What a suspended literal engine keeps between runs (device memory, one per zs_deflate stream): the reference's own state
 // -- window, prev, head, the Deflate fields (Deflate.cs:128-226) -- plus the symbols of the block in progress and the

@@ -47,7 +47,7 @@ struct zs_ctx {
     uint32_t *crc_tab = nullptr;
     DevBuf sd, st, work, geo, link, mm, maps, segmap, seg_entry, seg_symbase, seg_stale, entry, symbase, stale, syms, blk_end, blk_top, blocks, trees, info, pieces, scratch,
         stage_in, stage_out, wr, inf_desc, inf_state, par_ps, par_st, par_work, par_cbits, par_ccnt, par_surv, par_scnt, par_cands, par_tabs, par_blocks, par_cells,
-        par_windows, par_fail, run_syms, run_bits, run_scratch, run_outs, run_fail, adl_tr, adl_res, plan_blk;
+        par_windows, par_fail, run_syms, run_bits, run_scratch, run_outs, run_fail, adl_tr, adl_res, plan_blk, ins_bits;
     void *pinned = nullptr;
     size_t pinned_cap = 0;
 };
@@ -89,6 +89,7 @@ struct Plan {
     std::vector<uint2> w_clear, w_adler, w_links, w_match, w_chunks, w_segs, w_blocks, w_runs;
     int64_t n_pos = 0, n_syms = 0;
     int64_t n_chunks = 0, n_segs = 0, n_blocks = 0, n_pieces = 0, n_runs = 0;
+    bool any_fv = false;
     std::vector<int32_t> seg_c0, seg_after, seg_base;  // per parse segment (all streams, in seg_off order)
     std::vector<uint8_t> head;                         // per chunk (chunk_off order): a read event fires at its entry
     std::vector<BlockRec> plan_blk;                    // level 0: the stored blocks of every stream, stream after stream
@@ -164,6 +165,13 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
                              : multi ? (!real_flush && build_read_events(len, writes->ends, rev))
                                      : build_read_events(len, std::vector<int64_t>(one_write, one_write + 1), rev);
         s.body_end = (lv.func == 2 && strategy != kRle && len >= kMinLookahead && regular) ? (int32_t)(len - kMinLookahead) : -1;
+        // levels 1-3, one Write: the speculative chunk runs for large streams (they verify on periodic data and are parallel
+        // inside a stream), else -- and when they did not verify (force_seq) -- DeflateFast for the lanes of a wave
+        const bool fast_one = lv.func == 1 && strategy != kRle && !multi && !flushing && final_run && !ro && regular && len >= kMinLookahead;
+        const bool fast_par = fast_one && !force_seq && len >= kFastMinInput;
+        s.fv_end = (fast_one && !fast_par && !getenv("ZS_NO_FAST_VEC")) ? (int32_t)(len - kMinLookahead) : -1;
+        s.ins_bits = nullptr;
+        if (s.fv_end >= 0) pl.any_fv = true;
         s.n_wr = (multi || flushing) ? (int32_t)writes->ends.size() : 1;  // 0: a run without input (Finish alone)
         s.wr_end = nullptr;
         s.wr_flush = nullptr, s.wr_blk = nullptr, s.out_chunk = writes ? writes->chunk : 512, s.raw = writes && writes->raw;
@@ -178,19 +186,18 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
         s.seg_off = (int32_t)pl.n_segs;
         s.nsegs = 0;
         pl.head.resize((size_t)pl.n_chunks, 0);
-        if (s.body_end >= 0)
+        if (s.body_end >= 0 || s.fv_end >= 0)
             for (size_t k = 0; k < rev.size(); k++) {
                 const int64_t at = k ? rev[k].at - (kMinLookahead - 1) : 0;  // where the segment starts
-                if (at > s.body_end) break;
+                if (at > (s.body_end >= 0 ? s.body_end : s.fv_end)) break;
                 const int c0 = chunk_of(at);
                 pl.seg_c0.push_back(c0), pl.seg_after.push_back((int32_t)rev[k].after), pl.seg_base.push_back((int32_t)rev[k].base);
-                if (k) pl.head[(size_t)s.chunk_off + (size_t)c0] = 1;
+                if (k && s.body_end >= 0) pl.head[(size_t)s.chunk_off + (size_t)c0] = 1;
                 s.nsegs++;
             }
         s.seg_c0 = s.seg_after = s.seg_base = nullptr, s.head = nullptr;
         pl.n_segs += s.nsegs;
         // levels 1-3, one Write, large enough: speculative chunk runs instead of one sequential engine
-        const bool fast_par = lv.func == 1 && strategy != kRle && !multi && !flushing && !force_seq && final_run && len >= kFastMinInput;
         s.fast_runs = fast_par ? (int32_t)((len + kFastChunk - 1) / kFastChunk) : 0;
         s.run_off = (int32_t)pl.n_runs;
         pl.n_runs += s.fast_runs;
@@ -199,7 +206,7 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
         // level 0 runs with memLevel 7: a block is flushed every 8191 symbols (only Rle tallies symbols there)
         s.max_blocks = (int32_t)(level == 0 ? len / 8191 + len / 32506 + 4 : len / kBlockSyms + 2);
         if (flushing) s.max_blocks += (int32_t)writes->ends.size() + 1;  // every Write under a flush mode closes a block
-        s.plan_blk = nullptr, s.plan_nblk = 0, s.pad_ = 0;
+        s.plan_blk = nullptr, s.plan_nblk = 0;
         s.final_run = final_run ? 1 : 0, s.cont = cont ? 1 : 0, s.persist = ro ? ro->persist : nullptr;
         s.abs_off = ro ? ro->abs_off : 0, s.adler_stream = ro ? ro->adler_stream : 1, s.carry_byte = ro ? ro->carry_byte : 0;
         if (level == 0 && strategy != kRle && !ro) {
@@ -226,7 +233,7 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
         pl.n_pieces += s.n_adler;
         for (int64_t k = 0; k * 65536 < s.out_cap; k++) pl.w_clear.push_back(make_uint2((unsigned)i, (unsigned)k));
         for (int k = 0; k < s.n_adler; k++) pl.w_adler.push_back(make_uint2((unsigned)i, (unsigned)k));
-        if (s.body_end >= 0 || s.fast_runs > 0)
+        if (s.body_end >= 0 || s.fast_runs > 0 || s.fv_end >= 0)
             for (int64_t t = 0; t * link_span < len - 5; t++) pl.w_links.push_back(make_uint2((unsigned)i, (unsigned)t));
         if (s.body_end >= 0) {
             for (int64_t t = 0; t * kMatchTile <= s.body_end; t++) pl.w_match.push_back(make_uint2((unsigned)i, (unsigned)t));
@@ -258,6 +265,12 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
         const int32_t *g = (const int32_t *)c->geo.p;
         s.seg_c0 = g + s.seg_off, s.seg_after = g + pl.n_segs + s.seg_off, s.seg_base = g + 2 * pl.n_segs + s.seg_off;
         s.head = (const uint8_t *)c->geo.p + 12 * (size_t)pl.n_segs + (size_t)s.chunk_off;
+    }
+    if (pl.any_fv) {
+        // one bit per position (pos_off is a multiple of 64: every stream's bitmap starts on a word)
+        if (!ensure(c, c->ins_bits, (size_t)pl.n_pos / 8 + 1024)) return false;
+        for (int i = 0; i < n; i++)
+            if (pl.sd[(size_t)i].fv_end >= 0) pl.sd[(size_t)i].ins_bits = dev<uint32_t>(c->ins_bits) + pl.sd[(size_t)i].pos_off / 32;
     }
     if (!pl.plan_blk.empty()) {
         if (!ensure(c, c->plan_blk, sizeof(BlockRec) * pl.plan_blk.size())) return false;
@@ -322,6 +335,7 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
     ZS_HIP(c, hipMemcpyAsync(c->sd.p, hp, sizeof(StreamDesc) * (size_t)n, hipMemcpyHostToDevice, stream));
     if (n_work) ZS_HIP(c, hipMemcpyAsync(c->work.p, hw, sizeof(uint2) * n_work, hipMemcpyHostToDevice, stream));
     ZS_HIP(c, hipMemsetAsync(c->link.p, 0, 2 * (size_t)pl.n_pos + 64, stream));
+    if (pl.any_fv) ZS_HIP(c, hipMemsetAsync(c->ins_bits.p, 0, (size_t)pl.n_pos / 8 + 1024, stream));
     ZS_HIP(c, hipMemsetAsync(c->stale.p, 0, (size_t)pl.n_chunks + 64, stream));
     ZS_HIP(c, hipMemsetAsync(c->seg_stale.p, 0, (size_t)pl.n_segs + 64, stream));
     ZS_HIP(c, hipMemsetAsync(c->st.p, 0, sizeof(StreamState) * (size_t)n, stream));
@@ -368,6 +382,9 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
     mark(7);
     // fork: the tail engine (sequential, one workgroup per stream) needs only what the resolve kernel left, so it runs
     // on the second stream beside the symbol kernels
+    if (pl.any_fv)
+        hipLaunchKernelGGL(zs_fast_vec_kernel, dim3((unsigned)n), dim3(1024), kFvLds, stream, d_sd, d_st, dev<uint16_t>(c->link),
+                           dev<uint32_t>(c->syms), dev<int32_t>(c->blk_end), dev<int32_t>(c->blk_top), lv, strategy);
     const bool tail_late = ro && !ro->final_run;  // the engine is left for a later run: it needs K5's symbols and block ends
     if (!tail_late) {
         ZS_HIP(c, hipEventRecord(c->ev_fork, stream));
@@ -580,6 +597,7 @@ int zs_ctx_create(int device, zs_ctx **out) {
         hipFuncSetAttribute((const void *)zs_links_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLkLds) != hipSuccess ||
         hipFuncSetAttribute((const void *)zs_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kTailLds) != hipSuccess ||
         hipFuncSetAttribute((const void *)zs_fast_run_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kTailLds) != hipSuccess ||
+        hipFuncSetAttribute((const void *)zs_fast_vec_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kFvLds) != hipSuccess ||
         hipFuncSetAttribute((const void *)zs_inf_window_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kWinLds) != hipSuccess ||
         hipFuncSetAttribute((const void *)zs_inflate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kInfLds) != hipSuccess) {
         zs_ctx_destroy(c);
@@ -595,7 +613,7 @@ void zs_ctx_destroy(zs_ctx *c) {
     DevBuf *bufs[] = {&c->sd, &c->st, &c->work, &c->geo, &c->link, &c->mm, &c->maps, &c->segmap, &c->seg_entry, &c->seg_symbase, &c->seg_stale, &c->entry, &c->symbase, &c->stale, &c->syms,
                       &c->blk_end, &c->blk_top, &c->blocks, &c->trees, &c->info, &c->pieces, &c->scratch, &c->stage_in, &c->stage_out, &c->wr, &c->inf_desc, &c->inf_state, &c->par_ps, &c->par_st, &c->par_work, &c->par_cbits, &c->par_ccnt, &c->par_surv, &c->par_scnt,
                       &c->par_cands, &c->par_tabs, &c->par_blocks, &c->par_cells, &c->par_windows, &c->par_fail, &c->run_syms, &c->run_bits,
-                      &c->run_scratch, &c->run_outs, &c->run_fail, &c->adl_tr, &c->adl_res, &c->plan_blk};
+                      &c->run_scratch, &c->run_outs, &c->run_fail, &c->adl_tr, &c->adl_res, &c->plan_blk, &c->ins_bits};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     if (c->crc_tab) (void)hipFree(c->crc_tab);

@@ -1171,8 +1171,15 @@ __global__ __launch_bounds__(1024) void zs_tail_kernel(const StreamDesc *sd, Str
             if (lo < 0) lo = 0;
             int64_t hi = p;
             if (hi > (int64_t)s.n - 5) hi = (int64_t)s.n - 5;
+            const uint32_t *gb = s.ins_bits;
+            auto insf = [gb](int64_t c) { return ((gb[c >> 5] >> (c & 31)) & 1u) != 0; };
             for (int64_t q = lo + tid; q < hi; q += nth) {
-                le_restore_prev(e, q, lk);
+                if (s.fv_end >= 0) {  // DeflateFast: only what was inserted is in the chains
+                    if (!insf(q)) continue;
+                    le_restore_prev_ins(e, q, lk, insf);
+                } else {
+                    le_restore_prev(e, q, lk);
+                }
                 atomicMax(&head32[le_bucket(e, q)], (uint32_t)(q - e.base) + 1u);
             }
             __syncthreads();
@@ -1404,6 +1411,168 @@ __global__ __launch_bounds__(64) void zs_fast_blocks_kernel(const StreamDesc *sd
             r.eof = 1;
         }
         blocks[s.blk_off + b] = r;
+    }
+}
+
+// ------------------------------------------------------------------ KV: DeflateFast for the lanes of a wave (zs_fast_vec.h)
+// One workgroup per stream.  All threads stage a tile -- bytes, K1's all-position links and the inserted-position bitmap
+// of [t0 - 32 512, t0 + 16 Ki) -- then wave 0 takes the stream through it 64 positions at a time: every lane searches its
+// position over the filtered chain (fv_search), the hops of the parse are followed through the lanes' results
+// (fv_resolve, v_readlane), the loop-tops' symbols leave with one compacted store and the window's inserted bits are
+// OR-ed into the bitmap.  Refill events (one per 32 KiB) are applied where the parse reaches their loop-top.  The state
+// it leaves -- loop-top, symbols, block cuts, fired events -- is what K4 / K5 leave for the lazy parse: the tail engine
+// and the block kernels go on from it (the tail rebuilds head / prev from the bitmap).
+struct FvLdsAcc {
+    const uint8_t *wb;    // bytes, index = position - lo
+    const uint16_t *wl;   // links, 0 = none
+    const uint32_t *bm;   // inserted bits, word k = positions [32 (bw0 + k), +32)
+    int64_t lo, bw0;
+    __device__ int link(int64_t c) const { return wl[c - lo]; }
+    __device__ bool ins(int64_t c) const { return (bm[(c >> 5) - bw0] >> (c & 31)) & 1u; }
+    __device__ int lcp(int64_t q, int64_t c) const {
+        const int a = (int)(q - lo), b = (int)(c - lo);
+        int len = 0;
+        while (len < kMaxMatch) {
+            const uint64_t x = lds_u64(wb, a + len) ^ lds_u64(wb, b + len);
+            if (x) {
+                len += (int)(__builtin_ctzll(x) >> 3);
+                break;
+            }
+            len += 8;
+        }
+        return len < kMaxMatch ? len : kMaxMatch;
+    }
+};
+struct FvLaneRes {  // the lanes' results, read by a wave-uniform lane index
+    int len, dist, touched;
+    __device__ FvResult operator()(int i) const {
+        const int k = __builtin_amdgcn_readfirstlane(i);
+        return FvResult{__builtin_amdgcn_readlane(len, k), __builtin_amdgcn_readlane(dist, k), __builtin_amdgcn_readlane(touched, k)};
+    }
+};
+__global__ __launch_bounds__(1024) void zs_fast_vec_kernel(const StreamDesc *sd, StreamState *st, uint16_t *link, uint32_t *syms,
+                                                           int32_t *blk_end, int32_t *blk_top, LevelCfg lv, int strategy) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const StreamDesc s = sd[blockIdx.x];
+    if (s.fv_end < 0) return;
+    uint8_t *wb = smem;
+    uint16_t *wl = (uint16_t *)(smem + kFvBytes);
+    uint32_t *bm = (uint32_t *)(smem + kFvBytes + 2 * kFvLinks);
+    __shared__ int64_t sh_p, sh_nsyms, sh_trigger, sh_preins;
+    __shared__ int sh_k;
+    const int tid = threadIdx.x, lane = lane_id();
+    const int64_t n = s.n, body_end = s.fv_end;
+    const gcbytes in = as_global(s.in);
+    uint16_t *lk = link + s.pos_off;
+    uint32_t *gbits = s.ins_bits;
+    // read events of a single Write (zs_core.h): event k fires at the first loop-top >= E(k) - 261, E(k) = 64 Ki + 32 Ki (k - 1)
+    const int kl = s.kl;
+    if (tid == 0) sh_p = 0, sh_nsyms = 0, sh_k = 0, sh_preins = -1, sh_trigger = kl >= 1 ? read_end_before(1) - (kMinLookahead - 1) : -1;
+    __syncthreads();
+    const bool aligned = (((uintptr_t)in) & 15) == 0;
+    for (;;) {
+        const int64_t p_in = sh_p;
+        if (p_in > body_end) break;
+        const int64_t t0 = p_in & ~31LL, lo = t0 - kFvBack, bw0 = lo >> 5;  // lo is a multiple of 32: bitmap words line up
+        // ---- stage the tile
+        for (int i = tid; i < kFvBytes / 16; i += 1024) {
+            const int64_t a = lo + (int64_t)i * 16;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (a >= 0 && a + 15 < n && aligned) {
+                const u32x4 t = *(gcu32x4)(in + a);
+                v = make_uint4(t[0], t[1], t[2], t[3]);
+            } else if (a + 15 >= 0 && a < n) {
+                uint32_t t[4] = {0, 0, 0, 0};
+                for (int k = 0; k < 16; k++) {
+                    const int64_t b = a + k;
+                    if (b >= 0 && b < n) t[k >> 2] |= (uint32_t)in[b] << (8 * (k & 3));
+                }
+                v = make_uint4(t[0], t[1], t[2], t[3]);
+            }
+            ((uint4 *)wb)[i] = v;
+        }
+        for (int i = tid; i < kFvLinks / 8; i += 1024) {
+            const int64_t a = lo + (int64_t)i * 8;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (a >= 0 && a + 7 < n) {
+                v = *(const uint4 *)(lk + a);
+            } else if (a + 7 >= 0 && a < n) {
+                uint32_t t[4] = {0, 0, 0, 0};
+                for (int k = 0; k < 8; k++) {
+                    const int64_t b = a + k;
+                    if (b >= 0 && b < n) t[k >> 1] |= (uint32_t)lk[b] << (16 * (k & 1));
+                }
+                v = make_uint4(t[0], t[1], t[2], t[3]);
+            }
+            ((uint4 *)wl)[i] = v;
+        }
+        for (int i = tid; i < kFvBitWords; i += 1024) bm[i] = bw0 + i >= 0 ? gbits[bw0 + i] : 0u;
+        __syncthreads();
+        if (tid < 64) {
+            FvLdsAcc acc{wb, wl, bm, lo, bw0};
+            int64_t p0 = p_in, nsyms = sh_nsyms, trigger = sh_trigger, preins = sh_preins;
+            int k_fired = sh_k;
+            const bool search = strategy != kHuffmanOnly;
+            while (p0 <= body_end && p0 + kFvLanes <= t0 + kFvTile) {
+                bool dead0 = false, dead1 = false, only1 = false;
+                if (trigger >= 0 && p0 >= trigger) {
+                    // the read event at loop-top p0: p0 + 1 is inserted first (Deflate.cs:1010-1013)
+                    k_fired++;
+                    preins = p0 + 1;
+                    if (lane == 0) atomicOr(&bm[((p0 + 1) >> 5) - bw0], 1u << ((p0 + 1) & 31));
+                    if (wl[p0 + 1 - lo] == 1) {
+                        dead0 = true, only1 = true;
+                        if (lane == 0) wl[p0 - lo] = 0, lk[p0] = 0;  // the reference's prev[p0] = p0 + 1, prev[p0 + 1] = p0
+                    } else {
+                        dead1 = true;
+                    }
+                    trigger = k_fired < kl ? read_end_before(k_fired + 1) - (kMinLookahead - 1) : -1;
+                }
+                int limit = kFvLanes;
+                if (body_end - p0 + 1 < limit) limit = (int)(body_end - p0 + 1);
+                FvResult r{2, 0, 0};
+                if (lane < limit)
+                    r = fv_search(acc, p0 + lane, p0, lv.chain, lv.nice, !search || (lane == 0 && dead0) || (lane == 1 && dead1), lane == 1 && only1);
+                const FvLaneRes lr{r.len, r.dist, r.touched};
+                const FvWindow w = fv_resolve(lr, p0, limit, lv.lazy, trigger);
+                // ---- the loop-tops' symbols, compacted; block cuts every kBlockSyms symbols (Deflate.cs:910-948)
+                if ((w.tops >> lane) & 1ull) {
+                    const int64_t g = nsyms + __builtin_popcountll(w.tops & lanemask_lt());
+                    const bool match = r.len >= kMinMatch;
+                    syms[s.sym_off + g] = match ? (((uint32_t)r.dist << 16) | (uint32_t)(r.len - 3)) : (uint32_t)wb[p0 + lane - lo];
+                    if ((g + 1) % kBlockSyms == 0) {
+                        blk_end[s.blk_off + g / kBlockSyms] = (int32_t)(p0 + lane + (match ? r.len : 1));
+                        blk_top[s.blk_off + g / kBlockSyms] = (int32_t)(p0 + lane);
+                    }
+                }
+                nsyms += __builtin_popcountll(w.tops);
+                // ---- the window's inserted bits: 96 of them from bit (p0 & 31) of word p0 >> 5 on
+                if (lane < 4) {
+                    const int sh = (int)(p0 & 31);
+                    const uint32_t b[3] = {(uint32_t)w.ins_lo, (uint32_t)(w.ins_lo >> 32), w.ins_hi};
+                    // word j of the shifted 96-bit string
+                    const uint32_t cur = lane < 3 ? b[lane] : 0u, below = lane >= 1 ? b[lane - 1] : 0u;
+                    const uint32_t v = sh ? (cur << sh) | (below >> (32 - sh)) : cur;
+                    if (v) atomicOr(&bm[(p0 >> 5) - bw0 + lane], v);
+                }
+                p0 += w.advance;
+            }
+            // ---- leave the tile: the bitmap words that changed go back to the stream's bitmap
+            for (int64_t wd = (p_in >> 5) + lane; wd <= (p0 + 96) >> 5; wd += 64)
+                if (wd - bw0 < kFvBitWords) gbits[wd] = bm[wd - bw0];
+            if (lane == 0) sh_p = p0, sh_nsyms = nsyms, sh_trigger = trigger, sh_preins = preins, sh_k = k_fired;
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+    if (tid == 0) {
+        StreamState &ss = st[blockIdx.x];
+        ss.tail_p = (int32_t)sh_p;
+        ss.tail_kind = kR;
+        ss.tail_pend = 0;
+        ss.k_done = sh_k;
+        ss.preins = (int32_t)sh_preins;
+        ss.body_syms = (uint32_t)sh_nsyms;
     }
 }
 
