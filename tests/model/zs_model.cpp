@@ -160,9 +160,10 @@ static void parse_sequential(Model &m, bool on_demand, int64_t &p_out, int &kind
 //      all-position chains filtered by the inserted set, then the hops followed through the lanes' results ----
 struct FvAcc {
     const Model *m;
-    int link(int64_t c) const { return (int)m->link[(size_t)c]; }
+    mutable long visits = 0, cmps = 0;
+    int link(int64_t c) const { visits++; return (int)m->link[(size_t)c]; }
     bool ins(int64_t c) const { return m->ins[(size_t)c] != 0; }
-    int lcp(int64_t q, int64_t c) const { return m->lcp(q, c); }
+    int lcp(int64_t q, int64_t c) const { cmps++; return m->lcp(q, c); }
 };
 static void parse_fast_vec(Model &m, int64_t &p_out, int &kdone_out, int64_t &preins_out) {
     m.ins.assign((size_t)m.n + 128, 0);
@@ -192,8 +193,12 @@ static void parse_fast_vec(Model &m, int64_t &p_out, int &kdone_out, int64_t &pr
         int limit = kFvLanes;
         if (m.body_end - p0 + 1 < limit) limit = (int)(m.body_end - p0 + 1);
         FvResult res[kFvLanes];
-        for (int i = 0; i < limit; i++)
+        fv_max_iters = 0;
+        for (int i = 0; i < limit; i++) {
+            const long v0 = acc.visits;
             res[i] = fv_search(acc, p0 + i, p0, m.lv.chain, m.lv.nice, !search || (i == 0 && dead0) || (i == 1 && dead1), i == 1 && only1);
+            if (acc.visits - v0 > fv_max_iters) fv_max_iters = acc.visits - v0;
+        }
         auto rf = [&](int i) { return res[i]; };
         const FvWindow w = fv_resolve(rf, p0, limit, m.lv.lazy, st.trigger);
         for (int i = 0; i < limit; i++) {
@@ -221,7 +226,7 @@ static void parse_fast_vec(Model &m, int64_t &p_out, int &kdone_out, int64_t &pr
         st.p = p0 + w.advance;
         fv_windows++, fv_iters += fv_max_iters;
     }
-    if (getenv("ZS_FV_STATS")) printf("fvec: %ld windows, %.1f positions per window\n", fv_windows, (double)st.p / (double)(fv_windows ? fv_windows : 1));
+    if (getenv("ZS_FV_STATS")) printf("fvec: %ld windows, %.1f positions per window, max-lane chain visits per window %.1f, visits per position %.1f, compares per position %.2f\n", fv_windows, (double)st.p / (double)(fv_windows ? fv_windows : 1), (double)fv_iters / fv_windows, (double)acc.visits / st.p, (double)acc.cmps / st.p);
     p_out = st.p;
     kdone_out = st.k_fired;
     preins_out = st.preins;

@@ -27,3 +27,21 @@ for lvl in (1, 3):
 e64 = datagen.english(64 << 20)
 run("english64", e64, 0, reps=3)   # DeflateStored: host-planned blocks + copy kernel
 run("sparse64", sp, 0, reps=3)
+
+# many streams at the fast levels: one workgroup per stream (zs_fast_vec_kernel), all streams at once
+def run_batch(name, bufs, level, reps=1):
+    d_ins = [torch.frombuffer(bytearray(b), dtype=torch.uint8).cuda() for b in bufs]
+    caps = [deflate_bound(len(b)) for b in bufs]
+    d_outs = [torch.empty(c, dtype=torch.uint8, device="cuda") for c in caps]
+    args = ([t.data_ptr() for t in d_ins], [len(b) for b in bufs], [t.data_ptr() for t in d_outs], caps)
+    eng.deflate_batch_device(*args, level=level)
+    torch.cuda.synchronize(); t = time.perf_counter()
+    for _ in range(reps):
+        lens = eng.deflate_batch_device(*args, level=level)
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t) / reps
+    ok = all(zlib.decompress(d_outs[i][:lens[i]].cpu().numpy().tobytes()) == bufs[i] for i in range(0, len(bufs), 37))
+    n = sum(len(b) for b in bufs)
+    print(json.dumps({"workload": name, "level": level, "streams": len(bufs), "bytes": n, "ms": round(dt * 1e3, 2), "MBps": round(n / dt / 1e6, 1), "roundtrip": ok}), flush=True)
+texts = [datagen.english(512 << 10, 1000 + i) for i in range(512)]
+for lvl in (1, 3):
+    run_batch("english 512 x 512 KiB", texts, lvl)

@@ -1531,8 +1531,57 @@ __global__ __launch_bounds__(1024) void zs_fast_vec_kernel(const StreamDesc *sd,
                 int limit = kFvLanes;
                 if (body_end - p0 + 1 < limit) limit = (int)(body_end - p0 + 1);
                 FvResult r{2, 0, 0};
-                if (lane < limit)
-                    r = fv_search(acc, p0 + lane, p0, lv.chain, lv.nice, !search || (lane == 0 && dead0) || (lane == 1 && dead1), lane == 1 && only1);
+                {
+                    // fv_search (zs_fast_vec.h) with LDS-relative indices, one LDS round trip per chain entry: the entry's
+                    // link, its bit of the inserted set and its first 8 bytes are requested together, whether or not the
+                    // entry turns out to be in the set (a lone wave pays every dependent round trip in full)
+                    const int qi = (int)(p0 - lo) + lane, p0i = (int)(p0 - lo), min_i = (int)(1 - lo);  // position 0 is never a candidate
+                    const bool dead = !search || lane >= limit || (lane == 0 && dead0) || (lane == 1 && dead1);
+                    const bool only_prev = lane == 1 && only1;
+                    const uint64_t scan8 = lds_u64(wb, qi);
+                    int c = qi, l = wl[qi], found = 0, best = 2, bdist = 0, touched = 0;
+                    bool done = dead || only_prev;
+                    if (only_prev && lane < limit) {
+                        const int len = acc.lcp(p0 + lane, p0 + lane - 1);
+                        if (len > 2) best = len, bdist = 1;
+                    }
+                    const uint32_t *bmr = bm - (lo >> 5) + bw0;  // bmr[(rel index) >> 5] with rel = position - lo: lo is a multiple of 32
+                    while (__ballot(!done)) {
+                        const int nc = c - l, d = qi - nc;
+                        const bool valid = !done && l != 0 && nc >= min_i && (found == 0 ? d <= kMaxDist : d < kMaxDist);
+                        const bool recent = valid && nc >= p0i;
+                        touched |= recent ? 1 : 0;
+                        const bool go = valid && !recent;
+                        done = done || !go;
+                        const int cc = go ? nc : qi;  // lanes that are done read their own position (in range)
+                        l = wl[cc];
+                        const uint32_t word = bmr[cc >> 5];
+                        const uint64_t x = lds_u64(wb, cc) ^ scan8;
+                        c = cc;
+                        const bool in = go && ((word >> (cc & 31)) & 1u);
+                        if (in) {
+                            found++;
+                            int len = x ? (int)(__builtin_ctzll(x) >> 3) : 8;
+                            if (!x) {
+                                while (len < kMaxMatch) {
+                                    const uint64_t y = lds_u64(wb, qi + len) ^ lds_u64(wb, cc + len);
+                                    if (y) {
+                                        len += (int)(__builtin_ctzll(y) >> 3);
+                                        break;
+                                    }
+                                    len += 8;
+                                }
+                                len = len < kMaxMatch ? len : kMaxMatch;
+                            }
+                            if (len > best) {
+                                best = len, bdist = d;
+                                if (len >= lv.nice) done = true;
+                            }
+                            if (found >= lv.chain) done = true;
+                        }
+                    }
+                    r = FvResult{best, bdist, touched};
+                }
                 const FvLaneRes lr{r.len, r.dist, r.touched};
                 const FvWindow w = fv_resolve(lr, p0, limit, lv.lazy, trigger);
                 // ---- the loop-tops' symbols, compacted; block cuts every kBlockSyms symbols (Deflate.cs:910-948)
