@@ -113,6 +113,13 @@ struct StreamState {
     uint32_t adler;
     int32_t status;
     int64_t end_bits;  // bit position in the stream (zlib header included) behind the run's last block or marker
+    // the resolve kernel's position when it is run part by part behind the match kernel (one long stream: zs_engine.hip):
+    // next segment, entry slot, symbols so far, last fired refill; and the equal-bucket cuts whose repair reaches into
+    // positions whose matches were not computed yet (cut position, last position repaired)
+    int32_t r_seg, r_slot, r_kfired, r_preins1;
+    uint32_t r_total;
+    int32_t r_ncut;
+    int32_t r_cut_e[8], r_cut_done[8];
 };
 
 // DeflateFast (levels 1-3) as speculative chunk runs: run j re-parses kFastWarm bytes before its chunk with an

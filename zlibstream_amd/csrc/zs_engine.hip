@@ -38,6 +38,8 @@ struct zs_ctx {
     hipStream_t stream = nullptr;
     hipStream_t aux = nullptr;  // second stream: tree building of the finished blocks runs beside the tail engine
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_part[16] = {};          // one long stream run part by part: part k's maps are ready
+    std::vector<hipEvent_t> ev_pool;      // timing pairs of the part-wise launches (profiling)
     std::string err;
     bool profiling = false;
     int fast_fallbacks = 0;  // speculative DeflateFast batches that had to be redone sequentially
@@ -354,6 +356,119 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
     if (!pl.w_adler.empty())
         hipLaunchKernelGGL(zs_adler_kernel, dim3((unsigned)pl.w_adler.size()), dim3(256), 0, stream, d_sd, d_work + o_adler,
                            dev<uint32_t>(c->pieces));
+    // One long stream: the position-parallel kernels (links, matches, chunk maps) fill the chip, the kernels that follow
+    // the parse (resolve: one workgroup; symbols: one lane per chunk, a latency chain) leave it idle.  ZS_PIPE_PARTS=k cuts
+    // the stream into k parts at parse-segment boundaries: while the match kernel works on part i + 1 the second HIP stream
+    // resolves part i and emits its symbols (the resolve kernel keeps its place between launches, StreamState r_*).  Same
+    // kernels, same bytes -- and, measured on english64, the same time (5.82 ms with 2 parts, 5.90 with 4, against 5.85): the
+    // symbol kernel's ~0.65 ms latency floor is paid again behind the last part and the match kernel loses 0.2-0.3 ms to the
+    // company.  Off unless asked for.
+    int n_parts = 0;
+    if (n == 1 && !ro && pl.sd[0].body_end >= 0 && pl.sd[0].nsegs >= 256 && strategy != kHuffmanOnly && !pl.any_fv) {
+        const char *e = getenv("ZS_PIPE_PARTS");
+        n_parts = e ? atoi(e) : 0;
+        if (n_parts > 16) n_parts = 16;
+        if (n_parts < 2) n_parts = 0;
+    }
+    struct TimedPair {
+        int stage;
+        hipEvent_t a, b;
+    };
+    std::vector<TimedPair> pairs;
+    size_t pool_used = 0;
+    if (n_parts) {
+        for (int i = 2; i <= 9; i++) mark(i);  // stages 2..9 are timed launch by launch below; their marks only have to exist
+        auto timed = [&](int stage, hipStream_t st_, auto &&launch) {
+            if (!prof) {
+                launch();
+                if (getenv("ZS_DEBUG")) {
+                    hipError_t e_ = hipGetLastError();
+                    if (e_ != hipSuccess) fprintf(stderr, "zs: launch of stage %s failed: %s\n", kStageNames[stage], hipGetErrorString(e_));
+                }
+                return;
+            }
+            while (c->ev_pool.size() < pool_used + 2) {
+                hipEvent_t ev = nullptr;
+                (void)hipEventCreate(&ev);
+                c->ev_pool.push_back(ev);
+            }
+            hipEvent_t a = c->ev_pool[pool_used++], b = c->ev_pool[pool_used++];
+            (void)hipEventRecord(a, st_);
+            launch();
+            (void)hipEventRecord(b, st_);
+            pairs.push_back(TimedPair{stage, a, b});
+        };
+        const StreamDesc &s0 = pl.sd[0];
+        const int nsegs = s0.nsegs, nchunks = s0.nchunks;
+        const int64_t n_tiles = (int64_t)pl.w_match.size(), n_spans = (int64_t)pl.w_links.size();
+        int64_t tiles_done = 0, spans_done = 0;
+        for (int k = 0; k < n_parts; k++) {
+            const int sa = (int)((int64_t)nsegs * k / n_parts), sb = (int)((int64_t)nsegs * (k + 1) / n_parts);
+            const int ca = pl.seg_c0[(size_t)sa], cb = sb < nsegs ? pl.seg_c0[(size_t)sb] : nchunks;
+            // the chunks below cb need the match records of the positions below their end
+            const int64_t q = sb < nsegs ? chunk_start(cb) : (int64_t)s0.body_end + 1;
+            int64_t tiles_end = (q + kMatchTile - 1) / kMatchTile;
+            if (tiles_end > n_tiles || sb == nsegs) tiles_end = n_tiles;
+            int64_t spans_end = (tiles_end * kMatchTile + link_span - 1) / link_span;
+            if (spans_end > n_spans || sb == nsegs) spans_end = n_spans;
+            // the link kernel's time is that of one workgroup's span whatever the number of spans: all of them at once, up front
+            if (k == 0) spans_end = n_spans;
+            if (spans_end > spans_done)
+                timed(kStLinks, stream, [&] {
+                    hipLaunchKernelGGL(zs_links_kernel, dim3((unsigned)(spans_end - spans_done)), dim3(1024), kLkLds, stream, d_sd,
+                                       d_work + o_links + spans_done, dev<uint16_t>(c->link), c->crc_tab, hash_variant, (int)link_span);
+                });
+            if (tiles_end > tiles_done)
+                timed(kStMatch, stream, [&] {
+                    hipLaunchKernelGGL(zs_match_kernel, dim3((unsigned)(tiles_end - tiles_done)), dim3(1024), kMatchLds, stream, d_sd,
+                                       d_work + o_match + tiles_done, dev<uint16_t>(c->link), dev<uint2>(c->mm), lv, strategy);
+                });
+            spans_done = spans_end > spans_done ? spans_end : spans_done, tiles_done = tiles_end > tiles_done ? tiles_end : tiles_done;
+            timed(kStChunkMap, stream, [&] {
+                hipLaunchKernelGGL(zs_chunkmap_kernel, dim3((unsigned)(cb - ca)), dim3(512), 0, stream, d_sd, d_work + o_chunks + ca,
+                                   dev<uint2>(c->mm), dev<uint32_t>(c->maps), c->crc_tab, lv, strategy, hash_variant);
+            });
+            timed(kStSegMap, stream, [&] {
+                hipLaunchKernelGGL(zs_segmap_kernel, dim3((unsigned)(sb - sa)), dim3(320), 0, stream, d_sd, d_work + o_segs + sa,
+                                   dev<uint32_t>(c->maps), dev<uint2>(c->segmap));
+            });
+            ZS_HIP(c, hipEventRecord(c->ev_part[k], stream));
+            ZS_HIP(c, hipStreamWaitEvent(c->aux, c->ev_part[k], 0));
+            const int64_t mm_limit = tiles_end * kMatchTile - 1;
+            timed(kStResolve, c->aux, [&] {
+                hipLaunchKernelGGL(zs_resolve_kernel, dim3(1), dim3(1024), kResolveLds, c->aux, d_sd, d_st, dev<uint16_t>(c->link),
+                                   dev<uint2>(c->mm), dev<uint32_t>(c->maps), dev<uint2>(c->segmap), dev<uint16_t>(c->seg_entry),
+                                   dev<uint32_t>(c->seg_symbase), dev<uint8_t>(c->stale), dev<uint8_t>(c->seg_stale), c->crc_tab, lv,
+                                   strategy, hash_variant, sb, (int)(mm_limit > 0x7FFFFFFF ? 0x7FFFFFFF : mm_limit));
+            });
+            if (k == n_parts - 1) {
+                // the tail engine needs what the last resolve launch left: it runs on the first stream beside the last part's symbols
+                ZS_HIP(c, hipEventRecord(c->ev_fork, c->aux));
+                ZS_HIP(c, hipStreamWaitEvent(stream, c->ev_fork, 0));
+                timed(kStTail, stream, [&] {
+                    hipLaunchKernelGGL(zs_tail_kernel, dim3(1), dim3(1024), kTailLds, stream, d_sd, d_st, dev<uint16_t>(c->link),
+                                       dev<uint32_t>(c->syms), dev<int32_t>(c->blk_end), dev<int32_t>(c->blk_top), dev<BlockRec>(c->blocks),
+                                       dev<uint8_t>(c->scratch), c->crc_tab, lv, strategy, hash_variant, level);
+                });
+            }
+            timed(kStExpand, c->aux, [&] {
+                hipLaunchKernelGGL(zs_expand_kernel, dim3((unsigned)((sb - sa + 63) / 64)), dim3(64), 0, c->aux, d_sd, d_work + o_segs + sa,
+                                   sb - sa, dev<uint2>(c->mm), dev<uint32_t>(c->maps), dev<uint16_t>(c->seg_entry),
+                                   dev<uint32_t>(c->seg_symbase), dev<uint8_t>(c->stale), dev<uint16_t>(c->entry), dev<uint32_t>(c->symbase),
+                                   c->crc_tab, lv, strategy, hash_variant);
+            });
+            timed(kStEmitSyms, c->aux, [&] {
+                hipLaunchKernelGGL(zs_emit_syms_lane_kernel, dim3((unsigned)((cb - ca + 63) / 64)), dim3(64), 0, c->aux, d_sd,
+                                   d_work + o_chunks + ca, cb - ca, dev<uint2>(c->mm), dev<uint16_t>(c->entry), dev<uint32_t>(c->symbase),
+                                   dev<uint32_t>(c->syms), dev<int32_t>(c->blk_end), dev<int32_t>(c->blk_top), c->crc_tab, lv, strategy,
+                                   hash_variant);
+            });
+        }
+        ZS_HIP(c, hipEventRecord(c->ev_join, c->aux));
+        ZS_HIP(c, hipStreamWaitEvent(stream, c->ev_join, 0));
+        hipLaunchKernelGGL(zs_body_blocks_kernel, dim3((unsigned)n), dim3(256), 0, stream, d_sd, d_st, dev<int32_t>(c->blk_end),
+                           dev<int32_t>(c->blk_top), dev<BlockRec>(c->blocks));
+    } else {
     mark(2);
     if (!pl.w_links.empty())
         hipLaunchKernelGGL(zs_links_kernel, dim3((unsigned)pl.w_links.size()), dim3(1024), kLkLds, stream, d_sd, d_work + o_links,
@@ -378,7 +493,7 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
     hipLaunchKernelGGL(zs_resolve_kernel, dim3((unsigned)n), dim3(1024), kResolveLds, stream, d_sd, d_st, dev<uint16_t>(c->link),
                        dev<uint2>(c->mm), dev<uint32_t>(c->maps), dev<uint2>(c->segmap),
                        dev<uint16_t>(c->seg_entry), dev<uint32_t>(c->seg_symbase), dev<uint8_t>(c->stale),
-                       dev<uint8_t>(c->seg_stale), c->crc_tab, lv, strategy, hash_variant);
+                       dev<uint8_t>(c->seg_stale), c->crc_tab, lv, strategy, hash_variant, 0x7FFFFFFF, 0x7FFFFFFF);
     mark(7);
     // fork: the tail engine (sequential, one workgroup per stream) needs only what the resolve kernel left, so it runs
     // on the second stream beside the symbol kernels
@@ -414,6 +529,7 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
         hipLaunchKernelGGL(zs_tail_kernel, dim3((unsigned)n), dim3(1024), kTailLds, stream, d_sd, d_st, dev<uint16_t>(c->link),
                            dev<uint32_t>(c->syms), dev<int32_t>(c->blk_end), dev<int32_t>(c->blk_top), dev<BlockRec>(c->blocks),
                            dev<uint8_t>(c->scratch), c->crc_tab, lv, strategy, hash_variant, level);
+    }
     if (pl.n_runs) {
         // DeflateFast by speculative chunk runs; a run whose hand-over state does not verify sends the batch to the
         // sequential engine (the result is the reference's bytes either way)
@@ -466,12 +582,21 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
     ZS_HIP(c, hipMemcpyAsync(hst, d_st, sizeof(StreamState) * (size_t)n, hipMemcpyDeviceToHost, stream));
     ZS_HIP(c, hipStreamSynchronize(stream));
     c->last_op = 0;
-    if (prof)
+    if (prof) {
         for (int i = 0; i < kStCount; i++) {
             float ms = 0;
             (void)hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]);
             c->stage_ms[i] = ms;
         }
+        if (n_parts) {  // part-wise launches: every launch has its own pair of events, a stage is the sum of its launches
+            for (int i = kStLinks; i <= kStTail; i++) c->stage_ms[i] = 0;
+            for (const TimedPair &t : pairs) {
+                float ms = 0;
+                (void)hipEventElapsedTime(&ms, t.a, t.b);
+                c->stage_ms[t.stage] += ms;
+            }
+        }
+    }
     if (ro) ro->end_bits = hst[0].end_bits;
     // every stream's length and code are reported; the first failing one sets the message and the return value
     bool all_ok = true;
@@ -587,6 +712,11 @@ int zs_ctx_create(int device, zs_ctx **out) {
         delete c;
         return ZS_MEM_ERROR;
     }
+    for (auto &e : c->ev_part)
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
+            zs_ctx_destroy(c);
+            return ZS_MEM_ERROR;
+        }
     std::vector<uint32_t> tab(1024);
     for (int t = 0; t < 4; t++)
         for (int i = 0; i < 256; i++) tab[(size_t)t * 256 + i] = crc32c_table_entry(t, (uint32_t)i);
@@ -619,6 +749,10 @@ void zs_ctx_destroy(zs_ctx *c) {
     if (c->crc_tab) (void)hipFree(c->crc_tab);
     if (c->pinned) (void)hipHostFree(c->pinned);
     for (auto &e : c->ev)
+        if (e) (void)hipEventDestroy(e);
+    for (auto &e : c->ev_part)
+        if (e) (void)hipEventDestroy(e);
+    for (auto &e : c->ev_pool)
         if (e) (void)hipEventDestroy(e);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);

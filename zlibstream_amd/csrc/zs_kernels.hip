@@ -710,7 +710,7 @@ __global__ __launch_bounds__(1024) void zs_resolve_kernel(const StreamDesc *sd, 
                                                          const uint32_t *maps, const uint2 *segmap,
                                                          uint16_t *seg_entry, uint32_t *seg_symbase, uint8_t *stale,
                                                          uint8_t *seg_stale, const uint32_t *crc_tab_g, LevelCfg lv,
-                                                         int strategy, int hash_variant) {
+                                                         int strategy, int hash_variant, int seg_limit, int mm_limit) {
     // > 64 KiB of LDS: dynamic allocation, carved by hand
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint2 *rows = (uint2 *)smem;                                  // segment-map rows of the current batch (130 KiB)
@@ -727,7 +727,10 @@ __global__ __launch_bounds__(1024) void zs_resolve_kernel(const StreamDesc *sd, 
     const StreamDesc s = sd[blockIdx.x];
     StreamState &ss = st[blockIdx.x];
     load_crc_tab(tab, crc_tab_g);
-    if (threadIdx.x == 0) sh_seg = 0, sh_slot = 0, sh_total = 0, sh_kfired = 0, sh_preins = -1, sh_scan = 0;
+    // seg_limit / mm_limit (one long stream run part by part, else "everything"): segments below seg_limit have their maps,
+    // positions up to mm_limit their match records; the kernel goes on from where the launch before stopped
+    if (threadIdx.x == 0)
+        sh_seg = ss.r_seg, sh_slot = ss.r_slot, sh_total = ss.r_total, sh_kfired = ss.r_kfired, sh_preins = ss.r_preins1 - 1, sh_scan = 0;
     __syncthreads();
     if (s.body_end < 0) {
         if (threadIdx.x == 0) ss.tail_p = 0, ss.tail_kind = kR, ss.tail_pend = 0, ss.k_done = 0, ss.preins = -1, ss.body_syms = 0;
@@ -736,7 +739,58 @@ __global__ __launch_bounds__(1024) void zs_resolve_kernel(const StreamDesc *sd, 
     uint16_t *lk = link + s.pos_off;
     uint2 *a = mm + s.pos_off;
     GlobalAcc acc{as_global(s.in), a, tab, strategy, hash_variant};
-    const int nseg = s.nsegs, nch = s.nchunks;
+    const int nseg = s.nsegs < seg_limit ? s.nsegs : seg_limit, nch = s.nchunks;
+    const int64_t mm_end = (int64_t)s.body_end < (int64_t)mm_limit ? (int64_t)s.body_end : (int64_t)mm_limit;
+    // The reference leaves prev[e] = e + 1 at an equal-bucket refill loop-top e: everything older than e is hidden from
+    // later walks through that bucket.  link[e] is cut; positions in (from, to] whose recorded winner lies behind the cut are
+    // walked again and their chunks marked stale.
+    auto repair = [&](int64_t e, int64_t from, int64_t to) {
+        const uint32_t B = acc.bucket(e);
+        for (int64_t p = from + 1 + threadIdx.x; p <= to; p += blockDim.x) {
+            if (acc.bucket(p) != B) continue;
+            const uint2 old = a[p];
+            uint32_t x = old.x & kRecMask, y = old.y;
+            bool dirty = (x && p - match_dist(x) < e) || (y && p - match_dist(y) < e);
+            if (!dirty) continue;
+            auto lkf = [lk](int64_t q) { return (int)lk[q]; };
+            const gcbytes in = as_global(s.in);
+            auto lcp = [in](int64_t u, int64_t v) {
+                int len = 0;
+                while (len < kMaxMatch && in[u + len] == in[v + len]) len++;
+                return len;
+            };
+            uint32_t nx, ny;
+            walk_matches(lkf, lcp, p, lv, nx, ny);
+            if (nx != x || ny != y) {
+                a[p] = make_uint2(nx | (old.x & ~kRecMask), ny);
+                int cp = chunk_of(p);
+                stale[s.chunk_off + cp] = 1;
+                seg_stale[s.seg_off + seg_of(s, cp)] = 1;
+                if (p + 1 == chunk_geo(cp).ce && cp + 1 < nch) {
+                    stale[s.chunk_off + cp + 1] = 1;
+                    seg_stale[s.seg_off + seg_of(s, cp + 1)] = 1;
+                }
+            }
+        }
+    };
+    // cuts of an earlier launch whose repair had to stop where the match records ended
+    {
+        const int nc = ss.r_ncut;
+        int keep = 0;
+        for (int i = 0; i < nc; i++) {
+            const int64_t e = ss.r_cut_e[i], from = ss.r_cut_done[i];
+            int64_t full = e + kMaxDist;
+            if (full > s.body_end) full = s.body_end;
+            const int64_t to = full < mm_end ? full : mm_end;
+            if (to > from) repair(e, from, to);
+            __syncthreads();
+            if (threadIdx.x == 0 && to < full) ss.r_cut_e[keep] = (int32_t)e, ss.r_cut_done[keep] = (int32_t)to;
+            if (to < full) keep++;
+        }
+        __threadfence_block();
+        __syncthreads();
+        if (threadIdx.x == 0) ss.r_ncut = keep;
+    }
     for (;;) {
         // ---- stage the next kSegBatch segment-map rows (coalesced), then thread 0 follows the path through them
         //      (one LDS lookup per segment; its per-segment results go out coalesced afterwards); it stops early
@@ -884,42 +938,23 @@ __global__ __launch_bounds__(1024) void zs_resolve_kernel(const StreamDesc *sd, 
             const int c0 = s.seg_c0[sh_seg];
             const int slot = sh_slot;
             const int64_t e = slot <= 256 ? chunk_start(c0) + slot : chunk_start(c0);
-            const uint32_t B = acc.bucket(e);
             if (threadIdx.x == 0) lk[e] = 0;
             __threadfence_block();
             __syncthreads();
-            int64_t hi = e + kMaxDist;
-            if (hi > s.body_end) hi = s.body_end;
-            for (int64_t p = e + 1 + threadIdx.x; p <= hi; p += blockDim.x) {
-                if (acc.bucket(p) != B) continue;
-                const uint2 old = a[p];
-                uint32_t x = old.x & kRecMask, y = old.y;
-                bool dirty = (x && p - match_dist(x) < e) || (y && p - match_dist(y) < e);
-                if (!dirty) continue;
-                auto lkf = [lk](int64_t q) { return (int)lk[q]; };
-                const gcbytes in = as_global(s.in);
-                auto lcp = [in](int64_t u, int64_t v) {
-                    int len = 0;
-                    while (len < kMaxMatch && in[u + len] == in[v + len]) len++;
-                    return len;
-                };
-                uint32_t nx, ny;
-                walk_matches(lkf, lcp, p, lv, nx, ny);
-                if (nx != x || ny != y) {
-                    a[p] = make_uint2(nx | (old.x & ~kRecMask), ny);
-                    int cp = chunk_of(p);
-                    stale[s.chunk_off + cp] = 1;
-                    seg_stale[s.seg_off + seg_of(s, cp)] = 1;
-                    if (p + 1 == chunk_geo(cp).ce && cp + 1 < nch) {
-                        stale[s.chunk_off + cp + 1] = 1;
-                        seg_stale[s.seg_off + seg_of(s, cp + 1)] = 1;
-                    }
-                }
+            int64_t full = e + kMaxDist;
+            if (full > s.body_end) full = s.body_end;
+            const int64_t to = full < mm_end ? full : mm_end;
+            repair(e, e, to);
+            if (threadIdx.x == 0 && to < full) {  // the rest once the records beyond exist
+                const int k = ss.r_ncut < 8 ? ss.r_ncut++ : 7;
+                ss.r_cut_e[k] = (int32_t)e, ss.r_cut_done[k] = (int32_t)to;
             }
             __threadfence_block();
         }
         __syncthreads();
     }
+    if (threadIdx.x == 0) ss.r_seg = sh_seg, ss.r_slot = sh_slot, ss.r_total = sh_total, ss.r_kfired = sh_kfired, ss.r_preins1 = sh_preins + 1;
+    if (sh_seg < s.nsegs) return;  // more segments to come in a later launch
     if (threadIdx.x == 0) {
         int slot = sh_slot;
         int64_t ce = (int64_t)s.body_end + 1;
