@@ -66,11 +66,17 @@ public:
         : ZlibOutputStream(output, ZlibOptions{level, CompressionStrategy::DefaultStrategy, FlushMode::NoFlush}, ctx) {}
 
     ZlibOutputStream(std::ostream &output, const ZlibOptions &options, zs_ctx *ctx = nullptr) : BaseStream(output), Options(options) {
-        if (!Options.CompressionLevel_) throw std::invalid_argument("inflate mode of ZlibOutputStream is not supported");
-        int level = (int)*Options.CompressionLevel_;
-        // Deflate..ctor throws ArgumentOutOfRangeException (Deflate.cs:258-281)
-        z_ = zs_deflate_init(ctx ? ctx : GpuContext::Shared(), level, (int)Options.CompressionStrategy_, 15, 8, ZS_HASH_CRC32C);
-        if (!z_) throw std::out_of_range("level / strategy");
+        // ZlibStream.cs:18-29: a null level means inflate mode -- the stream inflates what is written to it
+        compress_ = Options.CompressionLevel_.has_value();
+        if (compress_) {
+            // Deflate..ctor throws ArgumentOutOfRangeException (Deflate.cs:258-281)
+            z_ = zs_deflate_init(ctx ? ctx : GpuContext::Shared(), (int)*Options.CompressionLevel_, (int)Options.CompressionStrategy_, 15, 8,
+                                 ZS_HASH_CRC32C);
+            if (!z_) throw std::out_of_range("level / strategy");
+        } else {
+            zi_ = zs_inflate_init(ctx ? ctx : GpuContext::Shared(), 15);
+            if (!zi_) throw std::out_of_range("windowBits");
+        }
     }
     ZlibOutputStream(const ZlibOutputStream &) = delete;
     ZlibOutputStream &operator=(const ZlibOutputStream &) = delete;
@@ -112,12 +118,10 @@ public:
                 Flush();
             }
         } catch (...) {
-            zs_deflate_end(z_);
-            z_ = nullptr;
+            End();
             throw;
         }
-        zs_deflate_end(z_);
-        z_ = nullptr;
+        End();
     }
 
 private:
@@ -127,18 +131,27 @@ private:
         for (;;) {
             int32_t availOut = BufferSize;
             int32_t before = availIn;
-            int state = zs_deflate(z_, next, &availIn, chunk_, &availOut, flush, &adler_, &totalIn_, &totalOut_);
+            int state = compress_ ? zs_deflate(z_, next, &availIn, chunk_, &availOut, flush, &adler_, &totalIn_, &totalOut_)
+                                  : zs_inflate(zi_, next, &availIn, chunk_, &availOut, flush, &adler_, &totalIn_, &totalOut_);
             next += before - availIn;
             if (state != ZS_OK && state != ZS_STREAM_END) {
-                const char *m = zs_last_message(z_);
-                throw ZlibStreamException(std::string("deflating: ") + (m ? m : ""));  // ThrowHelper.cs:21-23
+                const char *m = compress_ ? zs_last_message(z_) : zs_inflate_message(zi_);
+                throw ZlibStreamException(std::string(compress_ ? "deflating: " : "inflating: ") + (m ? m : ""));  // ThrowHelper.cs:21-23
             }
             if (BufferSize - availOut > 0) BaseStream.write((const char *)chunk_, BufferSize - availOut);
+            if (!compress_ && availIn == 0 && availOut == 0 && flush != ZS_FINISH) break;  // ZlibOutputStream.cs:155-158
             if (state == ZS_STREAM_END) break;
             if (!(availIn > 0 || availOut == 0)) break;
         }
     }
+    void End() {
+        if (z_) zs_deflate_end(z_);
+        if (zi_) zs_inflate_end(zi_);
+        z_ = nullptr, zi_ = nullptr;
+    }
     zs_deflate_stream *z_ = nullptr;
+    zs_inflate_stream *zi_ = nullptr;
+    bool compress_ = true;
     uint8_t chunk_[BufferSize];
     uint32_t adler_ = 1;
     int64_t totalIn_ = 0, totalOut_ = 0;

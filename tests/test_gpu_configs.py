@@ -324,3 +324,22 @@ print("OK")
     env = dict(os.environ, ZS_INC_SWITCH_BYTES="300000")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0 and "OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+
+
+def test_zlib_output_stream_without_a_level_inflates(engine):
+    """ZlibStream.cs:18-29: options without a CompressionLevel put the stream in inflate mode -- what is written to a
+    ZlibOutputStream is inflated into its BaseStream (ZlibOutputStream.cs:125-168 with compress == false)."""
+    import io
+    from zlibstream_amd import ZlibOptions, ZlibOutputStream
+    data = oracle_binding.corpus("alice29.txt") + datagen.sparse(64, 64)
+    z = engine.deflate_batch([data], level=6)[0]
+    out = io.BytesIO()
+    with ZlibOutputStream(out, ZlibOptions(), engine=engine) as s:
+        for o in range(0, len(z), 10000):
+            s.write(z[o:o + 10000])
+    assert out.getvalue() == data
+    bad = z[:-1] + bytes([z[-1] ^ 1])
+    with pytest.raises(ZlibStreamException) as ei:
+        with ZlibOutputStream(io.BytesIO(), ZlibOptions(), engine=engine) as s:
+            s.write(bad)
+    assert str(ei.value) == "inflating: incorrect data check"

@@ -331,21 +331,25 @@ class ZlibOutputStream(io.RawIOBase):
             self.Options = level_or_options
         else:
             self.Options = ZlibOptions(CompressionLevel=level_or_options)
-        if self.Options.CompressionLevel is None:
-            # ZlibStream.cs:20-28: a null level means inflate mode
-            raise NotImplementedError("inflate mode of ZlibOutputStream is not on the device path")
         self.BaseStream = base_stream
         self._engine = engine or default_engine()
         self._lib = _native.lib()
-        level = int(self.Options.CompressionLevel)
-        strategy = int(self.Options.CompressionStrategy)
-        if level < -1 or level > 9:
-            raise ValueError("level")  # ArgumentOutOfRangeException (Deflate.cs:273-276)
-        if strategy < 0 or strategy > 4:
-            raise ValueError("strategy")
-        self._z = self._lib.zs_deflate_init(self._engine.handle, level, strategy, 15, 8, hash_variant)
-        if not self._z:
-            raise ValueError("zs_deflate_init rejected the arguments")
+        # ZlibStream.cs:18-29: a null level means inflate mode -- the stream then inflates what is written to it
+        self._compress = self.Options.CompressionLevel is not None
+        if self._compress:
+            level = int(self.Options.CompressionLevel)
+            strategy = int(self.Options.CompressionStrategy)
+            if level < -1 or level > 9:
+                raise ValueError("level")  # ArgumentOutOfRangeException (Deflate.cs:273-276)
+            if strategy < 0 or strategy > 4:
+                raise ValueError("strategy")
+            self._z = self._lib.zs_deflate_init(self._engine.handle, level, strategy, 15, 8, hash_variant)
+            if not self._z:
+                raise ValueError("zs_deflate_init rejected the arguments")
+        else:
+            self._z = self._lib.zs_inflate_init(self._engine.handle, 15)
+            if not self._z:
+                raise ValueError("zs_inflate_init")
         self._chunk = ctypes.create_string_buffer(self.BUFFER_SIZE)
         self._finished = False
         self._total_in = ctypes.c_int64(0)
@@ -377,16 +381,18 @@ class ZlibOutputStream(io.RawIOBase):
             avail_out = ctypes.c_int32(self.BUFFER_SIZE)
             next_in = ctypes.c_void_p(ctypes.addressof(buf) + consumed) if buf is not None else ctypes.c_void_p(0)
             before = avail_in.value
-            state = self._lib.zs_deflate(self._z, next_in, ctypes.byref(avail_in), ctypes.addressof(self._chunk),
-                                         ctypes.byref(avail_out), int(flush), ctypes.byref(self._adler),
-                                         ctypes.byref(self._total_in), ctypes.byref(self._total_out))
+            fn = self._lib.zs_deflate if self._compress else self._lib.zs_inflate
+            state = fn(self._z, next_in, ctypes.byref(avail_in), ctypes.addressof(self._chunk), ctypes.byref(avail_out), int(flush),
+                       ctypes.byref(self._adler), ctypes.byref(self._total_in), ctypes.byref(self._total_out))
             consumed += before - avail_in.value
             if state not in (CompressionState.ZOK, CompressionState.ZSTREAMEND):
-                msg = self._lib.zs_last_message(self._z)
-                raise ZlibStreamException("deflating: " + (msg.decode() if msg else ""))  # ThrowHelper.cs:21-23
+                msg = (self._lib.zs_last_message if self._compress else self._lib.zs_inflate_message)(self._z)
+                raise ZlibStreamException(("deflating: " if self._compress else "inflating: ") + (msg.decode() if msg else ""))  # ThrowHelper.cs:21-23
             got = self.BUFFER_SIZE - avail_out.value
             if got:
                 self.BaseStream.write(self._chunk.raw[:got])
+            if not self._compress and avail_in.value == 0 and avail_out.value == 0 and not until_end:
+                break  # ZlibOutputStream.cs:155-158
             if state == CompressionState.ZSTREAMEND:
                 break
             if not (avail_in.value > 0 or avail_out.value == 0):
@@ -418,6 +424,6 @@ class ZlibOutputStream(io.RawIOBase):
                     self.Finish()
             finally:
                 if getattr(self, "_z", None):
-                    self._lib.zs_deflate_end(self._z)
+                    (self._lib.zs_deflate_end if self._compress else self._lib.zs_inflate_end)(self._z)
                     self._z = None
                 super().close()
