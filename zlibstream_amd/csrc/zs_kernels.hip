@@ -1495,6 +1495,7 @@ __global__ __launch_bounds__(1024) void zs_fast_vec_kernel(const StreamDesc *sd,
     uint32_t *bm = (uint32_t *)(smem + kFvBytes + 2 * kFvLinks);
     __shared__ int64_t sh_p, sh_nsyms, sh_trigger, sh_preins;
     __shared__ int sh_k;
+    __shared__ volatile uint32_t fv_flag[64];
     const int tid = threadIdx.x, lane = lane_id();
     const int64_t n = s.n, body_end = s.fv_end;
     const gcbytes in = as_global(s.in);
@@ -1617,29 +1618,47 @@ __global__ __launch_bounds__(1024) void zs_fast_vec_kernel(const StreamDesc *sd,
                     }
                     r = FvResult{best, bdist, touched};
                 }
-                const FvLaneRes lr{r.len, r.dist, r.touched};
-                const FvWindow w = fv_resolve(lr, p0, limit, lv.lazy, trigger);
+                // ---- fv_resolve (zs_fast_vec.h) for the wave: the hops of the parse through the lanes' results.  A lane hops
+                //      to lane + match length (or + 1); lanes that end the window -- not trusted, an event loop-top, beyond
+                //      the limit -- hop nowhere.  "Reached from lane 0" by pointer doubling: six rounds of one LDS scatter
+                //      (the reached lanes mark their targets) and one gather of the doubled hop.
+                const int adv = r.len >= kMinMatch ? r.len : 1;
+                const bool stopl = lane >= limit || (lane > 0 && (r.touched || (trigger >= 0 && p0 + lane >= trigger)));
+                int nxt = stopl || lane + adv > 63 ? 64 : lane + adv;
+                bool reach = lane == 0;
+#pragma unroll
+                for (int k = 0; k < 6; k++) {
+                    fv_flag[lane] = 0;
+                    if (reach && nxt < 64) fv_flag[nxt] = 1;
+                    reach = reach || fv_flag[lane] != 0;
+                    const int n2 = __builtin_amdgcn_ds_bpermute((nxt & 63) << 2, nxt);
+                    nxt = nxt < 64 ? n2 : 64;
+                }
+                const uint64_t reached = __ballot(reach), stops = __ballot(stopl), tops = reached & ~stops;
+                int advance;
+                if (reached & stops) {
+                    advance = (int)__builtin_ctzll(reached & stops);  // the parse arrived at a lane that ends the window
+                } else {
+                    const int t = 63 - (int)__builtin_clzll(tops);    // it left the window from its last loop-top
+                    advance = t + __builtin_amdgcn_readlane(adv, t);
+                }
                 // ---- the loop-tops' symbols, compacted; block cuts every kBlockSyms symbols (Deflate.cs:910-948)
-                if ((w.tops >> lane) & 1ull) {
-                    const int64_t g = nsyms + __builtin_popcountll(w.tops & lanemask_lt());
+                if ((tops >> lane) & 1ull) {
+                    const int64_t g = nsyms + __builtin_popcountll(tops & lanemask_lt());
                     const bool match = r.len >= kMinMatch;
                     syms[s.sym_off + g] = match ? (((uint32_t)r.dist << 16) | (uint32_t)(r.len - 3)) : (uint32_t)wb[p0 + lane - lo];
                     if ((g + 1) % kBlockSyms == 0) {
                         blk_end[s.blk_off + g / kBlockSyms] = (int32_t)(p0 + lane + (match ? r.len : 1));
                         blk_top[s.blk_off + g / kBlockSyms] = (int32_t)(p0 + lane);
                     }
+                    // ---- inserted: the loop-top, and the inside of its match when that is short (Deflate.Fast.cs:81-104)
+                    const int64_t pos = p0 + lane;
+                    const uint64_t m = (match && r.len <= lv.lazy ? (1ull << r.len) - 1 : 1ull) << (pos & 31);
+                    atomicOr(&bm[(pos >> 5) - bw0], (uint32_t)m);
+                    if (m >> 32) atomicOr(&bm[(pos >> 5) - bw0 + 1], (uint32_t)(m >> 32));
                 }
-                nsyms += __builtin_popcountll(w.tops);
-                // ---- the window's inserted bits: 96 of them from bit (p0 & 31) of word p0 >> 5 on
-                if (lane < 4) {
-                    const int sh = (int)(p0 & 31);
-                    const uint32_t b[3] = {(uint32_t)w.ins_lo, (uint32_t)(w.ins_lo >> 32), w.ins_hi};
-                    // word j of the shifted 96-bit string
-                    const uint32_t cur = lane < 3 ? b[lane] : 0u, below = lane >= 1 ? b[lane - 1] : 0u;
-                    const uint32_t v = sh ? (cur << sh) | (below >> (32 - sh)) : cur;
-                    if (v) atomicOr(&bm[(p0 >> 5) - bw0 + lane], v);
-                }
-                p0 += w.advance;
+                nsyms += __builtin_popcountll(tops);
+                p0 += advance;
             }
             // ---- leave the tile: the bitmap words that changed go back to the stream's bitmap
             for (int64_t wd = (p_in >> 5) + lane; wd <= (p0 + 96) >> 5; wd += 64)
