@@ -9,7 +9,7 @@
 import csv, glob, json, os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(ROOT, "gpurun_out", "prof_round")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
 
@@ -57,7 +57,47 @@ if fetch or write:
                        "FETCH_SIZE reports half the bytes of a wide (16 B/lane) coalesced read, so hbm_bytes = 2*FETCH + WRITE is an "
                        "upper bound for kernels whose reads are not all of that shape.",
                "kernels": ks}, open(os.path.join(dst, "%s_pmc_traffic_english64_L6.json" % tag), "w"), indent=1)
-for name, out in (("bench_english64.json", "bench_english64_L6.json"), ("bench_sparse64.json", "bench_sparse64_L6.json"),
+def counter_any(dirname, cname, pat):
+    per = {}
+    for fn in glob.glob(os.path.join(src, dirname, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(fn)):
+            if r["Counter_Name"] != cname or pat not in r["Kernel_Name"]:
+                continue
+            per.setdefault(short(r["Kernel_Name"]), []).append(float(r["Counter_Value"]))
+    return {k: sum(v) / len(v) for k, v in per.items()}
+
+# inflate traffic (16 x 64 MiB streams, one batch)
+fi, wi = counter_any("pmc_fetch_inf", "FETCH_SIZE", "zs_"), counter_any("pmc_write_inf", "WRITE_SIZE", "zs_")
+if fi or wi:
+    ks = {}
+    for k in sorted(set(fi) | set(wi)):
+        f, w = fi.get(k, 0.0) * 1024, wi.get(k, 0.0) * 1024
+        ks[k] = {"fetch_bytes_raw": int(f), "write_bytes": int(w), "hbm_bytes_corrected": int(2 * f + w)}
+    json.dump({"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over tools/bench_inflate.py (16 x 64 MiB level-6 "
+                       "streams, one batch per step); mean per launch, bytes; hbm_bytes_corrected = 2*FETCH + WRITE (MI355X_MICROARCH.md: "
+                       "FETCH_SIZE counts half of a wide coalesced read on gfx950; an upper bound for narrower reads).",
+               "kernels": ks}, open(os.path.join(dst, "%s_pmc_traffic_inflate1g.json" % tag), "w"), indent=1)
+
+# instruction / LDS counters of the deflate kernels (what bounds the match kernel)
+names = ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVES", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE"]
+cyc = ["SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS"]
+tab = {}
+for d, cs in (("pmc_insts", names), ("pmc_cycles", cyc)):
+    for cn in cs:
+        for k, v in counter_any(d, cn, "zs_").items():
+            tab.setdefault(k, {})[cn] = int(v)
+if tab:
+    for k, v in tab.items():
+        if v.get("SQ_LDS_IDX_ACTIVE"):
+            v["lds_bank_conflict_frac"] = round(v.get("SQ_LDS_BANK_CONFLICT", 0) / v["SQ_LDS_IDX_ACTIVE"], 3)
+        if "SQ_INSTS_VALU" in v:
+            v["valu_issue_ms_at_1024_simds_2.4GHz"] = round(v["SQ_INSTS_VALU"] * 4 / 1024 / 2.4e9 * 1e3, 3)
+    json.dump({"note": "rocprofv3 --pmc (two passes) over `bench.py --steps 2 --warmup 1 --no-secondary` (english64, level 6); mean per "
+                       "launch.  A wave64 vector instruction holds its SIMD for 4 cycles: valu_issue_ms is the time the kernel's vector "
+                       "instructions alone take on the chip's 1024 SIMDs.", "kernels": tab},
+              open(os.path.join(dst, "%s_pmc_insts_english64_L6.json" % tag), "w"), indent=1)
+
+for name, out in (("bench_default.json", "bench_default.json"), ("bench_english64.json", "bench_english64_L6.json"), ("bench_sparse64.json", "bench_sparse64_L6.json"),
                   ("bench_batch128.json", "bench_batch128x1MiB_L6.json"), ("bench_inflate.json", "bench_inflate1g.json"),
                   ("time_levels.jsonl", "time_levels.jsonl"), ("host_path.jsonl", "host_path.jsonl"),
                   ("bench_english64_pipelined.json", "bench_english64_L6_pipelined3.json"),

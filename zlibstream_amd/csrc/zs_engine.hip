@@ -49,7 +49,7 @@ struct zs_ctx {
     uint32_t *crc_tab = nullptr;
     DevBuf sd, st, work, geo, link, mm, maps, segmap, seg_entry, seg_symbase, seg_stale, entry, symbase, stale, syms, blk_end, blk_top, blocks, trees, info, pieces, scratch,
         stage_in, stage_out, wr, inf_desc, inf_state, par_ps, par_st, par_work, par_cbits, par_ccnt, par_surv, par_scnt, par_cands, par_tabs, par_blocks, par_cells,
-        par_windows, par_fail, run_syms, run_bits, run_scratch, run_outs, run_fail, adl_tr, adl_res, plan_blk, ins_bits;
+        par_windows, par_fail, run_syms, run_bits, run_scratch, run_outs, run_fail, adl_tr, adl_res, plan_blk, ins_bits, win_groups, win_sg, win_maps, win_entries;
     void *pinned = nullptr;
     size_t pinned_cap = 0;
 };
@@ -728,7 +728,7 @@ int zs_ctx_create(int device, zs_ctx **out) {
         hipFuncSetAttribute((const void *)zs_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kTailLds) != hipSuccess ||
         hipFuncSetAttribute((const void *)zs_fast_run_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kTailLds) != hipSuccess ||
         hipFuncSetAttribute((const void *)zs_fast_vec_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kFvLds) != hipSuccess ||
-        hipFuncSetAttribute((const void *)zs_inf_window_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kWinLds) != hipSuccess ||
+        hipFuncSetAttribute((const void *)zs_inf_window_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kWinMapLds) != hipSuccess ||
         hipFuncSetAttribute((const void *)zs_inflate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kInfLds) != hipSuccess) {
         zs_ctx_destroy(c);
         return ZS_MEM_ERROR;
@@ -743,7 +743,7 @@ void zs_ctx_destroy(zs_ctx *c) {
     DevBuf *bufs[] = {&c->sd, &c->st, &c->work, &c->geo, &c->link, &c->mm, &c->maps, &c->segmap, &c->seg_entry, &c->seg_symbase, &c->seg_stale, &c->entry, &c->symbase, &c->stale, &c->syms,
                       &c->blk_end, &c->blk_top, &c->blocks, &c->trees, &c->info, &c->pieces, &c->scratch, &c->stage_in, &c->stage_out, &c->wr, &c->inf_desc, &c->inf_state, &c->par_ps, &c->par_st, &c->par_work, &c->par_cbits, &c->par_ccnt, &c->par_surv, &c->par_scnt,
                       &c->par_cands, &c->par_tabs, &c->par_blocks, &c->par_cells, &c->par_windows, &c->par_fail, &c->run_syms, &c->run_bits,
-                      &c->run_scratch, &c->run_outs, &c->run_fail, &c->adl_tr, &c->adl_res, &c->plan_blk, &c->ins_bits};
+                      &c->run_scratch, &c->run_outs, &c->run_fail, &c->adl_tr, &c->adl_res, &c->plan_blk, &c->ins_bits, &c->win_groups, &c->win_sg, &c->win_maps, &c->win_entries};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     if (c->crc_tab) (void)hipFree(c->crc_tab);
@@ -1003,6 +1003,31 @@ bool run_inflate_par(zs_ctx *c, const std::vector<int> &idx, const void *const *
             for (int j = 0; j < m; j++) rest.push_back(idx[(size_t)j]);
             return true;
         }
+        // the window pass runs over groups of blocks (zs_inflate_par.hip, W): enough groups to give every CU one, none
+        // shorter than a few blocks
+        std::vector<WinGroup> groups;
+        std::vector<int2> sgv((size_t)m, make_int2(0, 0));
+        int n_ok = 0, n_slots = 0;
+        for (int j = 0; j < m; j++) n_ok += st[(size_t)j].ok ? 1 : 0;
+        for (int j = 0; j < m; j++) {
+            if (!st[(size_t)j].ok) continue;
+            const int nb = st[(size_t)j].nblk;
+            int G = (256 + n_ok - 1) / n_ok;
+            if (G > 16) G = 16;
+            if (G > nb / 4) G = nb / 4;
+            if (G < 1) G = 1;
+            sgv[(size_t)j] = make_int2((int)groups.size(), G);
+            for (int k = 0; k < G; k++) {
+                const int first = (int)((int64_t)nb * k / G), last = (int)((int64_t)nb * (k + 1) / G);
+                groups.push_back(WinGroup{j, first, last - first, k == 0 ? 0 : 1, k == 0 ? 0 : n_slots, 0});
+                if (k) n_slots++;
+            }
+        }
+        if (!ensure(c, c->win_groups, sizeof(WinGroup) * groups.size() + 64) || !ensure(c, c->win_sg, sizeof(int2) * (size_t)m + 64) ||
+            !ensure(c, c->win_maps, 2 * (size_t)kWSize * (size_t)n_slots + 64) || !ensure(c, c->win_entries, (size_t)kWSize * (size_t)n_slots + 64))
+            return false;
+        ZS_HIP(c, hipMemcpyAsync(c->win_groups.p, groups.data(), sizeof(WinGroup) * groups.size(), hipMemcpyHostToDevice, stream));
+        ZS_HIP(c, hipMemcpyAsync(c->win_sg.p, sgv.data(), sizeof(int2) * (size_t)m, hipMemcpyHostToDevice, stream));
         ZS_HIP(c, hipMemcpyAsync(d_st, st.data(), sizeof(ParState) * (size_t)m, hipMemcpyHostToDevice, stream));
         ZS_HIP(c, hipMemcpyAsync(c->par_work.p, w.data(), sizeof(uint2) * w.size(), hipMemcpyHostToDevice, stream));
         ZS_HIP(c, hipStreamSynchronize(stream));
@@ -1016,8 +1041,18 @@ bool run_inflate_par(zs_ctx *c, const std::vector<int> &idx, const void *const *
             hipLaunchKernelGGL(zs_inf_cellflat_kernel, dim3((unsigned)w.size()), dim3(256), 0, stream, d_ps, d_st, dev<uint2>(c->par_work),
                                dev<ParBlock>(c->par_blocks), dev<LaneTabs>(c->par_tabs), dev<uint16_t>(c->par_cells));
         mark(4);
-        hipLaunchKernelGGL(zs_inf_window_kernel, dim3((unsigned)m), dim3(1024), kWinLds, stream, d_ps, d_st, dev<ParBlock>(c->par_blocks),
-                           dev<uint16_t>(c->par_cells), dev<uint8_t>(c->par_windows));
+        if (!groups.empty()) {
+            hipLaunchKernelGGL(zs_inf_window_kernel, dim3((unsigned)groups.size()), dim3(1024), kWinMapLds, stream, d_ps, d_st, dev<WinGroup>(c->win_groups),
+                               dev<ParBlock>(c->par_blocks), dev<uint16_t>(c->par_cells), dev<uint8_t>(c->par_windows), dev<uint16_t>(c->win_maps),
+                               dev<uint8_t>(c->win_entries), 0);
+            if (n_slots) {
+                hipLaunchKernelGGL(zs_inf_winchain_kernel, dim3((unsigned)m), dim3(1024), 0, stream, d_st, dev<WinGroup>(c->win_groups), dev<int2>(c->win_sg),
+                                   dev<uint8_t>(c->par_windows), dev<uint16_t>(c->win_maps), dev<uint8_t>(c->win_entries));
+                hipLaunchKernelGGL(zs_inf_window_kernel, dim3((unsigned)groups.size()), dim3(1024), kWinMapLds, stream, d_ps, d_st,
+                                   dev<WinGroup>(c->win_groups), dev<ParBlock>(c->par_blocks), dev<uint16_t>(c->par_cells), dev<uint8_t>(c->par_windows),
+                                   dev<uint16_t>(c->win_maps), dev<uint8_t>(c->win_entries), 1);
+            }
+        }
         mark(5);
         hipLaunchKernelGGL(zs_inf_resolve_kernel, dim3((unsigned)w.size()), dim3(256), 0, stream, d_ps, d_st, dev<uint2>(c->par_work),
                            dev<ParBlock>(c->par_blocks), dev<uint16_t>(c->par_cells), dev<uint8_t>(c->par_windows));

@@ -1152,26 +1152,47 @@ __global__ __launch_bounds__(256) void zs_inf_cellflat_kernel(const ParStream *p
 }
 
 // ------------------------------------------------------------------ W
-// One workgroup per stream, block by block: win[k] = the 32 KiB of resolved output that end with block k.  Copies of
-// markers are markers, so on text a byte's chain of sources runs back through block after block: the windows are the
-// one place where that chain is cut, and the pass is serial per stream -- a step has to be short.  It is bound by
-// instruction issue (16 waves on one CU), so the LDS image of a window is laid out such that a cell *is* its own gather
-// address: a 256-byte identity table at offset 0 (a literal cell b reads b), the window at offset 0x8000 (a marker
-// 0x8000 | i reads window byte i); two such 64 KiB images, the previous window and the one being built.  A thread owns
-// runs of 4 consecutive window bytes: cells requested a block ahead (two aligned 8-byte loads and a funnel shift), four
-// byte gathers, one LDS dword and one HBM dword written.
+// win[k] = the 32 KiB of resolved output that end with block k.  Copies of markers are markers, so on text a byte's chain
+// of sources runs back through block after block: the windows are the one place where that chain is cut, and the pass is
+// serial along a stream -- a step has to be short.  It is bound by instruction issue (16 waves on one CU), so the LDS
+// image of a window is laid out such that a cell *is* its own gather address: a 256-byte identity table at offset 0 (a
+// literal cell b reads b), the window at offset 0x8000 (a marker 0x8000 | i reads window byte i); two such 64 KiB images,
+// the previous window and the one being built.  A thread owns runs of 4 consecutive window bytes: cells requested a block
+// ahead (two aligned 8-byte loads and a funnel shift), four byte gathers, one LDS dword and one HBM dword written.
+//
+// The serial pass is a composition of maps ("byte i of this window is a literal, or byte j of the window before"), and
+// maps compose associatively.  So a stream's blocks are cut into groups and the pass runs in three launches:
+//   A  zs_inf_window_kernel over (stream, group): group 0 as above, from the zero window before the stream; every other
+//      group in *map mode*: the same steps over 16-bit entries, starting from the identity map, which leaves the group's
+//      map M_g: byte i of the window after the group's last block = a literal, or byte j of the window before the group;
+//   B  zs_inf_winchain_kernel, one workgroup per stream: the window before group g = M_(g-1) applied to the window before
+//      group g - 1 (32 Ki gathers per group);
+//   C  zs_inf_window_kernel again over the groups >= 1, now in byte mode from their real entry windows.
+// Twice the work, 1 / groups of the length of the chain: a lone 64 MiB stream no longer waits 4.3 ms for one workgroup.
 constexpr int kWinImage = 0x10000;
 constexpr int kWinLds = 2 * kWinImage;
-__global__ __launch_bounds__(1024) void zs_inf_window_kernel(const ParStream *ps, const ParState *st, const ParBlock *blocks,
-                                                             const uint16_t *cells, uint8_t *windows) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t wl[];  // [2][kWinImage]
-    const ParStream s = ps[blockIdx.x];
-    const ParState ss = st[blockIdx.x];
-    if (!ss.ok) return;
+constexpr int kWinMapImage = 2 * (256 + kWSize);   // map mode: 16-bit entries, identity part + window part
+static_assert(2 * kWinMapImage <= 160 * 1024 - 1024, "two map images fit the LDS");
+constexpr int kWinMapLds = 2 * kWinMapImage;
+struct WinGroup {
+    int32_t stream, first, count;  // blocks [first, first + count) of the stream
+    int32_t mode;                  // 0: bytes from the zero window; 1: map from the identity; 2: bytes from entries[slot]
+    int32_t slot, pad_;            // index of the group's map / entry window
+};
+template <bool MAP>
+__device__ __forceinline__ void inf_window_pass(uint8_t *wl, const ParStream &s, const ParState &ss, const WinGroup &g, const ParBlock *blocks,
+                                                const uint16_t *cells, uint8_t *windows, const uint8_t *entry, uint16_t *map_out) {
     const uint16_t *cl = cells + s.cell_off;
     uint8_t *win = windows + (int64_t)ss.win_off * kWSize;
-    for (int i = threadIdx.x; i < kWSize; i += 1024) wl[0x8000 + i] = 0;  // before the stream: zeros
-    if (threadIdx.x < 256) wl[threadIdx.x] = (uint8_t)threadIdx.x, wl[kWinImage + threadIdx.x] = (uint8_t)threadIdx.x;
+    uint16_t *wl16 = (uint16_t *)wl;
+    if (MAP) {
+        // entry i of the window part = "byte i of the window before the group"; literal cells read themselves
+        for (int i = threadIdx.x; i < kWSize; i += 1024) wl16[256 + i] = (uint16_t)(0x8000u | i);
+        if (threadIdx.x < 256) wl16[threadIdx.x] = (uint16_t)threadIdx.x, wl16[kWinMapImage / 2 + threadIdx.x] = (uint16_t)threadIdx.x;
+    } else {
+        for (int i = threadIdx.x; i < kWSize / 4; i += 1024) ((uint32_t *)(wl + 0x8000))[i] = entry ? ((const uint32_t *)entry)[i] : 0u;
+        if (threadIdx.x < 256) wl[threadIdx.x] = (uint8_t)threadIdx.x, wl[kWinImage + threadIdx.x] = (uint8_t)threadIdx.x;
+    }
     __syncthreads();
     constexpr int kRuns = kWSize / 4096;  // runs of 4 window bytes per thread
     int cur = 1;
@@ -1212,30 +1233,97 @@ __global__ __launch_bounds__(1024) void zs_inf_window_kernel(const ParStream *ps
             }
         }
     };
-    if (ss.nblk > 0) {
-        bn = blocks[s.blk_off];
+    if (g.count > 0) {
+        bn = blocks[s.blk_off + g.first];
         request(bn);
     }
-    for (int k = 0; k < ss.nblk; k++) {
+    for (int k = 0; k < g.count; k++) {
         bk = bn;
         finish(bk);
-        if (k + 1 < ss.nblk) {
-            bn = blocks[s.blk_off + k + 1];
+        if (k + 1 < g.count) {
+            bn = blocks[s.blk_off + g.first + k + 1];
             request(bn);
         }
-        const uint8_t *pw = wl + (cur ^ 1) * kWinImage;
-        uint8_t *cw = wl + cur * kWinImage + 0x8000;
-        uint32_t *dst = (uint32_t *)(win + (int64_t)k * kWSize);
+        if (MAP) {
+            const uint16_t *pw = wl16 + (cur ^ 1) * (kWinMapImage / 2);
+            uint16_t *cw = wl16 + cur * (kWinMapImage / 2) + 256;
+            auto look = [pw](uint32_t cell) -> uint32_t { return pw[(cell & 0x8000u) ? 256u + (cell & 0x7FFFu) : cell]; };
 #pragma unroll
-        for (int j = 0; j < kRuns; j++) {
-            const int i = (threadIdx.x + j * 1024) * 4;
-            const uint32_t b0 = pw[c[j].x & 0xFFFFu], b1 = pw[c[j].x >> 16], b2 = pw[c[j].y & 0xFFFFu], b3 = pw[c[j].y >> 16];
-            const uint32_t word = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
-            *(uint32_t *)(cw + i) = word;
-            dst[i >> 2] = word;
+            for (int j = 0; j < kRuns; j++) {
+                const int i = (threadIdx.x + j * 1024) * 4;
+                const uint32_t b0 = look(c[j].x & 0xFFFFu), b1 = look(c[j].x >> 16), b2 = look(c[j].y & 0xFFFFu), b3 = look(c[j].y >> 16);
+                *(uint2 *)(cw + i) = make_uint2(b0 | (b1 << 16), b2 | (b3 << 16));
+            }
+        } else {
+            const uint8_t *pw = wl + (cur ^ 1) * kWinImage;
+            uint8_t *cw = wl + cur * kWinImage + 0x8000;
+            uint32_t *dst = (uint32_t *)(win + (int64_t)(g.first + k) * kWSize);
+#pragma unroll
+            for (int j = 0; j < kRuns; j++) {
+                const int i = (threadIdx.x + j * 1024) * 4;
+                const uint32_t b0 = pw[c[j].x & 0xFFFFu], b1 = pw[c[j].x >> 16], b2 = pw[c[j].y & 0xFFFFu], b3 = pw[c[j].y >> 16];
+                const uint32_t word = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
+                *(uint32_t *)(cw + i) = word;
+                dst[i >> 2] = word;
+            }
         }
         __syncthreads();
         cur ^= 1;
+    }
+    if (MAP) {
+        // the group's map: what the last step left (the identity when the group is empty)
+        const uint16_t *fin = wl16 + (cur ^ 1) * (kWinMapImage / 2) + 256;
+        for (int i = threadIdx.x; i < kWSize / 2; i += 1024) ((uint32_t *)map_out)[i] = ((const uint32_t *)fin)[i];
+    }
+}
+__global__ __launch_bounds__(1024) void zs_inf_window_kernel(const ParStream *ps, const ParState *st, const WinGroup *groups, const ParBlock *blocks,
+                                                             const uint16_t *cells, uint8_t *windows, uint16_t *maps, const uint8_t *entries,
+                                                             int pass) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t wl[];
+    const WinGroup g = groups[blockIdx.x];
+    const ParStream s = ps[g.stream];
+    const ParState ss = st[g.stream];
+    if (!ss.ok) return;
+    // pass 0 (launch A): group 0 in byte mode, the others in map mode; pass 1 (launch C): the others in byte mode
+    if (pass == 0) {
+        if (g.mode == 0) inf_window_pass<false>(wl, s, ss, g, blocks, cells, windows, nullptr, nullptr);
+        else inf_window_pass<true>(wl, s, ss, g, blocks, cells, windows, nullptr, maps + (int64_t)g.slot * kWSize);
+    } else if (g.mode != 0) {
+        inf_window_pass<false>(wl, s, ss, g, blocks, cells, windows, entries + (int64_t)g.slot * kWSize, nullptr);
+    }
+}
+// Launch B: the window before each group >= 1 of a stream, one workgroup per stream.  `sg` lists, per stream, the index
+// of its first WinGroup and the number of its groups.
+__global__ __launch_bounds__(1024) void zs_inf_winchain_kernel(const ParState *st, const WinGroup *groups, const int2 *sg, const uint8_t *windows,
+                                                               const uint16_t *maps, uint8_t *entries) {
+    __shared__ uint8_t cur[2][kWSize];
+    const int2 q = sg[blockIdx.x];
+    if (q.y < 2) return;
+    const WinGroup g0 = groups[q.x];
+    const ParState ss = st[g0.stream];
+    if (!ss.ok) return;
+    // the window after group 0 = the window of its last block (written by launch A); zero when group 0 has no block
+    const uint8_t *w0 = windows + ((int64_t)ss.win_off + g0.first + g0.count - 1) * kWSize;
+    for (int i = threadIdx.x; i < kWSize / 4; i += 1024) ((uint32_t *)cur[0])[i] = g0.count > 0 ? ((const uint32_t *)w0)[i] : 0u;
+    __syncthreads();
+    int b = 0;
+    for (int k = 1; k < q.y; k++) {
+        const WinGroup g = groups[q.x + k];
+        uint8_t *e = entries + (int64_t)g.slot * kWSize;
+        const uint16_t *m = maps + (int64_t)g.slot * kWSize;
+        for (int i = threadIdx.x; i < kWSize / 4; i += 1024) ((uint32_t *)e)[i] = ((const uint32_t *)cur[b])[i];
+        if (k + 1 < q.y) {
+            for (int i = threadIdx.x * 4; i < kWSize; i += 4096) {
+                const uint2 mv = *(const uint2 *)(m + i);
+                const uint32_t v[4] = {mv.x & 0xFFFFu, mv.x >> 16, mv.y & 0xFFFFu, mv.y >> 16};
+                uint32_t word = 0;
+#pragma unroll
+                for (int u = 0; u < 4; u++) word |= (uint32_t)((v[u] & 0x8000u) ? cur[b][v[u] & 0x7FFFu] : (uint8_t)v[u]) << (8 * u);
+                *(uint32_t *)(cur[b ^ 1] + i) = word;
+            }
+        }
+        __syncthreads();
+        b ^= 1;
     }
 }
 
