@@ -120,6 +120,17 @@ ZS_API int zs_deflate_batch_multi(zs_ctx *const *ctxs, int n_ctx, int n, const v
 ZS_API int zs_inflate_batch_multi(zs_ctx *const *ctxs, int n_ctx, int n, const void *const *in, const int64_t *in_len,
                                   void *const *out, const int64_t *out_cap, int64_t *out_len, int *status);
 
+/* ------------------------------------------------------------------ */
+/* PNG scanline filtering on the device (the caller path of the sparse case -- the reference exists
+ * for ImageSharp's PNG encoder, readme.md:16-19, which filters every scanline and writes the rows to ZlibOutputStream).
+ * pixels: height rows of row_bytes bytes (device pointer); bpp: bytes per complete pixel, 1..8 (PNG specification 9.2);
+ * filter: 0 None, 1 Sub, 2 Up, 3 Average, 4 Paeth, 5 adaptive (per row the filter with the smallest sum of absolute
+ * values, first one on ties).  out (device pointer): height * (row_bytes + 1) bytes, every row preceded by its filter
+ * type -- the IDAT payload before compression, ready for zs_deflate_batch_device.  With hip_stream == NULL the call
+ * returns when the rows are written; otherwise it is ordered on that stream. */
+ZS_API int zs_png_filter_device(zs_ctx *ctx, const void *pixels, int64_t row_bytes, int64_t height, int bpp, int filter,
+                                void *out, void *hip_stream);
+
 /* Stage timing of the last *_batch_device call, measured with hipEvents on
  * the stream the kernels ran on.  Enable before the call. */
 ZS_API void zs_ctx_set_profiling(zs_ctx *ctx, int enable);

@@ -343,3 +343,57 @@ def test_zlib_output_stream_without_a_level_inflates(engine):
         with ZlibOutputStream(io.BytesIO(), ZlibOptions(), engine=engine) as s:
             s.write(bad)
     assert str(ei.value) == "inflating: incorrect data check"
+
+
+# ---------------------------------------------------------------- PNG scanline filters feeding the deflate path
+def _png_filter_reference(img, row_bytes, height, bpp, ftype):
+    """PNG specification 9.2 in numpy: -> height * (row_bytes + 1) bytes."""
+    import numpy as np
+    a = np.frombuffer(img, dtype=np.uint8).reshape(height, row_bytes).astype(np.int32)
+    left = np.zeros_like(a)
+    left[:, bpp:] = a[:, :-bpp]
+    up = np.zeros_like(a)
+    up[1:] = a[:-1]
+    ul = np.zeros_like(a)
+    ul[1:, bpp:] = a[:-1, :-bpp]
+    p = left + up - ul
+    pa, pb, pc = abs(p - left), abs(p - up), abs(p - ul)
+    paeth = np.where((pa <= pb) & (pa <= pc), left, np.where(pb <= pc, up, ul))
+    cands = [a, a - left, a - up, a - ((left + up) >> 1), a - paeth]
+    cands = [(c & 0xFF).astype(np.uint8) for c in cands]
+    out = np.empty((height, row_bytes + 1), dtype=np.uint8)
+    for y in range(height):
+        if ftype == 5:
+            sums = [int(np.abs(c[y].view(np.int8).astype(np.int32)).sum()) for c in cands]
+            f = sums.index(min(sums))
+        else:
+            f = ftype
+        out[y, 0] = f
+        out[y, 1:] = cands[f][y]
+    return out.tobytes()
+
+
+@pytest.mark.parametrize("ftype", [0, 1, 2, 3, 4, 5])
+def test_png_filter_kernel_and_the_deflate_of_its_rows(engine, oracle, ftype):
+    """The scanline filters on the device against a numpy restatement of the PNG specification, and the filtered rows
+    through the deflate path: the oracle's bytes for the same rows (one Write), and an independent inflate gives them back."""
+    import numpy as np
+    import torch
+    from zlibstream_amd import png_filter_device
+    rng = np.random.default_rng(4)
+    w, h = 333, 97
+    grad = (np.add.outer(np.arange(h), np.arange(w * 4)) % 251).astype(np.uint8)
+    noisy = (grad + rng.integers(0, 3, grad.shape, dtype=np.uint8)).astype(np.uint8)
+    for img, row_bytes, height, bpp in ((datagen.sparse(512, 256), 2048, 256, 4), (noisy.tobytes(), w * 4, h, 4), (noisy.tobytes(), w * 4, h, 3),
+                                        (bytes(rng.integers(0, 256, 77 * 5, dtype=np.uint8)), 77, 5, 1)):
+        d_img = torch.frombuffer(bytearray(img), dtype=torch.uint8).cuda()
+        d_out = torch.zeros(height * (row_bytes + 1), dtype=torch.uint8, device="cuda")
+        png_filter_device(engine, d_img.data_ptr(), row_bytes, height, bpp, ftype, d_out.data_ptr())
+        got = d_out.cpu().numpy().tobytes()
+        assert got == _png_filter_reference(img, row_bytes, height, bpp, ftype), (ftype, row_bytes, height, bpp)
+        cap = deflate_bound(len(got))
+        d_z = torch.empty(cap, dtype=torch.uint8, device="cuda")
+        n = engine.deflate_batch_device([d_out.data_ptr()], [len(got)], [d_z.data_ptr()], [cap], level=6)[0]
+        z = d_z[:n].cpu().numpy().tobytes()
+        assert z == oracle.compress(got, 6)
+        assert zlib.decompress(z) == got

@@ -7,4 +7,4 @@ has no CPU fallback: it needs libzsgpu.so and an MI355X.
 """
 from .api import (CompressionLevel, CompressionState, CompressionStrategy, Engine, FlushMode, ZlibInputStream, ZlibOptions,  # noqa: F401
                   ZlibOutputStream, ZlibStreamException, compress, deflate_batch_multi, deflate_bound, device_count,
-                  inflate_batch_multi)
+                  inflate_batch_multi, png_filter_device)

@@ -226,6 +226,14 @@ def device_count():
     return int(_native.lib().zs_device_count())
 
 
+def png_filter_device(engine, pixels_ptr, row_bytes, height, bpp, filter_type, out_ptr, stream=None):
+    """PNG scanline filtering of a device-resident image into a device buffer of height * (row_bytes + 1) bytes."""
+    rc = _native.lib().zs_png_filter_device(engine.handle, ctypes.c_void_p(pixels_ptr), int(row_bytes), int(height), int(bpp),
+                                            int(filter_type), ctypes.c_void_p(out_ptr), ctypes.c_void_p(stream or 0))
+    if rc != 0:
+        raise ValueError("zs_png_filter_device rejected the arguments (%d)" % rc)
+
+
 _default_engine = None
 
 

@@ -1174,6 +1174,19 @@ int zs_inflate_batch(zs_ctx *c, int n, const void *const *in, const int64_t *in_
 
 }  // extern "C"
 
+// ------------------------------------------------------------------ PNG scanline filtering (the caller path of the sparse case)
+extern "C" int zs_png_filter_device(zs_ctx *c, const void *pixels, int64_t row_bytes, int64_t height, int bpp, int filter, void *out,
+                                    void *hip_stream) {
+    if (!c || !pixels || !out || row_bytes <= 0 || height <= 0 || bpp < 1 || bpp > 8 || filter < 0 || filter > 5 || height > 0x7FFFFFFF)
+        return ZS_STREAM_ERROR;
+    if (hipSetDevice(c->device) != hipSuccess) return ZS_STREAM_ERROR;
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    hipLaunchKernelGGL(zs_png_filter_kernel, dim3((unsigned)height), dim3(256), 0, s, (const uint8_t *)pixels, row_bytes, height, bpp, filter,
+                       (uint8_t *)out);
+    if (hipGetLastError() != hipSuccess) return ZS_STREAM_ERROR;
+    return hip_stream ? ZS_OK : (hipStreamSynchronize(s) == hipSuccess ? ZS_OK : ZS_STREAM_ERROR);
+}
+
 // ------------------------------------------------------------------ multi-GPU batch entry points
 // BASELINE north_star: "independent input buffers shard embarrassingly across the 8 GPUs of one node (no RCCL needed)".
 // The unit of sharding is the buffer (a zlib stream cannot be split bit-exactly: 32 KiB history, sequential parse,

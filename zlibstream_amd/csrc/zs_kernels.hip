@@ -2375,4 +2375,65 @@ __global__ __launch_bounds__(256) void zs_adler_finish_kernel(const StreamDesc *
     res[blockIdx.x] = make_uint2(ad_v[0], ok);
 }
 
+// ------------------------------------------------------------------ KP: PNG scanline filters (the caller path of the sparse case)
+// the reference exists because of PNG encoding (readme.md:16-19) -- ImageSharp filters every
+// scanline (PNG specification 9.2: None, Sub, Up, Average, Paeth, or per row the one with the smallest sum of absolute
+// values) and hands the rows to ZlibOutputStream.  One workgroup per row: the five candidate rows are never stored, each
+// thread adds up |filtered byte| for its bytes under all five filters, the row's filter is the minimum (first one on
+// ties, in the order None, Sub, Up, Average, Paeth), then the row is written: filter-type byte + filtered bytes.
+__device__ __forceinline__ int png_paeth(int a, int b, int c) {
+    const int p = a + b - c, pa = abs(p - a), pb = abs(p - b), pc = abs(p - c);
+    return (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+}
+__device__ __forceinline__ uint8_t png_apply(int f, int x, int a, int b, int c) {
+    switch (f) {
+    case 1: return (uint8_t)(x - a);
+    case 2: return (uint8_t)(x - b);
+    case 3: return (uint8_t)(x - ((a + b) >> 1));
+    case 4: return (uint8_t)(x - png_paeth(a, b, c));
+    default: return (uint8_t)x;
+    }
+}
+__global__ __launch_bounds__(256) void zs_png_filter_kernel(const uint8_t *pix, int64_t row_bytes, int64_t height, int bpp, int filter,
+                                                            uint8_t *out) {
+    __shared__ uint32_t sums[5][256];
+    __shared__ int chosen;
+    const int64_t y = blockIdx.x;
+    const gcbytes cur = as_global(pix) + y * row_bytes, up = y ? cur - row_bytes : cur;
+    const bool has_up = y > 0;
+    int f = filter;
+    if (filter == 5) {
+        uint32_t acc[5] = {0, 0, 0, 0, 0};
+        for (int64_t i = threadIdx.x; i < row_bytes; i += 256) {
+            const int x = cur[i], a = i >= bpp ? cur[i - bpp] : 0, b = has_up ? up[i] : 0, c = (has_up && i >= bpp) ? up[i - bpp] : 0;
+#pragma unroll
+            for (int k = 0; k < 5; k++) {
+                const int v = (int8_t)png_apply(k, x, a, b, c);  // the sum is over the bytes read as signed values
+                acc[k] += (uint32_t)(v < 0 ? -v : v);
+            }
+        }
+        for (int k = 0; k < 5; k++) sums[k][threadIdx.x] = acc[k];
+        __syncthreads();
+        for (int off = 128; off > 0; off >>= 1) {
+            if (threadIdx.x < off)
+                for (int k = 0; k < 5; k++) sums[k][threadIdx.x] += sums[k][threadIdx.x + off];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            int best = 0;
+            for (int k = 1; k < 5; k++)
+                if (sums[k][0] < sums[best][0]) best = k;
+            chosen = best;
+        }
+        __syncthreads();
+        f = chosen;
+    }
+    uint8_t *o = out + y * (row_bytes + 1);
+    if (threadIdx.x == 0) o[0] = (uint8_t)f;
+    for (int64_t i = threadIdx.x; i < row_bytes; i += 256) {
+        const int x = cur[i], a = i >= bpp ? cur[i - bpp] : 0, b = has_up ? up[i] : 0, c = (has_up && i >= bpp) ? up[i - bpp] : 0;
+        o[1 + i] = png_apply(f, x, a, b, c);
+    }
+}
+
 }  // namespace zs
