@@ -148,18 +148,22 @@ ZS_API double zs_ctx_stage_ms(const zs_ctx *ctx, int stage);
  * zs_deflate       <- Deflate.Compress (Deflate.cs:436-636).  The cursor fields
  *   of ZLibStream (ZlibStream.cs:34-94) are passed explicitly: *avail_in /
  *   *avail_out are decremented, *total_in / *total_out advanced, *adler
- *   updated.  Input is copied during the call.  The engine buffers input and
- *   records the Write boundary and its flush mode; compression runs on the GPU
- *   when ZS_FINISH arrives, after which output is handed out avail_out bytes
- *   at a time exactly like Flush_pending (Deflate.cs:828-854).
- *   ZS_PARTIAL_FLUSH / ZS_SYNC_FLUSH / ZS_FULL_FLUSH (Deflate.cs:583-613): the
- *   final bytes are the reference's for a caller that runs
+ *   updated.  Input is copied during the call.  NoFlush Writes are buffered
+ *   and a stream that never flushes is compressed by the bulk pipeline when
+ *   ZS_FINISH arrives, after which output is handed out avail_out bytes at a
+ *   time exactly like Flush_pending (Deflate.cs:828-854).
+ *   ZS_PARTIAL_FLUSH / ZS_SYNC_FLUSH / ZS_FULL_FLUSH (Deflate.cs:583-613) run the
+ *   engine at that call and deliver everything up to and including the flush
+ *   marker, so the reader can decode what has been written so far; from then on
+ *   the stream is incremental (the engine is kept suspended in device memory,
+ *   consumed input is dropped).  A NoFlush stream with more than 1 GiB buffered
+ *   becomes incremental too: a stream has no length limit (a single call takes
+ *   up to 2 GiB - 1 KiB).  The bytes are the reference's for a caller that runs
  *   ZlibOutputStream.WriteCore's loop (ZlibOutputStream.cs:125-168: a fresh
- *   output chunk of the same size for every call -- the size is taken from
- *   the first call), i.e. block end + Tr_align / empty stored block after every
+ *   output chunk of the same size for every call -- the size is taken from the
+ *   first call): block end + Tr_align / empty stored block after every flushed
  *   Write, FullFlush forgetting the hash heads, and the extra empty blocks of
- *   flushes that fill the chunk exactly; they are delivered at ZS_FINISH, not
- *   at the flush call.
+ *   flushes that fill the chunk exactly.
  * zs_deflate_end   <- Deflate.Dispose.
  * zs_last_message  <- ZLibStream.Message. */
 typedef struct zs_deflate_stream zs_deflate_stream;
@@ -177,7 +181,11 @@ ZS_API const char *zs_last_message(const zs_deflate_stream *s);
  *   zs_deflate.  The engine decodes whole streams: calls that bring input return ZS_OK after taking it; the first call
  *   with *avail_in == 0 (BaseStream is exhausted) decodes on the GPU and output is served from then on, ZS_STREAM_END
  *   with the last byte.  An incomplete stream at that point is ZS_BUF_ERROR; corrupt data gives ZS_DATA_ERROR with the
- *   reference's message (zs_inflate_message). */
+ *   reference's message (zs_inflate_message).
+ *   Malformed streams: incomplete code sets are accepted exactly where Huft_build accepts them (a single code of length
+ *   1, InfTree.cs:364); one deliberate difference -- a match distance that reaches before the first output byte is
+ *   ZS_DATA_ERROR "invalid distance code" here, the managed engine copies from its zeroed window instead
+ *   (InfCodes.cs:241,659). */
 typedef struct zs_inflate_stream zs_inflate_stream;
 ZS_API zs_inflate_stream *zs_inflate_init(zs_ctx *ctx, int window_bits);
 ZS_API int zs_inflate(zs_inflate_stream *s, const uint8_t *next_in, int32_t *avail_in, uint8_t *next_out, int32_t *avail_out,
