@@ -73,8 +73,6 @@ struct StreamDesc {
     // this stream; the stream's inserted-position bitmap (bit q of the array = position q)
     int32_t fv_end;
     uint32_t *ins_bits;
-    // the speculative parse: chunks of this stream and the index of its first one in the sp_* arrays; 0: not tried
-    int32_t nspec, spec_off;
 };
 
 // zs_fast_vec_kernel's tile: the window [t0 - kFvBack, t0 + kFvTile + kFvFwd) in LDS as bytes, links and inserted bits
@@ -122,18 +120,7 @@ struct StreamState {
     uint32_t r_total;
     int32_t r_ncut;
     int32_t r_cut_e[8], r_cut_done[8];
-    // the speculative parse (zs_spec_*_kernel): tiles the match kernel walked run-wise (periodic data: no speculation),
-    // and whether every chunk's entry state was confirmed (then K3 / K3b / K4 / K4b / K5 have nothing to do)
-    int32_t run_tiles, spec_ok;
 };
-
-// The speculative parse cuts the stream on the chunk grid's phase (chunk k starts at kSpecChunk k - 261, so every
-// second one is a chunk of the transfer-map pipeline and read events sit on chunk starts); no maps, so shorter chunks.
-constexpr int kSpecBits = 10;
-constexpr int kSpecChunk = 1 << kSpecBits;
-constexpr int kSpecWarm = 256;  // positions parsed before a chunk to find its entry state
-static_assert(kSpecChunk * 2 == kChunk, "read events sit on every second speculative chunk");
-ZS_HD int64_t spec_start(int k) { return k == 0 ? 0 : (int64_t)k * kSpecChunk - (kMinLookahead - 1); }
 
 // DeflateFast (levels 1-3) as speculative chunk runs: run j re-parses kFastWarm bytes before its chunk with an
 // "everything inserted" history, then its chunk; it is exact iff its state at the first loop-top of the chunk

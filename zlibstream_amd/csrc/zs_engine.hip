@@ -25,10 +25,10 @@ struct DevBuf {
 };
 
 enum Stage {
-    kStClear, kStAdler, kStLinks, kStMatch, kStSpec, kStChunkMap, kStSegMap, kStResolve, kStExpand, kStEmitSyms, kStTail, kStTrees,
+    kStClear, kStAdler, kStLinks, kStMatch, kStChunkMap, kStSegMap, kStResolve, kStExpand, kStEmitSyms, kStTail, kStTrees,
     kStOffsets, kStEmitBits, kStCount
 };
-const char *const kStageNames[kStCount] = {"clear", "adler", "links", "match", "spec", "chunkmap", "segmap", "resolve", "expand",
+const char *const kStageNames[kStCount] = {"clear", "adler", "links", "match", "chunkmap", "segmap", "resolve", "expand",
                                            "emit_syms", "tail", "trees", "offsets", "emit_bits"};
 
 }  // namespace
@@ -49,7 +49,7 @@ struct zs_ctx {
     uint32_t *crc_tab = nullptr;
     DevBuf sd, st, work, geo, link, mm, maps, segmap, seg_entry, seg_symbase, seg_stale, entry, symbase, stale, syms, blk_end, blk_top, blocks, trees, info, pieces, scratch,
         stage_in, stage_out, wr, inf_desc, inf_state, par_ps, par_st, par_work, par_cbits, par_ccnt, par_surv, par_scnt, par_cands, par_tabs, par_blocks, par_cells,
-        par_windows, par_fail, run_syms, run_bits, run_scratch, run_outs, run_fail, adl_tr, adl_res, plan_blk, ins_bits, win_groups, win_sg, win_maps, win_entries, sp_entry, sp_exit, sp_count, sp_syms, sp_tops;
+        par_windows, par_fail, run_syms, run_bits, run_scratch, run_outs, run_fail, adl_tr, adl_res, plan_blk, ins_bits, win_groups, win_sg, win_maps, win_entries;
     void *pinned = nullptr;
     size_t pinned_cap = 0;
 };
@@ -88,8 +88,7 @@ bool ensure_pinned(zs_ctx *c, size_t bytes) {
 
 struct Plan {
     std::vector<StreamDesc> sd;
-    std::vector<uint2> w_clear, w_adler, w_links, w_match, w_chunks, w_segs, w_blocks, w_runs, w_spec;
-    int64_t n_spec = 0;
+    std::vector<uint2> w_clear, w_adler, w_links, w_match, w_chunks, w_segs, w_blocks, w_runs;
     int64_t n_pos = 0, n_syms = 0;
     int64_t n_chunks = 0, n_segs = 0, n_blocks = 0, n_pieces = 0, n_runs = 0;
     bool any_fv = false;
@@ -243,18 +242,11 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
             for (int k = 0; k < s.nchunks; k++) pl.w_chunks.push_back(make_uint2((unsigned)i, (unsigned)k));
             for (int k = 0; k < s.nsegs; k++) pl.w_segs.push_back(make_uint2((unsigned)i, (unsigned)k));
         }
-        // the speculative parse (zs_spec_*_kernel) is tried on every stream of the bulk pipeline
-        s.nspec = 0, s.spec_off = (int32_t)pl.n_spec;
-        if (s.body_end >= 0 && !getenv("ZS_NO_SPEC")) {
-            s.nspec = (int32_t)((((int64_t)s.body_end + kMinLookahead - 1) >> kSpecBits) + 1);
-            for (int k = 0; k < s.nspec; k++) pl.w_spec.push_back(make_uint2((unsigned)i, (unsigned)k));
-            pl.n_spec += s.nspec;
-        }
         for (int k = 0; k < s.max_blocks; k++) pl.w_blocks.push_back(make_uint2((unsigned)i, (unsigned)k));
     }
     // ---- workspace ----
     size_t n_work = pl.w_clear.size() + pl.w_adler.size() + pl.w_links.size() + pl.w_match.size() + pl.w_chunks.size() +
-                    pl.w_segs.size() + pl.w_blocks.size() + pl.w_runs.size() + pl.w_spec.size();
+                    pl.w_segs.size() + pl.w_blocks.size() + pl.w_runs.size();
     if (!ensure(c, c->sd, sizeof(StreamDesc) * (size_t)n) || !ensure(c, c->st, sizeof(StreamState) * (size_t)n) ||
         !ensure(c, c->work, sizeof(uint2) * (n_work + 1)) || !ensure(c, c->link, 2 * (size_t)pl.n_pos + 64) ||
         !ensure(c, c->mm, 8 * (size_t)pl.n_pos + 64) ||
@@ -276,11 +268,6 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
         s.seg_c0 = g + s.seg_off, s.seg_after = g + pl.n_segs + s.seg_off, s.seg_base = g + 2 * pl.n_segs + s.seg_off;
         s.head = (const uint8_t *)c->geo.p + 12 * (size_t)pl.n_segs + (size_t)s.chunk_off;
     }
-    if (pl.n_spec &&
-        (!ensure(c, c->sp_entry, 4 * (size_t)pl.n_spec + 64) || !ensure(c, c->sp_exit, 4 * (size_t)pl.n_spec + 64) ||
-         !ensure(c, c->sp_count, 4 * (size_t)pl.n_spec + 64) || !ensure(c, c->sp_syms, 4 * (size_t)pl.n_pos + 64) ||
-         !ensure(c, c->sp_tops, 2 * (size_t)pl.n_pos + 64)))
-        return false;
     if (pl.any_fv) {
         // one bit per position (pos_off is a multiple of 64: every stream's bitmap starts on a word)
         if (!ensure(c, c->ins_bits, (size_t)pl.n_pos / 8 + 1024)) return false;
@@ -323,7 +310,7 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
     uint8_t *hp = (uint8_t *)c->pinned;
     memcpy(hp, pl.sd.data(), sizeof(StreamDesc) * (size_t)n);
     uint2 *hw = (uint2 *)(hp + sizeof(StreamDesc) * (size_t)n);
-    size_t o_clear = 0, o_adler, o_links, o_match, o_chunks, o_segs, o_blocks, o_runs, o_spec;
+    size_t o_clear = 0, o_adler, o_links, o_match, o_chunks, o_segs, o_blocks, o_runs;
     auto put = [&](const std::vector<uint2> &v, size_t &off, size_t at) {
         off = at;
         if (!v.empty()) memcpy(hw + at, v.data(), sizeof(uint2) * v.size());
@@ -337,7 +324,6 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
     at = put(pl.w_segs, o_segs, at);
     at = put(pl.w_blocks, o_blocks, at);
     at = put(pl.w_runs, o_runs, at);
-    at = put(pl.w_spec, o_spec, at);
     if (geo_bytes) {
         uint8_t *hg = hp + sizeof(StreamDesc) * (size_t)n + sizeof(uint2) * n_work;
         if (pl.n_segs) {
@@ -391,7 +377,7 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
     std::vector<TimedPair> pairs;
     size_t pool_used = 0;
     if (n_parts) {
-        for (int i = 2; i <= 10; i++) mark(i);  // stages 2..9 are timed launch by launch below; their marks only have to exist
+        for (int i = 2; i <= 9; i++) mark(i);  // stages 2..9 are timed launch by launch below; their marks only have to exist
         auto timed = [&](int stage, hipStream_t st_, auto &&launch) {
             if (!prof) {
                 launch();
@@ -434,16 +420,16 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
                 });
             if (tiles_end > tiles_done)
                 timed(kStMatch, stream, [&] {
-                    hipLaunchKernelGGL(zs_match_kernel, dim3((unsigned)(tiles_end - tiles_done)), dim3(1024), kMatchLds, stream, d_sd, d_st,
+                    hipLaunchKernelGGL(zs_match_kernel, dim3((unsigned)(tiles_end - tiles_done)), dim3(1024), kMatchLds, stream, d_sd,
                                        d_work + o_match + tiles_done, dev<uint16_t>(c->link), dev<uint2>(c->mm), lv, strategy);
                 });
             spans_done = spans_end > spans_done ? spans_end : spans_done, tiles_done = tiles_end > tiles_done ? tiles_end : tiles_done;
             timed(kStChunkMap, stream, [&] {
-                hipLaunchKernelGGL(zs_chunkmap_kernel, dim3((unsigned)(cb - ca)), dim3(512), 0, stream, d_sd, d_st, d_work + o_chunks + ca,
+                hipLaunchKernelGGL(zs_chunkmap_kernel, dim3((unsigned)(cb - ca)), dim3(512), 0, stream, d_sd, d_work + o_chunks + ca,
                                    dev<uint2>(c->mm), dev<uint32_t>(c->maps), c->crc_tab, lv, strategy, hash_variant);
             });
             timed(kStSegMap, stream, [&] {
-                hipLaunchKernelGGL(zs_segmap_kernel, dim3((unsigned)(sb - sa)), dim3(320), 0, stream, d_sd, d_st, d_work + o_segs + sa,
+                hipLaunchKernelGGL(zs_segmap_kernel, dim3((unsigned)(sb - sa)), dim3(320), 0, stream, d_sd, d_work + o_segs + sa,
                                    dev<uint32_t>(c->maps), dev<uint2>(c->segmap));
             });
             ZS_HIP(c, hipEventRecord(c->ev_part[k], stream));
@@ -466,13 +452,13 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
                 });
             }
             timed(kStExpand, c->aux, [&] {
-                hipLaunchKernelGGL(zs_expand_kernel, dim3((unsigned)((sb - sa + 63) / 64)), dim3(64), 0, c->aux, d_sd, d_st, d_work + o_segs + sa,
+                hipLaunchKernelGGL(zs_expand_kernel, dim3((unsigned)((sb - sa + 63) / 64)), dim3(64), 0, c->aux, d_sd, d_work + o_segs + sa,
                                    sb - sa, dev<uint2>(c->mm), dev<uint32_t>(c->maps), dev<uint16_t>(c->seg_entry),
                                    dev<uint32_t>(c->seg_symbase), dev<uint8_t>(c->stale), dev<uint16_t>(c->entry), dev<uint32_t>(c->symbase),
                                    c->crc_tab, lv, strategy, hash_variant);
             });
             timed(kStEmitSyms, c->aux, [&] {
-                hipLaunchKernelGGL(zs_emit_syms_lane_kernel, dim3((unsigned)((cb - ca + 63) / 64)), dim3(64), 0, c->aux, d_sd, d_st,
+                hipLaunchKernelGGL(zs_emit_syms_lane_kernel, dim3((unsigned)((cb - ca + 63) / 64)), dim3(64), 0, c->aux, d_sd,
                                    d_work + o_chunks + ca, cb - ca, dev<uint2>(c->mm), dev<uint16_t>(c->entry), dev<uint32_t>(c->symbase),
                                    dev<uint32_t>(c->syms), dev<int32_t>(c->blk_end), dev<int32_t>(c->blk_top), c->crc_tab, lv, strategy,
                                    hash_variant);
@@ -492,34 +478,23 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
         // Longest_match is never called (Deflate.Slow.cs:66-71): every position has no match
         ZS_HIP(c, hipMemsetAsync(c->mm.p, 0, 8 * (size_t)pl.n_pos + 64, stream));
     } else if (!pl.w_match.empty())
-        hipLaunchKernelGGL(zs_match_kernel, dim3((unsigned)pl.w_match.size()), dim3(1024), kMatchLds, stream, d_sd, d_st, d_work + o_match,
+        hipLaunchKernelGGL(zs_match_kernel, dim3((unsigned)pl.w_match.size()), dim3(1024), kMatchLds, stream, d_sd, d_work + o_match,
                            dev<uint16_t>(c->link), dev<uint2>(c->mm), lv, strategy);
     mark(4);
-    if (!pl.w_spec.empty()) {
-        hipLaunchKernelGGL(zs_spec_parse_kernel, dim3((unsigned)((pl.w_spec.size() + 63) / 64)), dim3(64), 0, stream, d_sd, d_st, d_work + o_spec,
-                           (int)pl.w_spec.size(), dev<uint2>(c->mm), dev<uint32_t>(c->sp_entry), dev<uint32_t>(c->sp_exit),
-                           dev<uint32_t>(c->sp_count), dev<uint32_t>(c->sp_syms), dev<uint16_t>(c->sp_tops), c->crc_tab, lv, strategy, hash_variant);
-        hipLaunchKernelGGL(zs_spec_verify_kernel, dim3((unsigned)n), dim3(1024), 0, stream, d_sd, d_st, dev<uint2>(c->mm), dev<uint32_t>(c->sp_entry),
-                           dev<uint32_t>(c->sp_exit), dev<uint32_t>(c->sp_count), strategy);
-        hipLaunchKernelGGL(zs_spec_compact_kernel, dim3((unsigned)pl.w_spec.size()), dim3(256), 0, stream, d_sd, d_st, d_work + o_spec,
-                           dev<uint32_t>(c->sp_count), dev<uint32_t>(c->sp_syms), dev<uint16_t>(c->sp_tops), dev<uint32_t>(c->syms),
-                           dev<int32_t>(c->blk_end), dev<int32_t>(c->blk_top));
-    }
-    mark(5);
     if (!pl.w_chunks.empty())
-        hipLaunchKernelGGL(zs_chunkmap_kernel, dim3((unsigned)pl.w_chunks.size()), dim3(512), 0, stream, d_sd, d_st, d_work + o_chunks,
+        hipLaunchKernelGGL(zs_chunkmap_kernel, dim3((unsigned)pl.w_chunks.size()), dim3(512), 0, stream, d_sd, d_work + o_chunks,
                            dev<uint2>(c->mm), dev<uint32_t>(c->maps), c->crc_tab, lv, strategy,
                            hash_variant);
-    mark(6);
+    mark(5);
     if (!pl.w_segs.empty())
-        hipLaunchKernelGGL(zs_segmap_kernel, dim3((unsigned)pl.w_segs.size()), dim3(320), 0, stream, d_sd, d_st, d_work + o_segs,
+        hipLaunchKernelGGL(zs_segmap_kernel, dim3((unsigned)pl.w_segs.size()), dim3(320), 0, stream, d_sd, d_work + o_segs,
                            dev<uint32_t>(c->maps), dev<uint2>(c->segmap));
-    mark(7);
+    mark(6);
     hipLaunchKernelGGL(zs_resolve_kernel, dim3((unsigned)n), dim3(1024), kResolveLds, stream, d_sd, d_st, dev<uint16_t>(c->link),
                        dev<uint2>(c->mm), dev<uint32_t>(c->maps), dev<uint2>(c->segmap),
                        dev<uint16_t>(c->seg_entry), dev<uint32_t>(c->seg_symbase), dev<uint8_t>(c->stale),
                        dev<uint8_t>(c->seg_stale), c->crc_tab, lv, strategy, hash_variant, 0x7FFFFFFF, 0x7FFFFFFF);
-    mark(8);
+    mark(7);
     // fork: the tail engine (sequential, one workgroup per stream) needs only what the resolve kernel left, so it runs
     // on the second stream beside the symbol kernels
     if (pl.any_fv)
@@ -535,18 +510,18 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
         ZS_HIP(c, hipEventRecord(c->ev_join, c->aux));
     }
     if (!pl.w_segs.empty())
-        hipLaunchKernelGGL(zs_expand_kernel, dim3((unsigned)((pl.w_segs.size() + 63) / 64)), dim3(64), 0, stream, d_sd, d_st,
+        hipLaunchKernelGGL(zs_expand_kernel, dim3((unsigned)((pl.w_segs.size() + 63) / 64)), dim3(64), 0, stream, d_sd,
                            d_work + o_segs, (int)pl.w_segs.size(), dev<uint2>(c->mm),
                            dev<uint32_t>(c->maps), dev<uint16_t>(c->seg_entry), dev<uint32_t>(c->seg_symbase),
                            dev<uint8_t>(c->stale), dev<uint16_t>(c->entry), dev<uint32_t>(c->symbase), c->crc_tab, lv, strategy,
                            hash_variant);
-    mark(9);
+    mark(8);
     if (!pl.w_chunks.empty())
-        hipLaunchKernelGGL(zs_emit_syms_lane_kernel, dim3((unsigned)((pl.w_chunks.size() + 63) / 64)), dim3(64), 0, stream, d_sd, d_st,
+        hipLaunchKernelGGL(zs_emit_syms_lane_kernel, dim3((unsigned)((pl.w_chunks.size() + 63) / 64)), dim3(64), 0, stream, d_sd,
                            d_work + o_chunks, (int)pl.w_chunks.size(), dev<uint2>(c->mm), dev<uint16_t>(c->entry),
                            dev<uint32_t>(c->symbase), dev<uint32_t>(c->syms), dev<int32_t>(c->blk_end), dev<int32_t>(c->blk_top),
                            c->crc_tab, lv, strategy, hash_variant);
-    mark(10);
+    mark(9);
     if (!tail_late) ZS_HIP(c, hipStreamWaitEvent(stream, c->ev_join, 0));
     hipLaunchKernelGGL(zs_body_blocks_kernel, dim3((unsigned)n), dim3(256), 0, stream, d_sd, d_st, dev<int32_t>(c->blk_end),
                        dev<int32_t>(c->blk_top), dev<BlockRec>(c->blocks));
@@ -589,19 +564,19 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
         hipLaunchKernelGGL(zs_fast_blocks_kernel, dim3((unsigned)n), dim3(64), 0, stream, d_sd, d_st, dev<FastRunOut>(c->run_outs),
                            dev<int32_t>(c->blk_end), dev<int32_t>(c->blk_top), dev<BlockRec>(c->blocks), n);
     }
-    mark(11);
+    mark(10);
     // the tree kernel is one latency chain per block: many small blocks (a batch of small streams) want more resident
     // workgroups, a long stream's 16 Ki-symbol blocks a wider histogram
     const int trees_threads = pl.w_blocks.size() > 8192 ? 128 : 256;
     hipLaunchKernelGGL(zs_trees_kernel, dim3((unsigned)pl.w_blocks.size()), dim3(trees_threads), 0, stream, d_sd, d_st, d_work + o_blocks,
                        dev<uint32_t>(c->syms), dev<BlockRec>(c->blocks), dev<TreeWork>(c->trees), dev<BlockInfo>(c->info), strategy, level, 2);
-    mark(12);
+    mark(11);
     hipLaunchKernelGGL(zs_offsets_kernel, dim3((unsigned)n), dim3(256), 0, stream, d_sd, d_st, dev<BlockRec>(c->blocks),
                        dev<BlockInfo>(c->info), dev<TreeWork>(c->trees), dev<uint32_t>(c->pieces), level, n);
-    mark(13);
+    mark(12);
     hipLaunchKernelGGL(zs_emit_bits_kernel, dim3((unsigned)pl.w_blocks.size()), dim3(256), 0, stream, d_sd, d_st, d_work + o_blocks,
                        dev<uint32_t>(c->syms), dev<BlockRec>(c->blocks), dev<TreeWork>(c->trees), dev<BlockInfo>(c->info));
-    mark(14);
+    mark(13);
     ZS_HIP(c, hipGetLastError());
     StreamState *hst = (StreamState *)c->pinned;
     ZS_HIP(c, hipMemcpyAsync(hst, d_st, sizeof(StreamState) * (size_t)n, hipMemcpyDeviceToHost, stream));
@@ -768,8 +743,7 @@ void zs_ctx_destroy(zs_ctx *c) {
     DevBuf *bufs[] = {&c->sd, &c->st, &c->work, &c->geo, &c->link, &c->mm, &c->maps, &c->segmap, &c->seg_entry, &c->seg_symbase, &c->seg_stale, &c->entry, &c->symbase, &c->stale, &c->syms,
                       &c->blk_end, &c->blk_top, &c->blocks, &c->trees, &c->info, &c->pieces, &c->scratch, &c->stage_in, &c->stage_out, &c->wr, &c->inf_desc, &c->inf_state, &c->par_ps, &c->par_st, &c->par_work, &c->par_cbits, &c->par_ccnt, &c->par_surv, &c->par_scnt,
                       &c->par_cands, &c->par_tabs, &c->par_blocks, &c->par_cells, &c->par_windows, &c->par_fail, &c->run_syms, &c->run_bits,
-                      &c->run_scratch, &c->run_outs, &c->run_fail, &c->adl_tr, &c->adl_res, &c->plan_blk, &c->ins_bits, &c->win_groups, &c->win_sg, &c->win_maps, &c->win_entries, &c->sp_entry, &c->sp_exit,
-                      &c->sp_count, &c->sp_syms, &c->sp_tops};
+                      &c->run_scratch, &c->run_outs, &c->run_fail, &c->adl_tr, &c->adl_res, &c->plan_blk, &c->ins_bits, &c->win_groups, &c->win_sg, &c->win_maps, &c->win_entries};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     if (c->crc_tab) (void)hipFree(c->crc_tab);

@@ -435,7 +435,7 @@ __device__ __forceinline__ void match_walk(const uint8_t *wb, const uint16_t *wl
 // as its walk ends (lanes of a wave have very different chain lengths).
 // Per main-loop iteration a lane does one unit of work: test a candidate and
 // compare its first 8 bytes, or compare 8 more bytes of a long match.
-__global__ __launch_bounds__(1024) void zs_match_kernel(const StreamDesc *sd, StreamState *st, const uint2 *work, const uint16_t *link,
+__global__ __launch_bounds__(1024) void zs_match_kernel(const StreamDesc *sd, const uint2 *work, const uint16_t *link,
                                                         uint2 *mm, LevelCfg lv, int strategy) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t *wb = smem;
@@ -528,10 +528,7 @@ __global__ __launch_bounds__(1024) void zs_match_kernel(const StreamDesc *sd, St
     // neighbours too: their LDS reads fall into the same words -- unless the tile is mostly the inside of long matches
     // (image rows, runs): then in runs per lane, for the sake of the hint.  Two instances of the walk, so that a text tile
     // pays nothing for the other kind.
-    if (wg_same * 4 > kMatchLdsLinks / 8) {
-        if (threadIdx.x == 0) atomicAdd(&st[w.x].run_tiles, 1);  // periodic data: parses do not re-converge there (no speculation)
-        match_walk<true>(wb, wl, om, lo, wendi, &wg_cursor, K, K4, nice, lane);
-    }
+    if (wg_same * 4 > kMatchLdsLinks / 8) match_walk<true>(wb, wl, om, lo, wendi, &wg_cursor, K, K4, nice, lane);
     else match_walk<false>(wb, wl, om, lo, wendi, &wg_cursor, K, K4, nice, lane);
 }
 
@@ -610,14 +607,13 @@ __device__ __forceinline__ void stage_chunk_matches(const StreamDesc &s, int c, 
 // positions: R, L-or-XK, XK4 -- zs_core.h node_step3) builds the 1-step table in LDS, in-place jumping passes turn it
 // into node -> (exit slot, symbols), then one lane per slot reads its entry (the refill-rule positions of
 // segment-first chunks are stepped explicitly).
-__global__ __launch_bounds__(512) void zs_chunkmap_kernel(const StreamDesc *sd, const StreamState *st, const uint2 *work, const uint2 *mm,
+__global__ __launch_bounds__(512) void zs_chunkmap_kernel(const StreamDesc *sd, const uint2 *work, const uint2 *mm,
                                                           uint32_t *maps, const uint32_t *crc_tab_g,
                                                           LevelCfg lv, int strategy, int hash_variant) {
     __shared__ uint32_t fk[kChunk + 1], fk4[kChunk + 1];
     __shared__ uint32_t tbl[kNodeExit3];
     __shared__ uint32_t tab[1024];
     uint2 w = work[blockIdx.x];
-    if (st[w.x].spec_ok) return;  // the speculative parse was confirmed: no maps needed
     const StreamDesc s = sd[w.x];
     const int c = (int)w.y;
     stage_chunk_matches(s, c, mm, strategy, fk, fk4);
@@ -680,10 +676,9 @@ __global__ __launch_bounds__(512) void zs_chunkmap_kernel(const StreamDesc *sd, 
 // ------------------------------------------------------------------ K3b
 // Compose the chunk maps of one parse segment (16 chunks; 32 for segment 0) for every
 // entry slot: 260 lanes, one dependent lookup per chunk.
-__global__ __launch_bounds__(320) void zs_segmap_kernel(const StreamDesc *sd, const StreamState *st, const uint2 *work, const uint32_t *maps,
+__global__ __launch_bounds__(320) void zs_segmap_kernel(const StreamDesc *sd, const uint2 *work, const uint32_t *maps,
                                                         uint2 *segmap) {
     uint2 w = work[blockIdx.x];
-    if (st[w.x].spec_ok) return;
     const StreamDesc s = sd[w.x];
     const int seg = (int)w.y;
     int slot = threadIdx.x;
@@ -741,7 +736,6 @@ __global__ __launch_bounds__(1024) void zs_resolve_kernel(const StreamDesc *sd, 
         if (threadIdx.x == 0) ss.tail_p = 0, ss.tail_kind = kR, ss.tail_pend = 0, ss.k_done = 0, ss.preins = -1, ss.body_syms = 0;
         return;
     }
-    if (ss.spec_ok) return;  // the speculative parse was confirmed and has left the tail state
     uint16_t *lk = link + s.pos_off;
     uint2 *a = mm + s.pos_off;
     GlobalAcc acc{as_global(s.in), a, tab, strategy, hash_variant};
@@ -977,7 +971,7 @@ __global__ __launch_bounds__(1024) void zs_resolve_kernel(const StreamDesc *sd, 
 
 // ------------------------------------------------------------------ K4b
 // One thread per parse segment: entry slot and first-symbol index of each of its chunks.
-__global__ __launch_bounds__(64) void zs_expand_kernel(const StreamDesc *sd, const StreamState *st, const uint2 *work, int nwork, const uint2 *mm,
+__global__ __launch_bounds__(64) void zs_expand_kernel(const StreamDesc *sd, const uint2 *work, int nwork, const uint2 *mm,
                                                        const uint32_t *maps, const uint16_t *seg_entry,
                                                        const uint32_t *seg_symbase, const uint8_t *stale, uint16_t *entry,
                                                        uint32_t *symbase, const uint32_t *crc_tab_g, LevelCfg lv, int strategy,
@@ -985,7 +979,6 @@ __global__ __launch_bounds__(64) void zs_expand_kernel(const StreamDesc *sd, con
     int i = blockIdx.x * 64 + threadIdx.x;
     if (i >= nwork) return;
     uint2 w = work[i];
-    if (st[w.x].spec_ok) return;
     const StreamDesc s = sd[w.x];
     const int seg = (int)w.y;
     GlobalAcc acc{as_global(s.in), mm + s.pos_off, crc_tab_g, strategy, hash_variant};
@@ -1031,14 +1024,13 @@ struct GlobalSymSink {
         }
     }
 };
-__global__ __launch_bounds__(64) void zs_emit_syms_lane_kernel(const StreamDesc *sd, const StreamState *st, const uint2 *work, int nwork, const uint2 *mm,
+__global__ __launch_bounds__(64) void zs_emit_syms_lane_kernel(const StreamDesc *sd, const uint2 *work, int nwork, const uint2 *mm,
                                                                const uint16_t *entry, const uint32_t *symbase, uint32_t *syms,
                                                                int32_t *blk_end, int32_t *blk_top, const uint32_t *crc_tab_g,
                                                                LevelCfg lv, int strategy, int hash_variant) {
     const int i = blockIdx.x * 64 + threadIdx.x;
     if (i >= nwork) return;
     const uint2 w = work[i];
-    if (st[w.x].spec_ok) return;
     const StreamDesc s = sd[w.x];
     const int c = (int)w.y;
     GlobalAcc acc{as_global(s.in), mm + s.pos_off, crc_tab_g, strategy, hash_variant};
@@ -1086,200 +1078,6 @@ __global__ __launch_bounds__(64) void zs_emit_syms_lane_kernel(const StreamDesc 
         cur = st.pos == p + 1 ? na : nb;
         lit = nlit;
         p = st.pos;
-    }
-}
-
-// ------------------------------------------------------------------ KS: the speculative parse
-// K3 / K4 exist because a chunk's entry state is not known before the chunks before it have been parsed, and speculative
-// parses do not re-converge on periodic data (SURVEY hard part 2).  On everything else they do, within a few dozen
-// bytes -- so on streams whose match tiles showed no periodic runs the parse is first tried the cheap way: one lane per
-// 1 Ki-position chunk starts kSpecWarm positions early in state R, notes the state in which it crosses its chunk start
-// (its *entry*), parses its chunk from there into a position-indexed scratch (a chunk cannot emit more symbols than it
-// has positions) and notes the state in which it leaves (its *exit*).  zs_spec_verify_kernel then asks every chunk
-// whether its entry is the exit of the chunk before: chunk 0 starts exactly, so if all agree every chunk was parsed from
-// its true state and the symbols are the reference's -- K3, K3b, K4, K4b and K5 return at once, the symbols are compacted
-// to their places (zs_spec_compact_kernel) and the tail state is the last chunk's exit.  One disagreement, or a refill at
-// two positions of one bucket (the cut of section 2), and the stream takes the exact path as if nothing had happened.
-// State of a parse at a chunk boundary b: the first loop-top p >= b and its node kind -- as (kind << 16 | p - b).
-struct SpecSink {
-    uint32_t *out;   // the chunk's scratch symbols
-    uint16_t *top;   // per symbol: loop-top that emitted it, relative to the chunk start
-    int64_t cs;
-    __device__ void operator()(int i, uint32_t sym, int64_t, int64_t looptop) const {
-        out[i] = sym;
-        top[i] = (uint16_t)(looptop - cs);
-    }
-};
-__global__ __launch_bounds__(64) void zs_spec_parse_kernel(const StreamDesc *sd, const StreamState *st, const uint2 *work, int nwork,
-                                                           const uint2 *mm, uint32_t *sp_entry, uint32_t *sp_exit, uint32_t *sp_count,
-                                                           uint32_t *sp_syms, uint16_t *sp_tops, const uint32_t *crc_tab_g, LevelCfg lv,
-                                                           int strategy, int hash_variant) {
-    const int i = blockIdx.x * 64 + threadIdx.x;
-    if (i >= nwork) return;
-    const uint2 w = work[i];
-    const StreamDesc s = sd[w.x];
-    if (st[w.x].run_tiles != 0) return;  // periodic data: not tried
-    const int k = (int)w.y;
-    GlobalAcc acc{as_global(s.in), mm + s.pos_off, crc_tab_g, strategy, hash_variant};
-    const int64_t cs = spec_start(k);
-    int64_t ce = spec_start(k + 1);
-    if (ce > (int64_t)s.body_end + 1) ce = (int64_t)s.body_end + 1;
-    const uint2 *a = acc.mm;
-    const gcbytes gin = acc.in;
-    const int64_t last = (int64_t)s.n - 1;
-    const bool rec_lits = strategy != kHuffmanOnly;
-    // ---- warm-up: from R(cs - kSpecWarm) to the first loop-top >= cs (chunk 0 starts exactly)
-    int kind = kR;
-    int64_t p = cs - kSpecWarm;
-    if (p < 0 || k == 0) p = 0;
-    uint32_t pend = kNoMatch;
-    while (p < cs) {
-        const uint2 cur = a[p];
-        uint32_t cK = acc.flt(cur.x), cK4 = acc.flt(cur.y);
-        if (p == 0) cK = cK4 = kNoMatch;
-        const Step stp = lazy_step(kind, p, pend, cK, cK4, lv);
-        pend = stp.kind == kXK ? cK : stp.kind == kXK4 ? cK4 : kNoMatch;
-        kind = stp.kind;
-        p = stp.pos;
-    }
-    const uint32_t entry = ((uint32_t)kind << 16) | (uint32_t)(p - cs);
-    uint32_t flags = 0;
-    uint32_t *so = sp_syms + s.pos_off + cs;  // the chunk's symbols: at most one per position
-    uint16_t *to = sp_tops + s.pos_off + cs;
-    SpecSink sink{so, to, cs};
-    int ns = 0;
-    // ---- a read event at the chunk's entry (every second chunk is one of the map pipeline's; its flags tell)
-    if (!(k & 1) && s.head[k >> 1] != 0 && p <= (int64_t)s.body_end) {
-        const int slot = kind == kR ? (int)(p - cs) : 256 + kind;
-        bool equal;
-        chunk_special_prefix(acc, sink, k >> 1, slot, true, s.body_end, lv, strategy, kind, p, ns, equal);
-        if (equal) flags = 1;  // the chain cut of an equal-bucket refill changes match records: the exact path's business
-        pend = kind == kXK ? acc.mK(p - 1) : kind == kXK4 ? acc.mK4(p - 1) : kNoMatch;
-    }
-    // ---- the chunk (the loop of zs_emit_syms_lane_kernel: both possible successors requested a step ahead)
-    if (p < ce) {
-        uint2 cur = a[p];
-        uint8_t lit = p >= 1 ? gin[p - 1] : 0;
-        while (p < ce) {
-            int64_t qa = p + 1, qb = pend ? p - 1 + match_len(pend) : qa;
-            if (qa > last) qa = last;
-            if (qb > last) qb = last;
-            const uint2 na = a[qa], nb = a[qb];
-            const uint8_t nlit = rec_lits ? (uint8_t)(cur.x >> 24) : gin[p];
-            uint32_t cK = acc.flt(cur.x), cK4 = acc.flt(cur.y);
-            if (p == 0) cK = cK4 = kNoMatch;
-            const Step stp = lazy_step(kind, p, pend, cK, cK4, lv);
-            if (stp.emit) {
-                so[ns] = stp.emit == 1 ? (uint32_t)lit : (((uint32_t)stp.dist << 16) | (uint32_t)(stp.len - 3));
-                to[ns] = (uint16_t)(p - cs);
-                ns++;
-            }
-            pend = stp.kind == kXK ? cK : stp.kind == kXK4 ? cK4 : kNoMatch;
-            kind = stp.kind;
-            cur = stp.pos == p + 1 ? na : nb;
-            lit = nlit;
-            p = stp.pos;
-        }
-    }
-    const int64_t kk = (int64_t)s.spec_off + k;
-    sp_entry[kk] = entry;
-    sp_exit[kk] = ((uint32_t)kind << 16) | (uint32_t)(p - ce) | (flags << 31);
-    sp_count[kk] = (uint32_t)ns;
-}
-// One workgroup per stream: are all entries confirmed?  Then: where every chunk's symbols go (exclusive scan of the
-// counts, left in sp_count), and the state the tail engine starts from (what the resolve kernel leaves otherwise).
-__global__ __launch_bounds__(1024) void zs_spec_verify_kernel(const StreamDesc *sd, StreamState *st, const uint2 *mm, const uint32_t *sp_entry,
-                                                              const uint32_t *sp_exit, uint32_t *sp_count, int strategy) {
-    __shared__ int bad;
-    __shared__ uint32_t wsum[16];
-    __shared__ uint32_t carry;
-    const StreamDesc s = sd[blockIdx.x];
-    StreamState &ss = st[blockIdx.x];
-    if (s.nspec <= 0) return;
-    if (threadIdx.x == 0) bad = ss.run_tiles != 0, carry = 0;
-    __syncthreads();
-    if (bad) return;
-    const int n = s.nspec;
-    const uint32_t *en = sp_entry + s.spec_off, *ex = sp_exit + s.spec_off;
-    uint32_t *cnt = sp_count + s.spec_off;
-    int mine = 0;
-    for (int k = threadIdx.x; k < n; k += 1024) {
-        if (ex[k] >> 31) mine = 1;
-        if (k > 0 && en[k] != (ex[k - 1] & 0x7FFFFFFFu)) mine = 1;
-        if (k == 0 && en[k] != 0) mine = 1;
-    }
-    if (mine) bad = 1;
-    __syncthreads();
-    if (bad) return;
-    // exclusive scan of the counts, 1024 at a time
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int k0 = 0; k0 < n; k0 += 1024) {
-        const int k = k0 + threadIdx.x;
-        const uint32_t v = k < n ? cnt[k] : 0;
-        uint32_t inc = v;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t x = (uint32_t)__shfl_up((int)inc, o);
-            if (lane >= o) inc += x;
-        }
-        if (lane == 63) wsum[wave] = inc;
-        __syncthreads();
-        uint32_t before = carry;
-        for (int j = 0; j < wave; j++) before += wsum[j];
-        if (k < n) cnt[k] = before + inc - v;
-        __syncthreads();
-        if (threadIdx.x == 1023) carry = before + inc;
-        __syncthreads();
-    }
-    if (threadIdx.x != 0) return;
-    // the tail state: the last chunk's exit; the last read event that fired and the position it inserted first
-    const uint32_t x = ex[n - 1] & 0x7FFFFFFFu;
-    const int kind = (int)(x >> 16);
-    const int64_t p = (int64_t)s.body_end + 1 + (int64_t)(x & 0xFFFFu);
-    const uint2 *a = mm + s.pos_off;
-    GlobalAcc acc{as_global(s.in), a, nullptr, strategy, 0};
-    ss.tail_p = (int32_t)p;
-    ss.tail_kind = kind;
-    ss.tail_pend = kind == kXK ? acc.mK(p - 1) : kind == kXK4 ? acc.mK4(p - 1) : 0;
-    int kf = 0, pre = -1;
-    for (int seg = s.nsegs - 1; seg >= 1; seg--) {
-        const int k = 2 * s.seg_c0[seg];
-        if (k >= n) continue;
-        const int64_t e = spec_start(k) + (int64_t)(en[k] & 0xFFFFu);
-        if (e <= (int64_t)s.body_end) {
-            kf = seg, pre = (int)(e + 1);
-            break;
-        }
-    }
-    ss.k_done = kf;
-    ss.preins = pre;
-    ss.body_syms = carry;
-    __threadfence();
-    ss.spec_ok = 1;
-}
-// The confirmed symbols to their places, and the block cuts (every kBlockSyms-th symbol: where it ends, which loop-top).
-__global__ __launch_bounds__(256) void zs_spec_compact_kernel(const StreamDesc *sd, const StreamState *st, const uint2 *work, const uint32_t *sp_count,
-                                                              const uint32_t *sp_syms, const uint16_t *sp_tops, uint32_t *syms, int32_t *blk_end,
-                                                              int32_t *blk_top) {
-    const uint2 w = work[blockIdx.x];
-    const StreamDesc s = sd[w.x];
-    if (!st[w.x].spec_ok) return;
-    const int k = (int)w.y;
-    const uint32_t base = sp_count[s.spec_off + k];
-    const uint32_t cnt = (k + 1 < s.nspec ? sp_count[s.spec_off + k + 1] : st[w.x].body_syms) - base;
-    const int64_t cs = spec_start(k);
-    const uint32_t *so = sp_syms + s.pos_off + cs;
-    const uint16_t *to = sp_tops + s.pos_off + cs;
-    uint32_t *dst = syms + s.sym_off + base;
-    for (uint32_t i = threadIdx.x; i < cnt; i += 256) {
-        const uint32_t v = so[i];
-        dst[i] = v;
-        const uint32_t g = base + i;
-        if ((g + 1) % kBlockSyms == 0) {
-            const int64_t top = cs + to[i];
-            blk_end[s.blk_off + g / kBlockSyms] = (int32_t)((v >> 16) ? top - 1 + (int64_t)(v & 0xFFFF) + 3 : top);
-            blk_top[s.blk_off + g / kBlockSyms] = (int32_t)top;
-        }
     }
 }
 
