@@ -307,10 +307,19 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal on a box with fewer GPUs than ranks: ZS_BENCH_BACKEND=gloo ZS_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 and
+    # carries the barrier and the report's scalars over gloo (the data path has no collective either way)
+    backend = os.environ.get("ZS_BENCH_BACKEND", "nccl")
+    if os.environ.get("ZS_BENCH_ONE_DEVICE"):
+        local_rank = 0
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    red_dev = dev if backend == "nccl" else torch.device("cpu")  # where the control plane's scalars live
     workload = args.workload or ("english64" if world == 1 else "batch")
 
     def barrier():
@@ -337,15 +346,15 @@ def main():
     total_n, total_out = n, sum(main_batch.out_lens)
     per_rank_bytes = [n]
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        g = torch.zeros(world, dtype=torch.int64, device=dev)
+        g = torch.zeros(world, dtype=torch.int64, device=red_dev)
         g[rank] = n
         dist.all_reduce(g)  # control plane only: per-rank input bytes for the report
         per_rank_bytes = [int(x) for x in g.tolist()]
         total_n = sum(per_rank_bytes)
-        o = torch.tensor([total_out], dtype=torch.int64, device=dev)
+        o = torch.tensor([total_out], dtype=torch.int64, device=red_dev)
         dist.all_reduce(o)
         total_out = int(o.item())
     main_batch.check_roundtrip(max(1, len(datas) // 8))

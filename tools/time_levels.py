@@ -45,3 +45,6 @@ def run_batch(name, bufs, level, reps=1):
 texts = [datagen.english(512 << 10, 1000 + i) for i in range(512)]
 for lvl in (1, 3):
     run_batch("english 512 x 512 KiB", texts, lvl)
+# many small streams at level 6: bound by the per-stream tail engine (one workgroup per stream) and the per-block tree chains
+small = [datagen.english(32 << 10, 5000 + i) for i in range(4096)]
+run_batch("english 4096 x 32 KiB", small, 6, reps=3)

@@ -420,7 +420,7 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
                 });
             if (tiles_end > tiles_done)
                 timed(kStMatch, stream, [&] {
-                    hipLaunchKernelGGL(zs_match_kernel, dim3((unsigned)(tiles_end - tiles_done)), dim3(1024), kMatchLds, stream, d_sd,
+                    hipLaunchKernelGGL(zs_match_kernel, dim3((unsigned)(tiles_end - tiles_done)), dim3(1024), kMatchLds + 16, stream, d_sd,
                                        d_work + o_match + tiles_done, dev<uint16_t>(c->link), dev<uint2>(c->mm), lv, strategy);
                 });
             spans_done = spans_end > spans_done ? spans_end : spans_done, tiles_done = tiles_end > tiles_done ? tiles_end : tiles_done;
@@ -478,7 +478,7 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
         // Longest_match is never called (Deflate.Slow.cs:66-71): every position has no match
         ZS_HIP(c, hipMemsetAsync(c->mm.p, 0, 8 * (size_t)pl.n_pos + 64, stream));
     } else if (!pl.w_match.empty())
-        hipLaunchKernelGGL(zs_match_kernel, dim3((unsigned)pl.w_match.size()), dim3(1024), kMatchLds, stream, d_sd, d_work + o_match,
+        hipLaunchKernelGGL(zs_match_kernel, dim3((unsigned)pl.w_match.size()), dim3(1024), kMatchLds + 16, stream, d_sd, d_work + o_match,
                            dev<uint16_t>(c->link), dev<uint2>(c->mm), lv, strategy);
     mark(4);
     if (!pl.w_chunks.empty())
@@ -722,7 +722,7 @@ int zs_ctx_create(int device, zs_ctx **out) {
         for (int i = 0; i < 256; i++) tab[(size_t)t * 256 + i] = crc32c_table_entry(t, (uint32_t)i);
     if (hipMalloc((void **)&c->crc_tab, 4096) != hipSuccess ||
         hipMemcpy(c->crc_tab, tab.data(), 4096, hipMemcpyHostToDevice) != hipSuccess ||
-        hipFuncSetAttribute((const void *)zs_match_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kMatchLds) != hipSuccess ||
+        hipFuncSetAttribute((const void *)zs_match_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kMatchLds + 16) != hipSuccess ||
         hipFuncSetAttribute((const void *)zs_resolve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kResolveLds) != hipSuccess ||
         hipFuncSetAttribute((const void *)zs_links_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLkLds) != hipSuccess ||
         hipFuncSetAttribute((const void *)zs_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kTailLds) != hipSuccess ||

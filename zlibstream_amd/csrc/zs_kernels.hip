@@ -445,7 +445,9 @@ __global__ __launch_bounds__(1024) void zs_match_kernel(const StreamDesc *sd, co
     const int64_t t0 = (int64_t)w.y * kMatchTile;
     const int64_t n = s.n;
     if (t0 > s.body_end) return;
-    __shared__ int wg_same;
+    // the two counters live behind the tile in the dynamic allocation: with no static LDS the tile starts at LDS address 0
+    // and the byte / link addresses of the walk need no base added (two vector instructions per candidate step)
+    int &wg_same = *(int *)(smem + kMatchLds), &wg_cursor = *(int *)(smem + kMatchLds + 4);
     if (threadIdx.x == 0) wg_same = 0;
     __syncthreads();
     const int64_t lo = t0 - kMatchBack;
@@ -516,7 +518,6 @@ __global__ __launch_bounds__(1024) void zs_match_kernel(const StreamDesc *sd, co
     const int wave = threadIdx.x >> 6, lane = lane_id();
     // one position cursor for the workgroup (an LDS counter): waves that run out of long walks early keep pulling, so
     // the idle tail is that of the tile, not of 16 separate ranges
-    __shared__ int wg_cursor;
     if (threadIdx.x == 0) wg_cursor = (int)(pbeg - lo);
     __syncthreads();
     const int wendi = (int)(pend - lo);  // LDS-relative end of the tile's positions
