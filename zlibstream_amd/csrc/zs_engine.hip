@@ -733,6 +733,13 @@ int zs_ctx_create(int device, zs_ctx **out) {
         zs_ctx_destroy(c);
         return ZS_MEM_ERROR;
     }
+    // the match kernel addresses its tile from LDS address 0 (lds0_u32 ...): true as long as it has no static LDS
+    hipFuncAttributes fa;
+    if (hipFuncGetAttributes(&fa, (const void *)zs_match_kernel) != hipSuccess || fa.sharedSizeBytes != 0) {
+        fprintf(stderr, "zsgpu: zs_match_kernel has static LDS; its tile addressing assumes none\n");
+        zs_ctx_destroy(c);
+        return ZS_STREAM_ERROR;
+    }
     *out = c;
     return ZS_OK;
 }

@@ -44,6 +44,22 @@ __device__ __forceinline__ uint64_t lds_u64(const uint8_t *base, int idx) {
     return (uint64_t)__builtin_amdgcn_alignbyte(b, a, sh) | ((uint64_t)__builtin_amdgcn_alignbyte(c, b, sh) << 32);
 }
 
+// The same for a byte array that starts at LDS address 0, with the index as the address: no base to add (K2's tile;
+// zs_match_kernel has no static LDS, so its dynamic allocation starts at 0 -- zs_ctx_create checks that).  v_alignbyte
+// looks at the low two bits of its shift operand only, so the index goes in as it is.
+typedef const __attribute__((address_space(3))) uint32_t *lds_cu32;
+typedef const __attribute__((address_space(3))) uint16_t *lds_cu16;
+__device__ __forceinline__ uint32_t lds0_u32(int idx) {
+    lds_cu32 q = (lds_cu32)(uint32_t)(idx & ~3);
+    return __builtin_amdgcn_alignbyte(q[1], q[0], (uint32_t)idx);
+}
+__device__ __forceinline__ uint64_t lds0_u64(int idx) {
+    lds_cu32 q = (lds_cu32)(uint32_t)(idx & ~3);
+    const uint32_t a = q[0], b = q[1], c = q[2];
+    return (uint64_t)__builtin_amdgcn_alignbyte(b, a, (uint32_t)idx) | ((uint64_t)__builtin_amdgcn_alignbyte(c, b, (uint32_t)idx) << 32);
+}
+__device__ __forceinline__ int lds0_link(int idx) { return *(lds_cu16)(uint32_t)(kMatchLdsBytes + 2 * idx); }
+
 // Match records in `mm` (uint2 per position): x = record for budget K, y = for budget K >> 2, each dist | (len-3) << 16
 // (zs_core.h pack_match); bits 24..31 of x carry the input byte of the position, so that the symbol kernel gets its
 // literals with the records it reads anyway.
@@ -297,13 +313,13 @@ __device__ __forceinline__ void match_walk(const uint8_t *wb, const uint16_t *wl
         snapped |= freeze;
         best = better ? len : best;
         bdist = better ? p - c : bdist;
-        if (better) scan_end = lds_u32(wb, p + len - 3);
+        if (better) scan_end = lds0_u32(p + len - 3);
         mask = better ? 0xFFFFFFFFu : mask;
         fmask = better ? 0xFFFFFFFFu : fmask;
         const int nice_hit = better & (len >= nice);
         cl = 0;
         n_eval++;
-        const int nc = c - wl[c];
+        const int nc = c - lds0_link(c);
         const int stop = nice_hit | (n_eval >= K) | (p - nc >= kMaxDist);
         c = stop ? c : nc;
         st = stop ? 3 : 1;
@@ -329,8 +345,8 @@ __device__ __forceinline__ void match_walk(const uint8_t *wb, const uint16_t *wl
                 const int mine = base + __builtin_popcountll(need & lanemask_lt());
                 const bool take = st == 3 && mine < wendi, dry = st == 3 && mine >= wendi;
                 const int q = take ? mine : 8;  // lanes that take nothing read an in-range dummy
-                const int l = wl[q];
-                const uint64_t first8 = lds_u64(wb, q);
+                const int l = lds0_link(q);
+                const uint64_t first8 = lds0_u64(q);
                 const bool has = l != 0xFFFF;  // link distances are already <= kMaxDist
                 // a position without a usable link is done at once; its lane takes its next one at the next visit (an
                 // immediate second pull cost more than the idle lane)
@@ -359,8 +375,8 @@ __device__ __forceinline__ void match_walk(const uint8_t *wb, const uint16_t *wl
             if (st == 3 && !cont) run_end = fresh + kRun < wendi ? fresh + kRun : wendi, hint_l = 0;
             run_next = st == 3 ? mine + 1 : run_next;
             const int q = take ? mine : 8;  // lanes that take nothing read an in-range dummy
-            const int l = wl[q];
-            const uint64_t first8 = lds_u64(wb, q);
+            const int l = lds0_link(q);
+            const uint64_t first8 = lds0_u64(q);
             const bool has = l != 0xFFFF;  // link distances are already <= kMaxDist
             // a position without a usable link is done at once; its lane takes its next one at the next visit
             if (take && !has) om[(int64_t)mine + lo] = make_uint2((uint32_t)first8 << 24, kNoMatch);
@@ -376,31 +392,30 @@ __device__ __forceinline__ void match_walk(const uint8_t *wb, const uint16_t *wl
             sc0 = take ? (uint32_t)first8 : sc0, sc1 = take ? (uint32_t)(first8 >> 32) : sc1;
         }
         if (!__ballot(st != 0)) break;
-        // ---- stepping phase (branch-free; lanes not in state 1 read their stale, in-range candidate)
+        // ---- stepping phase
         for (;;) {
             const int nact = __builtin_popcountll(__ballot(st == 1));
             const int nwait = __builtin_popcountll(__ballot(st >= 2));
             if (nact == 0 || nwait * kWaitNum >= nact * kWaitDen) break;
 #pragma unroll
             for (int u = 0; u < ZS_STEP_UNROLL; u++) {  // steps per look at the lane counts
-                const int l = wl[c];
-                const uint32_t e = lds_u32(wb, c + best - 3);
-#ifndef ZS_NO_FRONT_CHECK
-                // a candidate can only beat `best` if bytes [best-3 .. best] match too (bytes [0 .. 2] when best == 2) -- and
-                // its first bytes: the chain is keyed on bytes 2 .. 5, so most candidates that agree with the scan around
-                // `best` differ from it in bytes 0 and 1, and each of those would cost a visit to the compare phase
-                const uint32_t f = lds_u32(wb, c);
-                const int pass = (((e ^ scan_end) & mask) | ((f ^ sc0) & fmask)) == 0;
-#else
-                const int pass = ((e ^ scan_end) & mask) == 0;
-#endif
-                const int go = (st == 1) & !pass;
-                // leave the candidate: count it and follow its link; `cur_match > limit` is distance < kMaxDist
-                const int ne = n_eval + 1, nc = c - l;
-                const int stop = (ne >= K) | (p - nc >= kMaxDist);
-                n_eval = go ? ne : n_eval;
-                c = (go & !stop) ? nc : c;
-                st = (st == 1) ? (pass ? 2 : (stop ? 3 : 1)) : st;
+                // Only the lanes in state 1 run the step: the others' stale candidates would take part in the LDS bank conflicts
+                // (the kernel is bound by LDS cycles as much as by vector issue: 35 LDS cycles per wave-step with all 64 lanes
+                // reading, SQ_LDS_IDX_ACTIVE; masked, 2.75 ms against 3.0).
+                if (st == 1) {
+                    const int l = lds0_link(c);
+                    // a candidate can only beat `best` if bytes [best-3 .. best] match too (bytes [0 .. 2] when best == 2) -- and
+                    // its first bytes: the chain is keyed on bytes 2 .. 5, so most candidates that agree with the scan around
+                    // `best` differ from it in bytes 0 and 1, and each of those would cost a visit to the compare phase
+                    const uint32_t e = lds0_u32(c + best - 3), f = lds0_u32(c);
+                    const int pass = (((e ^ scan_end) & mask) | ((f ^ sc0) & fmask)) == 0;
+                    // leave the candidate: count it and follow its link; `cur_match > limit` is distance < kMaxDist
+                    const int ne = n_eval + 1, nc = c - l;
+                    const int stop = (ne >= K) | (p - nc >= kMaxDist);
+                    n_eval = pass ? n_eval : ne;
+                    c = (pass | stop) ? c : nc;
+                    st = pass ? 2 : (stop ? 3 : 1);
+                }
             }
         }
         // ---- compare phase.  First 8 bytes of every compare against the cached bytes of p (most end here) ...
@@ -408,7 +423,7 @@ __device__ __forceinline__ void match_walk(const uint8_t *wb, const uint16_t *wl
             if (RUNS && hint_l > 16 && p - c == hint_d) {
                 cl = (hint_l - 1) & ~7;  // the same distance matched hint_l bytes one position earlier
             } else {
-                const uint64_t x = lds_u64(wb, c) ^ ((uint64_t)sc0 | ((uint64_t)sc1 << 32));
+                const uint64_t x = lds0_u64(c) ^ ((uint64_t)sc0 | ((uint64_t)sc1 << 32));
                 if (x) after_compare((int)(__builtin_ctzll(x) >> 3));
                 else cl = 8;
             }
@@ -416,7 +431,7 @@ __device__ __forceinline__ void match_walk(const uint8_t *wb, const uint16_t *wl
         // ... then up to 32 more per visit for the lanes inside a long match (skipped by the wave when there is none)
         for (int r = 0; r < 4 && __ballot(st == 2 && cl != 0); r++) {
             if (st == 2 && cl != 0) {
-                const uint64_t x = lds_u64(wb, p + cl) ^ lds_u64(wb, c + cl);
+                const uint64_t x = lds0_u64(p + cl) ^ lds0_u64(c + cl);
                 if (x) {
                     after_compare(cl + (int)(__builtin_ctzll(x) >> 3));
                 } else {
@@ -1496,7 +1511,6 @@ __global__ __launch_bounds__(1024) void zs_fast_vec_kernel(const StreamDesc *sd,
     uint32_t *bm = (uint32_t *)(smem + kFvBytes + 2 * kFvLinks);
     __shared__ int64_t sh_p, sh_nsyms, sh_trigger, sh_preins;
     __shared__ int sh_k;
-    __shared__ volatile uint32_t fv_flag[64];
     const int tid = threadIdx.x, lane = lane_id();
     const int64_t n = s.n, body_end = s.fv_end;
     const gcbytes in = as_global(s.in);
@@ -1507,10 +1521,19 @@ __global__ __launch_bounds__(1024) void zs_fast_vec_kernel(const StreamDesc *sd,
     if (tid == 0) sh_p = 0, sh_nsyms = 0, sh_k = 0, sh_preins = -1, sh_trigger = kl >= 1 ? read_end_before(1) - (kMinLookahead - 1) : -1;
     __syncthreads();
     const bool aligned = (((uintptr_t)in) & 15) == 0;
+#ifdef ZS_FV_PROF
+    long long pf_stage = 0, pf_search = 0, pf_resolve = 0, pf_emit = 0, pf_windows = 0, pf_iters = 0, pf_t;
+#define PF_T0() pf_t = wall_clock64()
+#define PF_ADD(x) { const long long now_ = wall_clock64(); x += now_ - pf_t; pf_t = now_; }
+#else
+#define PF_T0()
+#define PF_ADD(x)
+#endif
     for (;;) {
         const int64_t p_in = sh_p;
         if (p_in > body_end) break;
         const int64_t t0 = p_in & ~31LL, lo = t0 - kFvBack, bw0 = lo >> 5;  // lo is a multiple of 32: bitmap words line up
+        PF_T0();
         // ---- stage the tile
         for (int i = tid; i < kFvBytes / 16; i += 1024) {
             const int64_t a = lo + (int64_t)i * 16;
@@ -1545,6 +1568,7 @@ __global__ __launch_bounds__(1024) void zs_fast_vec_kernel(const StreamDesc *sd,
         }
         for (int i = tid; i < kFvBitWords; i += 1024) bm[i] = bw0 + i >= 0 ? gbits[bw0 + i] : 0u;
         __syncthreads();
+        PF_ADD(pf_stage);
         if (tid < 64) {
             FvLdsAcc acc{wb, wl, bm, lo, bw0};
             int64_t p0 = p_in, nsyms = sh_nsyms, trigger = sh_trigger, preins = sh_preins;
@@ -1584,6 +1608,9 @@ __global__ __launch_bounds__(1024) void zs_fast_vec_kernel(const StreamDesc *sd,
                     }
                     const uint32_t *bmr = bm - (lo >> 5) + bw0;  // bmr[(rel index) >> 5] with rel = position - lo: lo is a multiple of 32
                     while (__ballot(!done)) {
+#ifdef ZS_FV_PROF
+                        pf_iters++;
+#endif
                         const int nc = c - l, d = qi - nc;
                         const bool valid = !done && l != 0 && nc >= min_i && (found == 0 ? d <= kMaxDist : d < kMaxDist);
                         const bool recent = valid && nc >= p0i;
@@ -1592,8 +1619,12 @@ __global__ __launch_bounds__(1024) void zs_fast_vec_kernel(const StreamDesc *sd,
                         done = done || !go;
                         const int cc = go ? nc : qi;  // lanes that are done read their own position (in range)
                         l = wl[cc];
-                        const uint32_t word = bmr[cc >> 5];
-                        const uint64_t x = lds_u64(wb, cc) ^ scan8;
+                        uint32_t word = bmr[cc >> 5];
+                        uint64_t c8 = lds_u64(wb, cc);
+                        // all three requests leave together: left alone, the compiler sinks the second and third below the tests
+                        // of the first one's result, and a lone wave then pays three LDS round trips per entry instead of one
+                        asm volatile("" : "+v"(l), "+v"(word), "+v"(c8));
+                        const uint64_t x = c8 ^ scan8;
                         c = cc;
                         const bool in = go && ((word >> (cc & 31)) & 1u);
                         if (in) {
@@ -1619,30 +1650,21 @@ __global__ __launch_bounds__(1024) void zs_fast_vec_kernel(const StreamDesc *sd,
                     }
                     r = FvResult{best, bdist, touched};
                 }
-                // ---- fv_resolve (zs_fast_vec.h) for the wave: the hops of the parse through the lanes' results.  A lane hops
-                //      to lane + match length (or + 1); lanes that end the window -- not trusted, an event loop-top, beyond
-                //      the limit -- hop nowhere.  "Reached from lane 0" by pointer doubling: six rounds of one LDS scatter
-                //      (the reached lanes mark their targets) and one gather of the doubled hop.
+                PF_ADD(pf_search);
+                // ---- fv_resolve (zs_fast_vec.h) for the wave: the hops of the parse through the lanes' results, followed on the
+                //      scalar unit (v_readlane of the hop length, ~17 loop-tops per window).  Lanes that end the window -- not
+                //      trusted, an event loop-top, beyond the limit -- stop it.  (Pointer doubling through an LDS flag array, six
+                //      rounds, took three times as long for a lone wave.)
                 const int adv = r.len >= kMinMatch ? r.len : 1;
                 const bool stopl = lane >= limit || (lane > 0 && (r.touched || (trigger >= 0 && p0 + lane >= trigger)));
-                int nxt = stopl || lane + adv > 63 ? 64 : lane + adv;
-                bool reach = lane == 0;
-#pragma unroll
-                for (int k = 0; k < 6; k++) {
-                    fv_flag[lane] = 0;
-                    if (reach && nxt < 64) fv_flag[nxt] = 1;
-                    reach = reach || fv_flag[lane] != 0;
-                    const int n2 = __builtin_amdgcn_ds_bpermute((nxt & 63) << 2, nxt);
-                    nxt = nxt < 64 ? n2 : 64;
+                const uint64_t stops = __ballot(stopl);
+                uint64_t tops = 0;
+                int advance = 0;
+                while (advance < 64 && !((stops >> advance) & 1ull)) {
+                    tops |= 1ull << advance;
+                    advance += __builtin_amdgcn_readlane(adv, advance);
                 }
-                const uint64_t reached = __ballot(reach), stops = __ballot(stopl), tops = reached & ~stops;
-                int advance;
-                if (reached & stops) {
-                    advance = (int)__builtin_ctzll(reached & stops);  // the parse arrived at a lane that ends the window
-                } else {
-                    const int t = 63 - (int)__builtin_clzll(tops);    // it left the window from its last loop-top
-                    advance = t + __builtin_amdgcn_readlane(adv, t);
-                }
+                PF_ADD(pf_resolve);
                 // ---- the loop-tops' symbols, compacted; block cuts every kBlockSyms symbols (Deflate.cs:910-948)
                 if ((tops >> lane) & 1ull) {
                     const int64_t g = nsyms + __builtin_popcountll(tops & lanemask_lt());
@@ -1660,6 +1682,10 @@ __global__ __launch_bounds__(1024) void zs_fast_vec_kernel(const StreamDesc *sd,
                 }
                 nsyms += __builtin_popcountll(tops);
                 p0 += advance;
+                PF_ADD(pf_emit);
+#ifdef ZS_FV_PROF
+                pf_windows++;
+#endif
             }
             // ---- leave the tile: the bitmap words that changed go back to the stream's bitmap
             for (int64_t wd = (p_in >> 5) + lane; wd <= (p0 + 96) >> 5; wd += 64)
@@ -1669,6 +1695,22 @@ __global__ __launch_bounds__(1024) void zs_fast_vec_kernel(const StreamDesc *sd,
         __threadfence_block();
         __syncthreads();
     }
+#ifdef ZS_FV_PROF
+    if (tid < 64 && blockIdx.x == 0) {
+        // calibration: 16 Ki dependent vector multiply-adds and 16 Ki dependent LDS reads by this lone wave, in the same ticks
+        long long c0 = wall_clock64();
+        uint32_t v = (uint32_t)lane + (uint32_t)n;
+        for (int i = 0; i < 16384; i++) v = v * 1664525u + 1013904223u;
+        long long c1 = wall_clock64();
+        uint32_t a = v & 0x3FFCu;
+        for (int i = 0; i < 16384; i++) a = (*(volatile uint32_t *)(smem + a) + a + 4) & 0x3FFCu;
+        long long c2 = wall_clock64();
+        if (tid == 0) printf("FVCAL 16384 dependent v_mad: %lld ticks; 16384 dependent ds_read: %lld ticks (%u %u)\n", c1 - c0, c2 - c1, v, a);
+    }
+    if (tid == 0 && blockIdx.x == 0)
+        printf("FVPROF n=%lld windows=%lld iters=%lld ticks(100MHz): stage=%lld search=%lld resolve=%lld emit=%lld\n", (long long)n, pf_windows,
+               pf_iters, pf_stage, pf_search, pf_resolve, pf_emit);
+#endif
     if (tid == 0) {
         StreamState &ss = st[blockIdx.x];
         ss.tail_p = (int32_t)sh_p;
