@@ -165,7 +165,45 @@ struct FvAcc {
     bool ins(int64_t c) const { return m->ins[(size_t)c] != 0; }
     int lcp(int64_t q, int64_t c) const { cmps++; return m->lcp(q, c); }
 };
+// Statistics only (ZS_FV_W=<lanes>): what a wider window would buy -- positions per window and the longest walk in it.
+// Read events are left out (one in 32 Ki positions).
+static void fv_window_stats(Model &m, int W) {
+    m.ins.assign((size_t)m.n + 512, 0);
+    FvAcc acc{&m};
+    std::vector<FvResult> res((size_t)W);
+    long windows = 0, iters = 0;
+    int64_t p0 = 0;
+    while (p0 <= m.body_end) {
+        int limit = W;
+        if (m.body_end - p0 + 1 < limit) limit = (int)(m.body_end - p0 + 1);
+        long mx = 0;
+        for (int i = 0; i < limit; i++) {
+            const long v0 = acc.visits;
+            res[(size_t)i] = fv_search(acc, p0 + i, p0, m.lv.chain, m.lv.nice, false, false);
+            if (acc.visits - v0 > mx) mx = acc.visits - v0;
+        }
+        int i = 0;
+        while (i < limit) {
+            const FvResult r = res[(size_t)i];
+            if (i > 0 && r.touched) break;
+            if (r.len >= kMinMatch) {
+                const int k = r.len <= m.lv.lazy ? r.len : 1;
+                for (int j = 0; j < k; j++) m.ins[(size_t)(p0 + i + j)] = 1;
+                i += r.len;
+            } else {
+                m.ins[(size_t)(p0 + i)] = 1;
+                i += 1;
+            }
+        }
+        p0 += i;
+        windows++, iters += mx;
+    }
+    printf("fvstat W=%d: %ld windows, %.1f positions per window, longest walk per window %.1f entries\n", W, windows, (double)p0 / windows,
+           (double)iters / windows);
+}
+
 static void parse_fast_vec(Model &m, int64_t &p_out, int &kdone_out, int64_t &preins_out) {
+    if (getenv("ZS_FV_W")) fv_window_stats(m, atoi(getenv("ZS_FV_W")));
     m.ins.assign((size_t)m.n + 128, 0);
     FvAcc acc{&m};
     const int kl = (int)m.rev.size() - 1;

@@ -1601,22 +1601,26 @@ __global__ __launch_bounds__(1024) void zs_fast_vec_kernel(const StreamDesc *sd,
                     const bool only_prev = lane == 1 && only1;
                     const uint64_t scan8 = lds_u64(wb, qi);
                     int c = qi, l = wl[qi], found = 0, best = 2, bdist = 0, touched = 0;
-                    bool done = dead || only_prev;
+                    int done = (dead || only_prev) ? 1 : 0;
                     if (only_prev && lane < limit) {
                         const int len = acc.lcp(p0 + lane, p0 + lane - 1);
                         if (len > 2) best = len, bdist = 1;
                     }
                     const uint32_t *bmr = bm - (lo >> 5) + bw0;  // bmr[(rel index) >> 5] with rel = position - lo: lo is a multiple of 32
+                    const int nice = lv.nice, chain = lv.chain;
+                    // Written with selects: a lone wave is bound by the number of instructions it issues, and the branchy form
+                    // of this loop spent two thirds of them on execution masks (~100 per entry against ~40).
                     while (__ballot(!done)) {
 #ifdef ZS_FV_PROF
                         pf_iters++;
 #endif
                         const int nc = c - l, d = qi - nc;
-                        const bool valid = !done && l != 0 && nc >= min_i && (found == 0 ? d <= kMaxDist : d < kMaxDist);
-                        const bool recent = valid && nc >= p0i;
-                        touched |= recent ? 1 : 0;
-                        const bool go = valid && !recent;
-                        done = done || !go;
+                        const int maxd = found ? kMaxDist - 1 : kMaxDist;  // hash_head: <= MAX_DIST; later: cur_match > limit
+                        const int valid = (done == 0) & (l != 0) & (nc >= min_i) & (d <= maxd);
+                        const int recent = valid & (nc >= p0i);
+                        touched |= recent;
+                        const int go = valid & (recent ^ 1);
+                        done |= go ^ 1;
                         const int cc = go ? nc : qi;  // lanes that are done read their own position (in range)
                         l = wl[cc];
                         uint32_t word = bmr[cc >> 5];
@@ -1626,11 +1630,10 @@ __global__ __launch_bounds__(1024) void zs_fast_vec_kernel(const StreamDesc *sd,
                         asm volatile("" : "+v"(l), "+v"(word), "+v"(c8));
                         const uint64_t x = c8 ^ scan8;
                         c = cc;
-                        const bool in = go && ((word >> (cc & 31)) & 1u);
-                        if (in) {
-                            found++;
-                            int len = x ? (int)(__builtin_ctzll(x) >> 3) : 8;
-                            if (!x) {
+                        const int isin = go & (int)((word >> (cc & 31)) & 1u);
+                        int len = x ? (int)(__builtin_ctzll(x) >> 3) : 8;
+                        if (__ballot(isin && !x)) {  // eight equal bytes: compare on (rare on text)
+                            if (isin && !x) {
                                 while (len < kMaxMatch) {
                                     const uint64_t y = lds_u64(wb, qi + len) ^ lds_u64(wb, cc + len);
                                     if (y) {
@@ -1641,12 +1644,12 @@ __global__ __launch_bounds__(1024) void zs_fast_vec_kernel(const StreamDesc *sd,
                                 }
                                 len = len < kMaxMatch ? len : kMaxMatch;
                             }
-                            if (len > best) {
-                                best = len, bdist = d;
-                                if (len >= lv.nice) done = true;
-                            }
-                            if (found >= lv.chain) done = true;
                         }
+                        found += isin;
+                        const int better = isin & (len > best);
+                        best = better ? len : best;
+                        bdist = better ? d : bdist;
+                        done |= (better & (len >= nice)) | (isin & (found >= chain));
                     }
                     r = FvResult{best, bdist, touched};
                 }
