@@ -1,0 +1,10 @@
+import os, sys
+sys.path.insert(0, '/root/repo')
+import torch
+from zlibstream_amd import Engine, datagen
+eng = Engine()
+for n in (32 << 10, 8 << 20):
+    d = datagen.english(n, 3)
+    for r in range(2):
+        z = eng.deflate_batch([d], level=6)[0]
+    print(n, len(z), flush=True)

@@ -400,8 +400,9 @@ __device__ __forceinline__ void match_walk(const uint8_t *wb, const uint16_t *wl
 #pragma unroll
             for (int u = 0; u < ZS_STEP_UNROLL; u++) {  // steps per look at the lane counts
                 // Only the lanes in state 1 run the step: the others' stale candidates would take part in the LDS bank conflicts
-                // (the kernel is bound by LDS cycles as much as by vector issue: 35 LDS cycles per wave-step with all 64 lanes
-                // reading, SQ_LDS_IDX_ACTIVE; masked, 2.75 ms against 3.0).
+                // (35 LDS cycles per wave-step with all 64 lanes reading, SQ_LDS_IDX_ACTIVE: 2.4 of the kernel's 3.0 ms; masked,
+                // 2.75 ms).  From here neither fewer vector instructions per step (lanes leaving through the execution mask
+                // instead of selects: -5 of 21) nor fewer LDS reads (none for `e` while best <= 3) moved the time: DESIGN.md.
                 if (st == 1) {
                     const int l = lds0_link(c);
                     // a candidate can only beat `best` if bytes [best-3 .. best] match too (bytes [0 .. 2] when best == 2) -- and
@@ -1212,10 +1213,16 @@ __global__ __launch_bounds__(1024) void zs_tail_kernel(const StreamDesc *sd, Str
     } else {
         // ss.k_done is the parse segment of the last read event that fired before p
         const bool have_seg = s.nsegs > 0;
+#ifdef ZS_FV_PROF
+        long long tk0 = wall_clock64(), tk1 = 0, tk2 = 0, tk3 = 0;
+#endif
         le_restore(e, p, have_seg ? s.seg_base[ss.k_done] : 0, have_seg ? s.seg_after[ss.k_done] : 0, ss.tail_kind, ss.tail_pend, lk,
                    ss.preins, tid, nth);
         for (int i = tid; i < kHashSize; i += nth) head32[i] = 0;
         __syncthreads();
+#ifdef ZS_FV_PROF
+        tk1 = wall_clock64();
+#endif
         if (e.avail_end > 0) {
             int64_t lo = p - (kWSize - 1);
             if (lo < e.base) lo = e.base;
@@ -1234,14 +1241,29 @@ __global__ __launch_bounds__(1024) void zs_tail_kernel(const StreamDesc *sd, Str
                 atomicMax(&head32[le_bucket(e, q)], (uint32_t)(q - e.base) + 1u);
             }
             __syncthreads();
+#ifdef ZS_FV_PROF
+            tk2 = wall_clock64();
+#endif
             for (int i = tid; i < kHashSize; i += nth) e.head[i] = (uint16_t)(head32[i] ? head32[i] - 1 : 0);
         }
         __syncthreads();
+#ifdef ZS_FV_PROF
+        tk3 = wall_clock64();
+        if (tid == 0 && blockIdx.x == 0) printf("TAILPROF p=%lld n=%lld ticks: window+clear=%lld prev+head=%lld convert=%lld\n", (long long)p, (long long)s.n, tk1 - tk0, tk2 - tk1, tk3 - tk2);
+#endif
     }
     if (tid >= 64) return;  // the engine is one wave, every lane running the same scalar code
+#ifdef ZS_FV_PROF
+    long long te0 = wall_clock64();
+#endif
     if (!s.cont && e.avail_end > 0) le_restore_finish(e, p, lk, ss.preins);
     __syncthreads();
     le_run(e, level, tid, 64);
+#ifdef ZS_FV_PROF
+    if (tid == 0 && blockIdx.x == 0)
+        printf("TAILPROF engine ticks=%lld syms=%lld: refill=%lld insert=%lld match=%lld tally=%lld flush=%lld\n", wall_clock64() - te0,
+               (long long)(e.nsyms - body_syms), e.pf[0], e.pf[1], e.pf[2], e.pf[3], e.pf[4]);
+#endif
     if (tid == 0) {
         ss.nsyms = (uint32_t)e.nsyms;
         ss.nblocks = e.nblocks;

@@ -40,6 +40,9 @@ struct BlockRec {
 };
 
 struct LitEngine {
+#ifdef ZS_FV_PROF
+    long long pf[5] = {0, 0, 0, 0, 0};  // ticks: refill, insert, longest match, tally / advance, final flush
+#endif
     // scratch (per stream)
     uint8_t *window;  // kWindowSize + 512 bytes
     uint16_t *head;   // kHashSize
@@ -352,9 +355,17 @@ ZS_HD bool le_tally(LitEngine &e, int dist, int lc, int lane) {
 }
 
 // Deflate.Slow.cs:18-159 with flush == Finish, run to the end of the stream.
+#if defined(ZS_FV_PROF) && defined(__HIP_DEVICE_COMPILE__)
+#define LE_PF_T0() long long pf_t_ = wall_clock64()
+#define LE_PF(i) { const long long now_ = wall_clock64(); e.pf[i] += now_ - pf_t_; pf_t_ = now_; }
+#else
+#define LE_PF_T0()
+#define LE_PF(i)
+#endif
 ZS_HD_NOINLINE inline void le_run_slow(LitEngine &e, int lane, int nlanes) {
     int hash_head = 0;
     for (;;) {
+        LE_PF_T0();
         if (e.lookahead < kMinLookahead) {
             le_refill(e, lane, nlanes, hash_head);
             if (e.suspended) return;
@@ -369,7 +380,9 @@ ZS_HD_NOINLINE inline void le_run_slow(LitEngine &e, int lane, int nlanes) {
                 continue;
             }
         }
+        LE_PF(0);
         if (e.lookahead >= kMinMatch) hash_head = le_insert(e, e.strstart);
+        LE_PF(1);
         e.prev_length = e.match_length;
         e.prev_match = e.match_start;
         e.match_length = kMinMatch - 1;
@@ -379,6 +392,7 @@ ZS_HD_NOINLINE inline void le_run_slow(LitEngine &e, int lane, int nlanes) {
                 (e.strategy == kFiltered || (e.match_length == kMinMatch && e.strstart - e.match_start > kTooFar)))
                 e.match_length = kMinMatch - 1;
         }
+        LE_PF(2);
         if (e.prev_length >= kMinMatch && e.match_length <= e.prev_length) {
             int max_insert = e.strstart + e.lookahead - kMinMatch;
             bool bflush = le_tally(e, e.strstart - 1 - e.prev_match, e.prev_length - kMinMatch, lane);
@@ -401,12 +415,15 @@ ZS_HD_NOINLINE inline void le_run_slow(LitEngine &e, int lane, int nlanes) {
             e.strstart++;
             e.lookahead--;
         }
+        LE_PF(3);
     }
+    LE_PF_T0();
     if (e.match_available != 0) {
         le_tally(e, 0, le_wbyte(e, e.strstart - 1), lane);
         e.match_available = 0;
     }
     le_flush_block(e, true, lane);
+    LE_PF(4);
 }
 
 // Deflate.Fast.cs:20-128 with flush == Finish, run to the end of the stream.
