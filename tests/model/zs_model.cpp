@@ -475,6 +475,23 @@ static void run_tail(Model &m, int64_t p, int kind, uint32_t pend, int k_done, i
         }
         le_restore_finish(e, p, m.link.data(), preins);
     }
+    // the tail's searches ahead of its parse (le_tail_record), under the conditions of zs_tail_kernel: a slow level, one
+    // Write, everything read, no pre-insert pending
+    std::vector<uint32_t> pre;
+    if (m.lv.func == 2 && m.strategy != kRle && m.strategy != kHuffmanOnly && !e.wr_end && !m.incremental && e.avail_end == e.n &&
+        e.avail_end > 0 && preins < p && m.ins.empty() && !getenv("ZS_NO_TAIL_RECORDS")) {
+        const int64_t hi = le_tail_record_end(e);
+        if (hi > p && hi - p <= 512) {
+            for (int64_t q = p; q < hi; q++) le_restore_prev(e, q, m.link.data());
+            pre.assign((size_t)(2 * (hi - p)), 0);
+            for (int64_t q = p; q < hi; q++) {
+                pre[(size_t)(2 * (q - p))] = le_tail_record(e, (int)(q - e.base), (int)(e.n - q), m.lv.chain);
+                pre[(size_t)(2 * (q - p)) + 1] = le_tail_record(e, (int)(q - e.base), (int)(e.n - q), m.lv.chain >> 2);
+            }
+            e.pre_rec = pre.data(), e.pre_lo = p, e.pre_hi = hi;
+            if (getenv("ZS_FV_STATS")) printf("tail records for [%ld, %ld) of n = %ld\n", (long)p, (long)hi, (long)e.n);
+        }
+    }
     if (m.incremental && !m.wr_end.empty()) {
         // incremental stream: one run per Write (the engine suspends where Deflate.Compress returns for more input and is
         // re-entered with the next Write), then the Finish call as a run of its own without input

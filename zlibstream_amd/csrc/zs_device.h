@@ -76,6 +76,7 @@ struct StreamDesc {
 };
 
 // zs_fast_vec_kernel's tile: the window [t0 - kFvBack, t0 + kFvTile + kFvFwd) in LDS as bytes, links and inserted bits
+constexpr int kTailRecMax = 288;  // positions of a tail whose searches are done ahead (zs_tail_kernel): <= 261 - max_lazy + a few
 constexpr int kFvTile = 16384;
 constexpr int kFvBack = 32512;  // >= kMaxDist, multiple of 32
 constexpr int kFvFwd = 272;     // >= kMaxMatch + 8, multiple of 16

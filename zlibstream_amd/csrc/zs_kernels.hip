@@ -1252,6 +1252,25 @@ __global__ __launch_bounds__(1024) void zs_tail_kernel(const StreamDesc *sd, Str
         if (tid == 0 && blockIdx.x == 0) printf("TAILPROF p=%lld n=%lld ticks: window+clear=%lld prev+head=%lld convert=%lld\n", (long long)p, (long long)s.n, tk1 - tk0, tk2 - tk1, tk3 - tk2);
 #endif
     }
+    // ---- the searches of the tail's loop-tops ahead of its parse, one position per thread (le_tail_record,
+    //      zs_lit_engine.h): a slow level, one Write, everything read, no pre-insert pending.  The engine then looks its
+    //      matches up; only the last max_lazy positions are searched by the engine itself.
+    __shared__ uint32_t pre_tab[2 * kTailRecMax];
+    {
+        const bool pre_ok = lv.func == 2 && strategy != kRle && strategy != kHuffmanOnly && !s.cont && s.final_run && !e.wr_end &&
+                            s.fv_end < 0 && e.avail_end == e.n && e.avail_end > 0 && ss.preins < p;
+        const int64_t hi = le_tail_record_end(e);
+        if (pre_ok && hi > p && hi - p <= kTailRecMax) {  // uniform over the workgroup
+            for (int64_t q = p + tid; q < hi; q += nth) le_restore_prev(e, q, lk);  // what the engine's inserts will write
+            __syncthreads();
+            for (int64_t q = p + tid; q < hi; q += nth) {
+                pre_tab[2 * (q - p)] = le_tail_record(e, (int)(q - e.base), (int)(e.n - q), lv.chain);
+                pre_tab[2 * (q - p) + 1] = le_tail_record(e, (int)(q - e.base), (int)(e.n - q), lv.chain >> 2);
+            }
+            e.pre_rec = pre_tab, e.pre_lo = p, e.pre_hi = hi;
+            __syncthreads();
+        }
+    }
     if (tid >= 64) return;  // the engine is one wave, every lane running the same scalar code
 #ifdef ZS_FV_PROF
     long long te0 = wall_clock64();

@@ -88,6 +88,10 @@ struct LitEngine {
     // (NeedMore under NoFlush, Deflate.Slow.cs:38-46; BlockDone after a flush, Deflate.cs:583-613) the engine stops with
     // `suspended` set, at a loop-top, and a later run re-enters the block function from there
     int final_run, suspended;
+    // match records computed ahead for the loop-tops [pre_lo, pre_hi) (le_tail_record): two words per position, the
+    // record for the full chain budget and the one for a quarter of it; nullptr: every search walks its chain
+    const uint32_t *pre_rec;
+    int64_t pre_lo, pre_hi;
     // outputs
     uint32_t *syms;     // symbol i: dist << 16 | lc  (dist 0 = literal)
     int64_t nsyms;      // symbols emitted so far in this stream (body + tail)
@@ -102,6 +106,7 @@ ZS_HD void le_defaults(LitEngine &e) {
     e.ins_bits = nullptr, e.ins_base = 0, e.no_blocks = 0, e.ins_word_idx = -1, e.ins_word = 0;
     e.ev_log = nullptr, e.n_ev = 0;
     e.final_run = 1, e.suspended = 0;
+    e.pre_rec = nullptr, e.pre_lo = e.pre_hi = 0;
     e.block_syms = kBlockSyms, e.block_sym_start = 0, e.block_start_abs = 0, e.defer_start = 0;
     e.nsyms = 0, e.nblocks = 0;
 }
@@ -313,6 +318,67 @@ ZS_HD_NOINLINE inline int le_longest_match(LitEngine &e, int cur_match) {
     return best_len < e.lookahead ? best_len : e.lookahead;
 }
 
+// The searches of the last loop-tops of a stream, ahead of the parse and one position per lane.  For a slow level every
+// position below a loop-top q is in the chains when q is searched (Deflate.Slow.cs:58,121-129), so q's chain is prev[] as
+// the restore builds it from K1's links -- for the tail positions too (le_restore_prev) -- and, as long as the lookahead
+// is at least max_lazy, the result depends on the parse only through prev_length >= good_match (a quarter of the chain
+// budget, Deflate.cs:1036-1039): a search starts from best_len = prev_length < max_lazy <= min(nice_match, lookahead), so
+// the candidate that ends it early is the same one whatever prev_length is, and the longest of the visited candidates
+// (the first of them) is the answer whenever it beats prev_length (le_match_from_record).  This is Longest_match
+// (Deflate.cs:1022-1100) for prev_length = 2 with the chain budget given, at loop-top `str` (window index) with `lookahead`
+// bytes left; returns pack_match(len, dist) or kNoMatch.  Reads the engine, changes nothing.
+ZS_HD_NOINLINE inline uint32_t le_tail_record(const LitEngine &e, int str, int lookahead, int chain_length) {
+    int cur_match = ZS_LDS_PTR(const uint16_t, e.prev)[str & kWMask];  // what InsertString(str) will return
+    if (cur_match == 0 || str - cur_match > kMaxDist) return kNoMatch;
+    const uint8_t *scan = e.window + str;
+    int best_len = kMinMatch - 1, ms = 0;
+    const int limit = str > kMaxDist ? str - kMaxDist : 0;
+    int nice = e.lv.nice;
+    if (nice > lookahead) nice = lookahead;
+    auto wl = ZS_LDS_PTR(const uint8_t, e.window);
+    auto pl = ZS_LDS_PTR(const uint16_t, e.prev);
+    auto sc = wl + str;
+    const uint8_t s0 = sc[0], s1 = sc[1];
+    uint8_t sb0 = sc[best_len - 1], sb1 = sc[best_len];
+    do {
+        if (cur_match >= str) break;
+        const uint8_t *m = e.window + cur_match;
+        auto ml = wl + cur_match;
+        const uint8_t mb1 = ml[best_len], mb0 = ml[best_len - 1], m0 = ml[0], m1 = ml[1];
+        const int next = pl[cur_match & kWMask];
+        if (!((mb1 ^ sb1) | (mb0 ^ sb0) | (m0 ^ s0) | (m1 ^ s1))) {
+            const int len = le_match_len(scan, m);
+            if (len > best_len) {
+                ms = cur_match;
+                best_len = len;
+                if (len >= nice) break;
+                sb0 = sc[best_len - 1], sb1 = sc[best_len];
+            }
+        }
+        cur_match = next;
+    } while (cur_match > limit && --chain_length != 0);
+    if (best_len > lookahead) best_len = lookahead;
+    return best_len >= kMinMatch ? pack_match(best_len, str - ms) : kNoMatch;
+}
+// The positions le_tail_record may be asked for when the engine takes over at loop-top p with all input read: links
+// exist up to n - 6, and the lookahead must not fall below max_lazy.
+ZS_HD int64_t le_tail_record_end(const LitEngine &e) {
+    const int64_t a = e.n - 5, b = e.n - e.lv.lazy + 1;
+    return a < b ? a : b;
+}
+// Longest_match's result at the current loop-top from its record.
+ZS_HD int le_match_from_record(LitEngine &e) {
+    const uint32_t *r = e.pre_rec + 2 * (e.base + e.strstart - e.pre_lo);
+    const uint32_t rec = e.prev_length >= e.lv.good ? r[1] : r[0];
+    int best_len = e.prev_length;
+    if (best_len == 0) best_len = 1;
+    if (rec != kNoMatch && match_len(rec) > best_len) {
+        best_len = match_len(rec);
+        e.match_start = e.strstart - match_dist(rec);
+    }
+    return best_len < e.lookahead ? best_len : e.lookahead;
+}
+
 ZS_HD void le_flush_block(LitEngine &e, bool eof, int lane, int flush = 0) {
     int64_t end_abs = e.base + e.strstart;
     if (lane == 0) {
@@ -367,7 +433,9 @@ ZS_HD_NOINLINE inline void le_run_slow(LitEngine &e, int lane, int nlanes) {
     for (;;) {
         LE_PF_T0();
         if (e.lookahead < kMinLookahead) {
-            le_refill(e, lane, nlanes, hash_head);
+            // the visits of a stream's last 261 loop-tops find nothing to read and nothing to slide: not worth the call
+            const bool idle = !e.wr_end && e.final_run && e.avail_end >= e.n && e.strstart < kSlideAt;
+            if (!idle) le_refill(e, lane, nlanes, hash_head);
             if (e.suspended) return;
             if (e.lookahead == 0) {
                 if (!le_write_flushes(e)) break;
@@ -387,7 +455,10 @@ ZS_HD_NOINLINE inline void le_run_slow(LitEngine &e, int lane, int nlanes) {
         e.prev_match = e.match_start;
         e.match_length = kMinMatch - 1;
         if (hash_head != 0 && e.prev_length < e.lv.lazy && e.strstart - hash_head <= kMaxDist) {
-            if (e.strategy != kHuffmanOnly) e.match_length = le_longest_match(e, hash_head);
+            if (e.strategy != kHuffmanOnly) {
+                const int64_t qa = e.base + e.strstart;
+                e.match_length = (e.pre_rec && qa >= e.pre_lo && qa < e.pre_hi) ? le_match_from_record(e) : le_longest_match(e, hash_head);
+            }
             if (e.match_length <= 5 &&
                 (e.strategy == kFiltered || (e.match_length == kMinMatch && e.strstart - e.match_start > kTooFar)))
                 e.match_length = kMinMatch - 1;
