@@ -3,6 +3,9 @@
 cp zlibstream_amd/libzsgpu.so /tmp/lib_orig.so
 for f in build/variants/*.so; do
   cp "$f" zlibstream_amd/libzsgpu.so
-  timeout -k 5 120 python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-secondary "$@" 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$f', d['value'], d['ms_per_step'], 'match', d['stage_ms']['match'], 'syms', d['stage_ms']['emit_syms'], 'chunkmap', d['stage_ms']['chunkmap'])"
+  timeout -k 5 120 python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-secondary "$@" 2>/dev/null | tail -1 | python -c "
+import sys, json
+d = json.loads(sys.stdin.read())
+print('$f', d['value'], d['ms_per_step'], {k: round(v, 2) for k, v in d['stage_ms'].items() if v > 0.1})"
 done
 cp /tmp/lib_orig.so zlibstream_amd/libzsgpu.so

@@ -1071,9 +1071,9 @@ __global__ __launch_bounds__(64) void zs_emit_syms_lane_kernel(const StreamDesc 
     uint32_t pend = kNoMatch;
     if (kind == kXK) pend = acc.mK(p - 1);
     else if (kind == kXK4) pend = acc.mK4(p - 1);
-    uint2 cur = a[p];
     uint8_t lit = p >= 1 ? gin[p - 1] : 0;
     const bool rec_lits = strategy != kHuffmanOnly;  // HuffmanOnly has no match pass: its records are zero-filled
+    uint2 cur = a[p];
     while (p < ce) {
         int64_t qa = p + 1, qb = pend ? p - 1 + match_len(pend) : qa;
         if (qa > last) qa = last;
