@@ -636,3 +636,38 @@ def test_fuzz_stream_protocol_writes_and_flush_modes(engine, oracle, seed):
                 s.write(data[o:o + c])
                 o += c
         assert out.getvalue() == want, (seed, case, n, kind, level, strategy, flush, unit, chunks[:4])
+
+
+def test_tail_searches_done_ahead_many_odd_sized_streams(engine, oracle):
+    """The tail kernel searches a stream's last loop-tops one position per thread before its engine parses them
+    (le_tail_record; Longest_match Deflate.cs:1022-1100 under the end-of-stream rules): 160 streams whose sizes sit around
+    the points where the window slides or fills, with periodic data and matches running into the data end, every byte
+    against the oracle at levels 4-9 and under Filtered / Fixed."""
+    rng = np.random.default_rng(4242)
+    alice = open(os.path.join(os.path.dirname(__file__), "golden", "corpus", "alice29.txt"), "rb").read() * 3
+    sizes = [263, 300, 520, 5000, 32768 + 261, 65274, 65275, 65535, 65536, 65536 + 200, 65536 + 262, 98304 - 100, 98304 + 5,
+             131072 - 261, 131072 + 1]
+    bufs = []
+    for i in range(160):
+        n = int(sizes[i % len(sizes)] + rng.integers(-3, 4))
+        kind = i % 4
+        if kind == 0:
+            o = int(rng.integers(0, len(alice) // 3))
+            b = alice[o:o + n]
+        elif kind == 1:
+            pat = rng.integers(0, 256, int(rng.integers(1, 40)), dtype=np.uint8).tobytes()
+            b = (pat * (n // len(pat) + 1))[:n]
+        elif kind == 2:
+            b = rng.integers(0, 4, n, dtype=np.uint8).tobytes()
+        else:
+            t = bytearray(alice[11:11 + n])
+            k = int(rng.integers(10, 600))
+            if n > 2 * k + 10:
+                src = int(rng.integers(0, n - 2 * k))
+                t[n - k:] = t[src:src + k]
+            b = bytes(t)
+        bufs.append(b)
+    for lvl, strat in ((4, 0), (5, 0), (6, 0), (7, 0), (8, 0), (9, 0), (6, int(CompressionStrategy.Filtered)), (6, int(CompressionStrategy.Fixed))):
+        got = engine.deflate_batch(bufs, level=lvl, strategy=strat)
+        for i, (b, z) in enumerate(zip(bufs, got)):
+            assert z == oracle.compress(b, lvl, strat), (lvl, strat, i, len(b))

@@ -128,3 +128,42 @@ def test_incremental_runs_of_the_literal_engine(model, tmp_path):
     run(model["alice_600"], 6, 0, "inc", 7, 2)
     run(model["zeros_98305"], 6, 0, "inc", 4096, 1)
     run(model["alice_0"], 6, 0, "inc", 0, 0)
+
+
+def test_tail_records_match_the_engine_search(model, tmp_path):
+    """The searches of a stream's last loop-tops done ahead of the tail engine's parse (le_tail_record, zs_lit_engine.h;
+    Longest_match Deflate.cs:1022-1100 with nice clipped to the lookahead and the length capped by it): tails around the
+    window-slide points, periodic data, matches that run into the data end; levels 4-9, default / Filtered / Fixed.
+    ZS_NO_TAIL_RECORDS=1 is the engine searching every position itself: both must be the oracle's symbols."""
+    import random
+    rng = random.Random(11)
+    alice = open(os.path.join(ROOT, "tests/golden/corpus/alice29.txt"), "rb").read()
+    npr = np.random.default_rng(5)
+    sizes = [300, 520, 5000, 32768 + 261, 65274, 65275, 65535, 65536 + 200, 65536 + 262, 98304 - 100, 131072 - 261]
+
+    def gen(kind, n):
+        if kind == 0:
+            o = rng.randrange(0, len(alice))
+            return (alice * 3)[o:o + n]
+        if kind == 1:
+            pat = bytes(rng.randrange(256) for _ in range(rng.randrange(1, 40)))
+            return (pat * (n // len(pat) + 1))[:n]
+        if kind == 2:
+            return npr.integers(0, 4, n, dtype=np.uint8).tobytes()
+        b = bytearray((alice * 3)[7:7 + n])  # the last few hundred bytes repeat an earlier stretch
+        k = rng.randrange(10, 600)
+        if n > 2 * k + 10:
+            src = rng.randrange(0, n - 2 * k)
+            b[n - k:] = b[src:src + k]
+        return bytes(b)
+    for it in range(24):
+        n = rng.choice(sizes) + rng.randrange(-3, 4)
+        p = tmp_path / ("tail_%d" % it)
+        p.write_bytes(gen(it % 4, n))
+        for level in (4, 6, 7, 9):
+            run(str(p), level, rng.choice([0, 0, 1, 4]))
+    os.environ["ZS_NO_TAIL_RECORDS"] = "1"
+    try:
+        run(str(tmp_path / "tail_3"), 6)
+    finally:
+        del os.environ["ZS_NO_TAIL_RECORDS"]
