@@ -84,6 +84,9 @@ constexpr int kFvBytes = kFvBack + kFvTile + kFvFwd;
 constexpr int kFvLinks = kFvBack + kFvTile;
 constexpr int kFvBitWords = kFvLinks / 32 + 8;  // the tile may start 16 positions into a word, and short matches reach out of it
 constexpr int kFvLds = kFvBytes + 2 * kFvLinks + 4 * kFvBitWords;
+// the last tile of a stream stages bitmap words for up to kFvTile + 256 positions past its loop-top, i.e. past the stream's end:
+// the bitmap array carries that much room behind the last stream
+constexpr size_t kFvBitSlack = (kFvTile + 512) / 8 + 64;
 
 // What a suspended literal engine keeps between runs (device memory, one per zs_deflate stream): the reference's own state
 // -- window, prev, head, the Deflate fields (Deflate.cs:128-226) -- plus the symbols of the block in progress and the

@@ -71,8 +71,21 @@ bool ensure(zs_ctx *c, DevBuf &b, size_t bytes) {
     if (b.p) (void)hipFree(b.p);
     b.p = nullptr;
     b.cap = 0;
+    // an eighth of headroom so that a slightly larger batch reuses the buffer; without it when the device is nearly full
     size_t want = bytes + bytes / 8 + 4096;
-    ZS_HIP(c, hipMalloc(&b.p, want));
+    if (hipMalloc(&b.p, want) != hipSuccess) {
+        (void)hipGetLastError();
+        b.p = nullptr;
+        want = bytes + 4096;
+        if (hipMalloc(&b.p, want) != hipSuccess) {
+            (void)hipGetLastError();
+            b.p = nullptr;
+            char msg[160];
+            snprintf(msg, sizeof msg, "workspace: %zu bytes do not fit the device's free memory (the pipeline needs ~17 bytes per input byte: split the batch)", bytes);
+            c->err = msg;
+            return false;
+        }
+    }
     b.cap = want;
     return true;
 }
@@ -270,7 +283,7 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
     }
     if (pl.any_fv) {
         // one bit per position (pos_off is a multiple of 64: every stream's bitmap starts on a word)
-        if (!ensure(c, c->ins_bits, (size_t)pl.n_pos / 8 + 1024)) return false;
+        if (!ensure(c, c->ins_bits, (size_t)pl.n_pos / 8 + kFvBitSlack)) return false;
         for (int i = 0; i < n; i++)
             if (pl.sd[(size_t)i].fv_end >= 0) pl.sd[(size_t)i].ins_bits = dev<uint32_t>(c->ins_bits) + pl.sd[(size_t)i].pos_off / 32;
     }
@@ -337,7 +350,7 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
     ZS_HIP(c, hipMemcpyAsync(c->sd.p, hp, sizeof(StreamDesc) * (size_t)n, hipMemcpyHostToDevice, stream));
     if (n_work) ZS_HIP(c, hipMemcpyAsync(c->work.p, hw, sizeof(uint2) * n_work, hipMemcpyHostToDevice, stream));
     ZS_HIP(c, hipMemsetAsync(c->link.p, 0, 2 * (size_t)pl.n_pos + 64, stream));
-    if (pl.any_fv) ZS_HIP(c, hipMemsetAsync(c->ins_bits.p, 0, (size_t)pl.n_pos / 8 + 1024, stream));
+    if (pl.any_fv) ZS_HIP(c, hipMemsetAsync(c->ins_bits.p, 0, (size_t)pl.n_pos / 8 + kFvBitSlack, stream));
     ZS_HIP(c, hipMemsetAsync(c->stale.p, 0, (size_t)pl.n_chunks + 64, stream));
     ZS_HIP(c, hipMemsetAsync(c->seg_stale.p, 0, (size_t)pl.n_segs + 64, stream));
     ZS_HIP(c, hipMemsetAsync(c->st.p, 0, sizeof(StreamState) * (size_t)n, stream));

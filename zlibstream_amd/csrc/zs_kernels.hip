@@ -1740,17 +1740,6 @@ __global__ __launch_bounds__(1024) void zs_fast_vec_kernel(const StreamDesc *sd,
         __syncthreads();
     }
 #ifdef ZS_FV_PROF
-    if (tid < 64 && blockIdx.x == 0) {
-        // calibration: 16 Ki dependent vector multiply-adds and 16 Ki dependent LDS reads by this lone wave, in the same ticks
-        long long c0 = wall_clock64();
-        uint32_t v = (uint32_t)lane + (uint32_t)n;
-        for (int i = 0; i < 16384; i++) v = v * 1664525u + 1013904223u;
-        long long c1 = wall_clock64();
-        uint32_t a = v & 0x3FFCu;
-        for (int i = 0; i < 16384; i++) a = (*(volatile uint32_t *)(smem + a) + a + 4) & 0x3FFCu;
-        long long c2 = wall_clock64();
-        if (tid == 0) printf("FVCAL 16384 dependent v_mad: %lld ticks; 16384 dependent ds_read: %lld ticks (%u %u)\n", c1 - c0, c2 - c1, v, a);
-    }
     if (tid == 0 && blockIdx.x == 0)
         printf("FVPROF n=%lld windows=%lld iters=%lld ticks(100MHz): stage=%lld search=%lld resolve=%lld emit=%lld\n", (long long)n, pf_windows,
                pf_iters, pf_stage, pf_search, pf_resolve, pf_emit);
