@@ -671,3 +671,25 @@ def test_tail_searches_done_ahead_many_odd_sized_streams(engine, oracle):
         got = engine.deflate_batch(bufs, level=lvl, strategy=strat)
         for i, (b, z) in enumerate(zip(bufs, got)):
             assert z == oracle.compress(b, lvl, strat), (lvl, strat, i, len(b))
+
+
+def test_resolve_through_composed_segment_maps_and_row_by_row(engine, oracle):
+    """The resolve kernel follows a long stream through the segment maps composed 16 at a time (zs_supmap_kernel) and goes
+    back to the row-by-row walk when the path meets an equal-bucket refill (Deflate.cs:1010-1013 with both positions in one
+    bucket: runs, periodic data).  Both ways, and the forced row-by-row way (ZS_NO_SUPMAP), give the oracle's bytes."""
+    rng = np.random.default_rng(77)
+    period = rng.integers(0, 256, 37, dtype=np.uint8).tobytes()
+    bufs = [datagen.english(3 << 20, 21),                                   # no equal-bucket refill: the short way
+            bytes(2 << 20),                                                # every refill is one
+            (period * ((1 << 20) // 37 + 1))[:1 << 20] + datagen.english(2 << 20, 22),   # the short way fails part-way
+            datagen.sparse(1024, 1024),
+            datagen.english(700_000, 23) + bytes(300_000) + datagen.english(1_500_000, 24)]
+    want = [oracle.compress(b, 6) for b in bufs]
+    assert engine.deflate_batch(bufs, level=6) == want
+    os.environ["ZS_NO_SUPMAP"] = "1"
+    try:
+        assert engine.deflate_batch(bufs, level=6) == want
+    finally:
+        del os.environ["ZS_NO_SUPMAP"]
+    for lvl in (4, 9):
+        assert engine.deflate_batch(bufs[:3], level=lvl) == [oracle.compress(b, lvl) for b in bufs[:3]]

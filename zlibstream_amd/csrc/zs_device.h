@@ -44,6 +44,7 @@ struct StreamDesc {
     int32_t run_off;   // index of run 0 in the run arrays
     int32_t seg_off;   // index of parse segment 0 in segmap / seg_entry / seg_symbase / seg_stale
     int32_t nsegs;
+    int32_t sup_off;   // index of the stream's first row in supmap (one row per kSupSegs parse segments, zs_supmap_kernel)
     // parse segments (one per read event, zs_core.h build_read_events), already offset to this stream: first chunk of
     // each, data end after its event's read, window base after it; and per chunk whether a read event fires at its entry
     const int32_t *seg_c0, *seg_after, *seg_base;
@@ -76,6 +77,7 @@ struct StreamDesc {
 };
 
 // zs_fast_vec_kernel's tile: the window [t0 - kFvBack, t0 + kFvTile + kFvFwd) in LDS as bytes, links and inserted bits
+constexpr int kSupSegs = 16;      // parse segments composed into one row of supmap ahead of the resolve kernel
 constexpr int kTailRecMax = 288;  // positions of a tail whose searches are done ahead (zs_tail_kernel): <= 261 - max_lazy + a few
 constexpr int kFvTile = 16384;
 constexpr int kFvBack = 32512;  // >= kMaxDist, multiple of 32

@@ -47,7 +47,7 @@ struct zs_ctx {
     hipEvent_t ev[kStCount + 1] = {};
     double stage_ms[kStCount] = {};
     uint32_t *crc_tab = nullptr;
-    DevBuf sd, st, work, geo, link, mm, maps, segmap, seg_entry, seg_symbase, seg_stale, entry, symbase, stale, syms, blk_end, blk_top, blocks, trees, info, pieces, scratch,
+    DevBuf sd, st, work, geo, link, mm, maps, segmap, supmap, seg_entry, seg_symbase, seg_stale, entry, symbase, stale, syms, blk_end, blk_top, blocks, trees, info, pieces, scratch,
         stage_in, stage_out, wr, inf_desc, inf_state, par_ps, par_st, par_work, par_cbits, par_ccnt, par_surv, par_scnt, par_cands, par_tabs, par_blocks, par_cells,
         par_windows, par_fail, run_syms, run_bits, run_scratch, run_outs, run_fail, adl_tr, adl_res, plan_blk, ins_bits, win_groups, win_sg, win_maps, win_entries;
     void *pinned = nullptr;
@@ -101,9 +101,9 @@ bool ensure_pinned(zs_ctx *c, size_t bytes) {
 
 struct Plan {
     std::vector<StreamDesc> sd;
-    std::vector<uint2> w_clear, w_adler, w_links, w_match, w_chunks, w_segs, w_blocks, w_runs;
+    std::vector<uint2> w_clear, w_adler, w_links, w_match, w_chunks, w_segs, w_sups, w_blocks, w_runs;
     int64_t n_pos = 0, n_syms = 0;
-    int64_t n_chunks = 0, n_segs = 0, n_blocks = 0, n_pieces = 0, n_runs = 0;
+    int64_t n_chunks = 0, n_segs = 0, n_sups = 0, n_blocks = 0, n_pieces = 0, n_runs = 0;
     bool any_fv = false;
     std::vector<int32_t> seg_c0, seg_after, seg_base;  // per parse segment (all streams, in seg_off order)
     std::vector<uint8_t> head;                         // per chunk (chunk_off order): a read event fires at its entry
@@ -212,6 +212,8 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
             }
         s.seg_c0 = s.seg_after = s.seg_base = nullptr, s.head = nullptr;
         pl.n_segs += s.nsegs;
+        s.sup_off = (int32_t)pl.n_sups;
+        pl.n_sups += (s.nsegs + kSupSegs - 1) / kSupSegs;
         // levels 1-3, one Write, large enough: speculative chunk runs instead of one sequential engine
         s.fast_runs = fast_par ? (int32_t)((len + kFastChunk - 1) / kFastChunk) : 0;
         s.run_off = (int32_t)pl.n_runs;
@@ -254,16 +256,19 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
             for (int64_t t = 0; t * kMatchTile <= s.body_end; t++) pl.w_match.push_back(make_uint2((unsigned)i, (unsigned)t));
             for (int k = 0; k < s.nchunks; k++) pl.w_chunks.push_back(make_uint2((unsigned)i, (unsigned)k));
             for (int k = 0; k < s.nsegs; k++) pl.w_segs.push_back(make_uint2((unsigned)i, (unsigned)k));
+            if (s.nsegs > kSupSegs)  // shorter streams are resolved row by row (zs_resolve_kernel)
+                for (int k = 0; k * kSupSegs < s.nsegs; k++) pl.w_sups.push_back(make_uint2((unsigned)i, (unsigned)k));
         }
         for (int k = 0; k < s.max_blocks; k++) pl.w_blocks.push_back(make_uint2((unsigned)i, (unsigned)k));
     }
     // ---- workspace ----
     size_t n_work = pl.w_clear.size() + pl.w_adler.size() + pl.w_links.size() + pl.w_match.size() + pl.w_chunks.size() +
-                    pl.w_segs.size() + pl.w_blocks.size() + pl.w_runs.size();
+                    pl.w_segs.size() + pl.w_sups.size() + pl.w_blocks.size() + pl.w_runs.size();
     if (!ensure(c, c->sd, sizeof(StreamDesc) * (size_t)n) || !ensure(c, c->st, sizeof(StreamState) * (size_t)n) ||
         !ensure(c, c->work, sizeof(uint2) * (n_work + 1)) || !ensure(c, c->link, 2 * (size_t)pl.n_pos + 64) ||
         !ensure(c, c->mm, 8 * (size_t)pl.n_pos + 64) ||
         !ensure(c, c->maps, 4 * (size_t)(pl.n_chunks + 1) * kSlots) || !ensure(c, c->segmap, 8 * (size_t)(pl.n_segs + 1) * kSlots) ||
+        !ensure(c, c->supmap, 8 * (size_t)(pl.n_sups + 1) * kSlots) ||
         !ensure(c, c->seg_entry, 2 * (size_t)(pl.n_segs + 2)) || !ensure(c, c->seg_symbase, 4 * (size_t)(pl.n_segs + 2)) ||
         !ensure(c, c->seg_stale, (size_t)pl.n_segs + 64) || !ensure(c, c->entry, 2 * (size_t)(pl.n_chunks + 2)) ||
         !ensure(c, c->symbase, 4 * (size_t)(pl.n_chunks + 2)) || !ensure(c, c->stale, (size_t)pl.n_chunks + 64) ||
@@ -323,7 +328,7 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
     uint8_t *hp = (uint8_t *)c->pinned;
     memcpy(hp, pl.sd.data(), sizeof(StreamDesc) * (size_t)n);
     uint2 *hw = (uint2 *)(hp + sizeof(StreamDesc) * (size_t)n);
-    size_t o_clear = 0, o_adler, o_links, o_match, o_chunks, o_segs, o_blocks, o_runs;
+    size_t o_clear = 0, o_adler, o_links, o_match, o_chunks, o_segs, o_sups, o_blocks, o_runs;
     auto put = [&](const std::vector<uint2> &v, size_t &off, size_t at) {
         off = at;
         if (!v.empty()) memcpy(hw + at, v.data(), sizeof(uint2) * v.size());
@@ -335,6 +340,7 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
     at = put(pl.w_match, o_match, at);
     at = put(pl.w_chunks, o_chunks, at);
     at = put(pl.w_segs, o_segs, at);
+    at = put(pl.w_sups, o_sups, at);
     at = put(pl.w_blocks, o_blocks, at);
     at = put(pl.w_runs, o_runs, at);
     if (geo_bytes) {
@@ -452,7 +458,7 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
                 hipLaunchKernelGGL(zs_resolve_kernel, dim3(1), dim3(1024), kResolveLds, c->aux, d_sd, d_st, dev<uint16_t>(c->link),
                                    dev<uint2>(c->mm), dev<uint32_t>(c->maps), dev<uint2>(c->segmap), dev<uint16_t>(c->seg_entry),
                                    dev<uint32_t>(c->seg_symbase), dev<uint8_t>(c->stale), dev<uint8_t>(c->seg_stale), c->crc_tab, lv,
-                                   strategy, hash_variant, sb, (int)(mm_limit > 0x7FFFFFFF ? 0x7FFFFFFF : mm_limit));
+                                   strategy, hash_variant, sb, (int)(mm_limit > 0x7FFFFFFF ? 0x7FFFFFFF : mm_limit), (const uint2 *)nullptr);
             });
             if (k == n_parts - 1) {
                 // the tail engine needs what the last resolve launch left: it runs on the first stream beside the last part's symbols
@@ -502,11 +508,17 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
     if (!pl.w_segs.empty())
         hipLaunchKernelGGL(zs_segmap_kernel, dim3((unsigned)pl.w_segs.size()), dim3(320), 0, stream, d_sd, d_work + o_segs,
                            dev<uint32_t>(c->maps), dev<uint2>(c->segmap));
+    // the segment maps composed 16 at a time, for the resolve kernel's short way through a long stream (ZS_NO_SUPMAP: without)
+    const bool use_sup = !pl.w_sups.empty() && !getenv("ZS_NO_SUPMAP");
+    if (use_sup)
+        hipLaunchKernelGGL(zs_supmap_kernel, dim3((unsigned)pl.w_sups.size()), dim3(320), 0, stream, d_sd, d_work + o_sups,
+                           dev<uint2>(c->segmap), dev<uint8_t>(c->seg_stale), dev<uint2>(c->supmap));
     mark(6);
     hipLaunchKernelGGL(zs_resolve_kernel, dim3((unsigned)n), dim3(1024), kResolveLds, stream, d_sd, d_st, dev<uint16_t>(c->link),
                        dev<uint2>(c->mm), dev<uint32_t>(c->maps), dev<uint2>(c->segmap),
                        dev<uint16_t>(c->seg_entry), dev<uint32_t>(c->seg_symbase), dev<uint8_t>(c->stale),
-                       dev<uint8_t>(c->seg_stale), c->crc_tab, lv, strategy, hash_variant, 0x7FFFFFFF, 0x7FFFFFFF);
+                       dev<uint8_t>(c->seg_stale), c->crc_tab, lv, strategy, hash_variant, 0x7FFFFFFF, 0x7FFFFFFF,
+                       use_sup ? dev<uint2>(c->supmap) : (const uint2 *)nullptr);
     mark(7);
     // fork: the tail engine (sequential, one workgroup per stream) needs only what the resolve kernel left, so it runs
     // on the second stream beside the symbol kernels
@@ -760,7 +772,7 @@ int zs_ctx_create(int device, zs_ctx **out) {
 void zs_ctx_destroy(zs_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    DevBuf *bufs[] = {&c->sd, &c->st, &c->work, &c->geo, &c->link, &c->mm, &c->maps, &c->segmap, &c->seg_entry, &c->seg_symbase, &c->seg_stale, &c->entry, &c->symbase, &c->stale, &c->syms,
+    DevBuf *bufs[] = {&c->sd, &c->st, &c->work, &c->geo, &c->link, &c->mm, &c->maps, &c->segmap, &c->supmap, &c->seg_entry, &c->seg_symbase, &c->seg_stale, &c->entry, &c->symbase, &c->stale, &c->syms,
                       &c->blk_end, &c->blk_top, &c->blocks, &c->trees, &c->info, &c->pieces, &c->scratch, &c->stage_in, &c->stage_out, &c->wr, &c->inf_desc, &c->inf_state, &c->par_ps, &c->par_st, &c->par_work, &c->par_cbits, &c->par_ccnt, &c->par_surv, &c->par_scnt,
                       &c->par_cands, &c->par_tabs, &c->par_blocks, &c->par_cells, &c->par_windows, &c->par_fail, &c->run_syms, &c->run_bits,
                       &c->run_scratch, &c->run_outs, &c->run_fail, &c->adl_tr, &c->adl_res, &c->plan_blk, &c->ins_bits, &c->win_groups, &c->win_sg, &c->win_maps, &c->win_entries};

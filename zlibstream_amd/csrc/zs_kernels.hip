@@ -712,6 +712,42 @@ __global__ __launch_bounds__(320) void zs_segmap_kernel(const StreamDesc *sd, co
     segmap[((int64_t)s.seg_off + seg) * kSlots + entry_slot] = make_uint2((uint32_t)slot | flags, total);
 }
 
+// ------------------------------------------------------------------ K3c
+// The maps of kSupSegs consecutive parse segments composed for every entry slot, all groups of all streams at once: exit
+// slot, symbols, and bit 15 when the path from that slot meets something the resolve kernel has to look at itself (a
+// refill whose loop-top and successor share a bucket, a stale segment).  The resolve kernel then follows a stream through
+// 1/16 of the rows, and its per-segment results are filled in by one thread per group (K4's first part).
+__device__ __forceinline__ uint32_t seg_row_meta(const StreamDesc &s, int seg, const uint8_t *seg_stale) {
+    // bit 0 = the segment starts with a refill (segments 1 .. kl), bit 1 = it holds stale chunks, bits 2.. = largest entry
+    // offset that is still a loop-top of the body (only the last segment limits it)
+    const int64_t cs = chunk_start(s.seg_c0[seg]);
+    int64_t lim = (int64_t)s.body_end - cs;
+    lim = lim > 511 ? 511 : lim;
+    uint32_t m = (seg >= 1 && lim >= 0) ? 1u : 0u;
+    if (seg_stale[s.seg_off + seg]) m |= 2u;
+    return m | ((uint32_t)(lim < 0 ? 0 : lim) << 2);
+}
+__global__ __launch_bounds__(320) void zs_supmap_kernel(const StreamDesc *sd, const uint2 *work, const uint2 *segmap,
+                                                        const uint8_t *seg_stale, uint2 *supmap) {
+    const uint2 w = work[blockIdx.x];
+    const StreamDesc s = sd[w.x];
+    const int g = (int)w.y;
+    if ((int)threadIdx.x >= kSlots) return;
+    int cur = threadIdx.x;
+    uint32_t cnt = 0, flag = 0;
+    for (int r = 0; r < kSupSegs; r++) {
+        const int seg = g * kSupSegs + r;
+        if (seg >= s.nsegs) break;
+        const uint2 v = segmap[((int64_t)s.seg_off + seg) * kSlots + cur];
+        const uint32_t m = seg_row_meta(s, seg, seg_stale);
+        const bool fires = (m & 1u) && (uint32_t)(cur <= 256 ? cur : 0) <= (m >> 2);
+        flag |= (m & 2u) | ((fires && (v.x & kMapEqualBit)) ? 1u : 0u);
+        cur = (int)(v.x & 0x1FF);
+        cnt += v.y;
+    }
+    supmap[((int64_t)s.sup_off + g) * kSlots + threadIdx.x] = make_uint2((uint32_t)cur | (flag ? 0x8000u : 0u), cnt);
+}
+
 constexpr int kSegBatch = 64;
 constexpr int kSegGroup = 8;  // rows composed in parallel before the sequential walk
 constexpr int kResolveLds = kSegBatch * kSlots * 8 + 4096 + kSegBatch * 12 + (kSegBatch / kSegGroup) * kSlots * 8;
@@ -727,7 +763,8 @@ __global__ __launch_bounds__(1024) void zs_resolve_kernel(const StreamDesc *sd, 
                                                          const uint32_t *maps, const uint2 *segmap,
                                                          uint16_t *seg_entry, uint32_t *seg_symbase, uint8_t *stale,
                                                          uint8_t *seg_stale, const uint32_t *crc_tab_g, LevelCfg lv,
-                                                         int strategy, int hash_variant, int seg_limit, int mm_limit) {
+                                                         int strategy, int hash_variant, int seg_limit, int mm_limit,
+                                                         const uint2 *supmap) {
     // > 64 KiB of LDS: dynamic allocation, carved by hand
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint2 *rows = (uint2 *)smem;                                  // segment-map rows of the current batch (130 KiB)
@@ -790,6 +827,80 @@ __global__ __launch_bounds__(1024) void zs_resolve_kernel(const StreamDesc *sd, 
             }
         }
     };
+    // ---- the common case first: a stream resolved in one launch whose path meets no equal-bucket refill.  The composed
+    //      rows of kSupSegs segments each (zs_supmap_kernel) are staged 64 at a time, thread 0 follows the path through them
+    //      -- 1/16 of the dependent lookups and of the bytes this one CU has to pull -- and one thread per row then fills in
+    //      its segments' entries and symbol bases from the segment maps.  Any flag on the path, and the kernel starts over the long way.
+    {
+        constexpr int kSupMax = (kSegBatch / kSegGroup) * kSlots * 8 / 8;  // entry slot + symbol base per row, in gmap's room
+        uint16_t *sup_slot = (uint16_t *)gmap;
+        uint32_t *sup_base = (uint32_t *)(sup_slot + kSupMax + (kSupMax & 1));
+        __shared__ int fp_ok;
+        __shared__ unsigned long long fp_kf;
+        const int nsup = (s.nsegs + kSupSegs - 1) / kSupSegs;
+        const bool try_fast = supmap != nullptr && ss.r_seg == 0 && ss.r_ncut == 0 && seg_limit >= s.nsegs && (int64_t)mm_limit >= (int64_t)s.body_end &&
+                              nsup <= kSupMax && s.nsegs > kSupSegs;
+        if (try_fast) {  // uniform over the workgroup
+            if (threadIdx.x == 0) fp_ok = 1, fp_kf = 0;
+            for (int b0 = 0; b0 < nsup; b0 += kSegBatch) {
+                int nrow = nsup - b0;
+                if (nrow > kSegBatch) nrow = kSegBatch;
+                __syncthreads();
+                const uint4 *src = (const uint4 *)(supmap + ((int64_t)s.sup_off + b0) * kSlots);
+                for (int i = threadIdx.x; i < nrow * kSlots / 2; i += blockDim.x) ((uint4 *)rows)[i] = src[i];
+                __syncthreads();
+                if (threadIdx.x == 0 && fp_ok) {
+                    int slot = sh_slot;
+                    uint32_t total = sh_total;
+                    if (b0 == 0) slot = ss.r_slot, total = ss.r_total;
+                    for (int i = 0; i < nrow; i++) {
+                        const uint2 e = rows[i * kSlots + slot];
+                        if (e.x & 0x8000u) {
+                            fp_ok = 0;
+                            break;
+                        }
+                        sup_slot[b0 + i] = (uint16_t)slot, sup_base[b0 + i] = total;
+                        slot = (int)(e.x & 0x1FF), total += e.y;
+                    }
+                    sh_slot = slot, sh_total = total;
+                }
+            }
+            __syncthreads();
+            if (fp_ok) {
+                for (int g = threadIdx.x; g < nsup; g += blockDim.x) {
+                    int cur = sup_slot[g];
+                    uint32_t total = sup_base[g];
+                    unsigned long long kf = 0;
+                    for (int r = 0; r < kSupSegs; r++) {
+                        const int seg = g * kSupSegs + r;
+                        if (seg >= s.nsegs) break;
+                        const uint2 v = segmap[((int64_t)s.seg_off + seg) * kSlots + cur];
+                        const uint32_t m = seg_row_meta(s, seg, seg_stale);
+                        if ((m & 1u) && (uint32_t)(cur <= 256 ? cur : 0) <= (m >> 2)) kf = ((unsigned long long)(seg + 1) << 16) | (unsigned)cur;
+                        seg_entry[s.seg_off + seg] = (uint16_t)cur;
+                        seg_symbase[s.seg_off + seg] = total;
+                        cur = (int)(v.x & 0x1FF);
+                        total += v.y;
+                    }
+                    if (kf) atomicMax(&fp_kf, kf);  // the last refill that fired
+                }
+                __syncthreads();
+                if (threadIdx.x == 0) {
+                    sh_seg = s.nsegs;
+                    if (fp_kf) {
+                        const int kf = (int)(fp_kf >> 16) - 1, ks = (int)(fp_kf & 0xFFFF);
+                        const int64_t cs = chunk_start(s.seg_c0[kf]);
+                        sh_kfired = kf, sh_preins = (int)((ks <= 256 ? cs + ks : cs) + 1);
+                    }
+                }
+                __syncthreads();
+            } else {
+                __syncthreads();
+                if (threadIdx.x == 0) sh_seg = ss.r_seg, sh_slot = ss.r_slot, sh_total = ss.r_total;
+                __syncthreads();
+            }
+        }
+    }
     // cuts of an earlier launch whose repair had to stop where the match records ended
     {
         const int nc = ss.r_ncut;
@@ -809,6 +920,7 @@ __global__ __launch_bounds__(1024) void zs_resolve_kernel(const StreamDesc *sd, 
         if (threadIdx.x == 0) ss.r_ncut = keep;
     }
     for (;;) {
+        if (sh_seg >= nseg) break;  // the composed rows have done it all (or there is nothing to do)
         // ---- stage the next kSegBatch segment-map rows (coalesced), then thread 0 follows the path through them
         //      (one LDS lookup per segment; its per-segment results go out coalesced afterwards); it stops early
         //      when a refill needs the whole workgroup ----
@@ -819,17 +931,7 @@ __global__ __launch_bounds__(1024) void zs_resolve_kernel(const StreamDesc *sd, 
             const uint4 *src = (const uint4 *)(segmap + ((int64_t)s.seg_off + seg0) * kSlots);  // kSlots is even: 16-byte aligned
             for (int i = threadIdx.x; i < nrow * kSlots / 2; i += blockDim.x) ((uint4 *)rows)[i] = src[i];
         }
-        if (threadIdx.x < nrow) {
-            // per row: bit 0 = the segment starts with a refill (segments 1 .. kl), bit 1 = it holds stale chunks,
-            // bits 2.. = largest entry offset that is still a loop-top of the body (only the last segment limits it)
-            const int seg = seg0 + (int)threadIdx.x;
-            const int64_t cs = chunk_start(s.seg_c0[seg]);
-            int64_t lim = (int64_t)s.body_end - cs;
-            lim = lim > 511 ? 511 : lim;
-            uint32_t m = (seg >= 1 && lim >= 0) ? 1u : 0u;
-            if (seg_stale[s.seg_off + seg]) m |= 2u;
-            row_meta[threadIdx.x] = m | ((uint32_t)(lim < 0 ? 0 : lim) << 2);
-        }
+        if (threadIdx.x < nrow) row_meta[threadIdx.x] = seg_row_meta(s, seg0 + (int)threadIdx.x, seg_stale);
         __syncthreads();
         // ---- compose every group of kSegGroup rows for all slots in parallel: exit slot, symbols, and whether the
         //      path from that slot meets anything the sequential walk must look at (an equal-bucket refill, a stale row)
