@@ -355,6 +355,13 @@ def test_inflate_block_parallel_path_on_foreign_large_streams(engine):
     got = engine.inflate_batch(cases, [len(w) for w in want])
     for i, (g_, w_) in enumerate(zip(got, want)):
         assert g_ == w_, (i, len(g_), len(w_))
+    # the chain of a stream's blocks is found without a walk when the finder reported them all (zs_inf_chain_par_kernel:
+    # the first three cases and the zeros) and by the walking kernel otherwise; forced to walk, the same bytes
+    os.environ["ZS_INF_CHAIN_WALK"] = "1"
+    try:
+        assert engine.inflate_batch(cases, [len(w) for w in want]) == want
+    finally:
+        del os.environ["ZS_INF_CHAIN_WALK"]
     # a corrupted byte in the middle of a large stream is a data error here as it is in zlib (message classes are covered
     # by test_inflate_errors_match_reference_messages)
     bad = bytearray(cases[1])

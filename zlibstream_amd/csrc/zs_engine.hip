@@ -754,6 +754,7 @@ int zs_ctx_create(int device, zs_ctx **out) {
         hipFuncSetAttribute((const void *)zs_fast_run_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kTailLds) != hipSuccess ||
         hipFuncSetAttribute((const void *)zs_fast_vec_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kFvLds) != hipSuccess ||
         hipFuncSetAttribute((const void *)zs_inf_window_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kWinMapLds) != hipSuccess ||
+        hipFuncSetAttribute((const void *)zs_inf_chain_par_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kChainParLds) != hipSuccess ||
         hipFuncSetAttribute((const void *)zs_inflate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kInfLds) != hipSuccess) {
         zs_ctx_destroy(c);
         return ZS_MEM_ERROR;
@@ -1013,8 +1014,12 @@ bool run_inflate_par(zs_ctx *c, const std::vector<int> &idx, const void *const *
     mark(2);
     // measured blocks carry checkpoints: they are decoded by sub-blocks, one lane each
     const bool lane_decode = !w.empty() && !wave_measure && !getenv("ZS_INF_WAVE_DECODE");
+    const bool chain_par = !getenv("ZS_INF_CHAIN_WALK");
+    if (chain_par)
+        hipLaunchKernelGGL(zs_inf_chain_par_kernel, dim3((unsigned)m), dim3(1024), kChainParLds, stream, d_ps, d_st, dev<ParCand>(c->par_cands),
+                           dev<ParBlock>(c->par_blocks), lane_decode ? 1 : 0);
     hipLaunchKernelGGL(zs_inf_chain_kernel, dim3((unsigned)m), dim3(64), 0, stream, d_ps, d_st, dev<ParCand>(c->par_cands),
-                       dev<ParBlock>(c->par_blocks), lane_decode ? 1 : 0);
+                       dev<ParBlock>(c->par_blocks), lane_decode ? 1 : 0, chain_par ? 1 : 0);
     mark(3);
     ZS_HIP(c, hipMemcpyAsync(st.data(), d_st, sizeof(ParState) * (size_t)m, hipMemcpyDeviceToHost, stream));
     ZS_HIP(c, hipStreamSynchronize(stream));

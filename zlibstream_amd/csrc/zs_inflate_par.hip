@@ -839,12 +839,131 @@ __global__ __launch_bounds__(64) void zs_inf_measure_sync_kernel(const ParStream
 }
 
 // ------------------------------------------------------------------ C
+// The chain of a stream's blocks without the walk, for the stream whose blocks the finder has all reported (dynamic blocks:
+// everything this library's own deflate writes at levels >= 1 on text): every measured candidate looks up the candidate
+// that starts where it ends (binary search over the sorted header offsets, in LDS), the candidates reachable from the one
+// at bit 16 are marked by pointer doubling (15 rounds for <= 16 Ki candidates), and since a block starts after the one
+// before it, the chain's order is the candidates' order: block numbers and output offsets are prefix sums over the marked
+// ones.  Anything else -- a block the finder did not report, a measure that failed, too many candidates -- leaves
+// nblk = -1 and zs_inf_chain_kernel walks the stream as before.
+constexpr int kChainParMax = 16384;
+constexpr int kChainParLds = kChainParMax * 9 + 64;
+__global__ __launch_bounds__(1024) void zs_inf_chain_par_kernel(const ParStream *ps, ParState *st, const ParCand *cands, ParBlock *blocks,
+                                                                int lane_decode) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint32_t *bits = (uint32_t *)smem;              // header bit offsets; later the second jump array
+    int32_t *jump = (int32_t *)(bits + kChainParMax);
+    uint8_t *reach = (uint8_t *)(jump + kChainParMax);
+    __shared__ int sh_fail;
+    __shared__ int64_t w_bytes[16];
+    __shared__ int w_cnt[16];
+    const ParStream s = ps[blockIdx.x];
+    ParState &ss = st[blockIdx.x];
+    if (!ss.ok) return;
+    const int n = ss.ncand, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const ParCand *cd = cands + s.cand_off;
+    bool can = n >= 1 && n <= kChainParMax && s.in_len >= 6 && s.in_len < ((int64_t)1 << 28);
+    // zlib header (Inflate.cs:120-170): anything unusual is the walking kernel's to classify
+    if (can && ((s.in[0] & 0x0F) != 8 || (s.in[0] >> 4) > 7 || (((unsigned)s.in[0] << 8) + s.in[1]) % 31 != 0 || (s.in[1] & 0x20))) can = false;
+    if (!can) {
+        if (tid == 0) ss.nblk = -1;
+        return;
+    }
+    if (tid == 0) sh_fail = 0;
+    for (int i = tid; i < n; i += 1024) bits[i] = (uint32_t)cd[i].bit, reach[i] = 0;
+    __syncthreads();
+    // successor of every candidate: -1 none, itself for a final block
+    int bad = 0;
+    for (int i = tid; i < n; i += 1024) {
+        const ParCand q = cd[i];
+        if (i + 1 < n && bits[i] >= bits[i + 1]) bad = 1;  // the offsets must ascend
+        int nx = -1;
+        if (q.ok && q.bfinal) nx = i;
+        else if (q.ok) {
+            const uint32_t e = (uint32_t)q.end_bit;
+            int lo = i + 1, hi = n;
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (bits[mid] < e) lo = mid + 1;
+                else hi = mid;
+            }
+            if (lo < n && bits[lo] == e && cd[lo].ok) nx = lo;
+        }
+        jump[i] = nx;
+    }
+    if (tid == 0 && !(bits[0] == 16u && cd[0].ok)) bad = 1;  // the first block starts behind the 2-byte header
+    if (bad) sh_fail = 1;
+    __syncthreads();
+    if (sh_fail) {
+        if (tid == 0) ss.nblk = -1;
+        return;
+    }
+    // reachable from candidate 0: round k marks what lies 2^k steps behind a marked candidate, then the jumps double
+    int32_t *ja = jump, *jb = (int32_t *)bits;
+    if (tid == 0) reach[0] = 1;
+    __syncthreads();
+    for (int r = 0; r < 15; r++) {
+        for (int i = tid; i < n; i += 1024)
+            if (reach[i] && ja[i] >= 0) reach[ja[i]] = 1;
+        for (int i = tid; i < n; i += 1024) {
+            const int j = ja[i];
+            jb[i] = j < 0 ? -1 : (ja[j] >= 0 ? ja[j] : j);  // a candidate without a successor keeps its -1: a dead end
+        }
+        __syncthreads();
+        int32_t *t = ja;
+        ja = jb, jb = t;
+    }
+    // block numbers and output offsets: prefix sums over the marked candidates, 16 consecutive ones per thread
+    const int per = (n + 1023) / 1024, i0 = tid * per, i1 = i0 + per < n ? i0 + per : n;
+    int cnt = 0, dead = 0;
+    int64_t bytes = 0;
+    for (int i = i0; i < i1; i++)
+        if (reach[i]) {
+            cnt++;
+            bytes += cd[i].out_bytes;
+            if (ja[i] < 0) dead = 1;
+        }
+    int pc = cnt;
+    int64_t pb = bytes;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int c2 = __shfl_up(pc, o);
+        const int64_t b2 = __shfl_up(pb, o);
+        if (lane >= o) pc += c2, pb += b2;
+    }
+    if (lane == 63) w_cnt[wave] = pc, w_bytes[wave] = pb;
+    if (dead) sh_fail = 1;
+    __syncthreads();
+    int base_c = 0, tot_c = 0;
+    int64_t base_b = 0, tot_b = 0;
+    for (int k = 0; k < 16; k++) {
+        if (k < wave) base_c += w_cnt[k], base_b += w_bytes[k];
+        tot_c += w_cnt[k], tot_b += w_bytes[k];
+    }
+    if (sh_fail || tot_c < 1 || tot_c > s.max_blk || tot_b > s.out_cap) {
+        if (tid == 0) ss.nblk = -1;
+        return;
+    }
+    int nb = base_c + pc - cnt;
+    int64_t out = base_b + pb - bytes;
+    ParBlock *bl = blocks + s.blk_off;
+    for (int i = i0; i < i1; i++)
+        if (reach[i]) {
+            const ParCand q = cd[i];
+            bl[nb] = {q.bit, out, q.out_bytes, lane_decode ? q.tab : -1, 0};
+            nb++, out += q.out_bytes;
+            if (q.bfinal) ss.end_bit = q.end_bit;  // exactly one marked candidate is final: the chain ends there
+        }
+    if (tid == 0) ss.nblk = tot_c, ss.out_len = tot_b;
+}
+
 __global__ __launch_bounds__(64) void zs_inf_chain_kernel(const ParStream *ps, ParState *st, const ParCand *cands, ParBlock *blocks,
-                                                          int lane_decode) {
+                                                          int lane_decode, int tried) {
     __shared__ ParLds L;
     const ParStream s = ps[blockIdx.x];
     ParState &ss = st[blockIdx.x];
     if (!ss.ok) return;
+    if (tried && ss.nblk >= 1) return;  // zs_inf_chain_par_kernel has done it
     const ParCand *cd = cands + s.cand_off;
     ParBlock *bl = blocks + s.blk_off;
     const int ncand = ss.ncand;
