@@ -1109,9 +1109,26 @@ __global__ __launch_bounds__(64) void zs_inf_decode_lane_kernel(const ParStream 
         // many of its lanes take it; as a loop inside the match it ran as often as the wave's longest match needed).
         int cp_left = 0, cp_sp0 = 0, cp_off = 0, cp_dist = 1;
         const int sub_mark = kSubMarkBase - 1 + S;  // sub-block marker of source position sp: sub_mark - sp
+        // Literals wait in two registers, up to 8 cells for positions [pos - lb_n, pos), and leave as one 16-byte store:
+        // a 2-byte store per literal had the L2 evict sectors it had a few bytes of and write them to HBM again and again
+        // (14.8 GB written per GiB of output, PMC).  A store of fewer than 8 waiting cells overshoots with zeros, like the
+        // match stores below: cells the lane itself writes next.  They are flushed before a match, which may read them.
+        uint64_t lb_lo = 0, lb_hi = 0;
+        int lb_n = 0;
+        auto flush_lits = [&]() {
+            if (lb_n == 0) return;
+            const int p0 = pos - lb_n;
+            if (p0 + 8 <= E) {
+                *(uint4 *)(o16 + p0) = make_uint4((uint32_t)lb_lo, (uint32_t)(lb_lo >> 32), (uint32_t)lb_hi, (uint32_t)(lb_hi >> 32));
+            } else {
+                for (int u = 0; u < lb_n; u++) o16[p0 + u] = (uint16_t)((u < 4 ? lb_lo >> (16 * u) : lb_hi >> (16 * (u - 4))) & 0xFFFFu);
+            }
+            lb_lo = lb_hi = 0, lb_n = 0;
+        };
         while (!bad && (!fin || cp_left > 0)) {
             if (cp_left == 0) {
                 if (b.tell() >= bit1) {
+                    flush_lits();
                     fin = true;
                     continue;
                 }
@@ -1132,9 +1149,13 @@ __global__ __launch_bounds__(64) void zs_inf_decode_lane_kernel(const ParStream 
                         bad = true;
                         break;
                     }
-                    o16[pos++] = (uint16_t)sym;
+                    const uint64_t v = (uint64_t)(uint32_t)sym << (16 * (lb_n & 3));
+                    lb_lo |= lb_n < 4 ? v : 0, lb_hi |= lb_n < 4 ? 0 : v;
+                    lb_n++, pos++;
+                    if (lb_n == 8) flush_lits();
                     continue;
                 }
+                flush_lits();
                 if (sym == 256) {
                     eob = true;
                     fin = true;
