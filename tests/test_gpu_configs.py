@@ -397,3 +397,28 @@ def test_png_filter_kernel_and_the_deflate_of_its_rows(engine, oracle, ftype):
         z = d_z[:n].cpu().numpy().tobytes()
         assert z == oracle.compress(got, 6)
         assert zlib.decompress(z) == got
+
+
+def test_z_stream_adler_field_after_every_write(engine):
+    """ZLibStream.Adler is updated as ReadBuffer copies the caller's bytes (ZlibStream.cs:197-222): zs_deflate reports it
+    after every call.  Pieces of every size class of the host routine (scalar tail, 8-byte steps, 32-byte AVX2 blocks, the
+    4 KiB reduction boundary) against zlib.adler32 of what has been written so far."""
+    lib = engine._lib
+    import numpy as np
+    data = np.random.default_rng(9).integers(0, 256, 3_000_000, dtype=np.uint8).tobytes()
+    z = lib.zs_deflate_init(engine.handle, 1, 0, 15, 8, 0)
+    assert z
+    try:
+        src = ctypes.create_string_buffer(data, len(data))
+        out = ctypes.create_string_buffer(1 << 16)
+        adler, tin, tout = ctypes.c_uint32(1), ctypes.c_int64(0), ctypes.c_int64(0)
+        off = 0
+        for n in (0, 1, 7, 8, 9, 31, 32, 33, 63, 64, 65, 100, 4095, 4096, 4097, 5551, 5552, 5553, 65536, 1_000_003, 1_234_567):
+            avail_in, avail_out = ctypes.c_int32(n), ctypes.c_int32(1 << 16)
+            rc = lib.zs_deflate(z, ctypes.addressof(src) + off, ctypes.byref(avail_in), ctypes.addressof(out), ctypes.byref(avail_out), 0,
+                                ctypes.byref(adler), ctypes.byref(tin), ctypes.byref(tout))
+            assert rc == 0 and avail_in.value == 0
+            off += n
+            assert tin.value == off and adler.value == zlib.adler32(data[:off]), (n, off)
+    finally:
+        lib.zs_deflate_end(z)
