@@ -526,7 +526,13 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
         hipLaunchKernelGGL(zs_fast_vec_kernel, dim3((unsigned)n), dim3(1024), kFvLds, stream, d_sd, d_st, dev<uint16_t>(c->link),
                            dev<uint32_t>(c->syms), dev<int32_t>(c->blk_end), dev<int32_t>(c->blk_top), lv, strategy);
     const bool tail_late = ro && !ro->final_run;  // the engine is left for a later run: it needs K5's symbols and block ends
-    if (!tail_late) {
+    // Beside the symbol kernel the tails of a few streams are free; those of hundreds are not: 256 tail workgroups of 1024
+    // threads and 133 KiB of LDS each, one per CU, cost the symbol kernel of 256 x 1 MiB 3 ms (6.8 against 3.9), more than
+    // they take alone (0.5).  From 64 streams of 256 KiB or more on the tails run behind the symbols instead (thousands of
+    // small streams are the other way round: 16 rounds of tails, a short symbol kernel -- beside each other 18.9 ms for
+    // 4096 x 32 KiB, one after the other 20.1).
+    const bool tail_serial = !tail_late && n >= 64 && pl.n_pos / n >= (256 << 10) && !getenv("ZS_TAIL_FORK");
+    if (!tail_late && !tail_serial) {
         ZS_HIP(c, hipEventRecord(c->ev_fork, stream));
         ZS_HIP(c, hipStreamWaitEvent(c->aux, c->ev_fork, 0));
         hipLaunchKernelGGL(zs_tail_kernel, dim3((unsigned)n), dim3(1024), kTailLds, c->aux, d_sd, d_st, dev<uint16_t>(c->link),
@@ -547,7 +553,11 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
                            dev<uint32_t>(c->symbase), dev<uint32_t>(c->syms), dev<int32_t>(c->blk_end), dev<int32_t>(c->blk_top),
                            c->crc_tab, lv, strategy, hash_variant);
     mark(9);
-    if (!tail_late) ZS_HIP(c, hipStreamWaitEvent(stream, c->ev_join, 0));
+    if (tail_serial)
+        hipLaunchKernelGGL(zs_tail_kernel, dim3((unsigned)n), dim3(1024), kTailLds, stream, d_sd, d_st, dev<uint16_t>(c->link),
+                           dev<uint32_t>(c->syms), dev<int32_t>(c->blk_end), dev<int32_t>(c->blk_top), dev<BlockRec>(c->blocks),
+                           dev<uint8_t>(c->scratch), c->crc_tab, lv, strategy, hash_variant, level);
+    else if (!tail_late) ZS_HIP(c, hipStreamWaitEvent(stream, c->ev_join, 0));
     hipLaunchKernelGGL(zs_body_blocks_kernel, dim3((unsigned)n), dim3(256), 0, stream, d_sd, d_st, dev<int32_t>(c->blk_end),
                        dev<int32_t>(c->blk_top), dev<BlockRec>(c->blocks));
     if (tail_late)
