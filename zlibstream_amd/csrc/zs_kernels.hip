@@ -777,6 +777,7 @@ __global__ __launch_bounds__(1024) void zs_resolve_kernel(const StreamDesc *sd, 
     __shared__ uint32_t g_base[kSegBatch / kSegGroup];
     __shared__ int sh_kf, sh_ks;
     __shared__ int sh_seg, sh_slot, sh_scan, sh_kfired, sh_preins;
+    __shared__ int b_seg0, b_nrow, b_groups;  // the batch of rows in LDS: first segment, rows, whether its composed groups may be used
     __shared__ uint32_t sh_total;
     const StreamDesc s = sd[blockIdx.x];
     StreamState &ss = st[blockIdx.x];
@@ -784,7 +785,8 @@ __global__ __launch_bounds__(1024) void zs_resolve_kernel(const StreamDesc *sd, 
     // seg_limit / mm_limit (one long stream run part by part, else "everything"): segments below seg_limit have their maps,
     // positions up to mm_limit their match records; the kernel goes on from where the launch before stopped
     if (threadIdx.x == 0)
-        sh_seg = ss.r_seg, sh_slot = ss.r_slot, sh_total = ss.r_total, sh_kfired = ss.r_kfired, sh_preins = ss.r_preins1 - 1, sh_scan = 0;
+        sh_seg = ss.r_seg, sh_slot = ss.r_slot, sh_total = ss.r_total, sh_kfired = ss.r_kfired, sh_preins = ss.r_preins1 - 1, sh_scan = 0, b_seg0 = 0,
+        b_nrow = 0, b_groups = 0;
     __syncthreads();
     if (s.body_end < 0) {
         if (threadIdx.x == 0) ss.tail_p = 0, ss.tail_kind = kR, ss.tail_pend = 0, ss.k_done = 0, ss.preins = -1, ss.body_syms = 0;
@@ -798,23 +800,93 @@ __global__ __launch_bounds__(1024) void zs_resolve_kernel(const StreamDesc *sd, 
     // The reference leaves prev[e] = e + 1 at an equal-bucket refill loop-top e: everything older than e is hidden from
     // later walks through that bucket.  link[e] is cut; positions in (from, to] whose recorded winner lies behind the cut are
     // walked again and their chunks marked stale.
+    // Two passes.  First every thread looks at its (up to) 32 positions of (from, to]: is the position in the cut's bucket
+    // and does its recorded winner lie behind the cut?  Straight-line code over loads that do not depend on each other, and
+    // the bucket test is "the same four bytes as at e" before it is a hash: on zeros or runs every refill is such a cut and
+    // every position behind it is in its bucket (one dependent load and one CRC per position were 42 us per cut, 86 ms for
+    // 64 MiB of zeros).  Only if some position has to be walked again do the window's bytes and links go into LDS -- the
+    // room of the staged rows, which are then staged again -- and the walks run from there (a run's long matches out of
+    // global memory: 0.25 ms per cut).
     auto repair = [&](int64_t e, int64_t from, int64_t to) {
-        const uint32_t B = acc.bucket(e);
-        for (int64_t p = from + 1 + threadIdx.x; p <= to; p += blockDim.x) {
-            if (acc.bucket(p) != B) continue;
+        const gcbytes in = as_global(s.in);
+        const int64_t nn = s.n;
+        const uint32_t vB = *(gcu32u)(in + e + 2);  // e + 5 < n: e is a loop-top of the body
+        const uint32_t B = dev_bucket(tab, vB, hash_variant);
+        uint32_t todo = 0;
+        const int64_t pb = from + 1 + threadIdx.x;
+#pragma unroll
+        for (int u = 0; u < 32; u++) {
+            const int64_t p = pb + (int64_t)u * blockDim.x;
+            const bool in_range = p <= to;
+            const int64_t pc = in_range ? p : to;
+            const uint2 rec = a[pc];
+            const uint32_t v = *(gcu32u)(in + pc + 2);
+            const uint32_t x = rec.x & kRecMask, y = rec.y;
+            const bool dirty = (x && pc - match_dist(x) < e) || (y && pc - match_dist(y) < e);
+            bool inb = v == vB;
+            if (in_range && dirty && !inb) inb = dev_bucket(tab, v, hash_variant) == B;
+            todo |= (in_range && dirty && inb) ? 1u << u : 0u;
+        }
+        if (!__syncthreads_or(todo != 0)) return;  // nothing behind the cut was seen through it: the staged rows stay
+        // index = position - o with o = (e - 1) rounded down to 16: the cut position has an index >= 1, so that walk_matches'
+        // "never position 0" holds as it stands, and both arrays move 16 bytes per lane and step
+        uint8_t *rb = (uint8_t *)rows;
+        const int64_t o = (e - 1) & ~15LL;
+        const int ie = (int)(e - o);
+        const int nby = ((int)(to - o) + 1 + 272 + 15) & ~15;
+        uint16_t *rl = (uint16_t *)(rb + nby);
+        if ((((uintptr_t)in) & 15) == 0) {
+            for (int i = threadIdx.x * 16; i < nby; i += blockDim.x * 16) {
+                const int64_t q = o + i;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (q + 16 <= nn) {
+                    const u32x4 t = *(gcu32x4)(in + q);
+                    v = make_uint4(t[0], t[1], t[2], t[3]);
+                } else {
+                    uint32_t t[4] = {0, 0, 0, 0};
+                    for (int k = 0; k < 16; k++)
+                        if (q + k < nn) t[k >> 2] |= (uint32_t)in[q + k] << (8 * (k & 3));
+                    v = make_uint4(t[0], t[1], t[2], t[3]);
+                }
+                *(uint4 *)(rb + i) = v;
+            }
+        } else {
+            for (int i = threadIdx.x * 4; i < nby; i += blockDim.x * 4) {
+                const int64_t q = o + i;
+                uint32_t v = 0;
+                if (q + 4 <= nn) v = *(gcu32u)(in + q);
+                else
+                    for (int k = 0; k < 4; k++)
+                        if (q + k < nn) v |= (uint32_t)in[q + k] << (8 * (k & 3));
+                *(uint32_t *)(rb + i) = v;
+            }
+        }
+        const int nlk = ((int)(to - o) + 1 + 7) & ~7;  // links of [o, to], 8 per lane and step (the array has room behind a stream's end)
+        for (int i = threadIdx.x * 8; i < nlk; i += blockDim.x * 8) *(uint4 *)(rl + i) = *(const uint4 *)(lk + o + i);
+        __syncthreads();
+        for (int i = threadIdx.x; i <= ie; i += blockDim.x) rl[i] = 0;  // link[e] is cut; nothing below it is reached
+        __syncthreads();
+        auto lkf = [rl](int64_t q) { return (int)rl[q]; };  // positions relative to o from here on
+        auto lcp = [rb](int64_t u, int64_t v) {
+            int len = 0;
+            while (len < kMaxMatch) {
+                const uint64_t x = lds_u64(rb, (int)u + len) ^ lds_u64(rb, (int)v + len);
+                if (x) {
+                    len += (int)(__builtin_ctzll(x) >> 3);
+                    break;
+                }
+                len += 8;
+            }
+            return len < kMaxMatch ? len : kMaxMatch;
+        };
+        while (todo) {
+            const int u = __builtin_ctz(todo);
+            todo &= todo - 1;
+            const int64_t p = pb + (int64_t)u * blockDim.x;
             const uint2 old = a[p];
-            uint32_t x = old.x & kRecMask, y = old.y;
-            bool dirty = (x && p - match_dist(x) < e) || (y && p - match_dist(y) < e);
-            if (!dirty) continue;
-            auto lkf = [lk](int64_t q) { return (int)lk[q]; };
-            const gcbytes in = as_global(s.in);
-            auto lcp = [in](int64_t u, int64_t v) {
-                int len = 0;
-                while (len < kMaxMatch && in[u + len] == in[v + len]) len++;
-                return len;
-            };
+            const uint32_t x = old.x & kRecMask, y = old.y;
             uint32_t nx, ny;
-            walk_matches(lkf, lcp, p, lv, nx, ny);
+            walk_matches(lkf, lcp, p - o, lv, nx, ny);  // the chain ends at e: distances are the same
             if (nx != x || ny != y) {
                 a[p] = make_uint2(nx | (old.x & ~kRecMask), ny);
                 int cp = chunk_of(p);
@@ -826,6 +898,8 @@ __global__ __launch_bounds__(1024) void zs_resolve_kernel(const StreamDesc *sd, 
                 }
             }
         }
+        __syncthreads();
+        if (threadIdx.x == 0) b_nrow = 0;  // the rows are gone: the next batch is staged afresh
     };
     // ---- the common case first: a stream resolved in one launch whose path meets no equal-bucket refill.  The composed
     //      rows of kSupSegs segments each (zs_supmap_kernel) are staged 64 at a time, thread 0 follows the path through them
@@ -919,23 +993,40 @@ __global__ __launch_bounds__(1024) void zs_resolve_kernel(const StreamDesc *sd, 
         __syncthreads();
         if (threadIdx.x == 0) ss.r_ncut = keep;
     }
+#ifdef ZS_FV_PROF
+    long long kp[6] = {0, 0, 0, 0, 0, 0}, kt = wall_clock64();
+    int kiter = 0;
+#define K4_PF(i) { const long long now_ = wall_clock64(); kp[i] += now_ - kt; kt = now_; }
+#else
+#define K4_PF(i)
+#endif
     for (;;) {
         if (sh_seg >= nseg) break;  // the composed rows have done it all (or there is nothing to do)
+#ifdef ZS_FV_PROF
+        kiter++;
+        kt = wall_clock64();
+#endif
         // ---- stage the next kSegBatch segment-map rows (coalesced), then thread 0 follows the path through them
         //      (one LDS lookup per segment; its per-segment results go out coalesced afterwards); it stops early
         //      when a refill needs the whole workgroup ----
-        const int seg0 = sh_seg;
+        // (after a repair the walk goes on inside the batch that is staged already -- data whose every refill is an equal-bucket
+        // one, zeros or runs, would otherwise stage 130 KiB per segment: the rows keep, their flags are read again because the
+        // repair may have marked segments stale, and the composed groups are not used for the rest of the batch)
+        const bool resume = sh_scan && b_nrow > 0 && sh_seg >= b_seg0 && sh_seg < b_seg0 + b_nrow;
+        const int seg0 = resume ? b_seg0 : sh_seg;
         int nrow = nseg - seg0;
         if (nrow > kSegBatch) nrow = kSegBatch;
-        {
+        if (!resume) {
             const uint4 *src = (const uint4 *)(segmap + ((int64_t)s.seg_off + seg0) * kSlots);  // kSlots is even: 16-byte aligned
             for (int i = threadIdx.x; i < nrow * kSlots / 2; i += blockDim.x) ((uint4 *)rows)[i] = src[i];
         }
         if (threadIdx.x < nrow) row_meta[threadIdx.x] = seg_row_meta(s, seg0 + (int)threadIdx.x, seg_stale);
         __syncthreads();
+        if (threadIdx.x == 0) b_seg0 = seg0, b_nrow = nrow, b_groups = resume ? 0 : 1;
+        K4_PF(0);
         // ---- compose every group of kSegGroup rows for all slots in parallel: exit slot, symbols, and whether the
         //      path from that slot meets anything the sequential walk must look at (an equal-bucket refill, a stale row)
-        const int ngroup = (nrow + kSegGroup - 1) / kSegGroup;
+        const int ngroup = resume ? 0 : (nrow + kSegGroup - 1) / kSegGroup;
         for (int t = threadIdx.x; t < ngroup * kSlots; t += blockDim.x) {
             const int g = t / kSlots;
             int cur = t - g * kSlots;
@@ -955,16 +1046,18 @@ __global__ __launch_bounds__(1024) void zs_resolve_kernel(const StreamDesc *sd, 
         __syncthreads();
         if (threadIdx.x < kSegBatch / kSegGroup) g_fast[threadIdx.x] = 0;
         __syncthreads();
+        K4_PF(1);
         if (threadIdx.x == 0) {
-            int seg = seg0, slot = sh_slot;
+            int seg = resume ? sh_seg : seg0, slot = sh_slot;
             uint32_t total = sh_total;
             bool scanned = sh_scan != 0;  // the pending segment's cut has just been applied
+            const bool groups = b_groups != 0;
             int kf = -1, kslot = 0;       // last refill that fired among the rows walked one by one
             const bool cuts = strategy != kHuffmanOnly;
             bool stop = false;
             while (seg < seg0 + nrow) {
                 const int i = seg - seg0;
-                if (!scanned && i % kSegGroup == 0) {
+                if (groups && !scanned && i % kSegGroup == 0) {
                     // a whole group at once when nothing on the path from `slot` needs attention; its per-row results are
                     // filled in afterwards, one lane per group
                     const int g = i / kSegGroup;
@@ -1015,6 +1108,7 @@ __global__ __launch_bounds__(1024) void zs_resolve_kernel(const StreamDesc *sd, 
             sh_seg = seg, sh_slot = slot, sh_total = total;
         }
         __syncthreads();
+        K4_PF(2);
         if (threadIdx.x < kSegBatch / kSegGroup && g_fast[threadIdx.x]) {
             const int g = threadIdx.x;
             int cur = g_slot[g], kf = -1, ks = 0;
@@ -1048,6 +1142,7 @@ __global__ __launch_bounds__(1024) void zs_resolve_kernel(const StreamDesc *sd, 
             seg_entry[s.seg_off + seg0 + i] = out_slot[i];
             seg_symbase[s.seg_off + seg0 + i] = out_base[i];
         }
+        K4_PF(3);
         if (!sh_scan) {
             if (sh_seg >= nseg) break;
             continue;
@@ -1071,7 +1166,12 @@ __global__ __launch_bounds__(1024) void zs_resolve_kernel(const StreamDesc *sd, 
             __threadfence_block();
         }
         __syncthreads();
+        K4_PF(4);
     }
+#ifdef ZS_FV_PROF
+    if (threadIdx.x == 0 && blockIdx.x == 0 && kiter > 4)
+        printf("K4PROF iterations=%d ticks: stage+meta=%lld compose=%lld walk=%lld fill+flush=%lld repair=%lld\n", kiter, kp[0], kp[1], kp[2], kp[3], kp[4]);
+#endif
     if (threadIdx.x == 0) ss.r_seg = sh_seg, ss.r_slot = sh_slot, ss.r_total = sh_total, ss.r_kfired = sh_kfired, ss.r_preins1 = sh_preins + 1;
     if (sh_seg < s.nsegs) return;  // more segments to come in a later launch
     if (threadIdx.x == 0) {
