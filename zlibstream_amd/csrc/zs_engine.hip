@@ -47,7 +47,7 @@ struct zs_ctx {
     hipEvent_t ev[kStCount + 1] = {};
     double stage_ms[kStCount] = {};
     uint32_t *crc_tab = nullptr;
-    DevBuf sd, st, work, geo, link, mm, maps, segmap, supmap, seg_entry, seg_symbase, seg_stale, entry, symbase, stale, syms, blk_end, blk_top, blocks, trees, info, pieces, scratch,
+    DevBuf sd, st, work, geo, link, mm, maps, chunk_far, segmap, supmap, seg_entry, seg_symbase, seg_stale, entry, symbase, stale, syms, blk_end, blk_top, blocks, trees, info, pieces, scratch,
         stage_in, stage_out, wr, inf_desc, inf_state, par_ps, par_st, par_work, par_cbits, par_ccnt, par_surv, par_scnt, par_cands, par_tabs, par_blocks, par_cells,
         par_windows, par_fail, run_syms, run_bits, run_scratch, run_outs, run_fail, adl_tr, adl_res, plan_blk, ins_bits, win_groups, win_sg, win_maps, win_entries;
     void *pinned = nullptr;
@@ -268,7 +268,7 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
         !ensure(c, c->work, sizeof(uint2) * (n_work + 1)) || !ensure(c, c->link, 2 * (size_t)pl.n_pos + 64) ||
         !ensure(c, c->mm, 8 * (size_t)pl.n_pos + 64) ||
         !ensure(c, c->maps, 4 * (size_t)(pl.n_chunks + 1) * kSlots) || !ensure(c, c->segmap, 8 * (size_t)(pl.n_segs + 1) * kSlots) ||
-        !ensure(c, c->supmap, 8 * (size_t)(pl.n_sups + 1) * kSlots) ||
+        !ensure(c, c->supmap, 8 * (size_t)(pl.n_sups + 1) * kSlots) || !ensure(c, c->chunk_far, 2 * (size_t)pl.n_chunks + 64) ||
         !ensure(c, c->seg_entry, 2 * (size_t)(pl.n_segs + 2)) || !ensure(c, c->seg_symbase, 4 * (size_t)(pl.n_segs + 2)) ||
         !ensure(c, c->seg_stale, (size_t)pl.n_segs + 64) || !ensure(c, c->entry, 2 * (size_t)(pl.n_chunks + 2)) ||
         !ensure(c, c->symbase, 4 * (size_t)(pl.n_chunks + 2)) || !ensure(c, c->stale, (size_t)pl.n_chunks + 64) ||
@@ -445,7 +445,7 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
             spans_done = spans_end > spans_done ? spans_end : spans_done, tiles_done = tiles_end > tiles_done ? tiles_end : tiles_done;
             timed(kStChunkMap, stream, [&] {
                 hipLaunchKernelGGL(zs_chunkmap_kernel, dim3((unsigned)(cb - ca)), dim3(512), 0, stream, d_sd, d_work + o_chunks + ca,
-                                   dev<uint2>(c->mm), dev<uint32_t>(c->maps), c->crc_tab, lv, strategy, hash_variant);
+                                   dev<uint2>(c->mm), dev<uint32_t>(c->maps), c->crc_tab, lv, strategy, hash_variant, dev<uint16_t>(c->chunk_far));
             });
             timed(kStSegMap, stream, [&] {
                 hipLaunchKernelGGL(zs_segmap_kernel, dim3((unsigned)(sb - sa)), dim3(320), 0, stream, d_sd, d_work + o_segs + sa,
@@ -458,7 +458,8 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
                 hipLaunchKernelGGL(zs_resolve_kernel, dim3(1), dim3(1024), kResolveLds, c->aux, d_sd, d_st, dev<uint16_t>(c->link),
                                    dev<uint2>(c->mm), dev<uint32_t>(c->maps), dev<uint2>(c->segmap), dev<uint16_t>(c->seg_entry),
                                    dev<uint32_t>(c->seg_symbase), dev<uint8_t>(c->stale), dev<uint8_t>(c->seg_stale), c->crc_tab, lv,
-                                   strategy, hash_variant, sb, (int)(mm_limit > 0x7FFFFFFF ? 0x7FFFFFFF : mm_limit), (const uint2 *)nullptr);
+                                   strategy, hash_variant, sb, (int)(mm_limit > 0x7FFFFFFF ? 0x7FFFFFFF : mm_limit), (const uint2 *)nullptr,
+                                   dev<uint16_t>(c->chunk_far));
             });
             if (k == n_parts - 1) {
                 // the tail engine needs what the last resolve launch left: it runs on the first stream beside the last part's symbols
@@ -503,7 +504,7 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
     if (!pl.w_chunks.empty())
         hipLaunchKernelGGL(zs_chunkmap_kernel, dim3((unsigned)pl.w_chunks.size()), dim3(512), 0, stream, d_sd, d_work + o_chunks,
                            dev<uint2>(c->mm), dev<uint32_t>(c->maps), c->crc_tab, lv, strategy,
-                           hash_variant);
+                           hash_variant, dev<uint16_t>(c->chunk_far));
     mark(5);
     if (!pl.w_segs.empty())
         hipLaunchKernelGGL(zs_segmap_kernel, dim3((unsigned)pl.w_segs.size()), dim3(320), 0, stream, d_sd, d_work + o_segs,
@@ -518,7 +519,7 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
                        dev<uint2>(c->mm), dev<uint32_t>(c->maps), dev<uint2>(c->segmap),
                        dev<uint16_t>(c->seg_entry), dev<uint32_t>(c->seg_symbase), dev<uint8_t>(c->stale),
                        dev<uint8_t>(c->seg_stale), c->crc_tab, lv, strategy, hash_variant, 0x7FFFFFFF, 0x7FFFFFFF,
-                       use_sup ? dev<uint2>(c->supmap) : (const uint2 *)nullptr);
+                       use_sup ? dev<uint2>(c->supmap) : (const uint2 *)nullptr, dev<uint16_t>(c->chunk_far));
     mark(7);
     // fork: the tail engine (sequential, one workgroup per stream) needs only what the resolve kernel left, so it runs
     // on the second stream beside the symbol kernels
@@ -783,7 +784,7 @@ int zs_ctx_create(int device, zs_ctx **out) {
 void zs_ctx_destroy(zs_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    DevBuf *bufs[] = {&c->sd, &c->st, &c->work, &c->geo, &c->link, &c->mm, &c->maps, &c->segmap, &c->supmap, &c->seg_entry, &c->seg_symbase, &c->seg_stale, &c->entry, &c->symbase, &c->stale, &c->syms,
+    DevBuf *bufs[] = {&c->sd, &c->st, &c->work, &c->geo, &c->link, &c->mm, &c->maps, &c->chunk_far, &c->segmap, &c->supmap, &c->seg_entry, &c->seg_symbase, &c->seg_stale, &c->entry, &c->symbase, &c->stale, &c->syms,
                       &c->blk_end, &c->blk_top, &c->blocks, &c->trees, &c->info, &c->pieces, &c->scratch, &c->stage_in, &c->stage_out, &c->wr, &c->inf_desc, &c->inf_state, &c->par_ps, &c->par_st, &c->par_work, &c->par_cbits, &c->par_ccnt, &c->par_surv, &c->par_scnt,
                       &c->par_cands, &c->par_tabs, &c->par_blocks, &c->par_cells, &c->par_windows, &c->par_fail, &c->run_syms, &c->run_bits,
                       &c->run_scratch, &c->run_outs, &c->run_fail, &c->adl_tr, &c->adl_res, &c->plan_blk, &c->ins_bits, &c->win_groups, &c->win_sg, &c->win_maps, &c->win_entries};

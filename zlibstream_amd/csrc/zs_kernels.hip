@@ -600,23 +600,32 @@ struct LdsAcc {
     }
 };
 
-__device__ __forceinline__ void stage_chunk_matches(const StreamDesc &s, int c, const uint2 *mm, int strategy, uint32_t *fk,
-                                                    uint32_t *fk4) {
+// Returns the largest distance among the thread's raw records of the chunk's own positions (K3 keeps the chunk's maximum for
+// the resolve kernel's repairs).
+__device__ __forceinline__ uint32_t stage_chunk_matches(const StreamDesc &s, int c, const uint2 *mm, int strategy, uint32_t *fk,
+                                                        uint32_t *fk4) {
     ChunkGeo g = chunk_geo(c);
     const uint2 *a = mm + s.pos_off;
     int64_t org = g.cs - 1;
+    uint32_t far = 0;
     for (int i = threadIdx.x; i < kChunk + 1; i += blockDim.x) {
         int64_t p = org + i;
         uint32_t x = 0, y = 0;
         if (p >= 1 && p <= s.body_end) {
             const uint2 v = a[p];
             x = v.x & kRecMask, y = v.y;
+            if (i >= 1) {
+                const uint32_t dx = (uint32_t)match_dist(x), dy = (uint32_t)match_dist(y);
+                far = far > dx ? far : dx;
+                far = far > dy ? far : dy;
+            }
             x = x ? filter_match(match_len(x), match_dist(x), strategy) : kNoMatch;
             y = y ? filter_match(match_len(y), match_dist(y), strategy) : kNoMatch;
         }
         fk[i] = x;
         fk4[i] = y;
     }
+    return far;
 }
 
 // ------------------------------------------------------------------ K3
@@ -624,25 +633,33 @@ __device__ __forceinline__ void stage_chunk_matches(const StreamDesc &s, int c, 
 // positions: R, L-or-XK, XK4 -- zs_core.h node_step3) builds the 1-step table in LDS, in-place jumping passes turn it
 // into node -> (exit slot, symbols), then one lane per slot reads its entry (the refill-rule positions of
 // segment-first chunks are stepped explicitly).
-__global__ __launch_bounds__(512) void zs_chunkmap_kernel(const StreamDesc *sd, const uint2 *work, const uint2 *mm,
-                                                          uint32_t *maps, const uint32_t *crc_tab_g,
-                                                          LevelCfg lv, int strategy, int hash_variant) {
-    __shared__ uint32_t fk[kChunk + 1], fk4[kChunk + 1];
-    __shared__ uint32_t tbl[kNodeExit3];
-    __shared__ uint32_t tab[1024];
-    uint2 w = work[blockIdx.x];
-    const StreamDesc s = sd[w.x];
-    const int c = (int)w.y;
-    stage_chunk_matches(s, c, mm, strategy, fk, fk4);
+// The transfer map of one chunk by the threads of a workgroup (K3's whole job; the resolve kernel calls it again for the few
+// chunks whose records a repair has changed).  fk, fk4: kChunk + 1 words each; tbl: kNodeExit3 words; tab: the CRC tables
+// (read for event chunks only; the caller has loaded them); far_word: a zeroed LDS word or nullptr.
+template <int NT>  // threads of the workgroup (compile-time: the loops below are K3's whole time)
+__device__ __forceinline__ void chunkmap_compute(const StreamDesc &s, int c, const uint2 *mm, uint32_t *maps, LevelCfg lv, int strategy, int hash_variant,
+                                                 uint32_t *fk, uint32_t *fk4, uint32_t *tbl, uint32_t *tab, uint32_t *far_word, uint16_t *chunk_far) {
+    constexpr int nt = NT;
+    uint32_t far = stage_chunk_matches(s, c, mm, strategy, fk, fk4);
+    // the largest match distance recorded in the chunk: a cut at e can only have been seen through from a chunk whose
+    // largest distance reaches back to e (zs_resolve_kernel's repair scans no others)
+    if (far_word) {
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            const uint32_t t = (uint32_t)__shfl_xor((int)far, o);
+            far = far > t ? far : t;
+        }
+        if (lane_id() == 0 && far) atomicMax(far_word, far);
+    }
     const ChunkGeo g = chunk_geo(c);
     const bool event_chunk = s.head[c] != 0;
-    if (event_chunk) load_crc_tab(tab, crc_tab_g);
     __syncthreads();
+    if (far_word && threadIdx.x == 0) chunk_far[s.chunk_off + c] = (uint16_t)*far_word;
     int64_t ce = g.ce;
     if (ce > (int64_t)s.body_end + 1) ce = (int64_t)s.body_end + 1;
     const int len = (int)(ce - g.cs);
     LdsAcc acc{as_global(s.in), fk, fk4, g.cs - 1, tab, hash_variant};
-    for (int off = threadIdx.x; off < len; off += 512) {
+    for (int off = threadIdx.x; off < len; off += nt) {
         uint32_t r0, r1, r2;
         node_step3_all(acc, g.cs + off, g.cs, ce, lv, r0, r1, r2);
         tbl[off] = r0, tbl[kChunk + off] = r1, tbl[2 * kChunk + off] = r2;
@@ -657,14 +674,15 @@ __global__ __launch_bounds__(512) void zs_chunkmap_kernel(const StreamDesc *sd, 
     for (int r = 0; r < ZS_JUMP_PASSES; r++) {
         // four nodes per thread at a time, their lookups issued together (the LDS round trips overlap); a node past the
         // end of the chunk or already at its exit looks itself up and stays as it is
-        for (int i0 = threadIdx.x; i0 < 3 * kChunk; i0 += 4 * 512) {
+        for (int i0 = threadIdx.x; i0 < 3 * kChunk; i0 += 4 * nt) {
             uint32_t v[4], w[4];
-            bool live[4];
+            bool live[4], have[4];
 #pragma unroll
             for (int k = 0; k < 4; k++) {
-                const int i = i0 + k * 512;
-                v[k] = tbl[i];
-                live[k] = (i & (kChunk - 1)) < len && node_succ(v[k]) < kNodeExit3;
+                const int i = i0 + k * nt;
+                have[k] = (3 * kChunk) % (4 * NT) == 0 || i < 3 * kChunk;
+                v[k] = tbl[have[k] ? i : 0];
+                live[k] = have[k] && (i & (kChunk - 1)) < len && node_succ(v[k]) < kNodeExit3;
             }
 #pragma unroll
             for (int k = 0; k < 4; k++) w[k] = tbl[live[k] ? node_succ(v[k]) : 0];
@@ -678,16 +696,33 @@ __global__ __launch_bounds__(512) void zs_chunkmap_kernel(const StreamDesc *sd, 
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 if (live[k]) v[k] = node_jump(v[k], w[k]);
-                if ((i0 + k * 512 & (kChunk - 1)) < len) tbl[i0 + k * 512] = v[k];
+                if (have[k] && ((i0 + k * nt) & (kChunk - 1)) < len) tbl[i0 + k * nt] = v[k];
             }
         }
         __syncthreads();
     }
     const int slot = threadIdx.x;
-    if (slot >= kSlots) return;
-    uint32_t out = 0;
-    if (slot_valid(c, slot, s.body_end)) out = chunk_exit_by_table3(acc, tbl, c, slot, event_chunk, s.body_end, lv, strategy);
-    maps[((int64_t)s.chunk_off + c) * kSlots + slot] = out;
+    if (slot < kSlots) {
+        uint32_t out = 0;
+        if (slot_valid(c, slot, s.body_end)) out = chunk_exit_by_table3(acc, tbl, c, slot, event_chunk, s.body_end, lv, strategy);
+        maps[((int64_t)s.chunk_off + c) * kSlots + slot] = out;
+    }
+}
+
+__global__ __launch_bounds__(512) void zs_chunkmap_kernel(const StreamDesc *sd, const uint2 *work, const uint2 *mm,
+                                                          uint32_t *maps, const uint32_t *crc_tab_g,
+                                                          LevelCfg lv, int strategy, int hash_variant, uint16_t *chunk_far) {
+    __shared__ uint32_t fk[kChunk + 1], fk4[kChunk + 1];
+    __shared__ uint32_t tbl[kNodeExit3];
+    __shared__ uint32_t tab[1024];
+    __shared__ uint32_t sh_far;
+    uint2 w = work[blockIdx.x];
+    const StreamDesc s = sd[w.x];
+    const int c = (int)w.y;
+    if (threadIdx.x == 0) sh_far = 0;
+    if (s.head[c] != 0) load_crc_tab(tab, crc_tab_g);
+    __syncthreads();
+    chunkmap_compute<512>(s, c, mm, maps, lv, strategy, hash_variant, fk, fk4, tbl, tab, &sh_far, chunk_far);
 }
 
 // ------------------------------------------------------------------ K3b
@@ -760,11 +795,11 @@ constexpr int kResolveLds = kSegBatch * kSlots * 8 + 4096 + kSegBatch * 12 + (kS
 // behind the cut, and marks the chunks whose matches changed; segments holding such
 // chunks are then followed chunk by chunk, stale chunks by a direct walk.
 __global__ __launch_bounds__(1024) void zs_resolve_kernel(const StreamDesc *sd, StreamState *st, uint16_t *link, uint2 *mm,
-                                                         const uint32_t *maps, const uint2 *segmap,
+                                                         uint32_t *maps, const uint2 *segmap,
                                                          uint16_t *seg_entry, uint32_t *seg_symbase, uint8_t *stale,
                                                          uint8_t *seg_stale, const uint32_t *crc_tab_g, LevelCfg lv,
                                                          int strategy, int hash_variant, int seg_limit, int mm_limit,
-                                                         const uint2 *supmap) {
+                                                         const uint2 *supmap, const uint16_t *chunk_far) {
     // > 64 KiB of LDS: dynamic allocation, carved by hand
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint2 *rows = (uint2 *)smem;                                  // segment-map rows of the current batch (130 KiB)
@@ -807,7 +842,34 @@ __global__ __launch_bounds__(1024) void zs_resolve_kernel(const StreamDesc *sd, 
     // 64 MiB of zeros).  Only if some position has to be walked again do the window's bytes and links go into LDS -- the
     // room of the staged rows, which are then staged again -- and the walks run from there (a run's long matches out of
     // global memory: 0.25 ms per cut).
-    auto repair = [&](int64_t e, int64_t from, int64_t to) {
+#ifdef ZS_FV_PROF
+    long long rp_scan = 0, rp_n = 0;
+#endif
+    __shared__ int rp_to, rp_nlist, rp_list[24];
+    __shared__ unsigned int rp_mark[24];
+    auto repair = [&](int64_t e, int64_t from, int64_t to_all) {
+#ifdef ZS_FV_PROF
+        const long long rp_t0 = wall_clock64();
+#endif
+        // a position can have seen through the cut only if its chunk's largest recorded distance reaches back to e (K3):
+        // the scan ends with the last such chunk -- on zeros and the like right behind the cut
+        if (threadIdx.x == 0) rp_to = (int)from, rp_nlist = 0;
+        if (threadIdx.x < 24) rp_mark[threadIdx.x] = 0;
+        const int c0r = chunk_of(from + 1);  // the chunks a repair can touch: c0r .. c0r + 17
+        __syncthreads();
+        {
+            const int c0 = chunk_of(from + 1), c1 = chunk_of(to_all);
+            const int cc = c0 + (int)threadIdx.x;
+            if (cc <= c1) {
+                int64_t lo = chunk_geo(cc).cs, hi = chunk_geo(cc).ce - 1;
+                if (lo < from + 1) lo = from + 1;
+                if (hi > to_all) hi = to_all;
+                if ((int64_t)chunk_far[s.chunk_off + cc] > lo - e) atomicMax(&rp_to, (int)hi);
+            }
+        }
+        __syncthreads();
+        const int64_t to = rp_to;
+        if (to <= from) return;
         const gcbytes in = as_global(s.in);
         const int64_t nn = s.n;
         const uint32_t vB = *(gcu32u)(in + e + 2);  // e + 5 < n: e is a loop-top of the body
@@ -827,6 +889,10 @@ __global__ __launch_bounds__(1024) void zs_resolve_kernel(const StreamDesc *sd, 
             if (in_range && dirty && !inb) inb = dev_bucket(tab, v, hash_variant) == B;
             todo |= (in_range && dirty && inb) ? 1u << u : 0u;
         }
+#ifdef ZS_FV_PROF
+        rp_scan += wall_clock64() - rp_t0;
+        rp_n++;
+#endif
         if (!__syncthreads_or(todo != 0)) return;  // nothing behind the cut was seen through it: the staged rows stay
         // index = position - o with o = (e - 1) rounded down to 16: the cut position has an index >= 1, so that walk_matches'
         // "never position 0" holds as it stands, and both arrays move 16 bytes per lane and step
@@ -890,12 +956,33 @@ __global__ __launch_bounds__(1024) void zs_resolve_kernel(const StreamDesc *sd, 
             if (nx != x || ny != y) {
                 a[p] = make_uint2(nx | (old.x & ~kRecMask), ny);
                 int cp = chunk_of(p);
-                stale[s.chunk_off + cp] = 1;
-                seg_stale[s.seg_off + seg_of(s, cp)] = 1;
-                if (p + 1 == chunk_geo(cp).ce && cp + 1 < nch) {
-                    stale[s.chunk_off + cp + 1] = 1;
-                    seg_stale[s.seg_off + seg_of(s, cp + 1)] = 1;
+                // the chunk's map (and its successor's, whose pending-match row starts with p) no longer holds: listed once
+                for (int k = 0; k < 2; k++) {
+                    const int cc = cp + k;
+                    if (k == 1 && !(p + 1 == chunk_geo(cp).ce && cp + 1 < nch)) break;
+                    seg_stale[s.seg_off + seg_of(s, cc)] = 1;
+                    stale[s.chunk_off + cc] = 1;
+                    if (cc - c0r < 24 && atomicExch(&rp_mark[cc - c0r], 1u) == 0) {
+                        const int at = atomicAdd(&rp_nlist, 1);
+                        if (at < 24) rp_list[at] = cc;
+                    }
                 }
+            }
+        }
+        __threadfence();
+        __syncthreads();
+        // The maps of those chunks again, by the whole workgroup (K3's routine, in the room of the rows): a stale chunk is
+        // otherwise walked by one thread out of global memory wherever its map is wanted -- 1.5 ms each here, as much
+        // again in K4b.  Only when the stream is resolved in one launch (all match records exist).
+        if (supmap != nullptr && rp_nlist <= 24) {
+            uint32_t *c_fk = (uint32_t *)rows, *c_fk4 = c_fk + kChunk + 1, *c_tbl = c_fk4 + kChunk + 1;
+            const int nl = rp_nlist;
+            for (int k = 0; k < nl; k++) {
+                const int cc = rp_list[k];
+                __syncthreads();
+                chunkmap_compute<1024>(s, cc, mm, maps, lv, strategy, hash_variant, c_fk, c_fk4, c_tbl, tab, nullptr, nullptr);
+                __syncthreads();
+                if (threadIdx.x == 0) stale[s.chunk_off + cc] = 0;
             }
         }
         __syncthreads();
@@ -1170,7 +1257,7 @@ __global__ __launch_bounds__(1024) void zs_resolve_kernel(const StreamDesc *sd, 
     }
 #ifdef ZS_FV_PROF
     if (threadIdx.x == 0 && blockIdx.x == 0 && kiter > 4)
-        printf("K4PROF iterations=%d ticks: stage+meta=%lld compose=%lld walk=%lld fill+flush=%lld repair=%lld\n", kiter, kp[0], kp[1], kp[2], kp[3], kp[4]);
+        printf("K4PROF iterations=%d ticks: stage+meta=%lld compose=%lld walk=%lld fill+flush=%lld repair=%lld (its scan %lld in %lld calls)\n", kiter, kp[0], kp[1], kp[2], kp[3], kp[4], rp_scan, rp_n);
 #endif
     if (threadIdx.x == 0) ss.r_seg = sh_seg, ss.r_slot = sh_slot, ss.r_total = sh_total, ss.r_kfired = sh_kfired, ss.r_preins1 = sh_preins + 1;
     if (sh_seg < s.nsegs) return;  // more segments to come in a later launch
