@@ -874,11 +874,14 @@ __global__ __launch_bounds__(1024) void zs_resolve_kernel(const StreamDesc *sd, 
         const int64_t nn = s.n;
         const uint32_t vB = *(gcu32u)(in + e + 2);  // e + 5 < n: e is a loop-top of the body
         const uint32_t B = dev_bucket(tab, vB, hash_variant);
+        // (positions dealt round the workgroup one by one: those to walk again cluster behind the cut.  Groups of 4 consecutive
+        // positions per thread, so that a match walked again at p could bound the one at p + 1 from below, were slower.)
         uint32_t todo = 0;
-        const int64_t pb = from + 1 + threadIdx.x;
+        const int64_t pb = from + 1 + (int64_t)threadIdx.x;
+        auto pos_of = [&](int u) { return pb + (int64_t)u * blockDim.x; };
 #pragma unroll
         for (int u = 0; u < 32; u++) {
-            const int64_t p = pb + (int64_t)u * blockDim.x;
+            const int64_t p = pos_of(u);
             const bool in_range = p <= to;
             const int64_t pc = in_range ? p : to;
             const uint2 rec = a[pc];
@@ -948,11 +951,45 @@ __global__ __launch_bounds__(1024) void zs_resolve_kernel(const StreamDesc *sd, 
         while (todo) {
             const int u = __builtin_ctz(todo);
             todo &= todo - 1;
-            const int64_t p = pb + (int64_t)u * blockDim.x;
+            const int64_t p = pos_of(u);
             const uint2 old = a[p];
             const uint32_t x = old.x & kRecMask, y = old.y;
             uint32_t nx, ny;
-            walk_matches(lkf, lcp, p - o, lv, nx, ny);  // the chain ends at e: distances are the same
+            {
+                // walk_matches (zs_core.h) with Longest_match's own shortcut in front of every compare: a candidate whose
+                // bytes [best - 1, best] or [0, 1] differ from the scan's cannot beat `best` (Deflate.cs:1072-1078)
+                nx = ny = kNoMatch;
+                const int64_t q = p - o;
+                int l = lkf(q);
+                int64_t c = q - l;
+                if (l && c >= 1 && q - c <= kMaxDist) {
+                    int best = 2, bdist = 0, n_eval = 0;
+                    const int k4 = lv.chain >> 2;
+                    bool snap = false;
+                    const uint32_t s01 = lds_u32(rb, (int)q) & 0xFFFFu;
+                    uint32_t send = lds_u32(rb, (int)q + best - 1) & 0xFFFFu;
+                    for (;;) {
+                        n_eval++;
+                        bool nice_exit = false;
+                        if ((lds_u32(rb, (int)c + best - 1) & 0xFFFFu) == send && (lds_u32(rb, (int)c) & 0xFFFFu) == s01) {
+                            const int len = lcp(q, c);
+                            if (len > best) {
+                                best = len, bdist = (int)(q - c);
+                                if (len >= lv.nice) nice_exit = true;
+                                send = lds_u32(rb, (int)q + best - 1) & 0xFFFFu;
+                            }
+                        }
+                        if (!snap && (n_eval == k4 || nice_exit)) ny = best >= kMinMatch ? pack_match(best, bdist) : kNoMatch, snap = true;
+                        if (nice_exit || n_eval == lv.chain) break;
+                        l = lkf(c);
+                        if (!l) break;
+                        c -= l;
+                        if (c < 1 || q - c >= kMaxDist) break;
+                    }
+                    nx = best >= kMinMatch ? pack_match(best, bdist) : kNoMatch;
+                    if (!snap) ny = nx;
+                }
+            }
             if (nx != x || ny != y) {
                 a[p] = make_uint2(nx | (old.x & ~kRecMask), ny);
                 int cp = chunk_of(p);
