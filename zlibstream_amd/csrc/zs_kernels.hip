@@ -649,12 +649,12 @@ __device__ __forceinline__ void chunkmap_compute(const StreamDesc &s, int c, con
             const uint32_t t = (uint32_t)__shfl_xor((int)far, o);
             far = far > t ? far : t;
         }
-        if (lane_id() == 0 && far) atomicMax(far_word, far);
+        if (threadIdx.x == 0) *far_word = 0;
     }
     const ChunkGeo g = chunk_geo(c);
     const bool event_chunk = s.head[c] != 0;
     __syncthreads();
-    if (far_word && threadIdx.x == 0) chunk_far[s.chunk_off + c] = (uint16_t)*far_word;
+    if (far_word && lane_id() == 0 && far) atomicMax(far_word, far);  // read behind the barriers of the passes below
     int64_t ce = g.ce;
     if (ce > (int64_t)s.body_end + 1) ce = (int64_t)s.body_end + 1;
     const int len = (int)(ce - g.cs);
@@ -707,6 +707,7 @@ __device__ __forceinline__ void chunkmap_compute(const StreamDesc &s, int c, con
         if (slot_valid(c, slot, s.body_end)) out = chunk_exit_by_table3(acc, tbl, c, slot, event_chunk, s.body_end, lv, strategy);
         maps[((int64_t)s.chunk_off + c) * kSlots + slot] = out;
     }
+    if (far_word && threadIdx.x == NT - 1) chunk_far[s.chunk_off + c] = (uint16_t)*far_word;
 }
 
 __global__ __launch_bounds__(512) void zs_chunkmap_kernel(const StreamDesc *sd, const uint2 *work, const uint2 *mm,
@@ -719,9 +720,7 @@ __global__ __launch_bounds__(512) void zs_chunkmap_kernel(const StreamDesc *sd, 
     uint2 w = work[blockIdx.x];
     const StreamDesc s = sd[w.x];
     const int c = (int)w.y;
-    if (threadIdx.x == 0) sh_far = 0;
-    if (s.head[c] != 0) load_crc_tab(tab, crc_tab_g);
-    __syncthreads();
+    if (s.head[c] != 0) load_crc_tab(tab, crc_tab_g);  // (chunkmap_compute's first barrier comes before the table's first use)
     chunkmap_compute<512>(s, c, mm, maps, lv, strategy, hash_variant, fk, fk4, tbl, tab, &sh_far, chunk_far);
 }
 
