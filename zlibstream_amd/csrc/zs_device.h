@@ -77,6 +77,10 @@ struct StreamDesc {
 };
 
 // zs_fast_vec_kernel's tile: the window [t0 - kFvBack, t0 + kFvTile + kFvFwd) in LDS as bytes, links and inserted bits
+// where each kernel's work items start in the work array (zs_worklist_kernel): 9 lists, then the total
+struct WorkOffsets {
+    uint32_t off[10];
+};
 constexpr int kSupSegs = 16;      // parse segments composed into one row of supmap ahead of the resolve kernel
 constexpr int kTailRecMax = 288;  // positions of a tail whose searches are done ahead (zs_tail_kernel): <= 261 - max_lazy + a few
 constexpr int kFvTile = 16384;

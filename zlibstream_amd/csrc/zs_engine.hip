@@ -37,7 +37,7 @@ struct zs_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t aux = nullptr;  // second stream: tree building of the finished blocks runs beside the tail engine
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_pre0 = nullptr, ev_pre = nullptr;
     hipEvent_t ev_part[16] = {};          // one long stream run part by part: part k's maps are ready
     std::vector<hipEvent_t> ev_pool;      // timing pairs of the part-wise launches (profiling)
     std::string err;
@@ -47,7 +47,7 @@ struct zs_ctx {
     hipEvent_t ev[kStCount + 1] = {};
     double stage_ms[kStCount] = {};
     uint32_t *crc_tab = nullptr;
-    DevBuf sd, st, work, geo, link, mm, maps, chunk_far, segmap, supmap, seg_entry, seg_symbase, seg_stale, entry, symbase, stale, syms, blk_end, blk_top, blocks, trees, info, pieces, scratch,
+    DevBuf sd, st, work, wpre, geo, link, mm, maps, chunk_far, segmap, supmap, seg_entry, seg_symbase, seg_stale, entry, symbase, stale, syms, blk_end, blk_top, blocks, trees, info, pieces, scratch,
         stage_in, stage_out, wr, inf_desc, inf_state, par_ps, par_st, par_work, par_cbits, par_ccnt, par_surv, par_scnt, par_cands, par_tabs, par_blocks, par_cells,
         par_windows, par_fail, run_syms, run_bits, run_scratch, run_outs, run_fail, adl_tr, adl_res, plan_blk, ins_bits, win_groups, win_sg, win_maps, win_entries;
     void *pinned = nullptr;
@@ -99,9 +99,26 @@ bool ensure_pinned(zs_ctx *c, size_t bytes) {
     return true;
 }
 
+// A kernel's work items: (stream, index) for index < count(stream), stream after stream.  The host keeps the running totals
+// (one per stream); the pairs themselves are written on the device (zs_worklist_kernel) -- for a 64 MiB stream they are
+// 46 K pairs, whose making and upload were 0.1 ms of host time per call.
+struct WorkList {
+    std::vector<int32_t> pre;  // pre[i] = items of the streams before i; one more entry = the total
+    void add(int stream, int64_t count) {
+        while ((int)pre.size() <= stream) pre.push_back(pre.empty() ? 0 : pre.back());
+        pre.push_back(pre.back() + (int32_t)count);
+    }
+    void finish(int n) {
+        if (pre.empty()) pre.push_back(0);
+        while ((int)pre.size() <= n) pre.push_back(pre.back());
+    }
+    size_t size() const { return pre.empty() ? 0 : (size_t)pre.back(); }
+    bool empty() const { return size() == 0; }
+};
+constexpr int kWorkLists = 9;
 struct Plan {
     std::vector<StreamDesc> sd;
-    std::vector<uint2> w_clear, w_adler, w_links, w_match, w_chunks, w_segs, w_sups, w_blocks, w_runs;
+    WorkList w_clear, w_adler, w_links, w_match, w_chunks, w_segs, w_sups, w_blocks, w_runs;
     int64_t n_pos = 0, n_syms = 0;
     int64_t n_chunks = 0, n_segs = 0, n_sups = 0, n_blocks = 0, n_pieces = 0, n_runs = 0;
     bool any_fv = false;
@@ -218,7 +235,7 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
         s.fast_runs = fast_par ? (int32_t)((len + kFastChunk - 1) / kFastChunk) : 0;
         s.run_off = (int32_t)pl.n_runs;
         pl.n_runs += s.fast_runs;
-        for (int k = 0; k < s.fast_runs; k++) pl.w_runs.push_back(make_uint2((unsigned)i, (unsigned)k));
+        pl.w_runs.add(i, s.fast_runs);
         s.blk_off = (int32_t)pl.n_blocks;
         // level 0 runs with memLevel 7: a block is flushed every 8191 symbols (only Rle tallies symbols there)
         s.max_blocks = (int32_t)(level == 0 ? len / 8191 + len / 32506 + 4 : len / kBlockSyms + 2);
@@ -248,19 +265,20 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
         s.adler_off = (int32_t)pl.n_pieces;
         s.n_adler = ro ? 0 : (int32_t)((len + kAdlerPiece - 1) / kAdlerPiece);  // an incremental stream's checksum is its owner's
         pl.n_pieces += s.n_adler;
-        for (int64_t k = 0; k * 65536 < s.out_cap; k++) pl.w_clear.push_back(make_uint2((unsigned)i, (unsigned)k));
-        for (int k = 0; k < s.n_adler; k++) pl.w_adler.push_back(make_uint2((unsigned)i, (unsigned)k));
+        pl.w_clear.add(i, (s.out_cap + 65535) / 65536);
+        pl.w_adler.add(i, s.n_adler);
         if (s.body_end >= 0 || s.fast_runs > 0 || s.fv_end >= 0)
-            for (int64_t t = 0; t * link_span < len - 5; t++) pl.w_links.push_back(make_uint2((unsigned)i, (unsigned)t));
+            pl.w_links.add(i, len - 5 > 0 ? (len - 5 + link_span - 1) / link_span : 0);
         if (s.body_end >= 0) {
-            for (int64_t t = 0; t * kMatchTile <= s.body_end; t++) pl.w_match.push_back(make_uint2((unsigned)i, (unsigned)t));
-            for (int k = 0; k < s.nchunks; k++) pl.w_chunks.push_back(make_uint2((unsigned)i, (unsigned)k));
-            for (int k = 0; k < s.nsegs; k++) pl.w_segs.push_back(make_uint2((unsigned)i, (unsigned)k));
-            if (s.nsegs > kSupSegs)  // shorter streams are resolved row by row (zs_resolve_kernel)
-                for (int k = 0; k * kSupSegs < s.nsegs; k++) pl.w_sups.push_back(make_uint2((unsigned)i, (unsigned)k));
+            pl.w_match.add(i, (int64_t)s.body_end / kMatchTile + 1);
+            pl.w_chunks.add(i, s.nchunks);
+            pl.w_segs.add(i, s.nsegs);
+            if (s.nsegs > kSupSegs) pl.w_sups.add(i, (s.nsegs + kSupSegs - 1) / kSupSegs);  // shorter streams are resolved row by row
         }
-        for (int k = 0; k < s.max_blocks; k++) pl.w_blocks.push_back(make_uint2((unsigned)i, (unsigned)k));
+        pl.w_blocks.add(i, s.max_blocks);
     }
+    WorkList *const lists[kWorkLists] = {&pl.w_clear, &pl.w_adler, &pl.w_links, &pl.w_match, &pl.w_chunks, &pl.w_segs, &pl.w_sups, &pl.w_blocks, &pl.w_runs};
+    for (WorkList *l : lists) l->finish(n);
     // ---- workspace ----
     size_t n_work = pl.w_clear.size() + pl.w_adler.size() + pl.w_links.size() + pl.w_match.size() + pl.w_chunks.size() +
                     pl.w_segs.size() + pl.w_sups.size() + pl.w_blocks.size() + pl.w_runs.size();
@@ -323,28 +341,27 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
         ZS_HIP(c, hipStreamSynchronize(stream));  // pageable source
     }
     // ---- upload descriptors and work lists (one pinned staging copy) ----
-    size_t up_bytes = sizeof(StreamDesc) * (size_t)n + sizeof(uint2) * n_work + geo_bytes + 16;
-    if (!ensure_pinned(c, std::max(up_bytes, sizeof(StreamState) * (size_t)n))) return false;
+    const size_t pre_bytes = 4 * (size_t)kWorkLists * (size_t)(n + 1);
+    size_t up_bytes = sizeof(StreamDesc) * (size_t)n + pre_bytes + geo_bytes + 16;
+    if (!ensure_pinned(c, std::max(up_bytes, sizeof(StreamState) * (size_t)n)) || !ensure(c, c->wpre, pre_bytes + 64)) return false;
     uint8_t *hp = (uint8_t *)c->pinned;
     memcpy(hp, pl.sd.data(), sizeof(StreamDesc) * (size_t)n);
-    uint2 *hw = (uint2 *)(hp + sizeof(StreamDesc) * (size_t)n);
+    int32_t *hpre = (int32_t *)(hp + sizeof(StreamDesc) * (size_t)n);
     size_t o_clear = 0, o_adler, o_links, o_match, o_chunks, o_segs, o_sups, o_blocks, o_runs;
-    auto put = [&](const std::vector<uint2> &v, size_t &off, size_t at) {
-        off = at;
-        if (!v.empty()) memcpy(hw + at, v.data(), sizeof(uint2) * v.size());
-        return at + v.size();
-    };
-    size_t at = put(pl.w_clear, o_clear, 0);
-    at = put(pl.w_adler, o_adler, at);
-    at = put(pl.w_links, o_links, at);
-    at = put(pl.w_match, o_match, at);
-    at = put(pl.w_chunks, o_chunks, at);
-    at = put(pl.w_segs, o_segs, at);
-    at = put(pl.w_sups, o_sups, at);
-    at = put(pl.w_blocks, o_blocks, at);
-    at = put(pl.w_runs, o_runs, at);
+    WorkOffsets wo;
+    {
+        size_t *const offs[kWorkLists] = {&o_clear, &o_adler, &o_links, &o_match, &o_chunks, &o_segs, &o_sups, &o_blocks, &o_runs};
+        size_t at = 0;
+        for (int l = 0; l < kWorkLists; l++) {
+            *offs[l] = at;
+            wo.off[l] = (uint32_t)at;
+            memcpy(hpre + (size_t)l * (size_t)(n + 1), lists[l]->pre.data(), 4 * (size_t)(n + 1));
+            at += lists[l]->size();
+        }
+        wo.off[kWorkLists] = (uint32_t)at;
+    }
     if (geo_bytes) {
-        uint8_t *hg = hp + sizeof(StreamDesc) * (size_t)n + sizeof(uint2) * n_work;
+        uint8_t *hg = hp + sizeof(StreamDesc) * (size_t)n + pre_bytes;
         if (pl.n_segs) {
             memcpy(hg, pl.seg_c0.data(), 4 * (size_t)pl.n_segs);
             memcpy(hg + 4 * (size_t)pl.n_segs, pl.seg_after.data(), 4 * (size_t)pl.n_segs);
@@ -354,12 +371,30 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
         ZS_HIP(c, hipMemcpyAsync(c->geo.p, hg, geo_bytes, hipMemcpyHostToDevice, stream));
     }
     ZS_HIP(c, hipMemcpyAsync(c->sd.p, hp, sizeof(StreamDesc) * (size_t)n, hipMemcpyHostToDevice, stream));
-    if (n_work) ZS_HIP(c, hipMemcpyAsync(c->work.p, hw, sizeof(uint2) * n_work, hipMemcpyHostToDevice, stream));
-    ZS_HIP(c, hipMemsetAsync(c->link.p, 0, 2 * (size_t)pl.n_pos + 64, stream));
-    if (pl.any_fv) ZS_HIP(c, hipMemsetAsync(c->ins_bits.p, 0, (size_t)pl.n_pos / 8 + kFvBitSlack, stream));
-    ZS_HIP(c, hipMemsetAsync(c->stale.p, 0, (size_t)pl.n_chunks + 64, stream));
-    ZS_HIP(c, hipMemsetAsync(c->seg_stale.p, 0, (size_t)pl.n_segs + 64, stream));
-    ZS_HIP(c, hipMemsetAsync(c->st.p, 0, sizeof(StreamState) * (size_t)n, stream));
+    if (n_work) {
+        ZS_HIP(c, hipMemcpyAsync(c->wpre.p, hpre, pre_bytes, hipMemcpyHostToDevice, stream));
+        hipLaunchKernelGGL(zs_worklist_kernel, dim3((unsigned)((n_work + 255) / 256)), dim3(256), 0, stream, dev<int32_t>(c->wpre), n, wo,
+                           dev<uint2>(c->work));
+    }
+    {
+        // the per-run flags and state in one launch (the link array is not cleared: K1 writes every entry that is read)
+        ZeroRegions z;
+        auto reg = [&](int r, DevBuf &b, size_t bytes) {
+            z.p[r] = b.p;
+            z.n16[r] = (uint32_t)(((bytes + 15) / 16 < b.cap / 16) ? (bytes + 15) / 16 : b.cap / 16);
+        };
+        reg(0, c->stale, (size_t)pl.n_chunks + 64);
+        reg(1, c->seg_stale, (size_t)pl.n_segs + 64);
+        reg(2, c->st, sizeof(StreamState) * (size_t)n);
+        if (pl.any_fv) reg(3, c->ins_bits, (size_t)pl.n_pos / 8 + kFvBitSlack);
+        else z.p[3] = nullptr, z.n16[3] = 0;
+        uint32_t most = 0;
+        for (int r = 0; r < 4; r++) most = z.n16[r] > most ? z.n16[r] : most;
+        unsigned blocks = (most + 255) / 256;
+        if (blocks > 2048) blocks = 2048;
+        if (blocks < 1) blocks = 1;
+        hipLaunchKernelGGL(zs_zero_kernel, dim3(blocks), dim3(256), 0, stream, z);
+    }
 
     const StreamDesc *d_sd = dev<StreamDesc>(c->sd);
     StreamState *d_st = dev<StreamState>(c->st);
@@ -369,12 +404,17 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
         if (prof) (void)hipEventRecord(c->ev[i], stream);
     };
     mark(0);
+    // the output buffers' clearing and the Adler-32 pieces are wanted by the last two kernels only: they run on the second
+    // stream beside the link and match kernels (their stage times then read ~0: 0.015 and 0.03 ms on english64 alone)
+    ZS_HIP(c, hipEventRecord(c->ev_pre0, stream));
+    ZS_HIP(c, hipStreamWaitEvent(c->aux, c->ev_pre0, 0));
     if (!pl.w_clear.empty())
-        hipLaunchKernelGGL(zs_clear_kernel, dim3((unsigned)pl.w_clear.size()), dim3(256), 0, stream, d_sd, d_work + o_clear);
+        hipLaunchKernelGGL(zs_clear_kernel, dim3((unsigned)pl.w_clear.size()), dim3(256), 0, c->aux, d_sd, d_work + o_clear);
     mark(1);
     if (!pl.w_adler.empty())
-        hipLaunchKernelGGL(zs_adler_kernel, dim3((unsigned)pl.w_adler.size()), dim3(256), 0, stream, d_sd, d_work + o_adler,
+        hipLaunchKernelGGL(zs_adler_kernel, dim3((unsigned)pl.w_adler.size()), dim3(256), 0, c->aux, d_sd, d_work + o_adler,
                            dev<uint32_t>(c->pieces));
+    ZS_HIP(c, hipEventRecord(c->ev_pre, c->aux));
     // One long stream: the position-parallel kernels (links, matches, chunk maps) fill the chip, the kernels that follow
     // the parse (resolve: one workgroup; symbols: one lane per chunk, a latency chain) leave it idle.  ZS_PIPE_PARTS=k cuts
     // the stream into k parts at parse-segment boundaries: while the match kernel works on part i + 1 the second HIP stream
@@ -607,6 +647,7 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
     hipLaunchKernelGGL(zs_trees_kernel, dim3((unsigned)pl.w_blocks.size()), dim3(trees_threads), 0, stream, d_sd, d_st, d_work + o_blocks,
                        dev<uint32_t>(c->syms), dev<BlockRec>(c->blocks), dev<TreeWork>(c->trees), dev<BlockInfo>(c->info), strategy, level, 2);
     mark(11);
+    ZS_HIP(c, hipStreamWaitEvent(stream, c->ev_pre, 0));  // the cleared output and the Adler pieces (second stream, above)
     hipLaunchKernelGGL(zs_offsets_kernel, dim3((unsigned)n), dim3(256), 0, stream, d_sd, d_st, dev<BlockRec>(c->blocks),
                        dev<BlockInfo>(c->info), dev<TreeWork>(c->trees), dev<uint32_t>(c->pieces), level, n);
     mark(12);
@@ -744,7 +785,9 @@ int zs_ctx_create(int device, zs_ctx **out) {
     }
     if (hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_pre0, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev_pre, hipEventDisableTiming) != hipSuccess) {
         delete c;
         return ZS_MEM_ERROR;
     }
@@ -784,7 +827,7 @@ int zs_ctx_create(int device, zs_ctx **out) {
 void zs_ctx_destroy(zs_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    DevBuf *bufs[] = {&c->sd, &c->st, &c->work, &c->geo, &c->link, &c->mm, &c->maps, &c->chunk_far, &c->segmap, &c->supmap, &c->seg_entry, &c->seg_symbase, &c->seg_stale, &c->entry, &c->symbase, &c->stale, &c->syms,
+    DevBuf *bufs[] = {&c->sd, &c->st, &c->work, &c->wpre, &c->geo, &c->link, &c->mm, &c->maps, &c->chunk_far, &c->segmap, &c->supmap, &c->seg_entry, &c->seg_symbase, &c->seg_stale, &c->entry, &c->symbase, &c->stale, &c->syms,
                       &c->blk_end, &c->blk_top, &c->blocks, &c->trees, &c->info, &c->pieces, &c->scratch, &c->stage_in, &c->stage_out, &c->wr, &c->inf_desc, &c->inf_state, &c->par_ps, &c->par_st, &c->par_work, &c->par_cbits, &c->par_ccnt, &c->par_surv, &c->par_scnt,
                       &c->par_cands, &c->par_tabs, &c->par_blocks, &c->par_cells, &c->par_windows, &c->par_fail, &c->run_syms, &c->run_bits,
                       &c->run_scratch, &c->run_outs, &c->run_fail, &c->adl_tr, &c->adl_res, &c->plan_blk, &c->ins_bits, &c->win_groups, &c->win_sg, &c->win_maps, &c->win_entries};
@@ -800,6 +843,8 @@ void zs_ctx_destroy(zs_ctx *c) {
         if (e) (void)hipEventDestroy(e);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->ev_pre0) (void)hipEventDestroy(c->ev_pre0);
+    if (c->ev_pre) (void)hipEventDestroy(c->ev_pre);
     if (c->aux) (void)hipStreamDestroy(c->aux);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;

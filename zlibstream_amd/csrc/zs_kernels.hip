@@ -75,6 +75,38 @@ __device__ __forceinline__ void load_crc_tab(uint32_t *tab, const uint32_t *g) {
     for (int i = threadIdx.x; i < 1024; i += blockDim.x) tab[i] = g[i];
 }
 
+// ------------------------------------------------------------------ work items
+// Every kernel below takes (stream, index) pairs from a list; list l holds, stream after stream, the indices 0 .. count - 1
+// of that stream.  pre[l * (n + 1) + i] = items of list l that belong to the streams before i.
+__global__ __launch_bounds__(256) void zs_worklist_kernel(const int32_t *pre, int n, WorkOffsets wo, uint2 *work) {
+    const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= wo.off[9]) return;
+    int l = 0;
+#pragma unroll
+    for (int k = 1; k < 9; k++) l += g >= wo.off[k] ? 1 : 0;
+    const int32_t j = (int32_t)(g - wo.off[l]);
+    const int32_t *p = pre + (size_t)l * (size_t)(n + 1);
+    int lo = 0, hi = n - 1;  // the last stream whose first item is <= j (streams without items share their successor's start)
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (p[mid] <= j) lo = mid;
+        else hi = mid - 1;
+    }
+    work[g] = make_uint2((uint32_t)lo, (uint32_t)(j - p[lo]));
+}
+
+// Up to four regions (16-byte multiples) zeroed in one launch: the per-run flags and state.
+struct ZeroRegions {
+    void *p[4];
+    uint32_t n16[4];  // 16-byte units
+};
+__global__ __launch_bounds__(256) void zs_zero_kernel(ZeroRegions z) {
+    const uint32_t g = blockIdx.x * 256 + threadIdx.x, stride = gridDim.x * 256;
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+        for (uint32_t i = g; i < z.n16[r]; i += stride) ((uint4 *)z.p[r])[i] = make_uint4(0, 0, 0, 0);
+}
+
 // ------------------------------------------------------------------ K0
 __global__ void zs_clear_kernel(const StreamDesc *sd, const uint2 *work) {
     uint2 w = work[blockIdx.x];
@@ -261,6 +293,12 @@ __global__ __launch_bounds__(1024) void zs_links_kernel(const StreamDesc *sd, co
             }
         }
         __syncthreads();
+    }
+    // the positions behind the last inserted one have no link: the stream's last span writes those zeros (the array is not
+    // cleared as a whole: every other entry is written above)
+    if (span_end == qend) {
+        const int64_t n_pad = ((int64_t)s.n + 64 + 63) & ~63LL;
+        for (int64_t q = qend + tid; q < n_pad; q += 1024) lk[q] = 0;
     }
 }
 
