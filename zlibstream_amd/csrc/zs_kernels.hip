@@ -831,6 +831,197 @@ constexpr int kResolveLds = kSegBatch * kSlots * 8 + 4096 + kSegBatch * 12 + (kS
 // bucket: the workgroup cuts link[s_k], re-walks the positions whose recorded winner lies
 // behind the cut, and marks the chunks whose matches changed; segments holding such
 // chunks are then followed chunk by chunk, stale chunks by a direct walk.
+// ------------------------------------------------------------------ repair of a cut (K4, and zs_repair_kernel over the chip)
+// The reference leaves prev[e] = e + 1 at an equal-bucket refill loop-top e: everything older than e is hidden from later
+// walks through that bucket.  link[e] is cut (by the caller); the positions of (from, to_all] whose recorded winner lies
+// behind the cut are walked again and their chunks marked stale.  Two passes.  First every thread looks at its U positions:
+// is the position in the cut's bucket and does its recorded winner lie behind the cut?  Straight-line code over loads that
+// do not depend on each other, and the bucket test is "the same four bytes as at e" before it is a hash: on zeros or runs
+// every refill is such a cut and every position behind it is in its bucket (one dependent load and one CRC per position
+// were 42 us per cut, 86 ms for 64 MiB of zeros).  Only if some position has to be walked again do the window's bytes and
+// links go into LDS (`lds`: up to 98 KiB) and the walks run from there (a run's long matches out of global memory: 0.25 ms
+// per cut).  Returns 0: nothing to walk again, LDS untouched; 1: there is, and scan_only; 2: walked and written.
+struct RepairArgs {
+    const StreamDesc *s;
+    uint2 *a;         // the stream's match records
+    uint16_t *lk;     // the stream's links
+    const uint32_t *tab;
+    uint8_t *lds;
+    uint8_t *stale, *seg_stale;
+    const uint16_t *chunk_far;
+    int nch;
+    LevelCfg lv;
+    int hash_variant;
+};
+template <int NT, int U>
+__device__ __forceinline__ int repair_cut(const RepairArgs &r, int64_t e, int64_t from, int64_t to_all, bool scan_only, int *sh_to,
+                                          int *list, int *nlist, unsigned int *mark) {
+    const StreamDesc &s = *r.s;
+    uint2 *a = r.a;
+    uint16_t *lk = r.lk;
+    const uint32_t *tab = r.tab;
+    const LevelCfg lv = r.lv;
+    const int hash_variant = r.hash_variant, nch = r.nch;
+    // a position can have seen through the cut only if its chunk's largest recorded distance reaches back to e (K3):
+    // the scan ends with the last such chunk -- on zeros and the like right behind the cut
+    if (threadIdx.x == 0) {
+        *sh_to = (int)from;
+        if (nlist) *nlist = 0;
+    }
+    if (mark && threadIdx.x < 24) mark[threadIdx.x] = 0;
+    const int c0r = chunk_of(from + 1);  // the chunks a repair can touch: c0r .. c0r + 17
+    __syncthreads();
+    {
+        const int c1 = chunk_of(to_all);
+        const int cc = c0r + (int)threadIdx.x;
+        if (cc <= c1) {
+            int64_t lo = chunk_geo(cc).cs, hi = chunk_geo(cc).ce - 1;
+            if (lo < from + 1) lo = from + 1;
+            if (hi > to_all) hi = to_all;
+            if ((int64_t)r.chunk_far[s.chunk_off + cc] > lo - e) atomicMax(sh_to, (int)hi);
+        }
+    }
+    __syncthreads();
+    const int64_t to = *sh_to;
+    if (to <= from) return 0;
+    const gcbytes in = as_global(s.in);
+    const int64_t nn = s.n;
+    const uint32_t vB = *(gcu32u)(in + e + 2);  // e + 5 < n: e is a loop-top of the body
+    const uint32_t B = dev_bucket(tab, vB, hash_variant);
+    // (positions dealt round the workgroup one by one: those to walk again cluster behind the cut.  Groups of 4 consecutive
+    // positions per thread, so that a match walked again at p could bound the one at p + 1 from below, were slower.)
+    uint32_t todo = 0;
+    const int64_t pb = from + 1 + (int64_t)threadIdx.x;
+    auto pos_of = [&](int u) { return pb + (int64_t)u * NT; };
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        const int64_t p = pos_of(u);
+        const bool in_range = p <= to;
+        const int64_t pc = in_range ? p : to;
+        const uint2 rec = a[pc];
+        const uint32_t v = *(gcu32u)(in + pc + 2);
+        const uint32_t x = rec.x & kRecMask, y = rec.y;
+        const bool dirty = (x && pc - match_dist(x) < e) || (y && pc - match_dist(y) < e);
+        bool inb = v == vB;
+        if (in_range && dirty && !inb) inb = dev_bucket(tab, v, hash_variant) == B;
+        todo |= (in_range && dirty && inb) ? 1u << u : 0u;
+    }
+    if (!__syncthreads_or(todo != 0)) return 0;  // nothing behind the cut was seen through it
+    if (scan_only) return 1;
+    // index = position - o with o = (e - 1) rounded down to 16: the cut position has an index >= 1, so that walk_matches'
+    // "never position 0" holds as it stands, and both arrays move 16 bytes per lane and step
+    uint8_t *rb = r.lds;
+    const int64_t o = (e - 1) & ~15LL;
+    const int ie = (int)(e - o);
+    const int nby = ((int)(to - o) + 1 + 272 + 15) & ~15;
+    uint16_t *rl = (uint16_t *)(rb + nby);
+    if ((((uintptr_t)in) & 15) == 0) {
+        for (int i = threadIdx.x * 16; i < nby; i += NT * 16) {
+            const int64_t q = o + i;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (q + 16 <= nn) {
+                const u32x4 t = *(gcu32x4)(in + q);
+                v = make_uint4(t[0], t[1], t[2], t[3]);
+            } else {
+                uint32_t t[4] = {0, 0, 0, 0};
+                for (int k = 0; k < 16; k++)
+                    if (q + k < nn) t[k >> 2] |= (uint32_t)in[q + k] << (8 * (k & 3));
+                v = make_uint4(t[0], t[1], t[2], t[3]);
+            }
+            *(uint4 *)(rb + i) = v;
+        }
+    } else {
+        for (int i = threadIdx.x * 4; i < nby; i += NT * 4) {
+            const int64_t q = o + i;
+            uint32_t v = 0;
+            if (q + 4 <= nn) v = *(gcu32u)(in + q);
+            else
+                for (int k = 0; k < 4; k++)
+                    if (q + k < nn) v |= (uint32_t)in[q + k] << (8 * (k & 3));
+            *(uint32_t *)(rb + i) = v;
+        }
+    }
+    const int nlk = ((int)(to - o) + 1 + 7) & ~7;  // links of [o, to], 8 per lane and step (the array has room behind a stream's end)
+    for (int i = threadIdx.x * 8; i < nlk; i += NT * 8) *(uint4 *)(rl + i) = *(const uint4 *)(lk + o + i);
+    __syncthreads();
+    for (int i = threadIdx.x; i <= ie; i += NT) rl[i] = 0;  // link[e] is cut; nothing below it is reached
+    __syncthreads();
+    auto lkf = [rl](int64_t q) { return (int)rl[q]; };  // positions relative to o from here on
+    auto lcp = [rb](int64_t u, int64_t v) {
+        int len = 0;
+        while (len < kMaxMatch) {
+            const uint64_t x = lds_u64(rb, (int)u + len) ^ lds_u64(rb, (int)v + len);
+            if (x) {
+                len += (int)(__builtin_ctzll(x) >> 3);
+                break;
+            }
+            len += 8;
+        }
+        return len < kMaxMatch ? len : kMaxMatch;
+    };
+    while (todo) {
+        const int u = __builtin_ctz(todo);
+        todo &= todo - 1;
+        const int64_t p = pos_of(u);
+        const uint2 old = a[p];
+        const uint32_t x = old.x & kRecMask, y = old.y;
+        uint32_t nx, ny;
+        {
+            // walk_matches (zs_core.h) with Longest_match's own shortcut in front of every compare: a candidate whose
+            // bytes [best - 1, best] or [0, 1] differ from the scan's cannot beat `best` (Deflate.cs:1072-1078)
+            nx = ny = kNoMatch;
+            const int64_t q = p - o;
+            int l = lkf(q);
+            int64_t c = q - l;
+            if (l && c >= 1 && q - c <= kMaxDist) {
+                int best = 2, bdist = 0, n_eval = 0;
+                const int k4 = lv.chain >> 2;
+                bool snap = false;
+                const uint32_t s01 = lds_u32(rb, (int)q) & 0xFFFFu;
+                uint32_t send = lds_u32(rb, (int)q + best - 1) & 0xFFFFu;
+                for (;;) {
+                    n_eval++;
+                    bool nice_exit = false;
+                    if ((lds_u32(rb, (int)c + best - 1) & 0xFFFFu) == send && (lds_u32(rb, (int)c) & 0xFFFFu) == s01) {
+                        const int len = lcp(q, c);
+                        if (len > best) {
+                            best = len, bdist = (int)(q - c);
+                            if (len >= lv.nice) nice_exit = true;
+                            send = lds_u32(rb, (int)q + best - 1) & 0xFFFFu;
+                        }
+                    }
+                    if (!snap && (n_eval == k4 || nice_exit)) ny = best >= kMinMatch ? pack_match(best, bdist) : kNoMatch, snap = true;
+                    if (nice_exit || n_eval == lv.chain) break;
+                    l = lkf(c);
+                    if (!l) break;
+                    c -= l;
+                    if (c < 1 || q - c >= kMaxDist) break;
+                }
+                nx = best >= kMinMatch ? pack_match(best, bdist) : kNoMatch;
+                if (!snap) ny = nx;
+            }
+        }
+        if (nx != x || ny != y) {
+            a[p] = make_uint2(nx | (old.x & ~kRecMask), ny);
+            int cp = chunk_of(p);
+            // the chunk's map (and its successor's, whose pending-match row starts with p) no longer holds: listed once
+            for (int k = 0; k < 2; k++) {
+                const int cc = cp + k;
+                if (k == 1 && !(p + 1 == chunk_geo(cp).ce && cp + 1 < nch)) break;
+                r.seg_stale[s.seg_off + seg_of(s, cc)] = 1;
+                r.stale[s.chunk_off + cc] = 1;
+                if (mark && cc - c0r >= 0 && cc - c0r < 24 && atomicExch(&mark[cc - c0r], 1u) == 0) {
+                    const int at = atomicAdd(nlist, 1);
+                    if (at < 24) list[at] = cc;
+                }
+            }
+        }
+    }
+    __threadfence();
+    __syncthreads();
+    return 2;
+}
+
 __global__ __launch_bounds__(1024) void zs_resolve_kernel(const StreamDesc *sd, StreamState *st, uint16_t *link, uint2 *mm,
                                                          uint32_t *maps, const uint2 *segmap,
                                                          uint16_t *seg_entry, uint32_t *seg_symbase, uint8_t *stale,
@@ -869,185 +1060,16 @@ __global__ __launch_bounds__(1024) void zs_resolve_kernel(const StreamDesc *sd, 
     GlobalAcc acc{as_global(s.in), a, tab, strategy, hash_variant};
     const int nseg = s.nsegs < seg_limit ? s.nsegs : seg_limit, nch = s.nchunks;
     const int64_t mm_end = (int64_t)s.body_end < (int64_t)mm_limit ? (int64_t)s.body_end : (int64_t)mm_limit;
-    // The reference leaves prev[e] = e + 1 at an equal-bucket refill loop-top e: everything older than e is hidden from
-    // later walks through that bucket.  link[e] is cut; positions in (from, to] whose recorded winner lies behind the cut are
-    // walked again and their chunks marked stale.
-    // Two passes.  First every thread looks at its (up to) 32 positions of (from, to]: is the position in the cut's bucket
-    // and does its recorded winner lie behind the cut?  Straight-line code over loads that do not depend on each other, and
-    // the bucket test is "the same four bytes as at e" before it is a hash: on zeros or runs every refill is such a cut and
-    // every position behind it is in its bucket (one dependent load and one CRC per position were 42 us per cut, 86 ms for
-    // 64 MiB of zeros).  Only if some position has to be walked again do the window's bytes and links go into LDS -- the
-    // room of the staged rows, which are then staged again -- and the walks run from there (a run's long matches out of
-    // global memory: 0.25 ms per cut).
-#ifdef ZS_FV_PROF
-    long long rp_scan = 0, rp_n = 0;
-#endif
     __shared__ int rp_to, rp_nlist, rp_list[24];
     __shared__ unsigned int rp_mark[24];
-    auto repair = [&](int64_t e, int64_t from, int64_t to_all) {
-#ifdef ZS_FV_PROF
-        const long long rp_t0 = wall_clock64();
-#endif
-        // a position can have seen through the cut only if its chunk's largest recorded distance reaches back to e (K3):
-        // the scan ends with the last such chunk -- on zeros and the like right behind the cut
-        if (threadIdx.x == 0) rp_to = (int)from, rp_nlist = 0;
-        if (threadIdx.x < 24) rp_mark[threadIdx.x] = 0;
-        const int c0r = chunk_of(from + 1);  // the chunks a repair can touch: c0r .. c0r + 17
-        __syncthreads();
-        {
-            const int c0 = chunk_of(from + 1), c1 = chunk_of(to_all);
-            const int cc = c0 + (int)threadIdx.x;
-            if (cc <= c1) {
-                int64_t lo = chunk_geo(cc).cs, hi = chunk_geo(cc).ce - 1;
-                if (lo < from + 1) lo = from + 1;
-                if (hi > to_all) hi = to_all;
-                if ((int64_t)chunk_far[s.chunk_off + cc] > lo - e) atomicMax(&rp_to, (int)hi);
-            }
-        }
-        __syncthreads();
-        const int64_t to = rp_to;
-        if (to <= from) return;
-        const gcbytes in = as_global(s.in);
-        const int64_t nn = s.n;
-        const uint32_t vB = *(gcu32u)(in + e + 2);  // e + 5 < n: e is a loop-top of the body
-        const uint32_t B = dev_bucket(tab, vB, hash_variant);
-        // (positions dealt round the workgroup one by one: those to walk again cluster behind the cut.  Groups of 4 consecutive
-        // positions per thread, so that a match walked again at p could bound the one at p + 1 from below, were slower.)
-        uint32_t todo = 0;
-        const int64_t pb = from + 1 + (int64_t)threadIdx.x;
-        auto pos_of = [&](int u) { return pb + (int64_t)u * blockDim.x; };
-#pragma unroll
-        for (int u = 0; u < 32; u++) {
-            const int64_t p = pos_of(u);
-            const bool in_range = p <= to;
-            const int64_t pc = in_range ? p : to;
-            const uint2 rec = a[pc];
-            const uint32_t v = *(gcu32u)(in + pc + 2);
-            const uint32_t x = rec.x & kRecMask, y = rec.y;
-            const bool dirty = (x && pc - match_dist(x) < e) || (y && pc - match_dist(y) < e);
-            bool inb = v == vB;
-            if (in_range && dirty && !inb) inb = dev_bucket(tab, v, hash_variant) == B;
-            todo |= (in_range && dirty && inb) ? 1u << u : 0u;
-        }
-#ifdef ZS_FV_PROF
-        rp_scan += wall_clock64() - rp_t0;
-        rp_n++;
-#endif
-        if (!__syncthreads_or(todo != 0)) return;  // nothing behind the cut was seen through it: the staged rows stay
-        // index = position - o with o = (e - 1) rounded down to 16: the cut position has an index >= 1, so that walk_matches'
-        // "never position 0" holds as it stands, and both arrays move 16 bytes per lane and step
-        uint8_t *rb = (uint8_t *)rows;
-        const int64_t o = (e - 1) & ~15LL;
-        const int ie = (int)(e - o);
-        const int nby = ((int)(to - o) + 1 + 272 + 15) & ~15;
-        uint16_t *rl = (uint16_t *)(rb + nby);
-        if ((((uintptr_t)in) & 15) == 0) {
-            for (int i = threadIdx.x * 16; i < nby; i += blockDim.x * 16) {
-                const int64_t q = o + i;
-                uint4 v = make_uint4(0, 0, 0, 0);
-                if (q + 16 <= nn) {
-                    const u32x4 t = *(gcu32x4)(in + q);
-                    v = make_uint4(t[0], t[1], t[2], t[3]);
-                } else {
-                    uint32_t t[4] = {0, 0, 0, 0};
-                    for (int k = 0; k < 16; k++)
-                        if (q + k < nn) t[k >> 2] |= (uint32_t)in[q + k] << (8 * (k & 3));
-                    v = make_uint4(t[0], t[1], t[2], t[3]);
-                }
-                *(uint4 *)(rb + i) = v;
-            }
-        } else {
-            for (int i = threadIdx.x * 4; i < nby; i += blockDim.x * 4) {
-                const int64_t q = o + i;
-                uint32_t v = 0;
-                if (q + 4 <= nn) v = *(gcu32u)(in + q);
-                else
-                    for (int k = 0; k < 4; k++)
-                        if (q + k < nn) v |= (uint32_t)in[q + k] << (8 * (k & 3));
-                *(uint32_t *)(rb + i) = v;
-            }
-        }
-        const int nlk = ((int)(to - o) + 1 + 7) & ~7;  // links of [o, to], 8 per lane and step (the array has room behind a stream's end)
-        for (int i = threadIdx.x * 8; i < nlk; i += blockDim.x * 8) *(uint4 *)(rl + i) = *(const uint4 *)(lk + o + i);
-        __syncthreads();
-        for (int i = threadIdx.x; i <= ie; i += blockDim.x) rl[i] = 0;  // link[e] is cut; nothing below it is reached
-        __syncthreads();
-        auto lkf = [rl](int64_t q) { return (int)rl[q]; };  // positions relative to o from here on
-        auto lcp = [rb](int64_t u, int64_t v) {
-            int len = 0;
-            while (len < kMaxMatch) {
-                const uint64_t x = lds_u64(rb, (int)u + len) ^ lds_u64(rb, (int)v + len);
-                if (x) {
-                    len += (int)(__builtin_ctzll(x) >> 3);
-                    break;
-                }
-                len += 8;
-            }
-            return len < kMaxMatch ? len : kMaxMatch;
-        };
-        while (todo) {
-            const int u = __builtin_ctz(todo);
-            todo &= todo - 1;
-            const int64_t p = pos_of(u);
-            const uint2 old = a[p];
-            const uint32_t x = old.x & kRecMask, y = old.y;
-            uint32_t nx, ny;
-            {
-                // walk_matches (zs_core.h) with Longest_match's own shortcut in front of every compare: a candidate whose
-                // bytes [best - 1, best] or [0, 1] differ from the scan's cannot beat `best` (Deflate.cs:1072-1078)
-                nx = ny = kNoMatch;
-                const int64_t q = p - o;
-                int l = lkf(q);
-                int64_t c = q - l;
-                if (l && c >= 1 && q - c <= kMaxDist) {
-                    int best = 2, bdist = 0, n_eval = 0;
-                    const int k4 = lv.chain >> 2;
-                    bool snap = false;
-                    const uint32_t s01 = lds_u32(rb, (int)q) & 0xFFFFu;
-                    uint32_t send = lds_u32(rb, (int)q + best - 1) & 0xFFFFu;
-                    for (;;) {
-                        n_eval++;
-                        bool nice_exit = false;
-                        if ((lds_u32(rb, (int)c + best - 1) & 0xFFFFu) == send && (lds_u32(rb, (int)c) & 0xFFFFu) == s01) {
-                            const int len = lcp(q, c);
-                            if (len > best) {
-                                best = len, bdist = (int)(q - c);
-                                if (len >= lv.nice) nice_exit = true;
-                                send = lds_u32(rb, (int)q + best - 1) & 0xFFFFu;
-                            }
-                        }
-                        if (!snap && (n_eval == k4 || nice_exit)) ny = best >= kMinMatch ? pack_match(best, bdist) : kNoMatch, snap = true;
-                        if (nice_exit || n_eval == lv.chain) break;
-                        l = lkf(c);
-                        if (!l) break;
-                        c -= l;
-                        if (c < 1 || q - c >= kMaxDist) break;
-                    }
-                    nx = best >= kMinMatch ? pack_match(best, bdist) : kNoMatch;
-                    if (!snap) ny = nx;
-                }
-            }
-            if (nx != x || ny != y) {
-                a[p] = make_uint2(nx | (old.x & ~kRecMask), ny);
-                int cp = chunk_of(p);
-                // the chunk's map (and its successor's, whose pending-match row starts with p) no longer holds: listed once
-                for (int k = 0; k < 2; k++) {
-                    const int cc = cp + k;
-                    if (k == 1 && !(p + 1 == chunk_geo(cp).ce && cp + 1 < nch)) break;
-                    seg_stale[s.seg_off + seg_of(s, cc)] = 1;
-                    stale[s.chunk_off + cc] = 1;
-                    if (cc - c0r < 24 && atomicExch(&rp_mark[cc - c0r], 1u) == 0) {
-                        const int at = atomicAdd(&rp_nlist, 1);
-                        if (at < 24) rp_list[at] = cc;
-                    }
-                }
-            }
-        }
-        __threadfence();
-        __syncthreads();
-        // The maps of those chunks again, by the whole workgroup (K3's routine, in the room of the rows): a stale chunk is
-        // otherwise walked by one thread out of global memory wherever its map is wanted -- 1.5 ms each here, as much
-        // again in K4b.  Only when the stream is resolved in one launch (all match records exist).
+    // the cut's repair (repair_cut above) with the staged rows' room as its LDS; then, when the stream is resolved in one
+    // launch (all match records exist), the maps of the chunks it changed again, by the whole workgroup (K3's routine): a
+    // stale chunk is otherwise walked by one thread out of global memory wherever its map is wanted -- 1.5 ms each here, as
+    // much again in K4b
+    auto repair = [&](int64_t e, int64_t from, int64_t to_all, bool scan_only) {
+        RepairArgs ra{&s, a, lk, tab, (uint8_t *)rows, stale, seg_stale, chunk_far, nch, lv, hash_variant};
+        const int rc = repair_cut<1024, 32>(ra, e, from, to_all, scan_only, &rp_to, rp_list, &rp_nlist, rp_mark);
+        if (rc != 2) return rc;
         if (supmap != nullptr && rp_nlist <= 24) {
             uint32_t *c_fk = (uint32_t *)rows, *c_fk4 = c_fk + kChunk + 1, *c_tbl = c_fk4 + kChunk + 1;
             const int nl = rp_nlist;
@@ -1061,6 +1083,7 @@ __global__ __launch_bounds__(1024) void zs_resolve_kernel(const StreamDesc *sd, 
         }
         __syncthreads();
         if (threadIdx.x == 0) b_nrow = 0;  // the rows are gone: the next batch is staged afresh
+        return rc;
     };
     // ---- the common case first: a stream resolved in one launch whose path meets no equal-bucket refill.  The composed
     //      rows of kSupSegs segments each (zs_supmap_kernel) are staged 64 at a time, thread 0 follows the path through them
@@ -1145,7 +1168,7 @@ __global__ __launch_bounds__(1024) void zs_resolve_kernel(const StreamDesc *sd, 
             int64_t full = e + kMaxDist;
             if (full > s.body_end) full = s.body_end;
             const int64_t to = full < mm_end ? full : mm_end;
-            if (to > from) repair(e, from, to);
+            if (to > from) repair(e, from, to, false);
             __syncthreads();
             if (threadIdx.x == 0 && to < full) ss.r_cut_e[keep] = (int32_t)e, ss.r_cut_done[keep] = (int32_t)to;
             if (to < full) keep++;
@@ -1319,7 +1342,7 @@ __global__ __launch_bounds__(1024) void zs_resolve_kernel(const StreamDesc *sd, 
             int64_t full = e + kMaxDist;
             if (full > s.body_end) full = s.body_end;
             const int64_t to = full < mm_end ? full : mm_end;
-            repair(e, e, to);
+            repair(e, e, to, false);
             if (threadIdx.x == 0 && to < full) {  // the rest once the records beyond exist
                 const int k = ss.r_ncut < 8 ? ss.r_ncut++ : 7;
                 ss.r_cut_e[k] = (int32_t)e, ss.r_cut_done[k] = (int32_t)to;
@@ -1331,7 +1354,7 @@ __global__ __launch_bounds__(1024) void zs_resolve_kernel(const StreamDesc *sd, 
     }
 #ifdef ZS_FV_PROF
     if (threadIdx.x == 0 && blockIdx.x == 0 && kiter > 4)
-        printf("K4PROF iterations=%d ticks: stage+meta=%lld compose=%lld walk=%lld fill+flush=%lld repair=%lld (its scan %lld in %lld calls)\n", kiter, kp[0], kp[1], kp[2], kp[3], kp[4], rp_scan, rp_n);
+        printf("K4PROF iterations=%d ticks: stage+meta=%lld compose=%lld walk=%lld fill+flush=%lld repair=%lld\n", kiter, kp[0], kp[1], kp[2], kp[3], kp[4]);
 #endif
     if (threadIdx.x == 0) ss.r_seg = sh_seg, ss.r_slot = sh_slot, ss.r_total = sh_total, ss.r_kfired = sh_kfired, ss.r_preins1 = sh_preins + 1;
     if (sh_seg < s.nsegs) return;  // more segments to come in a later launch
