@@ -700,3 +700,32 @@ def test_resolve_through_composed_segment_maps_and_row_by_row(engine, oracle):
         del os.environ["ZS_NO_SUPMAP"]
     for lvl in (4, 9):
         assert engine.deflate_batch(bufs[:3], level=lvl) == [oracle.compress(b, lvl) for b in bufs[:3]]
+
+
+def test_long_chain_levels_on_runs_and_zero_pages_go_through_rounds(engine, oracle):
+    """Levels 8 and 9 (chains of 1024 / 4096) on data whose refills are equal-bucket ones with thousands of positions to walk
+    again behind each: after kDeferBudget such cuts the resolve kernel gives the stream up and the batch is run again in
+    rounds (zs_repair_kernel and zs_stalemaps_kernel over the chip between launches of the resolve kernel).  The bytes are
+    the oracle's; a text stream in the same batch is carried along."""
+    rng = np.random.default_rng(123)
+    n = 3 << 20
+    runs = np.repeat(rng.integers(0, 4, n // 8, dtype=np.uint8), rng.integers(1, 40, n // 8))[:n].tobytes()
+    pages = b"".join(datagen.english(4096, 700 + i) if i % 3 else bytes(4096) for i in range(n // 4096))
+    bufs = [runs, pages, datagen.english(1 << 20, 31)]
+    for lvl in (8, 9):
+        assert engine.deflate_batch(bufs, level=lvl) == [oracle.compress(b, lvl) for b in bufs], lvl
+    # the same data at level 6 stays with the resolve kernel's own repairs
+    want6 = [oracle.compress(b, 6) for b in bufs]
+    assert engine.deflate_batch(bufs, level=6) == want6
+    # ... and through the rounds all the same: given up after the budget (ZS_DEFER_ALL), or in rounds from the start
+    # (ZS_FORCE_ROUNDS), with the edge inputs of the refill tests in the batch
+    edge = _edge_inputs()
+    names = ["runs", "zeros_98305", "lowent_98305", "lowent_131072", "alice_98566", "period256"]
+    more = bufs + [edge[k] for k in names]
+    want_more = want6 + [oracle.compress(edge[k], 6) for k in names]
+    for var in ("ZS_DEFER_ALL", "ZS_FORCE_ROUNDS"):
+        os.environ[var] = "1"
+        try:
+            assert engine.deflate_batch(more, level=6) == want_more, var
+        finally:
+            del os.environ[var]

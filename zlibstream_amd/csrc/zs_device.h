@@ -130,7 +130,13 @@ struct StreamState {
     uint32_t r_total;
     int32_t r_ncut;
     int32_t r_cut_e[8], r_cut_done[8];
+    // data whose refills are equal-bucket ones by the thousand (zeros pages, runs): the resolve kernel gives the stream up
+    // (deferred = 1: the kernels behind it skip the stream, the host runs the batch again in rounds) or, in a round, stops
+    // at a cut whose repair is worth the whole chip (deferred = 2: zs_repair_kernel, zs_stalemaps_kernel, and on it goes;
+    // r_scan: the walk resumes behind an applied cut)
+    int32_t deferred, r_scan;
 };
+constexpr int kDeferBudget = 8;   // cuts with positions to walk again that a stream may repair on its one CU before it is given up
 
 // DeflateFast (levels 1-3) as speculative chunk runs: run j re-parses kFastWarm bytes before its chunk with an
 // "everything inserted" history, then its chunk; it is exact iff its state at the first loop-top of the chunk

@@ -43,6 +43,7 @@ struct zs_ctx {
     std::string err;
     bool profiling = false;
     int fast_fallbacks = 0;  // speculative DeflateFast batches that had to be redone sequentially
+    int round_runs = 0;      // batches run again in rounds (a stream whose cuts were not one CU's job)
     int last_op = 0;  // 0: deflate stages, 1: block-parallel inflate stages (for zs_ctx_stage_name)
     hipEvent_t ev[kStCount + 1] = {};
     double stage_ms[kStCount] = {};
@@ -163,8 +164,9 @@ struct RunOpts {
 // `writes` (optional, one stream only): the Writes of a multi-Write stream, or of one whose Writes carry a flush mode
 bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len, void *const *out, const int64_t *out_cap,
                   int64_t *out_len, int *status, int level, int strategy, int hash_variant, hipStream_t stream,
-                  const WriteSpec *writes = nullptr, bool force_seq = false, RunOpts *ro = nullptr) {
+                  const WriteSpec *writes = nullptr, bool force_seq = false, RunOpts *ro = nullptr, bool rounds = false) {
     if (level == -1) level = 6;
+    if (getenv("ZS_FORCE_ROUNDS") && !ro) rounds = true;  // for the tests: every batch in rounds
     LevelCfg lv = level_cfg(level);
     for (int i = 0; i < n; i++) {  // what the caller sees if a HIP call fails before the results are known
         out_len[i] = 0;
@@ -499,7 +501,7 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
                                    dev<uint2>(c->mm), dev<uint32_t>(c->maps), dev<uint2>(c->segmap), dev<uint16_t>(c->seg_entry),
                                    dev<uint32_t>(c->seg_symbase), dev<uint8_t>(c->stale), dev<uint8_t>(c->seg_stale), c->crc_tab, lv,
                                    strategy, hash_variant, sb, (int)(mm_limit > 0x7FFFFFFF ? 0x7FFFFFFF : mm_limit), (const uint2 *)nullptr,
-                                   dev<uint16_t>(c->chunk_far));
+                                   dev<uint16_t>(c->chunk_far), 0);
             });
             if (k == n_parts - 1) {
                 // the tail engine needs what the last resolve launch left: it runs on the first stream beside the last part's symbols
@@ -512,13 +514,13 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
                 });
             }
             timed(kStExpand, c->aux, [&] {
-                hipLaunchKernelGGL(zs_expand_kernel, dim3((unsigned)((sb - sa + 63) / 64)), dim3(64), 0, c->aux, d_sd, d_work + o_segs + sa,
+                hipLaunchKernelGGL(zs_expand_kernel, dim3((unsigned)((sb - sa + 63) / 64)), dim3(64), 0, c->aux, d_sd, d_st, d_work + o_segs + sa,
                                    sb - sa, dev<uint2>(c->mm), dev<uint32_t>(c->maps), dev<uint16_t>(c->seg_entry),
                                    dev<uint32_t>(c->seg_symbase), dev<uint8_t>(c->stale), dev<uint16_t>(c->entry), dev<uint32_t>(c->symbase),
                                    c->crc_tab, lv, strategy, hash_variant);
             });
             timed(kStEmitSyms, c->aux, [&] {
-                hipLaunchKernelGGL(zs_emit_syms_lane_kernel, dim3((unsigned)((cb - ca + 63) / 64)), dim3(64), 0, c->aux, d_sd,
+                hipLaunchKernelGGL(zs_emit_syms_lane_kernel, dim3((unsigned)((cb - ca + 63) / 64)), dim3(64), 0, c->aux, d_sd, d_st,
                                    d_work + o_chunks + ca, cb - ca, dev<uint2>(c->mm), dev<uint16_t>(c->entry), dev<uint32_t>(c->symbase),
                                    dev<uint32_t>(c->syms), dev<int32_t>(c->blk_end), dev<int32_t>(c->blk_top), c->crc_tab, lv, strategy,
                                    hash_variant);
@@ -555,11 +557,40 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
         hipLaunchKernelGGL(zs_supmap_kernel, dim3((unsigned)pl.w_sups.size()), dim3(320), 0, stream, d_sd, d_work + o_sups,
                            dev<uint2>(c->segmap), dev<uint8_t>(c->seg_stale), dev<uint2>(c->supmap));
     mark(6);
-    hipLaunchKernelGGL(zs_resolve_kernel, dim3((unsigned)n), dim3(1024), kResolveLds, stream, d_sd, d_st, dev<uint16_t>(c->link),
-                       dev<uint2>(c->mm), dev<uint32_t>(c->maps), dev<uint2>(c->segmap),
-                       dev<uint16_t>(c->seg_entry), dev<uint32_t>(c->seg_symbase), dev<uint8_t>(c->stale),
-                       dev<uint8_t>(c->seg_stale), c->crc_tab, lv, strategy, hash_variant, 0x7FFFFFFF, 0x7FFFFFFF,
-                       use_sup ? dev<uint2>(c->supmap) : (const uint2 *)nullptr, dev<uint16_t>(c->chunk_far));
+    // A stream whose refills are equal-bucket ones with positions to walk again by the thousand (zero pages, runs) is not
+    // one CU's job: the resolve kernel gives it up after kDeferBudget such cuts (the kernels behind it skip the stream) and the
+    // batch is run again in rounds -- the kernel stops at every such cut, the repair and the chunk maps behind it run over the
+    // chip, and the kernel goes on (it keeps its place in StreamState).
+    // (Only where a walk is long -- chains of 1024 and 4096, levels 8 and 9: a round costs ~0.1 ms of launches and a
+    // synchronisation, which is what a cut's repair takes on one CU at level 6.  64 MiB of short runs: level 9 7.3 s -> 2.0 s,
+    // level 6 175 ms inline against 237 in rounds.)
+    // (ZS_DEFER_ALL: at every level, for the tests)
+    const int defer_mode = ro ? 0 : rounds ? 2 : (lv.chain > 256 || getenv("ZS_DEFER_ALL")) ? 1 : 0;
+    auto launch_resolve = [&]() {
+        hipLaunchKernelGGL(zs_resolve_kernel, dim3((unsigned)n), dim3(1024), kResolveLds, stream, d_sd, d_st, dev<uint16_t>(c->link),
+                           dev<uint2>(c->mm), dev<uint32_t>(c->maps), dev<uint2>(c->segmap),
+                           dev<uint16_t>(c->seg_entry), dev<uint32_t>(c->seg_symbase), dev<uint8_t>(c->stale),
+                           dev<uint8_t>(c->seg_stale), c->crc_tab, lv, strategy, hash_variant, 0x7FFFFFFF, 0x7FFFFFFF,
+                           use_sup ? dev<uint2>(c->supmap) : (const uint2 *)nullptr, dev<uint16_t>(c->chunk_far), defer_mode);
+    };
+    launch_resolve();
+    if (rounds) {
+        StreamState *hr = (StreamState *)c->pinned;
+        for (;;) {
+            ZS_HIP(c, hipMemcpyAsync(hr, d_st, sizeof(StreamState) * (size_t)n, hipMemcpyDeviceToHost, stream));
+            ZS_HIP(c, hipStreamSynchronize(stream));
+            bool any = false;
+            for (int i = 0; i < n; i++) any = any || hr[i].deferred == 2;
+            if (!any) break;
+            hipLaunchKernelGGL(zs_repair_kernel, dim3(kRepairParts, (unsigned)n), dim3(256), kRepairLds, stream, d_sd, d_st, dev<uint16_t>(c->link),
+                               dev<uint2>(c->mm), dev<uint8_t>(c->stale), dev<uint8_t>(c->seg_stale), dev<uint16_t>(c->chunk_far), c->crc_tab, lv,
+                               hash_variant);
+            hipLaunchKernelGGL(zs_stalemaps_kernel, dim3(18, (unsigned)n), dim3(512), 0, stream, d_sd, d_st, dev<uint2>(c->mm),
+                               dev<uint32_t>(c->maps), dev<uint8_t>(c->stale), c->crc_tab, lv, strategy, hash_variant);
+            hipLaunchKernelGGL(zs_round_end_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_st, n);
+            launch_resolve();
+        }
+    }
     mark(7);
     // fork: the tail engine (sequential, one workgroup per stream) needs only what the resolve kernel left, so it runs
     // on the second stream beside the symbol kernels
@@ -582,14 +613,14 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
         ZS_HIP(c, hipEventRecord(c->ev_join, c->aux));
     }
     if (!pl.w_segs.empty())
-        hipLaunchKernelGGL(zs_expand_kernel, dim3((unsigned)((pl.w_segs.size() + 63) / 64)), dim3(64), 0, stream, d_sd,
+        hipLaunchKernelGGL(zs_expand_kernel, dim3((unsigned)((pl.w_segs.size() + 63) / 64)), dim3(64), 0, stream, d_sd, d_st,
                            d_work + o_segs, (int)pl.w_segs.size(), dev<uint2>(c->mm),
                            dev<uint32_t>(c->maps), dev<uint16_t>(c->seg_entry), dev<uint32_t>(c->seg_symbase),
                            dev<uint8_t>(c->stale), dev<uint16_t>(c->entry), dev<uint32_t>(c->symbase), c->crc_tab, lv, strategy,
                            hash_variant);
     mark(8);
     if (!pl.w_chunks.empty())
-        hipLaunchKernelGGL(zs_emit_syms_lane_kernel, dim3((unsigned)((pl.w_chunks.size() + 63) / 64)), dim3(64), 0, stream, d_sd,
+        hipLaunchKernelGGL(zs_emit_syms_lane_kernel, dim3((unsigned)((pl.w_chunks.size() + 63) / 64)), dim3(64), 0, stream, d_sd, d_st,
                            d_work + o_chunks, (int)pl.w_chunks.size(), dev<uint2>(c->mm), dev<uint16_t>(c->entry),
                            dev<uint32_t>(c->symbase), dev<uint32_t>(c->syms), dev<int32_t>(c->blk_end), dev<int32_t>(c->blk_top),
                            c->crc_tab, lv, strategy, hash_variant);
@@ -672,6 +703,16 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
                 (void)hipEventElapsedTime(&ms, t.a, t.b);
                 c->stage_ms[t.stage] += ms;
             }
+        }
+    }
+    if (!ro && !rounds) {
+        // a stream the resolve kernel gave up (zs_device.h, StreamState::deferred): the batch again, in rounds
+        bool gave_up = false;
+        for (int i = 0; i < n; i++) gave_up = gave_up || hst[i].deferred != 0;
+        if (gave_up) {
+            ZS_HIP(c, hipStreamSynchronize(c->aux));
+            c->round_runs++;
+            return run_pipeline(c, n, in, in_len, out, out_cap, out_len, status, level, strategy, hash_variant, stream, writes, force_seq, ro, true);
         }
     }
     if (ro) ro->end_bits = hst[0].end_bits;
@@ -809,6 +850,7 @@ int zs_ctx_create(int device, zs_ctx **out) {
         hipFuncSetAttribute((const void *)zs_fast_vec_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kFvLds) != hipSuccess ||
         hipFuncSetAttribute((const void *)zs_inf_window_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kWinMapLds) != hipSuccess ||
         hipFuncSetAttribute((const void *)zs_inf_chain_par_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kChainParLds) != hipSuccess ||
+        hipFuncSetAttribute((const void *)zs_repair_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kRepairLds) != hipSuccess ||
         hipFuncSetAttribute((const void *)zs_inflate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kInfLds) != hipSuccess) {
         zs_ctx_destroy(c);
         return ZS_MEM_ERROR;

@@ -855,7 +855,7 @@ struct RepairArgs {
 };
 template <int NT, int U>
 __device__ __forceinline__ int repair_cut(const RepairArgs &r, int64_t e, int64_t from, int64_t to_all, bool scan_only, int *sh_to,
-                                          int *list, int *nlist, unsigned int *mark) {
+                                          int *list, int *nlist, unsigned int *mark, int part = 0, int nparts = 1) {
     const StreamDesc &s = *r.s;
     uint2 *a = r.a;
     uint16_t *lk = r.lk;
@@ -886,13 +886,15 @@ __device__ __forceinline__ int repair_cut(const RepairArgs &r, int64_t e, int64_
     if (to <= from) return 0;
     const gcbytes in = as_global(s.in);
     const int64_t nn = s.n;
-    const uint32_t vB = *(gcu32u)(in + e + 2);  // e + 5 < n: e is a loop-top of the body
+    // e + 5 < n: e is a loop-top of the body.  Byte loads: e is uniform in zs_repair_kernel, where the compiler made the
+    // unaligned dword load a scalar one, which reads from the address rounded down to 4 (the wrong bucket)
+    const uint32_t vB = (uint32_t)in[e + 2] | ((uint32_t)in[e + 3] << 8) | ((uint32_t)in[e + 4] << 16) | ((uint32_t)in[e + 5] << 24);
     const uint32_t B = dev_bucket(tab, vB, hash_variant);
     // (positions dealt round the workgroup one by one: those to walk again cluster behind the cut.  Groups of 4 consecutive
     // positions per thread, so that a match walked again at p could bound the one at p + 1 from below, were slower.)
     uint32_t todo = 0;
-    const int64_t pb = from + 1 + (int64_t)threadIdx.x;
-    auto pos_of = [&](int u) { return pb + (int64_t)u * NT; };
+    // (workgroup `part` of `nparts` takes every nparts-th position: the positions to walk again cluster behind the cut)
+    auto pos_of = [&](int u) { return from + 1 + part + ((int64_t)u * NT + threadIdx.x) * nparts; };
 #pragma unroll
     for (int u = 0; u < U; u++) {
         const int64_t p = pos_of(u);
@@ -1027,7 +1029,7 @@ __global__ __launch_bounds__(1024) void zs_resolve_kernel(const StreamDesc *sd, 
                                                          uint16_t *seg_entry, uint32_t *seg_symbase, uint8_t *stale,
                                                          uint8_t *seg_stale, const uint32_t *crc_tab_g, LevelCfg lv,
                                                          int strategy, int hash_variant, int seg_limit, int mm_limit,
-                                                         const uint2 *supmap, const uint16_t *chunk_far) {
+                                                         const uint2 *supmap, const uint16_t *chunk_far, int defer_mode) {
     // > 64 KiB of LDS: dynamic allocation, carved by hand
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint2 *rows = (uint2 *)smem;                                  // segment-map rows of the current batch (130 KiB)
@@ -1040,6 +1042,7 @@ __global__ __launch_bounds__(1024) void zs_resolve_kernel(const StreamDesc *sd, 
     __shared__ uint32_t g_base[kSegBatch / kSegGroup];
     __shared__ int sh_kf, sh_ks;
     __shared__ int sh_seg, sh_slot, sh_scan, sh_kfired, sh_preins;
+    __shared__ int sh_defer, sh_nexp;
     __shared__ int b_seg0, b_nrow, b_groups;  // the batch of rows in LDS: first segment, rows, whether its composed groups may be used
     __shared__ uint32_t sh_total;
     const StreamDesc s = sd[blockIdx.x];
@@ -1048,8 +1051,8 @@ __global__ __launch_bounds__(1024) void zs_resolve_kernel(const StreamDesc *sd, 
     // seg_limit / mm_limit (one long stream run part by part, else "everything"): segments below seg_limit have their maps,
     // positions up to mm_limit their match records; the kernel goes on from where the launch before stopped
     if (threadIdx.x == 0)
-        sh_seg = ss.r_seg, sh_slot = ss.r_slot, sh_total = ss.r_total, sh_kfired = ss.r_kfired, sh_preins = ss.r_preins1 - 1, sh_scan = 0, b_seg0 = 0,
-        b_nrow = 0, b_groups = 0;
+        sh_seg = ss.r_seg, sh_slot = ss.r_slot, sh_total = ss.r_total, sh_kfired = ss.r_kfired, sh_preins = ss.r_preins1 - 1, sh_scan = ss.r_scan,
+        ss.r_scan = 0, b_seg0 = 0, b_nrow = 0, b_groups = 0, sh_defer = 0, sh_nexp = 0;
     __syncthreads();
     if (s.body_end < 0) {
         if (threadIdx.x == 0) ss.tail_p = 0, ss.tail_kind = kR, ss.tail_pend = 0, ss.k_done = 0, ss.preins = -1, ss.body_syms = 0;
@@ -1342,21 +1345,32 @@ __global__ __launch_bounds__(1024) void zs_resolve_kernel(const StreamDesc *sd, 
             int64_t full = e + kMaxDist;
             if (full > s.body_end) full = s.body_end;
             const int64_t to = full < mm_end ? full : mm_end;
-            repair(e, e, to, false);
-            if (threadIdx.x == 0 && to < full) {  // the rest once the records beyond exist
-                const int k = ss.r_ncut < 8 ? ss.r_ncut++ : 7;
-                ss.r_cut_e[k] = (int32_t)e, ss.r_cut_done[k] = (int32_t)to;
+            if (defer_mode == 2) {
+                // a round: a cut with positions to walk again is left to zs_repair_kernel -- the kernel stops here
+                if (repair(e, e, to, true) == 1 && threadIdx.x == 0) ss.r_cut_e[0] = (int32_t)e, ss.r_cut_done[0] = (int32_t)e, ss.r_ncut = 1, sh_defer = 2;
+            } else {
+                const int rc = repair(e, e, to, false);
+                if (threadIdx.x == 0 && to < full) {  // the rest once the records beyond exist
+                    const int k = ss.r_ncut < 8 ? ss.r_ncut++ : 7;
+                    ss.r_cut_e[k] = (int32_t)e, ss.r_cut_done[k] = (int32_t)to;
+                }
+                if (defer_mode == 1 && rc == 2 && threadIdx.x == 0 && ++sh_nexp > kDeferBudget) sh_defer = 1;  // not this CU's job
             }
             __threadfence_block();
         }
         __syncthreads();
         K4_PF(4);
+        if (sh_defer) break;
     }
 #ifdef ZS_FV_PROF
     if (threadIdx.x == 0 && blockIdx.x == 0 && kiter > 4)
         printf("K4PROF iterations=%d ticks: stage+meta=%lld compose=%lld walk=%lld fill+flush=%lld repair=%lld\n", kiter, kp[0], kp[1], kp[2], kp[3], kp[4]);
 #endif
     if (threadIdx.x == 0) ss.r_seg = sh_seg, ss.r_slot = sh_slot, ss.r_total = sh_total, ss.r_kfired = sh_kfired, ss.r_preins1 = sh_preins + 1;
+    if (sh_defer) {
+        if (threadIdx.x == 0) ss.deferred = sh_defer, ss.r_scan = 1;
+        return;
+    }
     if (sh_seg < s.nsegs) return;  // more segments to come in a later launch
     if (threadIdx.x == 0) {
         int slot = sh_slot;
@@ -1374,7 +1388,51 @@ __global__ __launch_bounds__(1024) void zs_resolve_kernel(const StreamDesc *sd, 
 
 // ------------------------------------------------------------------ K4b
 // One thread per parse segment: entry slot and first-symbol index of each of its chunks.
-__global__ __launch_bounds__(64) void zs_expand_kernel(const StreamDesc *sd, const uint2 *work, int nwork, const uint2 *mm,
+// ------------------------------------------------------------------ a round of repairs over the chip
+// For the streams the resolve kernel has stopped at a cut (deferred == 2): the positions behind the cut walked again, 1 Ki
+// positions per workgroup (repair_cut), then the maps of the chunks that changed (K3's routine), then the flags reset;
+// the host launches the resolve kernel again.
+constexpr int kRepairParts = 128;  // x 256 threads >= kMaxDist positions, dealt round the workgroups
+constexpr int kRepairLds = ((kMaxDist + 16 + 273 + 15) & ~15) + 2 * (kMaxDist + 32) + 64;
+__global__ __launch_bounds__(256) void zs_repair_kernel(const StreamDesc *sd, const StreamState *st, uint16_t *link, uint2 *mm, uint8_t *stale,
+                                                        uint8_t *seg_stale, const uint16_t *chunk_far, const uint32_t *crc_tab_g, LevelCfg lv,
+                                                        int hash_variant) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    __shared__ uint32_t tab[1024];
+    __shared__ int sh_to;
+    const StreamDesc s = sd[blockIdx.y];
+    const StreamState &ss = st[blockIdx.y];
+    if (ss.deferred != 2) return;
+    const int64_t e = ss.r_cut_e[0];
+    int64_t full = e + kMaxDist;
+    if (full > s.body_end) full = s.body_end;
+    static_assert(kRepairParts * 256 >= kMaxDist, "one position per thread");
+    if (e >= full) return;
+    load_crc_tab(tab, crc_tab_g);
+    __syncthreads();
+    RepairArgs ra{&s, mm + s.pos_off, link + s.pos_off, tab, smem, stale, seg_stale, chunk_far, s.nchunks, lv, hash_variant};
+    repair_cut<256, 1>(ra, e, e, full, false, &sh_to, nullptr, nullptr, nullptr, (int)blockIdx.x, kRepairParts);
+}
+__global__ __launch_bounds__(512) void zs_stalemaps_kernel(const StreamDesc *sd, const StreamState *st, const uint2 *mm, uint32_t *maps,
+                                                           uint8_t *stale, const uint32_t *crc_tab_g, LevelCfg lv, int strategy, int hash_variant) {
+    __shared__ uint32_t fk[kChunk + 1], fk4[kChunk + 1];
+    __shared__ uint32_t tbl[kNodeExit3];
+    __shared__ uint32_t tab[1024];
+    const StreamDesc s = sd[blockIdx.y];
+    const StreamState &ss = st[blockIdx.y];
+    if (ss.deferred != 2) return;
+    const int c = chunk_of((int64_t)ss.r_cut_e[0] + 1) + (int)blockIdx.x;
+    if (c >= s.nchunks || !stale[s.chunk_off + c]) return;
+    if (s.head[c] != 0) load_crc_tab(tab, crc_tab_g);
+    chunkmap_compute<512>(s, c, mm, maps, lv, strategy, hash_variant, fk, fk4, tbl, tab, nullptr, nullptr);
+    if (threadIdx.x == 0) stale[s.chunk_off + c] = 0;
+}
+__global__ __launch_bounds__(256) void zs_round_end_kernel(StreamState *st, int n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n && st[i].deferred == 2) st[i].r_ncut = 0, st[i].deferred = 0;
+}
+
+__global__ __launch_bounds__(64) void zs_expand_kernel(const StreamDesc *sd, const StreamState *st, const uint2 *work, int nwork, const uint2 *mm,
                                                        const uint32_t *maps, const uint16_t *seg_entry,
                                                        const uint32_t *seg_symbase, const uint8_t *stale, uint16_t *entry,
                                                        uint32_t *symbase, const uint32_t *crc_tab_g, LevelCfg lv, int strategy,
@@ -1382,6 +1440,7 @@ __global__ __launch_bounds__(64) void zs_expand_kernel(const StreamDesc *sd, con
     int i = blockIdx.x * 64 + threadIdx.x;
     if (i >= nwork) return;
     uint2 w = work[i];
+    if (st[w.x].deferred) return;  // the resolve kernel gave the stream up: the batch is run again in rounds
     const StreamDesc s = sd[w.x];
     const int seg = (int)w.y;
     GlobalAcc acc{as_global(s.in), mm + s.pos_off, crc_tab_g, strategy, hash_variant};
@@ -1427,13 +1486,14 @@ struct GlobalSymSink {
         }
     }
 };
-__global__ __launch_bounds__(64) void zs_emit_syms_lane_kernel(const StreamDesc *sd, const uint2 *work, int nwork, const uint2 *mm,
+__global__ __launch_bounds__(64) void zs_emit_syms_lane_kernel(const StreamDesc *sd, const StreamState *st, const uint2 *work, int nwork, const uint2 *mm,
                                                                const uint16_t *entry, const uint32_t *symbase, uint32_t *syms,
                                                                int32_t *blk_end, int32_t *blk_top, const uint32_t *crc_tab_g,
                                                                LevelCfg lv, int strategy, int hash_variant) {
     const int i = blockIdx.x * 64 + threadIdx.x;
     if (i >= nwork) return;
     const uint2 w = work[i];
+    if (st[w.x].deferred) return;
     const StreamDesc s = sd[w.x];
     const int c = (int)w.y;
     GlobalAcc acc{as_global(s.in), mm + s.pos_off, crc_tab_g, strategy, hash_variant};
@@ -1489,7 +1549,7 @@ __global__ __launch_bounds__(64) void zs_emit_syms_lane_kernel(const StreamDesc 
 __global__ __launch_bounds__(256) void zs_body_blocks_kernel(const StreamDesc *sd, const StreamState *st, const int32_t *blk_end,
                                                              const int32_t *blk_top, BlockRec *blocks) {
     const StreamDesc s = sd[blockIdx.x];
-    if (s.fast_runs > 0) return;
+    if (s.fast_runs > 0 || st[blockIdx.x].deferred) return;
     const int nb_body = (int)(st[blockIdx.x].body_syms / kBlockSyms);
     BlockRec *blk = blocks + s.blk_off;
     // start = end of the previous block; stored blocks are allowed only while blockStart has not slid out of the
@@ -1529,6 +1589,7 @@ __global__ __launch_bounds__(1024) void zs_tail_kernel(const StreamDesc *sd, Str
     const StreamDesc s = sd[blockIdx.x];
     if (s.fast_runs > 0) return;  // handled by zs_fast_run_kernel / zs_fast_stitch_kernel
     StreamState &ss = st[blockIdx.x];
+    if (ss.deferred) return;  // given up by the resolve kernel: the batch is run again in rounds
     const int tid = threadIdx.x, nth = blockDim.x;  // all threads restore; wave 0 then runs the engine
     if (s.plan_nblk > 0) {
         // level 0: the stored blocks were planned on the host from the sizes; nothing to parse
@@ -2307,6 +2368,7 @@ __global__ __launch_bounds__(256) void zs_trees_kernel(const StreamDesc *sd, con
     __shared__ uint32_t hk[kHeapSize + 8];  // Build_tree's priority queue (the sift reads a few entries past the end)
     __shared__ uint32_t pd[kHeapSize + 1], nc[16];  // (ancestor, distance) words of the depth pass; per-length counters
     uint2 w = work[blockIdx.x];
+    if (st[w.x].deferred) return;
     const StreamDesc s = sd[w.x];
     const int b = (int)w.y;
     // phase 0: the blocks that end inside the bulk parse; phase 1: the rest; 2: all
@@ -2410,6 +2472,7 @@ __global__ __launch_bounds__(256) void zs_offsets_kernel(const StreamDesc *sd, S
     int fa_w = 0;
     const bool flushing = sd[blockIdx.x].wr_flush != nullptr;
     const int si = blockIdx.x;
+    if (st[si].deferred) return;
     const StreamDesc s = sd[si];
     StreamState &ss = st[si];
     const int nb = ss.nblocks;
@@ -2609,6 +2672,7 @@ __global__ __launch_bounds__(256) void zs_emit_bits_kernel(const StreamDesc *sd,
     __shared__ uint32_t wsum[4];
     __shared__ uint32_t sh_bits;
     uint2 w = work[blockIdx.x];
+    if (st[w.x].deferred) return;
     const StreamDesc s = sd[w.x];
     const int b = (int)w.y;
     if (b >= st[w.x].nblocks || st[w.x].status != 0) return;
