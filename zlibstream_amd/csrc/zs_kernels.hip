@@ -29,6 +29,12 @@ typedef __attribute__((address_space(1))) uint8_t *gbytes_w;
 __device__ __forceinline__ gcbytes as_global(const uint8_t *p) { return (gcbytes)(uintptr_t)p; }
 __device__ __forceinline__ gbytes_w as_global(uint8_t *p) { return (gbytes_w)(uintptr_t)p; }
 typedef const __attribute__((address_space(1))) uint32_t __attribute__((aligned(1))) *gcu32u;
+// (Only for addresses that differ from lane to lane: where the compiler can prove an address wave-uniform it makes the
+// load a scalar one, and a scalar dword load reads from the address rounded down to 4 whatever the type says -- found in
+// zs_repair_kernel.  Uniform or possibly uniform addresses take g_u32_bytes.)
+__device__ __forceinline__ uint32_t g_u32_bytes(gcbytes p) {
+    return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+}
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(1))) u32x4 *gcu32x4;
 // Unaligned 4 / 8 bytes out of an LDS byte array (16-byte aligned base, readable one dword past the last index
@@ -612,7 +618,7 @@ struct GlobalAcc {
     __device__ uint32_t mK(int64_t p) const { return flt(mm[p].x); }
     __device__ uint32_t mK4(int64_t p) const { return flt(mm[p].y); }
     __device__ uint8_t byte(int64_t p) const { return in[p]; }
-    __device__ uint32_t bucket(int64_t p) const { return dev_bucket(tab, *(gcu32u)(in + p + 2), hash_variant); }
+    __device__ uint32_t bucket(int64_t p) const { return dev_bucket(tab, g_u32_bytes(in + p + 2), hash_variant); }
     __device__ int run1(int64_t p) const {
         int len = 0;
         while (len < kMaxMatch && in[p + len] == in[p - 1 + len]) len++;
@@ -630,7 +636,7 @@ struct LdsAcc {
     __device__ uint32_t mK(int64_t p) const { return fk[p - org]; }
     __device__ uint32_t mK4(int64_t p) const { return fk4[p - org]; }
     __device__ uint8_t byte(int64_t p) const { return lbytes ? lbytes[p - org] : in[p]; }
-    __device__ uint32_t bucket(int64_t p) const { return dev_bucket(tab, *(gcu32u)(in + p + 2), hash_variant); }
+    __device__ uint32_t bucket(int64_t p) const { return dev_bucket(tab, g_u32_bytes(in + p + 2), hash_variant); }
     __device__ int run1(int64_t p) const {
         int len = 0;
         while (len < kMaxMatch && in[p + len] == in[p - 1 + len]) len++;
@@ -888,7 +894,7 @@ __device__ __forceinline__ int repair_cut(const RepairArgs &r, int64_t e, int64_
     const int64_t nn = s.n;
     // e + 5 < n: e is a loop-top of the body.  Byte loads: e is uniform in zs_repair_kernel, where the compiler made the
     // unaligned dword load a scalar one, which reads from the address rounded down to 4 (the wrong bucket)
-    const uint32_t vB = (uint32_t)in[e + 2] | ((uint32_t)in[e + 3] << 8) | ((uint32_t)in[e + 4] << 16) | ((uint32_t)in[e + 5] << 24);
+    const uint32_t vB = g_u32_bytes(in + e + 2);
     const uint32_t B = dev_bucket(tab, vB, hash_variant);
     // (positions dealt round the workgroup one by one: those to walk again cluster behind the cut.  Groups of 4 consecutive
     // positions per thread, so that a match walked again at p could bound the one at p + 1 from below, were slower.)
