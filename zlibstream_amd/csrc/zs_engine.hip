@@ -405,18 +405,21 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
     auto mark = [&](int i) {
         if (prof) (void)hipEventRecord(c->ev[i], stream);
     };
-    mark(0);
     // the output buffers' clearing and the Adler-32 pieces are wanted by the last two kernels only: they run on the second
-    // stream beside the link and match kernels (their stage times then read ~0: 0.015 and 0.03 ms on english64 alone)
+    // stream beside the link and match kernels (their stages are reported as 0: 0.015 and 0.03 ms on english64 alone, and
+    // their events are not recorded).  The host enqueues them behind the first launches of the critical path: every call
+    // in front of K1 is ~5 us in which the device waits for the host.
     ZS_HIP(c, hipEventRecord(c->ev_pre0, stream));
-    ZS_HIP(c, hipStreamWaitEvent(c->aux, c->ev_pre0, 0));
-    if (!pl.w_clear.empty())
-        hipLaunchKernelGGL(zs_clear_kernel, dim3((unsigned)pl.w_clear.size()), dim3(256), 0, c->aux, d_sd, d_work + o_clear);
-    mark(1);
-    if (!pl.w_adler.empty())
-        hipLaunchKernelGGL(zs_adler_kernel, dim3((unsigned)pl.w_adler.size()), dim3(256), 0, c->aux, d_sd, d_work + o_adler,
-                           dev<uint32_t>(c->pieces));
-    ZS_HIP(c, hipEventRecord(c->ev_pre, c->aux));
+    auto side_work = [&]() -> bool {
+        ZS_HIP(c, hipStreamWaitEvent(c->aux, c->ev_pre0, 0));
+        if (!pl.w_clear.empty())
+            hipLaunchKernelGGL(zs_clear_kernel, dim3((unsigned)pl.w_clear.size()), dim3(256), 0, c->aux, d_sd, d_work + o_clear);
+        if (!pl.w_adler.empty())
+            hipLaunchKernelGGL(zs_adler_kernel, dim3((unsigned)pl.w_adler.size()), dim3(256), 0, c->aux, d_sd, d_work + o_adler,
+                               dev<uint32_t>(c->pieces));
+        ZS_HIP(c, hipEventRecord(c->ev_pre, c->aux));
+        return true;
+    };
     // One long stream: the position-parallel kernels (links, matches, chunk maps) fill the chip, the kernels that follow
     // the parse (resolve: one workgroup; symbols: one lane per chunk, a latency chain) leave it idle.  ZS_PIPE_PARTS=k cuts
     // the stream into k parts at parse-segment boundaries: while the match kernel works on part i + 1 the second HIP stream
@@ -438,6 +441,7 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
     std::vector<TimedPair> pairs;
     size_t pool_used = 0;
     if (n_parts) {
+        if (!side_work()) return false;
         for (int i = 2; i <= 9; i++) mark(i);  // stages 2..9 are timed launch by launch below; their marks only have to exist
         auto timed = [&](int stage, hipStream_t st_, auto &&launch) {
             if (!prof) {
@@ -543,6 +547,7 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
         hipLaunchKernelGGL(zs_match_kernel, dim3((unsigned)pl.w_match.size()), dim3(1024), kMatchLds + 16, stream, d_sd, d_work + o_match,
                            dev<uint16_t>(c->link), dev<uint2>(c->mm), lv, strategy);
     mark(4);
+    if (!side_work()) return false;
     if (!pl.w_chunks.empty())
         hipLaunchKernelGGL(zs_chunkmap_kernel, dim3((unsigned)pl.w_chunks.size()), dim3(512), 0, stream, d_sd, d_work + o_chunks,
                            dev<uint2>(c->mm), dev<uint32_t>(c->maps), c->crc_tab, lv, strategy,
@@ -693,7 +698,7 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
     if (prof) {
         for (int i = 0; i < kStCount; i++) {
             float ms = 0;
-            (void)hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]);
+            if (i >= kStLinks) (void)hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]);  // clear / adler: beside the others, unmarked
             c->stage_ms[i] = ms;
         }
         if (n_parts) {  // part-wise launches: every launch has its own pair of events, a stage is the sum of its launches
