@@ -15,6 +15,8 @@
 //   KA zs_adler_kernel     Adler-32 per 64 KiB piece (Adler32.cs:270-326)
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "zs_device.h"
 
 namespace zs {
@@ -1492,6 +1494,11 @@ struct GlobalSymSink {
         }
     }
 };
+// One lane per chunk, ~1300 dependent steps, two waves per CU: what a step costs is the latency of its own instructions (a
+// lone wave issues one every 4-8 cycles), not memory -- asking for the lane's next lines from a second wave, or taking the
+// store's acknowledgement out of the step's wait, moved nothing (round 2).  So the step is written out here without
+// branches and in 32-bit positions: lazy_step (zs_core.h, which K3 / K4 and the CPU model use) is the specification,
+// tests/test_gpu_parity.py the check.
 __global__ __launch_bounds__(64) void zs_emit_syms_lane_kernel(const StreamDesc *sd, const StreamState *st, const uint2 *work, int nwork, const uint2 *mm,
                                                                const uint16_t *entry, const uint32_t *symbase, uint32_t *syms,
                                                                int32_t *blk_end, int32_t *blk_top, const uint32_t *crc_tab_g,
@@ -1514,40 +1521,67 @@ __global__ __launch_bounds__(64) void zs_emit_syms_lane_kernel(const StreamDesc 
     int64_t ce = g.ce;
     if (ce > (int64_t)s.body_end + 1) ce = (int64_t)s.body_end + 1;
     if (p >= ce) return;
-    // A step's successor is p+1 or, when the pending match is emitted, p-1+len(pend): both records (and the
-    // literal byte a step at p+1 may emit) are requested one step ahead, so the dependent chain sees the load
-    // latency of a step only where it exceeds the arithmetic of the step before.
+    // A step's successor is p+1 or, when the pending match is emitted, p-1+len(pend): both records (the literal byte a
+    // step at p+1 may emit rides in bits 24..31 of the first) are requested before the step is worked out.
     const uint2 *a = acc.mm;
     const gcbytes gin = acc.in;
-    const int64_t last = (int64_t)s.n - 1;
     uint32_t pend = kNoMatch;
     if (kind == kXK) pend = acc.mK(p - 1);
     else if (kind == kXK4) pend = acc.mK4(p - 1);
     uint8_t lit = p >= 1 ? gin[p - 1] : 0;
     const bool rec_lits = strategy != kHuffmanOnly;  // HuffmanOnly has no match pass: its records are zero-filled
     uint2 cur = a[p];
-    while (p < ce) {
-        int64_t qa = p + 1, qb = pend ? p - 1 + match_len(pend) : qa;
-        if (qa > last) qa = last;
-        if (qb > last) qb = last;
-        const uint2 na = a[qa], nb = a[qb];
-        const uint8_t nlit = rec_lits ? (uint8_t)(cur.x >> 24) : gin[p];
-        uint32_t cK = acc.flt(cur.x), cK4 = acc.flt(cur.y);
-        if (p == 0) cK = cK4 = kNoMatch;
-        const Step st = lazy_step(kind, p, pend, cK, cK4, lv);
-        if (st.emit) {
-            const uint32_t sym = st.emit == 1 ? (uint32_t)lit : (((uint32_t)st.dist << 16) | (uint32_t)(st.len - 3));
-            sink(ns, sym, st.emit == 1 ? p : p - 1 + st.len, p);
-            ns++;
+    if (p == 0) cur.x &= ~kRecMask, cur.y = 0;  // no search at position 0
+    // filter_match on a record: gone if len - 3 <= klm and dist > kdm (TOO_FAR: 3 / 4096; Filtered: <= 5 / any)
+    static_assert(kNoMatch == 0 && kMinMatch == 3, "record arithmetic below");
+    const uint32_t klm = strategy == kFiltered ? 2u : 0u, kdm = strategy == kFiltered ? 0u : (uint32_t)kTooFar;
+    const int q_end = (int)ce, q_last = s.n - 1, lazy = lv.lazy, good = lv.good;
+    int q = (int)p;
+    // the loop in two copies: with one, the literal's register is the target of a load in one case and of a shift in the
+    // other, and the compiler guards the shift with a wait for everything in flight -- the loads just issued
+    auto steps = [&](auto rl_tag) {
+        constexpr bool kRecLits = decltype(rl_tag)::value;
+        // a step's symbol is stored at the top of the next step, ahead of that step's loads (the wave's memory operations
+        // complete in order: behind the loads, its acknowledgement would be waited for with them in the same step)
+        uint32_t dsym = 0;
+        int dns = -1, dend = 0, dtop = 0;
+        while (q < q_end) {
+            if (dns >= 0) sink(dns, dsym, dend, dtop);
+            const int m = pend ? (int)(pend >> 16) + 3 : 2;
+            int qa = q + 1, qb = q - 1 + m;
+            qa = qa > q_last ? q_last : qa;
+            qb = qb > q_last ? q_last : qb;
+            qb = pend ? qb : qa;
+            const uint2 na = a[qa], nb = a[qb];
+            uint8_t nlit;
+            if constexpr (kRecLits) nlit = (uint8_t)(cur.x >> 24);
+            else nlit = gin[q];
+            uint32_t cK = cur.x & kRecMask, cK4 = cur.y & kRecMask;
+            cK = ((cK >> 16) <= klm) & ((cK & 0xFFFFu) > kdm) ? 0u : cK;
+            cK4 = ((cK4 >> 16) <= klm) & ((cK4 & 0xFFFFu) > kdm) ? 0u : cK4;
+            const bool is_x = kind >= kXK, use4 = m >= good;
+            const uint32_t curv = use4 ? cK4 : cK;
+            const int mv = curv ? (int)(curv >> 16) + 3 : 2;
+            const bool emit_match = is_x & !((m < lazy) & (mv > m));
+            const bool emit = is_x | (kind == kL);
+            const int nkind = is_x ? (emit_match ? (int)kR : use4 ? (int)kXK4 : (int)kXK) : cK ? (int)kXK : (int)kL;
+            const int npos = emit_match ? q - 1 + m : q + 1;
+            dsym = emit_match ? ((pend & 0xFFFFu) << 16) | (pend >> 16) : (uint32_t)lit;
+            dns = emit ? ns : -1;
+            dend = emit_match ? npos : q;
+            dtop = q;
+            ns += emit ? 1 : 0;
+            pend = nkind == kXK ? cK : nkind == kXK4 ? cK4 : 0u;
+            kind = nkind;
+            cur = npos == q + 1 ? na : nb;
+            asm volatile("" ::"v"(cur.x), "v"(cur.y));  // the wait for this step's loads stays in this step
+            lit = nlit;
+            q = npos;
         }
-        if (st.kind == kXK) pend = cK;
-        else if (st.kind == kXK4) pend = cK4;
-        else pend = kNoMatch;
-        kind = st.kind;
-        cur = st.pos == p + 1 ? na : nb;
-        lit = nlit;
-        p = st.pos;
-    }
+        if (dns >= 0) sink(dns, dsym, dend, dtop);
+    };
+    if (rec_lits) steps(std::true_type{});
+    else steps(std::false_type{});
 }
 
 // ------------------------------------------------------------------ K5b
