@@ -402,6 +402,7 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
     StreamState *d_st = dev<StreamState>(c->st);
     const uint2 *d_work = dev<uint2>(c->work);
     const bool prof = c->profiling;
+    const int k5_ahead = getenv("ZS_K5_AHEAD") ? atoi(getenv("ZS_K5_AHEAD")) : 1;  // lines the symbol kernel's helper wave asks for ahead of a lane
     auto mark = [&](int i) {
         if (prof) (void)hipEventRecord(c->ev[i], stream);
     };
@@ -524,10 +525,10 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
                                    c->crc_tab, lv, strategy, hash_variant);
             });
             timed(kStEmitSyms, c->aux, [&] {
-                hipLaunchKernelGGL(zs_emit_syms_lane_kernel, dim3((unsigned)((cb - ca + 63) / 64)), dim3(64), 0, c->aux, d_sd, d_st,
+                hipLaunchKernelGGL(zs_emit_syms_lane_kernel, dim3((unsigned)((cb - ca + 63) / 64)), dim3(128), 0, c->aux, d_sd, d_st,
                                    d_work + o_chunks + ca, cb - ca, dev<uint2>(c->mm), dev<uint16_t>(c->entry), dev<uint32_t>(c->symbase),
                                    dev<uint32_t>(c->syms), dev<int32_t>(c->blk_end), dev<int32_t>(c->blk_top), c->crc_tab, lv, strategy,
-                                   hash_variant);
+                                   hash_variant, k5_ahead);
             });
         }
         ZS_HIP(c, hipEventRecord(c->ev_join, c->aux));
@@ -625,10 +626,10 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
                            hash_variant);
     mark(8);
     if (!pl.w_chunks.empty())
-        hipLaunchKernelGGL(zs_emit_syms_lane_kernel, dim3((unsigned)((pl.w_chunks.size() + 63) / 64)), dim3(64), 0, stream, d_sd, d_st,
+        hipLaunchKernelGGL(zs_emit_syms_lane_kernel, dim3((unsigned)((pl.w_chunks.size() + 63) / 64)), dim3(128), 0, stream, d_sd, d_st,
                            d_work + o_chunks, (int)pl.w_chunks.size(), dev<uint2>(c->mm), dev<uint16_t>(c->entry),
                            dev<uint32_t>(c->symbase), dev<uint32_t>(c->syms), dev<int32_t>(c->blk_end), dev<int32_t>(c->blk_top),
-                           c->crc_tab, lv, strategy, hash_variant);
+                           c->crc_tab, lv, strategy, hash_variant, k5_ahead);
     mark(9);
     if (tail_serial)
         hipLaunchKernelGGL(zs_tail_kernel, dim3((unsigned)n), dim3(1024), kTailLds, stream, d_sd, d_st, dev<uint16_t>(c->link),

@@ -1499,11 +1499,60 @@ struct GlobalSymSink {
 // store's acknowledgement out of the step's wait, moved nothing (round 2).  So the step is written out here without
 // branches and in 32-bit positions: lazy_step (zs_core.h, which K3 / K4 and the CPU model use) is the specification,
 // tests/test_gpu_parity.py the check.
-__global__ __launch_bounds__(64) void zs_emit_syms_lane_kernel(const StreamDesc *sd, const StreamState *st, const uint2 *work, int nwork, const uint2 *mm,
+constexpr uint32_t kK5Idle = 0xFFFFFFFEu, kK5Done = 0xFFFFFFFFu;
+typedef __attribute__((address_space(3))) uint32_t *lds_u32p;
+__device__ __forceinline__ void k5_publish(lds_u32p slot, uint32_t v) {
+    asm volatile("ds_write_b32 %0, %1" ::"v"((uint32_t)(uintptr_t)slot), "v"(v) : "memory");
+}
+__device__ __forceinline__ uint32_t k5_peek(lds_u32p slot) {
+    uint32_t v;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"((uint32_t)(uintptr_t)slot) : "memory");
+    return v;
+}
+__global__ __launch_bounds__(128) void zs_emit_syms_lane_kernel(const StreamDesc *sd, const StreamState *st, const uint2 *work, int nwork, const uint2 *mm,
                                                                const uint16_t *entry, const uint32_t *symbase, uint32_t *syms,
                                                                int32_t *blk_end, int32_t *blk_top, const uint32_t *crc_tab_g,
-                                                               LevelCfg lv, int strategy, int hash_variant) {
-    const int i = blockIdx.x * 64 + threadIdx.x;
+                                                               LevelCfg lv, int strategy, int hash_variant, int ahead) {
+    // The second wave of the workgroup asks for the lines its sister lanes will want: the loads of a wave return in order,
+    // so a lane cannot ask for its own next line without waiting for it a step later.  Worker lanes publish the line they
+    // are in (16 records), the helper lane of the same number asks for the `ahead` lines behind it and waits for nothing.
+    __shared__ uint32_t sh_line_[64], sh_last_[64], sh_sink_[64];
+    const int lane = (int)(threadIdx.x & 63);
+    const lds_u32p sh_line = (lds_u32p)sh_line_ + lane, sh_last = (lds_u32p)sh_last_ + lane;
+    if (threadIdx.x < 64) k5_publish(sh_line, kK5Idle);
+    __syncthreads();
+    if (threadIdx.x >= 64) {
+        if (ahead <= 0) return;
+        uint32_t next = 0;
+        bool started = false;
+        for (;;) {
+            const uint32_t cur = k5_peek(sh_line);
+            if (__ballot(cur != kK5Done) == 0) break;
+            bool did = false;
+            if (cur < kK5Idle) {
+                if (!started || next <= cur) {
+                    next = cur + 1;
+                    started = true;
+                }
+                if (next <= cur + (uint32_t)ahead && next <= k5_peek(sh_last)) {
+                    // a load that names no register (the data goes to an LDS word per lane that nobody reads): a register
+                    // target would have to stay untouched until the data is in, and nothing here waits
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(uintptr_t)(mm + ((size_t)next << 4)),
+                                                     (__attribute__((address_space(3))) void *)sh_sink_, 4, 0, 0);
+                    next++;
+                    did = true;
+                }
+            }
+            if (__ballot(did) == 0) __builtin_amdgcn_s_sleep(2);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the LDS words must not be somebody else's when the data arrives
+        return;
+    }
+    struct Done {
+        lds_u32p slot;
+        __device__ ~Done() { k5_publish(slot, kK5Done); }
+    } done{sh_line};
+    const int i = blockIdx.x * 64 + lane;
     if (i >= nwork) return;
     const uint2 w = work[i];
     if (st[w.x].deferred) return;
@@ -1537,6 +1586,8 @@ __global__ __launch_bounds__(64) void zs_emit_syms_lane_kernel(const StreamDesc 
     const uint32_t klm = strategy == kFiltered ? 2u : 0u, kdm = strategy == kFiltered ? 0u : (uint32_t)kTooFar;
     const int q_end = (int)ce, q_last = s.n - 1, lazy = lv.lazy, good = lv.good;
     int q = (int)p;
+    const int64_t pos_off = s.pos_off;
+    k5_publish(sh_last, (uint32_t)((pos_off + q_last) >> 4));
     // the loop in two copies: with one, the literal's register is the target of a load in one case and of a shift in the
     // other, and the compiler guards the shift with a wait for everything in flight -- the loads just issued
     auto steps = [&](auto rl_tag) {
@@ -1547,6 +1598,7 @@ __global__ __launch_bounds__(64) void zs_emit_syms_lane_kernel(const StreamDesc 
         int dns = -1, dend = 0, dtop = 0;
         while (q < q_end) {
             if (dns >= 0) sink(dns, dsym, dend, dtop);
+            if (ahead > 0) k5_publish(sh_line, (uint32_t)((pos_off + q) >> 4));
             const int m = pend ? (int)(pend >> 16) + 3 : 2;
             int qa = q + 1, qb = q - 1 + m;
             qa = qa > q_last ? q_last : qa;
