@@ -1,6 +1,6 @@
 #!/bin/bash
-# the symbol kernel's helper wave: lines asked for ahead of each lane (ZS_K5_AHEAD), bench.py headline
-for a in 0 1 2 3 4; do
+# the symbol kernel with (1) and without (0) its feeding wave, bench.py headline
+for a in 0 1; do
   ZS_K5_AHEAD=$a timeout -k 5 200 python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-secondary 2>/dev/null | tail -1 | python -c "
 import sys, json
 d = json.loads(sys.stdin.read())

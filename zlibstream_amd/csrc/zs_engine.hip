@@ -286,7 +286,7 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
                     pl.w_segs.size() + pl.w_sups.size() + pl.w_blocks.size() + pl.w_runs.size();
     if (!ensure(c, c->sd, sizeof(StreamDesc) * (size_t)n) || !ensure(c, c->st, sizeof(StreamState) * (size_t)n) ||
         !ensure(c, c->work, sizeof(uint2) * (n_work + 1)) || !ensure(c, c->link, 2 * (size_t)pl.n_pos + 64) ||
-        !ensure(c, c->mm, 8 * (size_t)pl.n_pos + 64) ||
+        !ensure(c, c->mm, 8 * (size_t)pl.n_pos + 256) ||  // the symbol kernel stages whole 128-byte lines
         !ensure(c, c->maps, 4 * (size_t)(pl.n_chunks + 1) * kSlots) || !ensure(c, c->segmap, 8 * (size_t)(pl.n_segs + 1) * kSlots) ||
         !ensure(c, c->supmap, 8 * (size_t)(pl.n_sups + 1) * kSlots) || !ensure(c, c->chunk_far, 2 * (size_t)pl.n_chunks + 64) ||
         !ensure(c, c->seg_entry, 2 * (size_t)(pl.n_segs + 2)) || !ensure(c, c->seg_symbase, 4 * (size_t)(pl.n_segs + 2)) ||
@@ -525,7 +525,7 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
                                    c->crc_tab, lv, strategy, hash_variant);
             });
             timed(kStEmitSyms, c->aux, [&] {
-                hipLaunchKernelGGL(zs_emit_syms_lane_kernel, dim3((unsigned)((cb - ca + 63) / 64)), dim3(128), 0, c->aux, d_sd, d_st,
+                hipLaunchKernelGGL(zs_emit_syms_lane_kernel, dim3((unsigned)((cb - ca + 63) / 64)), dim3(kK5Threads), 0, c->aux, d_sd, d_st,
                                    d_work + o_chunks + ca, cb - ca, dev<uint2>(c->mm), dev<uint16_t>(c->entry), dev<uint32_t>(c->symbase),
                                    dev<uint32_t>(c->syms), dev<int32_t>(c->blk_end), dev<int32_t>(c->blk_top), c->crc_tab, lv, strategy,
                                    hash_variant, k5_ahead);
@@ -626,7 +626,7 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
                            hash_variant);
     mark(8);
     if (!pl.w_chunks.empty())
-        hipLaunchKernelGGL(zs_emit_syms_lane_kernel, dim3((unsigned)((pl.w_chunks.size() + 63) / 64)), dim3(128), 0, stream, d_sd, d_st,
+        hipLaunchKernelGGL(zs_emit_syms_lane_kernel, dim3((unsigned)((pl.w_chunks.size() + 63) / 64)), dim3(kK5Threads), 0, stream, d_sd, d_st,
                            d_work + o_chunks, (int)pl.w_chunks.size(), dev<uint2>(c->mm), dev<uint16_t>(c->entry),
                            dev<uint32_t>(c->symbase), dev<uint32_t>(c->syms), dev<int32_t>(c->blk_end), dev<int32_t>(c->blk_top),
                            c->crc_tab, lv, strategy, hash_variant, k5_ahead);

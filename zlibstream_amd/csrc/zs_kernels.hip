@@ -1500,52 +1500,92 @@ struct GlobalSymSink {
 // branches and in 32-bit positions: lazy_step (zs_core.h, which K3 / K4 and the CPU model use) is the specification,
 // tests/test_gpu_parity.py the check.
 constexpr uint32_t kK5Idle = 0xFFFFFFFEu, kK5Done = 0xFFFFFFFFu;
+constexpr int kK5Ring = 4;                                // lines (16 records, 128 bytes) per lane in LDS
+constexpr int kK5RingBytes = kK5Ring * 64 * 128;          // slot r of lane w: r * 8192 + w * 128
 typedef __attribute__((address_space(3))) uint32_t *lds_u32p;
 __device__ __forceinline__ void k5_publish(lds_u32p slot, uint32_t v) {
     asm volatile("ds_write_b32 %0, %1" ::"v"((uint32_t)(uintptr_t)slot), "v"(v) : "memory");
 }
-__device__ __forceinline__ uint32_t k5_peek(lds_u32p slot) {
-    uint32_t v;
-    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"((uint32_t)(uintptr_t)slot) : "memory");
-    return v;
-}
-__global__ __launch_bounds__(128) void zs_emit_syms_lane_kernel(const StreamDesc *sd, const StreamState *st, const uint2 *work, int nwork, const uint2 *mm,
+// (reads the compiler knows about: it places the waits; volatile keeps them in program order among themselves)
+__device__ __forceinline__ uint32_t k5_peek(lds_u32p slot) { return *(volatile __attribute__((address_space(3))) uint32_t *)slot; }
+__device__ __forceinline__ uint64_t k5_peek64(uint32_t addr) { return *(volatile __attribute__((address_space(3))) uint64_t *)addr; }
+__global__ __launch_bounds__(kK5Threads) void zs_emit_syms_lane_kernel(const StreamDesc *sd, const StreamState *st, const uint2 *work, int nwork, const uint2 *mm,
                                                                const uint16_t *entry, const uint32_t *symbase, uint32_t *syms,
                                                                int32_t *blk_end, int32_t *blk_top, const uint32_t *crc_tab_g,
                                                                LevelCfg lv, int strategy, int hash_variant, int ahead) {
-    // The second wave of the workgroup asks for the lines its sister lanes will want: the loads of a wave return in order,
-    // so a lane cannot ask for its own next line without waiting for it a step later.  Worker lanes publish the line they
-    // are in (16 records), the helper lane of the same number asks for the `ahead` lines behind it and waits for nothing.
-    __shared__ uint32_t sh_line_[64], sh_last_[64], sh_sink_[64];
+    // Wave 0 walks (one lane per chunk), wave 1 feeds it.  A lane's records come 8 bytes a step out of its own 128-byte
+    // lines: as loads of the walking wave they are 64 different lines per instruction (the texture path takes them one
+    // lane at a time), two instructions a step, and a wave's loads return in order, so it cannot ask ahead for itself.
+    // The feeding wave reads every line once, 8 lanes x 16 bytes, straight into LDS (LDS-DMA: no register is named, so
+    // nothing has to wait for the data), kK5Ring lines ahead of where each walking lane says it is; the walking lanes take
+    // their records from LDS and fall back to a load of their own where a jump (a long match) outran the ring.
+    // Lines are counted from the line of the chunk's first loop-top.  Slot of line L: L mod kK5Ring; line L + kK5Ring
+    // goes into it only when the lane has said it is past L, and the lane reads nothing below the line it has announced.
+    __shared__ uint4 sh_ring_[kK5RingBytes / 16];
+    __shared__ uint32_t sh_line_[64], sh_last_[64], sh_base_[64], sh_filled_[64];
     const int lane = (int)(threadIdx.x & 63);
-    const lds_u32p sh_line = (lds_u32p)sh_line_ + lane, sh_last = (lds_u32p)sh_last_ + lane;
-    if (threadIdx.x < 64) k5_publish(sh_line, kK5Idle);
+    const lds_u32p sh_line = (lds_u32p)sh_line_ + lane, sh_last = (lds_u32p)sh_last_ + lane, sh_base = (lds_u32p)sh_base_ + lane,
+                   sh_filled = (lds_u32p)sh_filled_ + lane;
+    if (threadIdx.x < 64) {
+        k5_publish(sh_line, kK5Idle);
+        k5_publish(sh_filled, (uint32_t)-1);
+    }
     __syncthreads();
     if (threadIdx.x >= 64) {
         if (ahead <= 0) return;
-        uint32_t next = 0;
-        bool started = false;
+        // feeding wave f serves the walking lanes 16 f .. 16 f + 15: two groups of 8, each lane one 16-byte piece of a line
+        constexpr int kG = 8 / kK5Feeders;
+        const int piece = lane & 7, wsub = lane >> 3;
+        const int g0 = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6) - 1) * kG;
+        int32_t nf[kG];  // per group of 8 walking lanes: the next line this lane's walker has not been given yet
+#pragma unroll
+        for (int g = 0; g < kG; g++) nf[g] = 0;
         for (;;) {
-            const uint32_t cur = k5_peek(sh_line);
-            if (__ballot(cur != kK5Done) == 0) break;
-            bool did = false;
-            if (cur < kK5Idle) {
-                if (!started || next <= cur) {
-                    next = cur + 1;
-                    started = true;
-                }
-                if (next <= cur + (uint32_t)ahead && next <= k5_peek(sh_last)) {
-                    // a load that names no register (the data goes to an LDS word per lane that nobody reads): a register
-                    // target would have to stay untouched until the data is in, and nothing here waits
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(uintptr_t)(mm + ((size_t)next << 4)),
-                                                     (__attribute__((address_space(3))) void *)sh_sink_, 4, 0, 0);
-                    next++;
-                    did = true;
+            uint32_t c[kG], la[kG], ba[kG];
+#pragma unroll
+            for (int g = 0; g < kG; g++) {
+                c[g] = k5_peek((lds_u32p)sh_line_ + 8 * (g0 + g) + wsub);
+                la[g] = k5_peek((lds_u32p)sh_last_ + 8 * (g0 + g) + wsub);
+                ba[g] = k5_peek((lds_u32p)sh_base_ + 8 * (g0 + g) + wsub);
+            }
+            bool busy = false, did = false;
+            int32_t pub[kG];
+#pragma unroll
+            for (int g = 0; g < kG; g++) {
+                busy |= c[g] != kK5Done;
+                pub[g] = -1;
+                if (c[g] < kK5Idle) {
+                    const int32_t cl = (int32_t)c[g], lo = nf[g] > cl ? nf[g] : cl;
+                    int32_t hi = cl + kK5Ring - 1;
+                    hi = hi > (int32_t)la[g] ? (int32_t)la[g] : hi;
+#pragma unroll
+                    for (int r = 0; r < kK5Ring; r++) {
+                        const int32_t L = lo + ((r - lo) & (kK5Ring - 1));
+                        if (L <= hi) {
+                            const uint2 *src = mm + (((size_t)ba[g] + (size_t)L) << 4) + 2 * piece;
+                            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(uintptr_t)src,
+                                                             (__attribute__((address_space(3))) void *)((__attribute__((address_space(3))) uint8_t *)sh_ring_ + r * 8192 + (g0 + g) * 1024),
+                                                             16, 0, 0);
+                            did = true;
+                        }
+                    }
+                    if (lo <= hi) {
+                        nf[g] = hi + 1;
+                        pub[g] = hi;
+                    }
                 }
             }
-            if (__ballot(did) == 0) __builtin_amdgcn_s_sleep(2);
+            if (__ballot(busy) == 0) break;
+            if (__ballot(did) != 0) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int g = 0; g < kG; g++)
+                    if (pub[g] >= 0 && piece == 0) k5_publish((lds_u32p)sh_filled_ + 8 * (g0 + g) + wsub, (uint32_t)pub[g]);
+            } else {
+                __builtin_amdgcn_s_sleep(2);
+            }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the LDS words must not be somebody else's when the data arrives
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the LDS must not be somebody else's when data arrives
         return;
     }
     struct Done {
@@ -1586,25 +1626,45 @@ __global__ __launch_bounds__(128) void zs_emit_syms_lane_kernel(const StreamDesc
     const uint32_t klm = strategy == kFiltered ? 2u : 0u, kdm = strategy == kFiltered ? 0u : (uint32_t)kTooFar;
     const int q_end = (int)ce, q_last = s.n - 1, lazy = lv.lazy, good = lv.good;
     int q = (int)p;
-    const int64_t pos_off = s.pos_off;
-    k5_publish(sh_last, (uint32_t)((pos_off + q_last) >> 4));
+    // line 0 = the line of the first loop-top's record; q0 = the position its first record would have
+    const int64_t gi0 = s.pos_off + q;
+    const int q0 = q - (int)(gi0 & 15);
+    const uint32_t ring_lane = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)sh_ring_ + (uint32_t)lane * 128u;
+    k5_publish(sh_base, (uint32_t)(gi0 >> 4));
+    k5_publish(sh_last, (uint32_t)(q_last - q0) >> 4);
     // the loop in two copies: with one, the literal's register is the target of a load in one case and of a shift in the
     // other, and the compiler guards the shift with a wait for everything in flight -- the loads just issued
-    auto steps = [&](auto rl_tag) {
-        constexpr bool kRecLits = decltype(rl_tag)::value;
+    auto steps = [&](auto rl_tag, auto ring_tag) {
+        constexpr bool kRecLits = decltype(rl_tag)::value, kRing = decltype(ring_tag)::value;
         // a step's symbol is stored at the top of the next step, ahead of that step's loads (the wave's memory operations
         // complete in order: behind the loads, its acknowledgement would be waited for with them in the same step)
         uint32_t dsym = 0;
         int dns = -1, dend = 0, dtop = 0;
+#ifdef ZS_FV_PROF
+        long long k5t0 = wall_clock64();
+        int k5steps = 0, k5miss = 0, k5lanemiss = 0, k5mysteps = 0;
+#endif
         while (q < q_end) {
             if (dns >= 0) sink(dns, dsym, dend, dtop);
-            if (ahead > 0) k5_publish(sh_line, (uint32_t)((pos_off + q) >> 4));
             const int m = pend ? (int)(pend >> 16) + 3 : 2;
             int qa = q + 1, qb = q - 1 + m;
             qa = qa > q_last ? q_last : qa;
             qb = qb > q_last ? q_last : qb;
             qb = pend ? qb : qa;
-            const uint2 na = a[qa], nb = a[qb];
+            uint2 na, nb;
+            int32_t filled = 0;
+            if constexpr (kRing) {
+                const uint32_t ua = (uint32_t)(qa - q0), ub = (uint32_t)(qb - q0);
+                k5_publish(sh_line, (uint32_t)(q - q0) >> 4);
+                filled = (int32_t)k5_peek(sh_filled);  // read ahead of the records: what it vouches for is in them
+                const uint64_t ra = k5_peek64(ring_lane + ((ua & (16u * (kK5Ring - 1))) << 9) + ((ua & 15u) << 3));
+                const uint64_t rb = k5_peek64(ring_lane + ((ub & (16u * (kK5Ring - 1))) << 9) + ((ub & 15u) << 3));
+                na = make_uint2((uint32_t)ra, (uint32_t)(ra >> 32));
+                nb = make_uint2((uint32_t)rb, (uint32_t)(rb >> 32));
+            } else {
+                na = a[qa];
+                nb = a[qb];
+            }
             uint8_t nlit;
             if constexpr (kRecLits) nlit = (uint8_t)(cur.x >> 24);
             else nlit = gin[q];
@@ -1625,15 +1685,38 @@ __global__ __launch_bounds__(128) void zs_emit_syms_lane_kernel(const StreamDesc
             ns += emit ? 1 : 0;
             pend = nkind == kXK ? cK : nkind == kXK4 ? cK4 : 0u;
             kind = nkind;
-            cur = npos == q + 1 ? na : nb;
+            if constexpr (kRing) {
+                const int qn = npos == q + 1 ? qa : qb;
+                cur = npos == q + 1 ? na : nb;
+#ifdef ZS_FV_PROF
+                k5steps++, k5mysteps++;
+                k5miss += __ballot((int32_t)((uint32_t)(qn - q0) >> 4) > filled) != 0;
+                k5lanemiss += (int32_t)((uint32_t)(qn - q0) >> 4) > filled;
+#endif
+                if ((int32_t)((uint32_t)(qn - q0) >> 4) > filled) {  // a jump past what the ring holds
+                    // (load and wait in one piece the compiler does not look into: a load of its own would make it wait,
+                    // in every step, for everything in flight -- the acknowledgement of the store at the step's top)
+                    uint64_t rec;
+                    asm volatile("global_load_dwordx2 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=&v"(rec) : "v"(a + qn) : "memory");
+                    cur = make_uint2((uint32_t)rec, (uint32_t)(rec >> 32));
+                }
+            } else {
+                cur = npos == q + 1 ? na : nb;
+            }
             asm volatile("" ::"v"(cur.x), "v"(cur.y));  // the wait for this step's loads stays in this step
             lit = nlit;
             q = npos;
         }
         if (dns >= 0) sink(dns, dsym, dend, dtop);
+#ifdef ZS_FV_PROF
+        if (kRing && (blockIdx.x & 63) == 7 && (lane == 0 || lane == 37))
+            printf("K5PROF block %d lane %d: my steps %d, my misses %d; steps with a miss in the wave %d; ticks (100 MHz) %lld\n", (int)blockIdx.x, lane,
+                   k5mysteps, k5lanemiss, k5miss, wall_clock64() - k5t0);
+#endif
     };
-    if (rec_lits) steps(std::true_type{});
-    else steps(std::false_type{});
+    if (!rec_lits) steps(std::false_type{}, std::false_type{});
+    else if (ahead > 0) steps(std::true_type{}, std::true_type{});
+    else steps(std::true_type{}, std::false_type{});
 }
 
 // ------------------------------------------------------------------ K5b
