@@ -81,7 +81,7 @@ struct StreamDesc {
 struct WorkOffsets {
     uint32_t off[10];
 };
-constexpr int kK5Feeders = 4;     // waves of the symbol kernel's workgroup that stage the walking wave's records in LDS
+constexpr int kK5Feeders = 2;     // waves of the symbol kernel's workgroup that stage the walking wave's records in LDS
 constexpr int kK5Threads = 64 * (1 + kK5Feeders);
 constexpr int kSupSegs = 16;      // parse segments composed into one row of supmap ahead of the resolve kernel
 constexpr int kTailRecMax = 288;  // positions of a tail whose searches are done ahead (zs_tail_kernel): <= 261 - max_lazy + a few

@@ -209,6 +209,17 @@ ZS_HD int le_insert(LitEngine &e, int str) {
         }
     }
     uint32_t h = le_hash(e, le_load32(e.window + str + 2));
+    if (e.pre_rec) {
+        // A loop-top whose search was done ahead (le_tail_record) from prev[] as the restore left it: what head[h] holds
+        // is prev[str], which is written already -- only head[h] has to follow, for the few inserts behind the records.
+        // The table is in HBM scratch: a store is not waited for, the load was a round trip per position (with the
+        // acknowledgements of the stores before it).
+        const int64_t qa = e.base + str;
+        if (qa >= e.pre_lo && qa < e.pre_hi) {
+            e.head[h] = (uint16_t)str;
+            return ZS_LDS_PTR(const uint16_t, e.prev)[str & kWMask];
+        }
+    }
     int cur = e.head[h];
     if (cur != str) {
         ZS_LDS_PTR(uint16_t, e.prev)[str & kWMask] = (uint16_t)cur;
