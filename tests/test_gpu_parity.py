@@ -680,6 +680,43 @@ def test_tail_searches_done_ahead_many_odd_sized_streams(engine, oracle):
             assert z == oracle.compress(b, lvl, strat), (lvl, strat, i, len(b))
 
 
+def test_symbol_kernel_records_through_the_lds_ring_and_by_direct_loads(engine, oracle):
+    """The symbol kernel (Tr_tally along the true path, Deflate.cs:910-948 / Deflate.Slow.cs:34-145) takes its match records
+    from an LDS ring that two feeding waves fill ahead of each walking lane, and loads for itself where a long match jumps
+    past the ring.  Text (short hops), long repeats at irregular distances (jumps of up to 258 positions, most of them
+    beyond the ring's 64), streams that end inside a 128-byte line of records, many streams per workgroup -- against the
+    oracle at levels 4-9 and under Filtered; and once more with the feeding waves switched off (ZS_K5_AHEAD=0), the same
+    bytes through direct loads only.  HuffmanOnly (literals from the input, no records) takes the direct path as well."""
+    rng = np.random.default_rng(555)
+    alice = open(os.path.join(os.path.dirname(__file__), "golden", "corpus", "alice29.txt"), "rb").read()
+    bufs = []
+    for i in range(96):
+        n = int(rng.integers(2400, 70000))
+        t = bytearray(datagen.english(n, 100 + i)) if i % 3 else bytearray(alice[i * 97:i * 97 + n])
+        n = len(t)
+        if i % 2:  # copies of 40..600 bytes from somewhere earlier, every few hundred bytes
+            q = 1000
+            while q + 700 < n:
+                k = int(rng.integers(40, 600))
+                src = int(rng.integers(0, q - 600)) if q > 700 else 0
+                t[q:q + k] = t[src:src + k]
+                q += k + int(rng.integers(30, 900))
+        bufs.append(bytes(t))
+    bufs.append(datagen.english(3 << 20, 9))
+    bufs.append(datagen.sparse(512, 512))
+    cases = ((4, 0), (6, 0), (9, 0), (6, int(CompressionStrategy.Filtered)))
+    want = {c: [oracle.compress(b, c[0], c[1]) for b in bufs] for c in cases}
+    for c in cases:
+        assert engine.deflate_batch(bufs, level=c[0], strategy=c[1]) == want[c], c
+    os.environ["ZS_K5_AHEAD"] = "0"
+    try:
+        assert engine.deflate_batch(bufs, level=6) == want[(6, 0)]
+    finally:
+        del os.environ["ZS_K5_AHEAD"]
+    ho = int(CompressionStrategy.HuffmanOnly)
+    assert engine.deflate_batch(bufs[:8], level=6, strategy=ho) == [oracle.compress(b, 6, ho) for b in bufs[:8]]
+
+
 def test_resolve_through_composed_segment_maps_and_row_by_row(engine, oracle):
     """The resolve kernel follows a long stream through the segment maps composed 16 at a time (zs_supmap_kernel) and goes
     back to the row-by-row walk when the path meets an equal-bucket refill (Deflate.cs:1010-1013 with both positions in one
