@@ -654,6 +654,7 @@ __device__ __forceinline__ uint32_t stage_chunk_matches(const StreamDesc &s, int
     const uint2 *a = mm + s.pos_off;
     int64_t org = g.cs - 1;
     uint32_t far = 0;
+    const uint32_t klm = strategy == kFiltered ? 2u : 0u, kdm = strategy == kFiltered ? 0u : (uint32_t)kTooFar;
     for (int i = threadIdx.x; i < kChunk + 1; i += blockDim.x) {
         int64_t p = org + i;
         uint32_t x = 0, y = 0;
@@ -665,8 +666,9 @@ __device__ __forceinline__ uint32_t stage_chunk_matches(const StreamDesc &s, int
                 far = far > dx ? far : dx;
                 far = far > dy ? far : dy;
             }
-            x = x ? filter_match(match_len(x), match_dist(x), strategy) : kNoMatch;
-            y = y ? filter_match(match_len(y), match_dist(y), strategy) : kNoMatch;
+            // filter_match (zs_core.h) on a record: gone if len - 3 <= klm and dist > kdm (TOO_FAR: 3 / 4096; Filtered: <= 5 / any)
+            x = ((x >> 16) <= klm) & ((x & 0xFFFFu) > kdm) ? 0u : x;
+            y = ((y >> 16) <= klm) & ((y & 0xFFFFu) > kdm) ? 0u : y;
         }
         fk[i] = x;
         fk4[i] = y;
@@ -705,10 +707,32 @@ __device__ __forceinline__ void chunkmap_compute(const StreamDesc &s, int c, con
     if (ce > (int64_t)s.body_end + 1) ce = (int64_t)s.body_end + 1;
     const int len = (int)(ce - g.cs);
     LdsAcc acc{as_global(s.in), fk, fk4, g.cs - 1, tab, hash_variant};
+    // node_step3_all (zs_core.h: three lazy_steps and their node ids) written out with selects: through the shared code it
+    // was half of this kernel's instructions, most of them execution-mask pairs around a move or two (the same finding as
+    // in the symbol kernel; the shared form stays the specification and what the CPU model runs)
+    static_assert(kR == 0 && kL == 1 && kXK == 2 && kXK4 == 3 && kNoMatch == 0, "node arithmetic below");
+    const int lazy = lv.lazy, good = lv.good;
+    auto node_at = [len](int kind, int rel, uint32_t cnt) -> uint32_t {  // node_pack(node_of3(kind, cs + rel, cs, ce), cnt)
+        const int inside = ((kind + 1) >> 1) * kChunk + rel, outside = kNodeExit3 + (kind == kR ? rel - len : 256 + kind);
+        return (uint32_t)(rel < len ? inside : outside) | (cnt << 14);
+    };
+    auto x_step = [&](uint32_t pend, uint32_t cK, uint32_t cK4, int rel) -> uint32_t {  // lazy_step at an XK / XK4 loop-top
+        const int m = pend ? (int)(pend >> 16) + 3 : 2;
+        const bool use4 = m >= good;
+        const uint32_t curv = use4 ? cK4 : cK;
+        const int mv = curv ? (int)(curv >> 16) + 3 : 2;
+        const bool defer = (m < lazy) & (mv > m);
+        return node_at(defer ? (use4 ? (int)kXK4 : (int)kXK) : (int)kR, defer ? rel + 1 : rel - 1 + m, 1u);
+    };
     for (int off = threadIdx.x; off < len; off += nt) {
-        uint32_t r0, r1, r2;
-        node_step3_all(acc, g.cs + off, g.cs, ce, lv, r0, r1, r2);
-        tbl[off] = r0, tbl[kChunk + off] = r1, tbl[2 * kChunk + off] = r2;
+        const uint32_t before = fk[off], before4 = fk4[off];
+        uint32_t cK = fk[off + 1], cK4 = fk4[off + 1];
+        if (g.cs + off == 0) cK = cK4 = kNoMatch;
+        const int plain_kind = cK ? (int)kXK : (int)kL;
+        const uint32_t r0 = node_at(plain_kind, off + 1, 0u);
+        const uint32_t r1x = x_step(before, cK, cK4, off), r1l = node_at(plain_kind, off + 1, 1u);
+        const uint32_t r2 = x_step(before4, cK, cK4, off);
+        tbl[off] = r0, tbl[kChunk + off] = before ? r1x : r1l, tbl[2 * kChunk + off] = r2;
     }
     __syncthreads();
     // two dependent lookups per pass: after pass r every entry jumps >= 3^r steps or reaches its exit (a step advances
