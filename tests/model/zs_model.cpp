@@ -459,6 +459,11 @@ static void run_tail(Model &m, int64_t p, int kind, uint32_t pend, int k_done, i
     e.block_syms = m.level == 0 ? (kLitBufsize / 2) - 1 : kBlockSyms;
     le_restore(e, p, m.rev.empty() ? 0 : m.rev[(size_t)k_done].base, m.rev.empty() ? 0 : m.rev[(size_t)k_done].after, kind, pend,
                m.link.data(), preins, 0, 1);
+    // the tail's searches ahead of its parse (le_tail_record) and the engine without hash heads (LitEngine::no_head), under
+    // the conditions of zs_tail_kernel: a slow level, one Write, everything read, no pre-insert pending
+    const bool use_rec = m.lv.func == 2 && m.strategy != kRle && m.strategy != kHuffmanOnly && !e.wr_end && !m.incremental &&
+                         e.avail_end == e.n && e.avail_end > 0 && preins < p && m.ins.empty() && !getenv("ZS_NO_TAIL_RECORDS") &&
+                         le_tail_record_end(e) > p && le_tail_record_end(e) - p <= kTailRecMax;
     if (e.avail_end > 0) {
         int64_t lo = p - (kWSize - 1);
         if (lo < e.base) lo = e.base;
@@ -471,18 +476,30 @@ static void run_tail(Model &m, int64_t p, int kind, uint32_t pend, int k_done, i
             } else {
                 le_restore_prev(e, q, m.link.data());
             }
-            e.head[le_bucket(e, q)] = (uint16_t)(q - e.base);  // increasing q: last writer = max
+            if (!(use_rec && le_no_head_ok(e))) e.head[le_bucket(e, q)] = (uint16_t)(q - e.base);  // increasing q: last writer = max
         }
         le_restore_finish(e, p, m.link.data(), preins);
     }
-    // the tail's searches ahead of its parse (le_tail_record), under the conditions of zs_tail_kernel: a slow level, one
-    // Write, everything read, no pre-insert pending
     std::vector<uint32_t> pre;
-    if (m.lv.func == 2 && m.strategy != kRle && m.strategy != kHuffmanOnly && !e.wr_end && !m.incremental && e.avail_end == e.n &&
-        e.avail_end > 0 && preins < p && m.ins.empty() && !getenv("ZS_NO_TAIL_RECORDS")) {
+    if (use_rec) {
         const int64_t hi = le_tail_record_end(e);
-        if (hi > p && hi - p <= 512) {
-            for (int64_t q = p; q < hi; q++) le_restore_prev(e, q, m.link.data());
+        for (int64_t q = p; q < hi; q++) le_restore_prev(e, q, m.link.data());
+        if (le_no_head_ok(e)) {
+            for (int64_t q = p; q < e.n - 5; q++) le_restore_prev(e, q, m.link.data());
+            int64_t lo = p - (kWSize - 1);
+            if (lo < e.base) lo = e.base;
+            if (lo < 1) lo = 1;
+            for (int k = 0; k < 3; k++) {
+                const uint32_t hb = le_tail_head_bucket(e, k);
+                e.tail_head[k] = 0;
+                for (int64_t q = lo; q < e.n - 5 + k; q++)
+                    if (le_bucket(e, q) == hb) e.tail_head[k] = (int)(q - e.base);
+            }
+            e.no_head = 1;
+            if (getenv("ZS_FV_STATS")) printf("tail heads (window index) %d %d %d, base %ld, p %ld n %ld\n", e.tail_head[0], e.tail_head[1], e.tail_head[2], (long)e.base, (long)p, (long)e.n);
+            std::fill(head.begin(), head.end(), (uint16_t)0xDEAD);  // not to be looked at
+        }
+        {
             pre.assign((size_t)(2 * (hi - p)), 0);
             for (int64_t q = p; q < hi; q++) {
                 pre[(size_t)(2 * (q - p))] = le_tail_record(e, (int)(q - e.base), (int)(e.n - q), m.lv.chain);

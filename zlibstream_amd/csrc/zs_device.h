@@ -84,7 +84,6 @@ struct WorkOffsets {
 constexpr int kK5Feeders = 2;     // waves of the symbol kernel's workgroup that stage the walking wave's records in LDS
 constexpr int kK5Threads = 64 * (1 + kK5Feeders);
 constexpr int kSupSegs = 16;      // parse segments composed into one row of supmap ahead of the resolve kernel
-constexpr int kTailRecMax = 288;  // positions of a tail whose searches are done ahead (zs_tail_kernel): <= 261 - max_lazy + a few
 constexpr int kFvTile = 16384;
 constexpr int kFvBack = 32512;  // >= kMaxDist, multiple of 32
 constexpr int kFvFwd = 272;     // >= kMaxMatch + 8, multiple of 16

@@ -525,7 +525,7 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
                                    c->crc_tab, lv, strategy, hash_variant);
             });
             timed(kStEmitSyms, c->aux, [&] {
-                hipLaunchKernelGGL(zs_emit_syms_lane_kernel, dim3((unsigned)((cb - ca + 63) / 64)), dim3(kK5Threads), 0, c->aux, d_sd, d_st,
+                hipLaunchKernelGGL(zs_emit_syms_lane_kernel<4>, dim3((unsigned)((cb - ca + 63) / 64)), dim3(kK5Threads), 0, c->aux, d_sd, d_st,
                                    d_work + o_chunks + ca, cb - ca, dev<uint2>(c->mm), dev<uint16_t>(c->entry), dev<uint32_t>(c->symbase),
                                    dev<uint32_t>(c->syms), dev<int32_t>(c->blk_end), dev<int32_t>(c->blk_top), c->crc_tab, lv, strategy,
                                    hash_variant, k5_ahead);
@@ -609,7 +609,7 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
     // they take alone (0.5).  From 64 streams of 256 KiB or more on the tails run behind the symbols instead (thousands of
     // small streams are the other way round: 16 rounds of tails, a short symbol kernel -- beside each other 18.9 ms for
     // 4096 x 32 KiB, one after the other 20.1).
-    const bool tail_serial = !tail_late && n >= 64 && pl.n_pos / n >= (256 << 10) && !getenv("ZS_TAIL_FORK");
+    const bool tail_serial = !tail_late && n >= 64 && (pl.n_pos / n >= (256 << 10) || getenv("ZS_TAIL_SERIAL")) && !getenv("ZS_TAIL_FORK");
     if (!tail_late && !tail_serial) {
         ZS_HIP(c, hipEventRecord(c->ev_fork, stream));
         ZS_HIP(c, hipStreamWaitEvent(c->aux, c->ev_fork, 0));
@@ -626,7 +626,13 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
                            hash_variant);
     mark(8);
     if (!pl.w_chunks.empty())
-        hipLaunchKernelGGL(zs_emit_syms_lane_kernel, dim3((unsigned)((pl.w_chunks.size() + 63) / 64)), dim3(kK5Threads), 0, stream, d_sd, d_st,
+        if (n >= 64)  // a batch: three lines per lane, so that a workgroup fits on a CU beside a tail-kernel workgroup (zs_kernels.hip)
+            hipLaunchKernelGGL(zs_emit_syms_lane_kernel<3>, dim3((unsigned)((pl.w_chunks.size() + 63) / 64)), dim3(kK5Threads), 0, stream, d_sd, d_st,
+                           d_work + o_chunks, (int)pl.w_chunks.size(), dev<uint2>(c->mm), dev<uint16_t>(c->entry),
+                           dev<uint32_t>(c->symbase), dev<uint32_t>(c->syms), dev<int32_t>(c->blk_end), dev<int32_t>(c->blk_top),
+                           c->crc_tab, lv, strategy, hash_variant, k5_ahead);
+        else
+            hipLaunchKernelGGL(zs_emit_syms_lane_kernel<4>, dim3((unsigned)((pl.w_chunks.size() + 63) / 64)), dim3(kK5Threads), 0, stream, d_sd, d_st,
                            d_work + o_chunks, (int)pl.w_chunks.size(), dev<uint2>(c->mm), dev<uint16_t>(c->entry),
                            dev<uint32_t>(c->symbase), dev<uint32_t>(c->syms), dev<int32_t>(c->blk_end), dev<int32_t>(c->blk_top),
                            c->crc_tab, lv, strategy, hash_variant, k5_ahead);
@@ -681,6 +687,12 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
     // the tree kernel is one latency chain per block: many small blocks (a batch of small streams) want more resident
     // workgroups, a long stream's 16 Ki-symbol blocks a wider histogram
     const int trees_threads = pl.w_blocks.size() > 8192 ? 128 : 256;
+    if (n >= 64 && !getenv("ZS_NO_LIVE_LIST")) {
+        // many streams: the block list rewritten with the blocks that exist in front (zs_live_scan_kernel)
+        hipLaunchKernelGGL(zs_live_scan_kernel, dim3(1), dim3(1024), 0, stream, d_st, n, dev<int32_t>(c->wpre));
+        hipLaunchKernelGGL(zs_live_fill_kernel, dim3((unsigned)((pl.w_blocks.size() + 255) / 256)), dim3(256), 0, stream, dev<int32_t>(c->wpre), n,
+                           (uint32_t)pl.w_blocks.size(), dev<uint2>(c->work) + o_blocks);
+    }
     hipLaunchKernelGGL(zs_trees_kernel, dim3((unsigned)pl.w_blocks.size()), dim3(trees_threads), 0, stream, d_sd, d_st, d_work + o_blocks,
                        dev<uint32_t>(c->syms), dev<BlockRec>(c->blocks), dev<TreeWork>(c->trees), dev<BlockInfo>(c->info), strategy, level, 2);
     mark(11);

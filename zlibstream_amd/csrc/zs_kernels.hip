@@ -1524,8 +1524,15 @@ struct GlobalSymSink {
 // branches and in 32-bit positions: lazy_step (zs_core.h, which K3 / K4 and the CPU model use) is the specification,
 // tests/test_gpu_parity.py the check.
 constexpr uint32_t kK5Idle = 0xFFFFFFFEu, kK5Done = 0xFFFFFFFFu;
-constexpr int kK5Ring = 4;                                // lines (16 records, 128 bytes) per lane in LDS
-constexpr int kK5RingBytes = kK5Ring * 64 * 128;          // slot r of lane w: r * 8192 + w * 128
+// Lines (16 records, 128 bytes) per walking lane in LDS; slot r of lane w: r * 8192 + w * 128.  Four for a few streams; three
+// for a batch, where a workgroup (25 KiB) then fits on a CU beside one of the tail kernel's (133 KiB of the 160): with four
+// the two kernels, launched side by side on two streams, took the CUs in turns (4096 x 32 KiB: 2.1 + 4.7 ms).
+template <int R>
+__device__ __forceinline__ uint32_t k5_slot(uint32_t line) {  // line mod R (lines of a chunk: < 512)
+    if constexpr (R == 4) return line & 3u;
+    else return line - (uint32_t)R * ((line * (uint32_t)(512 / R + 1)) >> 9);
+}
+static_assert(512 / 3 + 1 == 171, "k5_slot<3>: floor(L * 171 / 512) = floor(L / 3) for L < 512");
 typedef __attribute__((address_space(3))) uint32_t *lds_u32p;
 __device__ __forceinline__ void k5_publish(lds_u32p slot, uint32_t v) {
     asm volatile("ds_write_b32 %0, %1" ::"v"((uint32_t)(uintptr_t)slot), "v"(v) : "memory");
@@ -1533,6 +1540,7 @@ __device__ __forceinline__ void k5_publish(lds_u32p slot, uint32_t v) {
 // (reads the compiler knows about: it places the waits; volatile keeps them in program order among themselves)
 __device__ __forceinline__ uint32_t k5_peek(lds_u32p slot) { return *(volatile __attribute__((address_space(3))) uint32_t *)slot; }
 __device__ __forceinline__ uint64_t k5_peek64(uint32_t addr) { return *(volatile __attribute__((address_space(3))) uint64_t *)addr; }
+template <int kK5Ring>
 __global__ __launch_bounds__(kK5Threads) void zs_emit_syms_lane_kernel(const StreamDesc *sd, const StreamState *st, const uint2 *work, int nwork, const uint2 *mm,
                                                                const uint16_t *entry, const uint32_t *symbase, uint32_t *syms,
                                                                int32_t *blk_end, int32_t *blk_top, const uint32_t *crc_tab_g,
@@ -1545,7 +1553,7 @@ __global__ __launch_bounds__(kK5Threads) void zs_emit_syms_lane_kernel(const Str
     // their records from LDS and fall back to a load of their own where a jump (a long match) outran the ring.
     // Lines are counted from the line of the chunk's first loop-top.  Slot of line L: L mod kK5Ring; line L + kK5Ring
     // goes into it only when the lane has said it is past L, and the lane reads nothing below the line it has announced.
-    __shared__ uint4 sh_ring_[kK5RingBytes / 16];
+    __shared__ uint4 sh_ring_[kK5Ring * 64 * 128 / 16];
     __shared__ uint32_t sh_line_[64], sh_last_[64], sh_base_[64], sh_filled_[64];
     const int lane = (int)(threadIdx.x & 63);
     const lds_u32p sh_line = (lds_u32p)sh_line_ + lane, sh_last = (lds_u32p)sh_last_ + lane, sh_base = (lds_u32p)sh_base_ + lane,
@@ -1582,9 +1590,10 @@ __global__ __launch_bounds__(kK5Threads) void zs_emit_syms_lane_kernel(const Str
                     const int32_t cl = (int32_t)c[g], lo = nf[g] > cl ? nf[g] : cl;
                     int32_t hi = cl + kK5Ring - 1;
                     hi = hi > (int32_t)la[g] ? (int32_t)la[g] : hi;
+                    const int lo_slot = (int)k5_slot<kK5Ring>((uint32_t)lo);
 #pragma unroll
                     for (int r = 0; r < kK5Ring; r++) {
-                        const int32_t L = lo + ((r - lo) & (kK5Ring - 1));
+                        const int32_t L = lo + (r >= lo_slot ? r - lo_slot : r + kK5Ring - lo_slot);  // the line of [lo, lo + R) in slot r
                         if (L <= hi) {
                             const uint2 *src = mm + (((size_t)ba[g] + (size_t)L) << 4) + 2 * piece;
                             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(uintptr_t)src,
@@ -1681,8 +1690,8 @@ __global__ __launch_bounds__(kK5Threads) void zs_emit_syms_lane_kernel(const Str
                 const uint32_t ua = (uint32_t)(qa - q0), ub = (uint32_t)(qb - q0);
                 k5_publish(sh_line, (uint32_t)(q - q0) >> 4);
                 filled = (int32_t)k5_peek(sh_filled);  // read ahead of the records: what it vouches for is in them
-                const uint64_t ra = k5_peek64(ring_lane + ((ua & (16u * (kK5Ring - 1))) << 9) + ((ua & 15u) << 3));
-                const uint64_t rb = k5_peek64(ring_lane + ((ub & (16u * (kK5Ring - 1))) << 9) + ((ub & 15u) << 3));
+                const uint64_t ra = k5_peek64(ring_lane + (k5_slot<kK5Ring>(ua >> 4) << 13) + ((ua & 15u) << 3));
+                const uint64_t rb = k5_peek64(ring_lane + (k5_slot<kK5Ring>(ub >> 4) << 13) + ((ub & 15u) << 3));
                 na = make_uint2((uint32_t)ra, (uint32_t)(ra >> 32));
                 nb = make_uint2((uint32_t)rb, (uint32_t)(rb >> 32));
             } else {
@@ -1781,10 +1790,17 @@ __global__ __launch_bounds__(256) void zs_body_blocks_kernel(const StreamDesc *s
 // ------------------------------------------------------------------ K6
 // One wave per stream; all lanes run the engine uniformly.  Also turns the
 // block cuts recorded by K5 into BlockRec entries.
-__global__ __launch_bounds__(1024) void zs_tail_kernel(const StreamDesc *sd, StreamState *st, const uint16_t *link, uint32_t *syms,
+// (112 registers -- the attribute counts in pairs on this target: four waves per SIMD then leave 64 of its 512, room for a
+// wave of the symbol kernel; with the 115 the compiler took by itself, 120 as allocated, a CU running a tail workgroup
+// could run nothing else, and the two kernels of a batch, launched side by side, took the CUs in turns)
+__attribute__((amdgpu_num_vgpr(56))) __global__ __launch_bounds__(1024) void zs_tail_kernel(const StreamDesc *sd, StreamState *st, const uint16_t *link, uint32_t *syms,
                                                      const int32_t *blk_end, const int32_t *blk_top, BlockRec *blocks,
                                                      uint8_t *scratch, const uint32_t *crc_tab_g, LevelCfg lv, int strategy,
                                                      int hash_variant, int level) {
+#ifdef ZS_FV_PROF
+    const long long tk_start = wall_clock64();
+    long long pf_restore[4] = {0, 0, 0, 0};
+#endif
     const StreamDesc s = sd[blockIdx.x];
     if (s.fast_runs > 0) return;  // handled by zs_fast_run_kernel / zs_fast_stitch_kernel
     StreamState &ss = st[blockIdx.x];
@@ -1841,6 +1857,7 @@ __global__ __launch_bounds__(1024) void zs_tail_kernel(const StreamDesc *sd, Str
     const int64_t p = ss.tail_p;
     e.final_run = s.final_run;
     LitPersist *ps = s.persist;
+    bool use_rec = false, no_head = false;
     if (s.cont) {
         // a later run of an incremental stream: the engine as the run before left it.  The input buffer starts at stream
         // position abs_off: the last 64 KiB the engine has already read (a stored block is copied from there, like the
@@ -1864,7 +1881,14 @@ __global__ __launch_bounds__(1024) void zs_tail_kernel(const StreamDesc *sd, Str
 #endif
         le_restore(e, p, have_seg ? s.seg_base[ss.k_done] : 0, have_seg ? s.seg_after[ss.k_done] : 0, ss.tail_kind, ss.tail_pend, lk,
                    ss.preins, tid, nth);
-        for (int i = tid; i < kHashSize; i += nth) head32[i] = 0;
+        // a slow level, one Write, everything read, no pre-insert pending: the tail's searches are done ahead (below) and the
+        // engine runs without the hash heads (LitEngine::no_head) -- the table is not built
+        use_rec = lv.func == 2 && strategy != kRle && strategy != kHuffmanOnly && s.final_run && !e.wr_end && s.fv_end < 0 &&
+                  e.avail_end == e.n && e.avail_end > 0 && ss.preins < p && le_tail_record_end(e) > p &&
+                  le_tail_record_end(e) - p <= kTailRecMax;
+        no_head = use_rec && le_no_head_ok(e);
+        if (!no_head)
+            for (int i = tid; i < kHashSize; i += nth) head32[i] = 0;
         __syncthreads();
 #ifdef ZS_FV_PROF
         tk1 = wall_clock64();
@@ -1884,31 +1908,49 @@ __global__ __launch_bounds__(1024) void zs_tail_kernel(const StreamDesc *sd, Str
                 } else {
                     le_restore_prev(e, q, lk);
                 }
-                atomicMax(&head32[le_bucket(e, q)], (uint32_t)(q - e.base) + 1u);
+                if (!no_head) atomicMax(&head32[le_bucket(e, q)], (uint32_t)(q - e.base) + 1u);
             }
             __syncthreads();
 #ifdef ZS_FV_PROF
             tk2 = wall_clock64();
 #endif
-            for (int i = tid; i < kHashSize; i += nth) e.head[i] = (uint16_t)(head32[i] ? head32[i] - 1 : 0);
+            if (!no_head)
+                for (int i = tid; i < kHashSize; i += nth) e.head[i] = (uint16_t)(head32[i] ? head32[i] - 1 : 0);
         }
         __syncthreads();
 #ifdef ZS_FV_PROF
         tk3 = wall_clock64();
-        if (tid == 0 && blockIdx.x == 0) printf("TAILPROF p=%lld n=%lld ticks: window+clear=%lld prev+head=%lld convert=%lld\n", (long long)p, (long long)s.n, tk1 - tk0, tk2 - tk1, tk3 - tk2);
+        pf_restore[0] = tk0 - tk_start, pf_restore[1] = tk1 - tk0, pf_restore[2] = tk2 - tk1, pf_restore[3] = tk3 - tk2;
 #endif
     }
     // ---- the searches of the tail's loop-tops ahead of its parse, one position per thread (le_tail_record,
     //      zs_lit_engine.h): a slow level, one Write, everything read, no pre-insert pending.  The engine then looks its
     //      matches up; only the last max_lazy positions are searched by the engine itself.
     __shared__ uint32_t pre_tab[2 * kTailRecMax];
+    __shared__ uint32_t sh_tail_head[3];
     {
-        const bool pre_ok = lv.func == 2 && strategy != kRle && strategy != kHuffmanOnly && !s.cont && s.final_run && !e.wr_end &&
-                            s.fv_end < 0 && e.avail_end == e.n && e.avail_end > 0 && ss.preins < p;
         const int64_t hi = le_tail_record_end(e);
-        if (pre_ok && hi > p && hi - p <= kTailRecMax) {  // uniform over the workgroup
-            for (int64_t q = p + tid; q < hi; q += nth) le_restore_prev(e, q, lk);  // what the engine's inserts will write
+        if (use_rec) {  // uniform over the workgroup
+            // what the engine's inserts would write (and return: LitEngine::no_head), up to the last position K1 has a link for
+            for (int64_t q = p + tid; q < (no_head ? e.n - 5 : hi); q += nth) le_restore_prev(e, q, lk);
+            // ... and for the three positions behind: the nearest position below each with its bucket (le_tail_head_bucket)
+            if (tid < 3) sh_tail_head[tid] = 0;
             __syncthreads();
+            if (no_head) {
+                const uint32_t hb0 = le_tail_head_bucket(e, 0), hb1 = le_tail_head_bucket(e, 1), hb2 = le_tail_head_bucket(e, 2);
+                int64_t lo = p - (kWSize - 1);
+                if (lo < e.base) lo = e.base;
+                if (lo < 1) lo = 1;  // position 0 is never a candidate
+                for (int64_t q = lo + tid; q < e.n - 3; q += nth) {
+                    const uint32_t h = le_bucket(e, q);
+                    if (h == hb0 && q < e.n - 5) atomicMax(&sh_tail_head[0], (uint32_t)(q - e.base));
+                    if (h == hb1 && q < e.n - 4) atomicMax(&sh_tail_head[1], (uint32_t)(q - e.base));
+                    if (h == hb2 && q < e.n - 3) atomicMax(&sh_tail_head[2], (uint32_t)(q - e.base));
+                }
+            }
+            __syncthreads();
+            e.no_head = no_head ? 1 : 0;
+            e.tail_head[0] = (int)sh_tail_head[0], e.tail_head[1] = (int)sh_tail_head[1], e.tail_head[2] = (int)sh_tail_head[2];
             for (int64_t q = p + tid; q < hi; q += nth) {
                 pre_tab[2 * (q - p)] = le_tail_record(e, (int)(q - e.base), (int)(e.n - q), lv.chain);
                 pre_tab[2 * (q - p) + 1] = le_tail_record(e, (int)(q - e.base), (int)(e.n - q), lv.chain >> 2);
@@ -1917,6 +1959,9 @@ __global__ __launch_bounds__(1024) void zs_tail_kernel(const StreamDesc *sd, Str
             __syncthreads();
         }
     }
+#ifdef ZS_FV_PROF
+    const long long tk_pre = wall_clock64() - tk_start;
+#endif
     if (tid >= 64) return;  // the engine is one wave, every lane running the same scalar code
 #ifdef ZS_FV_PROF
     long long te0 = wall_clock64();
@@ -1926,7 +1971,7 @@ __global__ __launch_bounds__(1024) void zs_tail_kernel(const StreamDesc *sd, Str
     le_run(e, level, tid, 64);
 #ifdef ZS_FV_PROF
     if (tid == 0 && blockIdx.x == 0)
-        printf("TAILPROF engine ticks=%lld syms=%lld: refill=%lld insert=%lld match=%lld tally=%lld flush=%lld\n", wall_clock64() - te0,
+        printf("TAILPROF setup=%lld window+clear=%lld prev+head=%lld convert=%lld; before the engine (with the searches ahead) %lld; kernel so far %lld; engine ticks=%lld syms=%lld: refill=%lld insert=%lld match=%lld tally=%lld flush=%lld\n", pf_restore[0], pf_restore[1], pf_restore[2], pf_restore[3], tk_pre, wall_clock64() - tk_start, wall_clock64() - te0,
                (long long)(e.nsyms - body_syms), e.pf[0], e.pf[1], e.pf[2], e.pf[3], e.pf[4]);
 #endif
     if (tid == 0) {
@@ -2556,6 +2601,57 @@ __device__ int build_block_trees_wave(TreeWork &w, uint32_t *hk, uint32_t *pd, u
     return type;
 }
 
+// ------------------------------------------------------------------ K6b
+// The block list with the blocks that exist in front.  The list is laid out before the parse, with room for every stream's
+// worst case: a 32 KiB stream has four entries and uses one.  Workgroups are handed to the XCDs, and inside an XCD to its
+// shader engines, in order and round robin, so live entries at a stride of four all land on a quarter of the CUs: the tree
+// and bit-emission kernels of 4096 x 32 KiB streams ran 3-4 x longer than those of the same bytes in long streams (and no
+// faster with fewer dead entries per live one, as long as the stride stayed a power of two).  For batches the list is
+// rewritten once the block counts are known: a prefix sum over the streams, then (stream, block) pairs for the live
+// entries and a mark on the rest.
+constexpr uint32_t kNoWork = 0xFFFFFFFFu;
+__global__ __launch_bounds__(1024) void zs_live_scan_kernel(const StreamState *st, int n, int32_t *live_pre) {
+    __shared__ int32_t wsum[16];
+    __shared__ int32_t carry;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += 1024) {
+        const int i = base + tid;
+        const int32_t v = i < n && !st[i].deferred ? st[i].nblocks : 0;
+        int32_t inc = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int32_t o = __shfl_up(inc, off);
+            if (lane >= off) inc += o;
+        }
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        int32_t before = carry;
+        for (int k = 0; k < wave; k++) before += wsum[k];
+        if (i < n) live_pre[i] = before + inc - v;
+        __syncthreads();
+        if (tid == 1023) carry = before + inc;
+        __syncthreads();
+    }
+    if (tid == 0) live_pre[n] = carry;
+}
+__global__ __launch_bounds__(256) void zs_live_fill_kernel(const int32_t *live_pre, int n, uint32_t n_items, uint2 *work) {
+    const uint32_t g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= n_items) return;
+    if ((int32_t)g >= live_pre[n]) {
+        work[g] = make_uint2(kNoWork, 0);
+        return;
+    }
+    int lo = 0, hi = n - 1;  // the last stream whose first entry is <= g (streams without blocks share their successor's start)
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (live_pre[mid] <= (int32_t)g) lo = mid;
+        else hi = mid - 1;
+    }
+    work[g] = make_uint2((uint32_t)lo, g - (uint32_t)live_pre[lo]);
+}
+
 // ------------------------------------------------------------------ K7
 // One workgroup per block: histogram the block's symbols (Tr_tally_*), then wave 0 replays Build_tree x3 exactly
 // (build_tree_wave) and picks the block type.
@@ -2567,7 +2663,7 @@ __global__ __launch_bounds__(256) void zs_trees_kernel(const StreamDesc *sd, con
     __shared__ uint32_t hk[kHeapSize + 8];  // Build_tree's priority queue (the sift reads a few entries past the end)
     __shared__ uint32_t pd[kHeapSize + 1], nc[16];  // (ancestor, distance) words of the depth pass; per-length counters
     uint2 w = work[blockIdx.x];
-    if (st[w.x].deferred) return;
+    if (w.x == kNoWork || st[w.x].deferred) return;
     const StreamDesc s = sd[w.x];
     const int b = (int)w.y;
     // phase 0: the blocks that end inside the bulk parse; phase 1: the rest; 2: all
@@ -2871,7 +2967,7 @@ __global__ __launch_bounds__(256) void zs_emit_bits_kernel(const StreamDesc *sd,
     __shared__ uint32_t wsum[4];
     __shared__ uint32_t sh_bits;
     uint2 w = work[blockIdx.x];
-    if (st[w.x].deferred) return;
+    if (w.x == kNoWork || st[w.x].deferred) return;
     const StreamDesc s = sd[w.x];
     const int b = (int)w.y;
     if (b >= st[w.x].nblocks || st[w.x].status != 0) return;

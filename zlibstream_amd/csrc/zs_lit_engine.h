@@ -92,6 +92,12 @@ struct LitEngine {
     // record for the full chain budget and the one for a quarter of it; nullptr: every search walks its chain
     const uint32_t *pre_rec;
     int64_t pre_lo, pre_hi;
+    // with them, and if the window does not slide any more before the stream ends (le_no_head_ok): the hash heads are not
+    // kept at all.  What head[h] would return at the insert of position q is prev[q] as the restore wrote it from K1's links
+    // for q <= n - 6, and tail_head[q - (n - 5)] for the up to three positions behind them, whose hashes read past the data
+    // (le_tail_head_bucket) -- bytes that a slide would change under them, hence the condition
+    int no_head;
+    int tail_head[3];
     // outputs
     uint32_t *syms;     // symbol i: dist << 16 | lc  (dist 0 = literal)
     int64_t nsyms;      // symbols emitted so far in this stream (body + tail)
@@ -107,6 +113,7 @@ ZS_HD void le_defaults(LitEngine &e) {
     e.ev_log = nullptr, e.n_ev = 0;
     e.final_run = 1, e.suspended = 0;
     e.pre_rec = nullptr, e.pre_lo = e.pre_hi = 0;
+    e.no_head = 0, e.tail_head[0] = e.tail_head[1] = e.tail_head[2] = 0;
     e.block_syms = kBlockSyms, e.block_sym_start = 0, e.block_start_abs = 0, e.defer_start = 0;
     e.nsyms = 0, e.nblocks = 0;
 }
@@ -208,12 +215,20 @@ ZS_HD int le_insert(LitEngine &e, int str) {
             e.ins_bits[wi] |= bit;
         }
     }
+    if (e.no_head) {
+        // The table is in HBM scratch: every insert was a round trip (with the acknowledgements of the stores before it),
+        // and building it for the tail of a stream took as long as a third of the tail's parse.
+        const int64_t qa = e.base + str;
+        if (qa <= e.n - 6) return ZS_LDS_PTR(const uint16_t, e.prev)[str & kWMask];
+        const int cur = e.tail_head[qa - (e.n - 5)];
+        ZS_LDS_PTR(uint16_t, e.prev)[str & kWMask] = (uint16_t)cur;
+        return cur;
+    }
     uint32_t h = le_hash(e, le_load32(e.window + str + 2));
     if (e.pre_rec) {
-        // A loop-top whose search was done ahead (le_tail_record) from prev[] as the restore left it: what head[h] holds
-        // is prev[str], which is written already -- only head[h] has to follow, for the few inserts behind the records.
-        // The table is in HBM scratch: a store is not waited for, the load was a round trip per position (with the
-        // acknowledgements of the stores before it).
+        // (with the table kept -- the window will slide before the stream ends:) a loop-top whose search was done ahead from
+        // prev[] as the restore left it: what head[h] holds is prev[str], which is written already; only head[h] has to
+        // follow, for the few inserts behind the records -- a store is not waited for
         const int64_t qa = e.base + str;
         if (qa >= e.pre_lo && qa < e.pre_hi) {
             e.head[h] = (uint16_t)str;
@@ -245,13 +260,15 @@ ZS_HD void le_slide(LitEngine &e, int lane, int nlanes) {
     };
     V4 *w = (V4 *)e.window;
     for (int i = lane; i < kWSize / 16; i += nlanes) w[i] = w[i + kWSize / 16];
-    slide16(e.head, kHashSize);
+    if (!e.no_head) slide16(e.head, kHashSize);
     slide16(e.prev, kWSize);
 #else
     for (int i = lane; i < kWSize; i += nlanes) e.window[i] = e.window[i + kWSize];
-    for (int i = lane; i < kHashSize; i += nlanes) e.head[i] = (uint16_t)(e.head[i] >= kWSize ? e.head[i] - kWSize : 0);
+    if (!e.no_head)
+        for (int i = lane; i < kHashSize; i += nlanes) e.head[i] = (uint16_t)(e.head[i] >= kWSize ? e.head[i] - kWSize : 0);
     for (int i = lane; i < kWSize; i += nlanes) e.prev[i] = (uint16_t)(e.prev[i] >= kWSize ? e.prev[i] - kWSize : 0);
 #endif
+    for (int k = 0; k < 3; k++) e.tail_head[k] = e.tail_head[k] >= kWSize ? e.tail_head[k] - kWSize : 0;  // the heads kept apart (no_head)
 }
 
 // Deflate.cs:967-1019.  The whole remaining input is available (single Write
@@ -391,12 +408,23 @@ ZS_HD_NOINLINE inline uint32_t le_tail_record(const LitEngine &e, int str, int l
     if (best_len > lookahead) best_len = lookahead;
     return best_len >= kMinMatch ? pack_match(best_len, str - ms) : kNoMatch;
 }
+constexpr int kTailRecMax = 288;  // positions of a tail whose searches are done ahead (zs_tail_kernel): <= 261 - max_lazy + a few
 // The positions le_tail_record may be asked for when the engine takes over at loop-top p with all input read: links
 // exist up to n - 6, and the lookahead must not fall below max_lazy.
 ZS_HD int64_t le_tail_record_end(const LitEngine &e) {
     const int64_t a = e.n - 5, b = e.n - e.lv.lazy + 1;
     return a < b ? a : b;
 }
+// The positions n - 5 .. n - 3 are inserted like every other (Deflate.Slow.cs:58,121-129: lookahead >= MIN_MATCH) but hash
+// bytes behind the data, so K1 has no links for them.  What head[] holds for their buckets when they are inserted is the
+// nearest position below them with the same bucket -- every position up to n - 3 is in the table by then, in order.
+// Does q (an absolute position below n - 5 + k, in the window) qualify for target k?  The callers keep the largest.
+ZS_HD uint32_t le_tail_head_bucket(const LitEngine &e, int k) {
+    const int64_t t = e.n - 5 + k;
+    return t >= 1 && t >= e.base ? le_hash(e, le_load32(e.window + (t - e.base) + 2)) : 0xFFFFFFFFu;
+}
+// No slide from here on: every loop-top of the rest stays below the point where Fill_window slides (Deflate.cs:979).
+ZS_HD bool le_no_head_ok(const LitEngine &e) { return e.n - e.base <= kSlideAt; }
 // Longest_match's result at the current loop-top from its record.
 ZS_HD int le_match_from_record(LitEngine &e) {
     const uint32_t *r = e.pre_rec + 2 * (e.base + e.strstart - e.pre_lo);
