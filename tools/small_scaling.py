@@ -11,14 +11,14 @@ for kib, cnt in ((32, 4096),) if os.environ.get("ZS_EXP_MAXB") else ((32, 4096),
     d_ins = [torch.frombuffer(bytearray(b), dtype=torch.uint8).cuda() for b in bufs]
     caps = [deflate_bound(len(b)) for b in bufs]
     d_outs = [torch.empty(c, dtype=torch.uint8, device="cuda") for c in caps]
-    args = ([t.data_ptr() for t in d_ins], [len(b) for b in bufs], [t.data_ptr() for t in d_outs], caps)
-    eng.deflate_batch_device(*args, level=6)
+    batch = Engine.DeviceBatch([t.data_ptr() for t in d_ins], [len(b) for b in bufs], [t.data_ptr() for t in d_outs], caps)
+    eng.deflate_device_batch(batch, level=6)
     torch.cuda.synchronize(); t = time.perf_counter()
     for _ in range(3):
-        lens = eng.deflate_batch_device(*args, level=6)
+        lens = eng.deflate_device_batch(batch, level=6)
     torch.cuda.synchronize(); dt = (time.perf_counter() - t) / 3
     eng.set_profiling(True)
-    eng.deflate_batch_device(*args, level=6)
+    eng.deflate_device_batch(batch, level=6)
     stages = {k: round(v, 3) for k, v in eng.stage_ms().items() if k and v >= 0.05}
     eng.set_profiling(False)
     print(json.dumps({"streams": cnt, "KiB": kib, "ms": round(dt * 1e3, 2), "stage_ms": stages}), flush=True)
