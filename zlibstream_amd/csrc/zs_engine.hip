@@ -606,10 +606,11 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
     const bool tail_late = ro && !ro->final_run;  // the engine is left for a later run: it needs K5's symbols and block ends
     // Beside the symbol kernel the tails of a few streams are free; those of hundreds are not: 256 tail workgroups of 1024
     // threads and 133 KiB of LDS each, one per CU, cost the symbol kernel of 256 x 1 MiB 3 ms (6.8 against 3.9), more than
-    // they take alone (0.5).  From 64 streams of 256 KiB or more on the tails run behind the symbols instead (thousands of
+    // they take alone (0.5).  From 64 streams of 96 KiB or more on the tails run behind the symbols instead (thousands of
     // small streams are the other way round: 16 rounds of tails, a short symbol kernel -- beside each other 18.9 ms for
     // 4096 x 32 KiB, one after the other 20.1).
-    const bool tail_serial = !tail_late && n >= 64 && (pl.n_pos / n >= (256 << 10) || getenv("ZS_TAIL_SERIAL")) && !getenv("ZS_TAIL_FORK");
+    // (1024 x 128 KiB: 2.8 ms one after the other, 3.0 side by side; 4096 x 32 KiB: 5.7 against 4.9)
+    const bool tail_serial = !tail_late && n >= 64 && (pl.n_pos / n >= (96 << 10) || getenv("ZS_TAIL_SERIAL")) && !getenv("ZS_TAIL_FORK");
     if (!tail_late && !tail_serial) {
         ZS_HIP(c, hipEventRecord(c->ev_fork, stream));
         ZS_HIP(c, hipStreamWaitEvent(c->aux, c->ev_fork, 0));
