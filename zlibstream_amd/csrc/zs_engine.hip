@@ -627,13 +627,7 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
                            hash_variant);
     mark(8);
     if (!pl.w_chunks.empty())
-        if (n >= 64)  // a batch: three lines per lane, so that a workgroup fits on a CU beside a tail-kernel workgroup (zs_kernels.hip)
-            hipLaunchKernelGGL(zs_emit_syms_lane_kernel<3>, dim3((unsigned)((pl.w_chunks.size() + 63) / 64)), dim3(kK5Threads), 0, stream, d_sd, d_st,
-                           d_work + o_chunks, (int)pl.w_chunks.size(), dev<uint2>(c->mm), dev<uint16_t>(c->entry),
-                           dev<uint32_t>(c->symbase), dev<uint32_t>(c->syms), dev<int32_t>(c->blk_end), dev<int32_t>(c->blk_top),
-                           c->crc_tab, lv, strategy, hash_variant, k5_ahead);
-        else
-            hipLaunchKernelGGL(zs_emit_syms_lane_kernel<4>, dim3((unsigned)((pl.w_chunks.size() + 63) / 64)), dim3(kK5Threads), 0, stream, d_sd, d_st,
+        hipLaunchKernelGGL(zs_emit_syms_lane_kernel<4>, dim3((unsigned)((pl.w_chunks.size() + 63) / 64)), dim3(kK5Threads), 0, stream, d_sd, d_st,
                            d_work + o_chunks, (int)pl.w_chunks.size(), dev<uint2>(c->mm), dev<uint16_t>(c->entry),
                            dev<uint32_t>(c->symbase), dev<uint32_t>(c->syms), dev<int32_t>(c->blk_end), dev<int32_t>(c->blk_top),
                            c->crc_tab, lv, strategy, hash_variant, k5_ahead);

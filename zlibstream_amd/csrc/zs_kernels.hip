@@ -1524,9 +1524,8 @@ struct GlobalSymSink {
 // branches and in 32-bit positions: lazy_step (zs_core.h, which K3 / K4 and the CPU model use) is the specification,
 // tests/test_gpu_parity.py the check.
 constexpr uint32_t kK5Idle = 0xFFFFFFFEu, kK5Done = 0xFFFFFFFFu;
-// Lines (16 records, 128 bytes) per walking lane in LDS; slot r of lane w: r * 8192 + w * 128.  Four for a few streams; three
-// for a batch, where a workgroup (25 KiB) then fits on a CU beside one of the tail kernel's (133 KiB of the 160): with four
-// the two kernels, launched side by side on two streams, took the CUs in turns (4096 x 32 KiB: 2.1 + 4.7 ms).
+// Lines (16 records, 128 bytes) per walking lane in LDS; slot r of lane w: r * 8192 + w * 128.  The kernel runs with four
+// (eight: the feeding sweep twice as long, slower; three: the same as four).
 template <int R>
 __device__ __forceinline__ uint32_t k5_slot(uint32_t line) {  // line mod R (lines of a chunk: < 512)
     if constexpr (R == 4) return line & 3u;
@@ -1790,10 +1789,12 @@ __global__ __launch_bounds__(256) void zs_body_blocks_kernel(const StreamDesc *s
 // ------------------------------------------------------------------ K6
 // One wave per stream; all lanes run the engine uniformly.  Also turns the
 // block cuts recorded by K5 into BlockRec entries.
-// (112 registers -- the attribute counts in pairs on this target: four waves per SIMD then leave 64 of its 512, room for a
-// wave of the symbol kernel; with the 115 the compiler took by itself, 120 as allocated, a CU running a tail workgroup
-// could run nothing else, and the two kernels of a batch, launched side by side, took the CUs in turns)
-__attribute__((amdgpu_num_vgpr(56))) __global__ __launch_bounds__(1024) void zs_tail_kernel(const StreamDesc *sd, StreamState *st, const uint16_t *link, uint32_t *syms,
+// (Tried for batches, where this kernel and the symbol kernel are launched side by side and mostly take the CUs in turns:
+// 112 registers instead of 115 -- `amdgpu_num_vgpr(56)`, the attribute counts in pairs on this target -- so that four waves
+// per SIMD leave room for a wave of the symbol kernel, and a three-line ring there so that its 25 KiB fit beside this
+// kernel's 133.  Nothing moved (4096 x 32 KiB: 13.6 against 13.4 ms) and the four spilled registers cost a lone stream's
+// tail 0.04 ms; not kept.)
+__global__ __launch_bounds__(1024) void zs_tail_kernel(const StreamDesc *sd, StreamState *st, const uint16_t *link, uint32_t *syms,
                                                      const int32_t *blk_end, const int32_t *blk_top, BlockRec *blocks,
                                                      uint8_t *scratch, const uint32_t *crc_tab_g, LevelCfg lv, int strategy,
                                                      int hash_variant, int level) {
