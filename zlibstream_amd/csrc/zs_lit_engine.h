@@ -528,9 +528,23 @@ ZS_HD_NOINLINE inline void le_run_slow(LitEngine &e, int lane, int nlanes) {
             bool bflush = le_tally(e, e.strstart - 1 - e.prev_match, e.prev_length - kMinMatch, lane);
             e.lookahead -= e.prev_length - 1;
             e.prev_length -= 2;
-            do {
-                if (++e.strstart <= max_insert) hash_head = le_insert(e, e.strstart);
-            } while (--e.prev_length != 0);
+            if (e.no_head) {
+                // without the hash heads the inserts inside a match have nothing to do (their prev[] entries are written, what
+                // they return is not looked at) except for the three positions behind K1's links, which leave their prev[]
+                const int last = e.strstart + e.prev_length;  // the last position the loop below would visit
+                int s0 = (int)(e.n - 5 - e.base);
+                if (s0 <= e.strstart) s0 = e.strstart + 1;
+                for (int str = s0; str <= last && str <= max_insert; str++) (void)le_insert(e, str);
+                // hash_head outlives the iteration (it is only assigned while lookahead >= MIN_MATCH): what the last insert returned
+                const int li = last <= max_insert ? last : max_insert;
+                if (li > e.strstart) hash_head = le_insert(e, li);
+                e.strstart = last;
+                e.prev_length = 0;
+            } else {
+                do {
+                    if (++e.strstart <= max_insert) hash_head = le_insert(e, e.strstart);
+                } while (--e.prev_length != 0);
+            }
             e.match_available = 0;
             e.match_length = kMinMatch - 1;
             e.strstart++;
