@@ -1518,11 +1518,11 @@ struct GlobalSymSink {
         }
     }
 };
-// One lane per chunk, ~1300 dependent steps, two waves per CU: what a step costs is the latency of its own instructions (a
-// lone wave issues one every 4-8 cycles), not memory -- asking for the lane's next lines from a second wave, or taking the
-// store's acknowledgement out of the step's wait, moved nothing (round 2).  So the step is written out here without
-// branches and in 32-bit positions: lazy_step (zs_core.h, which K3 / K4 and the CPU model use) is the specification,
-// tests/test_gpu_parity.py the check.
+// One lane per chunk, ~1300 dependent steps, two walking waves per CU.  What a step costs is first of all the latency of
+// its own instructions (a lone wave issues a dependent one every 4-10 cycles): the step is written out here without
+// branches and in 32-bit positions -- lazy_step (zs_core.h, which K3 / K4 and the CPU model use) is the specification,
+// tests/test_gpu_parity.py the check -- and only then did the memory side show: the records come through LDS, staged by
+// feeding waves, and no step waits for a store's acknowledgement (DESIGN.md section 6 has the order of the findings).
 constexpr uint32_t kK5Idle = 0xFFFFFFFEu, kK5Done = 0xFFFFFFFFu;
 // Lines (16 records, 128 bytes) per walking lane in LDS; slot r of lane w: r * 8192 + w * 128.  The kernel runs with four
 // (eight: the feeding sweep twice as long, slower; three: the same as four).
