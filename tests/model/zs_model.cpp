@@ -457,8 +457,12 @@ static void run_tail(Model &m, int64_t p, int kind, uint32_t pend, int k_done, i
     e.block_start_abs = body_blocks ? m.blocks[body_blocks - 1].start + m.blocks[body_blocks - 1].stored_len : 0;
     e.block_sym_start = (int64_t)body_blocks * kBlockSyms;
     e.block_syms = m.level == 0 ? (kLitBufsize / 2) - 1 : kBlockSyms;
-    le_restore(e, p, m.rev.empty() ? 0 : m.rev[(size_t)k_done].base, m.rev.empty() ? 0 : m.rev[(size_t)k_done].after, kind, pend,
-               m.link.data(), preins, 0, 1);
+    int64_t base_in = m.rev.empty() ? 0 : m.rev[(size_t)k_done].base;
+    const int64_t after_in = m.rev.empty() ? 0 : m.rev[(size_t)k_done].after;
+    const bool preslid = m.lv.func == 2 && m.strategy != kRle && m.strategy != kHuffmanOnly && m.ins.empty() && !m.incremental &&
+                         !getenv("ZS_NO_TAIL_RECORDS") && le_tail_preslide(e, p, base_in, after_in, preins);
+    if (preslid) base_in += kWSize;  // as zs_tail_kernel: restored in the slid state
+    le_restore(e, p, base_in, after_in, kind, pend, m.link.data(), preins, 0, 1, preslid);
     // the tail's searches ahead of its parse (le_tail_record) and the engine without hash heads (LitEngine::no_head), under
     // the conditions of zs_tail_kernel: a slow level, one Write, everything read, no pre-insert pending
     const bool use_rec = m.lv.func == 2 && m.strategy != kRle && m.strategy != kHuffmanOnly && !e.wr_end && !m.incremental &&

@@ -25,7 +25,7 @@ def model(tmp_path_factory):
         p = d / name
         p.write_bytes(b)
         files[name] = str(p)
-    for n in (0, 1, 5, 261, 262, 263, 600, 65274, 65275, 65536, 65537, 65541, 98043, 98304, 98305):
+    for n in (0, 1, 5, 261, 262, 263, 600, 65274, 65275, 65276, 65531, 65535, 65536, 65537, 65541, 65798, 98043, 98304, 98305):
         put("alice_%d" % n, (alice * 2)[:n])
         put("zeros_%d" % n, bytes(n))
         put("lowent_%d" % n, rng.choice(np.array([0, 0, 0, 0, 1, 2, 255], dtype=np.uint8), n).tobytes())

@@ -1880,8 +1880,15 @@ __global__ __launch_bounds__(1024) void zs_tail_kernel(const StreamDesc *sd, Str
 #ifdef ZS_FV_PROF
         long long tk0 = wall_clock64(), tk1 = 0, tk2 = 0, tk3 = 0;
 #endif
-        le_restore(e, p, have_seg ? s.seg_base[ss.k_done] : 0, have_seg ? s.seg_after[ss.k_done] : 0, ss.tail_kind, ss.tail_pend, lk,
-                   ss.preins, tid, nth);
+        int64_t base_in = have_seg ? s.seg_base[ss.k_done] : 0;
+        const int64_t after_in = have_seg ? s.seg_after[ss.k_done] : 0;
+        // A tail that starts at or behind the slide point (Deflate.cs:979: strstart >= 2 * WSIZE - MIN_LOOKAHEAD; every stream
+        // whose length is a multiple of 32 KiB) slides the window in its first pass through the loop and reads nothing: the
+        // engine is restored in the slid state right away (le_tail_preslide), where the route without hash heads is open
+        const bool preslid = lv.func == 2 && strategy != kRle && strategy != kHuffmanOnly && s.fv_end < 0 &&
+                             le_tail_preslide(e, p, base_in, after_in, ss.preins);
+        if (preslid) base_in += kWSize;
+        le_restore(e, p, base_in, after_in, ss.tail_kind, ss.tail_pend, lk, ss.preins, tid, nth, preslid);
         // a slow level, one Write, everything read, no pre-insert pending: the tail's searches are done ahead (below) and the
         // engine runs without the hash heads (LitEngine::no_head) -- the table is not built
         use_rec = lv.func == 2 && strategy != kRle && strategy != kHuffmanOnly && s.final_run && !e.wr_end && s.fv_end < 0 &&

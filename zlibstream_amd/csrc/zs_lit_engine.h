@@ -423,6 +423,13 @@ ZS_HD uint32_t le_tail_head_bucket(const LitEngine &e, int k) {
     const int64_t t = e.n - 5 + k;
     return t >= 1 && t >= e.base ? le_hash(e, le_load32(e.window + (t - e.base) + 2)) : 0xFFFFFFFFu;
 }
+// The engine taking over at loop-top p with the window at `base` and everything read would slide first thing (its first
+// pass finds lookahead < MIN_LOOKAHEAD and strstart at or behind the slide point, and Fill_window has nothing to read):
+// one Write, the stream's last run, no pre-insert pending.  The caller restores it at base + WSIZE instead -- the same
+// window image (the upper half keeps its bytes, le_restore's stale-half rule), prev[] and scalars as after the slide.
+ZS_HD bool le_tail_preslide(const LitEngine &e, int64_t p, int64_t base, int64_t avail_end, int64_t preins) {
+    return e.final_run && !e.wr_end && avail_end >= e.n && e.n - p < kMinLookahead && preins < p && p - base >= kSlideAt;
+}
 // No slide from here on: every loop-top of the rest stays below the point where Fill_window slides (Deflate.cs:979).
 ZS_HD bool le_no_head_ok(const LitEngine &e) { return e.n - e.base <= kSlideAt; }
 // Longest_match's result at the current loop-top from its record.
@@ -701,7 +708,7 @@ ZS_HD void le_run(LitEngine &e, int level, int lane, int nlanes) {
 //   preins  the position that the last refill pre-inserted (s_k + 1) or -1.
 // `lane`/`nlanes` split the copy loops across a wave on the device.
 ZS_HD_NOINLINE inline void le_restore(LitEngine &e, int64_t p, int64_t base, int64_t avail_end, int kind, uint32_t pend,
-                                      const uint16_t *link, int64_t preins, int lane, int nlanes) {
+                                      const uint16_t *link, int64_t preins, int lane, int nlanes, bool preslid = false) {
     e.base = base;
     e.avail_end = avail_end;
     if (e.avail_end > e.n) e.avail_end = e.n;
@@ -711,11 +718,15 @@ ZS_HD_NOINLINE inline void le_restore(LitEngine &e, int64_t p, int64_t base, int
     e.cur_wr = 0;
     if (e.wr_end)
         while (e.cur_wr + 1 < e.n_wr && e.wr_end[e.cur_wr] < e.avail_end) e.cur_wr++;
-    int64_t valid = e.avail_end - e.base;
+    // preslid (le_tail_preslide): the image was filled at base - WSIZE and has slid since -- the lower half is what the upper
+    // half was, the upper half is what it was (bytes behind the data included: zeros in a window that was never full)
+    const int64_t ib = preslid ? e.base - kWSize : e.base;
+    const int64_t valid = e.avail_end - ib;
     for (int w = lane; w < kWindowSize + 512; w += nlanes) {
+        const int wi = preslid && w < kWSize ? w + kWSize : w;
         uint8_t v = 0;
-        if (w < valid) v = e.data[e.base + w];
-        else if (e.base >= kWSize && w < kWindowSize) v = e.data[e.base + w - kWSize];  // stale upper half
+        if (wi < valid) v = e.data[ib + wi];
+        else if (ib >= kWSize && wi < kWindowSize) v = e.data[ib + wi - kWSize];  // stale upper half
         e.window[w] = v;
     }
     for (int i = lane; i < kHashSize; i += nlanes) e.head[i] = 0;
