@@ -88,6 +88,16 @@ ZS_API int zs_deflate_batch_device(zs_ctx *ctx, int n, const void *const *in, co
                                    const int64_t *out_cap, int64_t *out_len, int *status, int level, int strategy,
                                    int hash_variant, void *hip_stream);
 
+/* One stream written in several NoFlush Writes, resident in HBM:
+ *     using (var s = new ZlibOutputStream(dst, level)) foreach (var w in writes) s.Write(w);
+ * (ZlibOutputStream.cs:114-168: every Write is a call of Deflate(NoFlush), and every Write end a read event of
+ * Fill_window, Deflate.cs:967-1019, which changes the bytes).  write_ends: the n_writes cumulative Write ends (HOST
+ * array, increasing, the last one = in_len).  What zs_deflate does at Finish for the Writes it has buffered, without
+ * the per-call protocol: the entry an encoder that has its image on the device (zs_png_filter_device) writes rows with. */
+ZS_API int zs_deflate_writes_device(zs_ctx *ctx, const void *in, int64_t in_len, const int64_t *write_ends, int64_t n_writes,
+                                    void *out, int64_t out_cap, int64_t *out_len, int level, int strategy, int hash_variant,
+                                    void *hip_stream);
+
 /* Host-pointer form: copies in over PCIe, runs the device path, copies out. */
 ZS_API int zs_deflate_batch(zs_ctx *ctx, int n, const void *const *in, const int64_t *in_len, void *const *out,
                             const int64_t *out_cap, int64_t *out_len, int *status, int level, int strategy,

@@ -11,7 +11,7 @@ SYMBOLS = [
     "zs_deflate_batch", "zs_ctx_set_profiling", "zs_ctx_stage_count", "zs_ctx_stage_name", "zs_ctx_stage_ms",
     "zs_deflate_init", "zs_deflate", "zs_deflate_end", "zs_last_message", "zs_adler32_device",
     "zs_inflate_batch_device", "zs_inflate_batch", "zs_inflate_init", "zs_inflate", "zs_inflate_end", "zs_inflate_message",
-    "zs_device_count", "zs_partition", "zs_deflate_batch_multi", "zs_inflate_batch_multi", "zs_png_filter_device",
+    "zs_device_count", "zs_partition", "zs_deflate_batch_multi", "zs_inflate_batch_multi", "zs_png_filter_device", "zs_deflate_writes_device",
 ]
 
 _lib = None
@@ -49,6 +49,8 @@ def lib():
     L.zs_deflate_batch_device.argtypes = batch_args + [vp]
     L.zs_deflate_batch.restype = i32
     L.zs_deflate_batch.argtypes = batch_args
+    L.zs_deflate_writes_device.restype = i32
+    L.zs_deflate_writes_device.argtypes = [vp, vp, i64, P(i64), i64, vp, i64, P(i64), i32, i32, i32, vp]
     inf_args = [vp, i32, P(vp), P(i64), P(vp), P(i64), P(i64), P(i32)]
     L.zs_inflate_batch_device.restype = i32
     L.zs_inflate_batch_device.argtypes = inf_args + [vp]

@@ -154,6 +154,19 @@ class Engine:
             raise ZlibStreamException("deflating: " + self.last_error())
         return lens
 
+    def deflate_writes_device(self, in_ptr, in_len, write_ends, out_ptr, out_cap, level=6, strategy=0, hash_variant=0, stream=None):
+        """One device-resident stream written in several NoFlush Writes (zs_deflate_writes_device): `write_ends` are the
+        cumulative Write ends (a sequence of ints or a ctypes int64 array).  Returns the output length."""
+        if not isinstance(write_ends, ctypes.Array):
+            write_ends = (ctypes.c_int64 * len(write_ends))(*write_ends)
+        olen = ctypes.c_int64(0)
+        rc = self._lib.zs_deflate_writes_device(self._h, ctypes.c_void_p(in_ptr), int(in_len), write_ends, len(write_ends),
+                                                ctypes.c_void_p(out_ptr), int(out_cap), ctypes.byref(olen), int(level), int(strategy),
+                                                int(hash_variant), ctypes.c_void_p(stream or 0))
+        if rc != 0:
+            raise ZlibStreamException("deflating: " + self.last_error())
+        return olen.value
+
     def deflate_batch(self, buffers, level=6, strategy=0, hash_variant=0):
         """Host buffers (bytes-like) -> list of zlib streams (bytes)."""
         bufs = [bytes(b) for b in buffers]

@@ -45,10 +45,14 @@ struct StreamDesc {
     int32_t seg_off;   // index of parse segment 0 in segmap / seg_entry / seg_symbase / seg_stale
     int32_t nsegs;
     int32_t sup_off;   // index of the stream's first row in supmap (one row per kSupSegs parse segments, zs_supmap_kernel)
-    // parse segments (one per read event, zs_core.h build_read_events), already offset to this stream: first chunk of
-    // each, data end after its event's read, window base after it; and per chunk whether a read event fires at its entry
-    const int32_t *seg_c0, *seg_after, *seg_base;
-    const uint8_t *head;
+    // parse segments (one per cluster of read events, zs_core.h build_geometry), already offset to this stream: first chunk
+    // of each, data end once its events have fired, window base after them, slide threshold at its entry, and where its
+    // cluster's boundaries are in `cl` (nsegs + 1 offsets); per chunk: its first position (nchunks + 1 entries) and, for the
+    // first chunk of a segment whose cluster fires inside it, the segment's number + 1 (else 0)
+    const int32_t *seg_c0, *seg_after, *seg_base, *seg_S, *seg_cl;
+    const uint32_t *cl;
+    const int32_t *cstart;
+    const int32_t *head;
     int32_t n_wr;            // > 1: several Writes -> the whole stream runs on the literal engine
     const int64_t *wr_end;   // device array of n_wr cumulative Write ends (or nullptr)
     // FlushMode Partial / Sync / Full (nullptr: every Write is NoFlush): the mode of each Write, the number of blocks
@@ -125,9 +129,9 @@ struct StreamState {
     int32_t status;
     int64_t end_bits;  // bit position in the stream (zlib header included) behind the run's last block or marker
     // the resolve kernel's position when it is run part by part behind the match kernel (one long stream: zs_engine.hip):
-    // next segment, entry slot, symbols so far, last fired refill; and the equal-bucket cuts whose repair reaches into
+    // next segment, entry slot, symbols so far, last segment whose events fired and its entry slot; and the equal-bucket cuts whose repair reaches into
     // positions whose matches were not computed yet (cut position, last position repaired)
-    int32_t r_seg, r_slot, r_kfired, r_preins1;
+    int32_t r_seg, r_slot, r_kfired, r_kslot;
     uint32_t r_total;
     int32_t r_ncut;
     int32_t r_cut_e[8], r_cut_done[8];
@@ -136,6 +140,10 @@ struct StreamState {
     // at a cut whose repair is worth the whole chip (deferred = 2: zs_repair_kernel, zs_stalemaps_kernel, and on it goes;
     // r_scan: the walk resumes behind an applied cut)
     int32_t deferred, r_scan;
+    int32_t r_cutidx;  // equal-bucket events of the current segment's cluster that have been cut already
+    // the true path met a read whose pre-insert hashes bytes behind the data (zs_core.h kMapPoisonBit): the host runs the
+    // stream on the literal engine
+    int32_t poison;
 };
 constexpr int kDeferBudget = 8;   // cuts with positions to walk again that a stream may repair on its one CU before it is given up
 

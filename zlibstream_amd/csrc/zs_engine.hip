@@ -44,6 +44,7 @@ struct zs_ctx {
     bool profiling = false;
     int fast_fallbacks = 0;  // speculative DeflateFast batches that had to be redone sequentially
     int round_runs = 0;      // batches run again in rounds (a stream whose cuts were not one CU's job)
+    int lit_fallbacks = 0;   // batches run again with a stream on the literal engine (zs_core.h kMapPoisonBit)
     int last_op = 0;  // 0: deflate stages, 1: block-parallel inflate stages (for zs_ctx_stage_name)
     hipEvent_t ev[kStCount + 1] = {};
     double stage_ms[kStCount] = {};
@@ -123,8 +124,10 @@ struct Plan {
     int64_t n_pos = 0, n_syms = 0;
     int64_t n_chunks = 0, n_segs = 0, n_sups = 0, n_blocks = 0, n_pieces = 0, n_runs = 0;
     bool any_fv = false;
-    std::vector<int32_t> seg_c0, seg_after, seg_base;  // per parse segment (all streams, in seg_off order)
-    std::vector<uint8_t> head;                         // per chunk (chunk_off order): a read event fires at its entry
+    // parse-segment tables (zs_core.h build_geometry), all streams: per segment (seg_off order); seg_cl and cstart hold one
+    // entry more per stream (stream i's lists begin at seg_off + i / chunk_off + i); seg_cl's values index `cl`
+    std::vector<int32_t> seg_c0, seg_after, seg_base, seg_S, seg_cl, cstart, head;
+    std::vector<uint32_t> cl;
     std::vector<BlockRec> plan_blk;                    // level 0: the stored blocks of every stream, stream after stream
     std::vector<int32_t> plan_wr_blk;                  // level 0 under a flush mode: blocks flushed before each Write began
 };
@@ -164,7 +167,8 @@ struct RunOpts {
 // `writes` (optional, one stream only): the Writes of a multi-Write stream, or of one whose Writes carry a flush mode
 bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len, void *const *out, const int64_t *out_cap,
                   int64_t *out_len, int *status, int level, int strategy, int hash_variant, hipStream_t stream,
-                  const WriteSpec *writes = nullptr, bool force_seq = false, RunOpts *ro = nullptr, bool rounds = false) {
+                  const WriteSpec *writes = nullptr, bool force_seq = false, RunOpts *ro = nullptr, bool rounds = false,
+                  const std::vector<uint8_t> *force_lit = nullptr) {
     if (level == -1) level = 6;
     if (getenv("ZS_FORCE_ROUNDS") && !ro) rounds = true;  // for the tests: every batch in rounds
     LevelCfg lv = level_cfg(level);
@@ -190,15 +194,19 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
         // an incremental run always takes the block-by-block output accounting (its state is carried from run to run)
         const bool flushing = writes && (writes->flushing() || ro);
         const bool cont = ro && ro->cont, final_run = !ro || ro->final_run;
-        // the bulk pipeline needs a regular read schedule (zs_core.h build_read_events): one Write, or NoFlush Writes
-        // whose ends fall on the chunk grid; other streams of several Writes run on the literal engine
+        // the bulk pipeline takes the NoFlush schedules build_geometry accepts (zs_core.h: any Write sizes but streams written
+        // a few bytes at a time); a stream the resolve kernel flagged (force_lit: a read whose pre-insert hashes bytes behind the
+        // data) and other streams of several Writes run on the literal engine.  Levels 1-3 keep the single Write's events.
         std::vector<ReadEvent> rev;
+        Geometry geo;
         const int64_t one_write[1] = {len};
         const bool real_flush = writes && writes->flushing();
-        const bool regular = cont ? false
-                             : multi ? (!real_flush && build_read_events(len, writes->ends, rev))
-                                     : build_read_events(len, std::vector<int64_t>(one_write, one_write + 1), rev);
-        s.body_end = (lv.func == 2 && strategy != kRle && len >= kMinLookahead && regular) ? (int32_t)(len - kMinLookahead) : -1;
+        const bool lit_forced = force_lit && (*force_lit)[(size_t)i];
+        const std::vector<int64_t> no_ends_;
+        const bool slow_ok = lv.func == 2 && strategy != kRle && !cont && !lit_forced && !(multi && real_flush) &&
+                             build_geometry(len, multi ? writes->ends : no_ends_, geo);
+        const bool regular = cont ? false : multi ? false : build_read_events(len, std::vector<int64_t>(one_write, one_write + 1), rev);
+        s.body_end = slow_ok ? (int32_t)geo.body_end : -1;
         // levels 1-3, one Write: the speculative chunk runs for large streams (they verify on periodic data and are parallel
         // inside a stream), else -- and when they did not verify (force_seq) -- DeflateFast for the lanes of a wave
         const bool fast_one = lv.func == 1 && strategy != kRle && !multi && !flushing && final_run && !ro && regular && len >= kMinLookahead;
@@ -210,7 +218,7 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
         s.wr_end = nullptr;
         s.wr_flush = nullptr, s.wr_blk = nullptr, s.out_chunk = writes ? writes->chunk : 512, s.raw = writes && writes->raw;
         s.kl = num_refills(len);
-        s.nchunks = s.body_end >= 0 ? chunk_of(s.body_end) + 1 : 0;
+        s.nchunks = s.body_end >= 0 ? geo.nchunks() : 0;
         s.pos_off = pl.n_pos;
         pl.n_pos += (len + 64 + 63) & ~63LL;
         s.sym_off = pl.n_syms;
@@ -219,17 +227,30 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
         pl.n_chunks += s.nchunks;
         s.seg_off = (int32_t)pl.n_segs;
         s.nsegs = 0;
-        pl.head.resize((size_t)pl.n_chunks, 0);
-        if (s.body_end >= 0 || s.fv_end >= 0)
-            for (size_t k = 0; k < rev.size(); k++) {
-                const int64_t at = k ? rev[k].at - (kMinLookahead - 1) : 0;  // where the segment starts
-                if (at > (s.body_end >= 0 ? s.body_end : s.fv_end)) break;
-                const int c0 = chunk_of(at);
-                pl.seg_c0.push_back(c0), pl.seg_after.push_back((int32_t)rev[k].after), pl.seg_base.push_back((int32_t)rev[k].base);
-                if (k && s.body_end >= 0) pl.head[(size_t)s.chunk_off + (size_t)c0] = 1;
-                s.nsegs++;
-            }
-        s.seg_c0 = s.seg_after = s.seg_base = nullptr, s.head = nullptr;
+        if (s.body_end >= 0) {
+            s.nsegs = geo.nsegs();
+            const int32_t cl0 = (int32_t)pl.cl.size();
+            pl.seg_c0.insert(pl.seg_c0.end(), geo.seg_c0.begin(), geo.seg_c0.end());
+            pl.seg_after.insert(pl.seg_after.end(), geo.seg_after.begin(), geo.seg_after.end());
+            pl.seg_base.insert(pl.seg_base.end(), geo.seg_base.begin(), geo.seg_base.end());
+            pl.seg_S.insert(pl.seg_S.end(), geo.seg_S.begin(), geo.seg_S.end());
+            for (int32_t v : geo.seg_cl) pl.seg_cl.push_back(v + cl0);
+            pl.cl.insert(pl.cl.end(), geo.cl.begin(), geo.cl.end());
+            pl.cstart.insert(pl.cstart.end(), geo.cstart.begin(), geo.cstart.end());
+            pl.head.insert(pl.head.end(), geo.head.begin(), geo.head.end());
+        } else {
+            if (s.fv_end >= 0)  // levels 1-3: the events of the single Write (the tail engine takes base and data end from them)
+                for (size_t k = 0; k < rev.size(); k++) {
+                    const int64_t at = k ? rev[k].at - (kMinLookahead - 1) : 0;  // where the segment starts
+                    if (at > s.fv_end) break;
+                    pl.seg_c0.push_back(0), pl.seg_after.push_back((int32_t)rev[k].after), pl.seg_base.push_back((int32_t)rev[k].base);
+                    pl.seg_S.push_back(0), pl.seg_cl.push_back((int32_t)pl.cl.size());
+                    s.nsegs++;
+                }
+            pl.seg_cl.push_back((int32_t)pl.cl.size());
+            pl.cstart.push_back(0);
+        }
+        s.seg_c0 = s.seg_after = s.seg_base = s.seg_S = s.seg_cl = nullptr, s.cl = nullptr, s.cstart = nullptr, s.head = nullptr;
         pl.n_segs += s.nsegs;
         s.sup_off = (int32_t)pl.n_sups;
         pl.n_sups += (s.nsegs + kSupSegs - 1) / kSupSegs;
@@ -297,14 +318,22 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
         !ensure(c, c->trees, sizeof(TreeWork) * (size_t)pl.n_blocks) || !ensure(c, c->info, sizeof(BlockInfo) * (size_t)pl.n_blocks) ||
         !ensure(c, c->pieces, 4 * (size_t)pl.n_pieces + 64) || !ensure(c, c->scratch, (size_t)kScratchBytes * (size_t)n))
         return false;
-    // parse-segment tables: [seg_c0 | seg_after | seg_base : int32 x n_segs each][head : u8 x n_chunks]
-    const size_t geo_bytes = 12 * (size_t)pl.n_segs + (size_t)pl.n_chunks;
+    // parse-segment tables: [seg_c0 | seg_after | seg_base | seg_S : int32 x n_segs each][seg_cl : int32 x (n_segs + n)]
+    // [cstart : int32 x (n_chunks + n)][head : int32 x n_chunks][cl : u32 x n_cl]
+    const size_t o_segcl = 16 * (size_t)pl.n_segs, o_cstart = o_segcl + 4 * ((size_t)pl.n_segs + (size_t)n),
+                 o_head = o_cstart + 4 * ((size_t)pl.n_chunks + (size_t)n), o_cl = o_head + 4 * (size_t)pl.n_chunks;
+    const size_t geo_bytes = o_cl + 4 * pl.cl.size();
     if (!ensure(c, c->geo, geo_bytes + 64)) return false;
     for (int i = 0; i < n; i++) {
         StreamDesc &s = pl.sd[(size_t)i];
         const int32_t *g = (const int32_t *)c->geo.p;
+        const uint8_t *gb = (const uint8_t *)c->geo.p;
         s.seg_c0 = g + s.seg_off, s.seg_after = g + pl.n_segs + s.seg_off, s.seg_base = g + 2 * pl.n_segs + s.seg_off;
-        s.head = (const uint8_t *)c->geo.p + 12 * (size_t)pl.n_segs + (size_t)s.chunk_off;
+        s.seg_S = g + 3 * pl.n_segs + s.seg_off;
+        s.seg_cl = (const int32_t *)(gb + o_segcl) + s.seg_off + i;
+        s.cstart = (const int32_t *)(gb + o_cstart) + s.chunk_off + i;
+        s.head = (const int32_t *)(gb + o_head) + s.chunk_off;
+        s.cl = (const uint32_t *)(gb + o_cl);
     }
     if (pl.any_fv) {
         // one bit per position (pos_off is a multiple of 64: every stream's bitmap starts on a word)
@@ -368,8 +397,12 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
             memcpy(hg, pl.seg_c0.data(), 4 * (size_t)pl.n_segs);
             memcpy(hg + 4 * (size_t)pl.n_segs, pl.seg_after.data(), 4 * (size_t)pl.n_segs);
             memcpy(hg + 8 * (size_t)pl.n_segs, pl.seg_base.data(), 4 * (size_t)pl.n_segs);
+            memcpy(hg + 12 * (size_t)pl.n_segs, pl.seg_S.data(), 4 * (size_t)pl.n_segs);
         }
-        if (pl.n_chunks) memcpy(hg + 12 * (size_t)pl.n_segs, pl.head.data(), (size_t)pl.n_chunks);
+        memcpy(hg + o_segcl, pl.seg_cl.data(), 4 * pl.seg_cl.size());
+        memcpy(hg + o_cstart, pl.cstart.data(), 4 * pl.cstart.size());
+        if (pl.n_chunks) memcpy(hg + o_head, pl.head.data(), 4 * (size_t)pl.n_chunks);
+        if (!pl.cl.empty()) memcpy(hg + o_cl, pl.cl.data(), 4 * pl.cl.size());
         ZS_HIP(c, hipMemcpyAsync(c->geo.p, hg, geo_bytes, hipMemcpyHostToDevice, stream));
     }
     ZS_HIP(c, hipMemcpyAsync(c->sd.p, hp, sizeof(StreamDesc) * (size_t)n, hipMemcpyHostToDevice, stream));
@@ -472,7 +505,7 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
             const int sa = (int)((int64_t)nsegs * k / n_parts), sb = (int)((int64_t)nsegs * (k + 1) / n_parts);
             const int ca = pl.seg_c0[(size_t)sa], cb = sb < nsegs ? pl.seg_c0[(size_t)sb] : nchunks;
             // the chunks below cb need the match records of the positions below their end
-            const int64_t q = sb < nsegs ? chunk_start(cb) : (int64_t)s0.body_end + 1;
+            const int64_t q = sb < nsegs ? (int64_t)pl.cstart[(size_t)cb] : (int64_t)s0.body_end + 1;
             int64_t tiles_end = (q + kMatchTile - 1) / kMatchTile;
             if (tiles_end > n_tiles || sb == nsegs) tiles_end = n_tiles;
             int64_t spans_end = (tiles_end * kMatchTile + link_span - 1) / link_span;
@@ -492,7 +525,7 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
             spans_done = spans_end > spans_done ? spans_end : spans_done, tiles_done = tiles_end > tiles_done ? tiles_end : tiles_done;
             timed(kStChunkMap, stream, [&] {
                 hipLaunchKernelGGL(zs_chunkmap_kernel, dim3((unsigned)(cb - ca)), dim3(512), 0, stream, d_sd, d_work + o_chunks + ca,
-                                   dev<uint2>(c->mm), dev<uint32_t>(c->maps), c->crc_tab, lv, strategy, hash_variant, dev<uint16_t>(c->chunk_far));
+                                   dev<uint2>(c->mm), dev<uint16_t>(c->link), dev<uint32_t>(c->maps), c->crc_tab, lv, strategy, hash_variant, dev<uint16_t>(c->chunk_far));
             });
             timed(kStSegMap, stream, [&] {
                 hipLaunchKernelGGL(zs_segmap_kernel, dim3((unsigned)(sb - sa)), dim3(320), 0, stream, d_sd, d_work + o_segs + sa,
@@ -520,13 +553,13 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
             }
             timed(kStExpand, c->aux, [&] {
                 hipLaunchKernelGGL(zs_expand_kernel, dim3((unsigned)((sb - sa + 63) / 64)), dim3(64), 0, c->aux, d_sd, d_st, d_work + o_segs + sa,
-                                   sb - sa, dev<uint2>(c->mm), dev<uint32_t>(c->maps), dev<uint16_t>(c->seg_entry),
+                                   sb - sa, dev<uint2>(c->mm), dev<uint16_t>(c->link), dev<uint32_t>(c->maps), dev<uint16_t>(c->seg_entry),
                                    dev<uint32_t>(c->seg_symbase), dev<uint8_t>(c->stale), dev<uint16_t>(c->entry), dev<uint32_t>(c->symbase),
                                    c->crc_tab, lv, strategy, hash_variant);
             });
             timed(kStEmitSyms, c->aux, [&] {
                 hipLaunchKernelGGL(zs_emit_syms_lane_kernel<4>, dim3((unsigned)((cb - ca + 63) / 64)), dim3(kK5Threads), 0, c->aux, d_sd, d_st,
-                                   d_work + o_chunks + ca, cb - ca, dev<uint2>(c->mm), dev<uint16_t>(c->entry), dev<uint32_t>(c->symbase),
+                                   d_work + o_chunks + ca, cb - ca, dev<uint2>(c->mm), dev<uint16_t>(c->link), dev<uint16_t>(c->entry), dev<uint32_t>(c->symbase),
                                    dev<uint32_t>(c->syms), dev<int32_t>(c->blk_end), dev<int32_t>(c->blk_top), c->crc_tab, lv, strategy,
                                    hash_variant, k5_ahead);
             });
@@ -551,7 +584,7 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
     if (!side_work()) return false;
     if (!pl.w_chunks.empty())
         hipLaunchKernelGGL(zs_chunkmap_kernel, dim3((unsigned)pl.w_chunks.size()), dim3(512), 0, stream, d_sd, d_work + o_chunks,
-                           dev<uint2>(c->mm), dev<uint32_t>(c->maps), c->crc_tab, lv, strategy,
+                           dev<uint2>(c->mm), dev<uint16_t>(c->link), dev<uint32_t>(c->maps), c->crc_tab, lv, strategy,
                            hash_variant, dev<uint16_t>(c->chunk_far));
     mark(5);
     if (!pl.w_segs.empty())
@@ -586,12 +619,12 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
             ZS_HIP(c, hipMemcpyAsync(hr, d_st, sizeof(StreamState) * (size_t)n, hipMemcpyDeviceToHost, stream));
             ZS_HIP(c, hipStreamSynchronize(stream));
             bool any = false;
-            for (int i = 0; i < n; i++) any = any || hr[i].deferred == 2;
+            for (int i = 0; i < n; i++) any = any || hr[i].deferred == 2;  // (3: a poisoned stream, dealt with at the end)
             if (!any) break;
             hipLaunchKernelGGL(zs_repair_kernel, dim3(kRepairParts, (unsigned)n), dim3(256), kRepairLds, stream, d_sd, d_st, dev<uint16_t>(c->link),
                                dev<uint2>(c->mm), dev<uint8_t>(c->stale), dev<uint8_t>(c->seg_stale), dev<uint16_t>(c->chunk_far), c->crc_tab, lv,
                                hash_variant);
-            hipLaunchKernelGGL(zs_stalemaps_kernel, dim3(18, (unsigned)n), dim3(512), 0, stream, d_sd, d_st, dev<uint2>(c->mm),
+            hipLaunchKernelGGL(zs_stalemaps_kernel, dim3(18, (unsigned)n), dim3(512), 0, stream, d_sd, d_st, dev<uint2>(c->mm), dev<uint16_t>(c->link),
                                dev<uint32_t>(c->maps), dev<uint8_t>(c->stale), c->crc_tab, lv, strategy, hash_variant);
             hipLaunchKernelGGL(zs_round_end_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_st, n);
             launch_resolve();
@@ -621,14 +654,14 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
     }
     if (!pl.w_segs.empty())
         hipLaunchKernelGGL(zs_expand_kernel, dim3((unsigned)((pl.w_segs.size() + 63) / 64)), dim3(64), 0, stream, d_sd, d_st,
-                           d_work + o_segs, (int)pl.w_segs.size(), dev<uint2>(c->mm),
+                           d_work + o_segs, (int)pl.w_segs.size(), dev<uint2>(c->mm), dev<uint16_t>(c->link),
                            dev<uint32_t>(c->maps), dev<uint16_t>(c->seg_entry), dev<uint32_t>(c->seg_symbase),
                            dev<uint8_t>(c->stale), dev<uint16_t>(c->entry), dev<uint32_t>(c->symbase), c->crc_tab, lv, strategy,
                            hash_variant);
     mark(8);
     if (!pl.w_chunks.empty())
         hipLaunchKernelGGL(zs_emit_syms_lane_kernel<4>, dim3((unsigned)((pl.w_chunks.size() + 63) / 64)), dim3(kK5Threads), 0, stream, d_sd, d_st,
-                           d_work + o_chunks, (int)pl.w_chunks.size(), dev<uint2>(c->mm), dev<uint16_t>(c->entry),
+                           d_work + o_chunks, (int)pl.w_chunks.size(), dev<uint2>(c->mm), dev<uint16_t>(c->link), dev<uint16_t>(c->entry),
                            dev<uint32_t>(c->symbase), dev<uint32_t>(c->syms), dev<int32_t>(c->blk_end), dev<int32_t>(c->blk_top),
                            c->crc_tab, lv, strategy, hash_variant, k5_ahead);
     mark(9);
@@ -669,7 +702,7 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
                                 (long long)o.mark_pos, (long long)o.mark_nsyms, (long long)o.end_pos, (long long)o.nsyms, o.n_ev);
                     }
                 }
-                return run_pipeline(c, n, in, in_len, out, out_cap, out_len, status, level, strategy, hash_variant, stream, writes, true, ro);
+                return run_pipeline(c, n, in, in_len, out, out_cap, out_len, status, level, strategy, hash_variant, stream, writes, true, ro, false, force_lit);
             }
         hipLaunchKernelGGL(zs_fast_plan_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, d_sd, d_st, dev<FastRunOut>(c->run_outs), n);
         hipLaunchKernelGGL(zs_fast_stitch_kernel, dim3((unsigned)pl.n_runs), dim3(256), 0, stream, d_sd, d_work + o_runs,
@@ -718,6 +751,19 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
             }
         }
     }
+    {
+        // a stream whose true path met a read the bulk form does not handle (zs_core.h kMapPoisonBit): the batch again with
+        // those streams on the literal engine
+        bool any_poison = false;
+        std::vector<uint8_t> fl(force_lit ? *force_lit : std::vector<uint8_t>((size_t)n, 0));
+        for (int i = 0; i < n; i++)
+            if (hst[i].poison) any_poison = true, fl[(size_t)i] = 1;
+        if (any_poison) {
+            ZS_HIP(c, hipStreamSynchronize(c->aux));
+            c->lit_fallbacks++;
+            return run_pipeline(c, n, in, in_len, out, out_cap, out_len, status, level, strategy, hash_variant, stream, writes, force_seq, ro, false, &fl);
+        }
+    }
     if (!ro && !rounds) {
         // a stream the resolve kernel gave up (zs_device.h, StreamState::deferred): the batch again, in rounds
         bool gave_up = false;
@@ -725,7 +771,7 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
         if (gave_up) {
             ZS_HIP(c, hipStreamSynchronize(c->aux));
             c->round_runs++;
-            return run_pipeline(c, n, in, in_len, out, out_cap, out_len, status, level, strategy, hash_variant, stream, writes, force_seq, ro, true);
+            return run_pipeline(c, n, in, in_len, out, out_cap, out_len, status, level, strategy, hash_variant, stream, writes, force_seq, ro, true, force_lit);
         }
     }
     if (ro) ro->end_bits = hst[0].end_bits;
@@ -928,6 +974,32 @@ int zs_deflate_batch_device(zs_ctx *c, int n, const void *const *in, const int64
     if (hipSetDevice(c->device) != hipSuccess) return ZS_STREAM_ERROR;
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
     if (!run_pipeline(c, n, in, in_len, out, out_cap, out_len, status, level, strategy, hash_variant, s))
+        return c->err == "buffer error" ? ZS_BUF_ERROR : ZS_STREAM_ERROR;
+    return ZS_OK;
+}
+
+int zs_deflate_writes_device(zs_ctx *c, const void *in, int64_t in_len, const int64_t *write_ends, int64_t n_writes, void *out,
+                             int64_t out_cap, int64_t *out_len, int level, int strategy, int hash_variant, void *hip_stream) {
+    if (!check_args(c, 1, &in_len, level, strategy)) return ZS_STREAM_ERROR;
+    if (hipSetDevice(c->device) != hipSuccess) return ZS_STREAM_ERROR;
+    WriteSpec ws;
+    int64_t prev = 0;
+    for (int64_t i = 0; i < n_writes; i++) {
+        if (write_ends[i] < prev || write_ends[i] > in_len) {
+            c->err = "stream error";
+            return ZS_STREAM_ERROR;
+        }
+        if (write_ends[i] > prev) ws.ends.push_back(write_ends[i]);  // an empty Write never reaches Deflate (ZlibOutputStream.cs:127-130)
+        prev = write_ends[i];
+    }
+    if (prev != in_len) {
+        c->err = "stream error";
+        return ZS_STREAM_ERROR;
+    }
+    ws.flush.assign(ws.ends.size(), 0);
+    hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
+    int st = 0;
+    if (!run_pipeline(c, 1, &in, &in_len, &out, &out_cap, out_len, &st, level, strategy, hash_variant, s, ws.ends.size() > 1 ? &ws : nullptr))
         return c->err == "buffer error" ? ZS_BUF_ERROR : ZS_STREAM_ERROR;
     return ZS_OK;
 }

@@ -607,12 +607,38 @@ __device__ __forceinline__ int seg_of(const StreamDesc &s, int c) {  // last seg
     return lo;
 }
 
+// chunk c of stream s as the walkers of zs_core.h see it (geometry and read-event cluster from the host's tables)
+__device__ __forceinline__ ChunkCtx chunk_ctx(const StreamDesc &s, int c) {
+    ChunkCtx cx;
+    cx.cs = s.cstart[c], cx.ce = s.cstart[c + 1];
+    if (cx.ce > (int64_t)s.body_end + 1) cx.ce = (int64_t)s.body_end + 1;
+    cx.cl = nullptr, cx.m = 0, cx.S = 0, cx.after = 0;
+    const int h = s.head[c];
+    if (h) {
+        const int k = h - 1;
+        const int o = s.seg_cl[k];
+        cx.cl = s.cl + o, cx.m = s.seg_cl[k + 1] - o, cx.S = s.seg_S[k], cx.after = s.seg_after[k];
+    }
+    return cx;
+}
+__device__ __forceinline__ int chunk_of(const StreamDesc &s, int64_t p) {  // last chunk whose first position is <= p
+    int lo = 0, hi = s.nchunks - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if ((int64_t)s.cstart[mid] <= p) lo = mid;
+        else hi = mid - 1;
+    }
+    return lo;
+}
+
 // ------------------------------------------------------------------ K3 / K4 / K5 accessors
 struct GlobalAcc {
     gcbytes in;
     const uint2 *mm;  // already offset to the stream's position 0
     const uint32_t *tab;
     int strategy, hash_variant;
+    const uint16_t *lk;  // the stream's links
+    __device__ int link(int64_t p) const { return (int)lk[p]; }
     __device__ uint32_t flt(uint32_t m) const {
         m &= kRecMask;
         return m ? filter_match(match_len(m), match_dist(m), strategy) : kNoMatch;
@@ -634,7 +660,9 @@ struct LdsAcc {
     int64_t org;  // cs - 1
     const uint32_t *tab;
     int hash_variant;
+    const uint16_t *lk;               // the stream's links
     const uint8_t *lbytes = nullptr;  // optional: input bytes [org, org + kChunk + 1) staged in LDS
+    __device__ int link(int64_t p) const { return (int)lk[p]; }
     __device__ uint32_t mK(int64_t p) const { return fk[p - org]; }
     __device__ uint32_t mK4(int64_t p) const { return fk4[p - org]; }
     __device__ uint8_t byte(int64_t p) const { return lbytes ? lbytes[p - org] : in[p]; }
@@ -648,11 +676,10 @@ struct LdsAcc {
 
 // Returns the largest distance among the thread's raw records of the chunk's own positions (K3 keeps the chunk's maximum for
 // the resolve kernel's repairs).
-__device__ __forceinline__ uint32_t stage_chunk_matches(const StreamDesc &s, int c, const uint2 *mm, int strategy, uint32_t *fk,
+__device__ __forceinline__ uint32_t stage_chunk_matches(const StreamDesc &s, int64_t cs, const uint2 *mm, int strategy, uint32_t *fk,
                                                         uint32_t *fk4) {
-    ChunkGeo g = chunk_geo(c);
     const uint2 *a = mm + s.pos_off;
-    int64_t org = g.cs - 1;
+    int64_t org = cs - 1;
     uint32_t far = 0;
     const uint32_t klm = strategy == kFiltered ? 2u : 0u, kdm = strategy == kFiltered ? 0u : (uint32_t)kTooFar;
     for (int i = threadIdx.x; i < kChunk + 1; i += blockDim.x) {
@@ -685,10 +712,11 @@ __device__ __forceinline__ uint32_t stage_chunk_matches(const StreamDesc &s, int
 // chunks whose records a repair has changed).  fk, fk4: kChunk + 1 words each; tbl: kNodeExit3 words; tab: the CRC tables
 // (read for event chunks only; the caller has loaded them); far_word: a zeroed LDS word or nullptr.
 template <int NT>  // threads of the workgroup (compile-time: the loops below are K3's whole time)
-__device__ __forceinline__ void chunkmap_compute(const StreamDesc &s, int c, const uint2 *mm, uint32_t *maps, LevelCfg lv, int strategy, int hash_variant,
+__device__ __forceinline__ void chunkmap_compute(const StreamDesc &s, int c, const uint2 *mm, const uint16_t *link, uint32_t *maps, LevelCfg lv, int strategy, int hash_variant,
                                                  uint32_t *fk, uint32_t *fk4, uint32_t *tbl, uint32_t *tab, uint32_t *far_word, uint16_t *chunk_far) {
     constexpr int nt = NT;
-    uint32_t far = stage_chunk_matches(s, c, mm, strategy, fk, fk4);
+    const ChunkCtx cx = chunk_ctx(s, c);
+    uint32_t far = stage_chunk_matches(s, cx.cs, mm, strategy, fk, fk4);
     // the largest match distance recorded in the chunk: a cut at e can only have been seen through from a chunk whose
     // largest distance reaches back to e (zs_resolve_kernel's repair scans no others)
     if (far_word) {
@@ -699,14 +727,11 @@ __device__ __forceinline__ void chunkmap_compute(const StreamDesc &s, int c, con
         }
         if (threadIdx.x == 0) *far_word = 0;
     }
-    const ChunkGeo g = chunk_geo(c);
-    const bool event_chunk = s.head[c] != 0;
     __syncthreads();
     if (far_word && lane_id() == 0 && far) atomicMax(far_word, far);  // read behind the barriers of the passes below
-    int64_t ce = g.ce;
-    if (ce > (int64_t)s.body_end + 1) ce = (int64_t)s.body_end + 1;
-    const int len = (int)(ce - g.cs);
-    LdsAcc acc{as_global(s.in), fk, fk4, g.cs - 1, tab, hash_variant};
+    const int64_t ce = cx.ce;
+    const int len = (int)(ce - cx.cs);
+    LdsAcc acc{as_global(s.in), fk, fk4, cx.cs - 1, tab, hash_variant, link + s.pos_off};
     // node_step3_all (zs_core.h: three lazy_steps and their node ids) written out with selects: through the shared code it
     // was half of this kernel's instructions, most of them execution-mask pairs around a move or two (the same finding as
     // in the symbol kernel; the shared form stays the specification and what the CPU model runs)
@@ -727,7 +752,7 @@ __device__ __forceinline__ void chunkmap_compute(const StreamDesc &s, int c, con
     for (int off = threadIdx.x; off < len; off += nt) {
         const uint32_t before = fk[off], before4 = fk4[off];
         uint32_t cK = fk[off + 1], cK4 = fk4[off + 1];
-        if (g.cs + off == 0) cK = cK4 = kNoMatch;
+        if (cx.cs + off == 0) cK = cK4 = kNoMatch;
         const int plain_kind = cK ? (int)kXK : (int)kL;
         const uint32_t r0 = node_at(plain_kind, off + 1, 0u);
         const uint32_t r1x = x_step(before, cK, cK4, off), r1l = node_at(plain_kind, off + 1, 1u);
@@ -774,13 +799,13 @@ __device__ __forceinline__ void chunkmap_compute(const StreamDesc &s, int c, con
     const int slot = threadIdx.x;
     if (slot < kSlots) {
         uint32_t out = 0;
-        if (slot_valid(c, slot, s.body_end)) out = chunk_exit_by_table3(acc, tbl, c, slot, event_chunk, s.body_end, lv, strategy);
+        if (slot_valid(cx, slot, s.body_end)) out = chunk_exit_by_table3(acc, tbl, cx, slot, lv, strategy);
         maps[((int64_t)s.chunk_off + c) * kSlots + slot] = out;
     }
     if (far_word && threadIdx.x == NT - 1) chunk_far[s.chunk_off + c] = (uint16_t)*far_word;
 }
 
-__global__ __launch_bounds__(512) void zs_chunkmap_kernel(const StreamDesc *sd, const uint2 *work, const uint2 *mm,
+__global__ __launch_bounds__(512) void zs_chunkmap_kernel(const StreamDesc *sd, const uint2 *work, const uint2 *mm, const uint16_t *link,
                                                           uint32_t *maps, const uint32_t *crc_tab_g,
                                                           LevelCfg lv, int strategy, int hash_variant, uint16_t *chunk_far) {
     __shared__ uint32_t fk[kChunk + 1], fk4[kChunk + 1];
@@ -791,7 +816,7 @@ __global__ __launch_bounds__(512) void zs_chunkmap_kernel(const StreamDesc *sd, 
     const StreamDesc s = sd[w.x];
     const int c = (int)w.y;
     if (s.head[c] != 0) load_crc_tab(tab, crc_tab_g);  // (chunkmap_compute's first barrier comes before the table's first use)
-    chunkmap_compute<512>(s, c, mm, maps, lv, strategy, hash_variant, fk, fk4, tbl, tab, &sh_far, chunk_far);
+    chunkmap_compute<512>(s, c, mm, link, maps, lv, strategy, hash_variant, fk, fk4, tbl, tab, &sh_far, chunk_far);
 }
 
 // ------------------------------------------------------------------ K3b
@@ -809,7 +834,7 @@ __global__ __launch_bounds__(320) void zs_segmap_kernel(const StreamDesc *sd, co
     uint32_t total = 0, flags = 0;
     for (int c = c0; c < c1; c++) {
         uint32_t v = maps[((int64_t)s.chunk_off + c) * kSlots + slot];
-        if (c == c0) flags = v & kMapEqualBit;
+        if (c == c0) flags = v & (kMapEqualBit | kMapPoisonBit);
         slot = map_exit(v);
         total += (uint32_t)map_count(v);
     }
@@ -822,12 +847,12 @@ __global__ __launch_bounds__(320) void zs_segmap_kernel(const StreamDesc *sd, co
 // refill whose loop-top and successor share a bucket, a stale segment).  The resolve kernel then follows a stream through
 // 1/16 of the rows, and its per-segment results are filled in by one thread per group (K4's first part).
 __device__ __forceinline__ uint32_t seg_row_meta(const StreamDesc &s, int seg, const uint8_t *seg_stale) {
-    // bit 0 = the segment starts with a refill (segments 1 .. kl), bit 1 = it holds stale chunks, bits 2.. = largest entry
+    // bit 0 = the segment starts with a cluster of read events, bit 1 = it holds stale chunks, bits 2.. = largest entry
     // offset that is still a loop-top of the body (only the last segment limits it)
-    const int64_t cs = chunk_start(s.seg_c0[seg]);
+    const int64_t cs = s.cstart[s.seg_c0[seg]];
     int64_t lim = (int64_t)s.body_end - cs;
     lim = lim > 511 ? 511 : lim;
-    uint32_t m = (seg >= 1 && lim >= 0) ? 1u : 0u;
+    uint32_t m = (s.head[s.seg_c0[seg]] != 0 && lim >= 0) ? 1u : 0u;
     if (seg_stale[s.seg_off + seg]) m |= 2u;
     return m | ((uint32_t)(lim < 0 ? 0 : lim) << 2);
 }
@@ -845,7 +870,7 @@ __global__ __launch_bounds__(320) void zs_supmap_kernel(const StreamDesc *sd, co
         const uint2 v = segmap[((int64_t)s.seg_off + seg) * kSlots + cur];
         const uint32_t m = seg_row_meta(s, seg, seg_stale);
         const bool fires = (m & 1u) && (uint32_t)(cur <= 256 ? cur : 0) <= (m >> 2);
-        flag |= (m & 2u) | ((fires && (v.x & kMapEqualBit)) ? 1u : 0u);
+        flag |= (m & 2u) | ((fires && (v.x & (kMapEqualBit | kMapPoisonBit))) ? 1u : 0u);
         cur = (int)(v.x & 0x1FF);
         cnt += v.y;
     }
@@ -901,13 +926,12 @@ __device__ __forceinline__ int repair_cut(const RepairArgs &r, int64_t e, int64_
         if (nlist) *nlist = 0;
     }
     if (mark && threadIdx.x < 24) mark[threadIdx.x] = 0;
-    const int c0r = chunk_of(from + 1);  // the chunks a repair can touch: c0r .. c0r + 17
+    const int c0r = chunk_of(s, from + 1);  // the chunks a repair can touch: c0r .. (18 of them on the single-Write grid)
     __syncthreads();
     {
-        const int c1 = chunk_of(to_all);
-        const int cc = c0r + (int)threadIdx.x;
-        if (cc <= c1) {
-            int64_t lo = chunk_geo(cc).cs, hi = chunk_geo(cc).ce - 1;
+        const int c1 = chunk_of(s, to_all);
+        for (int cc = c0r + (int)threadIdx.x; cc <= c1; cc += NT) {
+            int64_t lo = s.cstart[cc], hi = (int64_t)s.cstart[cc + 1] - 1;
             if (lo < from + 1) lo = from + 1;
             if (hi > to_all) hi = to_all;
             if ((int64_t)r.chunk_far[s.chunk_off + cc] > lo - e) atomicMax(sh_to, (int)hi);
@@ -1037,11 +1061,11 @@ __device__ __forceinline__ int repair_cut(const RepairArgs &r, int64_t e, int64_
         }
         if (nx != x || ny != y) {
             a[p] = make_uint2(nx | (old.x & ~kRecMask), ny);
-            int cp = chunk_of(p);
+            int cp = chunk_of(s, p);
             // the chunk's map (and its successor's, whose pending-match row starts with p) no longer holds: listed once
             for (int k = 0; k < 2; k++) {
                 const int cc = cp + k;
-                if (k == 1 && !(p + 1 == chunk_geo(cp).ce && cp + 1 < nch)) break;
+                if (k == 1 && !(p + 1 == (int64_t)s.cstart[cp + 1] && cp + 1 < nch)) break;
                 r.seg_stale[s.seg_off + seg_of(s, cc)] = 1;
                 r.stale[s.chunk_off + cc] = 1;
                 if (mark && cc - c0r >= 0 && cc - c0r < 24 && atomicExch(&mark[cc - c0r], 1u) == 0) {
@@ -1073,8 +1097,8 @@ __global__ __launch_bounds__(1024) void zs_resolve_kernel(const StreamDesc *sd, 
     __shared__ int g_slot[kSegBatch / kSegGroup], g_kf[kSegBatch / kSegGroup], g_ks[kSegBatch / kSegGroup], g_fast[kSegBatch / kSegGroup];
     __shared__ uint32_t g_base[kSegBatch / kSegGroup];
     __shared__ int sh_kf, sh_ks;
-    __shared__ int sh_seg, sh_slot, sh_scan, sh_kfired, sh_preins;
-    __shared__ int sh_defer, sh_nexp;
+    __shared__ int sh_seg, sh_slot, sh_scan, sh_kfired, sh_kslot;
+    __shared__ int sh_defer, sh_nexp, sh_cutidx, sh_poison, sh_cut_e;
     __shared__ int b_seg0, b_nrow, b_groups;  // the batch of rows in LDS: first segment, rows, whether its composed groups may be used
     __shared__ uint32_t sh_total;
     const StreamDesc s = sd[blockIdx.x];
@@ -1083,8 +1107,8 @@ __global__ __launch_bounds__(1024) void zs_resolve_kernel(const StreamDesc *sd, 
     // seg_limit / mm_limit (one long stream run part by part, else "everything"): segments below seg_limit have their maps,
     // positions up to mm_limit their match records; the kernel goes on from where the launch before stopped
     if (threadIdx.x == 0)
-        sh_seg = ss.r_seg, sh_slot = ss.r_slot, sh_total = ss.r_total, sh_kfired = ss.r_kfired, sh_preins = ss.r_preins1 - 1, sh_scan = ss.r_scan,
-        ss.r_scan = 0, b_seg0 = 0, b_nrow = 0, b_groups = 0, sh_defer = 0, sh_nexp = 0;
+        sh_seg = ss.r_seg, sh_slot = ss.r_slot, sh_total = ss.r_total, sh_kfired = ss.r_kfired, sh_kslot = ss.r_kslot, sh_scan = ss.r_scan,
+        ss.r_scan = 0, b_seg0 = 0, b_nrow = 0, b_groups = 0, sh_defer = 0, sh_nexp = 0, sh_cutidx = ss.r_cutidx, sh_poison = 0, sh_cut_e = -1;
     __syncthreads();
     if (s.body_end < 0) {
         if (threadIdx.x == 0) ss.tail_p = 0, ss.tail_kind = kR, ss.tail_pend = 0, ss.k_done = 0, ss.preins = -1, ss.body_syms = 0;
@@ -1092,7 +1116,7 @@ __global__ __launch_bounds__(1024) void zs_resolve_kernel(const StreamDesc *sd, 
     }
     uint16_t *lk = link + s.pos_off;
     uint2 *a = mm + s.pos_off;
-    GlobalAcc acc{as_global(s.in), a, tab, strategy, hash_variant};
+    GlobalAcc acc{as_global(s.in), a, tab, strategy, hash_variant, lk};
     const int nseg = s.nsegs < seg_limit ? s.nsegs : seg_limit, nch = s.nchunks;
     const int64_t mm_end = (int64_t)s.body_end < (int64_t)mm_limit ? (int64_t)s.body_end : (int64_t)mm_limit;
     __shared__ int rp_to, rp_nlist, rp_list[24];
@@ -1111,7 +1135,7 @@ __global__ __launch_bounds__(1024) void zs_resolve_kernel(const StreamDesc *sd, 
             for (int k = 0; k < nl; k++) {
                 const int cc = rp_list[k];
                 __syncthreads();
-                chunkmap_compute<1024>(s, cc, mm, maps, lv, strategy, hash_variant, c_fk, c_fk4, c_tbl, tab, nullptr, nullptr);
+                chunkmap_compute<1024>(s, cc, mm, link, maps, lv, strategy, hash_variant, c_fk, c_fk4, c_tbl, tab, nullptr, nullptr);
                 __syncthreads();
                 if (threadIdx.x == 0) stale[s.chunk_off + cc] = 0;
             }
@@ -1180,11 +1204,7 @@ __global__ __launch_bounds__(1024) void zs_resolve_kernel(const StreamDesc *sd, 
                 __syncthreads();
                 if (threadIdx.x == 0) {
                     sh_seg = s.nsegs;
-                    if (fp_kf) {
-                        const int kf = (int)(fp_kf >> 16) - 1, ks = (int)(fp_kf & 0xFFFF);
-                        const int64_t cs = chunk_start(s.seg_c0[kf]);
-                        sh_kfired = kf, sh_preins = (int)((ks <= 256 ? cs + ks : cs) + 1);
-                    }
+                    if (fp_kf) sh_kfired = (int)(fp_kf >> 16) - 1, sh_kslot = (int)(fp_kf & 0xFFFF);
                 }
                 __syncthreads();
             } else {
@@ -1212,6 +1232,62 @@ __global__ __launch_bounds__(1024) void zs_resolve_kernel(const StreamDesc *sd, 
         __syncthreads();
         if (threadIdx.x == 0) ss.r_ncut = keep;
     }
+    // The events of the cluster at the head of segment sh_seg, on the path from slot sh_slot, whose loop-top shares its bucket
+    // with the next position: the reference leaves prev[e] = e + 1 there (see above).  In stream order: thread 0 finds the
+    // next one (a repair changes records, and with them the path to the events behind it), link[e] is cut, the positions that
+    // saw through the cut are walked again.  sh_cutidx counts the cuts applied (a round leaves the kernel in the middle).
+    struct NthEqualEv {
+        int want, seen;
+        int64_t pos;
+        __device__ void operator()(int64_t p, bool eq) {
+            if (!eq) return;
+            if (seen == want) pos = p;
+            seen++;
+        }
+    };
+    auto process_cuts = [&]() {
+        const ChunkCtx cx = chunk_ctx(s, s.seg_c0[sh_seg]);
+        for (;;) {
+            if (threadIdx.x == 0) {
+                NthEqualEv ne{sh_cutidx, 0, -1};
+                NullSink nsk;
+                int kind, ns;
+                int64_t pp;
+                uint32_t fl;
+                chunk_special_prefix(acc, nsk, cx, sh_slot, lv, strategy, kind, pp, ns, fl, ne);
+                sh_cut_e = (int)ne.pos;
+                if (fl & kMapPoisonBit) sh_poison = 1;
+            }
+            __syncthreads();
+            const int64_t e = sh_cut_e;
+            if (e < 0 || sh_poison) break;
+            if (threadIdx.x == 0) lk[e] = 0, sh_cutidx++;
+            __threadfence_block();
+            __syncthreads();
+            int64_t full = e + kMaxDist;
+            if (full > s.body_end) full = s.body_end;
+            const int64_t to = full < mm_end ? full : mm_end;
+            if (defer_mode == 2) {
+                // a round: a cut with positions to walk again is left to zs_repair_kernel -- the kernel stops here
+                if (repair(e, e, to, true) == 1 && threadIdx.x == 0) ss.r_cut_e[0] = (int32_t)e, ss.r_cut_done[0] = (int32_t)e, ss.r_ncut = 1, sh_defer = 2;
+            } else {
+                const int rc = repair(e, e, to, false);
+                if (threadIdx.x == 0 && to < full) {  // the rest once the records beyond exist
+                    const int k = ss.r_ncut < 8 ? ss.r_ncut++ : 7;
+                    ss.r_cut_e[k] = (int32_t)e, ss.r_cut_done[k] = (int32_t)to;
+                }
+                if (defer_mode == 1 && rc == 2 && threadIdx.x == 0 && ++sh_nexp > kDeferBudget) sh_defer = 1;  // not this CU's job
+            }
+            __threadfence_block();
+            __syncthreads();
+            if (sh_defer) break;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0 && !sh_defer) sh_cutidx = 0;
+        __syncthreads();
+    };
+    // a round left the kernel in the middle of a cluster's cuts: the rest of them first
+    if (sh_scan && sh_seg < nseg) process_cuts();
 #ifdef ZS_FV_PROF
     long long kp[6] = {0, 0, 0, 0, 0, 0}, kt = wall_clock64();
     int kiter = 0;
@@ -1220,7 +1296,7 @@ __global__ __launch_bounds__(1024) void zs_resolve_kernel(const StreamDesc *sd, 
 #define K4_PF(i)
 #endif
     for (;;) {
-        if (sh_seg >= nseg) break;  // the composed rows have done it all (or there is nothing to do)
+        if (sh_seg >= nseg || sh_defer || sh_poison) break;  // the composed rows have done it all (or there is nothing to do), or the rest of a cluster's cuts stopped again
 #ifdef ZS_FV_PROF
         kiter++;
         kt = wall_clock64();
@@ -1256,7 +1332,7 @@ __global__ __launch_bounds__(1024) void zs_resolve_kernel(const StreamDesc *sd, 
                 const uint2 v = rows[i * kSlots + cur];
                 const uint32_t m = row_meta[i];
                 const bool fires = (m & 1u) && (uint32_t)(cur <= 256 ? cur : 0) <= (m >> 2);
-                flag |= (m & 2u) | ((fires && (v.x & kMapEqualBit)) ? 1u : 0u);
+                flag |= (m & 2u) | ((fires && (v.x & (kMapEqualBit | kMapPoisonBit))) ? 1u : 0u);
                 cur = (int)(v.x & 0x1FF);
                 cnt += v.y;
             }
@@ -1294,6 +1370,10 @@ __global__ __launch_bounds__(1024) void zs_resolve_kernel(const StreamDesc *sd, 
                 const uint32_t m = row_meta[i];
                 if ((m & 1u) && (uint32_t)(slot <= 256 ? slot : 0) <= (m >> 2)) {
                     kf = seg, kslot = slot;
+                    if (v.x & kMapPoisonBit) {  // not a stream for the bulk path (zs_core.h kMapPoisonBit)
+                        sh_poison = 1;
+                        break;
+                    }
                     if ((v.x & kMapEqualBit) && cuts && !scanned) {
                         stop = true;
                         break;
@@ -1308,7 +1388,9 @@ __global__ __launch_bounds__(1024) void zs_resolve_kernel(const StreamDesc *sd, 
                         int ex, cnt;
                         if (stale[s.chunk_off + cc]) {
                             NullSink ns;
-                            walk_chunk(acc, ns, cc, slot, s.head[cc] != 0, s.body_end, lv, strategy, ex, cnt);
+                            uint32_t fl;
+                            walk_chunk(acc, ns, chunk_ctx(s, cc), slot, lv, strategy, ex, cnt, &fl);
+                            if (fl & kMapPoisonBit) sh_poison = 1;
                         } else {
                             uint32_t mp = maps[((int64_t)s.chunk_off + cc) * kSlots + slot];
                             ex = map_exit(mp), cnt = map_count(mp);
@@ -1351,10 +1433,7 @@ __global__ __launch_bounds__(1024) void zs_resolve_kernel(const StreamDesc *sd, 
             int kf = sh_kf, ks = sh_ks;
             for (int g = 0; g < kSegBatch / kSegGroup; g++)
                 if (g_fast[g] && g_kf[g] > kf) kf = g_kf[g], ks = g_ks[g];
-            if (kf >= 0) {
-                const int64_t cs = chunk_start(s.seg_c0[kf]);
-                sh_kfired = kf, sh_preins = (int)((ks <= 256 ? cs + ks : cs) + 1);
-            }
+            if (kf >= 0) sh_kfired = kf, sh_kslot = ks;
         }
         __syncthreads();
         for (int i = threadIdx.x; i < sh_seg - seg0; i += blockDim.x) {
@@ -1362,43 +1441,26 @@ __global__ __launch_bounds__(1024) void zs_resolve_kernel(const StreamDesc *sd, 
             seg_symbase[s.seg_off + seg0 + i] = out_base[i];
         }
         K4_PF(3);
+        if (sh_poison) break;
         if (!sh_scan) {
             if (sh_seg >= nseg) break;
             continue;
         }
-        // ---- equal-bucket refill at the head of segment sh_seg: cut and repair ----
-        {
-            const int c0 = s.seg_c0[sh_seg];
-            const int slot = sh_slot;
-            const int64_t e = slot <= 256 ? chunk_start(c0) + slot : chunk_start(c0);
-            if (threadIdx.x == 0) lk[e] = 0;
-            __threadfence_block();
-            __syncthreads();
-            int64_t full = e + kMaxDist;
-            if (full > s.body_end) full = s.body_end;
-            const int64_t to = full < mm_end ? full : mm_end;
-            if (defer_mode == 2) {
-                // a round: a cut with positions to walk again is left to zs_repair_kernel -- the kernel stops here
-                if (repair(e, e, to, true) == 1 && threadIdx.x == 0) ss.r_cut_e[0] = (int32_t)e, ss.r_cut_done[0] = (int32_t)e, ss.r_ncut = 1, sh_defer = 2;
-            } else {
-                const int rc = repair(e, e, to, false);
-                if (threadIdx.x == 0 && to < full) {  // the rest once the records beyond exist
-                    const int k = ss.r_ncut < 8 ? ss.r_ncut++ : 7;
-                    ss.r_cut_e[k] = (int32_t)e, ss.r_cut_done[k] = (int32_t)to;
-                }
-                if (defer_mode == 1 && rc == 2 && threadIdx.x == 0 && ++sh_nexp > kDeferBudget) sh_defer = 1;  // not this CU's job
-            }
-            __threadfence_block();
-        }
+        // ---- equal-bucket events in the cluster at the head of segment sh_seg: cuts and repairs ----
+        process_cuts();
         __syncthreads();
         K4_PF(4);
-        if (sh_defer) break;
+        if (sh_defer || sh_poison) break;
     }
 #ifdef ZS_FV_PROF
     if (threadIdx.x == 0 && blockIdx.x == 0 && kiter > 4)
         printf("K4PROF iterations=%d ticks: stage+meta=%lld compose=%lld walk=%lld fill+flush=%lld repair=%lld\n", kiter, kp[0], kp[1], kp[2], kp[3], kp[4]);
 #endif
-    if (threadIdx.x == 0) ss.r_seg = sh_seg, ss.r_slot = sh_slot, ss.r_total = sh_total, ss.r_kfired = sh_kfired, ss.r_preins1 = sh_preins + 1;
+    if (threadIdx.x == 0) ss.r_seg = sh_seg, ss.r_slot = sh_slot, ss.r_total = sh_total, ss.r_kfired = sh_kfired, ss.r_kslot = sh_kslot, ss.r_cutidx = sh_cutidx;
+    if (sh_poison) {
+        if (threadIdx.x == 0) ss.poison = 1, ss.deferred = 3;  // the kernels behind skip the stream; the host runs it on the literal engine
+        return;
+    }
     if (sh_defer) {
         if (threadIdx.x == 0) ss.deferred = sh_defer, ss.r_scan = 1;
         return;
@@ -1413,7 +1475,19 @@ __global__ __launch_bounds__(1024) void zs_resolve_kernel(const StreamDesc *sd, 
         ss.tail_kind = kind;
         ss.tail_pend = kind == kXK ? acc.mK(p - 1) : kind == kXK4 ? acc.mK4(p - 1) : 0;
         ss.k_done = sh_kfired;
-        ss.preins = sh_preins;
+        // the position the last event pre-inserted: the last event loop-top of the last cluster that fired, + 1
+        struct LastEv {
+            int64_t pos;
+            __device__ void operator()(int64_t q, bool) { pos = q; }
+        } lev{-1};
+        if (s.nsegs > 0) {
+            NullSink nsk;
+            int k2, n2;
+            int64_t p2;
+            uint32_t f2;
+            chunk_special_prefix(acc, nsk, chunk_ctx(s, s.seg_c0[sh_kfired]), sh_kslot, lv, strategy, k2, p2, n2, f2, lev);
+        }
+        ss.preins = lev.pos >= 0 ? (int32_t)lev.pos + 1 : -1;
         ss.body_syms = sh_total;
     }
 }
@@ -1445,7 +1519,7 @@ __global__ __launch_bounds__(256) void zs_repair_kernel(const StreamDesc *sd, co
     RepairArgs ra{&s, mm + s.pos_off, link + s.pos_off, tab, smem, stale, seg_stale, chunk_far, s.nchunks, lv, hash_variant};
     repair_cut<256, 1>(ra, e, e, full, false, &sh_to, nullptr, nullptr, nullptr, (int)blockIdx.x, kRepairParts);
 }
-__global__ __launch_bounds__(512) void zs_stalemaps_kernel(const StreamDesc *sd, const StreamState *st, const uint2 *mm, uint32_t *maps,
+__global__ __launch_bounds__(512) void zs_stalemaps_kernel(const StreamDesc *sd, const StreamState *st, const uint2 *mm, const uint16_t *link, uint32_t *maps,
                                                            uint8_t *stale, const uint32_t *crc_tab_g, LevelCfg lv, int strategy, int hash_variant) {
     __shared__ uint32_t fk[kChunk + 1], fk4[kChunk + 1];
     __shared__ uint32_t tbl[kNodeExit3];
@@ -1453,11 +1527,17 @@ __global__ __launch_bounds__(512) void zs_stalemaps_kernel(const StreamDesc *sd,
     const StreamDesc s = sd[blockIdx.y];
     const StreamState &ss = st[blockIdx.y];
     if (ss.deferred != 2) return;
-    const int c = chunk_of((int64_t)ss.r_cut_e[0] + 1) + (int)blockIdx.x;
-    if (c >= s.nchunks || !stale[s.chunk_off + c]) return;
-    if (s.head[c] != 0) load_crc_tab(tab, crc_tab_g);
-    chunkmap_compute<512>(s, c, mm, maps, lv, strategy, hash_variant, fk, fk4, tbl, tab, nullptr, nullptr);
-    if (threadIdx.x == 0) stale[s.chunk_off + c] = 0;
+    // the chunks a cut's repair can have touched: those that begin within MAX_DIST behind it, dealt round the workgroups
+    const int64_t e = ss.r_cut_e[0];
+    bool tab_loaded = false;
+    for (int c = chunk_of(s, e + 1) + (int)blockIdx.x; c < s.nchunks && (int64_t)s.cstart[c] <= e + kMaxDist + 1; c += (int)gridDim.x) {
+        if (!stale[s.chunk_off + c]) continue;  // (uniform over the workgroup)
+        __syncthreads();
+        if (s.head[c] != 0 && !tab_loaded) load_crc_tab(tab, crc_tab_g), tab_loaded = true;
+        chunkmap_compute<512>(s, c, mm, link, maps, lv, strategy, hash_variant, fk, fk4, tbl, tab, nullptr, nullptr);
+        __syncthreads();
+        if (threadIdx.x == 0) stale[s.chunk_off + c] = 0;
+    }
 }
 __global__ __launch_bounds__(256) void zs_round_end_kernel(StreamState *st, int n) {
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -1465,7 +1545,7 @@ __global__ __launch_bounds__(256) void zs_round_end_kernel(StreamState *st, int 
 }
 
 __global__ __launch_bounds__(64) void zs_expand_kernel(const StreamDesc *sd, const StreamState *st, const uint2 *work, int nwork, const uint2 *mm,
-                                                       const uint32_t *maps, const uint16_t *seg_entry,
+                                                       const uint16_t *link, const uint32_t *maps, const uint16_t *seg_entry,
                                                        const uint32_t *seg_symbase, const uint8_t *stale, uint16_t *entry,
                                                        uint32_t *symbase, const uint32_t *crc_tab_g, LevelCfg lv, int strategy,
                                                        int hash_variant) {
@@ -1475,7 +1555,7 @@ __global__ __launch_bounds__(64) void zs_expand_kernel(const StreamDesc *sd, con
     if (st[w.x].deferred) return;  // the resolve kernel gave the stream up: the batch is run again in rounds
     const StreamDesc s = sd[w.x];
     const int seg = (int)w.y;
-    GlobalAcc acc{as_global(s.in), mm + s.pos_off, crc_tab_g, strategy, hash_variant};
+    GlobalAcc acc{as_global(s.in), mm + s.pos_off, crc_tab_g, strategy, hash_variant, link + s.pos_off};
     int slot = seg_entry[s.seg_off + seg];
     uint32_t total = seg_symbase[s.seg_off + seg];
     const int c0 = seg_first(s, seg), c1 = seg_first(s, seg + 1);
@@ -1485,7 +1565,7 @@ __global__ __launch_bounds__(64) void zs_expand_kernel(const StreamDesc *sd, con
         int ex, cnt;
         if (stale[s.chunk_off + c]) {
             NullSink ns;
-            walk_chunk(acc, ns, c, slot, s.head[c] != 0, s.body_end, lv, strategy, ex, cnt);
+            walk_chunk(acc, ns, chunk_ctx(s, c), slot, lv, strategy, ex, cnt);
         } else {
             uint32_t m = maps[((int64_t)s.chunk_off + c) * kSlots + slot];
             ex = map_exit(m), cnt = map_count(m);
@@ -1541,7 +1621,7 @@ __device__ __forceinline__ uint32_t k5_peek(lds_u32p slot) { return *(volatile _
 __device__ __forceinline__ uint64_t k5_peek64(uint32_t addr) { return *(volatile __attribute__((address_space(3))) uint64_t *)addr; }
 template <int kK5Ring>
 __global__ __launch_bounds__(kK5Threads) void zs_emit_syms_lane_kernel(const StreamDesc *sd, const StreamState *st, const uint2 *work, int nwork, const uint2 *mm,
-                                                               const uint16_t *entry, const uint32_t *symbase, uint32_t *syms,
+                                                               const uint16_t *link, const uint16_t *entry, const uint32_t *symbase, uint32_t *syms,
                                                                int32_t *blk_end, int32_t *blk_top, const uint32_t *crc_tab_g,
                                                                LevelCfg lv, int strategy, int hash_variant, int ahead) {
     // Wave 0 walks (one lane per chunk), wave 1 feeds it.  A lane's records come 8 bytes a step out of its own 128-byte
@@ -1630,17 +1710,17 @@ __global__ __launch_bounds__(kK5Threads) void zs_emit_syms_lane_kernel(const Str
     if (st[w.x].deferred) return;
     const StreamDesc s = sd[w.x];
     const int c = (int)w.y;
-    GlobalAcc acc{as_global(s.in), mm + s.pos_off, crc_tab_g, strategy, hash_variant};
+    GlobalAcc acc{as_global(s.in), mm + s.pos_off, crc_tab_g, strategy, hash_variant, link + s.pos_off};
     const uint32_t base = symbase[s.chunk_off + c];
     GlobalSymSink sink(syms + s.sym_off + base, base, blk_end + s.blk_off, blk_top + s.blk_off);
     // the refill-rule prefix (first chunks of segments) by the shared code, then plain automaton steps
     int kind, ns;
     int64_t p;
-    bool equal;
-    chunk_special_prefix(acc, sink, c, (int)entry[s.chunk_off + c], s.head[c] != 0, s.body_end, lv, strategy, kind, p, ns, equal);
-    const ChunkGeo g = chunk_geo(c);
-    int64_t ce = g.ce;
-    if (ce > (int64_t)s.body_end + 1) ce = (int64_t)s.body_end + 1;
+    uint32_t pflags;
+    NullEv nev;
+    const ChunkCtx cx = chunk_ctx(s, c);
+    chunk_special_prefix(acc, sink, cx, (int)entry[s.chunk_off + c], lv, strategy, kind, p, ns, pflags, nev);
+    const int64_t ce = cx.ce;
     if (p >= ce) return;
     // A step's successor is p+1 or, when the pending match is emitted, p-1+len(pend): both records (the literal byte a
     // step at p+1 may emit rides in bits 24..31 of the first) are requested before the step is worked out.
