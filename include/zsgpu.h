@@ -127,6 +127,12 @@ ZS_API int zs_partition(const int64_t *sizes, int n, int n_parts, int *part_of);
 ZS_API int zs_deflate_batch_multi(zs_ctx *const *ctxs, int n_ctx, int n, const void *const *in, const int64_t *in_len,
                                   void *const *out, const int64_t *out_cap, int64_t *out_len, int *status, int level,
                                   int strategy, int hash_variant);
+/* Device-pointer form: in[i] / out[i] live on the GPU of context part_of[i] (the caller places the buffers, e.g. by
+ * zs_partition over the sizes, and keeps them resident): no PCIe traffic, each context's share runs on its own host
+ * thread through zs_deflate_batch_device.  out_len / status are HOST arrays. */
+ZS_API int zs_deflate_batch_multi_device(zs_ctx *const *ctxs, int n_ctx, int n, const void *const *in, const int64_t *in_len,
+                                         void *const *out, const int64_t *out_cap, int64_t *out_len, int *status,
+                                         const int *part_of, int level, int strategy, int hash_variant);
 ZS_API int zs_inflate_batch_multi(zs_ctx *const *ctxs, int n_ctx, int n, const void *const *in, const int64_t *in_len,
                                   void *const *out, const int64_t *out_cap, int64_t *out_len, int *status);
 
@@ -168,7 +174,7 @@ ZS_API double zs_ctx_stage_ms(const zs_ctx *ctx, int stage);
  *   the stream is incremental (the engine is kept suspended in device memory,
  *   consumed input is dropped).  A NoFlush stream with more than 1 GiB buffered
  *   becomes incremental too: a stream has no length limit (a single call takes
- *   up to 2 GiB - 1 KiB).  The bytes are the reference's for a caller that runs
+ *   up to 2 GiB - 1 KiB; 2 GiB - 65 KiB on a stream that has become incremental, whose run keeps 64 KiB of history).  The bytes are the reference's for a caller that runs
  *   ZlibOutputStream.WriteCore's loop (ZlibOutputStream.cs:125-168: a fresh
  *   output chunk of the same size for every call -- the size is taken from the
  *   first call): block end + Tr_align / empty stored block after every flushed

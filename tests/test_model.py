@@ -77,9 +77,9 @@ def test_flush_modes_literal_engine_and_marker_accounting(model):
 
 
 def test_regular_multi_write_takes_the_chunked_form(model):
-    """NoFlush Writes whose sizes are multiples of the chunk size: read events at Write ends fall on the chunk grid
-    (zs_core.h build_read_events) and the chunked parse handles them like window-full refills -- including events
-    whose loop-top shares its bucket with the next position (zeros, runs)."""
+    """NoFlush Writes whose sizes are multiples of 2048 (Stream.CopyTo's 81920 and the like): one read event per Write end,
+    handled like the window-full refills -- including events whose loop-top shares its bucket with the next position
+    (zeros, runs)."""
     for name in ("alice_98304", "alice_98305", "lowent_98043", "zeros_98305", "zeros_65541", "runs", "ptt5"):
         for w in (2048, 4096, 8192, 32768, 65536, 81920):
             for level in (4, 6, 9):
@@ -89,6 +89,31 @@ def test_regular_multi_write_takes_the_chunked_form(model):
                 assert r.returncode == 0 and "PASS" in r.stdout, (name, w, level, r.stdout[-400:])
                 if os.path.getsize(model[name]) > w + 600:
                     assert "tail_from=0 " not in r.stdout + " ", (name, w, level)   # the bulk form really ran
+
+
+def test_any_write_sizes_take_the_chunked_form(model, tmp_path):
+    """NoFlush Writes of any size (ZlibOutputStream.cs:114-168: every Write end is a read event of Fill_window,
+    Deflate.cs:967-1019): zs_core.h build_geometry cuts the parse at the clusters of read boundaries and the chunked form
+    steps through a cluster's events per entry slot -- Write ends in the last 262 bytes of a window (whether the window
+    slides there depends on the loop-top), Writes shorter than MIN_LOOKAHEAD mixed in, first Writes of a few bytes, scanline
+    sized Writes; streams written a few bytes at a time throughout are left to the literal engine.  Bytes, symbols, blocks
+    and event loop-tops against the oracle."""
+    rng = np.random.default_rng(21)
+    big = tmp_path / "low300k"
+    big.write_bytes(rng.choice(np.array([0, 0, 0, 0, 1, 2, 255], dtype=np.uint8), 300000).tobytes())
+    files = dict(model)
+    files["low300k"] = str(big)
+    bulk = 0
+    for name in ("alice_98305", "lowent_98043", "zeros_98305", "runs", "low300k"):
+        for spec in ("1000", "16385", "81921", "3000", "r1:263:3000", "r2:1:5000", "r3:100:600", "5000,3", "65530,4,1000", "40000,2,25534,5", "32766,2",
+                     "100,100,100,5000", "263", "262"):
+            for level in (4, 6, 9):
+                if level != 6 and (name in ("runs", "zeros_98305") or spec not in ("1000", "r3:100:600", "5000,3", "32766,2")):
+                    continue
+                r = subprocess.run([EXE, files[name], str(level), "0", "chunk", spec, "0"], capture_output=True, text=True)
+                assert r.returncode == 0 and "PASS" in r.stdout, (name, spec, level, r.stdout[-400:])
+                bulk += "tail_from=0 " not in r.stdout + " "
+    assert bulk > 70   # the chunked form really ran for most of them (263- and 262-byte Writes are one long cluster)
 
 
 def test_level0_block_plan_equals_the_literal_engine(model, tmp_path):

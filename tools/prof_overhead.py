@@ -1,5 +1,6 @@
 import sys, time
-sys.path.insert(0, '/root/repo')
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from zlibstream_amd import Engine, datagen, deflate_bound
 eng = Engine(0)

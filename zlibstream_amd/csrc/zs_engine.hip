@@ -604,7 +604,7 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
     // synchronisation, which is what a cut's repair takes on one CU at level 6.  64 MiB of short runs: level 9 7.3 s -> 2.0 s,
     // level 6 175 ms inline against 237 in rounds.)
     // (ZS_DEFER_ALL: at every level, for the tests)
-    const int defer_mode = ro ? 0 : rounds ? 2 : (lv.chain > 256 || getenv("ZS_DEFER_ALL")) ? 1 : 0;
+    const int defer_mode = (ro || getenv("ZS_NO_DEFER") ? 0 : rounds ? 2 : (lv.chain > 256 || getenv("ZS_DEFER_ALL")) ? 1 : 0) | (getenv("ZS_DEBUG_CUTS") ? 0x100 : 0);
     auto launch_resolve = [&]() {
         hipLaunchKernelGGL(zs_resolve_kernel, dim3((unsigned)n), dim3(1024), kResolveLds, stream, d_sd, d_st, dev<uint16_t>(c->link),
                            dev<uint2>(c->mm), dev<uint32_t>(c->maps), dev<uint2>(c->segmap),
@@ -853,6 +853,7 @@ bool check_args(zs_ctx *c, int n, const int64_t *in_len, int level, int strategy
 
 extern "C" {
 
+void zs_ctx_destroy(zs_ctx *c);
 int zs_ctx_create(int device, zs_ctx **out) {
     if (!out) return ZS_STREAM_ERROR;
     *out = nullptr;
@@ -862,7 +863,7 @@ int zs_ctx_create(int device, zs_ctx **out) {
     zs_ctx *c = new zs_ctx();
     c->device = device;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
-        delete c;
+        zs_ctx_destroy(c);  // releases whatever was created so far
         return ZS_MEM_ERROR;
     }
     for (auto &e : c->ev) (void)hipEventCreate(&e);
@@ -870,7 +871,7 @@ int zs_ctx_create(int device, zs_ctx **out) {
         // the link kernel relies on the LDS applying the lanes of one DS_MSKOR_RTN_B32 in lane order: check it here
         int *d_ok = nullptr, ok = 0;
         if (hipMalloc((void **)&d_ok, sizeof(int)) != hipSuccess) {
-            delete c;
+            zs_ctx_destroy(c);  // releases whatever was created so far
             return ZS_MEM_ERROR;
         }
         hipLaunchKernelGGL(zs_lds_order_kernel, dim3(1), dim3(64), 0, c->stream, d_ok);
@@ -888,7 +889,7 @@ int zs_ctx_create(int device, zs_ctx **out) {
         hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_pre0, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->ev_pre, hipEventDisableTiming) != hipSuccess) {
-        delete c;
+        zs_ctx_destroy(c);  // releases whatever was created so far
         return ZS_MEM_ERROR;
     }
     for (auto &e : c->ev_part)
@@ -1354,9 +1355,19 @@ int zs_inflate_batch_device(zs_ctx *c, int n, const void *const *in, const int64
                             const int64_t *out_cap, int64_t *out_len, int *status, void *hip_stream) {
     if (!c || n < 0) return ZS_STREAM_ERROR;
     if (n == 0) return ZS_OK;
+    // what the caller sees if anything fails before the results are known (as run_pipeline does for deflate)
+    for (int i = 0; i < n; i++) {
+        out_len[i] = 0;
+        if (status) status[i] = ZS_STREAM_ERROR;
+    }
+    for (int i = 0; i < n; i++)
+        if (in_len[i] < 0 || in_len[i] > 0x7FFFFFFF - 1024 || out_cap[i] < 0 || out_cap[i] > 0x7FFFFFFF - 1024) {
+            c->err = "stream error";
+            return ZS_STREAM_ERROR;
+        }
     if (hipSetDevice(c->device) != hipSuccess) return ZS_STREAM_ERROR;
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
-    std::vector<int> st((size_t)n, 0);
+    std::vector<int> st((size_t)n, ZS_STREAM_ERROR);
     bool ok = run_inflate(c, n, in, in_len, out, out_cap, out_len, st.data(), s);
     if (status) memcpy(status, st.data(), sizeof(int) * (size_t)n);
     if (ok) return ZS_OK;
@@ -1371,7 +1382,17 @@ int zs_inflate_batch(zs_ctx *c, int n, const void *const *in, const int64_t *in_
     if (n == 0) return ZS_OK;
     if (hipSetDevice(c->device) != hipSuccess) return ZS_STREAM_ERROR;
     size_t tin = 0, tout = 0;
-    for (int i = 0; i < n; i++) tin += ((size_t)in_len[i] + 255) & ~(size_t)255, tout += ((size_t)out_cap[i] + 255) & ~(size_t)255;
+    for (int i = 0; i < n; i++) {
+        out_len[i] = 0;
+        if (status) status[i] = ZS_STREAM_ERROR;
+    }
+    for (int i = 0; i < n; i++) {
+        if (in_len[i] < 0 || in_len[i] > 0x7FFFFFFF - 1024 || out_cap[i] < 0 || out_cap[i] > 0x7FFFFFFF - 1024) {
+            c->err = "stream error";
+            return ZS_STREAM_ERROR;
+        }
+        tin += ((size_t)in_len[i] + 255) & ~(size_t)255, tout += ((size_t)out_cap[i] + 255) & ~(size_t)255;
+    }
     if (!ensure(c, c->stage_in, tin + 256) || !ensure(c, c->stage_out, tout + 256)) return ZS_MEM_ERROR;
     std::vector<const void *> din((size_t)n);
     std::vector<void *> dout((size_t)n);
@@ -1384,9 +1405,13 @@ int zs_inflate_batch(zs_ctx *c, int n, const void *const *in, const int64_t *in_
         oi += ((size_t)in_len[i] + 255) & ~(size_t)255;
         oo += ((size_t)out_cap[i] + 255) & ~(size_t)255;
     }
-    int rc = zs_inflate_batch_device(c, n, din.data(), in_len, dout.data(), out_cap, out_len, status, c->stream);
+    std::vector<int> st((size_t)n, ZS_STREAM_ERROR);
+    int rc = zs_inflate_batch_device(c, n, din.data(), in_len, dout.data(), out_cap, out_len, st.data(), c->stream);
+    if (status) memcpy(status, st.data(), sizeof(int) * (size_t)n);
+    // only what a stream that ended cleanly produced goes back, and never more than the caller's buffer holds
     for (int i = 0; i < n; i++)
-        if (out_len[i] > 0 && hipMemcpyAsync(out[i], dout[(size_t)i], (size_t)out_len[i], hipMemcpyDeviceToHost, c->stream) != hipSuccess)
+        if (st[(size_t)i] == ZS_STREAM_END && out_len[i] > 0 && out_len[i] <= out_cap[i] &&
+            hipMemcpyAsync(out[i], dout[(size_t)i], (size_t)out_len[i], hipMemcpyDeviceToHost, c->stream) != hipSuccess)
             return ZS_STREAM_ERROR;
     if (hipStreamSynchronize(c->stream) != hipSuccess) return ZS_STREAM_ERROR;
     return rc;
@@ -1440,13 +1465,25 @@ int zs_partition(const int64_t *sizes, int n, int n_parts, int *part_of) {
 namespace {
 template <class Fn>  // Fn(ctx, count, in, in_len, out, out_cap, out_len, status) -> code
 int run_multi(zs_ctx *const *ctxs, int n_ctx, int n, const void *const *in, const int64_t *in_len, void *const *out,
-              const int64_t *out_cap, int64_t *out_len, int *status, const int64_t *weights, Fn fn) {
+              const int64_t *out_cap, int64_t *out_len, int *status, const int64_t *weights, const int *part_of, Fn fn) {
     if (!ctxs || n_ctx <= 0 || n < 0) return ZS_STREAM_ERROR;
     for (int k = 0; k < n_ctx; k++)
         if (!ctxs[k]) return ZS_STREAM_ERROR;
+    // a context is one workspace and one pair of HIP streams: two host threads in it at once would corrupt both shares
+    for (int k = 0; k < n_ctx; k++)
+        for (int j = 0; j < k; j++)
+            if (ctxs[j] == ctxs[k]) {
+                ctxs[k]->err = "stream error: the same context passed twice";
+                return ZS_STREAM_ERROR;
+            }
     if (n == 0) return ZS_OK;
     std::vector<int> part((size_t)n);
-    if (zs_partition(weights, n, n_ctx, part.data()) != ZS_OK) return ZS_STREAM_ERROR;
+    if (part_of) {
+        for (int i = 0; i < n; i++) {
+            if (part_of[i] < 0 || part_of[i] >= n_ctx) return ZS_STREAM_ERROR;
+            part[(size_t)i] = part_of[i];
+        }
+    } else if (zs_partition(weights, n, n_ctx, part.data()) != ZS_OK) return ZS_STREAM_ERROR;
     std::vector<std::vector<int>> idx((size_t)n_ctx);
     for (int i = 0; i < n; i++) idx[(size_t)part[(size_t)i]].push_back(i);
     std::vector<int> rc((size_t)n_ctx, ZS_OK);
@@ -1479,16 +1516,26 @@ extern "C" {
 
 int zs_deflate_batch_multi(zs_ctx *const *ctxs, int n_ctx, int n, const void *const *in, const int64_t *in_len, void *const *out,
                            const int64_t *out_cap, int64_t *out_len, int *status, int level, int strategy, int hash_variant) {
-    return run_multi(ctxs, n_ctx, n, in, in_len, out, out_cap, out_len, status, in_len,
+    return run_multi(ctxs, n_ctx, n, in, in_len, out, out_cap, out_len, status, in_len, nullptr,
                      [=](zs_ctx *c, int m, const void *const *i, const int64_t *il, void *const *o, const int64_t *oc, int64_t *ol, int *st) {
                          return zs_deflate_batch(c, m, i, il, o, oc, ol, st, level, strategy, hash_variant);
+                     });
+}
+
+int zs_deflate_batch_multi_device(zs_ctx *const *ctxs, int n_ctx, int n, const void *const *in, const int64_t *in_len, void *const *out,
+                                  const int64_t *out_cap, int64_t *out_len, int *status, const int *part_of, int level, int strategy,
+                                  int hash_variant) {
+    if (!part_of) return ZS_STREAM_ERROR;
+    return run_multi(ctxs, n_ctx, n, in, in_len, out, out_cap, out_len, status, in_len, part_of,
+                     [=](zs_ctx *c, int m, const void *const *i, const int64_t *il, void *const *o, const int64_t *oc, int64_t *ol, int *st) {
+                         return zs_deflate_batch_device(c, m, i, il, o, oc, ol, st, level, strategy, hash_variant, nullptr);
                      });
 }
 
 int zs_inflate_batch_multi(zs_ctx *const *ctxs, int n_ctx, int n, const void *const *in, const int64_t *in_len, void *const *out,
                            const int64_t *out_cap, int64_t *out_len, int *status) {
     // balanced by output capacity: the decoded size is what an inflate costs
-    return run_multi(ctxs, n_ctx, n, in, in_len, out, out_cap, out_len, status, out_cap,
+    return run_multi(ctxs, n_ctx, n, in, in_len, out, out_cap, out_len, status, out_cap, nullptr,
                      [](zs_ctx *c, int m, const void *const *i, const int64_t *il, void *const *o, const int64_t *oc, int64_t *ol, int *st) {
                          return zs_inflate_batch(c, m, i, il, o, oc, ol, st);
                      });

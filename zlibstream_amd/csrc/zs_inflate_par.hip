@@ -31,6 +31,15 @@
 #include "zs_inflate.hip"
 
 namespace zs {
+// 16 bytes stored / loaded at 2-byte alignment (cells are 16-bit): the alignment is part of the type, so the compiler emits
+// global_store_dwordx4 without assuming what does not hold (gfx9 global memory takes unaligned accesses)
+struct __attribute__((packed, aligned(2))) uint4_a2 {
+    uint32_t x, y, z, w;
+};
+__device__ __forceinline__ void store_u4_a2(uint16_t *p, uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+    uint4_a2 v{a, b, c, d};
+    *(uint4_a2 *)p = v;
+}
 
 constexpr int kFindChunk = 4096;     // input bytes per finder workgroup
 constexpr int kFindMaxCand = 12;     // candidates kept per chunk
@@ -1119,7 +1128,7 @@ __global__ __launch_bounds__(64) void zs_inf_decode_lane_kernel(const ParStream 
             if (lb_n == 0) return;
             const int p0 = pos - lb_n;
             if (p0 + 8 <= E) {
-                *(uint4 *)(o16 + p0) = make_uint4((uint32_t)lb_lo, (uint32_t)(lb_lo >> 32), (uint32_t)lb_hi, (uint32_t)(lb_hi >> 32));
+                store_u4_a2(o16 + p0, (uint32_t)lb_lo, (uint32_t)(lb_lo >> 32), (uint32_t)lb_hi, (uint32_t)(lb_hi >> 32));
             } else {
                 for (int u = 0; u < lb_n; u++) o16[p0 + u] = (uint16_t)((u < 4 ? lb_lo >> (16 * u) : lb_hi >> (16 * (u - 4))) & 0xFFFFu);
             }
@@ -1231,8 +1240,8 @@ __global__ __launch_bounds__(64) void zs_inf_decode_lane_kernel(const ParStream 
                 // instructions, whatever their width or their active lanes.
                 if (pos + kDecCopy <= E) {
                     static_assert(kDecCopy == 8, "one 16-byte store per trip");
-                    *(uint4 *)(o16 + pos) = make_uint4((v[0] & 0xFFFFu) | (v[1] << 16), (v[2] & 0xFFFFu) | (v[3] << 16),
-                                                       (v[4] & 0xFFFFu) | (v[5] << 16), (v[6] & 0xFFFFu) | (v[7] << 16));
+                    store_u4_a2(o16 + pos, (v[0] & 0xFFFFu) | (v[1] << 16), (v[2] & 0xFFFFu) | (v[3] << 16),
+                                (v[4] & 0xFFFFu) | (v[5] << 16), (v[6] & 0xFFFFu) | (v[7] << 16));
                 } else {
 #pragma unroll
                     for (int u = 0; u < kDecCopy; u++)

@@ -1085,7 +1085,9 @@ __global__ __launch_bounds__(1024) void zs_resolve_kernel(const StreamDesc *sd, 
                                                          uint16_t *seg_entry, uint32_t *seg_symbase, uint8_t *stale,
                                                          uint8_t *seg_stale, const uint32_t *crc_tab_g, LevelCfg lv,
                                                          int strategy, int hash_variant, int seg_limit, int mm_limit,
-                                                         const uint2 *supmap, const uint16_t *chunk_far, int defer_mode) {
+                                                         const uint2 *supmap, const uint16_t *chunk_far, int defer_mode_in) {
+    const int defer_mode = defer_mode_in & 0xFF;
+    const bool dbg = (defer_mode_in & 0x100) != 0;  // ZS_DEBUG_CUTS: the cuts as they are applied
     // > 64 KiB of LDS: dynamic allocation, carved by hand
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint2 *rows = (uint2 *)smem;                                  // segment-map rows of the current batch (130 KiB)
@@ -1144,76 +1146,11 @@ __global__ __launch_bounds__(1024) void zs_resolve_kernel(const StreamDesc *sd, 
         if (threadIdx.x == 0) b_nrow = 0;  // the rows are gone: the next batch is staged afresh
         return rc;
     };
-    // ---- the common case first: a stream resolved in one launch whose path meets no equal-bucket refill.  The composed
-    //      rows of kSupSegs segments each (zs_supmap_kernel) are staged 64 at a time, thread 0 follows the path through them
-    //      -- 1/16 of the dependent lookups and of the bytes this one CU has to pull -- and one thread per row then fills in
-    //      its segments' entries and symbol bases from the segment maps.  Any flag on the path, and the kernel starts over the long way.
-    {
-        constexpr int kSupMax = (kSegBatch / kSegGroup) * kSlots * 8 / 8;  // entry slot + symbol base per row, in gmap's room
-        uint16_t *sup_slot = (uint16_t *)gmap;
-        uint32_t *sup_base = (uint32_t *)(sup_slot + kSupMax + (kSupMax & 1));
-        __shared__ int fp_ok;
-        __shared__ unsigned long long fp_kf;
-        const int nsup = (s.nsegs + kSupSegs - 1) / kSupSegs;
-        const bool try_fast = supmap != nullptr && ss.r_seg == 0 && ss.r_ncut == 0 && seg_limit >= s.nsegs && (int64_t)mm_limit >= (int64_t)s.body_end &&
-                              nsup <= kSupMax && s.nsegs > kSupSegs;
-        if (try_fast) {  // uniform over the workgroup
-            if (threadIdx.x == 0) fp_ok = 1, fp_kf = 0;
-            for (int b0 = 0; b0 < nsup; b0 += kSegBatch) {
-                int nrow = nsup - b0;
-                if (nrow > kSegBatch) nrow = kSegBatch;
-                __syncthreads();
-                const uint4 *src = (const uint4 *)(supmap + ((int64_t)s.sup_off + b0) * kSlots);
-                for (int i = threadIdx.x; i < nrow * kSlots / 2; i += blockDim.x) ((uint4 *)rows)[i] = src[i];
-                __syncthreads();
-                if (threadIdx.x == 0 && fp_ok) {
-                    int slot = sh_slot;
-                    uint32_t total = sh_total;
-                    if (b0 == 0) slot = ss.r_slot, total = ss.r_total;
-                    for (int i = 0; i < nrow; i++) {
-                        const uint2 e = rows[i * kSlots + slot];
-                        if (e.x & 0x8000u) {
-                            fp_ok = 0;
-                            break;
-                        }
-                        sup_slot[b0 + i] = (uint16_t)slot, sup_base[b0 + i] = total;
-                        slot = (int)(e.x & 0x1FF), total += e.y;
-                    }
-                    sh_slot = slot, sh_total = total;
-                }
-            }
-            __syncthreads();
-            if (fp_ok) {
-                for (int g = threadIdx.x; g < nsup; g += blockDim.x) {
-                    int cur = sup_slot[g];
-                    uint32_t total = sup_base[g];
-                    unsigned long long kf = 0;
-                    for (int r = 0; r < kSupSegs; r++) {
-                        const int seg = g * kSupSegs + r;
-                        if (seg >= s.nsegs) break;
-                        const uint2 v = segmap[((int64_t)s.seg_off + seg) * kSlots + cur];
-                        const uint32_t m = seg_row_meta(s, seg, seg_stale);
-                        if ((m & 1u) && (uint32_t)(cur <= 256 ? cur : 0) <= (m >> 2)) kf = ((unsigned long long)(seg + 1) << 16) | (unsigned)cur;
-                        seg_entry[s.seg_off + seg] = (uint16_t)cur;
-                        seg_symbase[s.seg_off + seg] = total;
-                        cur = (int)(v.x & 0x1FF);
-                        total += v.y;
-                    }
-                    if (kf) atomicMax(&fp_kf, kf);  // the last refill that fired
-                }
-                __syncthreads();
-                if (threadIdx.x == 0) {
-                    sh_seg = s.nsegs;
-                    if (fp_kf) sh_kfired = (int)(fp_kf >> 16) - 1, sh_kslot = (int)(fp_kf & 0xFFFF);
-                }
-                __syncthreads();
-            } else {
-                __syncthreads();
-                if (threadIdx.x == 0) sh_seg = ss.r_seg, sh_slot = ss.r_slot, sh_total = ss.r_total;
-                __syncthreads();
-            }
-        }
-    }
+    // (The composed rows of kSupSegs segments each -- zs_supmap_kernel -- carry the walk wherever nothing on the path needs
+    // attention: "fast stretches" inside the loop below.)
+    const bool can_sup = supmap != nullptr && seg_limit >= s.nsegs && (int64_t)mm_limit >= (int64_t)s.body_end && s.nsegs > kSupSegs;
+    __shared__ int fs_try, fs_n;
+    __shared__ unsigned long long fp_kf;
     // cuts of an earlier launch whose repair had to stop where the match records ended
     {
         const int nc = ss.r_ncut;
@@ -1260,6 +1197,7 @@ __global__ __launch_bounds__(1024) void zs_resolve_kernel(const StreamDesc *sd, 
             }
             __syncthreads();
             const int64_t e = sh_cut_e;
+            if (dbg && threadIdx.x == 0) printf("zs resolve: segment %d slot %d cut #%d at %ld (defer mode %d)\n", sh_seg, sh_slot, sh_cutidx, (long)e, defer_mode);
             if (e < 0 || sh_poison) break;
             if (threadIdx.x == 0) lk[e] = 0, sh_cutidx++;
             __threadfence_block();
@@ -1269,7 +1207,9 @@ __global__ __launch_bounds__(1024) void zs_resolve_kernel(const StreamDesc *sd, 
             const int64_t to = full < mm_end ? full : mm_end;
             if (defer_mode == 2) {
                 // a round: a cut with positions to walk again is left to zs_repair_kernel -- the kernel stops here
-                if (repair(e, e, to, true) == 1 && threadIdx.x == 0) ss.r_cut_e[0] = (int32_t)e, ss.r_cut_done[0] = (int32_t)e, ss.r_ncut = 1, sh_defer = 2;
+                const int rc = repair(e, e, to, true);
+                if (dbg && threadIdx.x == 0) printf("zs resolve:   scan of (%ld, %ld] says %d\n", (long)e, (long)to, rc);
+                if (rc == 1 && threadIdx.x == 0) ss.r_cut_e[0] = (int32_t)e, ss.r_cut_done[0] = (int32_t)e, ss.r_ncut = 1, sh_defer = 2;
             } else {
                 const int rc = repair(e, e, to, false);
                 if (threadIdx.x == 0 && to < full) {  // the rest once the records beyond exist
@@ -1296,11 +1236,75 @@ __global__ __launch_bounds__(1024) void zs_resolve_kernel(const StreamDesc *sd, 
 #define K4_PF(i)
 #endif
     for (;;) {
-        if (sh_seg >= nseg || sh_defer || sh_poison) break;  // the composed rows have done it all (or there is nothing to do), or the rest of a cluster's cuts stopped again
+        if (sh_seg >= nseg || sh_defer || sh_poison) break;  // done, or the rest of a cluster's cuts stopped again
 #ifdef ZS_FV_PROF
         kiter++;
         kt = wall_clock64();
 #endif
+        // ---- a fast stretch: at a multiple of kSupSegs segments the walk takes whole composed rows (zs_supmap_kernel: exit
+        //      slot, symbols and "something on the path from this slot needs attention" for kSupSegs segments at once) for as
+        //      long as neither the path nor a repair has touched them: 64 rows staged at a time, thread 0 follows the path
+        //      through them -- 1/16 of the dependent lookups and of the bytes this one CU has to pull -- and one thread per
+        //      row then fills in its segments' entries and symbol bases from the segment maps.  A flagged or stale row is
+        //      walked the long way below, and the stretches go on behind it. ----
+        if (can_sup && (sh_seg % kSupSegs) == 0 && !sh_scan) {
+            const int g0 = sh_seg / kSupSegs, nsup = (s.nsegs + kSupSegs - 1) / kSupSegs;
+            int nrow = nsup - g0;
+            if (nrow > kSegBatch) nrow = kSegBatch;
+            if (threadIdx.x == 0) fs_try = !(supmap[((int64_t)s.sup_off + g0) * kSlots + sh_slot].x & 0x8000u), fs_n = 0, fp_kf = 0;
+            __syncthreads();
+            if (fs_try) {  // uniform over the workgroup
+                const uint4 *src = (const uint4 *)(supmap + ((int64_t)s.sup_off + g0) * kSlots);
+                for (int i = threadIdx.x; i < nrow * kSlots / 2; i += blockDim.x) ((uint4 *)rows)[i] = src[i];
+                if ((int)threadIdx.x < nrow) {  // has a repair touched the row since it was composed?
+                    uint32_t st_any = 0;
+                    for (int r = 0; r < kSupSegs; r++) {
+                        const int seg = (g0 + (int)threadIdx.x) * kSupSegs + r;
+                        if (seg < s.nsegs) st_any |= seg_stale[s.seg_off + seg];
+                    }
+                    row_meta[threadIdx.x] = st_any;
+                }
+                __syncthreads();
+                if (threadIdx.x == 0) {
+                    int slot = sh_slot, i = 0;
+                    uint32_t total = sh_total;
+                    for (; i < nrow; i++) {
+                        const uint2 e = rows[i * kSlots + slot];
+                        if ((e.x & 0x8000u) || row_meta[i]) break;
+                        out_slot[i] = (uint16_t)slot, out_base[i] = total;
+                        slot = (int)(e.x & 0x1FF), total += e.y;
+                    }
+                    sh_slot = slot, sh_total = total, fs_n = i, b_nrow = 0;
+                }
+                __syncthreads();
+                if ((int)threadIdx.x < fs_n) {
+                    const int g = g0 + (int)threadIdx.x;
+                    int cur = out_slot[threadIdx.x];
+                    uint32_t total = out_base[threadIdx.x];
+                    unsigned long long kf = 0;
+                    for (int r = 0; r < kSupSegs; r++) {
+                        const int seg = g * kSupSegs + r;
+                        if (seg >= s.nsegs) break;
+                        const uint2 v = segmap[((int64_t)s.seg_off + seg) * kSlots + cur];
+                        const uint32_t m = seg_row_meta(s, seg, seg_stale);
+                        if ((m & 1u) && (uint32_t)(cur <= 256 ? cur : 0) <= (m >> 2)) kf = ((unsigned long long)(seg + 1) << 16) | (unsigned)cur;
+                        seg_entry[s.seg_off + seg] = (uint16_t)cur;
+                        seg_symbase[s.seg_off + seg] = total;
+                        cur = (int)(v.x & 0x1FF);
+                        total += v.y;
+                    }
+                    if (kf) atomicMax(&fp_kf, kf);  // the last segment whose events fired
+                }
+                __syncthreads();
+                if (threadIdx.x == 0 && fs_n > 0) {
+                    int seg = (g0 + fs_n) * kSupSegs;
+                    sh_seg = seg > s.nsegs ? s.nsegs : seg;
+                    if (fp_kf) sh_kfired = (int)(fp_kf >> 16) - 1, sh_kslot = (int)(fp_kf & 0xFFFF);
+                }
+                __syncthreads();
+                if (fs_n > 0) continue;
+            }
+        }
         // ---- stage the next kSegBatch segment-map rows (coalesced), then thread 0 follows the path through them
         //      (one LDS lookup per segment; its per-segment results go out coalesced afterwards); it stops early
         //      when a refill needs the whole workgroup ----
@@ -1310,7 +1314,9 @@ __global__ __launch_bounds__(1024) void zs_resolve_kernel(const StreamDesc *sd, 
         const bool resume = sh_scan && b_nrow > 0 && sh_seg >= b_seg0 && sh_seg < b_seg0 + b_nrow;
         const int seg0 = resume ? b_seg0 : sh_seg;
         int nrow = nseg - seg0;
-        if (nrow > kSegBatch) nrow = kSegBatch;
+        // (a batch ends on a multiple of kSupSegs segments, where a fast stretch can take over)
+        const int batch_max = resume ? b_nrow : kSegBatch - (can_sup ? seg0 % kSupSegs : 0);
+        if (nrow > batch_max) nrow = batch_max;
         if (!resume) {
             const uint4 *src = (const uint4 *)(segmap + ((int64_t)s.seg_off + seg0) * kSlots);  // kSlots is even: 16-byte aligned
             for (int i = threadIdx.x; i < nrow * kSlots / 2; i += blockDim.x) ((uint4 *)rows)[i] = src[i];
@@ -1370,11 +1376,27 @@ __global__ __launch_bounds__(1024) void zs_resolve_kernel(const StreamDesc *sd, 
                 const uint32_t m = row_meta[i];
                 if ((m & 1u) && (uint32_t)(slot <= 256 ? slot : 0) <= (m >> 2)) {
                     kf = seg, kslot = slot;
-                    if (v.x & kMapPoisonBit) {  // not a stream for the bulk path (zs_core.h kMapPoisonBit)
+                    // the flags of the path through the cluster: the row's, unless the segment has gone stale since the row was
+                    // made -- the events behind a cluster's first one are where the records of the positions before them put
+                    // them, and a repair may have changed those: then from what the first chunk holds now
+                    uint32_t vx = v.x;
+                    if (m & 2u) {
+                        const int c0s = seg_first(s, seg);
+                        if (stale[s.chunk_off + c0s]) {
+                            NullSink ns0;
+                            int ex0, cnt0;
+                            uint32_t fl0;
+                            walk_chunk(acc, ns0, chunk_ctx(s, c0s), slot, lv, strategy, ex0, cnt0, &fl0);
+                            vx = fl0;
+                        } else {
+                            vx = maps[((int64_t)s.chunk_off + c0s) * kSlots + slot];
+                        }
+                    }
+                    if (vx & kMapPoisonBit) {  // not a stream for the bulk path (zs_core.h kMapPoisonBit)
                         sh_poison = 1;
                         break;
                     }
-                    if ((v.x & kMapEqualBit) && cuts && !scanned) {
+                    if ((vx & kMapEqualBit) && cuts && !scanned) {
                         stop = true;
                         break;
                     }

@@ -716,8 +716,15 @@ ZS_HD_NOINLINE inline void le_restore(LitEngine &e, int64_t p, int64_t base, int
     if (!started) e.avail_end = 0;  // nothing read yet: the engine performs read 0 itself
     // the Write whose data the next Fill_window continues with
     e.cur_wr = 0;
-    if (e.wr_end)
-        while (e.cur_wr + 1 < e.n_wr && e.wr_end[e.cur_wr] < e.avail_end) e.cur_wr++;
+    if (e.wr_end) {  // the first Write whose end is not below avail_end (a stream of scanlines has thousands of Writes)
+        int lo = 0, hi = e.n_wr - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (e.wr_end[mid] < e.avail_end) lo = mid + 1;
+            else hi = mid;
+        }
+        e.cur_wr = lo;
+    }
     // preslid (le_tail_preslide): the image was filled at base - WSIZE and has slid since -- the lower half is what the upper
     // half was, the upper half is what it was (bytes behind the data included: zeros in a window that was never full)
     const int64_t ib = preslid ? e.base - kWSize : e.base;
