@@ -51,8 +51,9 @@ def lib():
     L.zs_deflate_batch_device.argtypes = batch_args + [vp]
     L.zs_deflate_batch.restype = i32
     L.zs_deflate_batch.argtypes = batch_args
-    L.zs_deflate_writes_device.restype = i32
-    L.zs_deflate_writes_device.argtypes = [vp, vp, i64, P(i64), i64, vp, i64, P(i64), i32, i32, i32, vp]
+    if hasattr(L, "zs_deflate_writes_device"):  # (an older build selected with ZS_LIB for an A/B run may lack it)
+        L.zs_deflate_writes_device.restype = i32
+        L.zs_deflate_writes_device.argtypes = [vp, vp, i64, P(i64), i64, vp, i64, P(i64), i32, i32, i32, vp]
     inf_args = [vp, i32, P(vp), P(i64), P(vp), P(i64), P(i64), P(i32)]
     L.zs_inflate_batch_device.restype = i32
     L.zs_inflate_batch_device.argtypes = inf_args + [vp]
@@ -88,8 +89,9 @@ def lib():
     L.zs_device_count.argtypes = []
     L.zs_partition.restype = i32
     L.zs_partition.argtypes = [P(i64), i32, i32, P(i32)]
-    L.zs_deflate_batch_multi_device.restype = i32
-    L.zs_deflate_batch_multi_device.argtypes = [P(vp), i32, i32, P(vp), P(i64), P(vp), P(i64), P(i64), P(i32), P(i32), i32, i32, i32]
+    if hasattr(L, "zs_deflate_batch_multi_device"):
+        L.zs_deflate_batch_multi_device.restype = i32
+        L.zs_deflate_batch_multi_device.argtypes = [P(vp), i32, i32, P(vp), P(i64), P(vp), P(i64), P(i64), P(i32), P(i32), i32, i32, i32]
     L.zs_deflate_batch_multi.restype = i32
     L.zs_deflate_batch_multi.argtypes = [P(vp), i32, i32, P(vp), P(i64), P(vp), P(i64), P(i64), P(i32), i32, i32, i32]
     L.zs_inflate_batch_multi.restype = i32

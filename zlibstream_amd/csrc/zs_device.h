@@ -78,6 +78,7 @@ struct StreamDesc {
     // this stream; the stream's inserted-position bitmap (bit q of the array = position q)
     int32_t fv_end;
     uint32_t *ins_bits;
+    int64_t fv_list_off;  // where the stream's candidate lists begin in the batch's list area (zs_fast_vec_kernel), in words
 };
 
 // zs_fast_vec_kernel's tile: the window [t0 - kFvBack, t0 + kFvTile + kFvFwd) in LDS as bytes, links and inserted bits
@@ -94,7 +95,10 @@ constexpr int kFvFwd = 272;     // >= kMaxMatch + 8, multiple of 16
 constexpr int kFvBytes = kFvBack + kFvTile + kFvFwd;
 constexpr int kFvLinks = kFvBack + kFvTile;
 constexpr int kFvBitWords = kFvLinks / 32 + 8;  // the tile may start 16 positions into a word, and short matches reach out of it
-constexpr int kFvLds = kFvBytes + 2 * kFvLinks + 4 * kFvBitWords;
+constexpr int kFvLds = kFvBytes + 2 * kFvLinks + 4 * kFvBitWords + 8192;  // + the first 16 list entries per lane of the window and of the 64 positions behind it
+// candidate-list entries per position (zs_fast_vec_kernel): enough for most searches of the level -- max_chain candidates
+// among the ~45 % of a chain that was inserted -- in multiples of 16; a longer search walks on through the staged links
+ZS_HD int fv_list_entries(int max_chain) { return max_chain <= 4 ? 16 : max_chain <= 8 ? 32 : 96; }
 // the last tile of a stream stages bitmap words for up to kFvTile + 256 positions past its loop-top, i.e. past the stream's end:
 // the bitmap array carries that much room behind the last stream
 constexpr size_t kFvBitSlack = (kFvTile + 512) / 8 + 64;

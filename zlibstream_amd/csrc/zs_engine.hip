@@ -51,7 +51,7 @@ struct zs_ctx {
     uint32_t *crc_tab = nullptr;
     DevBuf sd, st, work, wpre, geo, link, mm, maps, chunk_far, segmap, supmap, seg_entry, seg_symbase, seg_stale, entry, symbase, stale, syms, blk_end, blk_top, blocks, trees, info, pieces, scratch,
         stage_in, stage_out, wr, inf_desc, inf_state, par_ps, par_st, par_work, par_cbits, par_ccnt, par_surv, par_scnt, par_cands, par_tabs, par_blocks, par_cells,
-        par_windows, par_fail, run_syms, run_bits, run_scratch, run_outs, run_fail, adl_tr, adl_res, plan_blk, ins_bits, win_groups, win_sg, win_maps, win_entries;
+        par_windows, par_fail, run_syms, run_bits, run_scratch, run_outs, run_fail, adl_tr, adl_res, plan_blk, ins_bits, fv_lists, win_groups, win_sg, win_maps, win_entries;
     void *pinned = nullptr;
     size_t pinned_cap = 0;
 };
@@ -124,6 +124,7 @@ struct Plan {
     int64_t n_pos = 0, n_syms = 0;
     int64_t n_chunks = 0, n_segs = 0, n_sups = 0, n_blocks = 0, n_pieces = 0, n_runs = 0;
     bool any_fv = false;
+    int64_t n_fv_list = 0;  // words of candidate lists (zs_fast_vec_kernel): one tile's worth per stream
     // parse-segment tables (zs_core.h build_geometry), all streams: per segment (seg_off order); seg_cl and cstart hold one
     // entry more per stream (stream i's lists begin at seg_off + i / chunk_off + i); seg_cl's values index `cl`
     std::vector<int32_t> seg_c0, seg_after, seg_base, seg_S, seg_cl, cstart, head;
@@ -213,7 +214,12 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
         const bool fast_par = fast_one && !force_seq && len >= kFastMinInput;
         s.fv_end = (fast_one && !fast_par && !getenv("ZS_NO_FAST_VEC")) ? (int32_t)(len - kMinLookahead) : -1;
         s.ins_bits = nullptr;
-        if (s.fv_end >= 0) pl.any_fv = true;
+        s.fv_list_off = 0;
+        if (s.fv_end >= 0) {
+            pl.any_fv = true;
+            s.fv_list_off = pl.n_fv_list;
+            pl.n_fv_list += (int64_t)std::min<int64_t>(kFvTile, (len + 63) & ~63LL) * fv_list_entries(lv.chain);
+        }
         s.n_wr = (multi || flushing) ? (int32_t)writes->ends.size() : 1;  // 0: a run without input (Finish alone)
         s.wr_end = nullptr;
         s.wr_flush = nullptr, s.wr_blk = nullptr, s.out_chunk = writes ? writes->chunk : 512, s.raw = writes && writes->raw;
@@ -337,7 +343,7 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
     }
     if (pl.any_fv) {
         // one bit per position (pos_off is a multiple of 64: every stream's bitmap starts on a word)
-        if (!ensure(c, c->ins_bits, (size_t)pl.n_pos / 8 + kFvBitSlack)) return false;
+        if (!ensure(c, c->ins_bits, (size_t)pl.n_pos / 8 + kFvBitSlack) || !ensure(c, c->fv_lists, 4 * (size_t)pl.n_fv_list + 256)) return false;
         for (int i = 0; i < n; i++)
             if (pl.sd[(size_t)i].fv_end >= 0) pl.sd[(size_t)i].ins_bits = dev<uint32_t>(c->ins_bits) + pl.sd[(size_t)i].pos_off / 32;
     }
@@ -635,7 +641,8 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
     // on the second stream beside the symbol kernels
     if (pl.any_fv)
         hipLaunchKernelGGL(zs_fast_vec_kernel, dim3((unsigned)n), dim3(1024), kFvLds, stream, d_sd, d_st, dev<uint16_t>(c->link),
-                           dev<uint32_t>(c->syms), dev<int32_t>(c->blk_end), dev<int32_t>(c->blk_top), lv, strategy);
+                           dev<uint32_t>(c->syms), dev<int32_t>(c->blk_end), dev<int32_t>(c->blk_top), lv, strategy, dev<uint32_t>(c->fv_lists),
+                           fv_list_entries(lv.chain));
     const bool tail_late = ro && !ro->final_run;  // the engine is left for a later run: it needs K5's symbols and block ends
     // Beside the symbol kernel the tails of a few streams are free; those of hundreds are not: 256 tail workgroups of 1024
     // threads and 133 KiB of LDS each, one per CU, cost the symbol kernel of 256 x 1 MiB 3 ms (6.8 against 3.9), more than
@@ -932,7 +939,7 @@ void zs_ctx_destroy(zs_ctx *c) {
     DevBuf *bufs[] = {&c->sd, &c->st, &c->work, &c->wpre, &c->geo, &c->link, &c->mm, &c->maps, &c->chunk_far, &c->segmap, &c->supmap, &c->seg_entry, &c->seg_symbase, &c->seg_stale, &c->entry, &c->symbase, &c->stale, &c->syms,
                       &c->blk_end, &c->blk_top, &c->blocks, &c->trees, &c->info, &c->pieces, &c->scratch, &c->stage_in, &c->stage_out, &c->wr, &c->inf_desc, &c->inf_state, &c->par_ps, &c->par_st, &c->par_work, &c->par_cbits, &c->par_ccnt, &c->par_surv, &c->par_scnt,
                       &c->par_cands, &c->par_tabs, &c->par_blocks, &c->par_cells, &c->par_windows, &c->par_fail, &c->run_syms, &c->run_bits,
-                      &c->run_scratch, &c->run_outs, &c->run_fail, &c->adl_tr, &c->adl_res, &c->plan_blk, &c->ins_bits, &c->win_groups, &c->win_sg, &c->win_maps, &c->win_entries};
+                      &c->run_scratch, &c->run_outs, &c->run_fail, &c->adl_tr, &c->adl_res, &c->plan_blk, &c->ins_bits, &c->fv_lists, &c->win_groups, &c->win_sg, &c->win_maps, &c->win_entries};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     if (c->crc_tab) (void)hipFree(c->crc_tab);

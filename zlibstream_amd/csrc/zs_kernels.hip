@@ -2343,14 +2343,28 @@ struct FvLaneRes {  // the lanes' results, read by a wave-uniform lane index
         return FvResult{__builtin_amdgcn_readlane(len, k), __builtin_amdgcn_readlane(dist, k), __builtin_amdgcn_readlane(touched, k)};
     }
 };
+// Candidate lists.  The chain a search walks is K1's all-position chain with the positions that were never inserted left
+// out, so everything about a position's candidates but their membership is a function of the data: once a tile is staged,
+// all 16 waves write for every position of it the first `list_m` entries of its chain -- distance and common-prefix length
+// with the position, (len - 2) << 16 | distance, 0 behind the last -- into the stream's list area.  The parsing wave then
+// has no chain to walk and no bytes to compare: a lane loads its position's entries (contiguous), tests their bits of the
+// inserted set and combines them in order (Longest_match, Deflate.cs:1022-1100: count against max_chain, first strictly
+// longer, stop at nice_match).  An entry at or above the window's first loop-top has no membership yet: such a lane is
+// *conditional*, and when the hops of the parse reach it as a loop-top the whole wave evaluates that one position again,
+// one entry per lane, with the set as it stands then -- instead of ending the window there (51 of 64 positions on text).
+// A list that ends before the search does (chains longer than list_m) is followed by the walk through the staged links.
 __global__ __launch_bounds__(1024) void zs_fast_vec_kernel(const StreamDesc *sd, StreamState *st, uint16_t *link, uint32_t *syms,
-                                                           int32_t *blk_end, int32_t *blk_top, LevelCfg lv, int strategy) {
+                                                           int32_t *blk_end, int32_t *blk_top, LevelCfg lv, int strategy, uint32_t *lists_g,
+                                                           int list_m) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const StreamDesc s = sd[blockIdx.x];
     if (s.fv_end < 0) return;
     uint8_t *wb = smem;
     uint16_t *wl = (uint16_t *)(smem + kFvBytes);
     uint32_t *bm = (uint32_t *)(smem + kFvBytes + 2 * kFvLinks);
+    uint32_t *ent0 = bm + kFvBitWords;  // the window's first 16 entries per lane (16 x 64 words), for the conditional lanes
+    uint32_t *pre0 = ent0 + 1024;       // the same for the 64 positions behind the window, asked for a window ahead
+    uint32_t *lists = lists_g + s.fv_list_off;
     __shared__ int64_t sh_p, sh_nsyms, sh_trigger, sh_preins;
     __shared__ int sh_k;
     const int tid = threadIdx.x, lane = lane_id();
@@ -2364,7 +2378,7 @@ __global__ __launch_bounds__(1024) void zs_fast_vec_kernel(const StreamDesc *sd,
     __syncthreads();
     const bool aligned = (((uintptr_t)in) & 15) == 0;
 #ifdef ZS_FV_PROF
-    long long pf_stage = 0, pf_search = 0, pf_resolve = 0, pf_emit = 0, pf_windows = 0, pf_iters = 0, pf_t;
+    long long pf_stage = 0, pf_list = 0, pf_search = 0, pf_resolve = 0, pf_emit = 0, pf_windows = 0, pf_iters = 0, pf_conds = 0, pf_t;
 #define PF_T0() pf_t = wall_clock64()
 #define PF_ADD(x) { const long long now_ = wall_clock64(); x += now_ - pf_t; pf_t = now_; }
 #else
@@ -2411,11 +2425,58 @@ __global__ __launch_bounds__(1024) void zs_fast_vec_kernel(const StreamDesc *sd,
         for (int i = tid; i < kFvBitWords; i += 1024) bm[i] = bw0 + i >= 0 ? gbits[bw0 + i] : 0u;
         __syncthreads();
         PF_ADD(pf_stage);
+        // ---- the candidate lists of the tile's positions [t0, t0 + kFvTile): list i at lists[i * list_m ..]
+        {
+            const int min_i = (int)(1 - lo);  // position 0 is never a candidate
+            for (int i = tid; i < kFvTile; i += 1024) {
+                const int64_t q = t0 + i;
+                uint32_t *dst = lists + (size_t)i * (size_t)list_m;
+                if (q > body_end) continue;
+                const int qi = (int)(q - lo);
+                const uint64_t scan8 = lds_u64(wb, qi);
+                int c = qi, e = 0;
+                while (e < list_m) {
+                    const int l = wl[c];
+                    const int nc = c - l, d = qi - nc;
+                    if (l == 0 || nc < min_i || d > kMaxDist) break;
+                    c = nc;
+                    const uint64_t x = lds_u64(wb, c) ^ scan8;
+                    int len = x ? (int)(__builtin_ctzll(x) >> 3) : 8;
+                    if (!x) {
+                        while (len < kMaxMatch) {
+                            const uint64_t y = lds_u64(wb, qi + len) ^ lds_u64(wb, c + len);
+                            if (y) {
+                                len += (int)(__builtin_ctzll(y) >> 3);
+                                break;
+                            }
+                            len += 8;
+                        }
+                        len = len < kMaxMatch ? len : kMaxMatch;
+                    }
+                    dst[e++] = (uint32_t)d | ((uint32_t)(len >= kMinMatch ? len - 2 : 0) << 16);
+                }
+                if (e < list_m) dst[e] = 0;
+            }
+        }
+        __threadfence_block();
+        __syncthreads();
+        PF_ADD(pf_list);
         if (tid < 64) {
             FvLdsAcc acc{wb, wl, bm, lo, bw0};
             int64_t p0 = p_in, nsyms = sh_nsyms, trigger = sh_trigger, preins = sh_preins;
             int k_fired = sh_k;
             const bool search = strategy != kHuffmanOnly;
+            const uint32_t *bmr = bm - (lo >> 5) + bw0;  // bmr[(rel index) >> 5] with rel = position - lo: lo is a multiple of 32
+            const int nice = lv.nice, chain = lv.chain;
+            const int min_i = (int)(1 - lo);  // position 0 is never a candidate
+            // an equal-bucket event of this tile cuts the chain behind its loop-top (below); the lists were made before: an entry
+            // at the cut is the last one of its list that counts
+            int cut_i = -1;
+            // the first 16 entries of the positions [pf_base, pf_base + 64) wait in pre0: a lane's loads from the list area are a
+            // round trip to L2 (~2 us per window when every window paid it); the loads for the positions behind a window leave at
+            // its start and land in pre0 at its end, and the next window -- which starts there or a few positions on --
+            // takes its lists from LDS
+            int64_t pf_base = -(1ll << 40);
             while (p0 <= body_end && p0 + kFvLanes <= t0 + kFvTile) {
                 bool dead0 = false, dead1 = false, only1 = false;
                 if (trigger >= 0 && p0 >= trigger) {
@@ -2426,6 +2487,7 @@ __global__ __launch_bounds__(1024) void zs_fast_vec_kernel(const StreamDesc *sd,
                     if (wl[p0 + 1 - lo] == 1) {
                         dead0 = true, only1 = true;
                         if (lane == 0) wl[p0 - lo] = 0, lk[p0] = 0;  // the reference's prev[p0] = p0 + 1, prev[p0 + 1] = p0
+                        cut_i = (int)(p0 - lo);
                     } else {
                         dead1 = true;
                     }
@@ -2433,81 +2495,242 @@ __global__ __launch_bounds__(1024) void zs_fast_vec_kernel(const StreamDesc *sd,
                 }
                 int limit = kFvLanes;
                 if (body_end - p0 + 1 < limit) limit = (int)(body_end - p0 + 1);
-                FvResult r{2, 0, 0};
-                {
-                    // fv_search (zs_fast_vec.h) with LDS-relative indices, one LDS round trip per chain entry: the entry's
-                    // link, its bit of the inserted set and its first 8 bytes are requested together, whether or not the
-                    // entry turns out to be in the set (a lone wave pays every dependent round trip in full)
-                    const int qi = (int)(p0 - lo) + lane, p0i = (int)(p0 - lo), min_i = (int)(1 - lo);  // position 0 is never a candidate
-                    const bool dead = !search || lane >= limit || (lane == 0 && dead0) || (lane == 1 && dead1);
-                    const bool only_prev = lane == 1 && only1;
-                    const uint64_t scan8 = lds_u64(wb, qi);
-                    int c = qi, l = wl[qi], found = 0, best = 2, bdist = 0, touched = 0;
-                    int done = (dead || only_prev) ? 1 : 0;
-                    if (only_prev && lane < limit) {
-                        const int len = acc.lcp(p0 + lane, p0 + lane - 1);
-                        if (len > 2) best = len, bdist = 1;
+                const int qi = (int)(p0 - lo) + lane, p0i = (int)(p0 - lo);
+                const bool dead = !search || lane >= limit || (lane == 0 && dead0) || (lane == 1 && dead1);
+                const bool only_prev = lane == 1 && only1;
+                int found = 0, best = 2, bdist = 0, cond = 0;
+                int done = (dead || only_prev) ? 1 : 0;
+                if (only_prev && lane < limit) {
+                    const int len = acc.lcp(p0 + lane, p0 + lane - 1);
+                    if (len > 2) best = len, bdist = 1;
+                }
+                // ---- every lane combines its position's entries, 16 at a time
+                const uint32_t *mine = lists + (size_t)(p0 - t0 + lane) * (size_t)list_m;
+                int last_d = 0, listed = 0;  // where the list ended, for the walk that may have to go on
+
+                for (int k0 = 0; k0 < list_m; k0 += 16) {
+                    if (!__ballot(!done)) break;
+                    uint4 ev[4];
+                    const int64_t pidx = p0 + lane - pf_base;
+                    if (k0 == 0 && pidx >= 0 && pidx < 64) {
+#pragma unroll
+                        for (int u = 0; u < 4; u++) ev[u] = done ? make_uint4(0, 0, 0, 0) : *(const uint4 *)(pre0 + pidx * 16 + 4 * u);
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < 4; u++) ev[u] = done ? make_uint4(0, 0, 0, 0) : *(const uint4 *)(mine + k0 + 4 * u);
                     }
-                    const uint32_t *bmr = bm - (lo >> 5) + bw0;  // bmr[(rel index) >> 5] with rel = position - lo: lo is a multiple of 32
-                    const int nice = lv.nice, chain = lv.chain;
-                    // Written with selects: a lone wave is bound by the number of instructions it issues, and the branchy form
-                    // of this loop spent two thirds of them on execution masks (~100 per entry against ~40).
-                    while (__ballot(!done)) {
-#ifdef ZS_FV_PROF
-                        pf_iters++;
-#endif
-                        const int nc = c - l, d = qi - nc;
+                    const uint32_t *e16 = (const uint32_t *)ev;
+                    if (k0 == 0) {
+#pragma unroll
+                        for (int u = 0; u < 4; u++) *(uint4 *)(ent0 + lane * 16 + 4 * u) = ev[u];
+                    }
+                    uint32_t word[16];
+#pragma unroll
+                    for (int j = 0; j < 16; j++) {
+                        const int d = (int)(e16[j] & 0xFFFFu);
+                        const int nc = d ? qi - d : qi;
+                        word[j] = bmr[nc >> 5] >> (nc & 31);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 16; j++) {
+                        const int d = (int)(e16[j] & 0xFFFFu), lenc = (int)(e16[j] >> 16);
                         const int maxd = found ? kMaxDist - 1 : kMaxDist;  // hash_head: <= MAX_DIST; later: cur_match > limit
-                        const int valid = (done == 0) & (l != 0) & (nc >= min_i) & (d <= maxd);
-                        const int recent = valid & (nc >= p0i);
-                        touched |= recent;
+                        const int valid = (done == 0) & (d != 0) & (d <= maxd);
+                        const int recent = valid & (qi - d >= p0i);  // no membership yet: the lane is conditional
+                        cond |= recent;
                         const int go = valid & (recent ^ 1);
                         done |= go ^ 1;
-                        const int cc = go ? nc : qi;  // lanes that are done read their own position (in range)
-                        l = wl[cc];
-                        uint32_t word = bmr[cc >> 5];
-                        uint64_t c8 = lds_u64(wb, cc);
-                        // all three requests leave together: left alone, the compiler sinks the second and third below the tests
-                        // of the first one's result, and a lone wave then pays three LDS round trips per entry instead of one
-                        asm volatile("" : "+v"(l), "+v"(word), "+v"(c8));
-                        const uint64_t x = c8 ^ scan8;
-                        c = cc;
-                        const int isin = go & (int)((word >> (cc & 31)) & 1u);
-                        int len = x ? (int)(__builtin_ctzll(x) >> 3) : 8;
-                        if (__ballot(isin && !x)) {  // eight equal bytes: compare on (rare on text)
-                            if (isin && !x) {
-                                while (len < kMaxMatch) {
-                                    const uint64_t y = lds_u64(wb, qi + len) ^ lds_u64(wb, cc + len);
-                                    if (y) {
-                                        len += (int)(__builtin_ctzll(y) >> 3);
-                                        break;
-                                    }
-                                    len += 8;
-                                }
-                                len = len < kMaxMatch ? len : kMaxMatch;
-                            }
-                        }
+                        last_d = go ? d : last_d;
+                        listed += go;
+                        const int isin = go & (int)(word[j] & 1u);
+                        const int len = lenc ? lenc + 2 : 2;
                         found += isin;
                         const int better = isin & (len > best);
                         best = better ? len : best;
                         bdist = better ? d : bdist;
-                        done |= (better & (len >= nice)) | (isin & (found >= chain));
+                        done |= (better & (len >= nice)) | (isin & (found >= chain)) | (go & (qi - d == cut_i));
                     }
-                    r = FvResult{best, bdist, touched};
                 }
+                // ---- the loads for the 64 positions behind the window leave now (a wave's loads return in order: ahead of the
+                //      window's own they would be waited for with them) and are stored at the window's end
+                uint4 nx[4];
+                {
+                    const bool nx_ok = p0 + 64 + lane <= body_end && p0 + 128 <= t0 + kFvTile;
+                    const uint32_t *ahead = mine + (size_t)64 * (size_t)list_m;
+#pragma unroll
+                    for (int u = 0; u < 4; u++) nx[u] = nx_ok ? *(const uint4 *)(ahead + 4 * u) : make_uint4(0, 0, 0, 0);
+                }
+                // ---- a list that ended before the search did: on through the staged links (the walk the lists replaced)
+                {
+                    const int more = (done == 0) & (listed == list_m);
+                    done |= more ^ 1;
+                    if (__ballot(!done)) {
+                        const uint64_t scan8 = lds_u64(wb, qi);
+                        int c = more ? qi - last_d : qi, l = wl[c];
+                        while (__ballot(!done)) {
+#ifdef ZS_FV_PROF
+                            pf_iters++;
+#endif
+                            const int nc = c - l, d = qi - nc;
+                            const int maxd = found ? kMaxDist - 1 : kMaxDist;
+                            const int valid = (done == 0) & (l != 0) & (nc >= min_i) & (d <= maxd);
+                            const int recent = valid & (nc >= p0i);
+                            cond |= recent;
+                            const int go = valid & (recent ^ 1);
+                            done |= go ^ 1;
+                            const int cc = go ? nc : qi;  // lanes that are done read their own position (in range)
+                            l = wl[cc];
+                            uint32_t word = bmr[cc >> 5];
+                            uint64_t c8 = lds_u64(wb, cc);
+                            asm volatile("" : "+v"(l), "+v"(word), "+v"(c8));
+                            const uint64_t x = c8 ^ scan8;
+                            c = cc;
+                            const int isin = go & (int)((word >> (cc & 31)) & 1u);
+                            int len = x ? (int)(__builtin_ctzll(x) >> 3) : 8;
+                            if (__ballot(isin && !x)) {
+                                if (isin && !x) {
+                                    while (len < kMaxMatch) {
+                                        const uint64_t y = lds_u64(wb, qi + len) ^ lds_u64(wb, cc + len);
+                                        if (y) {
+                                            len += (int)(__builtin_ctzll(y) >> 3);
+                                            break;
+                                        }
+                                        len += 8;
+                                    }
+                                    len = len < kMaxMatch ? len : kMaxMatch;
+                                }
+                            }
+                            found += isin;
+                            const int better = isin & (len > best);
+                            best = better ? len : best;
+                            bdist = better ? d : bdist;
+                            done |= (better & (len >= nice)) | (isin & (found >= chain));
+                        }
+                    }
+                }
+                FvResult r{best, bdist, 0};
                 PF_ADD(pf_search);
-                // ---- fv_resolve (zs_fast_vec.h) for the wave: the hops of the parse through the lanes' results, followed on the
-                //      scalar unit (v_readlane of the hop length, ~17 loop-tops per window).  Lanes that end the window -- not
-                //      trusted, an event loop-top, beyond the limit -- stop it.  (Pointer doubling through an LDS flag array, six
-                //      rounds, took three times as long for a lone wave.)
-                const int adv = r.len >= kMinMatch ? r.len : 1;
-                const bool stopl = lane >= limit || (lane > 0 && (r.touched || (trigger >= 0 && p0 + lane >= trigger)));
-                const uint64_t stops = __ballot(stopl);
-                uint64_t tops = 0;
+                // ---- the hops of the parse through the lanes' results, followed on the scalar unit (v_readlane of the hop
+                //      length).  A conditional lane that turns out to be a loop-top is evaluated again first, by the whole wave,
+                //      one entry per lane, with the set as it stands: the loop-tops so far put their bits in, then the entries
+                //      are combined by ballots.  Lanes that end the window -- an event loop-top, beyond the limit -- stop it.
+                int adv = r.len >= kMinMatch ? r.len : 1;
+                const bool stopl = lane >= limit || (lane > 0 && trigger >= 0 && p0 + lane >= trigger);
+                const uint64_t stops = __ballot(stopl), conds = __ballot(cond != 0);
+                uint64_t tops = 0, flushed = 0;
                 int advance = 0;
+                auto flush_bits = [&](uint64_t which) {  // the loop-top, and the inside of its match when that is short (Deflate.Fast.cs:81-104)
+                    if ((which >> lane) & 1ull) {
+                        const int64_t pos = p0 + lane;
+                        const bool match = r.len >= kMinMatch;
+                        const uint64_t m = (match && r.len <= lv.lazy ? (1ull << r.len) - 1 : 1ull) << (pos & 31);
+                        atomicOr(&bm[(pos >> 5) - bw0], (uint32_t)m);
+                        if (m >> 32) atomicOr(&bm[(pos >> 5) - bw0 + 1], (uint32_t)(m >> 32));
+                    }
+                };
                 while (advance < 64 && !((stops >> advance) & 1ull)) {
+                    {
+                        // the plain hops in a loop of their own: bit test, mark, v_readlane, add
+                        const uint64_t special = stops | conds;
+                        while (advance < 64 && !((special >> advance) & 1ull)) {
+                            tops |= 1ull << advance;
+                            advance += __builtin_amdgcn_readlane(adv, advance);
+                        }
+                        if (advance >= 64 || ((stops >> advance) & 1ull)) break;
+                    }
+                    if ((conds >> advance) & 1ull) {
+#ifdef ZS_FV_PROF
+                        pf_conds++;
+#endif
+                        flush_bits(tops & ~flushed);
+                        flushed = tops;
+                        // position p0 + advance again, entry `lane` of each batch of 64 on lane `lane`
+                        const int qa = p0i + advance;
+                        int ufound = 0, ubest = 2, ubdist = 0, ustop = 0, ulast = 0, ulisted = 0;
+                        const uint32_t *its = lists + (size_t)(p0 - t0 + advance) * (size_t)list_m;
+                        for (int k0 = 0; k0 < list_m && !ustop; k0 += 64) {  // (uniform: every lane the same trip count)
+                            uint32_t e = 0;
+                            if (k0 + lane < list_m) e = (k0 == 0 && lane < 16) ? ent0[advance * 16 + lane] : its[k0 + lane];
+                            const int d = (int)(e & 0xFFFFu), lenc = (int)(e >> 16);
+                            const uint64_t term = __ballot(d == 0);  // the list's end (lanes past list_m read 0)
+                            int nent = term ? (int)__builtin_ctzll(term) : 64;
+                            const uint64_t atcut = __ballot(d != 0 && qa - d == cut_i);  // the chain is cut behind this entry
+                            bool cut_end = false;
+                            if (atcut && (int)__builtin_ctzll(atcut) < nent) nent = (int)__builtin_ctzll(atcut) + 1, cut_end = true;
+                            const int nc = d ? qa - d : qa;
+                            const uint32_t bit = (bmr[nc >> 5] >> (nc & 31)) & 1u;
+                            const uint64_t in_all = __ballot(lane < nent && bit);
+                            const int pre = ufound + (int)__builtin_popcountll(in_all & lanemask_lt());
+                            // an entry at MAX_DIST counts only as the first candidate found
+                            const bool isin = ((in_all >> lane) & 1ull) && (d < kMaxDist || pre == 0);
+                            const int len = lenc ? lenc + 2 : 2;
+                            const uint64_t in_m = __ballot(isin);
+                            // the search ends with the first candidate of nice length (it is longer than everything before it) or
+                            // with the max_chain-th candidate
+                            const uint64_t stoppers = __ballot(isin && (len >= nice || pre + 1 >= chain));
+                            const int cut = stoppers ? (int)__builtin_ctzll(stoppers) : 63;
+                            const uint64_t elig = in_m & (cut >= 63 ? ~0ull : ((2ull << cut) - 1ull));
+                            // the longest among them, the first of that length (a later one must be strictly longer to win)
+                            uint64_t cand = elig;
+                            int bl = 0;
+#pragma unroll
+                            for (int bbit = 8; bbit >= 0; bbit--) {
+                                const uint64_t mk = __ballot(((cand >> lane) & 1ull) && ((len >> bbit) & 1)) & cand;
+                                if (mk) cand = mk, bl |= 1 << bbit;
+                            }
+                            if (cand && bl > ubest) {
+                                const int w = (int)__builtin_ctzll(cand);
+                                ubest = bl, ubdist = __builtin_amdgcn_readlane(d, w);
+                            }
+                            ufound += (int)__builtin_popcountll(elig);
+                            ulisted += nent;
+                            if (nent > 0) ulast = __builtin_amdgcn_readlane(d, nent - 1);
+                            if (stoppers || cut_end) ustop = 1;
+                            if (nent < 64) break;  // the list's end (its terminator, or entry list_m)
+                        }
+                        if (!ustop && ulisted == list_m) {
+                            // the list ended before the search did: on through the staged links, every lane the same walk
+                            const uint64_t s8 = lds_u64(wb, qa);
+                            int c = qa - ulast;
+                            for (;;) {
+                                const int l = wl[c];
+                                const int nc = c - l, d = qa - nc;
+                                if (l == 0 || nc < min_i || d > (ufound ? kMaxDist - 1 : kMaxDist)) break;
+                                c = nc;
+                                if (!((bmr[c >> 5] >> (c & 31)) & 1u)) continue;
+                                ufound++;
+                                const uint64_t x = lds_u64(wb, c) ^ s8;
+                                int len = x ? (int)(__builtin_ctzll(x) >> 3) : 8;
+                                if (!x) {
+                                    while (len < kMaxMatch) {
+                                        const uint64_t y = lds_u64(wb, qa + len) ^ lds_u64(wb, c + len);
+                                        if (y) {
+                                            len += (int)(__builtin_ctzll(y) >> 3);
+                                            break;
+                                        }
+                                        len += 8;
+                                    }
+                                    len = len < kMaxMatch ? len : kMaxMatch;
+                                }
+                                if (len > ubest) {
+                                    ubest = len, ubdist = d;
+                                    if (len >= nice) break;
+                                }
+                                if (ufound >= chain) break;
+                            }
+                        }
+                        if (lane == advance) r.len = ubest, r.dist = ubdist, adv = ubest >= kMinMatch ? ubest : 1;
+                    }
                     tops |= 1ull << advance;
                     advance += __builtin_amdgcn_readlane(adv, advance);
+                }
+                flush_bits(tops & ~flushed);
+                {
+                    // (the chunk loop above has read pre0 for this window; nothing reads it again before the next window)
+                    const bool have = p0 + 128 <= t0 + kFvTile;
+#pragma unroll
+                    for (int u = 0; u < 4; u++) *(uint4 *)(pre0 + lane * 16 + 4 * u) = nx[u];
+                    pf_base = have ? p0 + 64 : -(1ll << 40);
                 }
                 PF_ADD(pf_resolve);
                 // ---- the loop-tops' symbols, compacted; block cuts every kBlockSyms symbols (Deflate.cs:910-948)
@@ -2519,11 +2742,6 @@ __global__ __launch_bounds__(1024) void zs_fast_vec_kernel(const StreamDesc *sd,
                         blk_end[s.blk_off + g / kBlockSyms] = (int32_t)(p0 + lane + (match ? r.len : 1));
                         blk_top[s.blk_off + g / kBlockSyms] = (int32_t)(p0 + lane);
                     }
-                    // ---- inserted: the loop-top, and the inside of its match when that is short (Deflate.Fast.cs:81-104)
-                    const int64_t pos = p0 + lane;
-                    const uint64_t m = (match && r.len <= lv.lazy ? (1ull << r.len) - 1 : 1ull) << (pos & 31);
-                    atomicOr(&bm[(pos >> 5) - bw0], (uint32_t)m);
-                    if (m >> 32) atomicOr(&bm[(pos >> 5) - bw0 + 1], (uint32_t)(m >> 32));
                 }
                 nsyms += __builtin_popcountll(tops);
                 p0 += advance;
@@ -2542,8 +2760,8 @@ __global__ __launch_bounds__(1024) void zs_fast_vec_kernel(const StreamDesc *sd,
     }
 #ifdef ZS_FV_PROF
     if (tid == 0 && blockIdx.x == 0)
-        printf("FVPROF n=%lld windows=%lld iters=%lld ticks(100MHz): stage=%lld search=%lld resolve=%lld emit=%lld\n", (long long)n, pf_windows,
-               pf_iters, pf_stage, pf_search, pf_resolve, pf_emit);
+        printf("FVPROF n=%lld windows=%lld walk iterations=%lld conditional loop-tops=%lld ticks(100MHz): stage=%lld lists=%lld search=%lld resolve=%lld emit=%lld\n", (long long)n, pf_windows,
+               pf_iters, pf_conds, pf_stage, pf_list, pf_search, pf_resolve, pf_emit);
 #endif
     if (tid == 0) {
         StreamState &ss = st[blockIdx.x];
