@@ -53,6 +53,7 @@ struct StreamDesc {
     const uint32_t *cl;
     const int32_t *cstart;
     const int32_t *head;
+    int32_t grid_chunks;     // the chunks are on the single Write's grid (chunk c >= 1 begins at 2048 c - 261): chunk_of in closed form
     int32_t n_wr;            // > 1: several Writes -> the whole stream runs on the literal engine
     const int64_t *wr_end;   // device array of n_wr cumulative Write ends (or nullptr)
     // FlushMode Partial / Sync / Full (nullptr: every Write is NoFlush): the mode of each Write, the number of blocks
@@ -78,6 +79,9 @@ struct StreamDesc {
     // this stream; the stream's inserted-position bitmap (bit q of the array = position q)
     int32_t fv_end;
     uint32_t *ins_bits;
+    // the cuts of equal-bucket events collected by the resolve kernel's dry passes (batched cut rounds): where the stream's
+    // entries begin in the two cut lists, and how many there is room for (one per read boundary)
+    int32_t cut_off, cut_cap;
     int64_t fv_list_off;  // where the stream's candidate lists begin in the batch's list area (zs_fast_vec_kernel), in words
 };
 
@@ -145,11 +149,18 @@ struct StreamState {
     // r_scan: the walk resumes behind an applied cut)
     int32_t deferred, r_scan;
     int32_t r_cutidx;  // equal-bucket events of the current segment's cluster that have been cut already
+    // batched cut rounds (zs_engine.hip): a stream with more cuts than one CU should repair one after the other is given up
+    // (deferred = 1) where it stands; dry passes of the resolve kernel then collect the cuts of the rest of the stream from
+    // the records as they are (nc[pass & 1] of them), the chip repairs them all at once, and the passes go on until one finds
+    // the cuts of the pass before (cuts_same).  cut_diff_idx / cut_diff_pos: the first cut that differs between the last two
+    // passes and the position from which the records are restored and repaired again.
+    int32_t nc[2], cuts_same, cut_diff_idx, cut_diff_pos;
     // the true path met a read whose pre-insert hashes bytes behind the data (zs_core.h kMapPoisonBit): the host runs the
     // stream on the literal engine
     int32_t poison;
 };
 constexpr int kDeferBudget = 8;   // cuts with positions to walk again that a stream may repair on its one CU before it is given up
+constexpr int kCutBudget = 32;    // ... and cuts of any kind (a cut without such positions is a scan of 32 Ki records on one CU)
 
 // DeflateFast (levels 1-3) as speculative chunk runs: run j re-parses kFastWarm bytes before its chunk with an
 // "everything inserted" history, then its chunk; it is exact iff its state at the first loop-top of the chunk

@@ -43,7 +43,8 @@ struct zs_ctx {
     std::string err;
     bool profiling = false;
     int fast_fallbacks = 0;  // speculative DeflateFast batches that had to be redone sequentially
-    int round_runs = 0;      // batches run again in rounds (a stream whose cuts were not one CU's job)
+    int round_runs = 0;      // batches with streams in the batched cut rounds (their cuts were not one CU's job)
+    int cut_rounds = 0;      // rounds of those
     int lit_fallbacks = 0;   // batches run again with a stream on the literal engine (zs_core.h kMapPoisonBit)
     int last_op = 0;  // 0: deflate stages, 1: block-parallel inflate stages (for zs_ctx_stage_name)
     hipEvent_t ev[kStCount + 1] = {};
@@ -51,7 +52,7 @@ struct zs_ctx {
     uint32_t *crc_tab = nullptr;
     DevBuf sd, st, work, wpre, geo, link, mm, maps, chunk_far, segmap, supmap, seg_entry, seg_symbase, seg_stale, entry, symbase, stale, syms, blk_end, blk_top, blocks, trees, info, pieces, scratch,
         stage_in, stage_out, wr, inf_desc, inf_state, par_ps, par_st, par_work, par_cbits, par_ccnt, par_surv, par_scnt, par_cands, par_tabs, par_blocks, par_cells,
-        par_windows, par_fail, run_syms, run_bits, run_scratch, run_outs, run_fail, adl_tr, adl_res, plan_blk, ins_bits, fv_lists, win_groups, win_sg, win_maps, win_entries;
+        par_windows, par_fail, run_syms, run_bits, run_scratch, run_outs, run_fail, adl_tr, adl_res, plan_blk, ins_bits, fv_lists, mm_bak, cut_pos, cut_bkt, win_groups, win_sg, win_maps, win_entries;
     void *pinned = nullptr;
     size_t pinned_cap = 0;
 };
@@ -125,6 +126,7 @@ struct Plan {
     int64_t n_chunks = 0, n_segs = 0, n_sups = 0, n_blocks = 0, n_pieces = 0, n_runs = 0;
     bool any_fv = false;
     int64_t n_fv_list = 0;  // words of candidate lists (zs_fast_vec_kernel): one tile's worth per stream
+    int64_t n_cuts = 0;     // entries of a cut list (batched cut rounds): one per read boundary
     // parse-segment tables (zs_core.h build_geometry), all streams: per segment (seg_off order); seg_cl and cstart hold one
     // entry more per stream (stream i's lists begin at seg_off + i / chunk_off + i); seg_cl's values index `cl`
     std::vector<int32_t> seg_c0, seg_after, seg_base, seg_S, seg_cl, cstart, head;
@@ -233,7 +235,14 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
         pl.n_chunks += s.nchunks;
         s.seg_off = (int32_t)pl.n_segs;
         s.nsegs = 0;
+        s.cut_off = (int32_t)pl.n_cuts, s.cut_cap = 0;
+        s.grid_chunks = 0;
         if (s.body_end >= 0) {
+            s.grid_chunks = 1;
+            for (size_t k = 1; k + 1 < geo.cstart.size() && s.grid_chunks; k++)
+                if (geo.cstart[k] != (int32_t)((int64_t)k * kChunk - (kMinLookahead - 1))) s.grid_chunks = 0;
+            s.cut_cap = (int32_t)(geo.cl.size() + (size_t)geo.nsegs() + 8);
+            pl.n_cuts += s.cut_cap;
             s.nsegs = geo.nsegs();
             const int32_t cl0 = (int32_t)pl.cl.size();
             pl.seg_c0.insert(pl.seg_c0.end(), geo.seg_c0.begin(), geo.seg_c0.end());
@@ -322,7 +331,8 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
         !ensure(c, c->syms, 4 * (size_t)pl.n_syms + 64) || !ensure(c, c->blk_end, 4 * (size_t)pl.n_blocks + 64) ||
         !ensure(c, c->blk_top, 4 * (size_t)pl.n_blocks + 64) || !ensure(c, c->blocks, sizeof(BlockRec) * (size_t)pl.n_blocks) ||
         !ensure(c, c->trees, sizeof(TreeWork) * (size_t)pl.n_blocks) || !ensure(c, c->info, sizeof(BlockInfo) * (size_t)pl.n_blocks) ||
-        !ensure(c, c->pieces, 4 * (size_t)pl.n_pieces + 64) || !ensure(c, c->scratch, (size_t)kScratchBytes * (size_t)n))
+        !ensure(c, c->pieces, 4 * (size_t)pl.n_pieces + 64) || !ensure(c, c->scratch, (size_t)kScratchBytes * (size_t)n) ||
+        !ensure(c, c->cut_pos, 8 * (size_t)pl.n_cuts + 64) || !ensure(c, c->cut_bkt, 8 * (size_t)pl.n_cuts + 64))
         return false;
     // parse-segment tables: [seg_c0 | seg_after | seg_base | seg_S : int32 x n_segs each][seg_cl : int32 x (n_segs + n)]
     // [cstart : int32 x (n_chunks + n)][head : int32 x n_chunks][cl : u32 x n_cl]
@@ -357,7 +367,9 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
          !ensure(c, c->run_scratch, (size_t)pl.n_runs * kFastRunScratch) || !ensure(c, c->run_outs, sizeof(FastRunOut) * (size_t)pl.n_runs) ||
          !ensure(c, c->run_fail, 4 * (size_t)n + 64)))
         return false;
-    if (writes && (writes->ends.size() > 1 || writes->flushing() || ro)) {
+    // rounds: the call goes on behind the batched cut rounds of the call that made it -- same plan, same workspace; nothing
+    // is uploaded or zeroed again and the kernels up to the resolve kernel are not run
+    if (!rounds && writes && (writes->ends.size() > 1 || writes->flushing() || ro)) {
         // [ends: int64 x nw][blocks before each Write: int32 x nw][flush modes: u8 x nw]
         const size_t nw = writes->ends.size();
         if (!ensure(c, c->wr, 13 * nw + 64)) return false;
@@ -373,7 +385,7 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
             ZS_HIP(c, hipMemcpyAsync((uint8_t *)c->wr.p + 8 * nw, pl.plan_wr_blk.data(), 4 * nw, hipMemcpyHostToDevice, stream));
         ZS_HIP(c, hipStreamSynchronize(stream));  // `writes` is caller-owned pageable memory
     }
-    if (!pl.plan_blk.empty()) {
+    if (!rounds && !pl.plan_blk.empty()) {
         ZS_HIP(c, hipMemcpyAsync(c->plan_blk.p, pl.plan_blk.data(), sizeof(BlockRec) * pl.plan_blk.size(), hipMemcpyHostToDevice, stream));
         ZS_HIP(c, hipStreamSynchronize(stream));  // pageable source
     }
@@ -409,15 +421,15 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
         memcpy(hg + o_cstart, pl.cstart.data(), 4 * pl.cstart.size());
         if (pl.n_chunks) memcpy(hg + o_head, pl.head.data(), 4 * (size_t)pl.n_chunks);
         if (!pl.cl.empty()) memcpy(hg + o_cl, pl.cl.data(), 4 * pl.cl.size());
-        ZS_HIP(c, hipMemcpyAsync(c->geo.p, hg, geo_bytes, hipMemcpyHostToDevice, stream));
+        if (!rounds) ZS_HIP(c, hipMemcpyAsync(c->geo.p, hg, geo_bytes, hipMemcpyHostToDevice, stream));
     }
-    ZS_HIP(c, hipMemcpyAsync(c->sd.p, hp, sizeof(StreamDesc) * (size_t)n, hipMemcpyHostToDevice, stream));
-    if (n_work) {
+    if (!rounds) ZS_HIP(c, hipMemcpyAsync(c->sd.p, hp, sizeof(StreamDesc) * (size_t)n, hipMemcpyHostToDevice, stream));
+    if (n_work && !rounds) {
         ZS_HIP(c, hipMemcpyAsync(c->wpre.p, hpre, pre_bytes, hipMemcpyHostToDevice, stream));
         hipLaunchKernelGGL(zs_worklist_kernel, dim3((unsigned)((n_work + 255) / 256)), dim3(256), 0, stream, dev<int32_t>(c->wpre), n, wo,
                            dev<uint2>(c->work));
     }
-    {
+    if (!rounds) {
         // the per-run flags and state in one launch (the link array is not cleared: K1 writes every entry that is read)
         ZeroRegions z;
         auto reg = [&](int r, DevBuf &b, size_t bytes) {
@@ -458,6 +470,88 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
             hipLaunchKernelGGL(zs_adler_kernel, dim3((unsigned)pl.w_adler.size()), dim3(256), 0, c->aux, d_sd, d_work + o_adler,
                                dev<uint32_t>(c->pieces));
         ZS_HIP(c, hipEventRecord(c->ev_pre, c->aux));
+        return true;
+    };
+    // (ZS_NO_DEFER: every cut on the stream's own CU; ZS_FORCE_ROUNDS: the rounds from the first cut on -- for the tests)
+    const int cut_budget = getenv("ZS_FORCE_ROUNDS") ? 0 : kCutBudget;
+    const int defer_mode = ((ro || getenv("ZS_NO_DEFER")) ? 0 : 1) | (getenv("ZS_DEBUG_CUTS") ? 0x100 : 0) | (cut_budget << 16);
+    const int cut_stride = (int)pl.n_cuts;
+    const bool use_sup = !pl.w_sups.empty() && !getenv("ZS_NO_SUPMAP");
+    auto launch_resolve = [&](int mode, int iter) {
+        hipLaunchKernelGGL(zs_resolve_kernel, dim3((unsigned)n), dim3(1024), kResolveLds, stream, d_sd, d_st, dev<uint16_t>(c->link),
+                           dev<uint2>(c->mm), dev<uint32_t>(c->maps), dev<uint2>(c->segmap),
+                           dev<uint16_t>(c->seg_entry), dev<uint32_t>(c->seg_symbase), dev<uint8_t>(c->stale),
+                           dev<uint8_t>(c->seg_stale), c->crc_tab, lv, strategy, hash_variant, 0x7FFFFFFF, 0x7FFFFFFF,
+                           use_sup ? dev<uint2>(c->supmap) : (const uint2 *)nullptr, dev<uint16_t>(c->chunk_far), mode, dev<int32_t>(c->cut_pos),
+                           dev<uint32_t>(c->cut_bkt), cut_stride, iter);
+    };
+    // Batched cut rounds, for the streams the resolve kernel has given up (StreamState::deferred = 1: data whose read events
+    // are equal-bucket ones by the dozen -- zeros, runs, zero pages -- or with thousands of positions to walk again behind
+    // each).  Where a cut falls depends on the parse up to it, and the parse on the repairs of the cuts before: one CU doing
+    // cut, repair, cut, repair is what made such streams 30-170 times slower than text.  Instead: a dry pass of the resolve
+    // kernel walks the rest of the stream on the records as they are and collects every cut on its way; the records from the
+    // first cut that differs from the pass before are put back as they were (a copy made when the rounds began) and all
+    // the cuts of the pass are repaired at once over the chip; the maps of the chunks that changed are made again; and so
+    // on until a pass finds the cuts of the pass before -- then the records it walked are the ones those cuts leave, which
+    // is what the one-after-the-other order gives (the first cut never depends on a repair, the second only on the
+    // first's, ...: a pass fixes at least one more cut, in practice nearly all of them).
+    auto run_cut_rounds = [&]() -> bool {
+        if (!ensure(c, c->mm_bak, 8 * (size_t)pl.n_pos + 256)) return false;
+        ZS_HIP(c, hipMemcpyAsync(c->mm_bak.p, c->mm.p, 8 * (size_t)pl.n_pos + 256, hipMemcpyDeviceToDevice, stream));
+        StreamState *hr = (StreamState *)c->pinned;
+        for (int iter = 0;; iter++) {
+            launch_resolve(3 | (defer_mode & 0x100), iter);
+            ZS_HIP(c, hipMemcpyAsync(hr, d_st, sizeof(StreamState) * (size_t)n, hipMemcpyDeviceToHost, stream));
+            ZS_HIP(c, hipStreamSynchronize(stream));
+            bool all_same = true;
+            int max_nc = 0;
+            for (int i = 0; i < n; i++)
+                if (hr[i].deferred == 1 && !hr[i].cuts_same) all_same = false, max_nc = std::max(max_nc, hr[i].nc[iter & 1]);
+            hipLaunchKernelGGL(zs_cuts_apply_kernel, dim3((unsigned)n), dim3(256), 0, stream, d_sd, d_st, dev<uint16_t>(c->link), dev<int32_t>(c->cut_pos),
+                               cut_stride, iter);  // (the streams that are through leave the rounds)
+            if (getenv("ZS_DEBUG")) {
+                int nd = 0, nsame = 0;
+                for (int i = 0; i < n; i++) nd += hr[i].deferred == 1, nsame += hr[i].deferred == 1 && hr[i].cuts_same;
+                fprintf(stderr, "zs: cut round %d: %d streams in the rounds, %d settled, most cuts %d, stream 0: %d cuts, first difference at cut %d (position %d)\n", iter,
+                        nd, nsame, max_nc, hr[0].nc[iter & 1], hr[0].cut_diff_idx, hr[0].cut_diff_pos);
+            }
+            if (all_same) break;
+            if (iter >= 4096) {
+                c->err = "the cut rounds did not settle";
+                return false;
+            }
+            c->cut_rounds++;
+            if (iter > 0)  // (before the first round's repairs the records are the copy)
+            hipLaunchKernelGGL(zs_cut_restore_kernel, dim3(2048, (unsigned)n), dim3(256), 0, stream, d_sd, d_st, dev<uint2>(c->mm), (const uint2 *)c->mm_bak.p,
+                               dev<uint8_t>(c->stale), dev<uint8_t>(c->seg_stale));
+            if (max_nc > 0) {
+                // few cuts: 128 workgroups each (every 128th position behind the cut); many: fewer, larger ones
+                if (max_nc <= 64)
+                    hipLaunchKernelGGL((zs_cuts_repair_kernel<256, 1>), dim3(128, (unsigned)max_nc, (unsigned)n), dim3(256), kRepairLds, stream, d_sd, d_st,
+                                       dev<uint16_t>(c->link), dev<uint2>(c->mm), dev<uint8_t>(c->stale), dev<uint8_t>(c->seg_stale),
+                                       dev<uint16_t>(c->chunk_far), c->crc_tab, lv, hash_variant, dev<int32_t>(c->cut_pos), dev<uint32_t>(c->cut_bkt),
+                                       cut_stride, iter);
+                else if (max_nc <= 2048)
+                    hipLaunchKernelGGL((zs_cuts_repair_kernel<256, 8>), dim3(16, (unsigned)max_nc, (unsigned)n), dim3(256), kRepairLds, stream, d_sd, d_st,
+                                       dev<uint16_t>(c->link), dev<uint2>(c->mm), dev<uint8_t>(c->stale), dev<uint8_t>(c->seg_stale),
+                                       dev<uint16_t>(c->chunk_far), c->crc_tab, lv, hash_variant, dev<int32_t>(c->cut_pos), dev<uint32_t>(c->cut_bkt),
+                                       cut_stride, iter);
+                else
+                    hipLaunchKernelGGL((zs_cuts_repair_kernel<1024, 32>), dim3(1, (unsigned)std::min(max_nc, 65535), (unsigned)n), dim3(1024), kRepairLds, stream, d_sd,
+                                       d_st, dev<uint16_t>(c->link), dev<uint2>(c->mm), dev<uint8_t>(c->stale), dev<uint8_t>(c->seg_stale),
+                                       dev<uint16_t>(c->chunk_far), c->crc_tab, lv, hash_variant, dev<int32_t>(c->cut_pos), dev<uint32_t>(c->cut_bkt),
+                                       cut_stride, iter);
+            }
+            hipLaunchKernelGGL(zs_chunkmap_kernel, dim3((unsigned)pl.w_chunks.size()), dim3(512), 0, stream, d_sd, d_work + o_chunks,
+                               dev<uint2>(c->mm), dev<uint16_t>(c->link), dev<uint32_t>(c->maps), c->crc_tab, lv, strategy,
+                               hash_variant, dev<uint16_t>(c->chunk_far), dev<uint8_t>(c->stale), (const StreamState *)d_st);
+            hipLaunchKernelGGL(zs_segmap_kernel, dim3((unsigned)pl.w_segs.size()), dim3(320), 0, stream, d_sd, d_work + o_segs,
+                               dev<uint32_t>(c->maps), dev<uint2>(c->segmap));
+            ZS_HIP(c, hipMemsetAsync(c->seg_stale.p, 0, (size_t)pl.n_segs + 64, stream));
+            if (use_sup)
+                hipLaunchKernelGGL(zs_supmap_kernel, dim3((unsigned)pl.w_sups.size()), dim3(320), 0, stream, d_sd, d_work + o_sups,
+                                   dev<uint2>(c->segmap), dev<uint8_t>(c->seg_stale), dev<uint2>(c->supmap));
+        }
         return true;
     };
     // One long stream: the position-parallel kernels (links, matches, chunk maps) fill the chip, the kernels that follow
@@ -545,7 +639,7 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
                                    dev<uint2>(c->mm), dev<uint32_t>(c->maps), dev<uint2>(c->segmap), dev<uint16_t>(c->seg_entry),
                                    dev<uint32_t>(c->seg_symbase), dev<uint8_t>(c->stale), dev<uint8_t>(c->seg_stale), c->crc_tab, lv,
                                    strategy, hash_variant, sb, (int)(mm_limit > 0x7FFFFFFF ? 0x7FFFFFFF : mm_limit), (const uint2 *)nullptr,
-                                   dev<uint16_t>(c->chunk_far), 0);
+                                   dev<uint16_t>(c->chunk_far), 0, (int32_t *)nullptr, (uint32_t *)nullptr, 0, 0);
             });
             if (k == n_parts - 1) {
                 // the tail engine needs what the last resolve launch left: it runs on the first stream beside the last part's symbols
@@ -575,6 +669,7 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
         hipLaunchKernelGGL(zs_body_blocks_kernel, dim3((unsigned)n), dim3(256), 0, stream, d_sd, d_st, dev<int32_t>(c->blk_end),
                            dev<int32_t>(c->blk_top), dev<BlockRec>(c->blocks));
     } else {
+    if (!rounds) {
     mark(2);
     if (!pl.w_links.empty())
         hipLaunchKernelGGL(zs_links_kernel, dim3((unsigned)pl.w_links.size()), dim3(1024), kLkLds, stream, d_sd, d_work + o_links,
@@ -597,7 +692,6 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
         hipLaunchKernelGGL(zs_segmap_kernel, dim3((unsigned)pl.w_segs.size()), dim3(320), 0, stream, d_sd, d_work + o_segs,
                            dev<uint32_t>(c->maps), dev<uint2>(c->segmap));
     // the segment maps composed 16 at a time, for the resolve kernel's short way through a long stream (ZS_NO_SUPMAP: without)
-    const bool use_sup = !pl.w_sups.empty() && !getenv("ZS_NO_SUPMAP");
     if (use_sup)
         hipLaunchKernelGGL(zs_supmap_kernel, dim3((unsigned)pl.w_sups.size()), dim3(320), 0, stream, d_sd, d_work + o_sups,
                            dev<uint2>(c->segmap), dev<uint8_t>(c->seg_stale), dev<uint2>(c->supmap));
@@ -610,31 +704,7 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
     // synchronisation, which is what a cut's repair takes on one CU at level 6.  64 MiB of short runs: level 9 7.3 s -> 2.0 s,
     // level 6 175 ms inline against 237 in rounds.)
     // (ZS_DEFER_ALL: at every level, for the tests)
-    const int defer_mode = (ro || getenv("ZS_NO_DEFER") ? 0 : rounds ? 2 : (lv.chain > 256 || getenv("ZS_DEFER_ALL")) ? 1 : 0) | (getenv("ZS_DEBUG_CUTS") ? 0x100 : 0);
-    auto launch_resolve = [&]() {
-        hipLaunchKernelGGL(zs_resolve_kernel, dim3((unsigned)n), dim3(1024), kResolveLds, stream, d_sd, d_st, dev<uint16_t>(c->link),
-                           dev<uint2>(c->mm), dev<uint32_t>(c->maps), dev<uint2>(c->segmap),
-                           dev<uint16_t>(c->seg_entry), dev<uint32_t>(c->seg_symbase), dev<uint8_t>(c->stale),
-                           dev<uint8_t>(c->seg_stale), c->crc_tab, lv, strategy, hash_variant, 0x7FFFFFFF, 0x7FFFFFFF,
-                           use_sup ? dev<uint2>(c->supmap) : (const uint2 *)nullptr, dev<uint16_t>(c->chunk_far), defer_mode);
-    };
-    launch_resolve();
-    if (rounds) {
-        StreamState *hr = (StreamState *)c->pinned;
-        for (;;) {
-            ZS_HIP(c, hipMemcpyAsync(hr, d_st, sizeof(StreamState) * (size_t)n, hipMemcpyDeviceToHost, stream));
-            ZS_HIP(c, hipStreamSynchronize(stream));
-            bool any = false;
-            for (int i = 0; i < n; i++) any = any || hr[i].deferred == 2;  // (3: a poisoned stream, dealt with at the end)
-            if (!any) break;
-            hipLaunchKernelGGL(zs_repair_kernel, dim3(kRepairParts, (unsigned)n), dim3(256), kRepairLds, stream, d_sd, d_st, dev<uint16_t>(c->link),
-                               dev<uint2>(c->mm), dev<uint8_t>(c->stale), dev<uint8_t>(c->seg_stale), dev<uint16_t>(c->chunk_far), c->crc_tab, lv,
-                               hash_variant);
-            hipLaunchKernelGGL(zs_stalemaps_kernel, dim3(18, (unsigned)n), dim3(512), 0, stream, d_sd, d_st, dev<uint2>(c->mm), dev<uint16_t>(c->link),
-                               dev<uint32_t>(c->maps), dev<uint8_t>(c->stale), c->crc_tab, lv, strategy, hash_variant);
-            hipLaunchKernelGGL(zs_round_end_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_st, n);
-            launch_resolve();
-        }
+    launch_resolve(defer_mode, 0);
     }
     mark(7);
     // fork: the tail engine (sequential, one workgroup per stream) needs only what the resolve kernel left, so it runs
@@ -772,12 +842,14 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
         }
     }
     if (!ro && !rounds) {
-        // a stream the resolve kernel gave up (zs_device.h, StreamState::deferred): the batch again, in rounds
+        // streams the resolve kernel gave up (zs_device.h, StreamState::deferred): the batched cut rounds, then the kernels
+        // behind the resolve kernel once more (they skipped those streams): this call again, from there
         bool gave_up = false;
-        for (int i = 0; i < n; i++) gave_up = gave_up || hst[i].deferred != 0;
+        for (int i = 0; i < n; i++) gave_up = gave_up || hst[i].deferred == 1;
         if (gave_up) {
             ZS_HIP(c, hipStreamSynchronize(c->aux));
             c->round_runs++;
+            if (!run_cut_rounds()) return false;
             return run_pipeline(c, n, in, in_len, out, out_cap, out_len, status, level, strategy, hash_variant, stream, writes, force_seq, ro, true, force_lit);
         }
     }
@@ -917,7 +989,9 @@ int zs_ctx_create(int device, zs_ctx **out) {
         hipFuncSetAttribute((const void *)zs_fast_vec_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kFvLds) != hipSuccess ||
         hipFuncSetAttribute((const void *)zs_inf_window_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kWinMapLds) != hipSuccess ||
         hipFuncSetAttribute((const void *)zs_inf_chain_par_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kChainParLds) != hipSuccess ||
-        hipFuncSetAttribute((const void *)zs_repair_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kRepairLds) != hipSuccess ||
+        hipFuncSetAttribute((const void *)zs_cuts_repair_kernel<256, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, kRepairLds) != hipSuccess ||
+        hipFuncSetAttribute((const void *)zs_cuts_repair_kernel<256, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, kRepairLds) != hipSuccess ||
+        hipFuncSetAttribute((const void *)zs_cuts_repair_kernel<1024, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, kRepairLds) != hipSuccess ||
         hipFuncSetAttribute((const void *)zs_inflate_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kInfLds) != hipSuccess) {
         zs_ctx_destroy(c);
         return ZS_MEM_ERROR;
@@ -939,7 +1013,7 @@ void zs_ctx_destroy(zs_ctx *c) {
     DevBuf *bufs[] = {&c->sd, &c->st, &c->work, &c->wpre, &c->geo, &c->link, &c->mm, &c->maps, &c->chunk_far, &c->segmap, &c->supmap, &c->seg_entry, &c->seg_symbase, &c->seg_stale, &c->entry, &c->symbase, &c->stale, &c->syms,
                       &c->blk_end, &c->blk_top, &c->blocks, &c->trees, &c->info, &c->pieces, &c->scratch, &c->stage_in, &c->stage_out, &c->wr, &c->inf_desc, &c->inf_state, &c->par_ps, &c->par_st, &c->par_work, &c->par_cbits, &c->par_ccnt, &c->par_surv, &c->par_scnt,
                       &c->par_cands, &c->par_tabs, &c->par_blocks, &c->par_cells, &c->par_windows, &c->par_fail, &c->run_syms, &c->run_bits,
-                      &c->run_scratch, &c->run_outs, &c->run_fail, &c->adl_tr, &c->adl_res, &c->plan_blk, &c->ins_bits, &c->fv_lists, &c->win_groups, &c->win_sg, &c->win_maps, &c->win_entries};
+                      &c->run_scratch, &c->run_outs, &c->run_fail, &c->adl_tr, &c->adl_res, &c->plan_blk, &c->ins_bits, &c->fv_lists, &c->mm_bak, &c->cut_pos, &c->cut_bkt, &c->win_groups, &c->win_sg, &c->win_maps, &c->win_entries};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     if (c->crc_tab) (void)hipFree(c->crc_tab);

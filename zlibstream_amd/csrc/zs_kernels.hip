@@ -31,6 +31,7 @@ typedef __attribute__((address_space(1))) uint8_t *gbytes_w;
 __device__ __forceinline__ gcbytes as_global(const uint8_t *p) { return (gcbytes)(uintptr_t)p; }
 __device__ __forceinline__ gbytes_w as_global(uint8_t *p) { return (gbytes_w)(uintptr_t)p; }
 typedef const __attribute__((address_space(1))) uint32_t __attribute__((aligned(1))) *gcu32u;
+typedef const __attribute__((address_space(1))) uint64_t __attribute__((aligned(1))) *gcu64u;
 // (Only for addresses that differ from lane to lane: where the compiler can prove an address wave-uniform it makes the
 // load a scalar one, and a scalar dword load reads from the address rounded down to 4 whatever the type says -- found in
 // zs_repair_kernel.  Uniform or possibly uniform addresses take g_u32_bytes.)
@@ -622,13 +623,19 @@ __device__ __forceinline__ ChunkCtx chunk_ctx(const StreamDesc &s, int c) {
     return cx;
 }
 __device__ __forceinline__ int chunk_of(const StreamDesc &s, int64_t p) {  // last chunk whose first position is <= p
-    int lo = 0, hi = s.nchunks - 1;
-    while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        if ((int64_t)s.cstart[mid] <= p) lo = mid;
-        else hi = mid - 1;
+    // a single Write's chunks are on the grid 2048 c - 261; otherwise from a guess by proportion, a few steps either way (every
+    // step is a dependent load from the table: a bisection over a long stream's table was 10 us, and the resolve kernel asks
+    // twice per cut)
+    int c;
+    if (s.grid_chunks) {
+        c = (int)((p + (kMinLookahead - 1)) >> kChunkBits);
+        return c < s.nchunks ? c : s.nchunks - 1;
     }
-    return lo;
+    c = (int)((p * (int64_t)s.nchunks) / ((int64_t)s.body_end + 1));
+    c = c < 0 ? 0 : c >= s.nchunks ? s.nchunks - 1 : c;
+    while (c > 0 && (int64_t)s.cstart[c] > p) c--;
+    while (c + 1 < s.nchunks && (int64_t)s.cstart[c + 1] <= p) c++;
+    return c;
 }
 
 // ------------------------------------------------------------------ K3 / K4 / K5 accessors
@@ -647,10 +654,17 @@ struct GlobalAcc {
     __device__ uint32_t mK4(int64_t p) const { return flt(mm[p].y); }
     __device__ uint8_t byte(int64_t p) const { return in[p]; }
     __device__ uint32_t bucket(int64_t p) const { return dev_bucket(tab, g_u32_bytes(in + p + 2), hash_variant); }
-    __device__ int run1(int64_t p) const {
+    __device__ int run1(int64_t p) const {  // (p is a loop-top of the body: 258 bytes and more behind it are input)
         int len = 0;
-        while (len < kMaxMatch && in[p + len] == in[p - 1 + len]) len++;
-        return len;
+        while (len < kMaxMatch) {
+            const uint64_t x = *(gcu64u)(in + p + len) ^ *(gcu64u)(in + p - 1 + len);
+            if (x) {
+                len += (int)(__builtin_ctzll(x) >> 3);
+                break;
+            }
+            len += 8;
+        }
+        return len < kMaxMatch ? len : kMaxMatch;
     }
 };
 // matches staged (already filtered) in LDS for one chunk: index p - (cs - 1)
@@ -667,10 +681,17 @@ struct LdsAcc {
     __device__ uint32_t mK4(int64_t p) const { return fk4[p - org]; }
     __device__ uint8_t byte(int64_t p) const { return lbytes ? lbytes[p - org] : in[p]; }
     __device__ uint32_t bucket(int64_t p) const { return dev_bucket(tab, g_u32_bytes(in + p + 2), hash_variant); }
-    __device__ int run1(int64_t p) const {
+    __device__ int run1(int64_t p) const {  // (p is a loop-top of the body: 258 bytes and more behind it are input)
         int len = 0;
-        while (len < kMaxMatch && in[p + len] == in[p - 1 + len]) len++;
-        return len;
+        while (len < kMaxMatch) {
+            const uint64_t x = *(gcu64u)(in + p + len) ^ *(gcu64u)(in + p - 1 + len);
+            if (x) {
+                len += (int)(__builtin_ctzll(x) >> 3);
+                break;
+            }
+            len += 8;
+        }
+        return len < kMaxMatch ? len : kMaxMatch;
     }
 };
 
@@ -807,7 +828,8 @@ __device__ __forceinline__ void chunkmap_compute(const StreamDesc &s, int c, con
 
 __global__ __launch_bounds__(512) void zs_chunkmap_kernel(const StreamDesc *sd, const uint2 *work, const uint2 *mm, const uint16_t *link,
                                                           uint32_t *maps, const uint32_t *crc_tab_g,
-                                                          LevelCfg lv, int strategy, int hash_variant, uint16_t *chunk_far) {
+                                                          LevelCfg lv, int strategy, int hash_variant, uint16_t *chunk_far,
+                                                          uint8_t *only_stale = nullptr, const StreamState *st = nullptr) {
     __shared__ uint32_t fk[kChunk + 1], fk4[kChunk + 1];
     __shared__ uint32_t tbl[kNodeExit3];
     __shared__ uint32_t tab[1024];
@@ -815,8 +837,11 @@ __global__ __launch_bounds__(512) void zs_chunkmap_kernel(const StreamDesc *sd, 
     uint2 w = work[blockIdx.x];
     const StreamDesc s = sd[w.x];
     const int c = (int)w.y;
+    // (batched cut rounds: only the chunks whose records a restore or a repair has changed, of the streams in the rounds)
+    if (only_stale && (st[w.x].deferred != 1 || st[w.x].cuts_same || !only_stale[s.chunk_off + c])) return;
     if (s.head[c] != 0) load_crc_tab(tab, crc_tab_g);  // (chunkmap_compute's first barrier comes before the table's first use)
     chunkmap_compute<512>(s, c, mm, link, maps, lv, strategy, hash_variant, fk, fk4, tbl, tab, &sh_far, chunk_far);
+    if (only_stale && threadIdx.x == 0) only_stale[s.chunk_off + c] = 0;
 }
 
 // ------------------------------------------------------------------ K3b
@@ -909,6 +934,11 @@ struct RepairArgs {
     int nch;
     LevelCfg lv;
     int hash_variant;
+    // batched cut rounds: the stream's cuts (ascending) and their buckets, this cut's index: a position with a later cut of
+    // its bucket in front of it is that cut's business
+    const int32_t *cl_pos = nullptr;
+    const uint32_t *cl_bkt = nullptr;
+    int cl_i = 0, cl_n = 0;
 };
 template <int NT, int U>
 __device__ __forceinline__ int repair_cut(const RepairArgs &r, int64_t e, int64_t from, int64_t to_all, bool scan_only, int *sh_to,
@@ -962,6 +992,9 @@ __device__ __forceinline__ int repair_cut(const RepairArgs &r, int64_t e, int64_
         const bool dirty = (x && pc - match_dist(x) < e) || (y && pc - match_dist(y) < e);
         bool inb = v == vB;
         if (in_range && dirty && !inb) inb = dev_bucket(tab, v, hash_variant) == B;
+        if (in_range && dirty && inb && r.cl_pos)
+            for (int j = r.cl_i + 1; j < r.cl_n && (int64_t)r.cl_pos[j] < pc; j++)
+                if (r.cl_bkt[j] == B) inb = false;  // a later cut of the bucket hides this one from the position
         todo |= (in_range && dirty && inb) ? 1u << u : 0u;
     }
     if (!__syncthreads_or(todo != 0)) return 0;  // nothing behind the cut was seen through it
@@ -1085,8 +1118,14 @@ __global__ __launch_bounds__(1024) void zs_resolve_kernel(const StreamDesc *sd, 
                                                          uint16_t *seg_entry, uint32_t *seg_symbase, uint8_t *stale,
                                                          uint8_t *seg_stale, const uint32_t *crc_tab_g, LevelCfg lv,
                                                          int strategy, int hash_variant, int seg_limit, int mm_limit,
-                                                         const uint2 *supmap, const uint16_t *chunk_far, int defer_mode_in) {
+                                                         const uint2 *supmap, const uint16_t *chunk_far, int defer_mode_in,
+                                                         int32_t *cut_pos, uint32_t *cut_bkt, int cut_stride, int cut_iter) {
+    // defer_mode: 0 every cut repaired here; 1 the same until the budgets are spent, then the stream is given up where it stands
+    // (StreamState::deferred = 1) for the batched cut rounds; 3 a dry pass of those rounds: the walk goes on from where the
+    // stream was given up, the cuts on its way are collected, nothing is repaired
     const int defer_mode = defer_mode_in & 0xFF;
+    const bool dry = defer_mode == 3;
+    const int cut_budget = (defer_mode_in >> 16) & 0xFF;  // (ZS_FORCE_ROUNDS: 0)
     const bool dbg = (defer_mode_in & 0x100) != 0;  // ZS_DEBUG_CUTS: the cuts as they are applied
     // > 64 KiB of LDS: dynamic allocation, carved by hand
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -1100,7 +1139,8 @@ __global__ __launch_bounds__(1024) void zs_resolve_kernel(const StreamDesc *sd, 
     __shared__ uint32_t g_base[kSegBatch / kSegGroup];
     __shared__ int sh_kf, sh_ks;
     __shared__ int sh_seg, sh_slot, sh_scan, sh_kfired, sh_kslot;
-    __shared__ int sh_defer, sh_nexp, sh_cutidx, sh_poison, sh_cut_e;
+    __shared__ int sh_defer, sh_nexp, sh_ncut_any, sh_cutidx, sh_poison, sh_cut_e, sh_nc, sh_diff;
+    __shared__ int row_cs[kSegBatch];  // per staged row: the first position of the segment's first chunk, bit 31: its cluster is one boundary
     __shared__ int b_seg0, b_nrow, b_groups;  // the batch of rows in LDS: first segment, rows, whether its composed groups may be used
     __shared__ uint32_t sh_total;
     const StreamDesc s = sd[blockIdx.x];
@@ -1110,8 +1150,10 @@ __global__ __launch_bounds__(1024) void zs_resolve_kernel(const StreamDesc *sd, 
     // positions up to mm_limit their match records; the kernel goes on from where the launch before stopped
     if (threadIdx.x == 0)
         sh_seg = ss.r_seg, sh_slot = ss.r_slot, sh_total = ss.r_total, sh_kfired = ss.r_kfired, sh_kslot = ss.r_kslot, sh_scan = ss.r_scan,
-        ss.r_scan = 0, b_seg0 = 0, b_nrow = 0, b_groups = 0, sh_defer = 0, sh_nexp = 0, sh_cutidx = ss.r_cutidx, sh_poison = 0, sh_cut_e = -1;
+        ss.r_scan = dry ? ss.r_scan : 0, b_seg0 = 0, b_nrow = 0, b_groups = 0, sh_defer = 0, sh_nexp = 0, sh_ncut_any = 0, sh_cutidx = ss.r_cutidx, sh_poison = 0,
+        sh_cut_e = -1, sh_nc = 0, sh_diff = 0x7FFFFFFF;
     __syncthreads();
+    if (dry && ss.deferred != 1) return;  // only the streams that were given up take part in the rounds
     if (s.body_end < 0) {
         if (threadIdx.x == 0) ss.tail_p = 0, ss.tail_kind = kR, ss.tail_pend = 0, ss.k_done = 0, ss.preins = -1, ss.body_syms = 0;
         return;
@@ -1186,14 +1228,19 @@ __global__ __launch_bounds__(1024) void zs_resolve_kernel(const StreamDesc *sd, 
         const ChunkCtx cx = chunk_ctx(s, s.seg_c0[sh_seg]);
         for (;;) {
             if (threadIdx.x == 0) {
-                NthEqualEv ne{sh_cutidx, 0, -1};
-                NullSink nsk;
-                int kind, ns;
-                int64_t pp;
-                uint32_t fl;
-                chunk_special_prefix(acc, nsk, cx, sh_slot, lv, strategy, kind, pp, ns, fl, ne);
-                sh_cut_e = (int)ne.pos;
-                if (fl & kMapPoisonBit) sh_poison = 1;
+                if (cx.m == 1) {
+                    // one boundary, one event: the entry loop-top (the flag that brought the walk here says its buckets are equal)
+                    sh_cut_e = sh_cutidx == 0 ? (int)(sh_slot <= 256 ? cx.cs + sh_slot : cx.cs) : -1;
+                } else {
+                    NthEqualEv ne{sh_cutidx, 0, -1};
+                    NullSink nsk;
+                    int kind, ns;
+                    int64_t pp;
+                    uint32_t fl;
+                    chunk_special_prefix(acc, nsk, cx, sh_slot, lv, strategy, kind, pp, ns, fl, ne);
+                    sh_cut_e = (int)ne.pos;
+                    if (fl & kMapPoisonBit) sh_poison = 1;
+                }
             }
             __syncthreads();
             const int64_t e = sh_cut_e;
@@ -1205,18 +1252,14 @@ __global__ __launch_bounds__(1024) void zs_resolve_kernel(const StreamDesc *sd, 
             int64_t full = e + kMaxDist;
             if (full > s.body_end) full = s.body_end;
             const int64_t to = full < mm_end ? full : mm_end;
-            if (defer_mode == 2) {
-                // a round: a cut with positions to walk again is left to zs_repair_kernel -- the kernel stops here
-                const int rc = repair(e, e, to, true);
-                if (dbg && threadIdx.x == 0) printf("zs resolve:   scan of (%ld, %ld] says %d\n", (long)e, (long)to, rc);
-                if (rc == 1 && threadIdx.x == 0) ss.r_cut_e[0] = (int32_t)e, ss.r_cut_done[0] = (int32_t)e, ss.r_ncut = 1, sh_defer = 2;
-            } else {
+            {
                 const int rc = repair(e, e, to, false);
                 if (threadIdx.x == 0 && to < full) {  // the rest once the records beyond exist
                     const int k = ss.r_ncut < 8 ? ss.r_ncut++ : 7;
                     ss.r_cut_e[k] = (int32_t)e, ss.r_cut_done[k] = (int32_t)to;
                 }
-                if (defer_mode == 1 && rc == 2 && threadIdx.x == 0 && ++sh_nexp > kDeferBudget) sh_defer = 1;  // not this CU's job
+                // not this CU's job any longer: the batched cut rounds take the stream from here (zs_engine.hip)
+                if (defer_mode == 1 && threadIdx.x == 0 && ((rc == 2 && ++sh_nexp > (cut_budget < kDeferBudget ? cut_budget : kDeferBudget)) || ++sh_ncut_any > cut_budget)) sh_defer = 1;
             }
             __threadfence_block();
             __syncthreads();
@@ -1226,8 +1269,49 @@ __global__ __launch_bounds__(1024) void zs_resolve_kernel(const StreamDesc *sd, 
         if (threadIdx.x == 0 && !sh_defer) sh_cutidx = 0;
         __syncthreads();
     };
-    // a round left the kernel in the middle of a cluster's cuts: the rest of them first
-    if (sh_scan && sh_seg < nseg) process_cuts();
+    // A dry pass: the equal-bucket events on the path are written to the stream's cut list of this pass, with their buckets
+    // (thread 0, in the middle of its walk; a cluster of one boundary has its one event at the entry loop-top).
+    int32_t *cl_out = cut_pos ? cut_pos + (size_t)(cut_iter & 1) * (size_t)cut_stride + s.cut_off : nullptr;
+    uint32_t *cb_out = cut_bkt ? cut_bkt + (size_t)(cut_iter & 1) * (size_t)cut_stride + s.cut_off : nullptr;
+    auto collect_cuts = [&](int seg, int slot, int skip, int cs_single) {  // thread 0; cs_single: row_cs of the segment, or 0
+        auto append = [&](int64_t e) {
+            if (sh_nc < s.cut_cap) cl_out[sh_nc] = (int32_t)e;  // (its bucket: by all threads when the pass is through)
+            else sh_poison = 1;  // (one cut per read boundary at most: not reached)
+            sh_nc++;
+        };
+        if (cs_single < 0) {  // one boundary, one event: the entry loop-top
+            const int64_t cs = cs_single & 0x7FFFFFFF;
+            if (skip == 0) append(slot <= 256 ? cs + slot : cs);
+            return;
+        }
+        const ChunkCtx cx = chunk_ctx(s, seg_first(s, seg));
+        if (cx.m == 1) {
+            if (skip == 0) append(slot <= 256 ? cx.cs + slot : cx.cs);
+            return;
+        }
+        struct AppendEqualEv {
+            decltype(append) &app;
+            int skip, seen;
+            __device__ void operator()(int64_t p, bool eq) {
+                if (eq && seen++ >= skip) app(p);
+            }
+        } ae{append, skip, 0};
+        NullSink nsk;
+        int kind, ns;
+        int64_t pp;
+        uint32_t fl;
+        chunk_special_prefix(acc, nsk, cx, slot, lv, strategy, kind, pp, ns, fl, ae);
+        if (fl & kMapPoisonBit) sh_poison = 1;
+    };
+    // the kernel was left in the middle of a cluster's cuts (a stream given up there): the rest of them first
+    if (sh_scan && sh_seg < nseg) {
+        if (dry) {
+            if (threadIdx.x == 0) collect_cuts(sh_seg, sh_slot, sh_cutidx, 0);
+            __syncthreads();
+        } else {
+            process_cuts();
+        }
+    }
 #ifdef ZS_FV_PROF
     long long kp[6] = {0, 0, 0, 0, 0, 0}, kt = wall_clock64();
     int kiter = 0;
@@ -1321,7 +1405,11 @@ __global__ __launch_bounds__(1024) void zs_resolve_kernel(const StreamDesc *sd, 
             const uint4 *src = (const uint4 *)(segmap + ((int64_t)s.seg_off + seg0) * kSlots);  // kSlots is even: 16-byte aligned
             for (int i = threadIdx.x; i < nrow * kSlots / 2; i += blockDim.x) ((uint4 *)rows)[i] = src[i];
         }
-        if (threadIdx.x < nrow) row_meta[threadIdx.x] = seg_row_meta(s, seg0 + (int)threadIdx.x, seg_stale);
+        if (threadIdx.x < nrow) {
+            const int sg = seg0 + (int)threadIdx.x, c0s = s.seg_c0[sg];
+            row_meta[threadIdx.x] = seg_row_meta(s, sg, seg_stale);
+            row_cs[threadIdx.x] = s.cstart[c0s] | ((s.head[c0s] != 0 && s.seg_cl[sg + 1] - s.seg_cl[sg] == 1) ? (int)0x80000000 : 0);
+        }
         __syncthreads();
         if (threadIdx.x == 0) b_seg0 = seg0, b_nrow = nrow, b_groups = resume ? 0 : 1;
         K4_PF(0);
@@ -1397,8 +1485,12 @@ __global__ __launch_bounds__(1024) void zs_resolve_kernel(const StreamDesc *sd, 
                         break;
                     }
                     if ((vx & kMapEqualBit) && cuts && !scanned) {
-                        stop = true;
-                        break;
+                        if (!dry) {
+                            stop = true;
+                            break;
+                        }
+                        collect_cuts(seg, slot, 0, row_cs[i]);
+                        if (sh_poison) break;
                     }
                 }
                 scanned = false;
@@ -1478,7 +1570,31 @@ __global__ __launch_bounds__(1024) void zs_resolve_kernel(const StreamDesc *sd, 
     if (threadIdx.x == 0 && blockIdx.x == 0 && kiter > 4)
         printf("K4PROF iterations=%d ticks: stage+meta=%lld compose=%lld walk=%lld fill+flush=%lld repair=%lld\n", kiter, kp[0], kp[1], kp[2], kp[3], kp[4]);
 #endif
-    if (threadIdx.x == 0) ss.r_seg = sh_seg, ss.r_slot = sh_slot, ss.r_total = sh_total, ss.r_kfired = sh_kfired, ss.r_kslot = sh_kslot, ss.r_cutidx = sh_cutidx;
+    if (threadIdx.x == 0 && !dry) ss.r_seg = sh_seg, ss.r_slot = sh_slot, ss.r_total = sh_total, ss.r_kfired = sh_kfired, ss.r_kslot = sh_kslot, ss.r_cutidx = sh_cutidx;
+    if (dry && !sh_poison) {
+        // this pass's cuts against the pass before: the same cuts mean the records they were repaired for are the ones this
+        // pass walked -- the stream is resolved; else the first cut that differs says from where to repair again
+        const int cur = cut_iter & 1, ncur = sh_nc, nold = cut_iter == 0 ? 0 : ss.nc[cur ^ 1];
+        const int32_t *a = cut_pos + (size_t)cur * (size_t)cut_stride + s.cut_off, *b = cut_pos + (size_t)(cur ^ 1) * (size_t)cut_stride + s.cut_off;
+        const int nmin = ncur < nold ? ncur : nold;
+        __threadfence_block();
+        __syncthreads();
+        {
+            uint32_t *cbw = cut_bkt + (size_t)cur * (size_t)cut_stride + s.cut_off;
+            for (int i = threadIdx.x; i < ncur && i < s.cut_cap; i += blockDim.x) cbw[i] = acc.bucket(a[i]);
+        }
+        for (int i = threadIdx.x; i < nmin; i += blockDim.x)
+            if (a[i] != b[i]) atomicMin(&sh_diff, i);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int di = sh_diff < nmin ? sh_diff : nmin;
+            const bool same = cut_iter > 0 && ncur == nold && sh_diff >= nmin;
+            int64_t dp = 0x7FFFFFFF;
+            if (di < ncur) dp = a[di];
+            if (di < nold && b[di] < dp) dp = b[di];
+            ss.nc[cur] = ncur, ss.cuts_same = same ? 1 : 0, ss.cut_diff_idx = di, ss.cut_diff_pos = (int32_t)dp;
+        }
+    }
     if (sh_poison) {
         if (threadIdx.x == 0) ss.poison = 1, ss.deferred = 3;  // the kernels behind skip the stream; the host runs it on the literal engine
         return;
@@ -1520,50 +1636,64 @@ __global__ __launch_bounds__(1024) void zs_resolve_kernel(const StreamDesc *sd, 
 // For the streams the resolve kernel has stopped at a cut (deferred == 2): the positions behind the cut walked again, 1 Ki
 // positions per workgroup (repair_cut), then the maps of the chunks that changed (K3's routine), then the flags reset;
 // the host launches the resolve kernel again.
-constexpr int kRepairParts = 128;  // x 256 threads >= kMaxDist positions, dealt round the workgroups
 constexpr int kRepairLds = ((kMaxDist + 16 + 273 + 15) & ~15) + 2 * (kMaxDist + 32) + 64;
-__global__ __launch_bounds__(256) void zs_repair_kernel(const StreamDesc *sd, const StreamState *st, uint16_t *link, uint2 *mm, uint8_t *stale,
-                                                        uint8_t *seg_stale, const uint16_t *chunk_far, const uint32_t *crc_tab_g, LevelCfg lv,
-                                                        int hash_variant) {
+// The records of a stream in the batched cut rounds, from the position of the first cut that changed on, as they were when
+// the rounds began (the copy `bak`): the pass's cuts are applied to records that have seen no cut of an earlier pass.  A
+// record that changes marks its chunk (and the next one when it is the chunk's last: its pending-match row) and segment.
+__global__ __launch_bounds__(256) void zs_cut_restore_kernel(const StreamDesc *sd, const StreamState *st, uint2 *mm, const uint2 *bak, uint8_t *stale,
+                                                             uint8_t *seg_stale) {
+    const StreamDesc s = sd[blockIdx.y];
+    const StreamState &ss = st[blockIdx.y];
+    if (ss.deferred != 1 || ss.cuts_same) return;
+    const int64_t from = (int64_t)ss.cut_diff_pos + 1, to = s.body_end;
+    for (int64_t p = from + (int64_t)blockIdx.x * 256 + threadIdx.x; p <= to; p += (int64_t)gridDim.x * 256) {
+        const uint2 want = bak[s.pos_off + p], have = mm[s.pos_off + p];
+        if (want.x == have.x && want.y == have.y) continue;
+        mm[s.pos_off + p] = want;
+        const int cp = chunk_of(s, p);
+        stale[s.chunk_off + cp] = 1, seg_stale[s.seg_off + seg_of(s, cp)] = 1;
+        if (p + 1 == (int64_t)s.cstart[cp + 1] && cp + 1 < s.nchunks) stale[s.chunk_off + cp + 1] = 1, seg_stale[s.seg_off + seg_of(s, cp + 1)] = 1;
+    }
+}
+// One pass's cuts applied over the chip: workgroup (part, cut, stream) takes every nparts-th position behind its cut
+// (repair_cut: the scan, and where something has to be walked again the window behind the cut in LDS).  Cuts whose reach
+// ends before the first cut that changed have their repairs in the records already.
+template <int NT, int U>
+__global__ __launch_bounds__(NT) void zs_cuts_repair_kernel(const StreamDesc *sd, const StreamState *st, uint16_t *link, uint2 *mm, uint8_t *stale,
+                                                             uint8_t *seg_stale, const uint16_t *chunk_far, const uint32_t *crc_tab_g, LevelCfg lv,
+                                                             int hash_variant, const int32_t *cut_pos, const uint32_t *cut_bkt, int cut_stride, int cut_iter) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     __shared__ uint32_t tab[1024];
     __shared__ int sh_to;
-    const StreamDesc s = sd[blockIdx.y];
-    const StreamState &ss = st[blockIdx.y];
-    if (ss.deferred != 2) return;
-    const int64_t e = ss.r_cut_e[0];
+    const StreamDesc s = sd[blockIdx.z];
+    const StreamState &ss = st[blockIdx.z];
+    if (ss.deferred != 1 || ss.cuts_same) return;
+    const int cur = cut_iter & 1, nc = ss.nc[cur], j = (int)blockIdx.y;
+    if (j >= nc) return;
+    const int32_t *cl = cut_pos + (size_t)cur * (size_t)cut_stride + s.cut_off;
+    const uint32_t *cb = cut_bkt + (size_t)cur * (size_t)cut_stride + s.cut_off;
+    const int64_t e = cl[j], dp = ss.cut_diff_pos;
     int64_t full = e + kMaxDist;
     if (full > s.body_end) full = s.body_end;
-    static_assert(kRepairParts * 256 >= kMaxDist, "one position per thread");
-    if (e >= full) return;
+    const int64_t from = e > dp ? e : dp;  // the records up to the first changed cut were not restored
+    if (from >= full) return;
     load_crc_tab(tab, crc_tab_g);
     __syncthreads();
-    RepairArgs ra{&s, mm + s.pos_off, link + s.pos_off, tab, smem, stale, seg_stale, chunk_far, s.nchunks, lv, hash_variant};
-    repair_cut<256, 1>(ra, e, e, full, false, &sh_to, nullptr, nullptr, nullptr, (int)blockIdx.x, kRepairParts);
+    RepairArgs ra{&s, mm + s.pos_off, link + s.pos_off, tab, smem, stale, seg_stale, chunk_far, s.nchunks, lv, hash_variant, cl, cb, j, nc};
+    repair_cut<NT, U>(ra, e, from, full, false, &sh_to, nullptr, nullptr, nullptr, (int)blockIdx.x, (int)gridDim.x);
 }
-__global__ __launch_bounds__(512) void zs_stalemaps_kernel(const StreamDesc *sd, const StreamState *st, const uint2 *mm, const uint16_t *link, uint32_t *maps,
-                                                           uint8_t *stale, const uint32_t *crc_tab_g, LevelCfg lv, int strategy, int hash_variant) {
-    __shared__ uint32_t fk[kChunk + 1], fk4[kChunk + 1];
-    __shared__ uint32_t tbl[kNodeExit3];
-    __shared__ uint32_t tab[1024];
-    const StreamDesc s = sd[blockIdx.y];
-    const StreamState &ss = st[blockIdx.y];
-    if (ss.deferred != 2) return;
-    // the chunks a cut's repair can have touched: those that begin within MAX_DIST behind it, dealt round the workgroups
-    const int64_t e = ss.r_cut_e[0];
-    bool tab_loaded = false;
-    for (int c = chunk_of(s, e + 1) + (int)blockIdx.x; c < s.nchunks && (int64_t)s.cstart[c] <= e + kMaxDist + 1; c += (int)gridDim.x) {
-        if (!stale[s.chunk_off + c]) continue;  // (uniform over the workgroup)
-        __syncthreads();
-        if (s.head[c] != 0 && !tab_loaded) load_crc_tab(tab, crc_tab_g), tab_loaded = true;
-        chunkmap_compute<512>(s, c, mm, link, maps, lv, strategy, hash_variant, fk, fk4, tbl, tab, nullptr, nullptr);
-        __syncthreads();
-        if (threadIdx.x == 0) stale[s.chunk_off + c] = 0;
-    }
-}
-__global__ __launch_bounds__(256) void zs_round_end_kernel(StreamState *st, int n) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < n && st[i].deferred == 2) st[i].r_ncut = 0, st[i].deferred = 0;
+// The rounds are over for a stream whose last pass found the cuts of the pass before: the cuts go into the links (the tail
+// engine restores prev[] from them, zs_lit_engine.h le_restore_prev) and the stream goes on down the pipeline.
+__global__ __launch_bounds__(256) void zs_cuts_apply_kernel(const StreamDesc *sd, StreamState *st, uint16_t *link, const int32_t *cut_pos, int cut_stride,
+                                                            int cut_iter) {
+    const StreamDesc s = sd[blockIdx.x];
+    StreamState &ss = st[blockIdx.x];
+    if (ss.deferred != 1 || !ss.cuts_same) return;
+    const int cur = cut_iter & 1, nc = ss.nc[cur];
+    const int32_t *cl = cut_pos + (size_t)cur * (size_t)cut_stride + s.cut_off;
+    for (int i = threadIdx.x; i < nc; i += 256) link[s.pos_off + cl[i]] = 0;
+    __syncthreads();
+    if (threadIdx.x == 0) ss.deferred = 0, ss.r_scan = 0;
 }
 
 __global__ __launch_bounds__(64) void zs_expand_kernel(const StreamDesc *sd, const StreamState *st, const uint2 *work, int nwork, const uint2 *mm,
