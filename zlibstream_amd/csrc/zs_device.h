@@ -160,7 +160,7 @@ struct StreamState {
     int32_t poison;
 };
 constexpr int kDeferBudget = 8;   // cuts with positions to walk again that a stream may repair on its one CU before it is given up
-constexpr int kCutBudget = 32;    // ... and cuts of any kind (a cut without such positions is a scan of 32 Ki records on one CU)
+constexpr int kCutBudget = 12;    // ... and cuts of any kind (a cut without such positions is a scan of 32 Ki records on one CU)
 
 // DeflateFast (levels 1-3) as speculative chunk runs: run j re-parses kFastWarm bytes before its chunk with an
 // "everything inserted" history, then its chunk; it is exact iff its state at the first loop-top of the chunk

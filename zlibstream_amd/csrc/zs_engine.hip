@@ -498,6 +498,7 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
     auto run_cut_rounds = [&]() -> bool {
         if (!ensure(c, c->mm_bak, 8 * (size_t)pl.n_pos + 256)) return false;
         ZS_HIP(c, hipMemcpyAsync(c->mm_bak.p, c->mm.p, 8 * (size_t)pl.n_pos + 256, hipMemcpyDeviceToDevice, stream));
+        ZS_HIP(c, hipMemsetAsync(c->cut_pos.p, 0xFF, 8 * (size_t)pl.n_cuts + 64, stream));  // no cut in any slot (the pass before the first)
         StreamState *hr = (StreamState *)c->pinned;
         for (int iter = 0;; iter++) {
             launch_resolve(3 | (defer_mode & 0x100), iter);

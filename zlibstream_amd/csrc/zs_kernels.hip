@@ -888,7 +888,7 @@ __global__ __launch_bounds__(320) void zs_supmap_kernel(const StreamDesc *sd, co
     const int g = (int)w.y;
     if ((int)threadIdx.x >= kSlots) return;
     int cur = threadIdx.x;
-    uint32_t cnt = 0, flag = 0;
+    uint32_t cnt = 0, flag = 0, hard = 0;  // hard: attention a dry pass needs too (it takes equal-bucket events in its stride)
     for (int r = 0; r < kSupSegs; r++) {
         const int seg = g * kSupSegs + r;
         if (seg >= s.nsegs) break;
@@ -896,10 +896,11 @@ __global__ __launch_bounds__(320) void zs_supmap_kernel(const StreamDesc *sd, co
         const uint32_t m = seg_row_meta(s, seg, seg_stale);
         const bool fires = (m & 1u) && (uint32_t)(cur <= 256 ? cur : 0) <= (m >> 2);
         flag |= (m & 2u) | ((fires && (v.x & (kMapEqualBit | kMapPoisonBit))) ? 1u : 0u);
+        hard |= (m & 2u) | ((fires && (v.x & kMapPoisonBit)) ? 1u : 0u);
         cur = (int)(v.x & 0x1FF);
         cnt += v.y;
     }
-    supmap[((int64_t)s.sup_off + g) * kSlots + threadIdx.x] = make_uint2((uint32_t)cur | (flag ? 0x8000u : 0u), cnt);
+    supmap[((int64_t)s.sup_off + g) * kSlots + threadIdx.x] = make_uint2((uint32_t)cur | (flag ? 0x8000u : 0u) | (hard ? 0x4000u : 0u), cnt);
 }
 
 constexpr int kSegBatch = 64;
@@ -993,8 +994,12 @@ __device__ __forceinline__ int repair_cut(const RepairArgs &r, int64_t e, int64_
         bool inb = v == vB;
         if (in_range && dirty && !inb) inb = dev_bucket(tab, v, hash_variant) == B;
         if (in_range && dirty && inb && r.cl_pos)
-            for (int j = r.cl_i + 1; j < r.cl_n && (int64_t)r.cl_pos[j] < pc; j++)
+            for (int j = r.cl_i + 1; j < r.cl_n; j++) {  // (slots in stream order, -1: no cut)
+                const int64_t ej = r.cl_pos[j];
+                if (ej < 0) continue;
+                if (ej >= pc) break;
                 if (r.cl_bkt[j] == B) inb = false;  // a later cut of the bucket hides this one from the position
+            }
         todo |= (in_range && dirty && inb) ? 1u << u : 0u;
     }
     if (!__syncthreads_or(todo != 0)) return 0;  // nothing behind the cut was seen through it
@@ -1125,6 +1130,7 @@ __global__ __launch_bounds__(1024) void zs_resolve_kernel(const StreamDesc *sd, 
     // stream was given up, the cuts on its way are collected, nothing is repaired
     const int defer_mode = defer_mode_in & 0xFF;
     const bool dry = defer_mode == 3;
+    const uint32_t attn = dry ? 0x4000u : 0x8000u;  // which flag of a composed row stops the walk (zs_supmap_kernel)
     const int cut_budget = (defer_mode_in >> 16) & 0xFF;  // (ZS_FORCE_ROUNDS: 0)
     const bool dbg = (defer_mode_in & 0x100) != 0;  // ZS_DEBUG_CUTS: the cuts as they are applied
     // > 64 KiB of LDS: dynamic allocation, carved by hand
@@ -1269,33 +1275,37 @@ __global__ __launch_bounds__(1024) void zs_resolve_kernel(const StreamDesc *sd, 
         if (threadIdx.x == 0 && !sh_defer) sh_cutidx = 0;
         __syncthreads();
     };
-    // A dry pass: the equal-bucket events on the path are written to the stream's cut list of this pass, with their buckets
-    // (thread 0, in the middle of its walk; a cluster of one boundary has its one event at the entry loop-top).
+    // A dry pass: the equal-bucket events on the path go into the stream's cut slots of this pass -- every segment has a slot
+    // per boundary of its cluster (slot of segment k's first: seg_cl[k] - seg_cl[0] + k), -1 = no cut: whoever fills in a
+    // segment's entry (thread 0 row by row, a lane per group or per composed row) writes them, so the walk itself stops for
+    // nothing but stale rows.  A cluster of one boundary has its one event at the entry loop-top.
     int32_t *cl_out = cut_pos ? cut_pos + (size_t)(cut_iter & 1) * (size_t)cut_stride + s.cut_off : nullptr;
-    uint32_t *cb_out = cut_bkt ? cut_bkt + (size_t)(cut_iter & 1) * (size_t)cut_stride + s.cut_off : nullptr;
-    auto collect_cuts = [&](int seg, int slot, int skip, int cs_single) {  // thread 0; cs_single: row_cs of the segment, or 0
-        auto append = [&](int64_t e) {
-            if (sh_nc < s.cut_cap) cl_out[sh_nc] = (int32_t)e;  // (its bucket: by all threads when the pass is through)
-            else sh_poison = 1;  // (one cut per read boundary at most: not reached)
-            sh_nc++;
-        };
+    const int cl_cap = s.nsegs > 0 ? s.seg_cl[s.nsegs] - s.seg_cl[0] + s.nsegs : 0;
+    if (dry) {
+        for (int i = threadIdx.x; i < cl_cap; i += blockDim.x) cl_out[i] = -1;
+        __threadfence_block();
+        __syncthreads();
+    }
+    auto collect_cuts = [&](int seg, int slot, int skip, int cs_single) {  // cs_single: row_cs of the segment, or 0
+        const int k0 = s.seg_cl[seg];
+        int32_t *dst = cl_out + (k0 - s.seg_cl[0]) + seg;
         if (cs_single < 0) {  // one boundary, one event: the entry loop-top
             const int64_t cs = cs_single & 0x7FFFFFFF;
-            if (skip == 0) append(slot <= 256 ? cs + slot : cs);
+            if (skip == 0) dst[0] = (int32_t)(slot <= 256 ? cs + slot : cs);
             return;
         }
         const ChunkCtx cx = chunk_ctx(s, seg_first(s, seg));
         if (cx.m == 1) {
-            if (skip == 0) append(slot <= 256 ? cx.cs + slot : cx.cs);
+            if (skip == 0) dst[0] = (int32_t)(slot <= 256 ? cx.cs + slot : cx.cs);
             return;
         }
-        struct AppendEqualEv {
-            decltype(append) &app;
-            int skip, seen;
+        struct SlotEqualEv {
+            int32_t *dst;
+            int skip, seen, n, cap;
             __device__ void operator()(int64_t p, bool eq) {
-                if (eq && seen++ >= skip) app(p);
+                if (eq && seen++ >= skip && n < cap) dst[n++] = (int32_t)p;
             }
-        } ae{append, skip, 0};
+        } ae{dst, skip, 0, 0, cx.m};
         NullSink nsk;
         int kind, ns;
         int64_t pp;
@@ -1335,7 +1345,7 @@ __global__ __launch_bounds__(1024) void zs_resolve_kernel(const StreamDesc *sd, 
             const int g0 = sh_seg / kSupSegs, nsup = (s.nsegs + kSupSegs - 1) / kSupSegs;
             int nrow = nsup - g0;
             if (nrow > kSegBatch) nrow = kSegBatch;
-            if (threadIdx.x == 0) fs_try = !(supmap[((int64_t)s.sup_off + g0) * kSlots + sh_slot].x & 0x8000u), fs_n = 0, fp_kf = 0;
+            if (threadIdx.x == 0) fs_try = !(supmap[((int64_t)s.sup_off + g0) * kSlots + sh_slot].x & attn), fs_n = 0, fp_kf = 0;
             __syncthreads();
             if (fs_try) {  // uniform over the workgroup
                 const uint4 *src = (const uint4 *)(supmap + ((int64_t)s.sup_off + g0) * kSlots);
@@ -1354,7 +1364,7 @@ __global__ __launch_bounds__(1024) void zs_resolve_kernel(const StreamDesc *sd, 
                     uint32_t total = sh_total;
                     for (; i < nrow; i++) {
                         const uint2 e = rows[i * kSlots + slot];
-                        if ((e.x & 0x8000u) || row_meta[i]) break;
+                        if ((e.x & attn) || row_meta[i]) break;
                         out_slot[i] = (uint16_t)slot, out_base[i] = total;
                         slot = (int)(e.x & 0x1FF), total += e.y;
                     }
@@ -1371,7 +1381,10 @@ __global__ __launch_bounds__(1024) void zs_resolve_kernel(const StreamDesc *sd, 
                         if (seg >= s.nsegs) break;
                         const uint2 v = segmap[((int64_t)s.seg_off + seg) * kSlots + cur];
                         const uint32_t m = seg_row_meta(s, seg, seg_stale);
-                        if ((m & 1u) && (uint32_t)(cur <= 256 ? cur : 0) <= (m >> 2)) kf = ((unsigned long long)(seg + 1) << 16) | (unsigned)cur;
+                        if ((m & 1u) && (uint32_t)(cur <= 256 ? cur : 0) <= (m >> 2)) {
+                            kf = ((unsigned long long)(seg + 1) << 16) | (unsigned)cur;
+                            if (dry && (v.x & kMapEqualBit) && strategy != kHuffmanOnly) collect_cuts(seg, cur, 0, 0);
+                        }
                         seg_entry[s.seg_off + seg] = (uint16_t)cur;
                         seg_symbase[s.seg_off + seg] = total;
                         cur = (int)(v.x & 0x1FF);
@@ -1419,7 +1432,7 @@ __global__ __launch_bounds__(1024) void zs_resolve_kernel(const StreamDesc *sd, 
         for (int t = threadIdx.x; t < ngroup * kSlots; t += blockDim.x) {
             const int g = t / kSlots;
             int cur = t - g * kSlots;
-            uint32_t cnt = 0, flag = 0;
+            uint32_t cnt = 0, flag = 0, hard = 0;
             for (int r = 0; r < kSegGroup; r++) {
                 const int i = g * kSegGroup + r;
                 if (i >= nrow) break;
@@ -1427,10 +1440,11 @@ __global__ __launch_bounds__(1024) void zs_resolve_kernel(const StreamDesc *sd, 
                 const uint32_t m = row_meta[i];
                 const bool fires = (m & 1u) && (uint32_t)(cur <= 256 ? cur : 0) <= (m >> 2);
                 flag |= (m & 2u) | ((fires && (v.x & (kMapEqualBit | kMapPoisonBit))) ? 1u : 0u);
+                hard |= (m & 2u) | ((fires && (v.x & kMapPoisonBit)) ? 1u : 0u);
                 cur = (int)(v.x & 0x1FF);
                 cnt += v.y;
             }
-            gmap[t] = make_uint2((uint32_t)cur | (flag ? 0x8000u : 0u), cnt);
+            gmap[t] = make_uint2((uint32_t)cur | (flag ? 0x8000u : 0u) | (hard ? 0x4000u : 0u), cnt);
         }
         __syncthreads();
         if (threadIdx.x < kSegBatch / kSegGroup) g_fast[threadIdx.x] = 0;
@@ -1451,7 +1465,7 @@ __global__ __launch_bounds__(1024) void zs_resolve_kernel(const StreamDesc *sd, 
                     // filled in afterwards, one lane per group
                     const int g = i / kSegGroup;
                     const uint2 e = gmap[g * kSlots + slot];
-                    if (!(e.x & 0x8000u)) {
+                    if (!(e.x & attn)) {
                         g_slot[g] = slot, g_base[g] = total, g_fast[g] = 1;
                         slot = (int)(e.x & 0x1FF);
                         total += e.y;
@@ -1533,7 +1547,10 @@ __global__ __launch_bounds__(1024) void zs_resolve_kernel(const StreamDesc *sd, 
                 if (i >= nrow) break;
                 const uint2 v = rows[i * kSlots + cur];
                 const uint32_t m = row_meta[i];
-                if ((m & 1u) && (uint32_t)(cur <= 256 ? cur : 0) <= (m >> 2)) kf = seg0 + i, ks = cur;
+                if ((m & 1u) && (uint32_t)(cur <= 256 ? cur : 0) <= (m >> 2)) {
+                    kf = seg0 + i, ks = cur;
+                    if (dry && (v.x & kMapEqualBit) && strategy != kHuffmanOnly) collect_cuts(seg0 + i, cur, 0, row_cs[i]);
+                }
                 out_slot[i] = (uint16_t)cur;
                 out_base[i] = total;
                 cur = (int)(v.x & 0x1FF);
@@ -1574,25 +1591,25 @@ __global__ __launch_bounds__(1024) void zs_resolve_kernel(const StreamDesc *sd, 
     if (dry && !sh_poison) {
         // this pass's cuts against the pass before: the same cuts mean the records they were repaired for are the ones this
         // pass walked -- the stream is resolved; else the first cut that differs says from where to repair again
-        const int cur = cut_iter & 1, ncur = sh_nc, nold = cut_iter == 0 ? 0 : ss.nc[cur ^ 1];
+        const int cur = cut_iter & 1;
         const int32_t *a = cut_pos + (size_t)cur * (size_t)cut_stride + s.cut_off, *b = cut_pos + (size_t)(cur ^ 1) * (size_t)cut_stride + s.cut_off;
-        const int nmin = ncur < nold ? ncur : nold;
+        uint32_t *cbw = cut_bkt + (size_t)cur * (size_t)cut_stride + s.cut_off;
         __threadfence_block();
         __syncthreads();
-        {
-            uint32_t *cbw = cut_bkt + (size_t)cur * (size_t)cut_stride + s.cut_off;
-            for (int i = threadIdx.x; i < ncur && i < s.cut_cap; i += blockDim.x) cbw[i] = acc.bucket(a[i]);
+        for (int i = threadIdx.x; i < cl_cap; i += blockDim.x) {
+            const int32_t e = a[i];
+            if (e >= 0) cbw[i] = acc.bucket(e);  // the cuts' buckets, for the repairs (a later cut of a bucket hides an earlier one)
+            if (e != b[i]) atomicMin(&sh_diff, i);
         }
-        for (int i = threadIdx.x; i < nmin; i += blockDim.x)
-            if (a[i] != b[i]) atomicMin(&sh_diff, i);
         __syncthreads();
         if (threadIdx.x == 0) {
-            const int di = sh_diff < nmin ? sh_diff : nmin;
-            const bool same = cut_iter > 0 && ncur == nold && sh_diff >= nmin;
+            const int di = sh_diff < cl_cap ? sh_diff : cl_cap;
             int64_t dp = 0x7FFFFFFF;
-            if (di < ncur) dp = a[di];
-            if (di < nold && b[di] < dp) dp = b[di];
-            ss.nc[cur] = ncur, ss.cuts_same = same ? 1 : 0, ss.cut_diff_idx = di, ss.cut_diff_pos = (int32_t)dp;
+            if (di < cl_cap) {
+                if (a[di] >= 0) dp = a[di];
+                if (b[di] >= 0 && b[di] < dp) dp = b[di];
+            }
+            ss.nc[cur] = cl_cap, ss.cuts_same = di >= cl_cap ? 1 : 0, ss.cut_diff_idx = di, ss.cut_diff_pos = (int32_t)dp;
         }
     }
     if (sh_poison) {
@@ -1673,6 +1690,7 @@ __global__ __launch_bounds__(NT) void zs_cuts_repair_kernel(const StreamDesc *sd
     const int32_t *cl = cut_pos + (size_t)cur * (size_t)cut_stride + s.cut_off;
     const uint32_t *cb = cut_bkt + (size_t)cur * (size_t)cut_stride + s.cut_off;
     const int64_t e = cl[j], dp = ss.cut_diff_pos;
+    if (e < 0) return;  // no cut in this slot
     int64_t full = e + kMaxDist;
     if (full > s.body_end) full = s.body_end;
     const int64_t from = e > dp ? e : dp;  // the records up to the first changed cut were not restored
@@ -1691,7 +1709,8 @@ __global__ __launch_bounds__(256) void zs_cuts_apply_kernel(const StreamDesc *sd
     if (ss.deferred != 1 || !ss.cuts_same) return;
     const int cur = cut_iter & 1, nc = ss.nc[cur];
     const int32_t *cl = cut_pos + (size_t)cur * (size_t)cut_stride + s.cut_off;
-    for (int i = threadIdx.x; i < nc; i += 256) link[s.pos_off + cl[i]] = 0;
+    for (int i = threadIdx.x; i < nc; i += 256)
+        if (cl[i] >= 0) link[s.pos_off + cl[i]] = 0;
     __syncthreads();
     if (threadIdx.x == 0) ss.deferred = 0, ss.r_scan = 0;
 }
