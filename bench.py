@@ -12,8 +12,13 @@ also measures the other BASELINE configs and the caller-visible paths and report
     inflate1g                 config 5: 16 x 64 MiB level-6 streams (seeds 0..15) -> 1 GiB, compared on the device
     host_path                 H2D + pipeline + D2H through zs_deflate_batch, pageable and pinned host memory
     stream_api                the C++ mirror of ZlibOutputStream / ZlibInputStream with the reference's 512-byte loop
-N > 1: config 4 -- the 1024 x 1 MiB batch is partitioned over the ranks (zs_partition, the library's own; no
-collective in the data path) and `value` is total input bytes / max-over-ranks time: strong scaling.
+    corpus_L1 / _L3 / _L6     config 1: the 11 Canterbury files as one batch, sizes against the reference's published ones, the CPU
+                              path file by file beside them (and the reference's own published MB/s)
+N > 1: the same headline -- one 64 MiB buffer per GPU (weak scaling: `value` is N buffers / max-over-ranks time, so the
+values of N = 1, 2, 4, 8 are one curve) -- and, in the same line under `sharded_batch1024`, BASELINE config 4: the
+1024 x 1 MiB batch partitioned over the ranks (zs_partition, the library's own; no collective in the data path), total
+input bytes / max-over-ranks time (strong scaling), with the same batch timed on rank 0's GPU alone beside it
+(`n1_same_workload`).  `--workload batch` makes config 4 the headline at any N.
 """
 import argparse
 import ctypes
@@ -89,6 +94,82 @@ def cpu_baseline(data, level, budget_s=15.0, name="english64"):
                      % (len(sample), name, level, iters)}
     res.update(cpu_info())
     return res, out.raw[:n], len(sample)
+
+
+def cpu_baseline_streams(datas, level, budget_s=6.0):
+    """Independent buffers on the host's cores, one oracle stream per thread (the reference is single-threaded per
+    stream; ctypes releases the GIL): 1 thread and all usable cores, each for ~budget_s."""
+    import threading
+    L = oracle_lib()
+    out = {}
+    for label, nthreads in (("1_thread", 1), ("all_cores", max(1, len(os.sched_getaffinity(0))))):
+        done = [0] * nthreads
+        t_end = time.perf_counter() + budget_s
+
+        def work(j):
+            cap = max(len(d) for d in datas) + max(len(d) for d in datas) // 8 + 1024
+            buf = ctypes.create_string_buffer(cap)
+            i = j
+            while time.perf_counter() < t_end:
+                d = datas[i % len(datas)]
+                L.zso_compress_stream(d, len(d), None, 0, level, 0, 0, 0, buf, cap, None)
+                done[j] += len(d)
+                i += nthreads
+        t0 = time.perf_counter()
+        th = [threading.Thread(target=work, args=(j,)) for j in range(nthreads)]
+        [x.start() for x in th]
+        [x.join() for x in th]
+        dt = time.perf_counter() - t0
+        out[label] = {"value": round(sum(done) / dt / 1e6, 2), "unit": "MB/s", "cores": nthreads, "kind": "port",
+                      "sample": "%d bytes of the batch's buffers in turn, level %d, %.1f s" % (sum(done), level, dt)}
+    out.update(cpu_info())
+    return out
+
+
+# benchmarks.md (reference, .NET Core 3.1 on an i7-8650U, one thread): MB/s at levels 1 / 3 / 6 = input bytes / Mean
+PUBLISHED_MBPS = {"alice29.txt": (54.8, 36.9, 22.1), "asyoulik.txt": (40.8, 35.1, 22.8), "cp.html": (65.8, 60.0, 42.0),
+                  "fields.c": (59.5, 50.5, 42.5), "grammar.lsp": (64.0, 56.4, 39.8), "kennedy.xls": (98.0, 46.6, 14.7),
+                  "lcet10.txt": (55.9, 46.7, 23.0), "plrabn12.txt": (47.0, 33.7, 18.3), "ptt5": (185.4, 145.6, 52.6),
+                  "sum": (62.6, 48.7, 26.6), "xargs.1": (50.8, 44.8, 33.0)}
+CRLF_FILES = ("alice29.txt", "lcet10.txt", "plrabn12.txt")  # LF-normalised in the reference's checkout: the published sizes are CRLF's
+
+
+def secondary_corpus(eng, dev, level, steps, with_cpu=True):
+    """BASELINE config 1: the Canterbury corpus (DeflateCorpusBenchmark.cs:86-100), every file one stream, the 11 of them one
+    batch on the device; compressed sizes against benchmarks.md's Bytes column, the CPU path file by file beside it."""
+    cdir = os.path.join(ROOT, "tests", "golden", "corpus")
+    kat = json.load(open(os.path.join(ROOT, "tests", "golden", "kat_sizes.json")))
+    names = sorted(PUBLISHED_MBPS)
+    datas = []
+    for nm in names:
+        d = open(os.path.join(cdir, nm), "rb").read()
+        datas.append(d.replace(b"\n", b"\r\n") if nm in CRLF_FILES else d)
+    res, b = secondary_deflate(eng, dev, "Canterbury corpus: 11 files, one stream each, one batch", datas, level, steps)
+    col = {1: 0, 3: 1, 6: 2}[level]
+    L = oracle_lib() if with_cpu else None
+    files = {}
+    for i, nm in enumerate(names):
+        f = {"bytes": len(datas[i]), "compressed": int(b.out_lens[i]), "published_bytes": kat[nm][col], "published_dotnet_MBps": PUBLISHED_MBPS[nm][col]}
+        if L is not None:
+            cap = len(datas[i]) + len(datas[i]) // 8 + 1024
+            buf = ctypes.create_string_buffer(cap)
+            L.zso_compress_stream(datas[i], len(datas[i]), None, 0, level, 0, 0, 0, buf, cap, None)
+            reps, t0 = 0, time.perf_counter()
+            while reps < 3 or time.perf_counter() - t0 < 0.3:
+                n = L.zso_compress_stream(datas[i], len(datas[i]), None, 0, level, 0, 0, 0, buf, cap, None)
+                reps += 1
+            f["cpu_port_MBps"] = round(len(datas[i]) * reps / (time.perf_counter() - t0) / 1e6, 1)
+            f["bit_identical_to_cpu"] = bool(b.stream_bytes(i) == buf.raw[:n])
+        files[nm] = f
+    res["files"] = files
+    res["sizes_equal_published"] = all(f["compressed"] == f["published_bytes"] for f in files.values())
+    if L is not None:
+        tot = sum(f["bytes"] for f in files.values())
+        res["cpu_baseline"] = {"value": round(tot / sum(f["bytes"] / f["cpu_port_MBps"] for f in files.values()), 2), "unit": "MB/s", "cores": 1,
+                               "kind": "port", "sample": "the 11 files one after the other, level %d, >= 3 passes each" % level}
+        res["published_dotnet_MBps_aggregate"] = round(tot / sum(f["bytes"] / f["published_dotnet_MBps"] for f in files.values()), 2)
+    del b
+    return res
 
 
 def cpu_inflate_baseline(z, out_len):
@@ -315,7 +396,7 @@ def main():
     ap.add_argument("--level", type=int, default=6)
     ap.add_argument("--size", type=int, default=64 << 20)
     ap.add_argument("--workload", default=None, choices=["english64", "sparse64", "batch"],
-                    help="default: english64 at --gpus 1, the sharded 1024 x 1 MiB batch at --gpus N > 1")
+                    help="default: english64 (one 64 MiB buffer per GPU; at --gpus N > 1 the sharded 1024 x 1 MiB batch is measured beside it)")
     ap.add_argument("--buffers", type=int, default=BATCH_BUFFERS, help="--workload batch: buffers in the whole job")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="headline only")
@@ -339,7 +420,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     red_dev = dev if backend == "nccl" else torch.device("cpu")  # where the control plane's scalars live
-    workload = args.workload or ("english64" if world == 1 else "batch")
+    workload = args.workload or "english64"
 
     def barrier():
         if world > 1:
@@ -377,6 +458,35 @@ def main():
         dist.all_reduce(o)
         total_out = int(o.item())
     main_batch.check_roundtrip(max(1, len(datas) // 8))
+
+    # N > 1, default workload: BASELINE config 4 beside the headline -- the 1024 x 1 MiB batch partitioned over the ranks, and the
+    # same batch on rank 0's GPU alone (the N = 1 point of that workload, measured in this very run)
+    sharded = None
+    if world > 1 and workload == "english64" and not args.no_secondary:
+        ssteps = max(2, min(args.steps, 5))
+        n1 = None
+        if rank == 0:
+            allb = DeviceBatch(eng, dev, [datagen.batch_buffer(i, BATCH_BYTES) for i in range(args.buffers)])
+            dt1, _ = allb.timed(args.level, ssteps, 1)
+            n1 = {"value": round(allb.n * ssteps / dt1 / 1e6, 2), "unit": "MB/s", "ms_per_step": round(dt1 / ssteps * 1e3, 3), "steps": ssteps,
+                  "n_gpus": 1}
+            del allb
+            torch.cuda.empty_cache()
+        barrier()
+        mine = partition([BATCH_BYTES] * args.buffers, world)[rank]
+        sb = DeviceBatch(eng, dev, [datagen.batch_buffer(i, BATCH_BYTES) for i in mine])
+        dts, _ = sb.timed(args.level, ssteps, 1, barrier)
+        t = torch.tensor([dts], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        g = torch.tensor([sb.n], dtype=torch.int64, device=red_dev)
+        dist.all_reduce(g)
+        sb.check_roundtrip(max(1, len(mine) // 4))
+        sharded = {"workload": "batch%d: %d x %d-byte alternating english / sparse-row buffers partitioned over %d GPUs by size (zs_partition), "
+                               "level %d" % (args.buffers, args.buffers, BATCH_BYTES, world, args.level),
+                   "value": round(int(g.item()) * ssteps / float(t.item()) / 1e6, 2), "unit": "MB/s", "n_gpus": world, "scaling": "strong",
+                   "ms_per_step": round(float(t.item()) / ssteps * 1e3, 3), "steps": ssteps, "buffers_rank0": len(mine), "n1_same_workload": n1}
+        del sb
+        torch.cuda.empty_cache()
 
     pipelined = None
     if world == 1 and args.inflight > 1:
@@ -440,6 +550,8 @@ def main():
             line["config"]["shard"] = shard_note
         if pipelined:
             line["pipelined"] = pipelined
+        if sharded:
+            line["sharded_batch1024"] = sharded
         if world == 1:
             data = datas[0]
             if not args.no_cpu_baseline:  # the CPU leg runs on rank 0 of the single-GPU run only
@@ -457,12 +569,21 @@ def main():
                 sp = datagen.sparse(4096, 4096)
                 for lvl in (1, 6, 9):
                     sec["sparse64_L%d" % lvl], b = secondary_deflate(eng, dev, "sparse64: 4096 x 4096 RGBA of GetImageBytes, 1 x 64 MiB", [sp], lvl, ks)
+                    if not args.no_cpu_baseline:
+                        cbs, refs, slen = cpu_baseline(sp, lvl, budget_s=4.0, name="sparse64")
+                        sec["sparse64_L%d" % lvl]["cpu_baseline"] = cbs
+                        if slen == len(sp):
+                            sec["sparse64_L%d" % lvl]["bit_identical_to_cpu"] = bool(b.stream_bytes(0) == refs)
                     del b
                 bufs = [datagen.batch_buffer(i, BATCH_BYTES) for i in range(BATCH_BUFFERS)]
                 sec["batch1024_L6"], b = secondary_deflate(eng, dev, "batch1024: 1024 x 1 MiB alternating english / sparse-row buffers on ONE GPU "
                                                            "(the N = 1 point of the --gpus N workload)", bufs, 6, ks, check_every=64)
+                if not args.no_cpu_baseline:
+                    sec["batch1024_L6"]["cpu_baseline"] = cpu_baseline_streams(bufs[:64], 6)
                 del b, bufs
                 torch.cuda.empty_cache()
+                for lvl in (1, 3, 6):
+                    sec["corpus_L%d" % lvl] = secondary_corpus(eng, dev, lvl, ks, with_cpu=not args.no_cpu_baseline)
                 sec["inflate1g"] = secondary_inflate(eng, dev, ks)
                 torch.cuda.empty_cache()
                 sec["host_path"] = secondary_host_path(eng, data, args.level)

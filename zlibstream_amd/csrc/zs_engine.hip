@@ -46,7 +46,7 @@ struct zs_ctx {
     int round_runs = 0;      // batches with streams in the batched cut rounds (their cuts were not one CU's job)
     int cut_rounds = 0;      // rounds of those
     int lit_fallbacks = 0;   // batches run again with a stream on the literal engine (zs_core.h kMapPoisonBit)
-    int last_op = 0;  // 0: deflate stages, 1: block-parallel inflate stages (for zs_ctx_stage_name)
+    int last_op = 0;  // 0: deflate stages, 1: block-parallel inflate stages, 2: deflate at levels 1-3 (for zs_ctx_stage_name)
     hipEvent_t ev[kStCount + 1] = {};
     double stage_ms[kStCount] = {};
     uint32_t *crc_tab = nullptr;
@@ -813,7 +813,7 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
     StreamState *hst = (StreamState *)c->pinned;
     ZS_HIP(c, hipMemcpyAsync(hst, d_st, sizeof(StreamState) * (size_t)n, hipMemcpyDeviceToHost, stream));
     ZS_HIP(c, hipStreamSynchronize(stream));
-    c->last_op = 0;
+    c->last_op = lv.func == 1 ? 2 : 0;
     if (prof) {
         for (int i = 0; i < kStCount; i++) {
             float ms = 0;
@@ -913,6 +913,28 @@ bool device_adlers(zs_ctx *c, int m, const void *const *bufs, const int64_t *len
         if (ok) ok[i] = (int)hres[i].y;
     }
     return true;
+}
+
+// The longest run of streams from `lo` on whose device memory -- per input byte: `per_byte` bytes of workspace (and staging),
+// plus the output capacity when it is staged -- fits what the device has free now plus what the context already holds (its
+// buffers are reused); at least one stream.
+int batch_prefix_that_fits(zs_ctx *c, int n, const int64_t *in_len, const int64_t *out_cap, int lo, int per_byte) {
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return n;
+    const DevBuf *held[] = {&c->link, &c->mm, &c->maps, &c->segmap, &c->supmap, &c->syms, &c->trees, &c->blocks, &c->info, &c->stage_in, &c->stage_out,
+                            &c->scratch, &c->fv_lists, &c->ins_bits, &c->mm_bak};
+    size_t have = 0;
+    for (const DevBuf *b : held) have += b->cap;
+    const double budget = 0.85 * ((double)free_b + (double)have);
+    double need = 0;
+    int hi = lo;
+    while (hi < n) {
+        const double add = (double)in_len[hi] * per_byte + (per_byte > 18 ? (double)out_cap[hi] : 0.0) + 4.0e6;
+        if (hi > lo && need + add > budget) break;
+        need += add;
+        hi++;
+    }
+    return hi;
 }
 
 bool check_args(zs_ctx *c, int n, const int64_t *in_len, int level, int strategy) {
@@ -1045,6 +1067,10 @@ int zs_ctx_stage_count(const zs_ctx *) { return kStCount; }
 const char *zs_ctx_stage_name(const zs_ctx *c, int s) {
     static const char *const inf_names[6] = {"inf_find", "inf_measure", "inf_chain", "inf_decode", "inf_windows", "inf_resolve"};
     if (c && c->last_op == 1) return s >= 0 && s < 6 ? inf_names[s] : "";
+    // levels 1-3: DeflateFast for the lanes of a wave runs where the lazy parse has its expand stage, and the speculative
+    // chunk runs (run / verify / stitch) are timed with the tail engine
+    if (c && c->last_op == 2 && s == kStExpand) return "fast_vec";
+    if (c && c->last_op == 2 && s == kStTail) return "fast_runs+tail";
     return s >= 0 && s < kStCount ? kStageNames[s] : "";
 }
 double zs_ctx_stage_ms(const zs_ctx *c, int s) { return c && s >= 0 && s < kStCount ? c->stage_ms[s] : 0.0; }
@@ -1056,9 +1082,17 @@ int zs_deflate_batch_device(zs_ctx *c, int n, const void *const *in, const int64
     if (n == 0) return ZS_OK;
     if (hipSetDevice(c->device) != hipSuccess) return ZS_STREAM_ERROR;
     hipStream_t s = hip_stream ? (hipStream_t)hip_stream : c->stream;
-    if (!run_pipeline(c, n, in, in_len, out, out_cap, out_len, status, level, strategy, hash_variant, s))
-        return c->err == "buffer error" ? ZS_BUF_ERROR : ZS_STREAM_ERROR;
-    return ZS_OK;
+    // a batch whose workspace (~17 bytes per input byte) does not fit the device's free memory runs in sub-batches: the
+    // streams are independent, the bytes the same
+    int rc = ZS_OK;
+    for (int lo = 0; lo < n;) {
+        const int hi = batch_prefix_that_fits(c, n, in_len, out_cap, lo, 18);
+        if (!run_pipeline(c, hi - lo, in + lo, in_len + lo, out + lo, out_cap + lo, out_len + lo, status ? status + lo : nullptr, level, strategy,
+                          hash_variant, s) && rc == ZS_OK)
+            rc = c->err == "buffer error" ? ZS_BUF_ERROR : ZS_STREAM_ERROR;
+        lo = hi;
+    }
+    return rc;
 }
 
 int zs_deflate_writes_device(zs_ctx *c, const void *in, int64_t in_len, const int64_t *write_ends, int64_t n_writes, void *out,
@@ -1087,11 +1121,9 @@ int zs_deflate_writes_device(zs_ctx *c, const void *in, int64_t in_len, const in
     return ZS_OK;
 }
 
-int zs_deflate_batch(zs_ctx *c, int n, const void *const *in, const int64_t *in_len, void *const *out, const int64_t *out_cap,
-                     int64_t *out_len, int *status, int level, int strategy, int hash_variant) {
-    if (!check_args(c, n, in_len, level, strategy)) return ZS_STREAM_ERROR;
-    if (n == 0) return ZS_OK;
-    if (hipSetDevice(c->device) != hipSuccess) return ZS_STREAM_ERROR;
+namespace {
+int deflate_batch_host_once(zs_ctx *c, int n, const void *const *in, const int64_t *in_len, void *const *out, const int64_t *out_cap,
+                            int64_t *out_len, int *status, int level, int strategy, int hash_variant) {
     std::vector<const void *> din((size_t)n);
     std::vector<void *> dout((size_t)n);
     std::vector<int64_t> dcap((size_t)n);
@@ -1131,6 +1163,27 @@ int zs_deflate_batch(zs_ctx *c, int n, const void *const *in, const int64_t *in_
         return first_err == "buffer error" ? ZS_BUF_ERROR : ZS_STREAM_ERROR;
     }
     return ZS_OK;
+}
+}  // namespace
+
+int zs_deflate_batch(zs_ctx *c, int n, const void *const *in, const int64_t *in_len, void *const *out, const int64_t *out_cap,
+                     int64_t *out_len, int *status, int level, int strategy, int hash_variant) {
+    if (!check_args(c, n, in_len, level, strategy)) return ZS_STREAM_ERROR;
+    if (n == 0) return ZS_OK;
+    if (hipSetDevice(c->device) != hipSuccess) return ZS_STREAM_ERROR;
+    // a batch that does not fit the device (staging for the inputs and outputs + ~17 bytes of workspace per input byte) runs
+    // in sub-batches, one after the other through the same buffers: the streams are independent, the bytes the same
+    int rc = ZS_OK;
+    std::string first_err;
+    for (int lo = 0; lo < n;) {
+        const int hi = batch_prefix_that_fits(c, n, in_len, out_cap, lo, 19);
+        const int r = deflate_batch_host_once(c, hi - lo, in + lo, in_len + lo, out + lo, out_cap + lo, out_len + lo, status ? status + lo : nullptr, level,
+                                              strategy, hash_variant);
+        if (r != ZS_OK && rc == ZS_OK) rc = r, first_err = c->err;
+        lo = hi;
+    }
+    if (rc != ZS_OK) c->err = first_err;
+    return rc;
 }
 
 int zs_adler32_device(zs_ctx *c, const void *d_buf, int64_t len, uint32_t seed, uint32_t *out, void *hip_stream) {
