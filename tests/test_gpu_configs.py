@@ -142,6 +142,29 @@ def test_batch_multi_two_contexts_matches_single_context_and_oracle(engine, orac
         e2.close()
 
 
+def test_a_batch_larger_than_the_device_runs_in_sub_batches(engine, oracle):
+    """A host batch whose staging and workspace (~19 bytes per input byte) exceed the device's memory -- 24 GiB of input: 300
+    zero buffers and 84 text buffers of 64 MiB, the same two host buffers passed again and again -- is split into
+    sub-batches by zs_deflate_batch itself (the streams are independent); the bytes are those of the buffers alone, which are
+    the oracle's (a 4 MiB prefix compared here, the whole stream by its inflation)."""
+    import zlib
+    size = 64 << 20
+    text, zeros = datagen.english(size, 77), bytes(size)
+    one = engine.deflate_batch([text, zeros], level=6)
+    assert zlib.decompress(one[0]) == text and zlib.decompress(one[1]) == zeros
+    assert engine.deflate_batch([text[:4 << 20]], level=6)[0] == oracle.compress(text[:4 << 20], 6)
+    kt, kz = ctypes.create_string_buffer(text, size), ctypes.create_string_buffer(zeros, size)
+    n = 384
+    is_text = [i % 32 < 7 for i in range(n)]  # 84 text streams among the 384
+    caps = [deflate_bound(size) if t else 1 << 20 for t in is_text]
+    outs = [ctypes.create_string_buffer(c) for c in caps]
+    rc, lens, status = engine._call_batch(engine._lib.zs_deflate_batch, [ctypes.addressof(kt if t else kz) for t in is_text], [size] * n,
+                                          [ctypes.addressof(o) for o in outs], caps, 6, 0, 0)
+    assert rc == 0 and all(x == 0 for x in status), (rc, engine.last_error())
+    for i in range(n):
+        assert outs[i].raw[:lens[i]] == (one[0] if is_text[i] else one[1]), i
+
+
 def test_batch_reports_every_stream_when_one_fails(engine, oracle):
     """One undersized output in a batch: that stream is ZBUFERROR, the others are delivered with their lengths."""
     bufs = [oracle_binding.corpus("sum"), oracle_binding.corpus("kennedy.xls"), oracle_binding.corpus("cp.html")]

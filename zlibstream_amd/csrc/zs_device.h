@@ -102,6 +102,7 @@ constexpr int kFvBitWords = kFvLinks / 32 + 8;  // the tile may start 16 positio
 constexpr int kFvLds = kFvBytes + 2 * kFvLinks + 4 * kFvBitWords + 8192;  // + the first 16 list entries per lane of the window and of the 64 positions behind it
 // candidate-list entries per position (zs_fast_vec_kernel): enough for most searches of the level -- max_chain candidates
 // among the ~45 % of a chain that was inserted -- in multiples of 16; a longer search walks on through the staged links
+constexpr int kFvQuitWalk = 96;  // walk steps per window behind the lists' ends beyond which a stream is left to the literal engine
 ZS_HD int fv_list_entries(int max_chain) { return max_chain <= 4 ? 16 : max_chain <= 8 ? 32 : 96; }
 // the last tile of a stream stages bitmap words for up to kFvTile + 256 positions past its loop-top, i.e. past the stream's end:
 // the bitmap array carries that much room behind the last stream

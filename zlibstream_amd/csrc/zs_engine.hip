@@ -925,11 +925,11 @@ int batch_prefix_that_fits(zs_ctx *c, int n, const int64_t *in_len, const int64_
                             &c->scratch, &c->fv_lists, &c->ins_bits, &c->mm_bak};
     size_t have = 0;
     for (const DevBuf *b : held) have += b->cap;
-    const double budget = 0.85 * ((double)free_b + (double)have);
+    const double budget = 0.55 * ((double)free_b + (double)have);  // (the buffers are grown with an eighth of headroom each)
     double need = 0;
     int hi = lo;
     while (hi < n) {
-        const double add = (double)in_len[hi] * per_byte + (per_byte > 18 ? (double)out_cap[hi] : 0.0) + 4.0e6;
+        const double add = (double)in_len[hi] * per_byte + (per_byte > 19 ? (double)out_cap[hi] : 0.0) + 4.0e6;
         if (hi > lo && need + add > budget) break;
         need += add;
         hi++;
@@ -1086,7 +1086,7 @@ int zs_deflate_batch_device(zs_ctx *c, int n, const void *const *in, const int64
     // streams are independent, the bytes the same
     int rc = ZS_OK;
     for (int lo = 0; lo < n;) {
-        const int hi = batch_prefix_that_fits(c, n, in_len, out_cap, lo, 18);
+        const int hi = batch_prefix_that_fits(c, n, in_len, out_cap, lo, 19);
         if (!run_pipeline(c, hi - lo, in + lo, in_len + lo, out + lo, out_cap + lo, out_len + lo, status ? status + lo : nullptr, level, strategy,
                           hash_variant, s) && rc == ZS_OK)
             rc = c->err == "buffer error" ? ZS_BUF_ERROR : ZS_STREAM_ERROR;
@@ -1176,7 +1176,7 @@ int zs_deflate_batch(zs_ctx *c, int n, const void *const *in, const int64_t *in_
     int rc = ZS_OK;
     std::string first_err;
     for (int lo = 0; lo < n;) {
-        const int hi = batch_prefix_that_fits(c, n, in_len, out_cap, lo, 19);
+        const int hi = batch_prefix_that_fits(c, n, in_len, out_cap, lo, 20);
         const int r = deflate_batch_host_once(c, hi - lo, in + lo, in_len + lo, out + lo, out_cap + lo, out_len + lo, status ? status + lo : nullptr, level,
                                               strategy, hash_variant);
         if (r != ZS_OK && rc == ZS_OK) rc = r, first_err = c->err;

@@ -2515,7 +2515,7 @@ __global__ __launch_bounds__(1024) void zs_fast_vec_kernel(const StreamDesc *sd,
     uint32_t *pre0 = ent0 + 1024;       // the same for the 64 positions behind the window, asked for a window ahead
     uint32_t *lists = lists_g + s.fv_list_off;
     __shared__ int64_t sh_p, sh_nsyms, sh_trigger, sh_preins;
-    __shared__ int sh_k;
+    __shared__ int sh_k, sh_quit;
     const int tid = threadIdx.x, lane = lane_id();
     const int64_t n = s.n, body_end = s.fv_end;
     const gcbytes in = as_global(s.in);
@@ -2523,7 +2523,7 @@ __global__ __launch_bounds__(1024) void zs_fast_vec_kernel(const StreamDesc *sd,
     uint32_t *gbits = s.ins_bits;
     // read events of a single Write (zs_core.h): event k fires at the first loop-top >= E(k) - 261, E(k) = 64 Ki + 32 Ki (k - 1)
     const int kl = s.kl;
-    if (tid == 0) sh_p = 0, sh_nsyms = 0, sh_k = 0, sh_preins = -1, sh_trigger = kl >= 1 ? read_end_before(1) - (kMinLookahead - 1) : -1;
+    if (tid == 0) sh_p = 0, sh_nsyms = 0, sh_k = 0, sh_quit = 0, sh_preins = -1, sh_trigger = kl >= 1 ? read_end_before(1) - (kMinLookahead - 1) : -1;
     __syncthreads();
     const bool aligned = (((uintptr_t)in) & 15) == 0;
 #ifdef ZS_FV_PROF
@@ -2536,7 +2536,7 @@ __global__ __launch_bounds__(1024) void zs_fast_vec_kernel(const StreamDesc *sd,
 #endif
     for (;;) {
         const int64_t p_in = sh_p;
-        if (p_in > body_end) break;
+        if (p_in > body_end || sh_quit) break;
         const int64_t t0 = p_in & ~31LL, lo = t0 - kFvBack, bw0 = lo >> 5;  // lo is a multiple of 32: bitmap words line up
         PF_T0();
         // ---- stage the tile
@@ -2621,6 +2621,7 @@ __global__ __launch_bounds__(1024) void zs_fast_vec_kernel(const StreamDesc *sd,
             // an equal-bucket event of this tile cuts the chain behind its loop-top (below); the lists were made before: an entry
             // at the cut is the last one of its list that counts
             int cut_i = -1;
+            long tile_walk = 0, tile_windows = 0;  // steps of the walks behind the lists' ends, windows
             // the first 16 entries of the positions [pf_base, pf_base + 64) wait in pre0: a lane's loads from the list area are a
             // round trip to L2 (~2 us per window when every window paid it); the loads for the positions behind a window leave at
             // its start and land in pre0 at its end, and the next window -- which starts there or a few positions on --
@@ -2720,6 +2721,7 @@ __global__ __launch_bounds__(1024) void zs_fast_vec_kernel(const StreamDesc *sd,
 #ifdef ZS_FV_PROF
                             pf_iters++;
 #endif
+                            tile_walk++;
                             const int nc = c - l, d = qi - nc;
                             const int maxd = found ? kMaxDist - 1 : kMaxDist;
                             const int valid = (done == 0) & (l != 0) & (nc >= min_i) & (d <= maxd);
@@ -2842,6 +2844,7 @@ __global__ __launch_bounds__(1024) void zs_fast_vec_kernel(const StreamDesc *sd,
                             const uint64_t s8 = lds_u64(wb, qa);
                             int c = qa - ulast;
                             for (;;) {
+                                tile_walk++;
                                 const int l = wl[c];
                                 const int nc = c - l, d = qa - nc;
                                 if (l == 0 || nc < min_i || d > (ufound ? kMaxDist - 1 : kMaxDist)) break;
@@ -2894,11 +2897,18 @@ __global__ __launch_bounds__(1024) void zs_fast_vec_kernel(const StreamDesc *sd,
                 }
                 nsyms += __builtin_popcountll(tops);
                 p0 += advance;
+                tile_windows++;
                 PF_ADD(pf_emit);
 #ifdef ZS_FV_PROF
                 pf_windows++;
 #endif
             }
+            // Data whose matches are long inserts little (Deflate.Fast.cs:81-104), and a search then walks hundreds of chain
+            // entries that were never inserted to find max_chain that were: the lists and the walks behind them are the wrong
+            // tool there (kennedy.xls: 0.2 MB/s).  The literal engine, whose prev[] holds the inserted positions only, is not
+            // fast but it is steady: a tile whose windows needed more than kFvQuitWalk steps each hands the rest of the
+            // stream to it (the tail kernel goes on from any loop-top; it restores its chains from the bitmap).
+            if (tile_windows > 16 && tile_walk > (long)kFvQuitWalk * tile_windows) sh_quit = 1;
             // ---- leave the tile: the bitmap words that changed go back to the stream's bitmap
             for (int64_t wd = (p_in >> 5) + lane; wd <= (p0 + 96) >> 5; wd += 64)
                 if (wd - bw0 < kFvBitWords) gbits[wd] = bm[wd - bw0];
