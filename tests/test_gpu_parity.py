@@ -273,6 +273,26 @@ def test_zlib_input_stream_mirror(engine):
     assert s.read(10) == b""  # past the end of the stream
 
 
+def test_zlib_input_stream_ends_with_the_stream_whatever_follows(engine):
+    """Inflate.Decompress ends at the final block's Adler trailer (Inflate.cs:292-357) and ZlibInputStream.ReadCore stops
+    there (ZlibInputStream.cs:133-186): bytes behind the stream in BaseStream are not the stream's.  zs_inflate looks for the
+    end in what it has buffered as the input arrives: the payload is returned, TotalIn is the stream's length, and a long
+    stream is delivered before BaseStream has been read to its end."""
+    from zlibstream_amd import ZlibInputStream
+    rng = np.random.default_rng(3)
+    garbage = rng.integers(0, 256, 1 << 20, dtype=np.uint8).tobytes()
+    for d in (oracle_binding.corpus("asyoulik.txt"), datagen.english(8 << 20, 5), b"", b"x" * 70000):
+        z = engine.deflate_batch([d], level=6)[0]
+        for tail in (garbage, z, b"\0" * 5000):
+            base = io.BytesIO(z + tail)
+            s = ZlibInputStream(base, engine=engine)
+            assert s.read() == d
+            assert s.TotalIn == len(z) and s.TotalOut == len(d) and s.Adler == zlib.adler32(d)
+            assert s.read(10) == b""
+            if len(z) >= (1 << 20) and len(tail) >= (1 << 20):
+                assert base.tell() < len(z) + len(tail)   # the end was found before BaseStream ran out
+
+
 def test_zs_inflate_stream_protocol(engine):
     """zs_inflate under the ReadCore cadence (8 KiB input chunks, caller-sized output): several sizes incl. a stream
     that expands ~1000x (output buffer grown on the device side), a truncated stream (ZBUFERROR, as the managed engine

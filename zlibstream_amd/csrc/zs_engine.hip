@@ -46,6 +46,10 @@ struct zs_ctx {
     int round_runs = 0;      // batches with streams in the batched cut rounds (their cuts were not one CU's job)
     int cut_rounds = 0;      // rounds of those
     int lit_fallbacks = 0;   // batches run again with a stream on the literal engine (zs_core.h kMapPoisonBit)
+    // inflate: compressed bytes each stream of the last call used, trailer included (0: unknown / not ended); and, for a
+    // probing call (zs_inflate asking whether the stream's end has arrived), where the block chain ended
+    std::vector<int64_t> inf_used;
+    int64_t *inf_probe = nullptr;
     int last_op = 0;  // 0: deflate stages, 1: block-parallel inflate stages, 2: deflate at levels 1-3 (for zs_ctx_stage_name)
     hipEvent_t ev[kStCount + 1] = {};
     double stage_ms[kStCount] = {};
@@ -1237,6 +1241,7 @@ bool run_inflate_seq(zs_ctx *c, int n, const void *const *in, const int64_t *in_
     std::vector<int> aidx;
     for (int i = 0; i < n; i++)
         if (st[(size_t)i].status == ZS_STREAM_END) abuf.push_back(out[i]), alen.push_back(st[(size_t)i].out_len), aidx.push_back(i);
+    if (c->inf_probe == nullptr && n == 1) c->inf_used.assign(1, st[0].status == ZS_STREAM_END ? st[0].in_used : 0);
     std::vector<uint32_t> ads(abuf.size(), 1u);
     if (!device_adlers(c, (int)abuf.size(), abuf.data(), alen.data(), nullptr, ads.data(), nullptr, stream)) return false;
     for (size_t k = 0; k < aidx.size(); k++) {
@@ -1279,7 +1284,8 @@ bool run_inflate_par(zs_ctx *c, const std::vector<int> &idx, const void *const *
         p.blk_off = (int32_t)nblk, p.max_blk = (int32_t)(in_len[i] / 256 + 64);
         nblk += p.max_blk;
         p.cell_off = ncells;
-        ncells += (out_cap[i] + 63) & ~63LL;
+        if (c->inf_probe) p.out_cap = (int64_t)0x7FFFFFFF - 1024;  // a probing call decodes nothing: any output size is fine
+        else ncells += (out_cap[i] + 63) & ~63LL;
         for (int k = 0; k < p.nchunks; k++) w_find.push_back(make_uint2((unsigned)j, (unsigned)k));
     }
     if (!ensure(c, c->par_ps, sizeof(ParStream) * (size_t)m) || !ensure(c, c->par_st, sizeof(ParState) * (size_t)m) ||
@@ -1342,6 +1348,13 @@ bool run_inflate_par(zs_ctx *c, const std::vector<int> &idx, const void *const *
     mark(3);
     ZS_HIP(c, hipMemcpyAsync(st.data(), d_st, sizeof(ParState) * (size_t)m, hipMemcpyDeviceToHost, stream));
     ZS_HIP(c, hipStreamSynchronize(stream));
+    if (c->inf_probe) {
+        // a probing call (zs_inflate: has the stream's end arrived?): the chain of blocks reached a final block and its
+        // trailer lies inside the bytes -- or not yet; nothing is decoded
+        const int64_t tb = (st[0].end_bit + 7) >> 3;
+        *c->inf_probe = (m == 1 && st[0].ok && tb + 4 <= in_len[idx[0]]) ? tb + 4 : 0;
+        return true;
+    }
     w.clear();
     // windows are laid out by the block counts the chain found (not by the per-stream bounds the other tables use)
     int64_t total_blk = 0;
@@ -1447,6 +1460,7 @@ bool run_inflate_par(zs_ctx *c, const std::vector<int> &idx, const void *const *
         const int j = aidx[k], i = idx[(size_t)j];
         out_len[i] = st[(size_t)j].out_len;
         status[i] = ZS_STREAM_END;
+        if (m == 1) c->inf_used.assign(1, ((st[(size_t)j].end_bit + 7) >> 3) + 4);
         if (adler_out) adler_out[i] = ads[k];
         if (!aok[k]) {
             status[i] = ZS_DATA_ERROR;
