@@ -1131,6 +1131,14 @@ size_t zso_compress_bound(size_t n) { return n + (n >> 10) * 8 + 1024; }
 size_t zso_compress_stream(const uint8_t *in, size_t n, const size_t *chunk_lens, size_t n_chunks, int level,
                            int strategy, int flush_mode, int hash_variant, uint8_t *out, size_t out_cap,
                            const zso_trace *trace) {
+    return zso_compress_stream_modes(in, n, chunk_lens, n_chunks, level, strategy, flush_mode, NULL, hash_variant, out, out_cap, trace);
+}
+
+/* the same with ZlibOptions.FlushMode set anew before every Write (the property is read by every WriteCore,
+ * ZlibOutputStream.cs:140): flush_modes[i] is the mode of Write i; NULL: flush_mode for all of them */
+size_t zso_compress_stream_modes(const uint8_t *in, size_t n, const size_t *chunk_lens, size_t n_chunks, int level,
+                                 int strategy, int flush_mode_all, const int *flush_modes, int hash_variant, uint8_t *out, size_t out_cap,
+                                 const zso_trace *trace) {
     zso_deflate *s = zso_deflate_new(level, strategy, 15, 8, hash_variant);
     if (!s) return (size_t)-1;
     if (trace) zso_deflate_set_trace(s, trace);
@@ -1149,6 +1157,7 @@ size_t zso_compress_stream(const uint8_t *in, size_t n, const size_t *chunk_lens
         s->next_in = in + off;
         s->avail_in = (int)len;
         off += len;
+        const int flush_mode = flush_modes ? flush_modes[c] : flush_mode_all;
         do {
             s->next_out = chunk;
             s->avail_out = (int)sizeof chunk;

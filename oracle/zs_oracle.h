@@ -96,6 +96,11 @@ size_t zso_compress_stream(const uint8_t *in, size_t n, const size_t *chunk_lens
                            int strategy, int flush_mode, int hash_variant, uint8_t *out, size_t out_cap,
                            const zso_trace *trace);
 
+/* ... with ZlibOptions.FlushMode set anew before every Write: flush_modes[i] (NULL: flush_mode_all for every Write) */
+size_t zso_compress_stream_modes(const uint8_t *in, size_t n, const size_t *chunk_lens, size_t n_chunks, int level,
+                                 int strategy, int flush_mode_all, const int *flush_modes, int hash_variant, uint8_t *out, size_t out_cap,
+                                 const zso_trace *trace);
+
 size_t zso_compress_bound(size_t n);
 
 /* Adler32.Calculate (Adler32.cs:61-78, scalar :270-326) */

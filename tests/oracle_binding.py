@@ -53,6 +53,21 @@ class Oracle:
             raise RuntimeError("oracle deflate failed")
         return out.raw[:n]
 
+    def compress_writes(self, data, level, strategy, chunks, flushes, hash_variant=0):
+        """One Write per chunk with ZlibOptions.FlushMode set to flushes[i] before it, then Finish."""
+        data = bytes(data)
+        cap = len(data) + len(data) // 8 + 1024 + 64 * len(chunks)
+        out = ctypes.create_string_buffer(cap)
+        arr = (ctypes.c_size_t * len(chunks))(*chunks)
+        fl = (ctypes.c_int * len(chunks))(*flushes)
+        self.L.zso_compress_stream_modes.restype = ctypes.c_size_t
+        self.L.zso_compress_stream_modes.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int,
+                                                     ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_void_p]
+        n = self.L.zso_compress_stream_modes(data, len(data), arr, len(chunks), level, strategy, 0, fl, hash_variant, out, cap, None)
+        if n == ctypes.c_size_t(-1).value:
+            raise RuntimeError("oracle deflate failed")
+        return out.raw[:n]
+
     def adler32(self, data, seed=1):
         return self.L.zso_adler32(seed, bytes(data), len(data))
 

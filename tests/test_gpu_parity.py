@@ -565,6 +565,48 @@ def test_flush_modes_partial_sync_full(engine, oracle, flush):
 
 
 @pytest.mark.gpu
+def test_writes_behind_a_flush_go_back_to_the_bulk_path(engine, oracle):
+    """A stream that has flushed is incremental: its engine is kept suspended on the device.  A long Write behind the
+    flush runs the literal engine for a window's length -- past the positions the flush left in the chains under hashes
+    of bytes that were not there yet, and past what a FullFlush forgot -- and the bulk pipeline takes the parse over at a
+    clean loop-top (zs_engine.hip RunOpts::resume): bytes against the oracle (Deflate.cs:583-613 for the flush, the
+    WriteCore loop literally), and the time of 8 MiB Writes shows which path ran (the literal engine does 2 MB/s)."""
+    import time
+    text = datagen.english(20 << 20, datagen.GOLDEN)
+    low = np.random.default_rng(9).choice(np.array([0, 0, 0, 0, 1, 2, 255], dtype=np.uint8), 3 << 20).tobytes()
+    cases = [(text, [5000, 8 << 20, 1000, 8 << 20], [2, 0, 0, 0], 6), (text, [300000, 8 << 20, 70001, 3 << 20], [3, 2, 0, 1], 6),
+             (text[:6 << 20], [100, 3 << 20, 2 << 20], [1, 0, 2], 4), (low, [65536, 1 << 20, 1 << 20], [2, 2, 0], 9),
+             (low, [4096, 2 << 20], [3, 0], 6), (bytes(3 << 20), [1000, 2 << 20], [2, 0], 6),
+             (text[:5 << 20], [1000, 1 << 20, 16385, 1 << 20, 999, 1 << 20], [2, 0, 0, 0, 0, 0], 6)]
+    for data, sizes, flushes, level in cases:
+        chunks, fl, o = [], [], 0
+        for c, f in zip(sizes, flushes):
+            c = min(c, len(data) - o)
+            if c > 0:
+                chunks.append(c), fl.append(f)
+                o += c
+        if o < len(data):
+            chunks.append(len(data) - o), fl.append(0)
+        # (ZlibOptions.FlushMode is read by every WriteCore: set anew before every Write)
+        out = io.BytesIO()
+        t0 = time.perf_counter()
+        s = ZlibOutputStream(out, ZlibOptions(CompressionLevel=CompressionLevel(level), FlushMode=0), engine=engine)
+        o = 0
+        for c, f in zip(chunks, fl):
+            s.Options.FlushMode = f
+            s.write(data[o:o + c])
+            o += c
+        s.Options.FlushMode = 0
+        s.close()
+        dt = time.perf_counter() - t0
+        z = out.getvalue()
+        assert zlib.decompress(z) == data, (len(data), chunks[:4], fl[:4], level)
+        assert z == oracle.compress_writes(data, level, 0, chunks, fl), (len(data), chunks[:4], fl[:4], level)
+        if len(data) >= (16 << 20):
+            assert dt < 6.0, "%.1f s: the Writes behind the flush did not leave the literal engine" % dt
+
+
+@pytest.mark.gpu
 def test_flush_mode_single_write_takes_the_bulk_path(engine, oracle):
     """One Write under SyncFlush at level 6: the bulk pipeline runs (the tail engine closes the block, the offsets kernel
     adds the marker and the re-entered empty block); 8 MiB so that the sequential engine would be visible in the time."""

@@ -1,6 +1,7 @@
 // zs_device.h -- device-visible descriptors shared by the kernels and the host
 // pipeline (zs_engine.hip).
 #pragma once
+#include <cstddef>
 #include "zs_core.h"
 #include "zs_lit_engine.h"
 #include "zs_fast_vec.h"
@@ -73,6 +74,16 @@ struct StreamDesc {
     struct LitPersist *persist;
     int64_t abs_off;
     int32_t cont;
+    // A run that takes a stream over from the literal engine in the middle (zs_engine.hip: the bulk pipeline behind the
+    // warm-up after a flush): `resume` -- the bulk parse begins at chunk 0's entry slot start_slot with start_syms symbols of
+    // the block in progress already there (copied from `persist`), the block began at start_block, the window stood at
+    // base0; all of them buffer positions, persist_off = the stream position of buffer position 0 (abs_off is 0 for such a
+    // run).  cont_bits: the run's output goes on in the middle of the stream's bits (a continued or a resumed run).
+    // stop_abs (a continued run): the literal engine stops at the first clean loop-top at or behind it (LitEngine::stopped).
+    int32_t resume, start_slot, cont_bits;
+    int32_t mid_write;  // the run begins in the middle of a Write (behind a stop of the literal engine): no new Deflate call begins with it
+    uint32_t start_syms;
+    int64_t base0, start_block, persist_off, stop_abs;
     uint32_t adler_stream;
     uint32_t carry_byte;  // cont: the bits of the stream's last, incomplete byte from the run before
     // DeflateFast for the lanes of a wave (zs_fast_vec.h, zs_fast_vec_kernel): last loop-top it handles (n - 262), -1: not
@@ -116,12 +127,14 @@ struct LitPersist {
     int32_t strstart, lookahead, match_length, match_start, match_available, prev_length, prev_match;
     int32_t pending_syms;
     FlushAcct fa;
-    int32_t fa_valid, pad_;
+    int32_t fa_valid, stopped;  // stopped: the engine was left at a clean loop-top for the bulk pipeline to go on from (LitEngine::stopped)
+    int32_t good_prev, pad2_[3];  // ... where the search before ran on the reduced chain budget (prev_length >= good_match); the arrays below stay 16-byte aligned
     uint8_t window[kWindowSize + 512];
     uint16_t prev[kWSize];
     uint16_t head[kHashSize];
     uint32_t syms[kLitBufsize];
 };
+static_assert(offsetof(LitPersist, window) % 16 == 0 && offsetof(LitPersist, prev) % 16 == 0 && offsetof(LitPersist, head) % 16 == 0, "16-byte copies");
 
 struct StreamState {
     // written by the resolve kernel

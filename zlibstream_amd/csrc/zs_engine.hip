@@ -169,6 +169,15 @@ struct RunOpts {
     int64_t abs_off = 0;
     uint32_t adler_stream = 1, carry_byte = 0;
     int64_t end_bits = 0;  // out: stream bit position behind the run's last block or marker
+    // cont: the literal engine stops at the first clean loop-top at or behind this stream position (< 0: runs on) ...
+    int64_t stop_abs = -1;
+    // ... and the run behind such a stop goes on from there on the bulk pipeline (`resume`): loop-top p0 with the input read up to
+    // E0, the window at base0, the block in progress begun at start_block -- buffer positions, the buffer beginning at
+    // stream position abs_off -- with start_syms symbols, in the lazy parse's node `slot` of a chunk that begins at p0
+    bool resume = false, mid_write = false;
+    int64_t p0 = 0, E0 = 0, base0 = 0, start_block = 0;
+    int slot = 0;
+    uint32_t start_syms = 0;
 };
 
 // `writes` (optional, one stream only): the Writes of a multi-Write stream, or of one whose Writes carry a flush mode
@@ -200,7 +209,8 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
         const bool multi = writes && writes->ends.size() > 1;
         // an incremental run always takes the block-by-block output accounting (its state is carried from run to run)
         const bool flushing = writes && (writes->flushing() || ro);
-        const bool cont = ro && ro->cont, final_run = !ro || ro->final_run;
+        const bool resume = ro && ro->resume;
+        const bool cont = ro && ro->cont && !resume, final_run = !ro || ro->final_run;
         // the bulk pipeline takes the NoFlush schedules build_geometry accepts (zs_core.h: any Write sizes but streams written
         // a few bytes at a time); a stream the resolve kernel flagged (force_lit: a read whose pre-insert hashes bytes behind the
         // data) and other streams of several Writes run on the literal engine.  Levels 1-3 keep the single Write's events.
@@ -210,8 +220,14 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
         const bool real_flush = writes && writes->flushing();
         const bool lit_forced = force_lit && (*force_lit)[(size_t)i];
         const std::vector<int64_t> no_ends_;
-        const bool slow_ok = lv.func == 2 && strategy != kRle && !cont && !lit_forced && !(multi && real_flush) &&
-                             build_geometry(len, multi ? writes->ends : no_ends_, geo);
+        GeoStart gs;
+        if (resume) gs.resume = true, gs.p0 = ro->p0, gs.E0 = ro->E0, gs.base0 = ro->base0;
+        // (a flush mode on the run's last Write alone is the tail engine's business: it closes the block there)
+        bool inner_flush = false;
+        if (writes)
+            for (size_t k = 0; k + 1 < writes->flush.size(); k++) inner_flush = inner_flush || writes->flush[k] != 0;
+        const bool slow_ok = lv.func == 2 && strategy != kRle && !cont && !lit_forced && !(multi && (resume ? inner_flush : real_flush)) &&
+                             build_geometry(len, multi ? writes->ends : no_ends_, geo, gs);
         const bool regular = cont ? false : multi ? false : build_read_events(len, std::vector<int64_t>(one_write, one_write + 1), rev);
         s.body_end = slow_ok ? (int32_t)geo.body_end : -1;
         // levels 1-3, one Write: the speculative chunk runs for large streams (they verify on periodic data and are parallel
@@ -229,7 +245,14 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
         s.n_wr = (multi || flushing) ? (int32_t)writes->ends.size() : 1;  // 0: a run without input (Finish alone)
         s.wr_end = nullptr;
         s.wr_flush = nullptr, s.wr_blk = nullptr, s.out_chunk = writes ? writes->chunk : 512, s.raw = writes && writes->raw;
-        s.kl = num_refills(len);
+        s.kl = num_refills(len - (resume ? ro->base0 : 0));
+        s.resume = resume && slow_ok ? 1 : 0, s.cont_bits = (cont || resume) ? 1 : 0, s.mid_write = (ro && (ro->mid_write || resume)) ? 1 : 0;
+        if (resume && !slow_ok) {
+            c->err = "the run cannot go on in the bulk pipeline from where the literal engine stopped";
+            return false;
+        }
+        s.start_slot = resume ? ro->slot : 0, s.start_syms = resume ? ro->start_syms : 0, s.base0 = resume ? ro->base0 : 0;
+        s.start_block = resume ? ro->start_block : 0, s.persist_off = resume ? ro->abs_off : 0, s.stop_abs = (ro && cont) ? ro->stop_abs : -1;
         s.nchunks = s.body_end >= 0 ? geo.nchunks() : 0;
         s.pos_off = pl.n_pos;
         pl.n_pos += (len + 64 + 63) & ~63LL;
@@ -284,7 +307,7 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
         if (flushing) s.max_blocks += (int32_t)writes->ends.size() + 1;  // every Write under a flush mode closes a block
         s.plan_blk = nullptr, s.plan_nblk = 0;
         s.final_run = final_run ? 1 : 0, s.cont = cont ? 1 : 0, s.persist = ro ? ro->persist : nullptr;
-        s.abs_off = ro ? ro->abs_off : 0, s.adler_stream = ro ? ro->adler_stream : 1, s.carry_byte = ro ? ro->carry_byte : 0;
+        s.abs_off = (ro && !resume) ? ro->abs_off : 0, s.adler_stream = ro ? ro->adler_stream : 1, s.carry_byte = ro ? ro->carry_byte : 0;
         if (level == 0 && strategy != kRle && !ro) {
             // DeflateStored: block boundaries from the sizes alone (zs_core.h plan_stored_blocks); s.plan_blk holds the
             // offset into the batch's list until the device address is known
@@ -672,7 +695,7 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
         ZS_HIP(c, hipEventRecord(c->ev_join, c->aux));
         ZS_HIP(c, hipStreamWaitEvent(stream, c->ev_join, 0));
         hipLaunchKernelGGL(zs_body_blocks_kernel, dim3((unsigned)n), dim3(256), 0, stream, d_sd, d_st, dev<int32_t>(c->blk_end),
-                           dev<int32_t>(c->blk_top), dev<BlockRec>(c->blocks));
+                           dev<int32_t>(c->blk_top), dev<BlockRec>(c->blocks), dev<uint32_t>(c->syms));
     } else {
     if (!rounds) {
     mark(2);
@@ -718,7 +741,8 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
         hipLaunchKernelGGL(zs_fast_vec_kernel, dim3((unsigned)n), dim3(1024), kFvLds, stream, d_sd, d_st, dev<uint16_t>(c->link),
                            dev<uint32_t>(c->syms), dev<int32_t>(c->blk_end), dev<int32_t>(c->blk_top), lv, strategy, dev<uint32_t>(c->fv_lists),
                            fv_list_entries(lv.chain));
-    const bool tail_late = ro && !ro->final_run;  // the engine is left for a later run: it needs K5's symbols and block ends
+    // the engine is left for a later run, or took the block in progress over from one: it needs K5's symbols and block ends
+    const bool tail_late = ro && (!ro->final_run || ro->resume);
     // Beside the symbol kernel the tails of a few streams are free; those of hundreds are not: 256 tail workgroups of 1024
     // threads and 133 KiB of LDS each, one per CU, cost the symbol kernel of 256 x 1 MiB 3 ms (6.8 against 3.9), more than
     // they take alone (0.5).  From 64 streams of 96 KiB or more on the tails run behind the symbols instead (thousands of
@@ -753,7 +777,7 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
                            dev<uint8_t>(c->scratch), c->crc_tab, lv, strategy, hash_variant, level);
     else if (!tail_late) ZS_HIP(c, hipStreamWaitEvent(stream, c->ev_join, 0));
     hipLaunchKernelGGL(zs_body_blocks_kernel, dim3((unsigned)n), dim3(256), 0, stream, d_sd, d_st, dev<int32_t>(c->blk_end),
-                       dev<int32_t>(c->blk_top), dev<BlockRec>(c->blocks));
+                       dev<int32_t>(c->blk_top), dev<BlockRec>(c->blocks), dev<uint32_t>(c->syms));
     if (tail_late)
         hipLaunchKernelGGL(zs_tail_kernel, dim3((unsigned)n), dim3(1024), kTailLds, stream, d_sd, d_st, dev<uint16_t>(c->link),
                            dev<uint32_t>(c->syms), dev<int32_t>(c->blk_end), dev<int32_t>(c->blk_top), dev<BlockRec>(c->blocks),

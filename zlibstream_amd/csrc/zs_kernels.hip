@@ -1160,6 +1160,9 @@ __global__ __launch_bounds__(1024) void zs_resolve_kernel(const StreamDesc *sd, 
         sh_cut_e = -1, sh_nc = 0, sh_diff = 0x7FFFFFFF;
     __syncthreads();
     if (dry && ss.deferred != 1) return;  // only the streams that were given up take part in the rounds
+    // a run that took the stream over in the middle (StreamDesc::resume) starts in the node and with the symbols it was handed
+    if (s.resume && threadIdx.x == 0 && sh_seg == 0 && sh_slot == 0 && sh_total == 0) sh_slot = s.start_slot, sh_total = s.start_syms;
+    __syncthreads();
     if (s.body_end < 0) {
         if (threadIdx.x == 0) ss.tail_p = 0, ss.tail_kind = kR, ss.tail_pend = 0, ss.k_done = 0, ss.preins = -1, ss.body_syms = 0;
         return;
@@ -2005,22 +2008,24 @@ __global__ __launch_bounds__(kK5Threads) void zs_emit_syms_lane_kernel(const Str
 // ------------------------------------------------------------------ K5b
 // The block cuts recorded by K5 become BlockRec entries (the blocks that end inside the bulk parse).
 __global__ __launch_bounds__(256) void zs_body_blocks_kernel(const StreamDesc *sd, const StreamState *st, const int32_t *blk_end,
-                                                             const int32_t *blk_top, BlockRec *blocks) {
+                                                             const int32_t *blk_top, BlockRec *blocks, uint32_t *syms) {
     const StreamDesc s = sd[blockIdx.x];
     if (s.fast_runs > 0 || st[blockIdx.x].deferred) return;
+    if (s.resume)  // the symbols of the block the run took over in the middle: in front of the run's own
+        for (uint32_t i = threadIdx.x; i < s.start_syms; i += blockDim.x) syms[s.sym_off + i] = s.persist->syms[i];
     const int nb_body = (int)(st[blockIdx.x].body_syms / kBlockSyms);
     BlockRec *blk = blocks + s.blk_off;
     // start = end of the previous block; stored blocks are allowed only while blockStart has not slid out of the
     // window (Deflate.cs:953)
     for (int i = threadIdx.x; i < nb_body; i += blockDim.x) {
-        int64_t start = i ? blk_end[s.blk_off + i - 1] : 0;
+        int64_t start = i ? blk_end[s.blk_off + i - 1] : (s.resume ? s.start_block : 0);
         int64_t end = blk_end[s.blk_off + i];
         BlockRec r;
         r.start = start;
         r.sym_start = (int64_t)i * kBlockSyms;
         r.stored_len = (int32_t)(end - start);
         r.nsyms = kBlockSyms;
-        r.can_store = start >= (int64_t)kWSize * refills_fired_at(blk_top[s.blk_off + i], s.kl);
+        r.can_store = start >= s.base0 + (int64_t)kWSize * refills_fired_at(blk_top[s.blk_off + i] - s.base0, s.kl);
         r.eof = 0;
         blk[i] = r;
     }
@@ -2097,12 +2102,13 @@ __global__ __launch_bounds__(1024) void zs_tail_kernel(const StreamDesc *sd, Str
     // gets its start from zs_body_blocks_kernel afterwards
     e.block_start_abs = 0;
     e.defer_start = nb_body > 0;
-    if (!s.final_run && nb_body > 0) {
+    if ((!s.final_run || s.resume) && nb_body > 0) {
         // a run that is not the stream's end runs behind K5 (the pending block's symbols and start must be final when the
         // engine is left for the next run): the last finished block's end is known
         e.block_start_abs = blk_end[s.blk_off + nb_body - 1];
         e.defer_start = 0;
     }
+    if (s.resume && nb_body == 0) e.block_start_abs = s.start_block;  // the block the run took over is still in progress
     e.block_sym_start = (int64_t)nb_body * kBlockSyms;
     e.block_syms = level == 0 ? (kLitBufsize / 2) - 1 : kBlockSyms;
     const uint16_t *lk = link + s.pos_off;
@@ -2124,6 +2130,7 @@ __global__ __launch_bounds__(1024) void zs_tail_kernel(const StreamDesc *sd, Str
         e.strstart = ps->strstart, e.lookahead = ps->lookahead, e.match_length = ps->match_length, e.match_start = ps->match_start;
         e.match_available = ps->match_available, e.prev_length = ps->prev_length, e.prev_match = ps->prev_match;
         e.nsyms = ps->pending_syms, e.block_sym_start = 0, e.nblocks = 0, e.defer_start = 0;
+        e.stop_abs = s.stop_abs;
         __syncthreads();
     } else {
         // ss.k_done is the parse segment of the last read event that fired before p
@@ -2233,6 +2240,8 @@ __global__ __launch_bounds__(1024) void zs_tail_kernel(const StreamDesc *sd, Str
         printf("TAILPROF setup=%lld window+clear=%lld prev+head=%lld convert=%lld; before the engine (with the searches ahead) %lld; kernel so far %lld; engine ticks=%lld syms=%lld: refill=%lld insert=%lld match=%lld tally=%lld flush=%lld\n", pf_restore[0], pf_restore[1], pf_restore[2], pf_restore[3], tk_pre, wall_clock64() - tk_start, wall_clock64() - te0,
                (long long)(e.nsyms - body_syms), e.pf[0], e.pf[1], e.pf[2], e.pf[3], e.pf[4]);
 #endif
+    if (tid == 0 && e.stopped && e.wr_blk)  // the Writes the engine did not get to: no block of this run lies behind their start
+        for (int w = e.cur_wr + 1; w < e.n_wr; w++) e.wr_blk[w] = 0x7FFFFFFF;
     if (tid == 0) {
         ss.nsyms = (uint32_t)e.nsyms;
         ss.nblocks = e.nblocks;
@@ -2247,10 +2256,13 @@ __global__ __launch_bounds__(1024) void zs_tail_kernel(const StreamDesc *sd, Str
     const int pending = (int)(e.nsyms - e.block_sym_start);
     for (int i = tid; i < pending; i += 64) ps->syms[i] = e.syms[e.block_sym_start + i];
     if (tid == 0) {
-        ps->base = e.base, ps->avail_end = e.avail_end, ps->block_start_abs = e.block_start_abs;
+        // (a resumed run works in buffer positions: the state goes back into stream positions)
+        const int64_t po = s.resume ? s.persist_off : 0;
+        ps->base = e.base + po, ps->avail_end = e.avail_end + po, ps->block_start_abs = e.block_start_abs + po;
         ps->strstart = e.strstart, ps->lookahead = e.lookahead, ps->match_length = e.match_length, ps->match_start = e.match_start;
         ps->match_available = e.match_available, ps->prev_length = e.prev_length, ps->prev_match = e.prev_match;
         ps->pending_syms = pending;
+        ps->stopped = e.stopped, ps->good_prev = e.prev_length >= lv.good ? 1 : 0;
     }
 }
 
@@ -3261,16 +3273,18 @@ __global__ __launch_bounds__(256) void zs_offsets_kernel(const StreamDesc *sd, S
     LitPersist *ps = s.persist;
     // a run that continues an incremental stream starts where the run before stopped: `bit_base` is the stream bit position
     // of this run's out[0], whose low bits (the stream's last, incomplete byte) come with the descriptor
-    const int64_t start_bits = s.cont ? ps->fa.bits : 16;
-    const int64_t bit_base = s.cont ? (start_bits & ~7LL) : 0;
+    const int64_t start_bits = s.cont_bits ? ps->fa.bits : 16;
+    const int64_t bit_base = s.cont_bits ? (start_bits & ~7LL) : 0;
     if (threadIdx.x == 0) sh_pos = start_bits, sh_bad = 0;
     const OrBitsAt fa_put{s.out, s.out_cap, bit_base};
     if (flushing) {
-        if (s.cont) fa = ps->fa;
+        if (s.cont_bits) fa = ps->fa;
         else fa_init(fa, s.out_chunk, level, s.raw != 0);
-        fa_enter(fa);  // the run's first Deflate call (of a stream: it delivers the header)
+        // the run's first Deflate call (of a stream: it delivers the header); a run that took the stream over in the middle of
+        // a Write goes on inside the call the run before was in
+        if (!s.mid_write) fa_enter(fa);
     }
-    if (threadIdx.x == 0 && s.cont && s.out_cap > 0) s.out[0] = (uint8_t)s.carry_byte;
+    if (threadIdx.x == 0 && s.cont_bits && s.out_cap > 0) s.out[0] = (uint8_t)s.carry_byte;
     __syncthreads();
     for (int b0 = 0; b0 < nb; b0 += 1024) {
         int cnt = nb - b0 < 1024 ? nb - b0 : 1024;
@@ -3395,7 +3409,7 @@ __global__ __launch_bounds__(256) void zs_offsets_kernel(const StreamDesc *sd, S
         return;
     }
     ss.status = 0;
-    if (!s.cont) {
+    if (!s.cont_bits) {
         unsigned hdr = zlib_header(level);
         s.out[0] = (uint8_t)(hdr >> 8);
         s.out[1] = (uint8_t)hdr;

@@ -88,6 +88,11 @@ struct LitEngine {
     // (NeedMore under NoFlush, Deflate.Slow.cs:38-46; BlockDone after a flush, Deflate.cs:583-613) the engine stops with
     // `suspended` set, at a loop-top, and a later run re-enters the block function from there
     int final_run, suspended;
+    // ... or, for a run that hands the stream over to the bulk pipeline (zs_engine.hip: a long Write behind a flush), at the
+    // first loop-top at or behind stop_abs with a full lookahead that no read event has touched (`stopped`): the state there
+    // is a node of the lazy parse with the schedule's state a function of the position (zs_core.h build_geometry)
+    int stopped;
+    int64_t last_event_abs;  // loop-top of the last read event (-1: none in this run)
     // match records computed ahead for the loop-tops [pre_lo, pre_hi) (le_tail_record): two words per position, the
     // record for the full chain budget and the one for a quarter of it; nullptr: every search walks its chain
     const uint32_t *pre_rec;
@@ -111,7 +116,7 @@ ZS_HD void le_defaults(LitEngine &e) {
     e.stop_abs = -1, e.mark_abs = -1, e.mark_pos = -1, e.mark_nsyms = 0;
     e.ins_bits = nullptr, e.ins_base = 0, e.no_blocks = 0, e.ins_word_idx = -1, e.ins_word = 0;
     e.ev_log = nullptr, e.n_ev = 0;
-    e.final_run = 1, e.suspended = 0;
+    e.final_run = 1, e.suspended = 0, e.stopped = 0, e.last_event_abs = -1;
     e.pre_rec = nullptr, e.pre_lo = e.pre_hi = 0;
     e.no_head = 0, e.tail_head[0] = e.tail_head[1] = e.tail_head[2] = 0;
     e.block_syms = kBlockSyms, e.block_sym_start = 0, e.block_start_abs = 0, e.defer_start = 0;
@@ -301,6 +306,7 @@ ZS_HD_NOINLINE inline void le_fill_window(LitEngine &e, int lane, int nlanes) {
             if (lane == 0) e.ev_log[e.n_ev] = e.base + e.strstart;
             e.n_ev++;
         }
+        e.last_event_abs = e.base + e.strstart;
         if (e.lookahead >= kMinMatch) le_insert(e, e.strstart + 1);
     } while (e.lookahead < kMinLookahead && e.avail_end < ((e.wr_end && e.cur_wr < e.n_wr) ? e.wr_end[e.cur_wr] : e.n));
 }
@@ -567,6 +573,10 @@ ZS_HD_NOINLINE inline void le_run_slow(LitEngine &e, int lane, int nlanes) {
             e.lookahead--;
         }
         LE_PF(3);
+        if (e.stop_abs >= 0 && e.base + e.strstart >= e.stop_abs && e.lookahead >= kMinLookahead && e.base + e.strstart > e.last_event_abs + 1) {
+            e.stopped = 1;
+            return;
+        }
     }
     LE_PF_T0();
     if (e.match_available != 0) {
