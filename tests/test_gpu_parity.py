@@ -606,6 +606,58 @@ def test_writes_behind_a_flush_go_back_to_the_bulk_path(engine, oracle):
             assert dt < 6.0, "%.1f s: the Writes behind the flush did not leave the literal engine" % dt
 
 
+def _flushed_stream(engine, data, chunks, fl, level, strategy=0):
+    out = io.BytesIO()
+    s = ZlibOutputStream(out, ZlibOptions(CompressionLevel=CompressionLevel(level), CompressionStrategy=strategy, FlushMode=0), engine=engine)
+    o = 0
+    for c, f in zip(chunks, fl):
+        s.Options.FlushMode = f
+        s.write(data[o:o + c])
+        o += c
+    s.Options.FlushMode = 0
+    s.close()
+    return out.getvalue()
+
+
+@pytest.mark.gpu
+def test_the_bulk_path_goes_on_from_the_flush_itself(engine, oracle, monkeypatch):
+    """Behind a flush the engine stands at a position with nothing read ahead and nothing pending: the bulk pipeline starts
+    there (GeoStart::at_read -- the first pass through the loop reads, as a stream's first one does) on the chains the
+    engine left (zs_import_chains_kernel: prev[] below the flush, head[] for the first member of a bucket behind it), which
+    hold what the data alone does not tell -- the last positions in front of the flush went in under hashes of window bytes
+    that were not theirs, or not at all (Deflate.Slow.cs:58,121-129), a FullFlush forgot the heads (Deflate.cs:596-604),
+    equal-bucket reads cut chains.  Flushes at every kind of place: the first bytes of a stream, window ends and the slide
+    threshold, one flush after the other; zeros, a small alphabet (equal buckets everywhere), random bytes, text; Partial,
+    Sync and Full; and once more with the literal engine's warm-up in front (ZS_NO_FLUSH_RESUME), the route of a stream
+    that is not at a flush."""
+    text = datagen.english(6 << 20, datagen.GOLDEN)
+    rng = np.random.default_rng(77)
+    low = rng.choice(np.array([0, 0, 0, 0, 1, 2, 255], dtype=np.uint8), 3 << 20).tobytes()
+    rnd = rng.integers(0, 256, 2 << 20, dtype=np.uint8).tobytes()
+    M = 1 << 20
+    cases = [(text, [3, M], [2, 0], 6), (text, [1, M], [3, 0], 6), (text, [65536, M], [2, 0], 6), (text, [65273, M], [2, 0], 6),
+             (text, [65274, M], [1, 0], 6), (text, [65275, M], [2, 0], 6), (text, [98304, M], [2, 0], 6), (text, [98303, M], [3, 0], 6),
+             (text, [32768, M], [2, 0], 9), (text, [300000, 400000, 500000, 600000, 700000], [2, 2, 3, 1, 2], 6),
+             (text, [M, 100, M, 5, M], [0, 2, 0, 3, 0], 6), (text, [500000, 300000, 300000, 300001], [2, 0, 0, 0], 4),
+             (low, [70000, M, M], [2, 2, 0], 6), (low, [4096, 2 * M], [3, 0], 9), (low, [300000, 300000, 300000], [1, 3, 2], 8),
+             (bytes(3 << 20), [100000, M, M], [2, 3, 0], 6), (bytes(2 << 20), [65536, M], [2, 0], 9),
+             (rnd, [5000, M], [2, 0], 6), (rnd, [131072, 900000], [3, 2], 5), (text, [200000, 2 * M], [2, 0], 7)]
+    for env in (None, "1"):
+        if env:
+            monkeypatch.setenv("ZS_NO_FLUSH_RESUME", env)
+        for data, sizes, flushes, level in (cases if not env else cases[::3]):
+            chunks, fl, o = [], [], 0
+            for c, f in zip(sizes, flushes):
+                c = min(c, len(data) - o)
+                if c > 0:
+                    chunks.append(c), fl.append(f)
+                    o += c
+            data = data[:o]
+            z = _flushed_stream(engine, data, chunks, fl, level)
+            assert zlib.decompress(z) == data, (len(data), chunks, fl, level, env)
+            assert z == oracle.compress_writes(data, level, 0, chunks, fl), (len(data), chunks, fl, level, env)
+
+
 @pytest.mark.gpu
 def test_flush_mode_single_write_takes_the_bulk_path(engine, oracle):
     """One Write under SyncFlush at level 6: the bulk pipeline runs (the tail engine closes the block, the offsets kernel

@@ -46,13 +46,10 @@ for name, writes, flushes in (("sync flush after 4 KiB, then one 64 MiB Write", 
         if w > 0:
             pw.append(w), pf.append(f)
             o += w
-    zp, _ = run(part, pw, pf)
-    want = orc.compress_writes(part, 6, 0, pw, pf)
-    exact = zp == want
-    if not exact:
-        zq, _ = run(part, pw, pf, chunk=512)
-        d = next((i for i in range(min(len(zp), len(want))) if zp[i] != want[i]), -1)
-        print("   lengths %d / %d, first difference at %d; with 512-byte output chunks exact: %s" % (len(zp), len(want), d, zq == want))
+    # (the reference's bytes are those of ZlibOutputStream.WriteCore's loop with its 512-byte chunk: a flush whose output
+    # does not fit one chunk is entered again and leaves another empty block)
+    zp, _ = run(part, pw, pf, chunk=512)
+    exact = zp == orc.compress_writes(part, 6, 0, pw, pf)
     behind = sum(times[1:])
-    print("%-58s roundtrip %s, first 6 MiB exact %s; calls behind the first Write: %.1f ms = %.2f GB/s (host memory in, host memory out)"
+    print("%-58s roundtrip %s, first 6 MiB (512-byte chunks) exact %s; calls behind the first Write: %.1f ms = %.2f GB/s (host memory in, host memory out)"
           % (name, ok, exact, behind * 1e3, (len(text) - writes[0]) / behind / 1e9 if len(writes) > 1 else len(text) / sum(times) / 1e9), flush=True)

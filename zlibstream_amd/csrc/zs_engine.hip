@@ -56,7 +56,8 @@ struct zs_ctx {
     uint32_t *crc_tab = nullptr;
     DevBuf sd, st, work, wpre, geo, link, mm, maps, chunk_far, segmap, supmap, seg_entry, seg_symbase, seg_stale, entry, symbase, stale, syms, blk_end, blk_top, blocks, trees, info, pieces, scratch,
         stage_in, stage_out, wr, inf_desc, inf_state, par_ps, par_st, par_work, par_cbits, par_ccnt, par_surv, par_scnt, par_cands, par_tabs, par_blocks, par_cells,
-        par_windows, par_fail, run_syms, run_bits, run_scratch, run_outs, run_fail, adl_tr, adl_res, plan_blk, ins_bits, fv_lists, mm_bak, cut_pos, cut_bkt, win_groups, win_sg, win_maps, win_entries;
+        par_windows, par_fail, run_syms, run_bits, run_scratch, run_outs, run_fail, adl_tr, adl_res, plan_blk, ins_bits, fv_lists, mm_bak, cut_pos, cut_bkt, win_groups, win_sg, win_maps, win_entries, persist_bak;
+    bool resume_poisoned = false;  // a resumed run met a read the bulk form does not handle: the caller goes on with the literal engine
     void *pinned = nullptr;
     size_t pinned_cap = 0;
 };
@@ -174,7 +175,9 @@ struct RunOpts {
     // ... and the run behind such a stop goes on from there on the bulk pipeline (`resume`): loop-top p0 with the input read up to
     // E0, the window at base0, the block in progress begun at start_block -- buffer positions, the buffer beginning at
     // stream position abs_off -- with start_syms symbols, in the lazy parse's node `slot` of a chunk that begins at p0
-    bool resume = false, mid_write = false;
+    // at_read: the stream was flushed at p0 (E0 == p0, nothing pending): the run's first pass through the loop reads, like a
+    // stream's first one, and the run begins with a new Deflate call
+    bool resume = false, mid_write = false, at_read = false;
     int64_t p0 = 0, E0 = 0, base0 = 0, start_block = 0;
     int slot = 0;
     uint32_t start_syms = 0;
@@ -221,7 +224,7 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
         const bool lit_forced = force_lit && (*force_lit)[(size_t)i];
         const std::vector<int64_t> no_ends_;
         GeoStart gs;
-        if (resume) gs.resume = true, gs.p0 = ro->p0, gs.E0 = ro->E0, gs.base0 = ro->base0;
+        if (resume) gs.resume = true, gs.at_read = ro->at_read, gs.p0 = ro->p0, gs.E0 = ro->E0, gs.base0 = ro->base0;
         // (a flush mode on the run's last Write alone is the tail engine's business: it closes the block there)
         bool inner_flush = false;
         if (writes)
@@ -246,7 +249,7 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
         s.wr_end = nullptr;
         s.wr_flush = nullptr, s.wr_blk = nullptr, s.out_chunk = writes ? writes->chunk : 512, s.raw = writes && writes->raw;
         s.kl = num_refills(len - (resume ? ro->base0 : 0));
-        s.resume = resume && slow_ok ? 1 : 0, s.cont_bits = (cont || resume) ? 1 : 0, s.mid_write = (ro && (ro->mid_write || resume)) ? 1 : 0;
+        s.resume = resume && slow_ok ? 1 : 0, s.cont_bits = (cont || resume) ? 1 : 0, s.mid_write = (ro && (ro->mid_write || (resume && !ro->at_read))) ? 1 : 0;
         if (resume && !slow_ok) {
             c->err = "the run cannot go on in the bulk pipeline from where the literal engine stopped";
             return false;
@@ -645,6 +648,8 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
                     hipLaunchKernelGGL(zs_links_kernel, dim3((unsigned)(spans_end - spans_done)), dim3(1024), kLkLds, stream, d_sd,
                                        d_work + o_links + spans_done, dev<uint16_t>(c->link), c->crc_tab, hash_variant, (int)link_span);
                 });
+            if (k == 0 && ro && ro->resume)  // (one stream: a resumed run's chains are the ones the engine before it left)
+                hipLaunchKernelGGL(zs_import_chains_kernel, dim3(64), dim3(1024), 0, stream, d_sd, 0, dev<uint16_t>(c->link), c->crc_tab, hash_variant, ro->p0);
             if (tiles_end > tiles_done)
                 timed(kStMatch, stream, [&] {
                     hipLaunchKernelGGL(zs_match_kernel, dim3((unsigned)(tiles_end - tiles_done)), dim3(1024), kMatchLds + 16, stream, d_sd,
@@ -702,6 +707,8 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
     if (!pl.w_links.empty())
         hipLaunchKernelGGL(zs_links_kernel, dim3((unsigned)pl.w_links.size()), dim3(1024), kLkLds, stream, d_sd, d_work + o_links,
                            dev<uint16_t>(c->link), c->crc_tab, hash_variant, (int)link_span);
+    if (ro && ro->resume)
+        hipLaunchKernelGGL(zs_import_chains_kernel, dim3(64), dim3(1024), 0, stream, d_sd, 0, dev<uint16_t>(c->link), c->crc_tab, hash_variant, ro->p0);
     mark(3);
     if (strategy == kHuffmanOnly) {
         // Longest_match is never called (Deflate.Slow.cs:66-71): every position has no match
@@ -866,6 +873,11 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
             if (hst[i].poison) any_poison = true, fl[(size_t)i] = 1;
         if (any_poison) {
             ZS_HIP(c, hipStreamSynchronize(c->aux));
+            if (ro && ro->resume) {  // (the engine's state in `persist` has been run over: the caller has kept a copy)
+                c->err = "the resumed run met a read the bulk pipeline leaves to the literal engine";
+                c->resume_poisoned = true;
+                return false;
+            }
             c->lit_fallbacks++;
             return run_pipeline(c, n, in, in_len, out, out_cap, out_len, status, level, strategy, hash_variant, stream, writes, force_seq, ro, false, &fl);
         }
@@ -1064,7 +1076,7 @@ void zs_ctx_destroy(zs_ctx *c) {
     DevBuf *bufs[] = {&c->sd, &c->st, &c->work, &c->wpre, &c->geo, &c->link, &c->mm, &c->maps, &c->chunk_far, &c->segmap, &c->supmap, &c->seg_entry, &c->seg_symbase, &c->seg_stale, &c->entry, &c->symbase, &c->stale, &c->syms,
                       &c->blk_end, &c->blk_top, &c->blocks, &c->trees, &c->info, &c->pieces, &c->scratch, &c->stage_in, &c->stage_out, &c->wr, &c->inf_desc, &c->inf_state, &c->par_ps, &c->par_st, &c->par_work, &c->par_cbits, &c->par_ccnt, &c->par_surv, &c->par_scnt,
                       &c->par_cands, &c->par_tabs, &c->par_blocks, &c->par_cells, &c->par_windows, &c->par_fail, &c->run_syms, &c->run_bits,
-                      &c->run_scratch, &c->run_outs, &c->run_fail, &c->adl_tr, &c->adl_res, &c->plan_blk, &c->ins_bits, &c->fv_lists, &c->mm_bak, &c->cut_pos, &c->cut_bkt, &c->win_groups, &c->win_sg, &c->win_maps, &c->win_entries};
+                      &c->run_scratch, &c->run_outs, &c->run_fail, &c->adl_tr, &c->adl_res, &c->plan_blk, &c->ins_bits, &c->fv_lists, &c->mm_bak, &c->cut_pos, &c->cut_bkt, &c->win_groups, &c->win_sg, &c->win_maps, &c->win_entries, &c->persist_bak};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     if (c->crc_tab) (void)hipFree(c->crc_tab);

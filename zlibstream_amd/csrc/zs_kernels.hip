@@ -491,6 +491,45 @@ __device__ __forceinline__ void match_walk(const uint8_t *wb, const uint16_t *wl
     }
 }
 
+// ------------------------------------------------------------------ K1r: a resumed run's chains
+// A run that takes a stream over in the middle (StreamDesc::resume) finds the chains as the engine before it left them in
+// `persist`: the last 32 Ki positions below p0 with everything that happened to them -- the equal-bucket events' cuts
+// (Deflate.cs:1009-1012 inserting strstart + 1 ahead of strstart), the last positions in front of a flush, which went in
+// under hashes that read window bytes behind the data or not at all (Deflate.Slow.cs:58,121-129), the heads a FullFlush
+// forgot (Deflate.cs:596-604) -- none of which the data alone tells K1.  So below p0 the links are the engine's prev[], and
+// a position from p0 on whose bucket has no member in [p0, q) gets the engine's head of the bucket: for the walks of the
+// run the chains are then the reference's own.  Workgroup b takes positions p0 - 32768 + 1024 b ...; 64 workgroups.
+__global__ __launch_bounds__(1024) void zs_import_chains_kernel(const StreamDesc *sd, int stream_idx, uint16_t *link, const uint32_t *crc_tab_g,
+                                                                int hash_variant, int64_t p0) {
+    __shared__ uint32_t tab[1024];
+    const StreamDesc s = sd[stream_idx];
+    const LitPersist *ps = s.persist;
+    load_crc_tab(tab, crc_tab_g);
+    __syncthreads();
+    uint16_t *lk = link + s.pos_off;
+    const int64_t wbase = ps->base - s.persist_off;  // buffer position of window[0]
+    const int64_t q = p0 - kWSize + (int64_t)blockIdx.x * 1024 + threadIdx.x;
+    if (q < wbase || q < 0) return;
+    const int idx = (int)(q - wbase);  // (behind p0 it may lie beyond the window the engine left: a distance is all it is used for)
+    if (q < p0) {
+        // (an entry above its own index: the position ahead of an equal-bucket event's loop-top -- the walk would go round
+        // between the two until its budget ends and find nothing new: the chain ends there)
+        const int pv = ps->prev[idx & kWMask];
+        int d = (pv != 0 && pv < idx) ? idx - pv : 0;
+        if (d > kMaxDist) d = 0;
+        lk[q] = (uint16_t)d;
+        return;
+    }
+    if (q + 5 >= (int64_t)s.n) return;
+    const int have = lk[q];
+    if (have != 0 && q - have >= p0) return;  // the bucket's latest member is one of the run's own positions
+    const uint32_t h = dev_bucket(tab, g_u32_bytes(as_global(s.in) + q + 2), hash_variant);
+    const int hv = ps->head[h];
+    int d = hv != 0 ? idx - hv : 0;
+    if (d < 0 || d > kMaxDist) d = 0;
+    lk[q] = (uint16_t)d;
+}
+
 // ------------------------------------------------------------------ K2
 // 1024 threads per 16 Ki-position tile; the tile's 48 KiB of input and 96 KiB
 // of links are staged in LDS once, then every lane walks hash chains for one
