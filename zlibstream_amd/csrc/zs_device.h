@@ -84,6 +84,7 @@ struct StreamDesc {
     int32_t mid_write;  // the run begins in the middle of a Write (behind a stop of the literal engine): no new Deflate call begins with it
     uint32_t start_syms;
     int64_t base0, start_block, persist_off, stop_abs;
+    int64_t start_pos;  // resume: the run's first loop-top (buffer position); the engine before it ran up to there
     uint32_t adler_stream;
     uint32_t carry_byte;  // cont: the bits of the stream's last, incomplete byte from the run before
     // DeflateFast for the lanes of a wave (zs_fast_vec.h, zs_fast_vec_kernel): last loop-top it handles (n - 262), -1: not

@@ -229,7 +229,7 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
         bool inner_flush = false;
         if (writes)
             for (size_t k = 0; k + 1 < writes->flush.size(); k++) inner_flush = inner_flush || writes->flush[k] != 0;
-        const bool slow_ok = lv.func == 2 && strategy != kRle && !cont && !lit_forced && !(multi && (resume ? inner_flush : real_flush)) &&
+        const bool slow_ok = lv.func == 2 && strategy != kRle && !cont && !lit_forced && !(multi && inner_flush) &&
                              build_geometry(len, multi ? writes->ends : no_ends_, geo, gs);
         const bool regular = cont ? false : multi ? false : build_read_events(len, std::vector<int64_t>(one_write, one_write + 1), rev);
         s.body_end = slow_ok ? (int32_t)geo.body_end : -1;
@@ -255,7 +255,7 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
             return false;
         }
         s.start_slot = resume ? ro->slot : 0, s.start_syms = resume ? ro->start_syms : 0, s.base0 = resume ? ro->base0 : 0;
-        s.start_block = resume ? ro->start_block : 0, s.persist_off = resume ? ro->abs_off : 0, s.stop_abs = (ro && cont) ? ro->stop_abs : -1;
+        s.start_block = resume ? ro->start_block : 0, s.start_pos = resume ? ro->p0 : 0, s.persist_off = resume ? ro->abs_off : 0, s.stop_abs = (ro && cont) ? ro->stop_abs : -1;
         s.nchunks = s.body_end >= 0 ? geo.nchunks() : 0;
         s.pos_off = pl.n_pos;
         pl.n_pos += (len + 64 + 63) & ~63LL;

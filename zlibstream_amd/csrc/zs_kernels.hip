@@ -2068,6 +2068,25 @@ __global__ __launch_bounds__(256) void zs_body_blocks_kernel(const StreamDesc *s
         r.eof = 0;
         blk[i] = r;
     }
+    // Writes that began inside the body (every Write is a Deflate call of its own, and under a flush mode the chunk accounting
+    // counts them: zs_core.h FlushAcct): Write w begins at the first loop-top that finds its predecessor's data short
+    // (>= end - 261), so the blocks flushed before it are those whose last symbol came at a loop-top below that.  The Writes
+    // the tail engine enters are its own to count.
+    if (s.wr_blk && s.wr_end && s.n_wr > 1) {
+        const StreamState &ss = st[blockIdx.x];
+        const int64_t read_to = s.nsegs > 0 ? (int64_t)s.seg_after[ss.k_done] : 0;  // data end where the tail engine takes over
+        for (int w = 1 + (int)threadIdx.x; w < s.n_wr; w += blockDim.x) {
+            if (s.wr_end[w - 1] >= read_to) continue;
+            const int64_t bound = s.wr_end[w - 1] - (kMinLookahead - 1);
+            int lo = 0, hi = nb_body;  // first block whose last loop-top is not below the bound
+            while (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if ((int64_t)blk_top[s.blk_off + mid] < bound) lo = mid + 1;
+                else hi = mid;
+            }
+            s.wr_blk[w] = lo;
+        }
+    }
     // the first block flushed by the tail engine (which ran beside K5) starts where the last finished block ends
     if (threadIdx.x == 0 && nb_body > 0 && s.final_run) {
         BlockRec r = blk[nb_body];
@@ -2186,14 +2205,34 @@ __global__ __launch_bounds__(1024) void zs_tail_kernel(const StreamDesc *sd, Str
                              le_tail_preslide(e, p, base_in, after_in, ss.preins);
         if (preslid) base_in += kWSize;
         le_restore(e, p, base_in, after_in, ss.tail_kind, ss.tail_pend, lk, ss.preins, tid, nth, preslid);
+        // A resumed run that has not slid the window the engine before it left (a short run behind a flush): what lies behind
+        // the data in it is what that engine had there, not what a window filled by this run alone would hold
+        const int64_t img_base = preslid ? e.base - kWSize : e.base;
+        const bool same_window = s.resume && ps && ps->base - s.persist_off == img_base;
+        if (same_window) {
+            const int64_t valid = e.avail_end - img_base;
+            for (int w = tid; w < kWindowSize + 512; w += nth) {
+                const int wi = preslid && w < kWSize ? w + kWSize : w;
+                if (wi >= valid) e.window[w] = ps->window[wi];
+            }
+        }
         // a slow level, one Write, everything read, no pre-insert pending: the tail's searches are done ahead (below) and the
         // engine runs without the hash heads (LitEngine::no_head) -- the table is not built
         use_rec = lv.func == 2 && strategy != kRle && strategy != kHuffmanOnly && s.final_run && !e.wr_end && s.fv_end < 0 &&
                   e.avail_end == e.n && e.avail_end > 0 && ss.preins < p && le_tail_record_end(e) > p &&
                   le_tail_record_end(e) - p <= kTailRecMax;
-        no_head = use_rec && le_no_head_ok(e);
-        if (!no_head)
-            for (int i = tid; i < kHashSize; i += nth) head32[i] = 0;
+        // (... unless the window still holds positions of the engine before a resumed run: their buckets are not the data's)
+        no_head = use_rec && le_no_head_ok(e) && !(s.resume && p - (kWSize - 1) < s.start_pos);
+        if (!no_head) {
+            // (a resumed run: the heads as the engine before it left them, in this window's indices -- the latest member of
+            // a bucket is one of the run's own positions or that; its chains and a FullFlush's forgetting are not the data's)
+            const int64_t shift = s.resume && ps ? e.base - (ps->base - s.persist_off) : 0;
+            for (int i = tid; i < kHashSize; i += nth) {
+                int64_t hv = s.resume && ps ? (int64_t)ps->head[i] : 0;
+                hv = hv != 0 && hv - shift > 0 ? hv - shift : 0;
+                head32[i] = hv ? (uint32_t)hv + 1u : 0u;
+            }
+        }
         __syncthreads();
 #ifdef ZS_FV_PROF
         tk1 = wall_clock64();
@@ -2213,7 +2252,7 @@ __global__ __launch_bounds__(1024) void zs_tail_kernel(const StreamDesc *sd, Str
                 } else {
                     le_restore_prev(e, q, lk);
                 }
-                if (!no_head) atomicMax(&head32[le_bucket(e, q)], (uint32_t)(q - e.base) + 1u);
+                if (!no_head && q >= s.start_pos) atomicMax(&head32[le_bucket(e, q)], (uint32_t)(q - e.base) + 1u);
             }
             __syncthreads();
 #ifdef ZS_FV_PROF
