@@ -194,10 +194,13 @@ ZS_API const char *zs_last_message(const zs_deflate_stream *s);
 /* zs_inflate_init <- Inflate..ctor (Inflate.cs:76-96); only window_bits 15 (zlib-wrapped) runs on the device: NULL otherwise.
  * zs_inflate      <- Inflate.Decompress (Inflate.cs:103-357) as ZLibStream.Inflate(FlushMode) calls it
  *   (ZlibStream.cs:119-122), driven by ZlibInputStream.ReadCore (ZlibInputStream.cs:133-186).  Same cursor convention as
- *   zs_deflate.  The engine decodes whole streams: calls that bring input return ZS_OK after taking it; the first call
- *   with *avail_in == 0 (BaseStream is exhausted) decodes on the GPU and output is served from then on, ZS_STREAM_END
- *   with the last byte.  An incomplete stream at that point is ZS_BUF_ERROR; corrupt data gives ZS_DATA_ERROR with the
- *   reference's message (zs_inflate_message).
+ *   zs_deflate.  The engine decodes whole streams: calls that bring input return ZS_OK after taking it; the stream is decoded
+ *   on the GPU at the call whose input completes it -- the end (final block + Adler-32 trailer, Inflate.cs:292-357) is
+ *   looked for in what has been buffered each time the buffered bytes have doubled, from 512 KiB on -- or at the first
+ *   call with *avail_in == 0 (BaseStream is exhausted); output is served from then on, ZS_STREAM_END with the last byte.
+ *   total_in is the stream's length with its trailer; bytes behind the trailer that the decoding call brought are left to
+ *   the caller (*avail_in), as the managed engine leaves them.  An incomplete stream at the call without input is
+ *   ZS_BUF_ERROR; corrupt data gives ZS_DATA_ERROR with the reference's message (zs_inflate_message).
  *   Malformed streams: incomplete code sets are accepted exactly where Huft_build accepts them (a single code of length
  *   1, InfTree.cs:364); one deliberate difference -- a match distance that reaches before the first output byte is
  *   ZS_DATA_ERROR "invalid distance code" here, the managed engine copies from its zeroed window instead

@@ -97,6 +97,42 @@ if tab:
                        "instructions alone take on the chip's 1024 SIMDs.", "kernels": tab},
               open(os.path.join(dst, "%s_pmc_insts_english64_L6.json" % tag), "w"), indent=1)
 
+# round 3: kernel statistics of the paths beside the headline, the counters of the DeflateFast kernel in a batch
+for w in ("fast512", "writes1000", "scanlines", "flushed64k"):
+    stw = glob.glob(os.path.join(src, "stats_" + w, "**", "*kernel_stats.csv"), recursive=True)
+    if stw:
+        rows = list(csv.reader(open(stw[0])))
+        with open(os.path.join(dst, "%s_%s_kernel_stats.csv" % (tag, w)), "w", newline="") as f:
+            wr = csv.writer(f)
+            wr.writerow(rows[0])
+            for r in rows[1:]:
+                if "zs_" in r[0]:
+                    wr.writerow([short(r[0])] + r[1:])
+    lg = os.path.join(src, "case_%s.log" % w)
+    if os.path.exists(lg) and os.path.getsize(lg) > 0:
+        shutil.copy(lg, os.path.join(dst, "%s_%s_times.log" % (tag, w)))
+tabf = {}
+for d, cs in (("pmc_insts_fast512", names), ("pmc_cycles_fast512", cyc), ("pmc_fetch_fast512", ["FETCH_SIZE"]), ("pmc_write_fast512", ["WRITE_SIZE"])):
+    for cn in cs:
+        for k, v in counter_any(d, cn, "zs_fast").items():
+            tabf.setdefault(k, {})[cn] = int(v)
+if tabf:
+    for k, v in tabf.items():
+        if "SQ_INSTS_VALU" in v:
+            v["valu_issue_ms_at_1024_simds_2.4GHz"] = round(v["SQ_INSTS_VALU"] * 4 / 1024 / 2.4e9 * 1e3, 3)
+        if "FETCH_SIZE" in v:
+            v["fetch_bytes_raw"] = v.pop("FETCH_SIZE") * 1024
+        if "WRITE_SIZE" in v:
+            v["write_bytes"] = v.pop("WRITE_SIZE") * 1024
+    json.dump({"note": "rocprofv3 --pmc (separate passes) over `tools/prof_cases.py fast512 1`: DeflateFast, level 1, 512 x 512 KiB text "
+                       "streams in one batch (256 MiB); mean per launch.", "kernels": tabf},
+              open(os.path.join(dst, "%s_pmc_fast512_L1.json" % tag), "w"), indent=1)
+for name, out in (("flush_resume.log", "flush_resume.log"), ("patho.jsonl", "patho.jsonl"), ("fast_levels.log", "fast_levels.log"),
+                  ("multiwrite_check.log", "multiwrite_check.log")):
+    pth = os.path.join(src, name)
+    if os.path.exists(pth) and os.path.getsize(pth) > 0:
+        shutil.copy(pth, os.path.join(dst, "%s_%s" % (tag, out)))
+
 for name, out in (("bench_default.json", "bench_default.json"), ("bench_english64.json", "bench_english64_L6.json"), ("bench_sparse64.json", "bench_sparse64_L6.json"),
                   ("bench_batch128.json", "bench_batch128x1MiB_L6.json"), ("bench_inflate.json", "bench_inflate1g.json"),
                   ("time_levels.jsonl", "time_levels.jsonl"), ("host_path.jsonl", "host_path.jsonl"),

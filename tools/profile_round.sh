@@ -5,8 +5,13 @@
 set -u
 R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out/prof_round
-rm -rf "$O"; mkdir -p "$O"
+# two gpurun calls (each well inside the 20-minute limit): `profile_round.sh` = the headline's bench lines, statistics and
+# counters; `profile_round.sh extras` = the round-3 paths beside it.  gpurun merges both into gpurun_out/prof_round/.
+PART=${1:-main}
+mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
+if [ "$PART" = main ]; then
+rm -rf "$O"; mkdir -p "$O"
 python3 $R/bench.py --steps 10 --warmup 2 > $O/bench_default.json 2> $O/bench_default.err
 echo "bench default done"
 python3 $R/bench.py --steps 9 --warmup 2 --no-cpu-baseline --no-secondary --inflight 3 > $O/bench_english64_pipelined.json 2> $O/bench_english64_pipelined.err
@@ -23,5 +28,21 @@ echo "traffic pmc done"
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $O/pmc_insts -o run -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary > /dev/null 2> $O/pmc_insts.err
 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS --output-format csv -d $O/pmc_cycles -o run -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary > /dev/null 2> $O/pmc_cycles.err
 echo "inst pmc done"
+else
+# round 3: the paths beside the headline -- DeflateFast in a batch, a stream written in small Writes, a stream that flushes
+for w in fast512 writes1000 scanlines flushed64k; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$w -o run -- python3 $R/tools/prof_cases.py $w > $O/case_$w.log 2> $O/stats_$w.err
+done
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $O/pmc_insts_fast512 -o run -- python3 $R/tools/prof_cases.py fast512 1 > /dev/null 2> $O/pmc_insts_fast512.err
+rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS --output-format csv -d $O/pmc_cycles_fast512 -o run -- python3 $R/tools/prof_cases.py fast512 1 > /dev/null 2> $O/pmc_cycles_fast512.err
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_fast512 -o run -- python3 $R/tools/prof_cases.py fast512 1 > /dev/null 2> $O/pmc_fetch_fast512.err
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_fast512 -o run -- python3 $R/tools/prof_cases.py fast512 1 > /dev/null 2> $O/pmc_write_fast512.err
+echo "round 3 cases done"
+python3 $R/tools/flush_resume_bench.py > $O/flush_resume.log 2> $O/flush_resume.err
+python3 $R/tools/patho.py > $O/patho.jsonl 2> $O/patho.err
+python3 $R/tools/fast_levels.py > $O/fast_levels.log 2> $O/fast_levels.err
+python3 $R/tools/multiwrite_check.py > $O/multiwrite_check.log 2> $O/multiwrite_check.err
+echo "tables done"
+fi
 find $O -name "*.csv" -size +20M -delete
 ls -R $O | head -60

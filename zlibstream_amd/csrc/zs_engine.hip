@@ -1380,7 +1380,7 @@ bool run_inflate_par(zs_ctx *c, const std::vector<int> &idx, const void *const *
         hipLaunchKernelGGL(zs_inf_chain_par_kernel, dim3((unsigned)m), dim3(1024), kChainParLds, stream, d_ps, d_st, dev<ParCand>(c->par_cands),
                            dev<ParBlock>(c->par_blocks), lane_decode ? 1 : 0);
     hipLaunchKernelGGL(zs_inf_chain_kernel, dim3((unsigned)m), dim3(64), 0, stream, d_ps, d_st, dev<ParCand>(c->par_cands),
-                       dev<ParBlock>(c->par_blocks), lane_decode ? 1 : 0, chain_par ? 1 : 0);
+                       dev<ParBlock>(c->par_blocks), lane_decode ? 1 : 0, (chain_par ? 1 : 0) | (c->inf_probe ? 2 : 0));
     mark(3);
     ZS_HIP(c, hipMemcpyAsync(st.data(), d_st, sizeof(ParState) * (size_t)m, hipMemcpyDeviceToHost, stream));
     ZS_HIP(c, hipStreamSynchronize(stream));

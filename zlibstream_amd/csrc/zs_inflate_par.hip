@@ -972,7 +972,8 @@ __global__ __launch_bounds__(64) void zs_inf_chain_kernel(const ParStream *ps, P
     const ParStream s = ps[blockIdx.x];
     ParState &ss = st[blockIdx.x];
     if (!ss.ok) return;
-    if (tried && ss.nblk >= 1) return;  // zs_inf_chain_par_kernel has done it
+    if ((tried & 1) && ss.nblk >= 1) return;  // zs_inf_chain_par_kernel has done it
+    const bool probing = (tried & 2) != 0;  // zs_inflate asking whether the stream's end has arrived (nothing is decoded)
     const ParCand *cd = cands + s.cand_off;
     ParBlock *bl = blocks + s.blk_off;
     const int ncand = ss.ncand;
@@ -1015,6 +1016,11 @@ __global__ __launch_bounds__(64) void zs_inf_chain_kernel(const ParStream *ps, P
         if (ci < ncand && rl64(m_bit, k) == cur && rl(m_ok, k)) {
             end = rl64(m_end, k), nbytes = rl64(m_out, k), bfinal = rl(m_bfinal, k);
             tab = lane_decode ? rl(m_tab, k) : -1;
+        } else if (probing && ci < ncand && rl64(m_bit, k) == cur) {
+            // the measuring pass has been through this block and did not reach its end: the input ends inside it (a whole
+            // block decoded again by this one wave, to find the same, cost the caller's loop 3-6 ms per look)
+            ok = 0;
+            break;
         } else {
             // a block the finder does not report (stored / fixed codes): measure it here
             inf_seek(b, cur);
