@@ -127,7 +127,7 @@ if tabf:
     json.dump({"note": "rocprofv3 --pmc (separate passes) over `tools/prof_cases.py fast512 1`: DeflateFast, level 1, 512 x 512 KiB text "
                        "streams in one batch (256 MiB); mean per launch.", "kernels": tabf},
               open(os.path.join(dst, "%s_pmc_fast512_L1.json" % tag), "w"), indent=1)
-for name, out in (("flush_resume.log", "flush_resume.log"), ("patho.jsonl", "patho.jsonl"), ("fast_levels.log", "fast_levels.log"),
+for name, out in (("flush_resume.log", "flush_resume.log"), ("patho.jsonl", "patho_final_build_L6.log"), ("fast_levels.log", "fast_levels.log"),
                   ("multiwrite_check.log", "multiwrite_check.log")):
     pth = os.path.join(src, name)
     if os.path.exists(pth) and os.path.getsize(pth) > 0:

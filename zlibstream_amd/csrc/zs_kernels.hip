@@ -1190,6 +1190,9 @@ __global__ __launch_bounds__(1024) void zs_resolve_kernel(const StreamDesc *sd, 
     __shared__ uint32_t sh_total;
     const StreamDesc s = sd[blockIdx.x];
     StreamState &ss = st[blockIdx.x];
+#ifdef ZS_FV_PROF
+    const long long k4_t0 = wall_clock64();
+#endif
     load_crc_tab(tab, crc_tab_g);
     // seg_limit / mm_limit (one long stream run part by part, else "everything"): segments below seg_limit have their maps,
     // positions up to mm_limit their match records; the kernel goes on from where the launch before stopped
@@ -1366,13 +1369,62 @@ __global__ __launch_bounds__(1024) void zs_resolve_kernel(const StreamDesc *sd, 
     }
 #ifdef ZS_FV_PROF
     long long kp[6] = {0, 0, 0, 0, 0, 0}, kt = wall_clock64();
+    const long long k4_t1 = kt;
     int kiter = 0;
 #define K4_PF(i) { const long long now_ = wall_clock64(); kp[i] += now_ - kt; kt = now_; }
 #else
 #define K4_PF(i)
 #endif
+    // The rows a fast stretch has walked wait here until their segments' entries are filled in (one thread per row follows
+    // its sixteen segment maps: sixteen dependent loads, ~30 us whatever the number of rows, so the stretches of a stream
+    // share one such pass; it runs before anything looks at the results: the long way below, the cuts, the kernel's end)
+    constexpr int kPendRows = 512;
+    __shared__ uint16_t pf_slot[kPendRows];
+    __shared__ uint32_t pf_base[kPendRows];
+    __shared__ int pf_g0, pf_n;
+    if (threadIdx.x == 0) pf_g0 = 0, pf_n = 0, fp_kf = 0;
+    __syncthreads();
+    auto flush_fill = [&]() {  // every thread of the workgroup
+        const int n_p = pf_n, g_p = pf_g0;
+        if (n_p == 0) return;
+        for (int t = threadIdx.x; t < n_p; t += blockDim.x) {
+            const int g = g_p + t;
+            int cur = pf_slot[t];
+            uint32_t total = pf_base[t];
+            unsigned long long kf = 0;
+            // (the segments' flags come from three levels of tables: all sixteen asked for before the chain of map lookups)
+            uint32_t metas[kSupSegs];
+#pragma unroll
+            for (int r = 0; r < kSupSegs; r++) {
+                const int seg = g * kSupSegs + r;
+                metas[r] = seg < s.nsegs ? seg_row_meta(s, seg, seg_stale) : 0u;
+            }
+#pragma unroll
+            for (int r = 0; r < kSupSegs; r++) {
+                const int seg = g * kSupSegs + r;
+                if (seg >= s.nsegs) break;
+                const uint2 v = segmap[((int64_t)s.seg_off + seg) * kSlots + cur];
+                const uint32_t m = metas[r];
+                if ((m & 1u) && (uint32_t)(cur <= 256 ? cur : 0) <= (m >> 2)) {
+                    kf = ((unsigned long long)(seg + 1) << 16) | (unsigned)cur;
+                    if (dry && (v.x & kMapEqualBit) && strategy != kHuffmanOnly) collect_cuts(seg, cur, 0, 0);
+                }
+                seg_entry[s.seg_off + seg] = (uint16_t)cur;
+                seg_symbase[s.seg_off + seg] = total;
+                cur = (int)(v.x & 0x1FF);
+                total += v.y;
+            }
+            if (kf) atomicMax(&fp_kf, kf);  // the last segment whose events fired
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            if (fp_kf) sh_kfired = (int)(fp_kf >> 16) - 1, sh_kslot = (int)(fp_kf & 0xFFFF);
+            pf_n = 0, fp_kf = 0;
+        }
+        __syncthreads();
+    };
     for (;;) {
-        if (sh_seg >= nseg || sh_defer || sh_poison) break;  // done, or the rest of a cluster's cuts stopped again
+        const bool k4_done = sh_seg >= nseg || sh_defer || sh_poison;  // done, or the rest of a cluster's cuts stopped again
 #ifdef ZS_FV_PROF
         kiter++;
         kt = wall_clock64();
@@ -1383,12 +1435,14 @@ __global__ __launch_bounds__(1024) void zs_resolve_kernel(const StreamDesc *sd, 
         //      through them -- 1/16 of the dependent lookups and of the bytes this one CU has to pull -- and one thread per
         //      row then fills in its segments' entries and symbol bases from the segment maps.  A flagged or stale row is
         //      walked the long way below, and the stretches go on behind it. ----
-        if (can_sup && (sh_seg % kSupSegs) == 0 && !sh_scan) {
+        bool went_fast = false;
+        if (!k4_done && can_sup && (sh_seg % kSupSegs) == 0 && !sh_scan) {
             const int g0 = sh_seg / kSupSegs, nsup = (s.nsegs + kSupSegs - 1) / kSupSegs;
             int nrow = nsup - g0;
             if (nrow > kSegBatch) nrow = kSegBatch;
-            if (threadIdx.x == 0) fs_try = !(supmap[((int64_t)s.sup_off + g0) * kSlots + sh_slot].x & attn), fs_n = 0, fp_kf = 0;
+            if (threadIdx.x == 0) fs_try = !(supmap[((int64_t)s.sup_off + g0) * kSlots + sh_slot].x & attn), fs_n = 0;
             __syncthreads();
+            K4_PF(0);
             if (fs_try) {  // uniform over the workgroup
                 const uint4 *src = (const uint4 *)(supmap + ((int64_t)s.sup_off + g0) * kSlots);
                 for (int i = threadIdx.x; i < nrow * kSlots / 2; i += blockDim.x) ((uint4 *)rows)[i] = src[i];
@@ -1401,49 +1455,35 @@ __global__ __launch_bounds__(1024) void zs_resolve_kernel(const StreamDesc *sd, 
                     row_meta[threadIdx.x] = st_any;
                 }
                 __syncthreads();
+                K4_PF(1);
                 if (threadIdx.x == 0) {
                     int slot = sh_slot, i = 0;
                     uint32_t total = sh_total;
+                    if (pf_n == 0) pf_g0 = g0;
                     for (; i < nrow; i++) {
                         const uint2 e = rows[i * kSlots + slot];
                         if ((e.x & attn) || row_meta[i]) break;
-                        out_slot[i] = (uint16_t)slot, out_base[i] = total;
+                        pf_slot[pf_n + i] = (uint16_t)slot, pf_base[pf_n + i] = total;
                         slot = (int)(e.x & 0x1FF), total += e.y;
                     }
                     sh_slot = slot, sh_total = total, fs_n = i, b_nrow = 0;
-                }
-                __syncthreads();
-                if ((int)threadIdx.x < fs_n) {
-                    const int g = g0 + (int)threadIdx.x;
-                    int cur = out_slot[threadIdx.x];
-                    uint32_t total = out_base[threadIdx.x];
-                    unsigned long long kf = 0;
-                    for (int r = 0; r < kSupSegs; r++) {
-                        const int seg = g * kSupSegs + r;
-                        if (seg >= s.nsegs) break;
-                        const uint2 v = segmap[((int64_t)s.seg_off + seg) * kSlots + cur];
-                        const uint32_t m = seg_row_meta(s, seg, seg_stale);
-                        if ((m & 1u) && (uint32_t)(cur <= 256 ? cur : 0) <= (m >> 2)) {
-                            kf = ((unsigned long long)(seg + 1) << 16) | (unsigned)cur;
-                            if (dry && (v.x & kMapEqualBit) && strategy != kHuffmanOnly) collect_cuts(seg, cur, 0, 0);
-                        }
-                        seg_entry[s.seg_off + seg] = (uint16_t)cur;
-                        seg_symbase[s.seg_off + seg] = total;
-                        cur = (int)(v.x & 0x1FF);
-                        total += v.y;
+                    pf_n += i;
+                    if (i > 0) {
+                        const int seg = (g0 + i) * kSupSegs;
+                        sh_seg = seg > s.nsegs ? s.nsegs : seg;
                     }
-                    if (kf) atomicMax(&fp_kf, kf);  // the last segment whose events fired
                 }
                 __syncthreads();
-                if (threadIdx.x == 0 && fs_n > 0) {
-                    int seg = (g0 + fs_n) * kSupSegs;
-                    sh_seg = seg > s.nsegs ? s.nsegs : seg;
-                    if (fp_kf) sh_kfired = (int)(fp_kf >> 16) - 1, sh_kslot = (int)(fp_kf & 0xFFFF);
-                }
-                __syncthreads();
-                if (fs_n > 0) continue;
+                K4_PF(2);
+                went_fast = fs_n > 0;
+                // (the rows' segments are filled in later, those of several stretches at once: flush_fill)
+                if (fs_n == nrow && pf_n + kSegBatch <= kPendRows && sh_seg < nseg) continue;
             }
         }
+        flush_fill();
+        K4_PF(5);
+        if (k4_done) break;
+        if (went_fast) continue;
         // ---- stage the next kSegBatch segment-map rows (coalesced), then thread 0 follows the path through them
         //      (one LDS lookup per segment; its per-segment results go out coalesced afterwards); it stops early
         //      when a refill needs the whole workgroup ----
@@ -1626,6 +1666,7 @@ __global__ __launch_bounds__(1024) void zs_resolve_kernel(const StreamDesc *sd, 
         if (sh_defer || sh_poison) break;
     }
 #ifdef ZS_FV_PROF
+    const long long k4_t2 = wall_clock64();
     if (threadIdx.x == 0 && blockIdx.x == 0 && kiter > 4)
         printf("K4PROF iterations=%d ticks: stage+meta=%lld compose=%lld walk=%lld fill+flush=%lld repair=%lld\n", kiter, kp[0], kp[1], kp[2], kp[3], kp[4]);
 #endif
@@ -1686,6 +1727,10 @@ __global__ __launch_bounds__(1024) void zs_resolve_kernel(const StreamDesc *sd, 
         }
         ss.preins = lev.pos >= 0 ? (int32_t)lev.pos + 1 : -1;
         ss.body_syms = sh_total;
+#ifdef ZS_FV_PROF
+        const long long k4_t3 = wall_clock64();
+        if (blockIdx.x == 0) printf("K4PROF ticks: prologue=%lld loop=%lld epilogue=%lld segs=%d; fast stretches: try=%lld stage=%lld walk=%lld fill=%lld\n", k4_t1 - k4_t0, k4_t2 - k4_t1, k4_t3 - k4_t2, s.nsegs, kp[0], kp[1], kp[2], kp[5]);
+#endif
     }
 }
 
