@@ -700,6 +700,26 @@ def test_short_runs_between_flushes_take_the_bulk_path(engine, oracle):
 
 
 @pytest.mark.gpu
+def test_random_streams_that_once_differed(engine, oracle):
+    """tools/fuzz_streams.py (random data kinds, Write sizes, flush modes, levels, strategies; 12 000 streams in 14 minutes)
+    found two things, each about once in a thousand streams.  A flush whose run also carried NoFlush Writes that had been
+    waiting could hand out its last byte with the caller's chunk exactly full; the caller's loop then comes back with nothing
+    to write (ZlibOutputStream.cs:125-168), and that call ran the engine for the flush a second time: two more empty blocks.
+    And a Write of one or two bytes behind a flush, where a read's two inserts share a bucket of stale hashes, leaves a forward
+    pointer in prev[] that no later insert closes into a cycle (Deflate.cs:1009-1012 with lookahead < MIN_MATCH at the next
+    loop-top): the chains cannot be handed to the bulk pipeline as links, the stream stays with the literal engine
+    (zs_resume_check_kernel).  The seeds that showed them, whole."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_cases
+    for seed in (2924, 3050, 3929, 4623, 4893, 5300, 6403, 7128, 8883, 11354, 11441, 11724):
+        data, sizes, fl, level, strategy = fuzz_cases.make(np.random.default_rng(seed))
+        z = _flushed_stream(engine, data, sizes, fl, level, strategy)
+        assert zlib.decompress(z) == data, seed
+        assert z == oracle.compress_writes(data, level, strategy, sizes, fl), seed
+
+
+@pytest.mark.gpu
 def test_flush_mode_single_write_takes_the_bulk_path(engine, oracle):
     """One Write under SyncFlush at level 6: the bulk pipeline runs (the tail engine closes the block, the offsets kernel
     adds the marker and the re-entered empty block); 8 MiB so that the sequential engine would be visible in the time."""

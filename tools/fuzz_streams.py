@@ -2,14 +2,13 @@
 seconds.   python tools/fuzz_streams.py [seconds] [seed]      (prints every failing case with what reproduces it)"""
 import io, os, sys, time, zlib
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "tools"))
 import numpy as np
 import oracle_binding
 from zlibstream_amd import CompressionLevel, Engine, ZlibOptions, ZlibOutputStream, datagen
 eng = Engine(0); orc = oracle_binding.Oracle()
-budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
-seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-text = datagen.english(6 << 20, datagen.GOLDEN)
+budget = float(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1] != "seeds" else 60.0
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[1] != "seeds" else 1
 def run(data, chunks, fl, level, strategy):
     out = io.BytesIO()
     s = ZlibOutputStream(out, ZlibOptions(CompressionLevel=CompressionLevel(level), CompressionStrategy=strategy, FlushMode=0), engine=eng)
@@ -20,45 +19,39 @@ def run(data, chunks, fl, level, strategy):
     s.Options.FlushMode = 0
     s.close()
     return out.getvalue()
-def make(rng):
-    kind = int(rng.integers(0, 7))
-    n = int(rng.choice([40000, 100000, 300000, 700000, 1500000, 3000000]))
-    if kind == 0:
-        o = int(rng.integers(0, len(text) - n)); data = text[o:o + n]
-    elif kind == 1:
-        data = rng.choice(np.array([0, 0, 0, 0, 1, 2, 255], dtype=np.uint8), n).tobytes()
-    elif kind == 2:
-        data = bytes(n)
-    elif kind == 3:
-        data = rng.integers(0, 256, n, dtype=np.uint8).tobytes()
-    elif kind == 4:
-        data = np.repeat(rng.integers(0, 256, n // 20 + 1, dtype=np.uint8), rng.integers(1, 60, n // 20 + 1))[:n].tobytes()
-    elif kind == 5:  # text with zero pages
-        a = bytearray(text[:n])
-        for _ in range(n // 40000 + 1):
-            o = int(rng.integers(0, max(1, n - 9000))); a[o:o + int(rng.integers(100, 9000))] = bytes(9000)[:min(9000, n - o)][:len(a[o:o + 9000])]
-        data = bytes(a[:n])
-    else:  # periodic
-        p = rng.integers(0, 256, int(rng.integers(1, 600)), dtype=np.uint8).tobytes()
-        data = (p * (n // len(p) + 1))[:n]
-    n = len(data)
-    style = int(rng.integers(0, 5))
-    sizes = []
-    o = 0
-    while o < n:
-        if style == 0: c = int(rng.choice([1, 3, 100, 261, 262, 263, 1000, 4096, 6144, 8192, 16385, 32768, 65536, 81921, 200000]))
-        elif style == 1: c = int(rng.integers(1, 70000))
-        elif style == 2: c = int(rng.integers(6000, 400000))
-        elif style == 3: c = int(rng.choice([32768, 65536, 65274, 65275, 32506, 98304])) - int(rng.integers(0, 300))
-        else: c = int(rng.integers(200000, 2000000))
-        c = max(1, min(c, n - o)); sizes.append(c); o += c
-    pf = float(rng.choice([0.0, 0.05, 0.3, 1.0]))
-    fl = [int(rng.choice([1, 2, 3])) if rng.random() < pf else 0 for _ in sizes]
-    level = int(rng.choice([4, 5, 6, 6, 6, 7, 8, 9]))
-    strategy = int(rng.choice([0, 0, 0, 1, 2]))
-    return data, sizes, fl, level, strategy
+from fuzz_cases import make
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "seeds":
+    # the named cases again: the shortest prefix of the Writes that still differs, and where
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from deflate_tokens import tokens
+    for sd in map(int, sys.argv[2:]):
+        data, sizes, fl, level, strategy = make(np.random.default_rng(sd))
+        def bad(m):
+            d = data[:sum(sizes[:m])]
+            return run(d, sizes[:m], fl[:m], level, strategy) != orc.compress_writes(d, level, strategy, sizes[:m], fl[:m])
+        if not bad(len(sizes)):
+            print("seed", sd, "passes now"); continue
+        lo, hi = 1, len(sizes)
+        while lo < hi:
+            mid = (lo + hi) // 2
+            if bad(mid): hi = mid
+            else: lo = mid + 1
+        m = lo
+        d = data[:sum(sizes[:m])]
+        z, w = run(d, sizes[:m], fl[:m], level, strategy), orc.compress_writes(d, level, strategy, sizes[:m], fl[:m])
+        ends = np.cumsum(sizes[:m]).tolist()
+        print("seed", sd, "level", level, "strategy", strategy, "fails with the first", m, "of", len(sizes), "Writes; (size, flush, end):", list(zip(sizes[:m], fl[:m], ends))[-8:], "lengths", len(z), len(w))
+        try:
+            tz, bz = tokens(z); tw, bw = tokens(w)
+            db = next((i for i in range(min(len(bz), len(bw))) if bz[i] != bw[i]), None)
+            print("   blocks ours / want:", len(bz), len(bw), "first different block", db, bz[db - 1:db + 2] if db is not None else None, bw[db - 1:db + 2] if db is not None else None)
+            dt = next((i for i in range(min(len(tz), len(tw))) if tz[i] != tw[i]), None)
+            print("   first different token", dt, tz[dt - 2:dt + 3] if dt is not None else None, tw[dt - 2:dt + 3] if dt is not None else None, "tokens", len(tz), len(tw))
+        except Exception as e:
+            print("   tokens:", repr(e))
+    sys.exit(0)
 t0 = time.time(); cases = fails = 0; seed = seed0
-while time.time() - t0 < budget:
+while __name__ == "__main__" and time.time() - t0 < budget:
     rng = np.random.default_rng(seed)
     data, sizes, fl, level, strategy = make(rng)
     try:
@@ -75,5 +68,7 @@ while time.time() - t0 < budget:
     if cases % 50 == 0:
         print("... %d cases, %d failures, %.0f s" % (cases, fails, time.time() - t0), flush=True)
     seed += 1
-print("fuzz: %d cases from seed %d, %d failures, %.0f s; literal-engine fallbacks of the bulk path: n/a" % (cases, seed0, fails, time.time() - t0))
-sys.exit(1 if fails else 0)
+if __name__ == "__main__":
+  print("fuzz: %d cases from seed %d, %d failures, %.0f s; literal-engine fallbacks of the bulk path: n/a" % (cases, seed0, fails, time.time() - t0))
+if __name__ == "__main__":
+    sys.exit(1 if fails else 0)

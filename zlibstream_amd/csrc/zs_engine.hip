@@ -56,7 +56,7 @@ struct zs_ctx {
     uint32_t *crc_tab = nullptr;
     DevBuf sd, st, work, wpre, geo, link, mm, maps, chunk_far, segmap, supmap, seg_entry, seg_symbase, seg_stale, entry, symbase, stale, syms, blk_end, blk_top, blocks, trees, info, pieces, scratch,
         stage_in, stage_out, wr, inf_desc, inf_state, par_ps, par_st, par_work, par_cbits, par_ccnt, par_surv, par_scnt, par_cands, par_tabs, par_blocks, par_cells,
-        par_windows, par_fail, run_syms, run_bits, run_scratch, run_outs, run_fail, adl_tr, adl_res, plan_blk, ins_bits, fv_lists, mm_bak, cut_pos, cut_bkt, win_groups, win_sg, win_maps, win_entries, persist_bak;
+        par_windows, par_fail, run_syms, run_bits, run_scratch, run_outs, run_fail, adl_tr, adl_res, plan_blk, ins_bits, fv_lists, mm_bak, cut_pos, cut_bkt, win_groups, win_sg, win_maps, win_entries, persist_bak, resume_flag;
     bool resume_poisoned = false;  // a resumed run met a read the bulk form does not handle: the caller goes on with the literal engine
     void *pinned = nullptr;
     size_t pinned_cap = 0;
@@ -849,6 +849,34 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
     ZS_HIP(c, hipMemcpyAsync(hst, d_st, sizeof(StreamState) * (size_t)n, hipMemcpyDeviceToHost, stream));
     ZS_HIP(c, hipStreamSynchronize(stream));
     c->last_op = lv.func == 1 ? 2 : 0;
+    if (getenv("ZS_DEBUG_CHAIN") && n == 1) {  // the chain of one position as the kernels saw it (buffer positions)
+        const int64_t q0 = atoll(getenv("ZS_DEBUG_CHAIN")) - (ro ? ro->abs_off : 0);
+        if (q0 > 0 && q0 < in_len[0]) {
+            std::vector<uint16_t> lk((size_t)in_len[0]);
+            (void)hipMemcpy(lk.data(), dev<uint16_t>(c->link) + pl.sd[0].pos_off, 2 * (size_t)in_len[0], hipMemcpyDeviceToHost);
+            fprintf(stderr, "[zs] run of %lld bytes (stream position %lld on), resume %d at %lld: chain of %lld:", (long long)in_len[0], (long long)(ro ? ro->abs_off : 0),
+                    pl.sd[0].resume, (long long)pl.sd[0].start_pos, (long long)q0);
+            int64_t q = q0;
+            int hops = 0;
+            const int64_t want = getenv("ZS_DEBUG_CHAIN_WANT") ? atoll(getenv("ZS_DEBUG_CHAIN_WANT")) - (ro ? ro->abs_off : 0) : -1;
+            int want_at = -1;
+            while (lk[(size_t)q] && hops < 100000) {
+                q -= lk[(size_t)q], hops++;
+                if (hops <= 12) fprintf(stderr, " %lld", (long long)q);
+                if (q == want) want_at = hops;
+            }
+            fprintf(stderr, " ... %d hops, ends at %lld; position %lld is hop %d\n", hops, (long long)q, (long long)want, want_at);
+        }
+    }
+    if (getenv("ZS_DEBUG_FA") && writes && pl.sd[0].wr_blk) {  // the flush accounting's inputs: blocks flushed before each Write began
+        const size_t nw = writes->ends.size();
+        std::vector<int32_t> wb(nw);
+        (void)hipMemcpy(wb.data(), pl.sd[0].wr_blk, 4 * nw, hipMemcpyDeviceToHost);
+        fprintf(stderr, "[zs] run of %lld bytes, %zu Writes, %d blocks, body ends at %d, resume %d; blocks before each Write:", (long long)in_len[0], nw, hst[0].nblocks,
+                pl.sd[0].body_end, pl.sd[0].resume);
+        for (size_t k = 0; k < nw && k < 24; k++) fprintf(stderr, " %d(end %lld, flush %d)", wb[k], (long long)writes->ends[k], writes->flush.empty() ? 0 : writes->flush[k]);
+        fprintf(stderr, "\n");
+    }
     if (prof) {
         for (int i = 0; i < kStCount; i++) {
             float ms = 0;
@@ -1076,7 +1104,7 @@ void zs_ctx_destroy(zs_ctx *c) {
     DevBuf *bufs[] = {&c->sd, &c->st, &c->work, &c->wpre, &c->geo, &c->link, &c->mm, &c->maps, &c->chunk_far, &c->segmap, &c->supmap, &c->seg_entry, &c->seg_symbase, &c->seg_stale, &c->entry, &c->symbase, &c->stale, &c->syms,
                       &c->blk_end, &c->blk_top, &c->blocks, &c->trees, &c->info, &c->pieces, &c->scratch, &c->stage_in, &c->stage_out, &c->wr, &c->inf_desc, &c->inf_state, &c->par_ps, &c->par_st, &c->par_work, &c->par_cbits, &c->par_ccnt, &c->par_surv, &c->par_scnt,
                       &c->par_cands, &c->par_tabs, &c->par_blocks, &c->par_cells, &c->par_windows, &c->par_fail, &c->run_syms, &c->run_bits,
-                      &c->run_scratch, &c->run_outs, &c->run_fail, &c->adl_tr, &c->adl_res, &c->plan_blk, &c->ins_bits, &c->fv_lists, &c->mm_bak, &c->cut_pos, &c->cut_bkt, &c->win_groups, &c->win_sg, &c->win_maps, &c->win_entries, &c->persist_bak};
+                      &c->run_scratch, &c->run_outs, &c->run_fail, &c->adl_tr, &c->adl_res, &c->plan_blk, &c->ins_bits, &c->fv_lists, &c->mm_bak, &c->cut_pos, &c->cut_bkt, &c->win_groups, &c->win_sg, &c->win_maps, &c->win_entries, &c->persist_bak, &c->resume_flag};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     if (c->crc_tab) (void)hipFree(c->crc_tab);

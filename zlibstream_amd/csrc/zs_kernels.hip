@@ -530,6 +530,20 @@ __global__ __launch_bounds__(1024) void zs_import_chains_kernel(const StreamDesc
     lk[q] = (uint16_t)d;
 }
 
+// Can the chains of the suspended engine be written as links at all?  A link is a distance back; the engine's prev[] has an
+// entry that points *forward* where a read inserted strstart + 1 ahead of strstart into one bucket (prev[s] = s + 1).  When
+// s + 1 is inserted again at its own loop-top the two close a cycle, which a walk leaves only by running out of budget: a
+// cut, and a link of 0 says that.  But a Write of one or two bytes behind a flush never reaches that second insert
+// (lookahead < MIN_MATCH), and the walk goes on from s + 1 into the older chain -- a path links cannot hold: such a stream
+// (seen once in 12 000 random ones) stays with the literal engine.  flag[0] = 1 then.
+__global__ __launch_bounds__(1024) void zs_resume_check_kernel(const LitPersist *ps, int64_t p0_abs, int *flag) {
+    const int64_t q = p0_abs - kWSize + (int64_t)blockIdx.x * 1024 + threadIdx.x;
+    if (q < ps->base || q < 0 || q >= p0_abs) return;
+    const int idx = (int)(q - ps->base);
+    const int pv = ps->prev[idx & kWMask];
+    if (pv > idx && pv < kWindowSize && ps->prev[pv & kWMask] != idx && pv - idx < kWSize) flag[0] = 1;
+}
+
 // ------------------------------------------------------------------ K2
 // 1024 threads per 16 Ki-position tile; the tile's 48 KiB of input and 96 KiB
 // of links are staged in LDS once, then every lane walks hash chains for one
