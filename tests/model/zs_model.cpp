@@ -235,7 +235,7 @@ static void parse_fast_vec(Model &m, int64_t &p_out, int &kdone_out, int64_t &pr
         fv_max_iters = 0;
         for (int i = 0; i < limit; i++) {
             const long v0 = acc.visits;
-            res[i] = fv_search(acc, p0 + i, p0, m.lv.chain, m.lv.nice, !search || (i == 0 && dead0) || (i == 1 && dead1), i == 1 && only1);
+            res[i] = fv_search(acc, p0 + i, p0, m.lv.chain, m.lv.nice, !search || (i == 0 && dead0) || (i == 1 && dead1), search && i == 1 && only1);
             if (acc.visits - v0 > fv_max_iters) fv_max_iters = acc.visits - v0;
         }
         auto rf = [&](int i) { return res[i]; };

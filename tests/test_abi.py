@@ -3,6 +3,7 @@ No compute calls: this runs without a GPU."""
 import ctypes
 import os
 import re
+import subprocess
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -59,3 +60,15 @@ def test_engine_fails_loudly_without_gpu():
 def test_cpp_host_mirror_compiles():
     import subprocess
     subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-Wall", os.path.join(ROOT, "tests", "cpp", "test_host_mirror.cpp")], check=True)
+
+
+def test_geometry_tables_hold_their_invariants():
+    """zs_core.h build_geometry on 20 000 random Write schedules -- fresh streams, runs behind a stop of the literal engine,
+    runs that begin where a flush left the stream: the chunks tile the body, a segment's first chunk holds every loop-top at
+    which its cluster's reads can fire, the clusters hold every Write end and window end once and in order, window bases and
+    slide thresholds follow the window ends (tests/cpp/test_geometry.cpp; what the kernels read from these tables)."""
+    exe = os.path.join(ROOT, "build", "test_geometry")
+    os.makedirs(os.path.dirname(exe), exist_ok=True)
+    subprocess.run(["g++", "-O2", "-std=c++17", "-o", exe, os.path.join(ROOT, "tests", "cpp", "test_geometry.cpp")], check=True)
+    r = subprocess.run([exe, "20000"], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.strip().splitlines()[-1].startswith("PASS"), r.stdout[-2000:]

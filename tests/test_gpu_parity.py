@@ -89,6 +89,18 @@ def test_fast_levels_run_on_device(engine, oracle):
             assert engine.deflate_batch([d], level=lvl)[0] == oracle.compress(d, lvl)
 
 
+def test_fast_levels_under_huffman_only_and_filtered(engine, oracle):
+    """DeflateFast never calls Longest_match under HuffmanOnly (Deflate.Fast.cs:61-66) -- also not at the position a read
+    inserted ahead when it shares its bucket with the loop-top (the one search that sees a single candidate): zeros, where
+    every read is such a one, and streams past the first window end (found by tools/fuzz_batch.py)."""
+    rng = np.random.default_rng(5)
+    low = rng.choice(np.array([0, 0, 0, 0, 1, 2, 255], dtype=np.uint8), 150000).tobytes()
+    for d in (bytes(98304), bytes(150000), low, oracle_binding.corpus("alice29.txt")[:150000], bytes(65536), bytes(65537)):
+        for lvl in (1, 2, 3):
+            for strategy in (2, 1, 4):
+                assert engine.deflate_batch([d], level=lvl, strategy=strategy)[0] == oracle.compress(d, lvl, strategy), (len(d), lvl, strategy)
+
+
 def test_mul_hash_variant(engine, oracle):
     d = oracle_binding.corpus("alice29.txt")
     assert engine.deflate_batch([d], level=6, hash_variant=1)[0] == oracle.compress(d, 6, hash_variant=1)

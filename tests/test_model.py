@@ -57,6 +57,23 @@ def test_strategies_and_fast_levels(model):
             run(model[name], level, 0, "seq")
 
 
+def test_fast_levels_for_the_lanes_of_a_wave(model, tmp_path):
+    """DeflateFast as zs_fast_vec_kernel does it (zs_fast_vec.h: 64 positions searched as if each were a loop-top, the
+    parse's hops followed through the lanes, the inserted-position bitmap), with the kernels' own code on the CPU: levels 1-3,
+    every strategy but Rle -- under HuffmanOnly no search happens, also not the one-candidate search behind an equal-bucket
+    read (Deflate.Fast.cs:61-66) --, streams past the first and second window end."""
+    rng = np.random.default_rng(11)
+    extra = {"low150k": rng.choice(np.array([0, 0, 0, 0, 1, 2, 255], dtype=np.uint8), 150000).tobytes(), "zeros150k": bytes(150000)}
+    files = dict(model)
+    for k, v in extra.items():
+        (tmp_path / k).write_bytes(v)
+        files[k] = str(tmp_path / k)
+    for name in ("alice_98304", "zeros_98305", "lowent_98305", "alice_65537", "ptt5", "cp.html", "runs", "low150k", "zeros150k", "alice_600", "alice_5"):
+        for level in (1, 2, 3):
+            for strategy in (0, 2) if name in ("ptt5", "cp.html", "runs") else (0, 1, 2, 4):
+                run(files[name], level, strategy, "fvec")
+
+
 def test_multi_write_literal_engine(model):
     for name in ("alice_98304", "lowent_65537", "zeros_98305"):
         for w in (1, 100, 8192, 65536, 70000):

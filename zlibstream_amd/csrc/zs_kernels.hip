@@ -2796,7 +2796,7 @@ __global__ __launch_bounds__(1024) void zs_fast_vec_kernel(const StreamDesc *sd,
                 if (body_end - p0 + 1 < limit) limit = (int)(body_end - p0 + 1);
                 const int qi = (int)(p0 - lo) + lane, p0i = (int)(p0 - lo);
                 const bool dead = !search || lane >= limit || (lane == 0 && dead0) || (lane == 1 && dead1);
-                const bool only_prev = lane == 1 && only1;
+                const bool only_prev = search && lane == 1 && only1;  // (HuffmanOnly: Longest_match is never called, Deflate.Fast.cs:61-66)
                 int found = 0, best = 2, bdist = 0, cond = 0;
                 int done = (dead || only_prev) ? 1 : 0;
                 if (only_prev && lane < limit) {
