@@ -269,6 +269,15 @@ static void parse_fast_vec(Model &m, int64_t &p_out, int &kdone_out, int64_t &pr
     p_out = st.p;
     kdone_out = st.k_fired;
     preins_out = st.preins;
+    if (getenv("ZS_MODEL_DEBUG_POS")) {  // the all-position chain of one position with the inserted flags
+        int64_t q = atoll(getenv("ZS_MODEL_DEBUG_POS"));
+        printf("chain of %lld (handed over at %lld, pre-insert %lld):", (long long)q, (long long)st.p, (long long)st.preins);
+        for (int k = 0; k < 60 && m.link[(size_t)q]; k++) {
+            q -= m.link[(size_t)q];
+            printf(" %lld%s", (long long)q, m.ins[(size_t)q] ? "" : "(-)");
+        }
+        printf("\n");
+    }
 }
 
 // ---- stage B: the chunked form the GPU runs ----
@@ -532,7 +541,8 @@ static void run_tail(Model &m, int64_t p, int kind, uint32_t pend, int k_done, i
             }
             if (!(use_rec && le_no_head_ok(e))) e.head[le_bucket(e, q)] = (uint16_t)(q - e.base);  // increasing q: last writer = max
         }
-        le_restore_finish(e, p, m.link.data(), preins);
+        if (!m.ins.empty()) le_restore_finish(e, p, m.link.data(), preins, insf);
+        else le_restore_finish(e, p, m.link.data(), preins);
     }
     std::vector<uint32_t> pre;
     if (use_rec) {

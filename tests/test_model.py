@@ -68,7 +68,16 @@ def test_fast_levels_for_the_lanes_of_a_wave(model, tmp_path):
     for k, v in extra.items():
         (tmp_path / k).write_bytes(v)
         files[k] = str(tmp_path / k)
-    for name in ("alice_98304", "zeros_98305", "lowent_98305", "alice_65537", "ptt5", "cp.html", "runs", "low150k", "zeros150k", "alice_600", "alice_5"):
+    # (tools/fuzz_batch.py seed 208279: 65537 bytes over four symbols -- the tail engine takes over at the position the first
+    # read inserted ahead, and what that insert finds as its bucket's head is the nearest *inserted* position)
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import fuzz_cases
+    rng = np.random.default_rng(208279)
+    rng.integers(0, 4)
+    (tmp_path / "fuzz208279").write_bytes(fuzz_cases.deflate_batch_case(rng)[2][2])
+    files["fuzz208279"] = str(tmp_path / "fuzz208279")
+    for name in ("alice_98304", "zeros_98305", "lowent_98305", "alice_65537", "ptt5", "cp.html", "runs", "low150k", "zeros150k", "alice_600", "alice_5", "fuzz208279"):
         for level in (1, 2, 3):
             for strategy in (0, 2) if name in ("ptt5", "cp.html", "runs") else (0, 1, 2, 4):
                 run(files[name], level, strategy, "fvec")

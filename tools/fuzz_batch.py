@@ -14,22 +14,14 @@ eng = Engine(0); orc = oracle_binding.Oracle()
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 t0 = time.time(); cases = fails = 0
-def data_of(rng, nmax):
-    d = fuzz_cases.make(rng)[0]
-    n = int(rng.choice([0, 1, 2, 5, 261, 262, 263, 1000, 32768, 65535, 65536, 65537, 98304, 200000, 262144, 262145, 600000, nmax]))
-    return d[:min(n, len(d))]
+data_of = fuzz_cases.data_of
 while time.time() - t0 < budget:
     rng = np.random.default_rng(seed)
     mode = int(rng.integers(0, 4))
     why = None
     try:
         if mode == 0:  # a batch through zs_deflate_batch
-            level, strategy = int(rng.integers(0, 10)), int(rng.choice([0, 0, 0, 1, 2, 3, 4]))
-            if level == 0 and strategy == 3:
-                strategy = 0  # (level 0 + Rle: the reference itself throws on compressible data)
-            bufs = [data_of(rng, 1 << 20) for _ in range(int(rng.choice([1, 1, 2, 5, 17, 40])))]
-            if level <= 3 or strategy == 3:
-                bufs = [b[:150000] for b in bufs[:6]]  # (the sequential paths: keep the case short)
+            level, strategy, bufs = fuzz_cases.deflate_batch_case(rng)
             zs = eng.deflate_batch(bufs, level=level, strategy=strategy)
             for i, (b, z) in enumerate(zip(bufs, zs)):
                 if z != orc.compress(b, level, strategy):

@@ -7,17 +7,10 @@ import oracle_binding, fuzz_cases
 from deflate_tokens import tokens
 from zlibstream_amd import Engine
 eng = Engine(0); orc = oracle_binding.Oracle()
-def data_of(rng, nmax):
-    d = fuzz_cases.make(rng)[0]
-    n = int(rng.choice([0, 1, 2, 5, 261, 262, 263, 1000, 32768, 65535, 65536, 65537, 98304, 200000, 262144, 262145, 600000, nmax]))
-    return d[:min(n, len(d))]
 for seed in map(int, sys.argv[1:]):
     rng = np.random.default_rng(seed)
     mode = int(rng.integers(0, 4))
-    level, strategy = int(rng.integers(0, 10)), int(rng.choice([0, 0, 0, 1, 2, 3, 4]))
-    bufs = [data_of(rng, 1 << 20) for _ in range(int(rng.choice([1, 1, 2, 5, 17, 40])))]
-    if level <= 3 or strategy == 3:
-        bufs = [b[:150000] for b in bufs[:6]]
+    level, strategy, bufs = fuzz_cases.deflate_batch_case(rng)
     for i, b in enumerate(bufs):
         z = eng.deflate_batch([b], level=level, strategy=strategy)[0]
         w = orc.compress(b, level, strategy)

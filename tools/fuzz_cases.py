@@ -49,3 +49,20 @@ def make(rng):
     level = int(rng.choice([4, 5, 6, 6, 6, 7, 8, 9]))
     strategy = int(rng.choice([0, 0, 0, 1, 2]))
     return data, sizes, fl, level, strategy
+
+
+def data_of(rng, nmax):
+    d = make(rng)[0]
+    n = int(rng.choice([0, 1, 2, 5, 261, 262, 263, 1000, 32768, 65535, 65536, 65537, 98304, 200000, 262144, 262145, 600000, nmax]))
+    return d[:min(n, len(d))]
+
+
+def deflate_batch_case(rng):
+    """(level, strategy, buffers) of a tools/fuzz_batch.py case of mode 0, the generator having drawn the mode already"""
+    level, strategy = int(rng.integers(0, 10)), int(rng.choice([0, 0, 0, 1, 2, 3, 4]))
+    if level == 0 and strategy == 3:
+        strategy = 0  # (level 0 + Rle: the reference itself throws on compressible data)
+    bufs = [data_of(rng, 1 << 20) for _ in range(int(rng.choice([1, 1, 2, 5, 17, 40])))]
+    if level <= 3 or strategy == 3:
+        bufs = [b[:150000] for b in bufs[:6]]  # (the sequential paths: keep the case short)
+    return level, strategy, bufs

@@ -2369,7 +2369,14 @@ __global__ __launch_bounds__(1024) void zs_tail_kernel(const StreamDesc *sd, Str
 #ifdef ZS_FV_PROF
     long long te0 = wall_clock64();
 #endif
-    if (!s.cont && e.avail_end > 0) le_restore_finish(e, p, lk, ss.preins);
+    if (!s.cont && e.avail_end > 0) {
+        if (s.fv_end >= 0) {  // DeflateFast: the pending pre-insert finds the nearest inserted position of its bucket
+            const uint32_t *gb = s.ins_bits;
+            le_restore_finish(e, p, lk, ss.preins, [gb](int64_t c) { return ((gb[c >> 5] >> (c & 31)) & 1u) != 0; });
+        } else {
+            le_restore_finish(e, p, lk, ss.preins);
+        }
+    }
     __syncthreads();
     le_run(e, level, tid, 64);
 #ifdef ZS_FV_PROF

@@ -787,7 +787,13 @@ ZS_HD uint32_t le_bucket(const LitEngine &e, int64_t q) { return le_hash(e, le_l
 // Third phase, sequential: the few positions below p that were inserted with
 // hashes reaching past the end of input (q in [n-5, p), at most 3 of them are
 // <= max_insert = n-3), then the pending pre-insert of the last refill.
-ZS_HD_NOINLINE inline void le_restore_finish(LitEngine &e, int64_t p, const uint16_t *link, int64_t preins) {
+// `ins` (DeflateFast: zs_fast_vec.h): which positions are in the chains -- what the pending pre-insert finds as its bucket's
+// head is the nearest inserted position on the all-position chain, as in le_restore_prev_ins; nullptr-like AllIns: all are.
+struct AllIns {
+    ZS_HD bool operator()(int64_t) const { return true; }
+};
+template <class Ins>
+ZS_HD_NOINLINE inline void le_restore_finish(LitEngine &e, int64_t p, const uint16_t *link, int64_t preins, const Ins &ins) {
     int64_t q = e.n - 5;
     if (q < 0) q = 0;
     if (q < e.base) q = e.base;
@@ -801,11 +807,23 @@ ZS_HD_NOINLINE inline void le_restore_finish(LitEngine &e, int64_t p, const uint
             // head[h] == preins-1 already; the reference left prev[preins-1] = preins
             e.prev[(w - 1) & kWMask] = (uint16_t)w;
         } else {
-            int64_t c = link[preins] ? preins - (int64_t)link[preins] : -1;
+            int64_t c = preins;
+            for (;;) {
+                const int l = link[c];
+                if (!l) {
+                    c = -1;
+                    break;
+                }
+                c -= l;
+                if (c < e.base || ins(c)) break;
+            }
             e.prev[w & kWMask] = (uint16_t)(c >= e.base ? c - e.base : 0);
             e.head[h1] = (uint16_t)w;
         }
     }
+}
+ZS_HD_NOINLINE inline void le_restore_finish(LitEngine &e, int64_t p, const uint16_t *link, int64_t preins) {
+    le_restore_finish(e, p, link, preins, AllIns());
 }
 
 }  // namespace zs
