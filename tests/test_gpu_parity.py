@@ -724,7 +724,9 @@ def test_random_streams_that_once_differed(engine, oracle):
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
     import fuzz_cases
-    for seed in (2924, 3050, 3929, 4623, 4893, 5300, 6403, 7128, 8883, 11354, 11441, 11724):
+    # (504158: a stream in the batched cut rounds whose second round put records back -- and must put back the chunks' largest
+    # match distances with them, which the repairs' scans go by)
+    for seed in (2924, 3050, 3929, 4623, 4893, 5300, 6403, 7128, 8883, 11354, 11441, 11724, 504158):
         data, sizes, fl, level, strategy = fuzz_cases.make(np.random.default_rng(seed))
         z = _flushed_stream(engine, data, sizes, fl, level, strategy)
         assert zlib.decompress(z) == data, seed

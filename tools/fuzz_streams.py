@@ -9,9 +9,9 @@ from zlibstream_amd import CompressionLevel, Engine, ZlibOptions, ZlibOutputStre
 eng = Engine(0); orc = oracle_binding.Oracle()
 budget = float(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1] != "seeds" else 60.0
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[1] != "seeds" else 1
-def run(data, chunks, fl, level, strategy):
+def run(data, chunks, fl, level, strategy, hash_variant=0):
     out = io.BytesIO()
-    s = ZlibOutputStream(out, ZlibOptions(CompressionLevel=CompressionLevel(level), CompressionStrategy=strategy, FlushMode=0), engine=eng)
+    s = ZlibOutputStream(out, ZlibOptions(CompressionLevel=CompressionLevel(level), CompressionStrategy=strategy, FlushMode=0), engine=eng, hash_variant=hash_variant)
     o = 0
     for c, f in zip(chunks, fl):
         s.Options.FlushMode = f
@@ -54,9 +54,23 @@ t0 = time.time(); cases = fails = 0; seed = seed0
 while __name__ == "__main__" and time.time() - t0 < budget:
     rng = np.random.default_rng(seed)
     data, sizes, fl, level, strategy = make(rng)
+    # (drawn behind the case, so that a seed's case stays what it was) now and then the other hash, a level of the fast or the
+    # stored engine -- those run on the literal engine behind the first flush: short streams -- or Rle
+    hv = int(rng.random() < 0.15)
+    if rng.random() < 0.12:
+        level, cut = int(rng.integers(0, 4)), 200000
+        if rng.random() < 0.3: strategy = 3
+        if level == 0 and strategy == 3: strategy = 0
+        keep, o = 0, 0
+        for c in sizes:
+            if o + c > cut: break
+            o += c; keep += 1
+        keep = max(keep, 1)
+        sizes, fl = sizes[:keep], fl[:keep]
+        sizes[-1] = min(sizes[-1], cut); data = data[:sum(sizes)]
     try:
-        z = run(data, sizes, fl, level, strategy)
-        want = orc.compress_writes(data, level, strategy, sizes, fl)
+        z = run(data, sizes, fl, level, strategy, hv)
+        want = orc.compress_writes(data, level, strategy, sizes, fl, hv)
         ok = z == want
         why = "" if ok else ("roundtrip %s, lengths %d / %d" % (zlib.decompress(z) == data, len(z), len(want)))
     except Exception as e:
@@ -64,7 +78,7 @@ while __name__ == "__main__" and time.time() - t0 < budget:
     cases += 1
     if not ok:
         fails += 1
-        print("FAIL seed %d: n=%d level=%d strategy=%d Writes=%d first sizes %s flushes %s: %s" % (seed, len(data), level, strategy, len(sizes), sizes[:6], fl[:6], why), flush=True)
+        print("FAIL seed %d: n=%d level=%d strategy=%d hash=%d Writes=%d first sizes %s flushes %s: %s" % (seed, len(data), level, strategy, hv, len(sizes), sizes[:6], fl[:6], why), flush=True)
     if cases % 50 == 0:
         print("... %d cases, %d failures, %.0f s" % (cases, fails, time.time() - t0), flush=True)
     seed += 1

@@ -189,7 +189,6 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
                   const WriteSpec *writes = nullptr, bool force_seq = false, RunOpts *ro = nullptr, bool rounds = false,
                   const std::vector<uint8_t> *force_lit = nullptr) {
     if (level == -1) level = 6;
-    if (getenv("ZS_FORCE_ROUNDS") && !ro) rounds = true;  // for the tests: every batch in rounds
     LevelCfg lv = level_cfg(level);
     for (int i = 0; i < n; i++) {  // what the caller sees if a HIP call fails before the results are known
         out_len[i] = 0;
@@ -271,6 +270,10 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
             s.grid_chunks = 1;
             for (size_t k = 1; k + 1 < geo.cstart.size() && s.grid_chunks; k++)
                 if (geo.cstart[k] != (int32_t)((int64_t)k * kChunk - (kMinLookahead - 1))) s.grid_chunks = 0;
+            // ... and the segments those of a single Write's window ends (chunk_ctx's closed form for the chunk -> segment marks)
+            if (geo.cstart.empty() || geo.cstart[0] != 0) s.grid_chunks = 0;
+            for (size_t k = 0; k < geo.head.size() && s.grid_chunks; k++)
+                if (geo.head[k] != ((k >= 32 && ((k - 32) & 15) == 0) ? (int32_t)((k - 32) >> 4) + 2 : 0)) s.grid_chunks = 0;
             s.cut_cap = (int32_t)(geo.cl.size() + (size_t)geo.nsegs() + 8);
             pl.n_cuts += s.cut_cap;
             s.nsegs = geo.nsegs();
@@ -526,8 +529,11 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
     // is what the one-after-the-other order gives (the first cut never depends on a repair, the second only on the
     // first's, ...: a pass fixes at least one more cut, in practice nearly all of them).
     auto run_cut_rounds = [&]() -> bool {
-        if (!ensure(c, c->mm_bak, 8 * (size_t)pl.n_pos + 256)) return false;
+        // (the records as they are now, and behind them the chunks' largest match distances: what a restore puts back)
+        const size_t far_off = 8 * (size_t)pl.n_pos + 256;
+        if (!ensure(c, c->mm_bak, far_off + 2 * (size_t)pl.n_chunks + 64)) return false;
         ZS_HIP(c, hipMemcpyAsync(c->mm_bak.p, c->mm.p, 8 * (size_t)pl.n_pos + 256, hipMemcpyDeviceToDevice, stream));
+        ZS_HIP(c, hipMemcpyAsync((uint8_t *)c->mm_bak.p + far_off, c->chunk_far.p, 2 * (size_t)pl.n_chunks + 64, hipMemcpyDeviceToDevice, stream));
         ZS_HIP(c, hipMemsetAsync(c->cut_pos.p, 0xFF, 8 * (size_t)pl.n_cuts + 64, stream));  // no cut in any slot (the pass before the first)
         StreamState *hr = (StreamState *)c->pinned;
         for (int iter = 0;; iter++) {
@@ -546,6 +552,17 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
                 fprintf(stderr, "zs: cut round %d: %d streams in the rounds, %d settled, most cuts %d, stream 0: %d cuts, first difference at cut %d (position %d)\n", iter,
                         nd, nsame, max_nc, hr[0].nc[iter & 1], hr[0].cut_diff_idx, hr[0].cut_diff_pos);
             }
+            if (all_same && getenv("ZS_DEBUG_CUTS")) {  // the cuts the rounds settled on, stream 0
+                const int ncap = hr[0].nc[iter & 1];
+                std::vector<int32_t> cp((size_t)ncap);
+                std::vector<uint32_t> cb((size_t)ncap);
+                (void)hipMemcpy(cp.data(), dev<int32_t>(c->cut_pos) + (size_t)(iter & 1) * (size_t)cut_stride + pl.sd[0].cut_off, 4 * (size_t)ncap, hipMemcpyDeviceToHost);
+                (void)hipMemcpy(cb.data(), dev<uint32_t>(c->cut_bkt) + (size_t)(iter & 1) * (size_t)cut_stride + pl.sd[0].cut_off, 4 * (size_t)ncap, hipMemcpyDeviceToHost);
+                fprintf(stderr, "zs: cuts of stream 0 (slot: position / bucket):");
+                for (int k = 0; k < ncap; k++)
+                    if (cp[(size_t)k] >= 0) fprintf(stderr, " %d: %d / %u", k, cp[(size_t)k], cb[(size_t)k]);
+                fprintf(stderr, "\n");
+            }
             if (all_same) break;
             if (iter >= 4096) {
                 c->err = "the cut rounds did not settle";
@@ -554,7 +571,7 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
             c->cut_rounds++;
             if (iter > 0)  // (before the first round's repairs the records are the copy)
             hipLaunchKernelGGL(zs_cut_restore_kernel, dim3(2048, (unsigned)n), dim3(256), 0, stream, d_sd, d_st, dev<uint2>(c->mm), (const uint2 *)c->mm_bak.p,
-                               dev<uint8_t>(c->stale), dev<uint8_t>(c->seg_stale));
+                               dev<uint8_t>(c->stale), dev<uint8_t>(c->seg_stale), dev<uint16_t>(c->chunk_far), (const uint16_t *)((const uint8_t *)c->mm_bak.p + far_off));
             if (max_nc > 0) {
                 // few cuts: 128 workgroups each (every 128th position behind the cut); many: fewer, larger ones
                 if (max_nc <= 64)

@@ -664,10 +664,20 @@ __device__ __forceinline__ int seg_of(const StreamDesc &s, int c) {  // last seg
 // chunk c of stream s as the walkers of zs_core.h see it (geometry and read-event cluster from the host's tables)
 __device__ __forceinline__ ChunkCtx chunk_ctx(const StreamDesc &s, int c) {
     ChunkCtx cx;
-    cx.cs = s.cstart[c], cx.ce = s.cstart[c + 1];
+    int h;
+    if (s.grid_chunks) {
+        // one Write: chunk c >= 1 begins at 2048 c - 261, and the segments are those of the window ends (65536 + 32768 k
+        // - 261 = the beginning of chunk 32 + 16 k); the host has checked both against its tables (zs_engine.hip) -- a
+        // workgroup's first loads would otherwise be a round trip for these three values before it can ask for anything else
+        cx.cs = c ? (int64_t)c * kChunk - (kMinLookahead - 1) : 0;
+        cx.ce = c + 1 < s.nchunks ? (int64_t)(c + 1) * kChunk - (kMinLookahead - 1) : (int64_t)s.body_end + 1;
+        h = (c >= 32 && ((c - 32) & 15) == 0) ? ((c - 32) >> 4) + 2 : 0;
+    } else {
+        cx.cs = s.cstart[c], cx.ce = s.cstart[c + 1];
+        h = s.head[c];
+    }
     if (cx.ce > (int64_t)s.body_end + 1) cx.ce = (int64_t)s.body_end + 1;
     cx.cl = nullptr, cx.m = 0, cx.S = 0, cx.after = 0;
-    const int h = s.head[c];
     if (h) {
         const int k = h - 1;
         const int o = s.seg_cl[k];
@@ -892,7 +902,7 @@ __global__ __launch_bounds__(512) void zs_chunkmap_kernel(const StreamDesc *sd, 
     const int c = (int)w.y;
     // (batched cut rounds: only the chunks whose records a restore or a repair has changed, of the streams in the rounds)
     if (only_stale && (st[w.x].deferred != 1 || st[w.x].cuts_same || !only_stale[s.chunk_off + c])) return;
-    if (s.head[c] != 0) load_crc_tab(tab, crc_tab_g);  // (chunkmap_compute's first barrier comes before the table's first use)
+    if (chunk_ctx(s, c).m != 0) load_crc_tab(tab, crc_tab_g);  // (chunkmap_compute's first barrier comes before the table's first use)
     chunkmap_compute<512>(s, c, mm, link, maps, lv, strategy, hash_variant, fk, fk4, tbl, tab, &sh_far, chunk_far);
     if (only_stale && threadIdx.x == 0) only_stale[s.chunk_off + c] = 0;
 }
@@ -1758,8 +1768,10 @@ constexpr int kRepairLds = ((kMaxDist + 16 + 273 + 15) & ~15) + 2 * (kMaxDist + 
 // The records of a stream in the batched cut rounds, from the position of the first cut that changed on, as they were when
 // the rounds began (the copy `bak`): the pass's cuts are applied to records that have seen no cut of an earlier pass.  A
 // record that changes marks its chunk (and the next one when it is the chunk's last: its pending-match row) and segment.
+// ... and gets back the largest match distance its chunk had then (chunk_far, which the repairs' scans go by: the map pass of the
+// round before has lowered it to what that round's repairs left).
 __global__ __launch_bounds__(256) void zs_cut_restore_kernel(const StreamDesc *sd, const StreamState *st, uint2 *mm, const uint2 *bak, uint8_t *stale,
-                                                             uint8_t *seg_stale) {
+                                                             uint8_t *seg_stale, uint16_t *chunk_far, const uint16_t *far_bak) {
     const StreamDesc s = sd[blockIdx.y];
     const StreamState &ss = st[blockIdx.y];
     if (ss.deferred != 1 || ss.cuts_same) return;
@@ -1770,6 +1782,7 @@ __global__ __launch_bounds__(256) void zs_cut_restore_kernel(const StreamDesc *s
         mm[s.pos_off + p] = want;
         const int cp = chunk_of(s, p);
         stale[s.chunk_off + cp] = 1, seg_stale[s.seg_off + seg_of(s, cp)] = 1;
+        chunk_far[s.chunk_off + cp] = far_bak[s.chunk_off + cp];
         if (p + 1 == (int64_t)s.cstart[cp + 1] && cp + 1 < s.nchunks) stale[s.chunk_off + cp + 1] = 1, seg_stale[s.seg_off + seg_of(s, cp + 1)] = 1;
     }
 }
