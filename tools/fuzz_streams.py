@@ -68,6 +68,15 @@ while __name__ == "__main__" and time.time() - t0 < budget:
         keep = max(keep, 1)
         sizes, fl = sizes[:keep], fl[:keep]
         sizes[-1] = min(sizes[-1], cut); data = data[:sum(sizes)]
+    elif rng.random() < 0.02 and len(data) >= 1000000:
+        # now and then a long stream: the case's data several times over (16-48 MiB), Writes of 0.1-3 MB, a flush here and there
+        N = int(rng.integers(16 << 20, 48 << 20))
+        data = (data * (N // len(data) + 1))[:N]
+        sizes, o = [], 0
+        while o < N:
+            c = min(int(rng.integers(100000, 3000000)), N - o); sizes.append(c); o += c
+        fl = [int(rng.choice([1, 2, 3])) if rng.random() < 0.05 else 0 for _ in sizes]
+        level = int(rng.choice([4, 6, 6, 9])) if len(set(data[:4096])) > 8 else 6
     try:
         z = run(data, sizes, fl, level, strategy, hv)
         want = orc.compress_writes(data, level, strategy, sizes, fl, hv)
