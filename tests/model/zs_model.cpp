@@ -524,8 +524,8 @@ static void run_tail(Model &m, int64_t p, int kind, uint32_t pend, int k_done, i
     le_restore(e, p, base_in, after_in, kind, pend, m.link.data(), preins, 0, 1, preslid);
     // the tail's searches ahead of its parse (le_tail_record) and the engine without hash heads (LitEngine::no_head), under
     // the conditions of zs_tail_kernel: a slow level, one Write, everything read, no pre-insert pending
-    const bool use_rec = m.lv.func == 2 && m.strategy != kRle && m.strategy != kHuffmanOnly && !e.wr_end && !m.incremental &&
-                         e.avail_end == e.n && e.avail_end > 0 && preins < p && m.ins.empty() && !getenv("ZS_NO_TAIL_RECORDS") &&
+    const bool use_rec = m.lv.func == 2 && m.strategy != kRle && m.strategy != kHuffmanOnly && !m.incremental && le_tail_reads_done(e) &&
+                         preins < p && m.ins.empty() && !getenv("ZS_NO_TAIL_RECORDS") &&
                          le_tail_record_end(e) > p && le_tail_record_end(e) - p <= kTailRecMax;
     if (e.avail_end > 0) {
         int64_t lo = p - (kWSize - 1);
@@ -539,7 +539,7 @@ static void run_tail(Model &m, int64_t p, int kind, uint32_t pend, int k_done, i
             } else {
                 le_restore_prev(e, q, m.link.data());
             }
-            if (!(use_rec && le_no_head_ok(e))) e.head[le_bucket(e, q)] = (uint16_t)(q - e.base);  // increasing q: last writer = max
+            if (!(use_rec && e.final_run && !e.wr_end && le_no_head_ok(e))) e.head[le_bucket(e, q)] = (uint16_t)(q - e.base);  // increasing q: last writer = max
         }
         if (!m.ins.empty()) le_restore_finish(e, p, m.link.data(), preins, insf);
         else le_restore_finish(e, p, m.link.data(), preins);
@@ -548,7 +548,7 @@ static void run_tail(Model &m, int64_t p, int kind, uint32_t pend, int k_done, i
     if (use_rec) {
         const int64_t hi = le_tail_record_end(e);
         for (int64_t q = p; q < hi; q++) le_restore_prev(e, q, m.link.data());
-        if (le_no_head_ok(e)) {
+        if (e.final_run && !e.wr_end && le_no_head_ok(e)) {  // (as zs_tail_kernel: only where the stream ends in one Write)
             for (int64_t q = p; q < e.n - 5; q++) le_restore_prev(e, q, m.link.data());
             int64_t lo = p - (kWSize - 1);
             if (lo < e.base) lo = e.base;

@@ -54,6 +54,6 @@ for name, writes, flushes in (("sync flush after 4 KiB, then one 64 MiB Write", 
     # does not fit one chunk is entered again and leaves another empty block)
     zp, _ = run(part, pw, pf, chunk=512)
     exact = zp == orc.compress_writes(part, 6, 0, pw, pf)
-    behind = sum(times[1:])
+    behind = sum(times[1:]) if len(writes) > 1 else sum(times)  # (one Write: the whole stream)
     print("%-58s roundtrip %s, first 6 MiB (512-byte chunks) exact %s; calls behind the first Write: %.1f ms = %.2f GB/s (host memory in, host memory out)"
           % (name, ok, exact, behind * 1e3, (len(data) - writes[0]) / behind / 1e9 if len(writes) > 1 else len(data) / sum(times) / 1e9), flush=True)

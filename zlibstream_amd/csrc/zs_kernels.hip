@@ -2290,11 +2290,12 @@ __global__ __launch_bounds__(1024) void zs_tail_kernel(const StreamDesc *sd, Str
         }
         // a slow level, one Write, everything read, no pre-insert pending: the tail's searches are done ahead (below) and the
         // engine runs without the hash heads (LitEngine::no_head) -- the table is not built
-        use_rec = lv.func == 2 && strategy != kRle && strategy != kHuffmanOnly && s.final_run && !e.wr_end && s.fv_end < 0 &&
-                  e.avail_end == e.n && e.avail_end > 0 && ss.preins < p && le_tail_record_end(e) > p &&
-                  le_tail_record_end(e) - p <= kTailRecMax;
-        // (... unless the window still holds positions of the engine before a resumed run: their buckets are not the data's)
-        no_head = use_rec && le_no_head_ok(e) && !(s.resume && p - (kWSize - 1) < s.start_pos);
+        // (the run's last Write, which ends the stream or closes under a flush mode: le_tail_reads_done)
+        use_rec = lv.func == 2 && strategy != kRle && strategy != kHuffmanOnly && s.fv_end < 0 && le_tail_reads_done(e) && ss.preins < p &&
+                  le_tail_record_end(e) > p && le_tail_record_end(e) - p <= kTailRecMax;
+        // (... only where the stream ends: a run that goes on leaves the heads for the next one; and not while the window still
+        // holds positions of the engine before a resumed run: their buckets are not the data's)
+        no_head = use_rec && s.final_run && !e.wr_end && le_no_head_ok(e) && !(s.resume && p - (kWSize - 1) < s.start_pos);
         if (!no_head) {
             // (a resumed run: the heads as the engine before it left them, in this window's indices -- the latest member of
             // a bucket is one of the run's own positions or that; its chains and a FullFlush's forgetting are not the data's)

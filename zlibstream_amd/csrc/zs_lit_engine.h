@@ -436,6 +436,15 @@ ZS_HD uint32_t le_tail_head_bucket(const LitEngine &e, int k) {
 ZS_HD bool le_tail_preslide(const LitEngine &e, int64_t p, int64_t base, int64_t avail_end, int64_t preins) {
     return e.final_run && !e.wr_end && avail_end >= e.n && e.n - p < kMinLookahead && preins < p && p - base >= kSlideAt;
 }
+// Can the searches of the rest be done ahead (le_tail_record)?  Everything has been read and the engine is in the run's last
+// Write, which the stream ends with (final_run) or which closes under a flush mode: either way the parse goes down to
+// lookahead 0 on what is there (Deflate.Slow.cs:38-46), and no read changes the chains on the way.
+ZS_HD bool le_tail_reads_done(const LitEngine &e) {
+    if (e.avail_end != e.n || e.avail_end <= 0) return false;
+    if (e.wr_end && e.cur_wr + 1 < e.n_wr) return false;
+    const bool flushes = e.wr_flush && e.cur_wr < e.n_wr && e.wr_flush[e.cur_wr] != 0;
+    return e.final_run || flushes;
+}
 // No slide from here on: every loop-top of the rest stays below the point where Fill_window slides (Deflate.cs:979).
 ZS_HD bool le_no_head_ok(const LitEngine &e) { return e.n - e.base <= kSlideAt; }
 // Longest_match's result at the current loop-top from its record.
