@@ -47,6 +47,7 @@ struct InfTables {
 };
 
 constexpr int kInfInBuf = 512;   // LDS window over the compressed bytes [ibase, ibase + kInfInBuf): small, so that 32 decoder waves fit a CU
+typedef uint64_t __attribute__((aligned(1))) u64_unaligned;  // (an attribute on the cast's type itself is ignored: the load would be assumed aligned)
 struct InfBits {
     const uint8_t *in;
     int64_t n, pos;  // next byte to load
@@ -79,7 +80,7 @@ struct InfBits {
         stage();
         if (cnt < 56 && pos + 8 <= n) {
             // one unaligned 8-byte LDS read; bits above the whole bytes taken are re-ORed identically next time
-            buf |= *(const uint64_t __attribute__((aligned(1))) *)(ibuf + (pos - ibase)) << cnt;
+            buf |= *(const u64_unaligned *)(ibuf + (pos - ibase)) << cnt;
             const int adv = (63 - cnt) >> 3;
             pos += adv;
             cnt += adv * 8;

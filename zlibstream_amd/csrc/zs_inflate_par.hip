@@ -322,7 +322,7 @@ struct LaneBits {
     __device__ void fill() {
         if (cnt > 40) return;  // a symbol needs at most 15 + 5 + 15 + 13 bits; every load is on the decode's dependency chain
         if (pos + 8 <= n) {
-            buf |= *(const __attribute__((address_space(1))) uint64_t __attribute__((aligned(1))) *)(in + pos) << cnt;
+            buf |= *(const __attribute__((address_space(1))) u64_unaligned *)(in + pos) << cnt;
             const int adv = (63 - cnt) >> 3;
             pos += adv;
             cnt += adv * 8;

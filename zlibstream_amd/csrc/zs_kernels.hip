@@ -59,15 +59,15 @@ __device__ __forceinline__ uint64_t lds_u64(const uint8_t *base, int idx) {
 typedef const __attribute__((address_space(3))) uint32_t *lds_cu32;
 typedef const __attribute__((address_space(3))) uint16_t *lds_cu16;
 __device__ __forceinline__ uint32_t lds0_u32(int idx) {
-    lds_cu32 q = (lds_cu32)(uint32_t)(idx & ~3);
+    lds_cu32 q = (lds_cu32)(uintptr_t)(uint32_t)(idx & ~3);
     return __builtin_amdgcn_alignbyte(q[1], q[0], (uint32_t)idx);
 }
 __device__ __forceinline__ uint64_t lds0_u64(int idx) {
-    lds_cu32 q = (lds_cu32)(uint32_t)(idx & ~3);
+    lds_cu32 q = (lds_cu32)(uintptr_t)(uint32_t)(idx & ~3);
     const uint32_t a = q[0], b = q[1], c = q[2];
     return (uint64_t)__builtin_amdgcn_alignbyte(b, a, (uint32_t)idx) | ((uint64_t)__builtin_amdgcn_alignbyte(c, b, (uint32_t)idx) << 32);
 }
-__device__ __forceinline__ int lds0_link(int idx) { return *(lds_cu16)(uint32_t)(kMatchLdsBytes + 2 * idx); }
+__device__ __forceinline__ int lds0_link(int idx) { return *(lds_cu16)(uintptr_t)(uint32_t)(kMatchLdsBytes + 2 * idx); }
 
 // Match records in `mm` (uint2 per position): x = record for budget K, y = for budget K >> 2, each dist | (len-3) << 16
 // (zs_core.h pack_match); bits 24..31 of x carry the input byte of the position, so that the symbol kernel gets its
@@ -778,8 +778,8 @@ __device__ __forceinline__ uint32_t stage_chunk_matches(const StreamDesc &s, int
                 far = far > dy ? far : dy;
             }
             // filter_match (zs_core.h) on a record: gone if len - 3 <= klm and dist > kdm (TOO_FAR: 3 / 4096; Filtered: <= 5 / any)
-            x = ((x >> 16) <= klm) & ((x & 0xFFFFu) > kdm) ? 0u : x;
-            y = ((y >> 16) <= klm) & ((y & 0xFFFFu) > kdm) ? 0u : y;
+            x = (((x >> 16) <= klm) & ((x & 0xFFFFu) > kdm)) ? 0u : x;
+            y = (((y >> 16) <= klm) & ((y & 0xFFFFu) > kdm)) ? 0u : y;
         }
         fk[i] = x;
         fk4[i] = y;
@@ -1426,17 +1426,18 @@ __global__ __launch_bounds__(1024) void zs_resolve_kernel(const StreamDesc *sd, 
 #pragma unroll
             for (int r = 0; r < kSupSegs; r++) {
                 const int seg = g * kSupSegs + r;
-                if (seg >= s.nsegs) break;
-                const uint2 v = segmap[((int64_t)s.seg_off + seg) * kSlots + cur];
-                const uint32_t m = metas[r];
-                if ((m & 1u) && (uint32_t)(cur <= 256 ? cur : 0) <= (m >> 2)) {
-                    kf = ((unsigned long long)(seg + 1) << 16) | (unsigned)cur;
-                    if (dry && (v.x & kMapEqualBit) && strategy != kHuffmanOnly) collect_cuts(seg, cur, 0, 0);
+                if (seg < s.nsegs) {  // (no break: the loop is unrolled, metas[] stays in registers)
+                    const uint2 v = segmap[((int64_t)s.seg_off + seg) * kSlots + cur];
+                    const uint32_t m = metas[r];
+                    if ((m & 1u) && (uint32_t)(cur <= 256 ? cur : 0) <= (m >> 2)) {
+                        kf = ((unsigned long long)(seg + 1) << 16) | (unsigned)cur;
+                        if (dry && (v.x & kMapEqualBit) && strategy != kHuffmanOnly) collect_cuts(seg, cur, 0, 0);
+                    }
+                    seg_entry[s.seg_off + seg] = (uint16_t)cur;
+                    seg_symbase[s.seg_off + seg] = total;
+                    cur = (int)(v.x & 0x1FF);
+                    total += v.y;
                 }
-                seg_entry[s.seg_off + seg] = (uint16_t)cur;
-                seg_symbase[s.seg_off + seg] = total;
-                cur = (int)(v.x & 0x1FF);
-                total += v.y;
             }
             if (kf) atomicMax(&fp_kf, kf);  // the last segment whose events fired
         }
@@ -1903,7 +1904,7 @@ __device__ __forceinline__ void k5_publish(lds_u32p slot, uint32_t v) {
 }
 // (reads the compiler knows about: it places the waits; volatile keeps them in program order among themselves)
 __device__ __forceinline__ uint32_t k5_peek(lds_u32p slot) { return *(volatile __attribute__((address_space(3))) uint32_t *)slot; }
-__device__ __forceinline__ uint64_t k5_peek64(uint32_t addr) { return *(volatile __attribute__((address_space(3))) uint64_t *)addr; }
+__device__ __forceinline__ uint64_t k5_peek64(uint32_t addr) { return *(volatile __attribute__((address_space(3))) uint64_t *)(uintptr_t)addr; }
 template <int kK5Ring>
 __global__ __launch_bounds__(kK5Threads) void zs_emit_syms_lane_kernel(const StreamDesc *sd, const StreamState *st, const uint2 *work, int nwork, const uint2 *mm,
                                                                const uint16_t *link, const uint16_t *entry, const uint32_t *symbase, uint32_t *syms,
@@ -2066,8 +2067,8 @@ __global__ __launch_bounds__(kK5Threads) void zs_emit_syms_lane_kernel(const Str
             if constexpr (kRecLits) nlit = (uint8_t)(cur.x >> 24);
             else nlit = gin[q];
             uint32_t cK = cur.x & kRecMask, cK4 = cur.y & kRecMask;
-            cK = ((cK >> 16) <= klm) & ((cK & 0xFFFFu) > kdm) ? 0u : cK;
-            cK4 = ((cK4 >> 16) <= klm) & ((cK4 & 0xFFFFu) > kdm) ? 0u : cK4;
+            cK = (((cK >> 16) <= klm) & ((cK & 0xFFFFu) > kdm)) ? 0u : cK;
+            cK4 = (((cK4 >> 16) <= klm) & ((cK4 & 0xFFFFu) > kdm)) ? 0u : cK4;
             const bool is_x = kind >= kXK, use4 = m >= good;
             const uint32_t curv = use4 ? cK4 : cK;
             const int mv = curv ? (int)(curv >> 16) + 3 : 2;
