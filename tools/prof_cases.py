@@ -23,7 +23,9 @@ if what == "fast512":  # DeflateFast (level 1), 512 x 512 KiB text streams in on
 elif what in ("writes1000", "scanlines"):  # 64 MiB in 1000-byte Writes / 16385-byte scanlines, level 6, resident in HBM
     data = datagen.english(64 << 20, datagen.GOLDEN)
     size = 1000 if what == "writes1000" else 16385
+    import ctypes
     ends = list(range(size, len(data), size)) + [len(data)]
+    ends = (ctypes.c_int64 * len(ends))(*ends)  # (made once, as a C# or C++ caller has it: 67 109 entries cost Python 2 ms a call)
     d_in = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
     cap = deflate_bound(len(data))
     d_out = torch.empty(cap, dtype=torch.uint8, device="cuda")
