@@ -1289,6 +1289,11 @@ __global__ __launch_bounds__(256) void zs_inf_cellflat_kernel(const ParStream *p
         }
         return ck[lo];
     };
+    // (One cell per lane and trip.  Round 3 tried four -- one 8-byte load, the pass being bound by the count of its 2-byte
+    // loads: with a lane chasing its own four cells one after the other the decode stage was 0.7 ms per GiB slower, with
+    // the markers of 1024 cells queued in LDS and chased one per lane 0.4 ms slower.  The chases -- dependent loads through
+    // L2, a binary search over the sub-block starts in front of each -- are what the pass takes its time for, and this form
+    // starts every one of them as early as it can.)
     for (int64_t i = threadIdx.x; i < k.out_bytes; i += 256) {
         uint16_t c = cl[i];
         if (c < kSubMarkBase || c >= 0x8000) continue;
@@ -1483,8 +1488,14 @@ __global__ __launch_bounds__(1024) void zs_inf_winchain_kernel(const ParState *s
 }
 
 // ------------------------------------------------------------------ R
+// One workgroup per block: the 32 KiB window before the block staged in LDS once (16-byte loads; the gathers were round trips
+// to L1 / L2 for every marker cell), then four cells per lane and trip -- one 8-byte load, four LDS byte gathers, one 4-byte
+// store, the lanes of a wave on consecutive cells (the one-cell form was bound by the count of its memory instructions:
+// 2-byte loads and 1-byte stores, 2.2 ms per GiB).  The cells and the output share their phase mod 4 when the caller's
+// buffer is 4-byte aligned; the few cells in front of the first aligned group and behind the last go one by one.
 __global__ __launch_bounds__(256) void zs_inf_resolve_kernel(const ParStream *ps, const ParState *st, const uint2 *work, const ParBlock *blocks,
                                                              const uint16_t *cells, const uint8_t *windows) {
+    __shared__ __attribute__((aligned(16))) uint8_t win[kWSize];
     const uint2 w = work[blockIdx.x];
     const ParStream s = ps[w.x];
     if (!st[w.x].ok || (int)w.y >= st[w.x].nblk) return;
@@ -1492,10 +1503,36 @@ __global__ __launch_bounds__(256) void zs_inf_resolve_kernel(const ParStream *ps
     const uint8_t *pw = w.y ? windows + ((int64_t)st[w.x].win_off + w.y - 1) * kWSize : nullptr;
     const uint16_t *cl = cells + s.cell_off + k.out_off;
     uint8_t *o = s.out + k.out_off;
-    for (int64_t i = threadIdx.x; i < k.out_bytes; i += 256) {
-        const uint16_t c = cl[i];
-        o[i] = (c & 0x8000) ? (pw ? pw[c & 0x7FFF] : 0) : (uint8_t)c;
+    const int64_t n = k.out_bytes;
+    if (pw) {
+        for (int i = threadIdx.x * 16; i < kWSize; i += 256 * 16) *(uint4 *)(win + i) = *(const uint4 *)(pw + i);
+    } else {
+        for (int i = threadIdx.x * 16; i < kWSize; i += 256 * 16) *(uint4 *)(win + i) = make_uint4(0, 0, 0, 0);
     }
+    __syncthreads();
+    auto one = [&](int64_t i) {
+        const uint16_t c = cl[i];
+        o[i] = (c & 0x8000) ? win[c & 0x7FFF] : (uint8_t)c;
+    };
+    // cells are 2 bytes: cl + i is 8-byte aligned where the output address o + i is 4-byte aligned, if the two agree mod 4
+    const int64_t head = (int64_t)((4 - ((uintptr_t)o & 3)) & 3);
+    const bool same_phase = (((uintptr_t)(cl + head)) & 7) == 0;
+    if (!same_phase) {
+        for (int64_t i = threadIdx.x; i < n; i += 256) one(i);
+        return;
+    }
+    const int64_t body = n > head ? ((n - head) & ~3LL) : 0;
+    if ((int64_t)threadIdx.x < head && (int64_t)threadIdx.x < n) one(threadIdx.x);
+    for (int64_t i = head + (int64_t)threadIdx.x * 4; i < head + body; i += 256 * 4) {
+        const uint2 v = *(const uint2 *)(cl + i);
+        const uint32_t c0 = v.x & 0xFFFFu, c1 = v.x >> 16, c2 = v.y & 0xFFFFu, c3 = v.y >> 16;
+        const uint32_t b0 = (c0 & 0x8000u) ? win[c0 & 0x7FFFu] : (c0 & 0xFFu);
+        const uint32_t b1 = (c1 & 0x8000u) ? win[c1 & 0x7FFFu] : (c1 & 0xFFu);
+        const uint32_t b2 = (c2 & 0x8000u) ? win[c2 & 0x7FFFu] : (c2 & 0xFFu);
+        const uint32_t b3 = (c3 & 0x8000u) ? win[c3 & 0x7FFFu] : (c3 & 0xFFu);
+        *(uint32_t *)(o + i) = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
+    }
+    for (int64_t i = head + body + threadIdx.x; i < n; i += 256) one(i);
 }
 
 }  // namespace zs
