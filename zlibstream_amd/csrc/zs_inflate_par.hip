@@ -1280,13 +1280,27 @@ __global__ __launch_bounds__(256) void zs_inf_cellflat_kernel(const ParStream *p
     for (int i = threadIdx.x; i <= nsub; i += 256) ck[i] = T.ck_out[i];
     __syncthreads();
     uint16_t *cl = cells + s.cell_off + k.out_off;
-    auto sub_start = [&](uint32_t p) {  // start of the sub-block that holds block-relative position p
+    auto sub_index = [&](uint32_t p) {  // the sub-block that holds block-relative position p
         int lo = 0, hi = nsub - 1;
         while (lo < hi) {
             const int mid = (lo + hi + 1) >> 1;
             if (ck[mid] <= p) lo = mid;
             else hi = mid - 1;
         }
+        return lo;
+    };
+    // (every hop of a chase asks for a sub-block's start: eight dependent LDS reads as a bisection; a table with the
+    // sub-block of every 512th position leaves a step or two)
+    constexpr int kHintShift = 9, kHintMax = 512;
+    __shared__ uint16_t hint[kHintMax];
+    const bool hinted = (k.out_bytes >> kHintShift) < kHintMax;
+    if (hinted)
+        for (int g = threadIdx.x; g <= (int)(k.out_bytes >> kHintShift); g += 256) hint[g] = (uint16_t)sub_index((uint32_t)g << kHintShift);
+    __syncthreads();
+    auto sub_start = [&](uint32_t p) {
+        if (!hinted) return ck[sub_index(p)];
+        int lo = hint[p >> kHintShift];
+        while (lo + 1 < nsub && ck[lo + 1] <= p) lo++;
         return ck[lo];
     };
     // (One cell per lane and trip.  Round 3 tried four -- one 8-byte load, the pass being bound by the count of its 2-byte
