@@ -52,6 +52,15 @@ namespace SixLabors.ZlibStream
                                                                          long* outCap, long* outLen, int* status, int level, int strategy, int hashVariant);
         [DllImport(Lib)] public static extern int zs_inflate_batch_multi(IntPtr* ctxs, int nCtx, int n, IntPtr* input, long* inLen, IntPtr* output,
                                                                          long* outCap, long* outLen, int* status);
+        // ---- device-resident forms (buffers already in HBM: an encoder whose image lives on the GPU): one stream written in
+        //      several NoFlush Writes (writeEnds: the cumulative Write ends, a host array), and the multi-GPU batch over
+        //      device pointers (partOf[i]: the context whose GPU holds buffer i, e.g. from zs_partition)
+        [DllImport(Lib)] public static extern int zs_partition(long* sizes, int n, int nParts, int* partOf);
+        [DllImport(Lib)] public static extern int zs_deflate_writes_device(IntPtr ctx, IntPtr input, long inLen, long* writeEnds, long nWrites, IntPtr output,
+                                                                           long outCap, long* outLen, int level, int strategy, int hashVariant, IntPtr hipStream);
+        [DllImport(Lib)] public static extern int zs_deflate_batch_multi_device(IntPtr* ctxs, int nCtx, int n, IntPtr* input, long* inLen, IntPtr* output,
+                                                                                long* outCap, long* outLen, int* status, int* partOf, int level,
+                                                                                int strategy, int hashVariant);
     }
 
     /// <summary>
