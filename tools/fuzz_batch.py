@@ -19,6 +19,8 @@ while time.time() - t0 < budget:
     rng = np.random.default_rng(seed)
     mode = int(rng.integers(0, 4))
     why = None
+    if os.environ.get("ZS_FUZZ_VERBOSE"):
+        print("seed %d mode %d" % (seed, mode), flush=True)
     try:
         if mode == 0:  # a batch through zs_deflate_batch
             level, strategy, bufs = fuzz_cases.deflate_batch_case(rng)
@@ -39,17 +41,7 @@ while time.time() - t0 < budget:
             if z != orc.compress(data, level, strategy, chunks=sizes):
                 why = "deflate_writes_device n=%d level %d strategy %d Writes %d %s: roundtrip %s" % (len(data), level, strategy, len(sizes), sizes[:5], zlib.decompress(z) == data)
         elif mode == 2:  # inflate_batch of streams from zlib / with flush markers / stored and fixed blocks
-            bufs = [data_of(rng, 3 << 20) for _ in range(int(rng.choice([1, 2, 6, 16])))]
-            zs = []
-            for b in bufs:
-                lv = int(rng.integers(0, 10))
-                co = zlib.compressobj(lv, zlib.DEFLATED, 15, 9, int(rng.choice([zlib.Z_DEFAULT_STRATEGY, zlib.Z_FIXED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE])))
-                z, o = b"", 0
-                while o < len(b):
-                    c = int(rng.choice([len(b), 100000, 300000, 7000]))
-                    z += co.compress(b[o:o + c]); o += c
-                    if rng.random() < 0.3: z += co.flush(int(rng.choice([zlib.Z_SYNC_FLUSH, zlib.Z_FULL_FLUSH, zlib.Z_PARTIAL_FLUSH])))
-                zs.append(z + co.flush())
+            bufs, zs = fuzz_cases.inflate_batch_case(rng)
             outs = eng.inflate_batch(zs, [len(b) for b in bufs])
             for i, (b, o) in enumerate(zip(bufs, outs)):
                 if o != b:

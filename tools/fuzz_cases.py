@@ -66,3 +66,21 @@ def deflate_batch_case(rng):
     if level <= 3 or strategy == 3:
         bufs = [b[:150000] for b in bufs[:6]]  # (the sequential paths: keep the case short)
     return level, strategy, bufs
+
+
+def inflate_batch_case(rng):
+    """(buffers, zlib streams) of a tools/fuzz_batch.py case of mode 2: zlib's own streams at any level and strategy, written in
+    pieces with flush markers now and then"""
+    import zlib
+    bufs = [data_of(rng, 3 << 20) for _ in range(int(rng.choice([1, 2, 6, 16])))]
+    zs = []
+    for b in bufs:
+        lv = int(rng.integers(0, 10))
+        co = zlib.compressobj(lv, zlib.DEFLATED, 15, 9, int(rng.choice([zlib.Z_DEFAULT_STRATEGY, zlib.Z_FIXED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE])))
+        z, o = b"", 0
+        while o < len(b):
+            c = int(rng.choice([len(b), 100000, 300000, 7000]))
+            z += co.compress(b[o:o + c]); o += c
+            if rng.random() < 0.3: z += co.flush(int(rng.choice([zlib.Z_SYNC_FLUSH, zlib.Z_FULL_FLUSH, zlib.Z_PARTIAL_FLUSH])))
+        zs.append(z + co.flush())
+    return bufs, zs

@@ -78,7 +78,28 @@ while __name__ == "__main__" and time.time() - t0 < budget:
         fl = [int(rng.choice([1, 2, 3])) if rng.random() < 0.05 else 0 for _ in sizes]
         level = int(rng.choice([4, 6, 6, 9])) if len(set(data[:4096])) > 8 else 6
     try:
-        z = run(data, sizes, fl, level, strategy, hv)
+        if rng.random() < 0.1:
+            # two streams on one context, their Writes taking turns: the suspended engines are the streams' own, the workspace
+            # (staging buffers, the copy a resumed run keeps of its engine) the context's
+            d2, s2, f2, l2, st2 = make(np.random.default_rng(seed + 7777777))
+            d2, s2, f2 = d2[:sum(s2[:len(sizes)])], s2[:len(sizes)], f2[:len(sizes)]
+            d2 = d2[:sum(s2)]
+            oa, ob = io.BytesIO(), io.BytesIO()
+            sa = ZlibOutputStream(oa, ZlibOptions(CompressionLevel=CompressionLevel(level), CompressionStrategy=strategy, FlushMode=0), engine=eng, hash_variant=hv)
+            sb = ZlibOutputStream(ob, ZlibOptions(CompressionLevel=CompressionLevel(l2), CompressionStrategy=st2, FlushMode=0), engine=eng)
+            pa = pb = 0
+            for k in range(max(len(sizes), len(s2))):
+                if k < len(sizes):
+                    sa.Options.FlushMode = fl[k]; sa.write(data[pa:pa + sizes[k]]); pa += sizes[k]
+                if k < len(s2):
+                    sb.Options.FlushMode = f2[k]; sb.write(d2[pb:pb + s2[k]]); pb += s2[k]
+            sa.Options.FlushMode = 0; sb.Options.FlushMode = 0
+            sb.close(); sa.close()
+            if ob.getvalue() != orc.compress_writes(d2, l2, st2, s2, f2):
+                raise RuntimeError("the second of two interleaved streams differs (its case: seed %d + 7777777, %d Writes)" % (seed, len(s2)))
+            z = oa.getvalue()
+        else:
+            z = run(data, sizes, fl, level, strategy, hv)
         want = orc.compress_writes(data, level, strategy, sizes, fl, hv)
         ok = z == want
         why = "" if ok else ("roundtrip %s, lengths %d / %d" % (zlib.decompress(z) == data, len(z), len(want)))

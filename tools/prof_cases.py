@@ -8,7 +8,19 @@ from zlibstream_amd import CompressionLevel, Engine, ZlibOptions, ZlibOutputStre
 eng = Engine(0)
 what = sys.argv[1]
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
-if what == "fast512":  # DeflateFast (level 1), 512 x 512 KiB text streams in one batch: zs_fast_vec_kernel
+if what == "fast1024":  # 1024 x 256 KiB: more streams than two per CU
+    texts = [datagen.english(256 << 10, 1000 + i) for i in range(1024)]
+    d_ins = [torch.frombuffer(bytearray(b), dtype=torch.uint8).cuda() for b in texts]
+    caps = [deflate_bound(len(b)) for b in texts]
+    d_outs = [torch.empty(c, dtype=torch.uint8, device="cuda") for c in caps]
+    batch = Engine.DeviceBatch([t.data_ptr() for t in d_ins], [len(b) for b in texts], [t.data_ptr() for t in d_outs], caps)
+    eng.deflate_device_batch(batch, level=1)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(steps):
+        eng.deflate_device_batch(batch, level=1)
+    torch.cuda.synchronize()
+    print("fast1024 level 1: %.2f ms per batch of 256 MiB" % ((time.perf_counter() - t0) / steps * 1e3))
+elif what == "fast512":  # DeflateFast (level 1), 512 x 512 KiB text streams in one batch: zs_fast_vec_kernel
     texts = [datagen.english(512 << 10, 1000 + i) for i in range(512)]
     d_ins = [torch.frombuffer(bytearray(b), dtype=torch.uint8).cuda() for b in texts]
     caps = [deflate_bound(len(b)) for b in texts]

@@ -111,6 +111,8 @@ constexpr int kFvFwd = 272;     // >= kMaxMatch + 8, multiple of 16
 constexpr int kFvBytes = kFvBack + kFvTile + kFvFwd;
 constexpr int kFvLinks = kFvBack + kFvTile;
 constexpr int kFvBitWords = kFvLinks / 32 + 8;  // the tile may start 16 positions into a word, and short matches reach out of it
+// the form that reads K1's links where they lie: two workgroups of 512 threads per CU
+constexpr int kFvLdsNoLinks = kFvBytes + 4 * kFvBitWords + 8192;
 constexpr int kFvLds = kFvBytes + 2 * kFvLinks + 4 * kFvBitWords + 8192;  // + the first 16 list entries per lane of the window and of the 64 positions behind it
 // candidate-list entries per position (zs_fast_vec_kernel): enough for most searches of the level -- max_chain candidates
 // among the ~45 % of a chain that was inserted -- in multiples of 16; a longer search walks on through the staged links

@@ -761,10 +761,24 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
     mark(7);
     // fork: the tail engine (sequential, one workgroup per stream) needs only what the resolve kernel left, so it runs
     // on the second stream beside the symbol kernels
-    if (pl.any_fv)
-        hipLaunchKernelGGL(zs_fast_vec_kernel, dim3((unsigned)n), dim3(1024), kFvLds, stream, d_sd, d_st, dev<uint16_t>(c->link),
-                           dev<uint32_t>(c->syms), dev<int32_t>(c->blk_end), dev<int32_t>(c->blk_top), lv, strategy, dev<uint32_t>(c->fv_lists),
-                           fv_list_entries(lv.chain));
+    if (pl.any_fv) {
+        // (The kernel's time is its lone parsing wave's, so a batch of more streams than CUs gets two workgroups of 512 threads
+        // per CU, with K1's links read where they lie: 512 x 512 KiB at level 1 104 -> 70 ms; up to one stream per CU: 1024
+        // threads and the links staged in LDS.  Three of 256 threads on a tile of half the size were slower than two -- 79 ms,
+        // also for 1024 streams.  ZS_FV_PER_CU=1/2 overrides.)
+        int n_fv_streams = 0;
+        for (int i = 0; i < n; i++) n_fv_streams += pl.sd[(size_t)i].fv_end >= 0;
+        int per_cu = n_fv_streams > 256 ? 2 : 1;
+        if (getenv("ZS_FV_PER_CU")) per_cu = atoi(getenv("ZS_FV_PER_CU"));
+        if (per_cu >= 2)
+            hipLaunchKernelGGL((zs_fast_vec_kernel<512, false, kFvTile>), dim3((unsigned)n), dim3(512), kFvLdsNoLinks, stream, d_sd, d_st, dev<uint16_t>(c->link),
+                               dev<uint32_t>(c->syms), dev<int32_t>(c->blk_end), dev<int32_t>(c->blk_top), lv, strategy, dev<uint32_t>(c->fv_lists),
+                               fv_list_entries(lv.chain));
+        else
+            hipLaunchKernelGGL((zs_fast_vec_kernel<1024, true, kFvTile>), dim3((unsigned)n), dim3(1024), kFvLds, stream, d_sd, d_st, dev<uint16_t>(c->link),
+                               dev<uint32_t>(c->syms), dev<int32_t>(c->blk_end), dev<int32_t>(c->blk_top), lv, strategy, dev<uint32_t>(c->fv_lists),
+                               fv_list_entries(lv.chain));
+    }
     // the engine is left for a later run, or took the block in progress over from one: it needs K5's symbols and block ends
     const bool tail_late = ro && (!ro->final_run || ro->resume);
     // Beside the symbol kernel the tails of a few streams are free; those of hundreds are not: 256 tail workgroups of 1024
@@ -1094,7 +1108,8 @@ int zs_ctx_create(int device, zs_ctx **out) {
         hipFuncSetAttribute((const void *)zs_links_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLkLds) != hipSuccess ||
         hipFuncSetAttribute((const void *)zs_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kTailLds) != hipSuccess ||
         hipFuncSetAttribute((const void *)zs_fast_run_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kTailLds) != hipSuccess ||
-        hipFuncSetAttribute((const void *)zs_fast_vec_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kFvLds) != hipSuccess ||
+        hipFuncSetAttribute((const void *)zs_fast_vec_kernel<1024, true, kFvTile>, hipFuncAttributeMaxDynamicSharedMemorySize, kFvLds) != hipSuccess ||
+        hipFuncSetAttribute((const void *)zs_fast_vec_kernel<512, false, kFvTile>, hipFuncAttributeMaxDynamicSharedMemorySize, kFvLdsNoLinks) != hipSuccess ||
         hipFuncSetAttribute((const void *)zs_inf_window_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kWinMapLds) != hipSuccess ||
         hipFuncSetAttribute((const void *)zs_inf_chain_par_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kChainParLds) != hipSuccess ||
         hipFuncSetAttribute((const void *)zs_cuts_repair_kernel<256, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, kRepairLds) != hipSuccess ||
@@ -1399,8 +1414,22 @@ bool run_inflate_par(zs_ctx *c, const std::vector<int> &idx, const void *const *
     ZS_HIP(c, hipStreamSynchronize(stream));
     std::vector<uint2> w;
     bool wave_measure = false;
+    // (a stream whose candidate lists overflowed -- ok == 0: it goes to the sequential decoder -- is not measured: what
+    // its list holds behind the overflow is whatever was in the buffer)
     for (int j = 0; j < m; j++)
-        for (int k = 0; k < st[(size_t)j].ncand; k++) w.push_back(make_uint2((unsigned)j, (unsigned)k));
+        for (int k = 0; st[(size_t)j].ok && k < st[(size_t)j].ncand; k++) w.push_back(make_uint2((unsigned)j, (unsigned)k));
+    if (getenv("ZS_DEBUG_INF")) {  // the finder's candidates per stream: count, range, order
+        for (int j = 0; j < m; j++) {
+            const int nc = st[(size_t)j].ncand;
+            std::vector<ParCand> hc((size_t)std::max(nc, 1));
+            if (nc) (void)hipMemcpy(hc.data(), dev<ParCand>(c->par_cands) + ps[(size_t)j].cand_off, sizeof(ParCand) * (size_t)nc, hipMemcpyDeviceToHost);
+            int bad = 0;
+            for (int k = 0; k < nc; k++) bad += hc[(size_t)k].bit < 16 || hc[(size_t)k].bit >= ps[(size_t)j].in_len * 8 || (k && hc[(size_t)k].bit <= hc[(size_t)k - 1].bit);
+            fprintf(stderr, "[zs] inflate stream %d: %lld bytes, %d candidates (room for %d), ok %d, out of range or order: %d, first %lld last %lld\n", j,
+                    (long long)ps[(size_t)j].in_len, nc, ps[(size_t)j].max_cand, st[(size_t)j].ok, bad, nc ? (long long)hc[0].bit : -1LL,
+                    nc ? (long long)hc[(size_t)nc - 1].bit : -1LL);
+        }
+    }
     if (!w.empty()) {
         ZS_HIP(c, hipMemcpyAsync(c->par_work.p, w.data(), sizeof(uint2) * w.size(), hipMemcpyHostToDevice, stream));
         ZS_HIP(c, hipStreamSynchronize(stream));

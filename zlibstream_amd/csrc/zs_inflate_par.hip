@@ -629,6 +629,10 @@ __global__ __launch_bounds__(64) void zs_inf_measure_kernel(const ParStream *ps,
     const ParStream s = ps[w.x];
     if ((int)w.y >= st[w.x].ncand) return;
     ParCand &c = cands[s.cand_off + w.y];
+    if (!st[w.x].ok || c.bit < 16 || c.bit + 17 > s.in_len * 8) {  // (as in zs_inf_measure_sync_kernel)
+        if (threadIdx.x == 0) c.ok = 0;
+        return;
+    }
     InfBits b{s.in, s.in_len, 0, 0, 0, false, L.ibuf, -1};
     inf_seek(b, c.bit);
     BlockOut r = inf_block<0>(b, L.T, L.lens, L.ll, nullptr, (int64_t)1 << 40);
@@ -738,8 +742,13 @@ __global__ __launch_bounds__(64) void zs_inf_measure_sync_kernel(const ParStream
     ParCand &c = cands[s.cand_off + w.y];
     const int lane = threadIdx.x;
     const int64_t cbit = c.bit, nbits = s.in_len * 8;
+    if (!st[w.x].ok || cbit < 16 || cbit + 17 > nbits) {  // (not a header offset of this stream: nothing is read through it)
+        if (lane == 0) c.ok = 0;
+        return;
+    }
     // the block most likely ends where the next candidate begins (candidate bits are final since the flatten pass)
-    const int64_t hint = (int)w.y + 1 < ncand ? cands[s.cand_off + w.y + 1].bit : nbits;
+    int64_t hint = (int)w.y + 1 < ncand ? cands[s.cand_off + w.y + 1].bit : nbits;
+    if (hint <= cbit || hint > nbits) hint = nbits;
     InfBits hb{s.in, s.in_len, 0, 0, 0, false, L.ibuf, -1};
     inf_seek(hb, cbit);
     hb.fill();

@@ -2673,20 +2673,29 @@ struct FvLaneRes {  // the lanes' results, read by a wave-uniform lane index
 // *conditional*, and when the hops of the parse reach it as a loop-top the whole wave evaluates that one position again,
 // one entry per lane, with the set as it stands then -- instead of ending the window there (51 of 64 positions on text).
 // A list that ends before the search does (chains longer than list_m) is followed by the walk through the staged links.
-__global__ __launch_bounds__(1024) void zs_fast_vec_kernel(const StreamDesc *sd, StreamState *st, uint16_t *link, uint32_t *syms,
+// NT threads; LL: K1's links of the tile staged in LDS (one workgroup per CU: 157 KiB), or read where they lie (62 KiB and, with
+// 512 threads, two workgroups -- two streams -- per CU: the kernel's time is its lone parsing wave's, so a batch of more
+// streams than CUs runs twice as many of them at a time; the lists' walks then hop through L2 / HBM, behind 7 to 14 % of
+// the time they had).
+template <int NT, bool LL, int TILE>
+__global__ __launch_bounds__(NT) void zs_fast_vec_kernel(const StreamDesc *sd, StreamState *st, uint16_t *link, uint32_t *syms,
                                                            int32_t *blk_end, int32_t *blk_top, LevelCfg lv, int strategy, uint32_t *lists_g,
                                                            int list_m) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    // (the tile: TILE positions behind 32 512 of history -- zs_device.h has the sizes for the 16 Ki-position one)
+    constexpr int fvBytes = kFvBack + TILE + kFvFwd, fvLinks = kFvBack + TILE, fvBitWords = fvLinks / 32 + 8;
     const StreamDesc s = sd[blockIdx.x];
     if (s.fv_end < 0) return;
     uint8_t *wb = smem;
-    uint16_t *wl = (uint16_t *)(smem + kFvBytes);
-    uint32_t *bm = (uint32_t *)(smem + kFvBytes + 2 * kFvLinks);
-    uint32_t *ent0 = bm + kFvBitWords;  // the window's first 16 entries per lane (16 x 64 words), for the conditional lanes
+    uint16_t *wl = LL ? (uint16_t *)(smem + fvBytes) : nullptr;
+    uint32_t *bm = (uint32_t *)(smem + fvBytes + (LL ? 2 * fvLinks : 0));
+    uint32_t *ent0 = bm + fvBitWords;  // the window's first 16 entries per lane (16 x 64 words), for the conditional lanes
     uint32_t *pre0 = ent0 + 1024;       // the same for the 64 positions behind the window, asked for a window ahead
     uint32_t *lists = lists_g + s.fv_list_off;
     __shared__ int64_t sh_p, sh_nsyms, sh_trigger, sh_preins;
     __shared__ int sh_k, sh_quit;
+    // (tried, round 3: the parsing wave a different wave of the workgroup from stream to stream, so that two workgroups on a
+    // CU would not have theirs on one SIMD -- no difference: 72.7 against 70.5 ms for 512 streams)
     const int tid = threadIdx.x, lane = lane_id();
     const int64_t n = s.n, body_end = s.fv_end;
     const gcbytes in = as_global(s.in);
@@ -2709,9 +2718,12 @@ __global__ __launch_bounds__(1024) void zs_fast_vec_kernel(const StreamDesc *sd,
         const int64_t p_in = sh_p;
         if (p_in > body_end || sh_quit) break;
         const int64_t t0 = p_in & ~31LL, lo = t0 - kFvBack, bw0 = lo >> 5;  // lo is a multiple of 32: bitmap words line up
+        // a link, by index = position - lo (never below position 0); where they are not staged: read past L1 -- the parsing wave
+        // cuts links (an equal-bucket read) that it and, a tile later, the other waves then walk
+        auto LK = [&](int c) -> int { return LL ? (int)wl[c] : (int)__hip_atomic_load(lk + lo + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
         PF_T0();
         // ---- stage the tile
-        for (int i = tid; i < kFvBytes / 16; i += 1024) {
+        for (int i = tid; i < fvBytes / 16; i += NT) {
             const int64_t a = lo + (int64_t)i * 16;
             uint4 v = make_uint4(0, 0, 0, 0);
             if (a >= 0 && a + 15 < n && aligned) {
@@ -2727,7 +2739,7 @@ __global__ __launch_bounds__(1024) void zs_fast_vec_kernel(const StreamDesc *sd,
             }
             ((uint4 *)wb)[i] = v;
         }
-        for (int i = tid; i < kFvLinks / 8; i += 1024) {
+        for (int i = tid; LL && i < fvLinks / 8; i += NT) {
             const int64_t a = lo + (int64_t)i * 8;
             uint4 v = make_uint4(0, 0, 0, 0);
             if (a >= 0 && a + 7 < n) {
@@ -2742,13 +2754,13 @@ __global__ __launch_bounds__(1024) void zs_fast_vec_kernel(const StreamDesc *sd,
             }
             ((uint4 *)wl)[i] = v;
         }
-        for (int i = tid; i < kFvBitWords; i += 1024) bm[i] = bw0 + i >= 0 ? gbits[bw0 + i] : 0u;
+        for (int i = tid; i < fvBitWords; i += NT) bm[i] = bw0 + i >= 0 ? gbits[bw0 + i] : 0u;
         __syncthreads();
         PF_ADD(pf_stage);
-        // ---- the candidate lists of the tile's positions [t0, t0 + kFvTile): list i at lists[i * list_m ..]
+        // ---- the candidate lists of the tile's positions [t0, t0 + TILE): list i at lists[i * list_m ..]
         {
             const int min_i = (int)(1 - lo);  // position 0 is never a candidate
-            for (int i = tid; i < kFvTile; i += 1024) {
+            for (int i = tid; i < TILE; i += NT) {
                 const int64_t q = t0 + i;
                 uint32_t *dst = lists + (size_t)i * (size_t)list_m;
                 if (q > body_end) continue;
@@ -2756,7 +2768,7 @@ __global__ __launch_bounds__(1024) void zs_fast_vec_kernel(const StreamDesc *sd,
                 const uint64_t scan8 = lds_u64(wb, qi);
                 int c = qi, e = 0;
                 while (e < list_m) {
-                    const int l = wl[c];
+                    const int l = LK(c);
                     const int nc = c - l, d = qi - nc;
                     if (l == 0 || nc < min_i || d > kMaxDist) break;
                     c = nc;
@@ -2798,16 +2810,20 @@ __global__ __launch_bounds__(1024) void zs_fast_vec_kernel(const StreamDesc *sd,
             // its start and land in pre0 at its end, and the next window -- which starts there or a few positions on --
             // takes its lists from LDS
             int64_t pf_base = -(1ll << 40);
-            while (p0 <= body_end && p0 + kFvLanes <= t0 + kFvTile) {
+            while (p0 <= body_end && p0 + kFvLanes <= t0 + TILE) {
                 bool dead0 = false, dead1 = false, only1 = false;
                 if (trigger >= 0 && p0 >= trigger) {
                     // the read event at loop-top p0: p0 + 1 is inserted first (Deflate.cs:1010-1013)
                     k_fired++;
                     preins = p0 + 1;
                     if (lane == 0) atomicOr(&bm[((p0 + 1) >> 5) - bw0], 1u << ((p0 + 1) & 31));
-                    if (wl[p0 + 1 - lo] == 1) {
+                    if (LK((int)(p0 + 1 - lo)) == 1) {
                         dead0 = true, only1 = true;
-                        if (lane == 0) wl[p0 - lo] = 0, lk[p0] = 0;  // the reference's prev[p0] = p0 + 1, prev[p0 + 1] = p0
+                        if (lane == 0) {
+                            if (LL) wl[p0 - lo] = 0;
+                            lk[p0] = 0;
+                            if (!LL) __threadfence();
+                        }  // the reference's prev[p0] = p0 + 1, prev[p0 + 1] = p0
                         cut_i = (int)(p0 - lo);
                     } else {
                         dead1 = true;
@@ -2876,7 +2892,7 @@ __global__ __launch_bounds__(1024) void zs_fast_vec_kernel(const StreamDesc *sd,
                 //      window's own they would be waited for with them) and are stored at the window's end
                 uint4 nx[4];
                 {
-                    const bool nx_ok = p0 + 64 + lane <= body_end && p0 + 128 <= t0 + kFvTile;
+                    const bool nx_ok = p0 + 64 + lane <= body_end && p0 + 128 <= t0 + TILE;
                     const uint32_t *ahead = mine + (size_t)64 * (size_t)list_m;
 #pragma unroll
                     for (int u = 0; u < 4; u++) nx[u] = nx_ok ? *(const uint4 *)(ahead + 4 * u) : make_uint4(0, 0, 0, 0);
@@ -2887,7 +2903,7 @@ __global__ __launch_bounds__(1024) void zs_fast_vec_kernel(const StreamDesc *sd,
                     done |= more ^ 1;
                     if (__ballot(!done)) {
                         const uint64_t scan8 = lds_u64(wb, qi);
-                        int c = more ? qi - last_d : qi, l = wl[c];
+                        int c = more ? qi - last_d : qi, l = LK(c);
                         while (__ballot(!done)) {
 #ifdef ZS_FV_PROF
                             pf_iters++;
@@ -2901,7 +2917,7 @@ __global__ __launch_bounds__(1024) void zs_fast_vec_kernel(const StreamDesc *sd,
                             const int go = valid & (recent ^ 1);
                             done |= go ^ 1;
                             const int cc = go ? nc : qi;  // lanes that are done read their own position (in range)
-                            l = wl[cc];
+                            l = LK(cc);
                             uint32_t word = bmr[cc >> 5];
                             uint64_t c8 = lds_u64(wb, cc);
                             asm volatile("" : "+v"(l), "+v"(word), "+v"(c8));
@@ -3016,7 +3032,7 @@ __global__ __launch_bounds__(1024) void zs_fast_vec_kernel(const StreamDesc *sd,
                             int c = qa - ulast;
                             for (;;) {
                                 tile_walk++;
-                                const int l = wl[c];
+                                const int l = LK(c);
                                 const int nc = c - l, d = qa - nc;
                                 if (l == 0 || nc < min_i || d > (ufound ? kMaxDist - 1 : kMaxDist)) break;
                                 c = nc;
@@ -3050,7 +3066,7 @@ __global__ __launch_bounds__(1024) void zs_fast_vec_kernel(const StreamDesc *sd,
                 flush_bits(tops & ~flushed);
                 {
                     // (the chunk loop above has read pre0 for this window; nothing reads it again before the next window)
-                    const bool have = p0 + 128 <= t0 + kFvTile;
+                    const bool have = p0 + 128 <= t0 + TILE;
 #pragma unroll
                     for (int u = 0; u < 4; u++) *(uint4 *)(pre0 + lane * 16 + 4 * u) = nx[u];
                     pf_base = have ? p0 + 64 : -(1ll << 40);
@@ -3082,7 +3098,7 @@ __global__ __launch_bounds__(1024) void zs_fast_vec_kernel(const StreamDesc *sd,
             if (tile_windows > 16 && tile_walk > (long)kFvQuitWalk * tile_windows) sh_quit = 1;
             // ---- leave the tile: the bitmap words that changed go back to the stream's bitmap
             for (int64_t wd = (p_in >> 5) + lane; wd <= (p0 + 96) >> 5; wd += 64)
-                if (wd - bw0 < kFvBitWords) gbits[wd] = bm[wd - bw0];
+                if (wd - bw0 < fvBitWords) gbits[wd] = bm[wd - bw0];
             if (lane == 0) sh_p = p0, sh_nsyms = nsyms, sh_trigger = trigger, sh_preins = preins, sh_k = k_fired;
         }
         __threadfence_block();
