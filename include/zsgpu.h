@@ -172,7 +172,10 @@ ZS_API double zs_ctx_stage_ms(const zs_ctx *ctx, int stage);
  *   engine at that call and deliver everything up to and including the flush
  *   marker, so the reader can decode what has been written so far; from then on
  *   the stream is incremental (the engine is kept suspended in device memory,
- *   consumed input is dropped).  A NoFlush stream with more than 1 GiB buffered
+ *   consumed input is dropped); at levels 4-9 the runs behind a flush are the
+ *   bulk pipeline's again, started at the flush on the suspended engine's hash
+ *   chains, so NoFlush Writes behind a flush wait for the next flush or Finish
+ *   like those in front of the first.  A NoFlush stream with more than 1 GiB buffered
  *   becomes incremental too: a stream has no length limit (a single call takes
  *   up to 2 GiB - 1 KiB; 2 GiB - 65 KiB on a stream that has become incremental, whose run keeps 64 KiB of history).  The bytes are the reference's for a caller that runs
  *   ZlibOutputStream.WriteCore's loop (ZlibOutputStream.cs:125-168: a fresh
