@@ -710,6 +710,110 @@ static std::vector<uint8_t> emit_stream(Model &m) {
     return out;
 }
 
+// ---- mode "resume": a stream flushed after its first F bytes, the rest one Write.  The first Write runs on the literal engine
+// (as a run of an incremental stream does, zs_stream_api.inc); the run behind the flush is laid out by build_geometry with
+// GeoStart::at_read and parsed in the chunked form on chains taken from that engine -- what zs_import_chains_kernel does on
+// the device: prev[] for the 32 Ki positions below the flush, head[] for the first link of every bucket behind it.  The
+// symbols of both runs against the oracle's (per-Write flush modes).
+static int resume_main(std::vector<uint8_t> &buf, int64_t n, int level, int strategy, int64_t F, int flush) {
+    if (F <= 0 || F >= n || flush < 1 || flush > 3) {
+        printf("resume: need 0 < F < n and a flush mode 1..3\n");
+        return 2;
+    }
+    OracleTrace tr;
+    zso_trace t;
+    memset(&t, 0, sizeof t);
+    t.on_symbol = on_symbol, t.on_block = on_block, t.on_read = on_read, t.user = &tr;
+    std::vector<uint8_t> ref(zso_compress_bound((size_t)n) + 4096);
+    const size_t wl[2] = {(size_t)F, (size_t)(n - F)};
+    const int fm[2] = {flush, 0};
+    if (zso_compress_stream_modes(buf.data(), (size_t)n, wl, 2, level, strategy, 0, fm, 0, ref.data(), ref.size(), &t) == (size_t)-1) {
+        printf("oracle failed\n");
+        return 1;
+    }
+    std::vector<uint32_t> crc(1024);
+    for (int tt = 0; tt < 4; tt++)
+        for (int i = 0; i < 256; i++) crc[tt * 256 + i] = crc32c_table_entry(tt, (uint32_t)i);
+    // ---- the first Write on the literal engine, left where Deflate.Compress returns behind the flush
+    LitEngine e;
+    memset(&e, 0, sizeof e);
+    le_defaults(e);
+    std::vector<uint8_t> window(kWindowSize + 512);
+    std::vector<uint16_t> head(kHashSize), prev(kWSize);
+    std::vector<uint32_t> asyms((size_t)F + 1024);
+    std::vector<BlockRec> ablocks((size_t)F / 4000 + 64);
+    const int64_t wend[1] = {F};
+    const uint8_t wflush[1] = {(uint8_t)flush};
+    int32_t wblk[1] = {0};
+    e.window = window.data(), e.head = head.data(), e.prev = prev.data(), e.crc_tab = crc.data();
+    e.data = buf.data(), e.n = F, e.lv = level_cfg(level), e.strategy = strategy, e.hash_variant = kHashCrc32c;
+    e.wr_end = wend, e.n_wr = 1, e.wr_flush = wflush, e.wr_blk = wblk;
+    e.syms = asyms.data(), e.nsyms = 0, e.blocks = ablocks.data(), e.nblocks = 0;
+    e.block_syms = level == 0 ? (kLitBufsize / 2) - 1 : kBlockSyms;
+    e.final_run = 0;
+    le_restore(e, 0, 0, 0, kR, 0, nullptr, -1, 0, 1);
+    le_run(e, level, 0, 1);
+    if (!e.suspended || e.base + e.strstart != F || e.lookahead != 0 || e.match_available != 0) {
+        printf("the engine is not where a flush leaves it: suspended %d at %ld lookahead %d\n", e.suspended, (long)(e.base + e.strstart), e.lookahead);
+        return 1;
+    }
+    const int64_t nA = e.nsyms;
+    bool ok = true;
+    for (int64_t i = 0; i < nA && ok; i++)
+        if ((size_t)i >= tr.syms.size() || asyms[(size_t)i] != tr.syms[(size_t)i]) printf("first run: symbol %ld differs\n", (long)i), ok = false;
+    // ---- the run behind the flush
+    Model m;
+    m.data = buf.data(), m.n = n, m.level = level, m.strategy = strategy, m.lv = level_cfg(level), m.crc_tab = crc;
+    m.flush_mode = 0, m.incremental = false;
+    GeoStart gs;
+    gs.resume = true, gs.at_read = true, gs.p0 = gs.E0 = F, gs.base0 = e.base;
+    const std::vector<int64_t> none;
+    const bool bulk = m.lv.func == 2 && strategy != kRle && build_geometry(n, none, m.geo, gs);
+    if (!bulk) {
+        printf("PASS (not a schedule for the bulk path) n=%ld F=%ld\n", (long)n, (long)F);
+        return ok ? 0 : 1;
+    }
+    m.body_end = m.geo.body_end;
+    m.build_links();
+    // the engine's chains: below F its prev[] (a forward pointer that its partner closes into a cycle is a cut) ...
+    // (ZS_MODEL_NO_IMPORT: the data's own links, to see what the import is for)
+    for (int64_t x = F - kWSize > e.base ? F - kWSize : e.base; x < F && !getenv("ZS_MODEL_NO_IMPORT"); x++) {
+        if (x < 0) continue;
+        const int idx = (int)(x - e.base), pv = prev[(size_t)(idx & kWMask)];
+        if (pv > idx && prev[(size_t)(pv & kWMask)] != idx) {
+            printf("PASS (a forward pointer in prev[] that is not a cycle: the stream stays with the literal engine) n=%ld F=%ld\n", (long)n, (long)F);
+            return ok ? 0 : 1;
+        }
+        int d = (pv != 0 && pv < idx) ? idx - pv : 0;
+        if (d > kMaxDist) d = 0;
+        m.link[(size_t)x] = (uint16_t)d;
+    }
+    // ... and behind it, for a position whose bucket has no member in [F, q) yet, the engine's head of the bucket
+    for (int64_t q = F; q < F + kWSize && q + 5 < n && !getenv("ZS_MODEL_NO_IMPORT"); q++) {
+        const int have = m.link[(size_t)q];
+        if (have != 0 && q - have >= F) continue;
+        const int hv = head[m.bucket(q)], idx = (int)(q - e.base);
+        int d = hv != 0 ? idx - hv : 0;
+        if (d < 0 || d > kMaxDist) d = 0;
+        m.link[(size_t)q] = (uint16_t)d;
+    }
+    m.match_all();
+    int64_t p, preins;
+    int kind, k_done;
+    uint32_t pend;
+    parse_chunked(m, p, kind, pend, k_done, preins);
+    run_tail(m, p, kind, pend, k_done, preins);
+    if ((int64_t)tr.syms.size() != nA + (int64_t)m.syms.size()) printf("symbol count %ld + %zu vs oracle %zu\n", (long)nA, m.syms.size(), tr.syms.size()), ok = false;
+    for (size_t i = 0; i < m.syms.size() && ok; i++)
+        if ((size_t)nA + i >= tr.syms.size() || m.syms[i] != tr.syms[(size_t)nA + i]) {
+            printf("run behind the flush: symbol %zu differs: model %08x oracle %08x\n", i, m.syms[i], nA + i < tr.syms.size() ? tr.syms[(size_t)nA + i] : 0u);
+            ok = false;
+        }
+    printf("%s n=%ld level=%d strat=%d mode=resume F=%ld flush=%d base=%ld syms=%ld+%zu events=%zu tail_from=%ld\n", ok ? "PASS" : "FAIL", (long)n, level, strategy,
+           (long)F, flush, (long)e.base, (long)nA, m.syms.size(), m.events.size(), (long)p);
+    return ok ? 0 : 1;
+}
+
 int main(int argc, char **argv) {
     if (argc < 3) {
         fprintf(stderr, "usage: %s file level [strategy] [mode]\n", argv[0]);
@@ -749,6 +853,7 @@ int main(int argc, char **argv) {
     int flush_mode = argc > 6 ? atoi(argv[6]) : 0;
     int64_t n = (int64_t)buf.size();
     buf.resize(buf.size() + 1024, 0);
+    if (mode == "resume") return resume_main(buf, n, level, strategy, (int64_t)wchunk, flush_mode);
 
     OracleTrace tr;
     zso_trace t;

@@ -83,6 +83,39 @@ def test_fast_levels_for_the_lanes_of_a_wave(model, tmp_path):
                 run(files[name], level, strategy, "fvec")
 
 
+def test_runs_behind_a_flush_in_the_chunked_form(model, tmp_path):
+    """A stream flushed after its first F bytes (Deflate.cs:583-613), the rest one Write: the first Write on the literal engine,
+    the run behind the flush laid out by build_geometry's GeoStart::at_read -- its first pass through the loop reads, with a
+    window behind it -- and parsed in the chunked form on chains taken from that engine (prev[] below the flush, head[] for the
+    first link of every bucket behind it: what zs_import_chains_kernel does on the device).  Symbols of both runs against the
+    oracle's per-Write flush modes; flushes in the first bytes, around window ends and the slide threshold, Partial / Sync /
+    Full (a FullFlush's forgotten heads are the case the data's own links get wrong: ZS_MODEL_NO_IMPORT shows it)."""
+    rng = np.random.default_rng(31)
+    alice = open(os.path.join(ROOT, "tests/golden/corpus/alice29.txt"), "rb").read()
+    extra = {"alice300k": (alice * 3)[:300000], "low300k": rng.choice(np.array([0, 0, 0, 0, 1, 2, 255], dtype=np.uint8), 300000).tobytes(),
+             "zeros200k": bytes(200000), "runs200k": np.repeat(rng.integers(0, 4, 30000, dtype=np.uint8), rng.integers(1, 40, 30000))[:200000].tobytes()}
+    files = {}
+    for k, v in extra.items():
+        (tmp_path / k).write_bytes(v)
+        files[k] = str(tmp_path / k)
+    n_bulk = 0
+    for name in files:
+        for F in (3, 5, 262, 5000, 32768, 65273, 65274, 65275, 65536, 98304, 100000):
+            for flush, level in ((2, 6), (3, 6), (1, 4), (3, 9)):
+                if level == 9 and (name != "alice300k" or F not in (5000, 65536)):
+                    continue
+                if level == 4 and F not in (5, 65274, 100000):
+                    continue
+                r = subprocess.run([EXE, files[name], str(level), "0", "resume", str(F), str(flush)], capture_output=True, text=True)
+                assert r.returncode == 0 and "PASS" in r.stdout, (name, F, flush, level, r.stdout[-400:])
+                n_bulk += "mode=resume" in r.stdout
+    assert n_bulk > 60  # (the chunked form really ran)
+    # ... and the data's own links are not enough behind a FullFlush
+    env = dict(os.environ, ZS_MODEL_NO_IMPORT="1")
+    r = subprocess.run([EXE, files["alice300k"], "6", "0", "resume", "100000", "3"], capture_output=True, text=True, env=env)
+    assert r.returncode != 0 and "FAIL" in r.stdout
+
+
 def test_multi_write_literal_engine(model):
     for name in ("alice_98304", "lowent_65537", "zeros_98305"):
         for w in (1, 100, 8192, 65536, 70000):
