@@ -715,7 +715,7 @@ static std::vector<uint8_t> emit_stream(Model &m) {
 // GeoStart::at_read and parsed in the chunked form on chains taken from that engine -- what zs_import_chains_kernel does on
 // the device: prev[] for the 32 Ki positions below the flush, head[] for the first link of every bucket behind it.  The
 // symbols of both runs against the oracle's (per-Write flush modes).
-static int resume_main(std::vector<uint8_t> &buf, int64_t n, int level, int strategy, int64_t F, int flush) {
+static int resume_main(std::vector<uint8_t> &buf, int64_t n, int level, int strategy, int64_t F, int flush, const std::vector<size_t> &behind) {
     if (F <= 0 || F >= n || flush < 1 || flush > 3) {
         printf("resume: need 0 < F < n and a flush mode 1..3\n");
         return 2;
@@ -725,9 +725,18 @@ static int resume_main(std::vector<uint8_t> &buf, int64_t n, int level, int stra
     memset(&t, 0, sizeof t);
     t.on_symbol = on_symbol, t.on_block = on_block, t.on_read = on_read, t.user = &tr;
     std::vector<uint8_t> ref(zso_compress_bound((size_t)n) + 4096);
-    const size_t wl[2] = {(size_t)F, (size_t)(n - F)};
-    const int fm[2] = {flush, 0};
-    if (zso_compress_stream_modes(buf.data(), (size_t)n, wl, 2, level, strategy, 0, fm, 0, ref.data(), ref.size(), &t) == (size_t)-1) {
+    // the Writes: F bytes under the flush mode, then NoFlush ones -- `behind` in turn until the stream ends, or all of it at once
+    std::vector<size_t> wl{(size_t)F};
+    std::vector<int64_t> wends;  // the ends of the Writes behind the flush
+    for (int64_t o = F, k = 0; o < n; k++) {
+        const size_t w = behind.empty() ? (size_t)(n - o) : std::min(std::max<size_t>(behind[(size_t)k % behind.size()], 1), (size_t)(n - o));
+        wl.push_back(w);
+        o += (int64_t)w;
+        wends.push_back(o);
+    }
+    std::vector<int> fm(wl.size(), 0);
+    fm[0] = flush;
+    if (zso_compress_stream_modes(buf.data(), (size_t)n, wl.data(), wl.size(), level, strategy, 0, fm.data(), 0, ref.data(), ref.size(), &t) == (size_t)-1) {
         printf("oracle failed\n");
         return 1;
     }
@@ -768,7 +777,8 @@ static int resume_main(std::vector<uint8_t> &buf, int64_t n, int level, int stra
     GeoStart gs;
     gs.resume = true, gs.at_read = true, gs.p0 = gs.E0 = F, gs.base0 = e.base;
     const std::vector<int64_t> none;
-    const bool bulk = m.lv.func == 2 && strategy != kRle && build_geometry(n, none, m.geo, gs);
+    if (wends.size() > 1) m.wr_end = wends;
+    const bool bulk = m.lv.func == 2 && strategy != kRle && build_geometry(n, wends.size() > 1 ? wends : none, m.geo, gs);
     if (!bulk) {
         printf("PASS (not a schedule for the bulk path) n=%ld F=%ld\n", (long)n, (long)F);
         return ok ? 0 : 1;
@@ -853,7 +863,8 @@ int main(int argc, char **argv) {
     int flush_mode = argc > 6 ? atoi(argv[6]) : 0;
     int64_t n = (int64_t)buf.size();
     buf.resize(buf.size() + 1024, 0);
-    if (mode == "resume") return resume_main(buf, n, level, strategy, (int64_t)wchunk, flush_mode);
+    if (mode == "resume")  // "F" or "F,a,b,...": the flushed Write, then the sizes of the NoFlush Writes behind it in turn
+        return resume_main(buf, n, level, strategy, (int64_t)wchunk, flush_mode, wcycle.size() > 1 ? std::vector<size_t>(wcycle.begin() + 1, wcycle.end()) : std::vector<size_t>());
 
     OracleTrace tr;
     zso_trace t;

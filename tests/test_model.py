@@ -109,7 +109,15 @@ def test_runs_behind_a_flush_in_the_chunked_form(model, tmp_path):
                 r = subprocess.run([EXE, files[name], str(level), "0", "resume", str(F), str(flush)], capture_output=True, text=True)
                 assert r.returncode == 0 and "PASS" in r.stdout, (name, F, flush, level, r.stdout[-400:])
                 n_bulk += "mode=resume" in r.stdout
-    assert n_bulk > 60  # (the chunked form really ran)
+    # several NoFlush Writes behind the flush ("F,a,b,..": their sizes in turn): clusters of read events right behind the
+    # run's first read, equal-bucket cuts among them
+    for name in ("low300k", "alice300k", "runs200k"):
+        for spec in ("5000,1000", "65536,16385", "100000,300,40000", "65274,100,263,5000", "3,70000", "32768,32768,200"):
+            for flush in (2, 3):
+                r = subprocess.run([EXE, files[name], "6", "0", "resume", spec, str(flush)], capture_output=True, text=True)
+                assert r.returncode == 0 and "PASS" in r.stdout, (name, spec, flush, r.stdout[-400:])
+                n_bulk += "mode=resume" in r.stdout
+    assert n_bulk > 90  # (the chunked form really ran)
     # ... and the data's own links are not enough behind a FullFlush
     env = dict(os.environ, ZS_MODEL_NO_IMPORT="1")
     r = subprocess.run([EXE, files["alice300k"], "6", "0", "resume", "100000", "3"], capture_output=True, text=True, env=env)
