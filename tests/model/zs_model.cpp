@@ -56,6 +56,8 @@ struct Model {
     std::vector<int64_t> wr_end;
     std::vector<ReadEvent> rev;    // the stream's read events (zs_core.h build_read_events); rev[0] = the first read
     Geometry geo;                  // mode "chunk": segments, chunks and read-event clusters (zs_core.h build_geometry)
+    int start_slot = 0;            // a run that takes the stream over in the middle (mode resume): chunk 0's entry slot ...
+    std::vector<uint32_t> start_syms;  // ... and the symbols of the block in progress, in front of the run's own
     bool poisoned = false;         // the true path met a read the bulk form does not handle: the device falls back
     int flush_mode = 0;            // ZlibOptions.FlushMode of every Write
     std::vector<uint8_t> wr_flush;
@@ -380,8 +382,8 @@ static void parse_chunked(Model &m, int64_t &p_out, int &kind_out, uint32_t &pen
     std::vector<int> entry(nchunks);
     std::vector<int64_t> symbase(nchunks);
     std::vector<char> stale(nchunks + 40, 0);
-    int slot = 0, k_fired = 0;
-    int64_t total = 0, preins = -1;
+    int slot = m.start_slot, k_fired = 0;
+    int64_t total = (int64_t)m.start_syms.size(), preins = -1;
     long n_dirty = 0, n_equal = 0, n_stale = 0, n_events = 0;
     for (int c = 0; c < nchunks; c++) {
         const ChunkCtx cx = chunk_ctx(m, c);
@@ -451,6 +453,7 @@ static void parse_chunked(Model &m, int64_t &p_out, int &kind_out, uint32_t &pen
     }
     // K5: emission (one lane per chunk on the GPU)
     m.syms.assign((size_t)total, 0);
+    std::copy(m.start_syms.begin(), m.start_syms.end(), m.syms.begin());
     size_t nb = (size_t)(total / kBlockSyms);
     std::vector<int64_t> blk_end(nb), blk_top(nb);
     for (int c = 0; c < nchunks; c++) {
@@ -710,16 +713,110 @@ static std::vector<uint8_t> emit_stream(Model &m) {
     return out;
 }
 
+// ---- mode "resume" without a flush: one Write; the literal engine stops at the first loop-top at or behind F that no read has
+// touched (LitEngine::stop_abs: the warm-up of zs_stream_api.inc for a stream that is not at a flush), and the chunked form
+// takes the parse over there -- in the lazy parse's node the engine stands in, with the symbols of the block in progress in
+// front of its own, on the engine's chains (GeoStart without at_read).
+static int resume_stop_main(std::vector<uint8_t> &buf, int64_t n, int level, int strategy, int64_t F) {
+    OracleTrace tr;
+    zso_trace t;
+    memset(&t, 0, sizeof t);
+    t.on_symbol = on_symbol, t.on_block = on_block, t.on_read = on_read, t.user = &tr;
+    std::vector<uint8_t> ref(zso_compress_bound((size_t)n) + 4096);
+    if (zso_compress_stream(buf.data(), (size_t)n, nullptr, 0, level, strategy, 0, 0, ref.data(), ref.size(), &t) == (size_t)-1) {
+        printf("oracle failed\n");
+        return 1;
+    }
+    std::vector<uint32_t> crc(1024);
+    for (int tt = 0; tt < 4; tt++)
+        for (int i = 0; i < 256; i++) crc[tt * 256 + i] = crc32c_table_entry(tt, (uint32_t)i);
+    LitEngine e;
+    memset(&e, 0, sizeof e);
+    le_defaults(e);
+    std::vector<uint8_t> window(kWindowSize + 512);
+    std::vector<uint16_t> head(kHashSize), prev(kWSize);
+    std::vector<uint32_t> asyms((size_t)n + 1024);
+    std::vector<BlockRec> ablocks((size_t)n / 4000 + 64);
+    e.window = window.data(), e.head = head.data(), e.prev = prev.data(), e.crc_tab = crc.data();
+    e.data = buf.data(), e.n = n, e.lv = level_cfg(level), e.strategy = strategy, e.hash_variant = kHashCrc32c;
+    e.syms = asyms.data(), e.nsyms = 0, e.blocks = ablocks.data(), e.nblocks = 0;
+    e.block_syms = level == 0 ? (kLitBufsize / 2) - 1 : kBlockSyms;
+    e.final_run = 1, e.stop_abs = F;
+    le_restore(e, 0, 0, 0, kR, 0, nullptr, -1, 0, 1);
+    le_run(e, level, 0, 1);
+    if (!e.stopped) {
+        printf("PASS (the engine did not stop before the stream's end) n=%ld F=%ld\n", (long)n, (long)F);
+        return 0;
+    }
+    const int64_t p0 = e.base + e.strstart;
+    const int64_t done_syms = e.block_sym_start, pending = e.nsyms - e.block_sym_start;  // finished blocks' symbols, the block in progress
+    bool ok = true;
+    for (int64_t i = 0; i < e.nsyms && ok; i++)
+        if ((size_t)i >= tr.syms.size() || asyms[(size_t)i] != tr.syms[(size_t)i]) printf("first run: symbol %ld differs\n", (long)i), ok = false;
+    Model m;
+    m.data = buf.data(), m.n = n, m.level = level, m.strategy = strategy, m.lv = level_cfg(level), m.crc_tab = crc;
+    m.flush_mode = 0, m.incremental = false;
+    GeoStart gs;
+    gs.resume = true, gs.at_read = false, gs.p0 = p0, gs.E0 = e.avail_end, gs.base0 = e.base;
+    const std::vector<int64_t> none;
+    const bool bulk = m.lv.func == 2 && strategy != kRle && build_geometry(n, none, m.geo, gs);
+    if (!bulk) {
+        printf("PASS (not a schedule for the bulk path) n=%ld F=%ld p0=%ld\n", (long)n, (long)F, (long)p0);
+        return ok ? 0 : 1;
+    }
+    m.body_end = m.geo.body_end;
+    m.build_links();
+    for (int64_t x = p0 - kWSize > e.base ? p0 - kWSize : e.base; x < p0; x++) {
+        if (x < 0) continue;
+        const int idx = (int)(x - e.base), pv = prev[(size_t)(idx & kWMask)];
+        if (pv > idx && prev[(size_t)(pv & kWMask)] != idx) {
+            printf("PASS (a forward pointer in prev[] that is not a cycle) n=%ld F=%ld\n", (long)n, (long)F);
+            return ok ? 0 : 1;
+        }
+        int d = (pv != 0 && pv < idx) ? idx - pv : 0;
+        if (d > kMaxDist) d = 0;
+        m.link[(size_t)x] = (uint16_t)d;
+    }
+    for (int64_t q = p0; q < p0 + kWSize && q + 5 < n; q++) {
+        const int have = m.link[(size_t)q];
+        if (have != 0 && q - have >= p0) continue;
+        const int hv = head[m.bucket(q)], idx = (int)(q - e.base);
+        int d = hv != 0 ? idx - hv : 0;
+        if (d < 0 || d > kMaxDist) d = 0;
+        m.link[(size_t)q] = (uint16_t)d;
+    }
+    m.match_all();
+    // the node of the lazy parse the engine stands in (as zs_stream_api.inc hands it to the run)
+    m.start_slot = e.match_available == 0 ? 0 : e.match_length < kMinMatch ? 256 + kL : e.prev_length >= m.lv.good ? 256 + kXK4 : 256 + kXK;
+    m.start_syms.assign(asyms.begin() + done_syms, asyms.begin() + done_syms + pending);
+    int64_t p, preins;
+    int kind, k_done;
+    uint32_t pend;
+    parse_chunked(m, p, kind, pend, k_done, preins);
+    run_tail(m, p, kind, pend, k_done, preins);
+    if ((int64_t)tr.syms.size() != done_syms + (int64_t)m.syms.size()) printf("symbol count %ld + %zu vs oracle %zu\n", (long)done_syms, m.syms.size(), tr.syms.size()), ok = false;
+    for (size_t i = 0; i < m.syms.size() && ok; i++)
+        if ((size_t)done_syms + i >= tr.syms.size() || m.syms[i] != tr.syms[(size_t)done_syms + i]) {
+            printf("run behind the stop: symbol %zu differs: model %08x oracle %08x\n", i, m.syms[i], done_syms + (int64_t)i < (int64_t)tr.syms.size() ? tr.syms[(size_t)done_syms + i] : 0u);
+            ok = false;
+        }
+    printf("%s n=%ld level=%d strat=%d mode=resume stop at %ld (asked %ld) slot=%d base=%ld read to %ld, syms=%ld done + %ld pending + %zu, tail_from=%ld\n",
+           ok ? "PASS" : "FAIL", (long)n, level, strategy, (long)p0, (long)F, m.start_slot, (long)e.base, (long)e.avail_end, (long)done_syms, (long)pending,
+           m.syms.size() - (size_t)pending, (long)p);
+    return ok ? 0 : 1;
+}
+
 // ---- mode "resume": a stream flushed after its first F bytes, the rest one Write.  The first Write runs on the literal engine
 // (as a run of an incremental stream does, zs_stream_api.inc); the run behind the flush is laid out by build_geometry with
 // GeoStart::at_read and parsed in the chunked form on chains taken from that engine -- what zs_import_chains_kernel does on
 // the device: prev[] for the 32 Ki positions below the flush, head[] for the first link of every bucket behind it.  The
 // symbols of both runs against the oracle's (per-Write flush modes).
 static int resume_main(std::vector<uint8_t> &buf, int64_t n, int level, int strategy, int64_t F, int flush, const std::vector<size_t> &behind) {
-    if (F <= 0 || F >= n || flush < 1 || flush > 3) {
-        printf("resume: need 0 < F < n and a flush mode 1..3\n");
+    if (F <= 0 || F >= n || flush < 0 || flush > 3) {
+        printf("resume: need 0 < F < n and a flush mode 0..3\n");
         return 2;
     }
+    if (flush == 0) return resume_stop_main(buf, n, level, strategy, F);
     OracleTrace tr;
     zso_trace t;
     memset(&t, 0, sizeof t);

@@ -83,7 +83,7 @@ def test_fast_levels_for_the_lanes_of_a_wave(model, tmp_path):
                 run(files[name], level, strategy, "fvec")
 
 
-def test_runs_behind_a_flush_in_the_chunked_form(model, tmp_path):
+def test_resumed_runs_in_the_chunked_form(model, tmp_path):
     """A stream flushed after its first F bytes (Deflate.cs:583-613), the rest one Write: the first Write on the literal engine,
     the run behind the flush laid out by build_geometry's GeoStart::at_read -- its first pass through the loop reads, with a
     window behind it -- and parsed in the chunked form on chains taken from that engine (prev[] below the flush, head[] for the
@@ -118,6 +118,20 @@ def test_runs_behind_a_flush_in_the_chunked_form(model, tmp_path):
                 assert r.returncode == 0 and "PASS" in r.stdout, (name, spec, flush, r.stdout[-400:])
                 n_bulk += "mode=resume" in r.stdout
     assert n_bulk > 90  # (the chunked form really ran)
+    # ... and the other way into a resumed run: no flush, the literal engine stops at the first loop-top at or behind F that no
+    # read has touched (LitEngine::stop_abs), the chunked form goes on in the lazy parse's node it stands in -- a literal or
+    # a match pending or not -- with the symbols of the block in progress in front of its own
+    slots = set()
+    for name in files:
+        for F in (300, 33792, 40000, 65000, 65536, 70000, 100000, 131072, 150000):
+            for level in (4, 6, 9):
+                if level != 6 and (name not in ("alice300k", "low300k") or F not in (40000, 100000)):
+                    continue
+                r = subprocess.run([EXE, files[name], str(level), "0", "resume", str(F), "0"], capture_output=True, text=True)
+                assert r.returncode == 0 and "PASS" in r.stdout, (name, F, level, r.stdout[-400:])
+                if "slot=" in r.stdout:
+                    slots.add(int(r.stdout.split("slot=")[1].split()[0]))
+    assert len(slots) >= 3, slots  # (the run began in different nodes)
     # ... and the data's own links are not enough behind a FullFlush
     env = dict(os.environ, ZS_MODEL_NO_IMPORT="1")
     r = subprocess.run([EXE, files["alice300k"], "6", "0", "resume", "100000", "3"], capture_output=True, text=True, env=env)
