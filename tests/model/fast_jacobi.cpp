@@ -254,6 +254,20 @@ int main(int argc, char **argv) {
             for (int64_t p = w0; p < t; p++) G[(size_t)p] = nb[(size_t)(p - w0)];
             for (int64_t p = w0; p < hi; p++) rprev[(size_t)p] = rcur[(size_t)(p - w0)];
             progress.push_back((long)(next_w0 - w0));
+            // path compression (ZS_FJ_COMPRESS=1): the link of a final position becomes the distance to the nearest *inserted*
+            // position of its bucket below it -- what prev[] holds in the reference -- so that a search walks the all-position
+            // chain only inside the window
+            if (getenv("ZS_FJ_COMPRESS"))
+                for (int64_t c = w0; c < next_w0; c++) {
+                    int64_t c1 = c;
+                    for (;;) {
+                        const int l = cx.link[(size_t)c1];
+                        if (!l) { c1 = -1; break; }
+                        c1 -= l;
+                        if (G[(size_t)c1]) break;
+                    }
+                    cx.link[(size_t)c] = (c1 < 0 || c - c1 > 32767) ? 0 : (uint16_t)(c - c1);
+                }
             w0 = next_w0;
         }
         printf("slide W=%d K=%d T=%d: %zu sweeps, %.1f positions per sweep, searches per position %.2f (+ %.2f in the pre-sweeps), chain steps per search %.1f\n", W, K, T,

@@ -21,6 +21,7 @@
 #include "../../zlibstream_amd/csrc/zs_core.h"
 #include "../../zlibstream_amd/csrc/zs_lit_engine.h"
 #include "../../zlibstream_amd/csrc/zs_fast_vec.h"
+#include "../../zlibstream_amd/csrc/zs_fast_sweep.h"
 
 using namespace zs;
 
@@ -280,6 +281,109 @@ static void parse_fast_vec(Model &m, int64_t &p_out, int &kdone_out, int64_t &pr
         }
         printf("\n");
     }
+}
+
+
+// ---- DeflateFast as window-wide sweeps (zs_fast_sweep.h): every sweep searches the positions from the first loop-top that
+//      is not final on under the current guess of the inserted set, follows the parse through the results, and makes
+//      final what lies in front of (and at) the first loop-top whose result is not the sweep before's.  The control flow is
+//      the kernel's (zs_fast_sweep_kernel): windows aligned to 64 positions, searches up to the tile's end / the next
+//      trigger / the last bulk loop-top, events at a sweep's first loop-top, links compressed behind the final part.
+struct FsAcc {
+    Model *m;
+    mutable long visits = 0, cmps = 0;
+    int link(int64_t c) const { visits++; return (int)m->link[(size_t)c]; }
+    bool ins(int64_t c) const { return m->ins[(size_t)c] != 0; }
+    int lcp(int64_t q, int64_t c) const { cmps++; return m->lcp(q, c); }
+};
+static void parse_fast_sweep(Model &m, int64_t &p_out, int &kdone_out, int64_t &preins_out) {
+    const int W = getenv("ZS_FS_W") ? atoi(getenv("ZS_FS_W")) : 1024;
+    const int TILE = getenv("ZS_FS_TILE") ? atoi(getenv("ZS_FS_TILE")) : 12288;
+    m.ins.assign((size_t)m.n + 1024, 1);  // the guess for a position no sweep has parsed: inserted
+    FsAcc acc{&m};
+    const int kl = (int)m.rev.size() - 1;
+    FsState st{0, 0, kl >= 1 ? m.rev[1].at - (kMinLookahead - 1) : -1, 0, -1, -1, -1, 0};
+    const bool search = m.strategy != kHuffmanOnly;
+    std::vector<uint32_t> rprev((size_t)m.n + 1024, kFsFresh), rcur((size_t)W + 64);
+    int64_t block_start = 0, t0 = 0;
+    long sweeps = 0;
+    while (st.w0 <= m.body_end) {
+        int64_t g0 = st.w0 & ~63LL;
+        if (g0 + W > t0 + TILE) t0 = g0;  // the tile is staged again from the window's first group on
+        // the read event at loop-top w0: w0 + 1 is inserted first (Deflate.cs:1010-1013)
+        if (st.trigger >= 0 && st.w0 >= st.trigger) {
+            const int64_t t = st.w0;
+            st.k_fired++;
+            m.events.push_back(t);
+            st.preins = t + 1;
+            m.ins[(size_t)t + 1] = 1;
+            if (m.link[(size_t)t + 1] == 1) {
+                st.dead_pos = t, st.only_pos = t + 1;
+                m.link[(size_t)t] = 0;  // prev[t] = t + 1, prev[t + 1] = t: nothing older is reachable through them
+            } else {
+                st.dead_pos = t + 1, st.only_pos = -1;
+            }
+            st.trigger = st.k_fired < kl ? m.rev[(size_t)st.k_fired + 1].at - (kMinLookahead - 1) : -1;
+        }
+        int64_t hi = std::min<int64_t>(std::min<int64_t>(g0 + W, t0 + TILE), m.body_end + 1);
+        if (st.trigger >= 0 && st.trigger < hi) hi = st.trigger;  // (the trigger lies behind w0: the event at w0 has fired)
+        // ---- search [w0, hi) under the guess
+        for (int64_t q = st.w0; q < hi; q++)
+            rcur[(size_t)(q - g0)] = fs_search(acc, q, m.lv.chain, m.lv.nice, !search || q == st.dead_pos, search && q == st.only_pos);
+        // ---- the parse from w0: loop-tops, the first whose result is new, where the path leaves [w0, hi)
+        int64_t t = st.w0, tstar = -1, last_top = -1;
+        std::vector<int64_t> tops;
+        while (t < hi) {
+            const uint32_t r = rcur[(size_t)(t - g0)];
+            tops.push_back(t);
+            if (tstar < 0 && !(t < st.ev_end && rprev[(size_t)t] == r)) tstar = t;
+            last_top = t;
+            t += fs_adv(r);
+        }
+        const int64_t X = t;  // the path's first position at or behind hi
+        if (tstar < 0) tstar = last_top;
+        const int64_t w0_new = tstar + fs_adv(rcur[(size_t)(tstar - g0)]);
+        // ---- the final loop-tops' symbols; block cuts every kBlockSyms symbols (Deflate.cs:910-948)
+        for (int64_t q : tops) {
+            if (q > tstar) break;
+            const uint32_t r = rcur[(size_t)(q - g0)];
+            const bool match = fs_len(r) >= kMinMatch;
+            m.syms.push_back(match ? (((uint32_t)fs_dist(r) << 16) | (uint32_t)(fs_len(r) - 3)) : (uint32_t)m.data[q]);
+            if (m.syms.size() % kBlockSyms == 0) {
+                const int64_t end = q + (match ? fs_len(r) : 1);
+                BlockRec b;
+                b.start = block_start;
+                b.sym_start = (int64_t)m.syms.size() - kBlockSyms;
+                b.stored_len = (int32_t)(end - block_start);
+                b.nsyms = kBlockSyms;
+                b.can_store = block_start >= m.rev[(size_t)st.k_fired].base;
+                b.eof = 0;
+                m.blocks.push_back(b);
+                block_start = end;
+            }
+        }
+        // ---- the next guess: the bits of this parse on [w0, X), "inserted" behind it
+        for (int64_t q = st.w0; q < X; q++) m.ins[(size_t)q] = 0;
+        for (int64_t q : tops) {
+            const int span = fs_inserted_span(rcur[(size_t)(q - g0)], m.lv.lazy);
+            for (int k = 0; k < span; k++) m.ins[(size_t)q + k] = 1;
+        }
+        if (st.preins >= st.w0) m.ins[(size_t)st.preins] = 1;
+        for (int64_t q = st.w0; q < hi; q++) rprev[(size_t)q] = rcur[(size_t)(q - g0)];
+        st.ev_end = hi;
+        // ---- the links of what has become final, compressed
+        for (int64_t c = st.w0; c < w0_new; c++) m.link[(size_t)c] = (uint16_t)fs_compress(acc, c);
+        st.nsyms += 0;
+        st.w0 = w0_new;
+        sweeps++;
+    }
+    // what the tail engine reads: the set below the hand-over loop-top
+    for (int64_t q = st.w0; q < m.n + 1024; q++) m.ins[(size_t)q] = 0;
+    if (st.preins >= st.w0) m.ins[(size_t)st.preins] = 1;
+    if (getenv("ZS_FV_STATS")) printf("fsweep: %ld sweeps, %.1f positions per sweep, %.2f chain steps and %.2f compares per position\n", sweeps, (double)st.w0 / (double)(sweeps ? sweeps : 1), (double)acc.visits / (double)st.w0, (double)acc.cmps / (double)st.w0);
+    p_out = st.w0;
+    kdone_out = st.k_fired;
+    preins_out = st.preins;
 }
 
 // ---- stage B: the chunked form the GPU runs ----
@@ -1024,11 +1128,12 @@ int main(int argc, char **argv) {
     uint32_t pend;
     int64_t preins;
     if (mode == "bulk" || mode == "chunk") m.match_all();
-    if (mode == "fvec") {
+    if (mode == "fvec" || mode == "fsweep") {
         // DeflateFast, single Write: the vector form up to the last loop-top with a full lookahead, then the literal engine
         m.body_end = (m.lv.func == 1 && strategy != kRle && wends.size() <= 1 && flush_mode == 0 && n >= kMinLookahead) ? n - kMinLookahead : -1;
         kind = kR, pend = 0, p = 0, k_done = 0, preins = -1;
-        if (m.body_end >= 0) parse_fast_vec(m, p, k_done, preins);
+        if (m.body_end >= 0 && mode == "fsweep") parse_fast_sweep(m, p, k_done, preins);
+        else if (m.body_end >= 0) parse_fast_vec(m, p, k_done, preins);
     } else if (mode == "chunk") parse_chunked(m, p, kind, pend, k_done, preins);
     else parse_sequential(m, mode != "bulk", p, kind, pend, k_done, preins);
     run_tail(m, p, kind, pend, k_done, preins);

@@ -35,9 +35,9 @@ def model(tmp_path_factory):
     return files
 
 
-def run(path, level, strategy=0, mode="chunk", wchunk=None, flush=0):
+def run(path, level, strategy=0, mode="chunk", wchunk=None, flush=0, env=None):
     cmd = [EXE, path, str(level), str(strategy), mode, str(wchunk or 0), str(flush)]
-    r = subprocess.run(cmd, capture_output=True, text=True)
+    r = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, **env) if env else None)
     assert r.returncode == 0 and "PASS" in r.stdout, (cmd, r.stdout[-500:])
 
 
@@ -81,6 +81,13 @@ def test_fast_levels_for_the_lanes_of_a_wave(model, tmp_path):
         for level in (1, 2, 3):
             for strategy in (0, 2) if name in ("ptt5", "cp.html", "runs") else (0, 1, 2, 4):
                 run(files[name], level, strategy, "fvec")
+                # ... and as window-wide sweeps of a workgroup (zs_fast_sweep.h, zs_fast_sweep_kernel): the control flow of
+                # the kernel -- windows aligned to 64 positions, the guess of the inserted set, what a sweep makes final,
+                # events at a sweep's first loop-top, compressed links -- at the kernel's window and at small ones
+                run(files[name], level, strategy, "fsweep")
+    for name in ("alice_98304", "zeros_98305", "lowent_98305", "runs", "ptt5", "fuzz208279"):
+        for w, tile in ((64, 256), (256, 1024), (2048, 8192)):
+            run(files[name], 1 + (w // 64) % 3, 0, "fsweep", env={"ZS_FS_W": str(w), "ZS_FS_TILE": str(tile)})
 
 
 def test_resumed_runs_in_the_chunked_form(model, tmp_path):

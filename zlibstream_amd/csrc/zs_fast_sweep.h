@@ -1,0 +1,107 @@
+// zs_fast_sweep.h -- DeflateFast (levels 1-3, Deflate.Fast.cs:20-128) as window-wide sweeps of a workgroup.
+//
+// DeflateFast inserts a position into the hash chains only when it is a loop-top or lies inside a match no longer than
+// max_lazy (Deflate.Fast.cs:81-104), so its chains -- and with them its matches -- depend on its own parse.  Three facts
+// make the parse a workgroup's job all the same (checked against the oracle by the CPU model, tests/model mode "fsweep",
+// and measured by tests/model/fast_jacobi.cpp before the kernel existed):
+//
+//  1. The reference's chain of a bucket is the chain of ALL positions of that bucket (K1's links) with the positions that
+//     were never inserted left out.  Given a bitmap of inserted positions the search at a position is a function of the
+//     data (fs_search: walk the all-position chain, skip what is not in the set, count the rest against max_chain).
+//  2. Sweeps.  Let w0 be a loop-top with everything below it final, and G a *guess* of the bitmap from w0 on.  A sweep
+//     searches all W positions from w0 on at once under G, follows the hops of the parse from w0 through the results
+//     (next loop-top = p + 1 or p + match length) and takes the bitmap that parse implies as the next guess.  A loop-top's
+//     search only looks below itself, so by induction over the loop-tops: up to AND INCLUDING the first loop-top on the
+//     path whose result differs from the sweep before, the results of this sweep are the reference's (the guess they
+//     were searched under is, below each of them, the bitmap of a parse that has been the reference's so far).  They are
+//     final; the next sweep starts behind them.  Every sweep makes at least one loop-top final, whatever the data; on
+//     text a sweep of 1024 positions makes ~390 final, one of 4096 ~1100 (profiles/r04_fast_jacobi_convergence.txt).
+//  3. Path compression.  Below w0 the set is final, so the link of a final position c may be replaced by the distance to
+//     the nearest INSERTED position of its bucket below c -- what prev[] holds in the reference (fs_compress).  A walk that
+//     skips uninserted positions finds the same candidates in the same order through either link, so the replacement
+//     needs no synchronisation with the walkers; data whose matches are long (little is inserted: kennedy.xls walked
+//     ~190 chain entries per search) is then searched in max_chain steps like any other.
+//
+// The refill quirk (Deflate.cs:1010-1013: the read at the first loop-top t within 261 bytes of the data end inserts t + 1
+// before t) is applied when a sweep starts at such a loop-top: a sweep never searches beyond the next trigger, so the
+// event's loop-top is always some sweep's w0.  t + 1 joins the set; if t and t + 1 share a bucket (link[t + 1] == 1) the
+// search at t is dead, the one at t + 1 sees only t, and the chain is cut behind t (link[t] = 0: the 2-cycle prev[t] = t + 1,
+// prev[t + 1] = t of the reference); otherwise the search at t + 1 is dead.
+#pragma once
+#include "zs_core.h"
+
+namespace zs {
+
+// a search's result: match length << 16 | distance; length 2, distance 0: no match
+constexpr uint32_t kFsNone = 2u << 16;
+constexpr uint32_t kFsFresh = 0xFFFFFFFFu;  // "not searched by the sweep before"
+ZS_HD int fs_len(uint32_t r) { return (int)(r >> 16); }
+ZS_HD int fs_dist(uint32_t r) { return (int)(r & 0xFFFFu); }
+ZS_HD int fs_adv(uint32_t r) { return fs_len(r) >= kMinMatch ? fs_len(r) : 1; }
+
+// Longest_match (Deflate.cs:1022-1100) at position q with prev_length 2 over the all-position chain filtered by the set.
+//   acc.link(c): distance to the previous position of c's bucket -- or, for a final position, to the previous inserted one
+//                (fs_compress) --, 0 = none within reach
+//   acc.ins(c):  c is in the set (final below the sweep's first loop-top, the guess from there on)
+//   acc.lcp(q, c): common prefix length of the strings at q and c, at most kMaxMatch
+// dead: the search does not happen (refill quirk); only_prev: the search sees just q - 1 (equal-bucket refill).
+template <class Acc>
+ZS_HD uint32_t fs_search(const Acc &acc, int64_t q, int max_chain, int nice, bool dead, bool only_prev) {
+    if (dead) return kFsNone;
+    if (only_prev) {
+        const int len = acc.lcp(q, q - 1);
+        return len > 2 ? ((uint32_t)len << 16) | 1u : kFsNone;
+    }
+    int found = 0, best = 2, bdist = 0;
+    int64_t c = q;
+    for (;;) {
+        const int l = acc.link(c);
+        if (!l) break;
+        c -= l;
+        const int64_t d = q - c;
+        if (c < 1 || (found == 0 ? d > kMaxDist : d >= kMaxDist)) break;  // hash_head: <= MAX_DIST; later: cur_match > limit
+        if (!acc.ins(c)) continue;
+        found++;
+        const int len = acc.lcp(q, c);
+        if (len > best) {
+            best = len, bdist = (int)d;
+            if (len >= nice) break;
+        }
+        if (found >= max_chain) break;
+    }
+    return ((uint32_t)best << 16) | (uint32_t)bdist;
+}
+
+// The link of a final position c, compressed: the distance to the nearest inserted position of c's bucket below it, 0 when
+// there is none a later search could still use.  Reads links that may or may not be compressed already (same answer).
+template <class Acc>
+ZS_HD int fs_compress(const Acc &acc, int64_t c) {
+    int64_t c1 = c;
+    for (;;) {
+        const int l = acc.link(c1);
+        if (!l) return 0;
+        c1 -= l;
+        if (c1 < 1 || c - c1 > kMaxDist) return 0;
+        if (acc.ins(c1)) return (int)(c - c1);
+    }
+}
+
+// What a loop-top puts into the set: itself, and the inside of its match when that is short (Deflate.Fast.cs:81-104).
+ZS_HD int fs_inserted_span(uint32_t r, int max_lazy) {
+    const int len = fs_len(r);
+    return (len >= kMinMatch && len <= max_lazy) ? len : 1;
+}
+
+// The state that goes from sweep to sweep.
+struct FsState {
+    int64_t w0;        // first loop-top that is not final
+    int64_t nsyms;     // symbols emitted so far
+    int64_t trigger;   // the next read event fires at the first loop-top >= trigger (data end before it - 261); < 0: none left
+    int k_fired;       // read events fired so far
+    int64_t preins;    // position pre-inserted by the last fired event, -1
+    int64_t dead_pos;  // position whose search is dead by the last event, -1
+    int64_t only_pos;  // position whose search sees only its predecessor (equal-bucket event), -1
+    int64_t ev_end;    // positions below this were searched by the sweep before (their results are there to compare with)
+};
+
+}  // namespace zs
