@@ -5,6 +5,7 @@
 #include "zs_core.h"
 #include "zs_lit_engine.h"
 #include "zs_fast_vec.h"
+#include "zs_fast_sweep.h"
 
 namespace zs {
 

@@ -766,6 +766,12 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
         // per CU, with K1's links read where they lie: 512 x 512 KiB at level 1 104 -> 70 ms; up to one stream per CU: 1024
         // threads and the links staged in LDS.  Three of 256 threads on a tile of half the size were slower than two -- 79 ms,
         // also for 1024 streams.  ZS_FV_PER_CU=1/2 overrides.)
+        if (!getenv("ZS_FAST_VEC")) {
+            // window-wide sweeps of a workgroup (zs_fast_sweep.hip)
+            constexpr int fs_lds = fs_lds_bytes<1024, 1, kFsTile1>();
+            hipLaunchKernelGGL((zs_fast_sweep_kernel<1024, 1, kFsTile1>), dim3((unsigned)n), dim3(1024), fs_lds, stream, d_sd, d_st,
+                               dev<uint16_t>(c->link), dev<uint32_t>(c->syms), dev<int32_t>(c->blk_end), dev<int32_t>(c->blk_top), lv, strategy);
+        } else {
         int n_fv_streams = 0;
         for (int i = 0; i < n; i++) n_fv_streams += pl.sd[(size_t)i].fv_end >= 0;
         int per_cu = n_fv_streams > 256 ? 2 : 1;
@@ -778,6 +784,7 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
             hipLaunchKernelGGL((zs_fast_vec_kernel<1024, true, kFvTile>), dim3((unsigned)n), dim3(1024), kFvLds, stream, d_sd, d_st, dev<uint16_t>(c->link),
                                dev<uint32_t>(c->syms), dev<int32_t>(c->blk_end), dev<int32_t>(c->blk_top), lv, strategy, dev<uint32_t>(c->fv_lists),
                                fv_list_entries(lv.chain));
+        }
     }
     // the engine is left for a later run, or took the block in progress over from one: it needs K5's symbols and block ends
     const bool tail_late = ro && (!ro->final_run || ro->resume);
@@ -1108,6 +1115,7 @@ int zs_ctx_create(int device, zs_ctx **out) {
         hipFuncSetAttribute((const void *)zs_links_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLkLds) != hipSuccess ||
         hipFuncSetAttribute((const void *)zs_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kTailLds) != hipSuccess ||
         hipFuncSetAttribute((const void *)zs_fast_run_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kTailLds) != hipSuccess ||
+        hipFuncSetAttribute((const void *)zs_fast_sweep_kernel<1024, 1, kFsTile1>, hipFuncAttributeMaxDynamicSharedMemorySize, (fs_lds_bytes<1024, 1, kFsTile1>())) != hipSuccess ||
         hipFuncSetAttribute((const void *)zs_fast_vec_kernel<1024, true, kFvTile>, hipFuncAttributeMaxDynamicSharedMemorySize, kFvLds) != hipSuccess ||
         hipFuncSetAttribute((const void *)zs_fast_vec_kernel<512, false, kFvTile>, hipFuncAttributeMaxDynamicSharedMemorySize, kFvLdsNoLinks) != hipSuccess ||
         hipFuncSetAttribute((const void *)zs_inf_window_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kWinMapLds) != hipSuccess ||

@@ -3120,6 +3120,8 @@ __global__ __launch_bounds__(NT) void zs_fast_vec_kernel(const StreamDesc *sd, S
     }
 }
 
+#include "zs_fast_sweep.hip"
+
 // Build_tree (Trees.cs:404-501) by one wave.  The priority queue is sifted by lane 0 exactly as the reference does
 // (zs_core.h build_tree: tie-breaking decides the tree); what surrounds it is data-parallel and costs as much as the
 // queue on blocks with a full alphabet (binary or image data: ~260 of 286 symbols in use):
