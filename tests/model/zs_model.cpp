@@ -306,7 +306,8 @@ static void parse_fast_sweep(Model &m, int64_t &p_out, int &kdone_out, int64_t &
     const bool search = m.strategy != kHuffmanOnly;
     std::vector<uint32_t> rprev((size_t)m.n + 1024, kFsFresh), rcur((size_t)W + 64);
     int64_t block_start = 0, t0 = 0;
-    long sweeps = 0;
+    long sweeps = 0, skipped = 0, searched = 0;
+    std::vector<long> walk_hist;  // chain steps of a search by its distance from w0 (four bands of 256)
     while (st.w0 <= m.body_end) {
         int64_t g0 = st.w0 & ~63LL;
         if (g0 + W > t0 + TILE) t0 = g0;  // the tile is staged again from the window's first group on
@@ -328,15 +329,32 @@ static void parse_fast_sweep(Model &m, int64_t &p_out, int &kdone_out, int64_t &
         int64_t hi = std::min<int64_t>(std::min<int64_t>(g0 + W, t0 + TILE), m.body_end + 1);
         if (st.trigger >= 0 && st.trigger < hi) hi = st.trigger;  // (the trigger lies behind w0: the event at w0 has fired)
         // ---- search [w0, hi) under the guess
-        for (int64_t q = st.w0; q < hi; q++)
-            rcur[(size_t)(q - g0)] = fs_search(acc, q, m.lv.chain, m.lv.nice, !search || q == st.dead_pos, search && q == st.only_pos);
+        for (int64_t q = st.w0; q < hi; q++) {
+            // a search whose first candidate lies below w0 looks at final bits only: its result stays (kFsExact), and the
+            // sweeps behind it do not search the position again
+            if (q < st.ev_end && (rprev[(size_t)q] & kFsExact) && q != st.dead_pos && q != st.only_pos) {
+                rcur[(size_t)(q - g0)] = rprev[(size_t)q];
+                skipped++;
+                continue;
+            }
+            const int l0 = m.link[(size_t)q];
+            const bool exact = l0 == 0 || q - l0 < st.w0;
+            const long v0 = acc.visits;
+            rcur[(size_t)(q - g0)] = fs_search(acc, q, m.lv.chain, m.lv.nice, !search || q == st.dead_pos, search && q == st.only_pos) | (exact ? kFsExact : 0u);
+            searched++;
+            if (walk_hist.empty()) walk_hist.assign(4 * 64, 0);
+            {
+                const int b = (int)std::min<int64_t>(3, (q - st.w0) / 256);
+                walk_hist[(size_t)b * 64 + (size_t)std::min<long>(63, acc.visits - v0)]++;
+            }
+        }
         // ---- the parse from w0: loop-tops, the first whose result is new, where the path leaves [w0, hi)
         int64_t t = st.w0, tstar = -1, last_top = -1;
         std::vector<int64_t> tops;
         while (t < hi) {
             const uint32_t r = rcur[(size_t)(t - g0)];
             tops.push_back(t);
-            if (tstar < 0 && !(t < st.ev_end && rprev[(size_t)t] == r)) tstar = t;
+            if (tstar < 0 && !(t < st.ev_end && ((rprev[(size_t)t] ^ r) & kFsResMask) == 0)) tstar = t;
             last_top = t;
             t += fs_adv(r);
         }
@@ -380,7 +398,22 @@ static void parse_fast_sweep(Model &m, int64_t &p_out, int &kdone_out, int64_t &
     // what the tail engine reads: the set below the hand-over loop-top
     for (int64_t q = st.w0; q < m.n + 1024; q++) m.ins[(size_t)q] = 0;
     if (st.preins >= st.w0) m.ins[(size_t)st.preins] = 1;
-    if (getenv("ZS_FV_STATS")) printf("fsweep: %ld sweeps, %.1f positions per sweep, %.2f chain steps and %.2f compares per position\n", sweeps, (double)st.w0 / (double)(sweeps ? sweeps : 1), (double)acc.visits / (double)st.w0, (double)acc.cmps / (double)st.w0);
+    if (getenv("ZS_FV_STATS")) printf("fsweep: %ld sweeps, %.1f positions per sweep, %.2f searches (%.2f skipped: exact) %.2f chain steps and %.2f compares per position\n", sweeps, (double)st.w0 / (double)(sweeps ? sweeps : 1), (double)searched / (double)st.w0, (double)skipped / (double)st.w0, (double)acc.visits / (double)st.w0, (double)acc.cmps / (double)st.w0);
+    if (getenv("ZS_FV_STATS") && !walk_hist.empty())
+        for (int b = 0; b < 4; b++) {
+            long tot = 0, sum = 0;
+            for (int k = 0; k < 64; k++) tot += walk_hist[(size_t)b * 64 + k], sum += k * walk_hist[(size_t)b * 64 + k];
+            long acc2 = 0;
+            int p50 = 0, p90 = 0, p99 = 0, p999 = 0;
+            for (int k = 0; k < 64; k++) {
+                acc2 += walk_hist[(size_t)b * 64 + k];
+                if (acc2 * 2 < tot) p50 = k + 1;
+                if (acc2 * 10 < tot * 9) p90 = k + 1;
+                if (acc2 * 100 < tot * 99) p99 = k + 1;
+                if (acc2 * 1000 < tot * 999) p999 = k + 1;
+            }
+            printf("  searches %d-%d behind w0: %ld, chain steps mean %.1f p50 %d p90 %d p99 %d p99.9 %d (63 = more)\n", 256 * b, 256 * b + 255, tot, tot ? (double)sum / tot : 0.0, p50, p90, p99, p999);
+        }
     p_out = st.w0;
     kdone_out = st.k_fired;
     preins_out = st.preins;

@@ -768,8 +768,8 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
         // also for 1024 streams.  ZS_FV_PER_CU=1/2 overrides.)
         if (!getenv("ZS_FAST_VEC")) {
             // window-wide sweeps of a workgroup (zs_fast_sweep.hip)
-            constexpr int fs_lds = fs_lds_bytes<1024, 1, kFsTile1>();
-            hipLaunchKernelGGL((zs_fast_sweep_kernel<1024, 1, kFsTile1>), dim3((unsigned)n), dim3(1024), fs_lds, stream, d_sd, d_st,
+            constexpr int fs_lds = fs_lds_bytes<1024, kFsTile1>();
+            hipLaunchKernelGGL((zs_fast_sweep_kernel<1024, kFsTile1>), dim3((unsigned)n), dim3(1024), fs_lds, stream, d_sd, d_st,
                                dev<uint16_t>(c->link), dev<uint32_t>(c->syms), dev<int32_t>(c->blk_end), dev<int32_t>(c->blk_top), lv, strategy);
         } else {
         int n_fv_streams = 0;
@@ -1115,7 +1115,7 @@ int zs_ctx_create(int device, zs_ctx **out) {
         hipFuncSetAttribute((const void *)zs_links_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLkLds) != hipSuccess ||
         hipFuncSetAttribute((const void *)zs_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kTailLds) != hipSuccess ||
         hipFuncSetAttribute((const void *)zs_fast_run_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kTailLds) != hipSuccess ||
-        hipFuncSetAttribute((const void *)zs_fast_sweep_kernel<1024, 1, kFsTile1>, hipFuncAttributeMaxDynamicSharedMemorySize, (fs_lds_bytes<1024, 1, kFsTile1>())) != hipSuccess ||
+        hipFuncSetAttribute((const void *)zs_fast_sweep_kernel<1024, kFsTile1>, hipFuncAttributeMaxDynamicSharedMemorySize, (fs_lds_bytes<1024, kFsTile1>())) != hipSuccess ||
         hipFuncSetAttribute((const void *)zs_fast_vec_kernel<1024, true, kFvTile>, hipFuncAttributeMaxDynamicSharedMemorySize, kFvLds) != hipSuccess ||
         hipFuncSetAttribute((const void *)zs_fast_vec_kernel<512, false, kFvTile>, hipFuncAttributeMaxDynamicSharedMemorySize, kFvLdsNoLinks) != hipSuccess ||
         hipFuncSetAttribute((const void *)zs_inf_window_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kWinMapLds) != hipSuccess ||

@@ -35,7 +35,11 @@ namespace zs {
 // a search's result: match length << 16 | distance; length 2, distance 0: no match
 constexpr uint32_t kFsNone = 2u << 16;
 constexpr uint32_t kFsFresh = 0xFFFFFFFFu;  // "not searched by the sweep before"
-ZS_HD int fs_len(uint32_t r) { return (int)(r >> 16); }
+// flags above the result (length: 9 bits from bit 16): the search looked at final bits only -- its first candidate lay below
+// the sweep's first loop-top -- so the result stays whatever later sweeps guess
+constexpr uint32_t kFsExact = 1u << 30;
+constexpr uint32_t kFsResMask = 0x01FFFFFFu;
+ZS_HD int fs_len(uint32_t r) { return (int)((r & kFsResMask) >> 16); }
 ZS_HD int fs_dist(uint32_t r) { return (int)(r & 0xFFFFu); }
 ZS_HD int fs_adv(uint32_t r) { return fs_len(r) >= kMinMatch ? fs_len(r) : 1; }
 

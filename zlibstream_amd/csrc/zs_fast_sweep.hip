@@ -1,88 +1,137 @@
 // zs_fast_sweep.hip -- KS: DeflateFast (levels 1-3, Deflate.Fast.cs:20-128) as window-wide sweeps of a workgroup.
 // Included by zs_kernels.hip; zs_fast_sweep.h has the formulation and the code shared with the CPU model.
 //
-// One workgroup of NT threads per stream.  The tile -- bytes, K1's all-position links and the inserted-position bitmap of
-// [t0 - 32 512, t0 + TILE) -- is staged in LDS once per TILE - W positions of progress.  A sweep:
+// One workgroup of 1024 threads per stream.  The tile -- bytes, K1's all-position links and the inserted-position bitmap of
+// [t0 - 32 512, t0 + TILE) -- is staged in LDS once per TILE - W positions of progress.  A link entry in LDS is a halfword:
+// bits 0..14 the distance to the previous position of the bucket (0x7FFF: none), bit 15 the position's own membership in the
+// set, so a walker gets an entry's membership and the way on with one read.  A sweep (W = 1024 positions from g0 = w0
+// rounded down to 64 on; a wave owns the group of 64 positions with its number):
 //
-//   1. search     every thread searches its PPT positions of the window [g0, g0 + W), g0 = w0 rounded down to 64, under the
-//                 bitmap as it stands (final below w0, the last sweep's parse behind it, "inserted" where nothing has been
-//                 parsed yet): fs_search's walk over the staged links, one chain step per trip of a wave-wide loop
-//   2. hops       a wave owns groups of 64 consecutive positions.  next(p) = p + 1 or p + match length; the first position
-//                 behind its group that a lane's hops lead to comes from six rounds of pointer doubling with ds_bpermute
-//                 (the doubling tables stay in registers), and goes into the exit table in LDS           -- barrier 1
-//   3. path       every wave follows the path from w0 through the exit table up to its own groups (at most W / 64 dependent
-//                 LDS reads), which gives each group the lane the path enters it at; the lanes on the path -- the window's
-//                 loop-tops -- are then found by walking the doubling tables down (six ds_bpermute).  The first loop-top
-//                 whose result differs from the sweep before (results are kept in a ring by position): LDS atomic min;
-//                 loop-tops per group: LDS                                                                -- barrier 2
-//   4. final      loop-tops up to and including that one are final: their symbols leave in order (a wave's rank offset is
-//                 the sum of the groups' counts before it), every group writes the bits of its 64 positions as this sweep's
-//                 parse has them (loop-tops, the inside of short matches, "inserted" behind the path's end) -- barrier 3
-//   5. compress   the links of the positions that have become final are replaced by the distance to the nearest inserted
-//                 position of their bucket (fs_compress), in LDS and in the stream's link array; no barrier: walkers find the
-//                 same candidates through either link (zs_fast_sweep.h, fact 3), so this overlaps the next sweep's searches
+//   1. search     every lane searches its position under the set as it stands (final below w0, the last sweep's parse
+//                 behind it, "inserted" where nothing has been parsed yet): fs_search in two alternating phases -- all
+//                 walking lanes skip along their chains to the next entry that is in the set (a dozen instructions a step),
+//                 then all compare once -- because the CU is bound by instruction issue here (16 waves, every one of their
+//                 instructions costs the sweep 4 cycles) and a one-phase step is 70 instructions whatever the lane does.  A
+//                 search whose first candidate lies below w0 rests on final bits alone: its result is marked and the
+//                 position is not searched again
+//   2. hops       next(p) = p + 1 or p + match length.  Per lane, by six rounds of pointer doubling with ds_bpermute: the
+//                 first index behind its group that its hops lead to, the length of the hop that leaves the group and the
+//                 number of hops (the doubling tables stay in registers; the result goes to the exit table)  -- barrier 1
+//   3. path       ONE wave follows the path from w0 through the exit table, whose rows it holds in registers (a hop from
+//                 group to group is a v_readlane), and publishes per group: where the path enters it, the hop that enters,
+//                 the loop-tops before it.  The other waves compress links meanwhile (5.)                    -- barrier 2
+//   4. loop-tops  per group: the lanes on the path, by walking the doubling tables down from the entry (six ds_bpermute);
+//                 the first whose result differs from the sweep before (results are kept in a ring by position): LDS
+//                 atomic min                                                                                 -- barrier 3
+//   5. final      loop-tops up to and including that one are final: their symbols leave in order; every group writes the
+//                 bits of its 64 positions as this sweep's parse has them (loop-tops, the inside of short matches,
+//                 "inserted" behind the path's end), into the bitmap and into the link entries              -- barrier 4
+//      compress   (in step 3 of the next sweep, by the waves that do not follow the path) the links of the positions that
+//                 became final are replaced by the distance to the nearest inserted position of their bucket (fs_compress),
+//                 in LDS and in the stream's link array; walkers find the same candidates through either link
+//                 (zs_fast_sweep.h, fact 3), so nothing waits for this
 //
-// Three barriers per sweep; 1024 positions searched, ~390 made final on text (profiles/r04_fast_jacobi_convergence.txt).
 // What it leaves is what K4 / K5 leave for the lazy parse, so the tail engine (restored from the bitmap and the links --
 // compressed or not, le_restore_prev_ins finds the same predecessor) and the block kernels go on unchanged.
 
-constexpr int kFsBack = 32512;  // >= kMaxDist, multiple of 64
-constexpr int kFsFwd = 272;     // >= kMaxMatch + 8, multiple of 16
-constexpr int kFsTile1 = 12288; // positions per tile with one position per thread (W = 1024): 152.7 KiB of LDS
+constexpr int kFsBack = 32512;   // >= kMaxDist, multiple of 64
+constexpr int kFsFwd = 272;      // >= kMaxMatch + 8, multiple of 16
+constexpr int kFsTile1 = 12288;  // positions per tile with one position per thread (W = 1024): 152.8 KiB of LDS
+constexpr uint32_t kFsNoLink = 0x7FFFu;
 template <int TILE>
 struct FsLayout {
     static constexpr int bytes = kFsBack + TILE + kFsFwd, links = kFsBack + TILE, bit_words = links / 32 + 16;
 };
-template <int NT, int PPT, int TILE>
+template <int NT, int TILE>
 constexpr int fs_lds_bytes() {
-    return FsLayout<TILE>::bytes + 2 * FsLayout<TILE>::links + 4 * FsLayout<TILE>::bit_words + 4 * (2 * NT * PPT) + 4 * (NT * PPT) + 4 * (NT * PPT / 64) + 64;
+    return FsLayout<TILE>::bytes + 2 * FsLayout<TILE>::links + 2 * 4 * FsLayout<TILE>::bit_words + 4 * (2 * NT) + 4 * NT + 8 * (NT / 64) + 64;
+}
+// a pair of link halfwords as the link kernel left them -> the staged form (no membership bit yet); p = position of the low one
+__device__ __forceinline__ uint32_t fs_stage_links(uint32_t pair, int p) {
+    uint32_t a = pair & 0xFFFFu, b = pair >> 16;
+    a = (a == 0 || p - (int)a < 1) ? kFsNoLink : a;  // position 0 is never a candidate
+    b = (b == 0 || p + 1 - (int)b < 1) ? kFsNoLink : b;
+    return a | (b << 16);
+}
+// the doubling word of a lane: index (12 bits) | last hop's length (9) | hops (7)
+__device__ __forceinline__ int fs_pj(uint32_t p) { return (int)(p & 0xFFFu); }
+__device__ __forceinline__ int fs_pl(uint32_t p) { return (int)((p >> 12) & 0x1FFu); }
+__device__ __forceinline__ int fs_pc(uint32_t p) { return (int)(p >> 21); }
+
+// Runs.  Inside a run of equal bytes every position's bucket is its neighbour's, the all-position chain goes down one position
+// at a time, and a long match inserts none of them: a walker at an entry c that is not in the set and whose link is 1 would
+// take a step per position (ptt5: 145 per search).  With a bit per position for "link is 1" the next 32 entries are looked
+// at together: the stretch below c that is reachable by such links, and the highest member of the set in it.  Returns the
+// index to go on from with link 1: one above that member, or one above the stretch's lowest position.
+__device__ __forceinline__ int fs_run_skip(int c, const uint32_t *bm, const uint32_t *rb) {
+    const int s = c - 1, sb = s & 31, wi = s >> 5;
+    const uint32_t cont = (rb[wi] >> 1) | (rb[wi + 1] << 31);  // bit p: one can step from p + 1 to p
+    const uint32_t t = cont << (31 - sb);
+    const int k = __builtin_clz(~t | 1u) ;                      // positions s, s - 1, ... s - k + 1 are reachable (k >= 1: rb[c] is set)
+    const int k1 = k < 1 ? 1 : (k > sb + 1 ? sb + 1 : k);
+    const uint32_t reach = (k1 >= 32 ? 0xFFFFFFFFu : ((1u << k1) - 1u)) << (sb + 1 - k1);
+    const uint32_t f = bm[wi] & reach;
+    const int land = f ? 31 - __builtin_clz(f) : sb + 1 - k1;
+    return (wi << 5) + land + 1;
 }
 
-template <int NT, int PPT, int TILE>
+template <int NT, int TILE>
 __global__ __launch_bounds__(NT) void zs_fast_sweep_kernel(const StreamDesc *sd, StreamState *st, uint16_t *link, uint32_t *syms, int32_t *blk_end,
                                                              int32_t *blk_top, LevelCfg lv, int strategy) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    constexpr int W = NT * PPT, NG = W / 64, NW = NT / 64, RING = 2 * W;
+    constexpr int W = NT, NG = W / 64, RING = 2 * W;
     constexpr int fsBytes = FsLayout<TILE>::bytes, fsLinks = FsLayout<TILE>::links, fsBitWords = FsLayout<TILE>::bit_words;
-    static_assert(TILE % 64 == 0 && TILE >= 2 * W, "tile");
+    static_assert(TILE % 64 == 0 && TILE >= 2 * W && W + 258 < 4096 && NG <= 64, "tile / doubling word");
     const StreamDesc s = sd[blockIdx.x];
     if (s.fv_end < 0) return;
-    uint8_t *wb = smem;                                  // bytes, index = position - lo
-    uint16_t *wl = (uint16_t *)(smem + fsBytes);         // links, 0 = none
+    uint8_t *wb = smem;                                         // bytes, index = position - lo
+    uint16_t *wl = (uint16_t *)(smem + fsBytes);                // link entries
     uint32_t *bm = (uint32_t *)(smem + fsBytes + 2 * fsLinks);  // inserted bits, word k = positions [lo + 32 k, + 32)
-    uint32_t *ring = bm + fsBitWords;                    // the last sweep's result of position q at q & (RING - 1)
-    uint32_t *ex = ring + RING;                          // window index -> first index behind its group on its path | last hop << 16
-    uint32_t *cnt = ex + W;                              // loop-tops per group
-    uint32_t *shv = cnt + NG;                            // [0] first loop-top with a new result, [1] last loop-top, [2] final ones in its group
-    const int tid = threadIdx.x, lane = lane_id(), wave = tid >> 6;
-    const int64_t n = s.n, body_end = s.fv_end;
+    uint32_t *ring = bm + fsBitWords;                           // the last sweep's result of position q at q & (RING - 1)
+    uint32_t *ex = ring + RING;                                 // window index -> doubling word of its way out of its group
+    uint32_t *gent = ex + W;                                    // per group: entry index (0xFFF: none) | entering hop << 12 | path ended before << 21
+    uint32_t *gbef = gent + NG;                                 // per group: loop-tops in the groups before it
+    uint32_t *rb = gbef + NG;                                   // bit of a position: its link is 1 (the previous position of its bucket is its neighbour: runs)
+    // [0] first loop-top with a new result, [1] last loop-top, [2] final loop-tops of the sweep
+    // (static: the compiler then knows the address space and the atomics below are LDS instructions, not flat ones)
+    __shared__ uint32_t shv[4];
+    const int tid = threadIdx.x, lane = lane_id(), wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (uniform, and the compiler knows)
+    const int n = s.n, body_end = s.fv_end;
     const gcbytes in = as_global(s.in);
     uint16_t *lk = link + s.pos_off;
     uint32_t *gbits = s.ins_bits;
+    uint32_t *out_syms = syms + s.sym_off;
     const int kl = s.kl;
     const bool search = strategy != kHuffmanOnly;  // (HuffmanOnly: Longest_match is never called, Deflate.Fast.cs:61-66)
     const int nice = lv.nice, chain = lv.chain, lazy = lv.lazy;
     const bool aligned = (((uintptr_t)in) & 15) == 0;
-    // the state that goes from sweep to sweep, held by every thread (all of it is computed from shared values)
-    int64_t w0 = 0, nsyms = 0, trigger = kl >= 1 ? read_end_before(1) - (kMinLookahead - 1) : -1, preins = -1, dead_pos = -1, only_pos = -1, ev_end = 0;
-    int k_fired = 0;
-    int64_t t0 = -(1ll << 40), w0_staged = 0;
-    int64_t x_end = 0;  // where the last sweep's parse ended: the bits of [w0, x_end) are that parse's (the guess the results in the ring belong to)
+    // the state that goes from sweep to sweep, held by every thread (all of it is computed from shared values); positions are
+    // below 2^31 (StreamDesc::n)
+    int w0 = 0, nsyms = 0, trigger = kl >= 1 ? (int)read_end_before(1) - (kMinLookahead - 1) : -1, preins = -1, dead_pos = -1, only_pos = -1, ev_end = 0;
+    int k_fired = 0, next_cut = kBlockSyms - 1;  // (the symbol with this index ends a block, Deflate.cs:910-948)
+    int t0 = -(1 << 30), w0_staged = 0;
+    int x_end = 0;  // where the last sweep's parse ended: the bits of [w0, x_end) are that parse's (the guess the results in the ring belong to)
     if (tid == 0) shv[0] = 0xFFFFFFFFu, shv[1] = 0, shv[2] = 0;
+#ifdef ZS_FS_PROF
+    long long pf[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pf_t = wall_clock64(), pf_sweeps = 0, pf_skips = 0, pf_cmps = 0;
+#define FS_PF(i) { const long long now_ = wall_clock64(); pf[i] += now_ - pf_t; pf_t = now_; }
+#else
+#define FS_PF(i)
+#endif
     while (w0 <= body_end) {
-        int64_t g0 = w0 & ~63LL;
+        const int g0 = w0 & ~63;
         if (g0 + W > t0 + TILE) {
             // ---- (leave the tile: the bits that became final go back to the stream's bitmap) stage the tile at g0
-            __syncthreads();  // the compression of the last sweep reads the tile that is about to be overwritten
+            __syncthreads();
             if (t0 >= 0) {
-                const int64_t lo_old = t0 - kFsBack;
-                for (int64_t wd = (w0_staged >> 5) + tid; wd <= (x_end >> 5); wd += NT) gbits[wd] = bm[wd - (lo_old >> 5)];
+                const int lo_old = t0 - kFsBack;
+                for (int wd = (w0_staged >> 5) + tid; wd <= (x_end >> 5); wd += NT) gbits[wd] = bm[wd - (lo_old >> 5)];
                 __syncthreads();
             }
             t0 = g0, w0_staged = w0;
-            const int64_t lo = t0 - kFsBack;
+            const int lo = t0 - kFsBack;
             for (int i = tid; i < fsBytes / 16; i += NT) {
-                const int64_t a = lo + (int64_t)i * 16;
+                const int a = lo + i * 16;
                 uint4 v = make_uint4(0, 0, 0, 0);
                 if (a >= 0 && a + 15 < n && aligned) {
                     const u32x4 t = *(gcu32x4)(in + a);
@@ -90,105 +139,107 @@ __global__ __launch_bounds__(NT) void zs_fast_sweep_kernel(const StreamDesc *sd,
                 } else if (a + 15 >= 0 && a < n) {
                     uint32_t t[4] = {0, 0, 0, 0};
                     for (int k = 0; k < 16; k++) {
-                        const int64_t b = a + k;
+                        const int b = a + k;
                         if (b >= 0 && b < n) t[k >> 2] |= (uint32_t)in[b] << (8 * (k & 3));
                     }
                     v = make_uint4(t[0], t[1], t[2], t[3]);
                 }
                 ((uint4 *)wb)[i] = v;
             }
-            for (int i = tid; i < fsLinks / 8; i += NT) {
-                const int64_t a = lo + (int64_t)i * 8;
-                uint4 v = make_uint4(0, 0, 0, 0);
-                if (a >= 0 && a + 7 < n) {
-                    v = *(const uint4 *)(lk + a);
-                } else if (a + 7 >= 0 && a < n) {
-                    uint32_t t[4] = {0, 0, 0, 0};
-                    for (int k = 0; k < 8; k++) {
-                        const int64_t b = a + k;
-                        if (b >= 0 && b < n) t[k >> 1] |= (uint32_t)lk[b] << (16 * (k & 1));
-                    }
-                    v = make_uint4(t[0], t[1], t[2], t[3]);
-                }
-                ((uint4 *)wl)[i] = v;
-            }
             // the set: the stream's bits below the last parse's end (final below w0, that parse's from there on), "inserted"
             // behind it (the guess for what no sweep has parsed)
             for (int i = tid; i < fsBitWords; i += NT) {
-                const int64_t p32 = lo + 32ll * i;  // first position of the word
+                const int p32 = lo + 32 * i;  // first position of the word
                 uint32_t v = 0xFFFFFFFFu;
                 if (p32 + 32 <= x_end) v = p32 >= 0 ? gbits[p32 >> 5] : 0u;
                 else if (p32 < x_end) v = gbits[p32 >> 5] | (0xFFFFFFFFu << (uint32_t)(x_end - p32));
                 bm[i] = v;
             }
             __syncthreads();
+            // the link entries: distance (none: 0x7FFF) + the position's bit of the set
+            for (int i = tid; i < fsLinks / 8; i += NT) {
+                const int a = lo + i * 8;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (a >= 0 && a + 7 < n) {
+                    v = *(const uint4 *)(lk + a);
+                } else if (a + 7 >= 0 && a < n) {
+                    uint32_t t[4] = {0, 0, 0, 0};
+                    for (int k = 0; k < 8; k++) {
+                        const int b = a + k;
+                        if (b >= 0 && b < n) t[k >> 1] |= (uint32_t)lk[b] << (16 * (k & 1));
+                    }
+                    v = make_uint4(t[0], t[1], t[2], t[3]);
+                }
+                const uint32_t f = bm[i >> 2] >> (8 * (i & 3));  // the bits of positions 8 i .. 8 i + 7
+                v.x = fs_stage_links(v.x, a), v.y = fs_stage_links(v.y, a + 2), v.z = fs_stage_links(v.z, a + 4), v.w = fs_stage_links(v.w, a + 6);
+                ((uint8_t *)rb)[i] = (uint8_t)(((v.x & 0xFFFFu) == 1u) | (((v.x >> 16) == 1u) << 1) | (((v.y & 0xFFFFu) == 1u) << 2) | (((v.y >> 16) == 1u) << 3) |
+                                               (((v.z & 0xFFFFu) == 1u) << 4) | (((v.z >> 16) == 1u) << 5) | (((v.w & 0xFFFFu) == 1u) << 6) | (((v.w >> 16) == 1u) << 7));
+                v.x |= ((f & 1u) << 15) | ((f & 2u) << 30);
+                v.y |= ((f & 4u) << 13) | ((f & 8u) << 28);
+                v.z |= ((f & 16u) << 11) | ((f & 32u) << 26);
+                v.w |= ((f & 64u) << 9) | ((f & 128u) << 24);
+                ((uint4 *)wl)[i] = v;
+            }
+            if (tid < 16) rb[fsLinks / 32 + tid] = 0;
+            __syncthreads();
+            FS_PF(0);
         }
-        const int64_t lo = t0 - kFsBack;
-        const int min_i = (int)(1 - lo);  // position 0 is never a candidate
+        const int lo = t0 - kFsBack;
         // ---- the read event at loop-top w0: w0 + 1 is inserted first (Deflate.cs:1010-1013).  One per 32 Ki positions.
         if (trigger >= 0 && w0 >= trigger) {
-            const bool same = wl[w0 + 1 - lo] == 1;
-            __syncthreads();  // (the read above, the compression of the sweep before) before the cut below
+            const bool same = (wl[w0 + 1 - lo] & 0x7FFFu) == 1u;
+            __syncthreads();
             k_fired++;
             preins = w0 + 1;
             if (same) dead_pos = w0, only_pos = w0 + 1;
             else dead_pos = w0 + 1, only_pos = -1;
             if (tid == 0) {
                 bm[(w0 + 1 - lo) >> 5] |= 1u << ((w0 + 1 - lo) & 31);
-                if (same) wl[w0 - lo] = 0, lk[w0] = 0;  // the reference's prev[w0] = w0 + 1, prev[w0 + 1] = w0
+                wl[w0 + 1 - lo] |= 0x8000u;
+                if (same) wl[w0 - lo] |= kFsNoLink, lk[w0] = 0, rb[(w0 - lo) >> 5] &= ~(1u << ((w0 - lo) & 31));  // the reference's prev[w0] = w0 + 1, prev[w0 + 1] = w0
             }
-            trigger = k_fired < kl ? read_end_before(k_fired + 1) - (kMinLookahead - 1) : -1;
+            trigger = k_fired < kl ? (int)read_end_before(k_fired + 1) - (kMinLookahead - 1) : -1;
             __syncthreads();
         }
-        int64_t hi = g0 + W;
+        int hi = g0 + W;
         if (body_end + 1 < hi) hi = body_end + 1;
         if (trigger >= 0 && trigger < hi) hi = trigger;
-        const int w0r = (int)(w0 - g0), hir = (int)(hi - g0), gi = (int)(g0 - lo);
-        uint32_t res[PPT], dbl[PPT][6];
-        bool act[PPT], agr[PPT];
-#pragma unroll
-        for (int k = 0; k < PPT; k++) {
-            const int grp = wave + NW * k, self = 64 * grp + lane;  // index in the window
-            const int qi = gi + self;                                // index in the tile
-            const int64_t q = g0 + self;
-            act[k] = self >= w0r && self < hir;
-            // ---- 1. search (fs_search, one chain step per trip)
-            int found = 0, best = 2, bdist = 0;
-            const bool dead = !search || q == dead_pos, only_prev = search && q == only_pos;
-            int done = (!act[k] || dead || only_prev) ? 1 : 0;
-            if (act[k] && only_prev) {
-                int len = 0;
-                while (len < kMaxMatch) {
-                    const uint64_t y = lds_u64(wb, qi + len) ^ lds_u64(wb, qi - 1 + len);
-                    if (y) {
-                        len += (int)(__builtin_ctzll(y) >> 3);
-                        break;
-                    }
-                    len += 8;
-                }
-                len = len < kMaxMatch ? len : kMaxMatch;
-                if (len > 2) best = len, bdist = 1;
-            }
-            if (__ballot(!done)) {
-                const uint64_t scan8 = lds_u64(wb, qi);
-                int c = qi;
-                while (__ballot(!done)) {
-                    const int l = wl[c];
-                    const int nc = c - l, d = qi - nc;
-                    const int maxd = found ? kMaxDist - 1 : kMaxDist;  // hash_head: <= MAX_DIST; later: cur_match > limit
-                    const int valid = (done == 0) & (l != 0) & (nc >= min_i) & (d <= maxd);
-                    done |= valid ^ 1;
-                    c = valid ? nc : qi;  // lanes that are done read their own position (in range)
-                    const uint32_t word = bm[c >> 5];
-                    const int isin = valid & (int)((word >> (c & 31)) & 1u);
-                    if (__ballot(isin)) {
-                        int len = 0;
-                        if (isin) {
-                            const uint64_t x = lds_u64(wb, c) ^ scan8;
-                            len = x ? (int)(__builtin_ctzll(x) >> 3) : 8;
+        const int w0r = w0 - g0, hir = hi - g0, gi = g0 - lo;
+        const int grp = wave, gbase = 64 * grp, self = gbase + lane;  // the lane's index in the window
+        const int qi = gi + self, q = g0 + self;                       // ... in the tile, and its position
+        const bool act = self >= w0r && self < hir;
+        // ---- 1. search
+        const int slot = q & (RING - 1);
+        const uint32_t old = ring[slot];
+        const bool dead = !search || q == dead_pos, only_prev = search && q == only_pos;
+        const bool known = q < ev_end && (old & kFsExact) != 0 && !dead && !only_prev;
+        int best = 2, bdist = 0;
+        uint32_t exact = (dead || only_prev) ? kFsExact : 0u;
+        {
+            const uint64_t scan8 = lds_u64(wb, qi);
+            bool walking = act && !dead && !known;
+            int c = qi, rem = chain, maxd = kMaxDist;  // hash_head: <= MAX_DIST; later: cur_match > limit
+            uint32_t l = wl[qi] & 0x7FFFu;
+            if (qi - (int)l < gi + w0r) exact = kFsExact;  // (no link: 0x7FFF, below anything)
+            if (only_prev) l = 1, rem = 1;                 // the search sees only q - 1 (equal-bucket refill), whatever the set says
+            while (__ballot(walking)) {
+#ifdef ZS_FS_PROF
+                pf_skips++;
+#endif
+                if (walking) {
+                    const int nc = c - (int)l, d = qi - nc;
+                    if (d > maxd) {
+                        walking = false;
+                    } else {
+                        const uint32_t v = wl[nc];
+                        c = nc, l = v & 0x7FFFu;
+                        if ((v >> 15) || only_prev) {
+                            const uint64_t x = lds_u64(wb, nc) ^ scan8;
+                            int len = (int)(__builtin_ctzll(x) >> 3);
                             if (!x) {
+                                len = 8;
                                 while (len < kMaxMatch) {
-                                    const uint64_t y = lds_u64(wb, qi + len) ^ lds_u64(wb, c + len);
+                                    const uint64_t y = lds_u64(wb, qi + len) ^ lds_u64(wb, nc + len);
                                     if (y) {
                                         len += (int)(__builtin_ctzll(y) >> 3);
                                         break;
@@ -197,164 +248,203 @@ __global__ __launch_bounds__(NT) void zs_fast_sweep_kernel(const StreamDesc *sd,
                                 }
                                 len = len < kMaxMatch ? len : kMaxMatch;
                             }
+                            maxd = kMaxDist - 1;
+                            if (len > best) {
+                                best = len, bdist = d;
+                                if (len >= nice) walking = false;
+                            }
+                            if (--rem == 0) walking = false;
+                        } else if (l == 1u) {
+                            c = fs_run_skip(nc, bm, rb);
                         }
-                        found += isin;
-                        const int better = isin & (len > best);
-                        best = better ? len : best;
-                        bdist = better ? d : bdist;
-                        done |= (better & (len >= nice)) | (isin & (found >= chain));
                     }
                 }
             }
-            const uint32_t r = ((uint32_t)best << 16) | (uint32_t)bdist;
-            res[k] = r;
-            // the result of the sweep before, if that sweep searched the position (the slot is the position's own)
-            const int slot = (int)(q & (RING - 1));
-            agr[k] = q < ev_end && ring[slot] == r;
-            if (act[k]) ring[slot] = r;
-            // ---- 2. hops: the first index behind the group on the lane's path, by pointer doubling; a lane that is not
-            //         searched (behind hi: the path ends there) points at itself, with hop length 0
-            uint32_t P = act[k] ? (uint32_t)(self + fs_adv(r)) | ((uint32_t)fs_adv(r) << 16) : (uint32_t)self;
+        }
+        uint32_t r = ((uint32_t)best << 16) | (uint32_t)bdist | exact;
+        if (known) r = old;
+        // the result of the sweep before, if that sweep searched the position (the slot is the position's own)
+        const bool agr = q < ev_end && ((old ^ r) & kFsResMask) == 0;
+        if (act) ring[slot] = r;
+        FS_PF(1);
+        // ---- 2. hops: pointer doubling inside the group; a lane that is not searched (behind hi: the path ends there) points
+        //         at itself, with hop length 0 and no hops
+        uint32_t dbl[6];
+        {
+            const int adv = fs_adv(r);
+            uint32_t P = act ? (uint32_t)(self + adv) | ((uint32_t)adv << 12) | (1u << 21) : (uint32_t)self;
 #pragma unroll
             for (int j = 0; j < 6; j++) {
-                dbl[k][j] = P;
-                const int tgt = (int)(P & 0xFFFFu);
+                dbl[j] = P;
+                const int tgt = fs_pj(P);
                 const uint32_t f = (uint32_t)__builtin_amdgcn_ds_bpermute((tgt & 63) << 2, (int)P);
-                const uint32_t fl = f >> 16;
-                const uint32_t np = (f & 0xFFFFu) | ((fl ? fl : (P >> 16)) << 16);
+                const uint32_t np = (uint32_t)fs_pj(f) | ((uint32_t)(fs_pl(f) ? fs_pl(f) : fs_pl(P)) << 12) | ((uint32_t)(fs_pc(P) + fs_pc(f)) << 21);
                 P = (tgt >> 6) == grp ? np : P;
             }
             ex[self] = P;
         }
+        FS_PF(2);
         __syncthreads();  // -------- barrier 1: the exit table
-        uint64_t topsm[PPT];
-        int lin[PPT], entry[PPT];  // the hop that enters the group (0: none), the index it enters at (-1: the path does not)
-        bool term_before[PPT];
+        FS_PF(3);
+        if (wave == 0) {
+            // ---- 3. the path from w0 through the groups: a row of the table (the 64 exits of a group) per register, the hop from
+            //         group to group a v_readlane
+            uint32_t row[NG];
 #pragma unroll
-        for (int k = 0; k < PPT; k++) {
-            const int grp = wave + NW * k, gbase = 64 * grp, self = gbase + lane;
-            // ---- 3. the path from w0 up to this group
-            int cur = w0r, Lin = 0;
+            for (int g = 0; g < NG; g++) row[g] = ex[64 * g + lane];
+            int cur = w0r, Lin = 0, before = 0;
             bool term = false;
-            while (cur < gbase) {
-                const uint32_t p = ex[cur];
-                const int nj = (int)(p & 0xFFFFu);
-                if (nj == cur) {
-                    term = true;
-                    break;
-                }
-                Lin = (int)(p >> 16), cur = nj;
-            }
-            cur = __builtin_amdgcn_readfirstlane(cur), Lin = __builtin_amdgcn_readfirstlane(Lin);
-            const bool entered = !term && cur < gbase + 64 && gbase + 64 > w0r;
-            lin[k] = Lin, entry[k] = entered ? cur : -1, term_before[k] = term;
-            // the lanes on the path: from the entry, the doubling tables downwards
-            bool top = false;
-            if (entered) {
-                int at = cur;
+            uint32_t mine = 0, mine_b = 0;
 #pragma unroll
-                for (int j = 5; j >= 0; j--) {
-                    const int nx = (int)((uint32_t)__builtin_amdgcn_ds_bpermute((at & 63) << 2, (int)dbl[k][j]) & 0xFFFFu);
-                    at = ((nx >> 6) == grp && nx <= self) ? nx : at;
+            for (int g = 0; g < NG; g++) {
+                const bool entered = !term && (cur >> 6) == g;
+                const uint32_t pub = (entered ? (uint32_t)cur : 0xFFFu) | ((uint32_t)Lin << 12) | (term ? 1u << 21 : 0u);
+                if (lane == g) mine = pub, mine_b = (uint32_t)before;
+                if (entered) {
+                    const uint32_t p = (uint32_t)__builtin_amdgcn_readlane((int)row[g], cur & 63);
+                    const int nj = fs_pj(p);
+                    if (nj != cur) Lin = fs_pl(p);
+                    before += fs_pc(p);
+                    term = (nj >> 6) == g;  // an exit inside the group is a lane at which the path ends (it points at itself)
+                    cur = nj;
                 }
-                top = at == self && act[k];
             }
-            const uint64_t tm = __ballot(top);
-            topsm[k] = tm;
-            const uint64_t dis = tm & ~__ballot(agr[k]);
+            if (lane < NG) gent[lane] = mine, gbef[lane] = mine_b;
+        }
+        FS_PF(4);
+        __syncthreads();  // -------- barrier 2: where the path enters the groups
+        FS_PF(5);
+        // ---- 4. the lanes on the path: from the entry, the doubling tables downwards
+        const uint32_t ge = gent[grp];
+        const int entry = fs_pj(ge), lin = fs_pl(ge), before = (int)gbef[grp];
+        const bool term_before = (ge >> 21) != 0;
+        bool top = false;
+        if (entry != 0xFFF) {
+            int at = entry;
+#pragma unroll
+            for (int j = 5; j >= 0; j--) {
+                const int nx = fs_pj((uint32_t)__builtin_amdgcn_ds_bpermute((at & 63) << 2, (int)dbl[j]));
+                at = ((nx >> 6) == grp && nx <= self) ? nx : at;
+            }
+            top = at == self && act;
+        }
+        const uint64_t tm = __ballot(top);
+        {
+            const uint64_t dis = tm & ~__ballot(agr);
             if (lane == 0) {
-                cnt[grp] = (uint32_t)__builtin_popcountll(tm);
                 if (dis) atomicMin(&shv[0], (uint32_t)(gbase + (int)__builtin_ctzll(dis)));
                 if (tm) atomicMax(&shv[1], (uint32_t)(gbase + 63 - (int)__builtin_clzll(tm)));
             }
         }
-        __syncthreads();  // -------- barrier 2: the first loop-top with a new result, the last loop-top, the counts
+        FS_PF(6);
+        __syncthreads();  // -------- barrier 3: the first loop-top with a new result, the last loop-top
+        FS_PF(7);
         const int last_top = (int)shv[1];
         const int tstar = shv[0] != 0xFFFFFFFFu ? (int)shv[0] : last_top;
         const uint32_t r_star = ring[(g0 + tstar) & (RING - 1)], r_last = ring[(g0 + last_top) & (RING - 1)];
-        const int64_t w0_new = g0 + tstar + fs_adv(r_star);
+        const int w0_new = g0 + tstar + fs_adv(r_star);
         const int Xr = last_top + fs_adv(r_last);  // where the path leaves the searched part of the window
-#pragma unroll
-        for (int k = 0; k < PPT; k++) {
-            const int grp = wave + NW * k, gbase = 64 * grp, self = gbase + lane;
-            const uint64_t tm = topsm[k];
-            // ---- 4. the final loop-tops' symbols, in order; block cuts every kBlockSyms symbols (Deflate.cs:910-948)
-            if (gbase <= tstar && tm) {
-                int before = lane < grp ? (int)cnt[lane] : 0;  // (NG <= 64)
-                for (int o = 32; o >= 1; o >>= 1) before += __shfl_xor(before, o);
-                const uint64_t fin = tstar - gbase >= 63 ? tm : tm & ((2ull << (tstar - gbase)) - 1ull);
-                if ((fin >> lane) & 1ull) {
-                    const int64_t g = nsyms + before + __builtin_popcountll(fin & lanemask_lt());
-                    const uint32_t r = res[k];
-                    const bool match = fs_len(r) >= kMinMatch;
-                    syms[s.sym_off + g] = match ? (((uint32_t)fs_dist(r) << 16) | (uint32_t)(fs_len(r) - 3)) : (uint32_t)wb[gi + self];
-                    if ((g + 1) % kBlockSyms == 0) {
-                        blk_end[s.blk_off + g / kBlockSyms] = (int32_t)(g0 + self + (match ? fs_len(r) : 1));
-                        blk_top[s.blk_off + g / kBlockSyms] = (int32_t)(g0 + self);
-                    }
+        // ---- 5. the final loop-tops' symbols, in order; block cuts every kBlockSyms symbols (Deflate.cs:910-948)
+        if (gbase <= tstar && tm) {
+            const uint64_t fin = tstar - gbase >= 63 ? tm : tm & ((2ull << (tstar - gbase)) - 1ull);
+            if ((fin >> lane) & 1ull) {
+                const int g = nsyms + before + (int)__builtin_popcountll(fin & lanemask_lt());
+                const bool match = fs_len(r) >= kMinMatch;
+                out_syms[g] = match ? (((uint32_t)fs_dist(r) << 16) | (uint32_t)(fs_len(r) - 3)) : (uint32_t)wb[qi];
+                if (g == next_cut) {
+                    blk_end[s.blk_off + g / kBlockSyms] = q + (match ? fs_len(r) : 1);
+                    blk_top[s.blk_off + g / kBlockSyms] = q;
                 }
-                if (lane == 0 && tstar < gbase + 64) shv[2] = (uint32_t)(before + (int)__builtin_popcountll(fin));
             }
-            // ---- the next guess: the bits of this sweep's parse for the group's 64 positions
-            if (gbase + 64 > w0r) {
-                // the last loop-top at or below the lane, and what it inserts; no loop-top below the lane: the hop that enters
-                // the group covers it (short matches insert their inside, Deflate.Fast.cs:81-104)
-                const uint64_t below = tm & ((2ull << lane) - 1ull);
-                const int ti = below ? 63 - (int)__builtin_clzll(below) : 0;
-                const int span = __builtin_amdgcn_ds_bpermute(ti << 2, fs_inserted_span(res[k], lazy));
-                bool ins = below ? (lane - ti) < span : (lin[k] >= kMinMatch && lin[k] <= lazy);
-                if (self >= Xr || term_before[k]) ins = true;  // behind the path's end: not parsed yet
-                if (g0 + self == preins) ins = true;
-                uint64_t m = __ballot(ins);
-                const int wi = (gi + gbase) >> 5;
-                if (gbase < w0r) {  // the group of w0: what lies below it is final
-                    const uint64_t keep = (1ull << (w0r - gbase)) - 1ull;
-                    const uint64_t old = (uint64_t)bm[wi] | ((uint64_t)bm[wi + 1] << 32);
-                    m = (m & ~keep) | (old & keep);
-                }
-                if (lane < 2) bm[wi + lane] = (uint32_t)(m >> (32 * lane));
+            if (lane == 0 && tstar < gbase + 64) shv[2] = (uint32_t)(before + (int)__builtin_popcountll(fin));
+        }
+        // ---- the next guess: the bits of this sweep's parse for the group's 64 positions
+        {
+            // the last loop-top at or below the lane, and what it inserts; no loop-top below the lane: the hop that enters
+            // the group covers it (short matches insert their inside, Deflate.Fast.cs:81-104)
+            const uint64_t below = tm & ((2ull << lane) - 1ull);
+            const int ti = below ? 63 - (int)__builtin_clzll(below) : 0;
+            const int span = __builtin_amdgcn_ds_bpermute(ti << 2, fs_inserted_span(r, lazy));
+            bool ins = below ? (lane - ti) < span : (lin >= kMinMatch && lin <= lazy);
+            if (self >= Xr || term_before) ins = true;  // behind the path's end: not parsed yet
+            if (q == preins) ins = true;
+            uint64_t m = __ballot(ins);
+            const int wi = (gi + gbase) >> 5;
+            if (gbase < w0r) {  // the group of w0: what lies below it is final
+                const uint64_t keep = (1ull << (w0r - gbase)) - 1ull;
+                const uint64_t oldm = (uint64_t)bm[wi] | ((uint64_t)bm[wi + 1] << 32);
+                m = (m & ~keep) | (oldm & keep);
+            }
+            if (lane < 2) bm[wi + lane] = (uint32_t)(m >> (32 * lane));
+            if (self >= w0r) {  // ... and in the position's link entry, where the walkers look
+                const uint32_t v = wl[qi];
+                wl[qi] = (uint16_t)((v & 0x7FFFu) | (ins ? 0x8000u : 0u));
             }
         }
         // a last match that reaches out of the window: its positions' bits, "inserted" behind it
-        if (Xr > W && tid < 9) {
+        if (Xr > W) {
             const int span = fs_inserted_span(r_last, lazy);
-            uint32_t v = 0;
-            for (int b = 0; b < 32; b++) {
-                const int idx = W + 32 * tid + b;
-                v |= (uint32_t)((idx >= Xr || idx - last_top < span || g0 + idx == preins) ? 1 : 0) << b;
+            if (tid < 9) {
+                uint32_t v = 0;
+                for (int b = 0; b < 32; b++) {
+                    const int idx = W + 32 * tid + b;
+                    v |= (uint32_t)((idx >= Xr || idx - last_top < span || g0 + idx == preins) ? 1 : 0) << b;
+                }
+                bm[((gi + W) >> 5) + tid] = v;
             }
-            bm[((gi + W) >> 5) + tid] = v;
+            if (W + tid < Xr && gi + W + tid < fsLinks) {  // (tid < 258; behind the tile's links: the next staging takes the bits)
+                const int idx = W + tid;
+                const bool ins = idx - last_top < span || g0 + idx == preins;
+                const uint32_t v = wl[gi + idx];
+                wl[gi + idx] = (uint16_t)((v & 0x7FFFu) | (ins ? 0x8000u : 0u));
+            }
         }
-        __syncthreads();  // -------- barrier 3: the bits
-        nsyms += shv[2];
+        FS_PF(8);
+        __syncthreads();  // -------- barrier 4: the bits
+        nsyms += (int)shv[2];
+        if (nsyms > next_cut) next_cut += kBlockSyms;
         if (tid == 0) shv[0] = 0xFFFFFFFFu, shv[1] = 0;
-        // ---- 5. the links of what has become final, compressed (fs_compress); the next sweep's searches run beside this
-        const int64_t c_end = w0_new < lo + fsLinks ? w0_new : lo + fsLinks;  // (a last match may reach out of the tile: those links stay as they are)
-        for (int64_t c = w0 + tid; c < c_end; c += NT) {
-            const int ci = (int)(c - lo);
+        // ---- the links of what has become final, compressed (fs_compress); no barrier behind this: the next sweep's walkers
+        //      find the same candidates through either form of a link
+        const int c_hi = w0_new < lo + fsLinks ? w0_new : lo + fsLinks;  // (a last match may reach out of the tile: those links stay as they are)
+        for (int c = w0 + tid; c < c_hi; c += NT) {
+            const int ci = c - lo;
             int c1 = ci, out = 0;
+            const uint32_t own = wl[ci];
+            uint32_t l = own & 0x7FFFu;
             for (;;) {
-                const int l = wl[c1];
-                if (!l) break;
-                c1 -= l;
-                if (c1 < min_i || ci - c1 > kMaxDist) break;
-                if ((bm[c1 >> 5] >> (c1 & 31)) & 1u) {
+                c1 -= (int)l;
+                if (ci - c1 > kMaxDist) break;
+                const uint32_t v = wl[c1];
+                if (v >> 15) {
                     out = ci - c1;
                     break;
                 }
+                l = v & 0x7FFFu;
+                if (l == 1u) c1 = fs_run_skip(c1, bm, rb);
             }
-            wl[ci] = (uint16_t)out;
+            wl[ci] = (uint16_t)((out ? (uint32_t)out : kFsNoLink) | (own & 0x8000u));
             lk[c] = (uint16_t)out;
         }
         ev_end = hi;
         x_end = g0 + Xr;
         w0 = w0_new;
+        FS_PF(9);
+#ifdef ZS_FS_PROF
+        pf_sweeps++;
+#endif
     }
+#ifdef ZS_FS_PROF
+    if (tid == 0 && blockIdx.x == 0)
+        printf("FSPROF n=%d sweeps=%lld skip trips (wave 0)=%lld compare trips=%lld ticks(100MHz): stage=%lld search=%lld hops=%lld barrier1=%lld path=%lld barrier2=%lld tops=%lld barrier3=%lld final+bits=%lld barrier4=%lld\n",
+               n, pf_sweeps, pf_skips, pf_cmps, pf[0], pf[1], pf[2], pf[3], pf[4], pf[5], pf[6], pf[7], pf[8], pf[9]);
+#endif
     __syncthreads();
-    // ---- leave: the bits that became final go back to the stream's bitmap (the tail engine restores its chains from them)
+    // ---- leave: the bits that became final go back to the stream's bitmap (the tail engine restores its chains from them and
+    //      the links)
     if (t0 >= 0) {
-        const int64_t lo = t0 - kFsBack;
-        for (int64_t wd = (w0_staged >> 5) + tid; wd <= (w0 >> 5); wd += NT) {  // (x_end >= w0: the words of a tile left earlier are all there)
+        const int lo = t0 - kFsBack;
+        for (int wd = (w0_staged >> 5) + tid; wd <= (w0 >> 5); wd += NT) {  // (x_end >= w0: the words of a tile left earlier are all there)
             uint32_t v = bm[wd - (lo >> 5)];
             if (wd == (w0 >> 5)) {  // nothing at or above the hand-over loop-top but the pending pre-insert
                 v &= (1u << (w0 & 31)) - 1u;
@@ -366,11 +456,11 @@ __global__ __launch_bounds__(NT) void zs_fast_sweep_kernel(const StreamDesc *sd,
     }
     if (tid == 0) {
         StreamState &ss = st[blockIdx.x];
-        ss.tail_p = (int32_t)w0;
+        ss.tail_p = w0;
         ss.tail_kind = kR;
         ss.tail_pend = 0;
         ss.k_done = k_fired;
-        ss.preins = (int32_t)preins;
+        ss.preins = preins;
         ss.body_syms = (uint32_t)nsyms;
     }
 }
