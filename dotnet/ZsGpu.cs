@@ -61,6 +61,10 @@ namespace SixLabors.ZlibStream
         [DllImport(Lib)] public static extern int zs_deflate_batch_multi_device(IntPtr* ctxs, int nCtx, int n, IntPtr* input, long* inLen, IntPtr* output,
                                                                                 long* outCap, long* outLen, int* status, int* partOf, int level,
                                                                                 int strategy, int hashVariant);
+        [DllImport(Lib)] public static extern int zs_inflate_batch_multi_device(IntPtr* ctxs, int nCtx, int n, IntPtr* input, long* inLen, IntPtr* output,
+                                                                                long* outCap, long* outLen, int* status, int* partOf);
+        // bytes fed behind a stream's trailer before its end was seen (the engine looks for the end now and then)
+        [DllImport(Lib)] public static extern long zs_inflate_surplus(IntPtr s, IntPtr* p);
     }
 
     /// <summary>

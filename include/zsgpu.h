@@ -135,6 +135,10 @@ ZS_API int zs_deflate_batch_multi_device(zs_ctx *const *ctxs, int n_ctx, int n, 
                                          const int *part_of, int level, int strategy, int hash_variant);
 ZS_API int zs_inflate_batch_multi(zs_ctx *const *ctxs, int n_ctx, int n, const void *const *in, const int64_t *in_len,
                                   void *const *out, const int64_t *out_cap, int64_t *out_len, int *status);
+/* ... over device pointers, as zs_deflate_batch_multi_device: stream i and its output live on the GPU of ctxs[part_of[i]]
+ * (zs_partition over the decoded sizes gives a balanced part_of). */
+ZS_API int zs_inflate_batch_multi_device(zs_ctx *const *ctxs, int n_ctx, int n, const void *const *in, const int64_t *in_len,
+                                         void *const *out, const int64_t *out_cap, int64_t *out_len, int *status, const int *part_of);
 
 /* ------------------------------------------------------------------ */
 /* PNG scanline filtering on the device (the caller path of the sparse case -- the reference exists
@@ -197,13 +201,18 @@ ZS_API const char *zs_last_message(const zs_deflate_stream *s);
 /* zs_inflate_init <- Inflate..ctor (Inflate.cs:76-96); only window_bits 15 (zlib-wrapped) runs on the device: NULL otherwise.
  * zs_inflate      <- Inflate.Decompress (Inflate.cs:103-357) as ZLibStream.Inflate(FlushMode) calls it
  *   (ZlibStream.cs:119-122), driven by ZlibInputStream.ReadCore (ZlibInputStream.cs:133-186).  Same cursor convention as
- *   zs_deflate.  The engine decodes whole streams: calls that bring input return ZS_OK after taking it; the stream is decoded
- *   on the GPU at the call whose input completes it -- the end (final block + Adler-32 trailer, Inflate.cs:292-357) is
- *   looked for in what has been buffered each time the buffered bytes have doubled, from 512 KiB on -- or at the first
- *   call with *avail_in == 0 (BaseStream is exhausted); output is served from then on, ZS_STREAM_END with the last byte.
- *   total_in is the stream's length with its trailer; bytes behind the trailer that the decoding call brought are left to
- *   the caller (*avail_in), as the managed engine leaves them.  An incomplete stream at the call without input is
- *   ZS_BUF_ERROR; corrupt data gives ZS_DATA_ERROR with the reference's message (zs_inflate_message).
+ *   zs_deflate.  Calls that bring input return ZS_OK after taking it.  A whole stream is decoded by the block-parallel
+ *   decoder at the call whose input completes it -- the end (final block + Adler-32 trailer, Inflate.cs:292-357) is looked
+ *   for in what has been buffered each time the buffered bytes have doubled, from 512 KiB on.  A call with *avail_in == 0
+ *   (the reader has run out of input for now: ZlibInputStream.ReadCore behind a writer's flush) decodes what the bytes so
+ *   far hold in complete blocks -- a flush ends on a block boundary (Deflate.cs:583-613), so everything the writer flushed
+ *   is delivered -- and the stream goes on piece by piece from there with the next input; so does a stream that is fed 64
+ *   MiB without a call for output (bounded host memory for a stream of any length).  ZS_STREAM_END comes with the last
+ *   byte.  total_in is the stream's length with its trailer; bytes behind the trailer that the call which met the end
+ *   brought are left to the caller (*avail_in), as the managed engine leaves them; bytes behind it from earlier calls
+ *   (the end is only looked for now and then) are kept: zs_inflate_surplus.  A call without input that has nothing new to
+ *   give is ZS_BUF_ERROR (Inflate.Decompress's "no progress"); corrupt data gives ZS_DATA_ERROR with the reference's
+ *   message (zs_inflate_message).
  *   Malformed streams: incomplete code sets are accepted exactly where Huft_build accepts them (a single code of length
  *   1, InfTree.cs:364); one deliberate difference -- a match distance that reaches before the first output byte is
  *   ZS_DATA_ERROR "invalid distance code" here, the managed engine copies from its zeroed window instead
@@ -214,6 +223,9 @@ ZS_API int zs_inflate(zs_inflate_stream *s, const uint8_t *next_in, int32_t *ava
                       int flush, uint32_t *adler, int64_t *total_in, int64_t *total_out);
 ZS_API void zs_inflate_end(zs_inflate_stream *s);
 ZS_API const char *zs_inflate_message(const zs_inflate_stream *s);
+/* Bytes fed behind the stream's trailer by calls before the one that met the stream's end (no counterpart in the reference,
+ * whose engine stops at the trailer byte for byte): count, *p -> the bytes (owned by the stream object). */
+ZS_API int64_t zs_inflate_surplus(const zs_inflate_stream *s, const uint8_t **p);
 
 /* Adler32.Calculate (Adler32.cs:61-78) on the GPU, for a device-resident
  * buffer; result returned to the host. */

@@ -142,6 +142,45 @@ def test_batch_multi_two_contexts_matches_single_context_and_oracle(engine, orac
         e2.close()
 
 
+def test_batch_multi_over_device_pointers(engine, oracle):
+    """zs_deflate_batch_multi_device / zs_inflate_batch_multi_device: the N-GPU data path without PCIe in it -- every buffer
+    and its output already resident on the GPU of the context zs_partition gave it to.  On the one GPU of this box: two and
+    three contexts, against the single-context call and the oracle; a part_of outside the contexts and the same context
+    passed twice are refused (ZS_STREAM_ERROR) with nothing written."""
+    import torch
+    from zlibstream_amd import deflate_batch_multi_device, deflate_bound, inflate_batch_multi_device, shard
+    bufs = [datagen.batch_buffer(i, 256 << 10) for i in range(20)] + [b"x", oracle_binding.corpus("kennedy.xls"), datagen.english(3 << 20, 9)]
+    d_in = [torch.frombuffer(bytearray(b), dtype=torch.uint8).cuda() for b in bufs]
+    caps = [deflate_bound(len(b)) for b in bufs]
+    d_out = [torch.empty(c, dtype=torch.uint8, device="cuda") for c in caps]
+    want = engine.deflate_batch(bufs, level=6)
+    e2, e3 = Engine(0), Engine(0)
+    try:
+        for engines in ([engine, e2], [engine, e2, e3]):
+            part = shard.part_of([len(b) for b in bufs], len(engines))
+            assert set(part) == set(range(len(engines)))
+            lens = deflate_batch_multi_device(engines, [t.data_ptr() for t in d_in], [len(b) for b in bufs], [t.data_ptr() for t in d_out], caps, part)
+            torch.cuda.synchronize()
+            got = [d_out[i][:lens[i]].cpu().numpy().tobytes() for i in range(len(bufs))]
+            assert got == want
+            for i in (0, 1, 20, 21, 22):
+                assert got[i] == oracle.compress(bufs[i], 6)
+            # ... and back: the streams stay where they are, partitioned by the decoded sizes
+            d_z = [d_out[i][:lens[i]] for i in range(len(bufs))]
+            d_back = [torch.empty(max(len(b), 1), dtype=torch.uint8, device="cuda") for b in bufs]
+            blens = inflate_batch_multi_device(engines, [t.data_ptr() for t in d_z], lens, [t.data_ptr() for t in d_back], [len(b) for b in bufs], part)
+            torch.cuda.synchronize()
+            assert [d_back[i][:blens[i]].cpu().numpy().tobytes() for i in range(len(bufs))] == bufs
+        ptrs = ([t.data_ptr() for t in d_in], [len(b) for b in bufs], [t.data_ptr() for t in d_out], caps)
+        with pytest.raises(Exception):
+            deflate_batch_multi_device([engine, e2], *ptrs, [2] * len(bufs))     # a part outside the contexts
+        with pytest.raises(Exception):
+            deflate_batch_multi_device([engine, engine], *ptrs, [0] * len(bufs))  # one context twice
+    finally:
+        e2.close()
+        e3.close()
+
+
 def test_a_batch_larger_than_the_device_runs_in_sub_batches(engine, oracle):
     """A host batch whose staging and workspace (~19 bytes per input byte) exceed the device's memory -- 24 GiB of input: 300
     zero buffers and 84 text buffers of 64 MiB, the same two host buffers passed again and again -- is split into
@@ -298,21 +337,45 @@ def test_flush_makes_the_data_readable_before_finish(engine, oracle, level, flus
     """Deflate.cs:583-613: after a Write under Partial / Sync / Full flush the reader can decode everything written so far
     from the bytes delivered so far.  The stream's final bytes are the oracle's for the same Writes and mode."""
     import io
-    from zlibstream_amd import CompressionLevel, FlushMode, ZlibOptions, ZlibOutputStream
+    from zlibstream_amd import CompressionLevel, FlushMode, ZlibInputStream, ZlibOptions, ZlibOutputStream
     text = datagen.english(700000, 31)
     pieces = [text[:300000], text[300000:300007], text[300007:520000], text[520000:]]
-    out = io.BytesIO()
+
+    class Pipe(io.RawIOBase):  # what the writer has delivered so far, read by the reader as far as it goes
+        def __init__(self):
+            super().__init__()
+            self.data, self.rpos = bytearray(), 0
+
+        def write(self, b):
+            self.data += bytes(b)
+            return len(b)
+
+        def read(self, n=-1):
+            k = len(self.data) - self.rpos if n < 0 else min(n, len(self.data) - self.rpos)
+            r = bytes(self.data[self.rpos:self.rpos + k])
+            self.rpos += k
+            return r
+
+    out = Pipe()
     s = ZlibOutputStream(out, ZlibOptions(CompressionLevel=CompressionLevel(level), FlushMode=FlushMode(flush)), engine=engine)
+    # the repo's own reader on the other end (ZlibInputStream.ReadCore, ZlibInputStream.cs:133-186): behind every flushed
+    # Write it reads, without the writer's Finish, exactly what that Write brought (zs_inflate decodes the complete blocks
+    # of what has arrived at the call that comes without input; Inflate.cs:103-357)
+    r = ZlibInputStream(out, engine=engine)
     done = b""
     for p in pieces:
         s.write(p)
         done += p
         d = zlib.decompressobj()
-        assert d.decompress(out.getvalue()) == done, "the data written so far is not readable after the flush"
+        assert d.decompress(bytes(out.data)) == done, "the data written so far is not readable after the flush"
+        got = bytearray(len(p))
+        assert r.readinto(got) == len(p) and bytes(got) == p, "ZlibInputStream does not deliver what the flush made readable"
     s.close()
-    z = out.getvalue()
+    z = bytes(out.data)
     assert zlib.decompress(z) == text
     assert z == oracle.compress(text, level, 0, chunks=[len(p) for p in pieces], flush=flush)
+    assert r.read(100) == b"" and r.TotalOut == len(text)  # the trailer behind Finish: the stream's end, nothing more
+    r.close()
 
 
 def test_noflush_stream_that_outgrows_the_buffer_becomes_incremental(oracle):

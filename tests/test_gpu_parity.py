@@ -459,6 +459,31 @@ def test_cpp_host_mirror(tmp_path):
     assert r.returncode == 0 and "PASS" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+def test_fast_levels_single_stream_rate(engine, oracle):
+    """DeflateFast on ONE text stream (Deflate.Fast.cs:20-128; the reference does 54.8 / 36.9 MB/s at levels 1 / 3 on its
+    2018 laptop core, benchmarks.md:63,118): the window-wide sweeps of zs_fast_sweep_kernel hold 43-45 / 20 MB/s on 8 MiB of
+    text resident in HBM (round 3's one-wave form: 9.1 / 4.0).  The floors below leave a third of margin for a busy box; the
+    bytes of a 2 MiB prefix are the oracle's, and an 8 MiB text stream must not go through the speculative chunk runs first
+    (zs_fast_probe_kernel: they never verify on text)."""
+    import time
+    import torch
+    text = datagen.english(8 << 20, 77)
+    d_in = torch.frombuffer(bytearray(text), dtype=torch.uint8).cuda()
+    cap = deflate_bound(len(text))
+    d_out = torch.empty(cap, dtype=torch.uint8, device="cuda")
+    for lvl, floor in ((1, 30e6), (3, 14e6)):
+        assert engine.deflate_batch([text[:2 << 20]], level=lvl)[0] == oracle.compress(text[:2 << 20], lvl), lvl
+        engine.deflate_batch_device([d_in.data_ptr()], [len(text)], [d_out.data_ptr()], [cap], level=lvl)
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        m = engine.deflate_batch_device([d_in.data_ptr()], [len(text)], [d_out.data_ptr()], [cap], level=lvl)[0]
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t
+        assert zlib.decompress(d_out[:m].cpu().numpy().tobytes()) == text
+        assert len(text) / dt >= floor, "level %d: %.1f ms = %.1f MB/s" % (lvl, dt * 1e3, len(text) / dt / 1e6)
+
+
+@pytest.mark.gpu
 def test_fast_levels_large_streams_speculative_runs(engine, oracle):
     """Levels 1-3 on streams >= 1 MiB take the speculative chunk-run path (verified hand-over states, sequential
     fallback when a run does not verify): text, sparse rows, periodic data that resists re-synchronisation, zeros."""
@@ -856,6 +881,25 @@ def test_any_write_sizes_on_the_bulk_path(engine, oracle):
                 z, _ = _deflate_writes(engine, data, ends, level)
                 chunks = [ends[0]] + [ends[i] - ends[i - 1] for i in range(1, len(ends))]
                 assert z == oracle.compress(data, level, chunks=chunks), (name, spec, level)
+
+
+@pytest.mark.gpu
+def test_cut_rounds_with_more_slots_than_a_grid_dimension(engine, oracle):
+    """The batched cut rounds launch one workgroup row per cut slot (one slot per data end and per parse segment); a grid's
+    y dimension ends at 65 535.  24 MiB of zero pages and text in 300-byte Writes has ~84 000 data ends: with the rounds
+    forced from the first cut on (ZS_FORCE_ROUNDS) the cuts in the slots behind 65 535 have to be repaired like the others
+    (zs_cuts_repair_kernel takes the slots in turns) -- every byte against the oracle's WriteCore loop."""
+    n = 24 << 20
+    data = b"".join(datagen.english(8192, 900 + i) if i % 4 == 3 else bytes(8192) for i in range(n // 8192))
+    ends = _write_ends(len(data), 300, None)
+    assert len(ends) > 70000
+    os.environ["ZS_FORCE_ROUNDS"] = "1"
+    try:
+        z, _ = _deflate_writes(engine, data, ends, 6)
+    finally:
+        del os.environ["ZS_FORCE_ROUNDS"]
+    chunks = [ends[0]] + [ends[i] - ends[i - 1] for i in range(1, len(ends))]
+    assert z == oracle.compress(data, 6, chunks=chunks)
 
 
 @pytest.mark.gpu

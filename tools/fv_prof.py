@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Times one level-1 / level-3 text stream through the vectorised DeflateFast kernel; with a library built with
--DZS_FV_PROF (ZS_LIB=build/variants/fvprof.so) the kernel prints its own cycle split."""
+-DZS_FV_PROF (ZS_DEV=1 ZS_LIB=build/variants/fvprof.so) the kernel prints its own cycle split."""
 import os, sys, time, zlib
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

@@ -39,7 +39,7 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_fast512 -o run --
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_fast512 -o run -- python3 $R/tools/prof_cases.py fast512 1 > /dev/null 2> $O/pmc_write_fast512.err
 echo "round 3 cases done"
 python3 $R/tools/flush_resume_bench.py > $O/flush_resume.log 2> $O/flush_resume.err
-python3 $R/tools/patho.py > $O/patho.jsonl  # (text lines, level 6; profiles/r03_patho.jsonl is the table with level 9 beside it) 2> $O/patho.err
+python3 $R/tools/patho.py > $O/patho.jsonl 2> $O/patho.err  # (text lines, level 6; profiles/r03_patho.jsonl is the table with level 9 beside it)
 python3 $R/tools/fast_levels.py > $O/fast_levels.log 2> $O/fast_levels.err
 python3 $R/tools/multiwrite_check.py > $O/multiwrite_check.log 2> $O/multiwrite_check.err
 echo "tables done"

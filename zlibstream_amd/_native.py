@@ -4,16 +4,16 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# ZS_LIB: another build of the same library (the A/B tools under tools/ select a variant this way instead of overwriting
-# the product library); unset, the in-tree build is the one that loads
-LIB_PATH = os.environ.get("ZS_LIB") or os.path.join(_HERE, "libzsgpu.so")
+# ZS_DEV=1 ZS_LIB=<path>: another build of the same library (the A/B tools under tools/ select a variant this way instead of
+# overwriting the product library); without the explicit development flag the in-tree build is the one that loads
+LIB_PATH = (os.environ.get("ZS_LIB") if os.environ.get("ZS_DEV") == "1" else None) or os.path.join(_HERE, "libzsgpu.so")
 
 SYMBOLS = [
     "zs_ctx_create", "zs_ctx_destroy", "zs_ctx_last_error", "zs_deflate_bound", "zs_deflate_batch_device",
     "zs_deflate_batch", "zs_ctx_set_profiling", "zs_ctx_stage_count", "zs_ctx_stage_name", "zs_ctx_stage_ms",
     "zs_deflate_init", "zs_deflate", "zs_deflate_end", "zs_last_message", "zs_adler32_device",
-    "zs_inflate_batch_device", "zs_inflate_batch", "zs_inflate_init", "zs_inflate", "zs_inflate_end", "zs_inflate_message",
-    "zs_device_count", "zs_partition", "zs_deflate_batch_multi", "zs_inflate_batch_multi", "zs_png_filter_device", "zs_deflate_writes_device", "zs_deflate_batch_multi_device",
+    "zs_inflate_batch_device", "zs_inflate_batch", "zs_inflate_init", "zs_inflate", "zs_inflate_end", "zs_inflate_message", "zs_inflate_surplus",
+    "zs_device_count", "zs_partition", "zs_deflate_batch_multi", "zs_inflate_batch_multi", "zs_png_filter_device", "zs_deflate_writes_device", "zs_deflate_batch_multi_device", "zs_inflate_batch_multi_device",
 ]
 
 _lib = None
@@ -83,6 +83,8 @@ def lib():
     L.zs_inflate_end.argtypes = [vp]
     L.zs_inflate_message.restype = ctypes.c_char_p
     L.zs_inflate_message.argtypes = [vp]
+    L.zs_inflate_surplus.restype = i64
+    L.zs_inflate_surplus.argtypes = [vp, P(vp)]
     L.zs_adler32_device.restype = i32
     L.zs_adler32_device.argtypes = [vp, vp, i64, ctypes.c_uint32, P(ctypes.c_uint32), vp]
     L.zs_device_count.restype = i32
@@ -94,6 +96,8 @@ def lib():
         L.zs_deflate_batch_multi_device.argtypes = [P(vp), i32, i32, P(vp), P(i64), P(vp), P(i64), P(i64), P(i32), P(i32), i32, i32, i32]
     L.zs_deflate_batch_multi.restype = i32
     L.zs_deflate_batch_multi.argtypes = [P(vp), i32, i32, P(vp), P(i64), P(vp), P(i64), P(i64), P(i32), i32, i32, i32]
+    L.zs_inflate_batch_multi_device.restype = i32
+    L.zs_inflate_batch_multi_device.argtypes = [P(vp), i32, i32, P(vp), P(i64), P(vp), P(i64), P(i64), P(i32), P(i32)]
     L.zs_inflate_batch_multi.restype = i32
     L.zs_inflate_batch_multi.argtypes = [P(vp), i32, i32, P(vp), P(i64), P(vp), P(i64), P(i64), P(i32)]
     L.zs_png_filter_device.restype = i32

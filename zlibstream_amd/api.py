@@ -258,6 +258,37 @@ def inflate_batch_multi(engines, streams, out_sizes):
     return [outs[i].raw[:out_len[i]] for i in range(n)]
 
 
+def _multi_device_call(fn_name, engines, in_ptrs, in_lens, out_ptrs, out_caps, part_of, extra=()):
+    lib = _native.lib()
+    n = len(in_ptrs)
+    VP, I64, I32 = ctypes.c_void_p * max(n, 1), ctypes.c_int64 * max(n, 1), ctypes.c_int * max(n, 1)
+    out_len, status = I64(), I32()
+    ctxs = (ctypes.c_void_p * len(engines))(*[e.handle for e in engines])
+    rc = getattr(lib, fn_name)(ctxs, len(engines), n, VP(*[int(p) for p in in_ptrs]), I64(*[int(x) for x in in_lens]), VP(*[int(p) for p in out_ptrs]),
+                               I64(*[int(x) for x in out_caps]), out_len, status, I32(*[int(x) for x in part_of]), *extra)
+    return rc, list(out_len)[:n], list(status)[:n]
+
+
+def deflate_batch_multi_device(engines, in_ptrs, in_lens, out_ptrs, out_caps, part_of, level=6, strategy=0, hash_variant=0):
+    """Device-resident buffers sharded over several engines (zs_deflate_batch_multi_device): buffer i and its output live on
+    the GPU of engines[part_of[i]] (shard.partition / zs_partition gives a balanced part_of).  -> compressed lengths."""
+    rc, lens, _ = _multi_device_call("zs_deflate_batch_multi_device", engines, in_ptrs, in_lens, out_ptrs, out_caps, part_of,
+                                     (int(level), int(strategy), int(hash_variant)))
+    if rc != 0:
+        bad = [e.last_error() for e in engines if e.last_error()]
+        raise ZlibStreamException("deflating: " + (bad[0] if bad else "error %d" % rc))
+    return lens
+
+
+def inflate_batch_multi_device(engines, in_ptrs, in_lens, out_ptrs, out_caps, part_of):
+    """Device-resident zlib streams sharded over several engines (zs_inflate_batch_multi_device).  -> decoded lengths."""
+    rc, lens, _ = _multi_device_call("zs_inflate_batch_multi_device", engines, in_ptrs, in_lens, out_ptrs, out_caps, part_of)
+    if rc != 0:
+        bad = [e.last_error() for e in engines if e.last_error()]
+        raise ZlibStreamException("inflating: " + (bad[0] if bad else "error %d" % rc))
+    return lens
+
+
 def device_count():
     return int(_native.lib().zs_device_count())
 
@@ -289,8 +320,9 @@ class ZlibInputStream(io.RawIOBase):
     """ZlibInputStream.cs: a read-only stream that inflates `base_stream`.
 
     Same loop as ReadCore (ZlibInputStream.cs:133-186): 8 KiB chunks of BaseStream go to `Inflate(flush)` while the
-    caller's buffer has room and the state is ZOK.  The device engine (zs_inflate) takes the chunks in, decodes the
-    whole stream on the GPU when a call arrives without input, and serves the output from then on.
+    caller's buffer has room and the state is ZOK.  The device engine (zs_inflate) takes the chunks in; a whole stream
+    is decoded on the GPU at the call that completes it, and a call that arrives without input (BaseStream has nothing more
+    for now: a reader behind a writer's flush) decodes the complete blocks of what has arrived and serves them.
     """
 
     BUFFER_SIZE = 8192

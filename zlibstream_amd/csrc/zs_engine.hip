@@ -570,25 +570,25 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
             }
             c->cut_rounds++;
             if (iter > 0)  // (before the first round's repairs the records are the copy)
-            hipLaunchKernelGGL(zs_cut_restore_kernel, dim3(2048, (unsigned)n), dim3(256), 0, stream, d_sd, d_st, dev<uint2>(c->mm), (const uint2 *)c->mm_bak.p,
-                               dev<uint8_t>(c->stale), dev<uint8_t>(c->seg_stale), dev<uint16_t>(c->chunk_far), (const uint16_t *)((const uint8_t *)c->mm_bak.p + far_off));
+            hipLaunchKernelGGL(zs_cut_restore_kernel, dim3(2048, (unsigned)std::min(n, 65535)), dim3(256), 0, stream, d_sd, d_st, dev<uint2>(c->mm), (const uint2 *)c->mm_bak.p,
+                               dev<uint8_t>(c->stale), dev<uint8_t>(c->seg_stale), dev<uint16_t>(c->chunk_far), (const uint16_t *)((const uint8_t *)c->mm_bak.p + far_off), n);
             if (max_nc > 0) {
                 // few cuts: 128 workgroups each (every 128th position behind the cut); many: fewer, larger ones
                 if (max_nc <= 64)
-                    hipLaunchKernelGGL((zs_cuts_repair_kernel<256, 1>), dim3(128, (unsigned)max_nc, (unsigned)n), dim3(256), kRepairLds, stream, d_sd, d_st,
+                    hipLaunchKernelGGL((zs_cuts_repair_kernel<256, 1>), dim3(128, (unsigned)max_nc, (unsigned)std::min(n, 65535)), dim3(256), kRepairLds, stream, d_sd, d_st,
                                        dev<uint16_t>(c->link), dev<uint2>(c->mm), dev<uint8_t>(c->stale), dev<uint8_t>(c->seg_stale),
                                        dev<uint16_t>(c->chunk_far), c->crc_tab, lv, hash_variant, dev<int32_t>(c->cut_pos), dev<uint32_t>(c->cut_bkt),
-                                       cut_stride, iter);
+                                       cut_stride, iter, n);
                 else if (max_nc <= 2048)
-                    hipLaunchKernelGGL((zs_cuts_repair_kernel<256, 8>), dim3(16, (unsigned)max_nc, (unsigned)n), dim3(256), kRepairLds, stream, d_sd, d_st,
+                    hipLaunchKernelGGL((zs_cuts_repair_kernel<256, 8>), dim3(16, (unsigned)max_nc, (unsigned)std::min(n, 65535)), dim3(256), kRepairLds, stream, d_sd, d_st,
                                        dev<uint16_t>(c->link), dev<uint2>(c->mm), dev<uint8_t>(c->stale), dev<uint8_t>(c->seg_stale),
                                        dev<uint16_t>(c->chunk_far), c->crc_tab, lv, hash_variant, dev<int32_t>(c->cut_pos), dev<uint32_t>(c->cut_bkt),
-                                       cut_stride, iter);
+                                       cut_stride, iter, n);
                 else
-                    hipLaunchKernelGGL((zs_cuts_repair_kernel<1024, 32>), dim3(1, (unsigned)std::min(max_nc, 65535), (unsigned)n), dim3(1024), kRepairLds, stream, d_sd,
+                    hipLaunchKernelGGL((zs_cuts_repair_kernel<1024, 32>), dim3(1, (unsigned)std::min(max_nc, 65535), (unsigned)std::min(n, 65535)), dim3(1024), kRepairLds, stream, d_sd,
                                        d_st, dev<uint16_t>(c->link), dev<uint2>(c->mm), dev<uint8_t>(c->stale), dev<uint8_t>(c->seg_stale),
                                        dev<uint16_t>(c->chunk_far), c->crc_tab, lv, hash_variant, dev<int32_t>(c->cut_pos), dev<uint32_t>(c->cut_bkt),
-                                       cut_stride, iter);
+                                       cut_stride, iter, n);
             }
             hipLaunchKernelGGL(zs_chunkmap_kernel, dim3((unsigned)pl.w_chunks.size()), dim3(512), 0, stream, d_sd, d_work + o_chunks,
                                dev<uint2>(c->mm), dev<uint16_t>(c->link), dev<uint32_t>(c->maps), c->crc_tab, lv, strategy,
@@ -831,6 +831,18 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
     if (pl.n_runs) {
         // DeflateFast by speculative chunk runs; a run whose hand-over state does not verify sends the batch to the
         // sequential engine (the result is the reference's bytes either way)
+        if (!getenv("ZS_FAST_NO_PROBE")) {
+            // only data that looks periodic is worth the attempt (zs_fast_probe_kernel); anything else goes to the sweeps right away
+            hipLaunchKernelGGL(zs_fast_probe_kernel, dim3((unsigned)n), dim3(256), 0, stream, d_sd, dev<uint16_t>(c->link), dev<int32_t>(c->run_fail));
+            std::vector<int32_t> np((size_t)n, 0);
+            ZS_HIP(c, hipMemcpyAsync(np.data(), c->run_fail.p, 4 * (size_t)n, hipMemcpyDeviceToHost, stream));
+            ZS_HIP(c, hipStreamSynchronize(stream));
+            for (int i = 0; i < n; i++)
+                if (np[(size_t)i]) {
+                    ZS_HIP(c, hipStreamSynchronize(c->aux));  // (the forked passes read the workspace that is about to be reused)
+                    return run_pipeline(c, n, in, in_len, out, out_cap, out_len, status, level, strategy, hash_variant, stream, writes, true, ro, false, force_lit);
+                }
+        }
         ZS_HIP(c, hipMemsetAsync(c->run_fail.p, 0, 4 * (size_t)n + 64, stream));
         hipLaunchKernelGGL(zs_fast_run_kernel, dim3((unsigned)pl.n_runs), dim3(1024), kTailLds, stream, d_sd, d_work + o_runs,
                            dev<uint16_t>(c->link), dev<uint32_t>(c->run_syms), dev<uint32_t>(c->run_bits), dev<uint8_t>(c->run_scratch),
@@ -1366,6 +1378,26 @@ bool run_inflate_seq(zs_ctx *c, int n, const void *const *in, const int64_t *in_
     return all_ok;
 }
 
+// One piece of a stream that is decoded as it arrives (zs_inflate): the complete blocks in [start_bit, 8 in_len) of the
+// device buffer `in`, behind `hist_have` bytes of history (device), into `out`.  status: ZS_OK -- stopped in front of a
+// block that is not complete --, ZS_STREAM_END -- the trailer is behind it (its Adler-32 in *adler_stored; the caller
+// keeps the running checksum) --, or the stream's error; good_bits: the bit behind the last complete block.
+bool run_inflate_piece(zs_ctx *c, const void *in, int64_t in_len, bool first, int64_t start_bit, const void *hist, int hist_have, void *out, int64_t out_cap,
+                       int64_t *out_len, int64_t *good_bits, int64_t *in_used, int *status, uint32_t *adler_stored, hipStream_t stream) {
+    InfDesc d{(const uint8_t *)in, (uint8_t *)out, in_len, out_cap, (const uint8_t *)hist, first ? 0 : start_bit, hist_have, first ? 1 : 2};
+    if (!ensure(c, c->inf_desc, sizeof(InfDesc)) || !ensure(c, c->inf_state, sizeof(InfState))) return false;
+    InfState st;
+    ZS_HIP(c, hipMemcpyAsync(c->inf_desc.p, &d, sizeof d, hipMemcpyHostToDevice, stream));
+    ZS_HIP(c, hipStreamSynchronize(stream));
+    hipLaunchKernelGGL(zs_inflate_kernel, dim3(1), dim3(64), kInfLds, stream, dev<InfDesc>(c->inf_desc), dev<InfState>(c->inf_state));
+    ZS_HIP(c, hipGetLastError());
+    ZS_HIP(c, hipMemcpyAsync(&st, c->inf_state.p, sizeof st, hipMemcpyDeviceToHost, stream));
+    ZS_HIP(c, hipStreamSynchronize(stream));
+    *out_len = st.out_len, *good_bits = st.good_bits, *in_used = st.in_used, *status = st.status, *adler_stored = st.adler_stored;
+    if (st.status != ZS_OK && st.status != ZS_STREAM_END) c->err = kInfMessages[st.msg];
+    return true;
+}
+
 constexpr int64_t kParMinInput = 256 * 1024;  // shorter streams go straight to the one-wave decoder
 
 // Block-parallel path for the streams listed in `idx`; streams it cannot handle are appended to `rest`.
@@ -1805,6 +1837,17 @@ int zs_inflate_batch_multi(zs_ctx *const *ctxs, int n_ctx, int n, const void *co
     return run_multi(ctxs, n_ctx, n, in, in_len, out, out_cap, out_len, status, out_cap, nullptr,
                      [](zs_ctx *c, int m, const void *const *i, const int64_t *il, void *const *o, const int64_t *oc, int64_t *ol, int *st) {
                          return zs_inflate_batch(c, m, i, il, o, oc, ol, st);
+                     });
+}
+
+// ... and over device pointers: every stream and its output already resident on the GPU of the context `part_of` names (the
+// caller partitions with zs_partition -- by the decoded sizes -- and places them), so the data path of N GPUs has no PCIe in it
+int zs_inflate_batch_multi_device(zs_ctx *const *ctxs, int n_ctx, int n, const void *const *in, const int64_t *in_len, void *const *out,
+                                  const int64_t *out_cap, int64_t *out_len, int *status, const int *part_of) {
+    if (!part_of) return ZS_STREAM_ERROR;
+    return run_multi(ctxs, n_ctx, n, in, in_len, out, out_cap, out_len, status, out_cap, part_of,
+                     [](zs_ctx *c, int m, const void *const *i, const int64_t *il, void *const *o, const int64_t *oc, int64_t *ol, int *st) {
+                         return zs_inflate_batch_device(c, m, i, il, o, oc, ol, st, nullptr);
                      });
 }
 

@@ -26,6 +26,14 @@ struct InfDesc {
     const uint8_t *in;
     uint8_t *out;
     int64_t in_len, out_cap;
+    // A stream decoded piece by piece (zs_inflate, zs_stream_api.inc: Inflate.Decompress hands out what has arrived,
+    // Inflate.cs:103-357): partial != 0 -- decode the blocks that are complete in [start_bit, 8 in_len) and stop in front of the
+    // first that is not (no error: InfState::good_bits / out_len say where); partial == 2: no zlib header, a block
+    // begins at that bit (partial == 2: a piece behind the stream's first, also when that bit is 0); hist: the last
+    // hist_have <= 32 768 bytes the stream produced before this piece.
+    const uint8_t *hist;
+    int64_t start_bit;
+    int32_t hist_have, partial;
 };
 struct InfState {
     int64_t out_len, in_used;
@@ -33,6 +41,7 @@ struct InfState {
     int32_t status;  // CompressionState
     int32_t msg;     // InfMsg
     int32_t pad_;
+    int64_t good_bits;  // partial: the bit behind the last complete block (behind the trailer when the stream ended)
 };
 
 constexpr int kInfRing = 65536;
@@ -173,7 +182,16 @@ __global__ __launch_bounds__(64) void zs_inflate_kernel(const InfDesc *descs, In
     const InfDesc d = descs[blockIdx.x];
     InfState &st = states[blockIdx.x];
     InfBits b{d.in, d.in_len, 0, 0, 0, false, ibuf, -1};
-    int64_t pos = 0, flushed = 0;
+    // a piece of a stream: the history lies in the ring below the piece's first byte, which is ring (and output) position
+    // pos0 = 32 768 whatever there is of it (the flushes below go by 4-byte steps from there)
+    const int64_t pos0 = d.partial ? kWSize : 0, valid_from = pos0 - d.hist_have;
+    uint8_t *const outp = d.out - pos0;
+    int64_t pos = pos0, flushed = pos0;
+    int64_t good_bits = d.start_bit, good_out = pos0;
+    if (d.partial && d.hist_have > 0) {
+        for (int i = lane; i < d.hist_have; i += 64) ring[(valid_from + i) & (kInfRing - 1)] = d.hist[i];
+        __syncthreads();
+    }
     enum { ZS_OK_ = 0, ZS_END_ = 1, ZS_NEED_DICT_ = 2, ZS_DATA_ = -3, ZS_BUF_ = -5 };
     int status = ZS_OK_, msg = kInfOk;
 #define INF_FAIL(code, m) \
@@ -184,13 +202,18 @@ __global__ __launch_bounds__(64) void zs_inflate_kernel(const InfDesc *descs, In
     } while (0)
     auto flush_to = [&](int64_t upto) {  // ring -> HBM, coalesced
         for (int64_t o = flushed + lane * 4; o + 3 < upto; o += 256)
-            *(uint32_t *)(d.out + o) = *(const uint32_t *)(ring + (o & (kInfRing - 1)));  // flushed and ring offsets are multiples of 4 apart
+            *(uint32_t *)(outp + o) = *(const uint32_t *)(ring + (o & (kInfRing - 1)));  // flushed and ring offsets are multiples of 4 apart
         int64_t tail = flushed + ((upto - flushed) & ~3LL);
-        if (lane < (int)(upto - tail)) d.out[tail + lane] = ring[(tail + lane) & (kInfRing - 1)];
+        if (lane < (int)(upto - tail)) outp[tail + lane] = ring[(tail + lane) & (kInfRing - 1)];
         __syncthreads();
         flushed = upto;
     };
     // zlib header (Inflate.cs:120-170, 243)
+    if (d.partial == 2) {  // a piece behind the stream's first: no header, a block begins at start_bit
+        b.pos = d.start_bit >> 3;
+        b.fill();
+        b.drop((int)(d.start_bit & 7));
+    } else {
     b.fill();
     if (d.in_len < 2) INF_FAIL(ZS_BUF_, kInfTruncated);
     {
@@ -200,7 +223,9 @@ __global__ __launch_bounds__(64) void zs_inflate_kernel(const InfDesc *descs, In
         if (((cmf << 8) + flg) % 31 != 0) INF_FAIL(ZS_DATA_, kInfBadHeaderCheck);
         if (flg & 0x20) INF_FAIL(ZS_NEED_DICT_, kInfNeedDict);
     }
+    }
     for (int last = 0; !last;) {
+        good_bits = 8 * b.pos - b.cnt, good_out = pos;  // a block begins here: everything in front of it is complete
         b.fill();
         if (b.cnt < 3) INF_FAIL(ZS_BUF_, kInfTruncated);
         last = (int)b.take(1);
@@ -214,7 +239,7 @@ __global__ __launch_bounds__(64) void zs_inflate_kernel(const InfDesc *descs, In
             // give the bytes still in the bit buffer back to the byte cursor
             int64_t src = b.pos - (b.cnt >> 3);
             if (src + len > d.in_len) INF_FAIL(ZS_BUF_, kInfTruncated);
-            if (pos + len > d.out_cap) INF_FAIL(ZS_BUF_, kInfOutputFull);
+            if (pos - pos0 + len > d.out_cap) INF_FAIL(ZS_BUF_, kInfOutputFull);
             for (unsigned done = 0; done < len;) {
                 unsigned room = (unsigned)(flushed + kInfRing / 2 + kInfRing / 4 - pos);
                 unsigned n = len - done < room ? len - done : room;
@@ -325,7 +350,7 @@ __global__ __launch_bounds__(64) void zs_inflate_kernel(const InfDesc *descs, In
             }
             b.drop(clen);
             if (sym < 256) {
-                if (pos >= d.out_cap) INF_FAIL(ZS_BUF_, kInfOutputFull);
+                if (pos - pos0 >= d.out_cap) INF_FAIL(ZS_BUF_, kInfOutputFull);
                 if (lane == 0) ring[pos & (kInfRing - 1)] = (uint8_t)sym;
                 pos++;
             } else if (sym == 256) {
@@ -348,8 +373,8 @@ __global__ __launch_bounds__(64) void zs_inflate_kernel(const InfDesc *descs, In
                 b.drop(dl);
                 const int dist = base_dist(ds) + 1 + (int)b.take(extra_dbits(ds));
                 if (b.bad) INF_FAIL(ZS_BUF_, kInfTruncated);  // extra bits past the end of the input
-                if (dist > pos || dist > kWSize) INF_FAIL(ZS_DATA_, kInfBadDistCode);
-                if (pos + mlen > d.out_cap) INF_FAIL(ZS_BUF_, kInfOutputFull);
+                if (dist > pos - valid_from || dist > kWSize) INF_FAIL(ZS_DATA_, kInfBadDistCode);
+                if (pos - pos0 + mlen > d.out_cap) INF_FAIL(ZS_BUF_, kInfOutputFull);
                 // one wave: DS operations execute in program order, so lane 0's literal stores are
                 // visible to every lane here without a barrier
                 for (int i = lane; i < mlen; i += 64) {
@@ -374,14 +399,18 @@ __global__ __launch_bounds__(64) void zs_inflate_kernel(const InfDesc *descs, In
     }
     status = b.bad ? (int)ZS_BUF_ : (int)ZS_END_;
     if (b.bad) msg = kInfTruncated;
+    else good_bits = 8 * b.pos - b.cnt, good_out = pos;
 done:
     __syncthreads();
+    // a piece whose input ends inside a block (or inside the trailer): not an error, the piece ends in front of that block
+    if (d.partial && status == ZS_BUF_ && msg != kInfOutputFull) status = ZS_OK_, msg = kInfOk;
     if (pos > flushed) {
         if (pos - flushed > kInfRing / 2) flush_to(flushed + kInfRing / 2);
         flush_to(pos);
     }
     if (lane == 0) {
-        st.out_len = pos;
+        st.out_len = d.partial ? good_out - pos0 : pos;
+        st.good_bits = good_bits;
         st.in_used = b.pos - (b.cnt >> 3);
         st.status = status;
         st.msg = msg;

@@ -1772,19 +1772,21 @@ constexpr int kRepairLds = ((kMaxDist + 16 + 273 + 15) & ~15) + 2 * (kMaxDist + 
 // ... and gets back the largest match distance its chunk had then (chunk_far, which the repairs' scans go by: the map pass of the
 // round before has lowered it to what that round's repairs left).
 __global__ __launch_bounds__(256) void zs_cut_restore_kernel(const StreamDesc *sd, const StreamState *st, uint2 *mm, const uint2 *bak, uint8_t *stale,
-                                                             uint8_t *seg_stale, uint16_t *chunk_far, const uint16_t *far_bak) {
-    const StreamDesc s = sd[blockIdx.y];
-    const StreamState &ss = st[blockIdx.y];
-    if (ss.deferred != 1 || ss.cuts_same) return;
-    const int64_t from = (int64_t)ss.cut_diff_pos + 1, to = s.body_end;
-    for (int64_t p = from + (int64_t)blockIdx.x * 256 + threadIdx.x; p <= to; p += (int64_t)gridDim.x * 256) {
-        const uint2 want = bak[s.pos_off + p], have = mm[s.pos_off + p];
-        if (want.x == have.x && want.y == have.y) continue;
-        mm[s.pos_off + p] = want;
-        const int cp = chunk_of(s, p);
-        stale[s.chunk_off + cp] = 1, seg_stale[s.seg_off + seg_of(s, cp)] = 1;
-        chunk_far[s.chunk_off + cp] = far_bak[s.chunk_off + cp];
-        if (p + 1 == (int64_t)s.cstart[cp + 1] && cp + 1 < s.nchunks) stale[s.chunk_off + cp + 1] = 1, seg_stale[s.seg_off + seg_of(s, cp + 1)] = 1;
+                                                             uint8_t *seg_stale, uint16_t *chunk_far, const uint16_t *far_bak, int n_streams) {
+    for (int si = (int)blockIdx.y; si < n_streams; si += (int)gridDim.y) {  // (a grid's y and z end at 65 535: more streams than that take turns)
+        const StreamDesc s = sd[si];
+        const StreamState &ss = st[si];
+        if (ss.deferred != 1 || ss.cuts_same) continue;
+        const int64_t from = (int64_t)ss.cut_diff_pos + 1, to = s.body_end;
+        for (int64_t p = from + (int64_t)blockIdx.x * 256 + threadIdx.x; p <= to; p += (int64_t)gridDim.x * 256) {
+            const uint2 want = bak[s.pos_off + p], have = mm[s.pos_off + p];
+            if (want.x == have.x && want.y == have.y) continue;
+            mm[s.pos_off + p] = want;
+            const int cp = chunk_of(s, p);
+            stale[s.chunk_off + cp] = 1, seg_stale[s.seg_off + seg_of(s, cp)] = 1;
+            chunk_far[s.chunk_off + cp] = far_bak[s.chunk_off + cp];
+            if (p + 1 == (int64_t)s.cstart[cp + 1] && cp + 1 < s.nchunks) stale[s.chunk_off + cp + 1] = 1, seg_stale[s.seg_off + seg_of(s, cp + 1)] = 1;
+        }
     }
 }
 // One pass's cuts applied over the chip: workgroup (part, cut, stream) takes every nparts-th position behind its cut
@@ -1793,27 +1795,35 @@ __global__ __launch_bounds__(256) void zs_cut_restore_kernel(const StreamDesc *s
 template <int NT, int U>
 __global__ __launch_bounds__(NT) void zs_cuts_repair_kernel(const StreamDesc *sd, const StreamState *st, uint16_t *link, uint2 *mm, uint8_t *stale,
                                                              uint8_t *seg_stale, const uint16_t *chunk_far, const uint32_t *crc_tab_g, LevelCfg lv,
-                                                             int hash_variant, const int32_t *cut_pos, const uint32_t *cut_bkt, int cut_stride, int cut_iter) {
+                                                             int hash_variant, const int32_t *cut_pos, const uint32_t *cut_bkt, int cut_stride, int cut_iter,
+                                                             int n_streams) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     __shared__ uint32_t tab[1024];
     __shared__ int sh_to;
-    const StreamDesc s = sd[blockIdx.z];
-    const StreamState &ss = st[blockIdx.z];
-    if (ss.deferred != 1 || ss.cuts_same) return;
-    const int cur = cut_iter & 1, nc = ss.nc[cur], j = (int)blockIdx.y;
-    if (j >= nc) return;
-    const int32_t *cl = cut_pos + (size_t)cur * (size_t)cut_stride + s.cut_off;
-    const uint32_t *cb = cut_bkt + (size_t)cur * (size_t)cut_stride + s.cut_off;
-    const int64_t e = cl[j], dp = ss.cut_diff_pos;
-    if (e < 0) return;  // no cut in this slot
-    int64_t full = e + kMaxDist;
-    if (full > s.body_end) full = s.body_end;
-    const int64_t from = e > dp ? e : dp;  // the records up to the first changed cut were not restored
-    if (from >= full) return;
     load_crc_tab(tab, crc_tab_g);
     __syncthreads();
-    RepairArgs ra{&s, mm + s.pos_off, link + s.pos_off, tab, smem, stale, seg_stale, chunk_far, s.nchunks, lv, hash_variant, cl, cb, j, nc};
-    repair_cut<NT, U>(ra, e, from, full, false, &sh_to, nullptr, nullptr, nullptr, (int)blockIdx.x, (int)gridDim.x);
+    // A grid's y and z end at 65 535, and the slots of a stream are one per data end plus one per parse segment -- a GiB in one
+    // Write, or 64 MiB in 1000-byte Writes, has more: the workgroups take the slots (and the streams) in turns.
+    for (int si = (int)blockIdx.z; si < n_streams; si += (int)gridDim.z) {
+        const StreamDesc s = sd[si];
+        const StreamState &ss = st[si];
+        if (ss.deferred != 1 || ss.cuts_same) continue;
+        const int cur = cut_iter & 1, nc = ss.nc[cur];
+        const int32_t *cl = cut_pos + (size_t)cur * (size_t)cut_stride + s.cut_off;
+        const uint32_t *cb = cut_bkt + (size_t)cur * (size_t)cut_stride + s.cut_off;
+        const int64_t dp = ss.cut_diff_pos;
+        for (int j = (int)blockIdx.y; j < nc; j += (int)gridDim.y) {
+            const int64_t e = cl[j];
+            if (e < 0) continue;  // no cut in this slot
+            int64_t full = e + kMaxDist;
+            if (full > s.body_end) full = s.body_end;
+            const int64_t from = e > dp ? e : dp;  // the records up to the first changed cut were not restored
+            if (from >= full) continue;
+            RepairArgs ra{&s, mm + s.pos_off, link + s.pos_off, tab, smem, stale, seg_stale, chunk_far, s.nchunks, lv, hash_variant, cl, cb, j, nc};
+            repair_cut<NT, U>(ra, e, from, full, false, &sh_to, nullptr, nullptr, nullptr, (int)blockIdx.x, (int)gridDim.x);
+            __syncthreads();  // (the window in LDS and sh_to are the next slot's)
+        }
+    }
 }
 // The rounds are over for a stream whose last pass found the cuts of the pass before: the cuts go into the links (the tail
 // engine restores prev[] from them, zs_lit_engine.h le_restore_prev) and the stream goes on down the pipeline.
@@ -2500,6 +2510,32 @@ __global__ __launch_bounds__(1024) void zs_fast_run_kernel(const StreamDesc *sd,
         o.ok = 1, o.n_ev = e.n_ev;
         if (j == 0) o.mark_pos = 0, o.mark_nsyms = 0;
     }
+}
+
+// Is a stream worth the speculative runs?  They verify on data whose parse falls back into step whatever came before it --
+// periodic data: image rows, runs, tables -- and never on text, where the attempt costs as much as the sweeps that then do
+// the work (8 MiB of text: 140 ms thrown away in front of 190).  On periodic data the previous position of a bucket lies at
+// one and the same distance for position after position: the share of positions whose link equals their neighbour's is 0.97
+// for image rows, 0.80 for ptt5, 0.61 for kennedy.xls, 0.2-0.33 for text.  64 windows of 256 positions are looked at.
+__global__ __launch_bounds__(256) void zs_fast_probe_kernel(const StreamDesc *sd, const uint16_t *link, int32_t *not_periodic) {
+    __shared__ int same;
+    const StreamDesc s = sd[blockIdx.x];
+    if (s.fast_runs <= 0) {
+        if (threadIdx.x == 0) not_periodic[blockIdx.x] = 0;
+        return;
+    }
+    if (threadIdx.x == 0) same = 0;
+    __syncthreads();
+    const uint16_t *lk = link + s.pos_off;
+    const int64_t span = (int64_t)s.n - 8 - kWSize;
+    int mine = 0;
+    for (int w = 0; w < 64; w++) {
+        const int64_t p = kWSize + span * w / 64 + threadIdx.x;
+        if (p + 8 < s.n) mine += lk[p] != 0 && lk[p] == lk[p - 1];
+    }
+    atomicAdd(&same, mine);
+    __syncthreads();
+    if (threadIdx.x == 0) not_periodic[blockIdx.x] = same * 4 < 64 * 256 * 3;
 }
 
 // run j (j >= 1) is exact iff it entered its chunk where run j-1 stopped, with the same strings inserted in the

@@ -12,14 +12,19 @@ import ctypes
 from . import _native
 
 
-def partition(sizes, world):
-    """-> list of `world` sorted index lists."""
+def part_of(sizes, world):
+    """-> for every buffer the part (GPU) that takes it: the `part_of` argument of the *_multi_device calls."""
     n = len(sizes)
     part = (ctypes.c_int * max(n, 1))()
     rc = _native.lib().zs_partition((ctypes.c_int64 * max(n, 1))(*[int(x) for x in sizes]), n, int(world), part)
     if rc != 0:
         raise ValueError("zs_partition(%d sizes, %d parts) failed" % (n, world))
+    return [int(part[i]) for i in range(n)]
+
+
+def partition(sizes, world):
+    """-> list of `world` sorted index lists."""
     parts = [[] for _ in range(world)]
-    for i in range(n):
-        parts[part[i]].append(i)
+    for i, k in enumerate(part_of(sizes, world)):
+        parts[k].append(i)
     return parts
