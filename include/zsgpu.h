@@ -203,7 +203,7 @@ ZS_API const char *zs_last_message(const zs_deflate_stream *s);
  *   (ZlibStream.cs:119-122), driven by ZlibInputStream.ReadCore (ZlibInputStream.cs:133-186).  Same cursor convention as
  *   zs_deflate.  Calls that bring input return ZS_OK after taking it.  A whole stream is decoded by the block-parallel
  *   decoder at the call whose input completes it -- the end (final block + Adler-32 trailer, Inflate.cs:292-357) is looked
- *   for in what has been buffered each time the buffered bytes have doubled, from 512 KiB on.  A call with *avail_in == 0
+ *   for in what has been buffered each time the buffered bytes have quadrupled, from 1 MiB on.  A call with *avail_in == 0
  *   (the reader has run out of input for now: ZlibInputStream.ReadCore behind a writer's flush) decodes what the bytes so
  *   far hold in complete blocks -- a flush ends on a block boundary (Deflate.cs:583-613), so everything the writer flushed
  *   is delivered -- and the stream goes on piece by piece from there with the next input; so does a stream that is fed 64
