@@ -22,6 +22,7 @@
 #include "../../zlibstream_amd/csrc/zs_lit_engine.h"
 #include "../../zlibstream_amd/csrc/zs_fast_vec.h"
 #include "../../zlibstream_amd/csrc/zs_fast_sweep.h"
+#include "../../zlibstream_amd/csrc/zs_rle.h"
 
 using namespace zs;
 
@@ -417,6 +418,42 @@ static void parse_fast_sweep(Model &m, int64_t &p_out, int &kdone_out, int64_t &
     p_out = st.w0;
     kdone_out = st.k_fired;
     preins_out = st.preins;
+}
+
+
+// ---- CompressionStrategy.Rle without a sequential parse (zs_rle.h): every position's part in the parse from the first position
+//      of its run; the loop-tops below the hand-over position in order, blocks cut every kBlockSyms symbols, then the tail engine
+static void parse_rle_runs(Model &m, int64_t &p_out, int &kdone_out) {
+    const int64_t H = rle_body_end(m.n);
+    p_out = 0, kdone_out = 0;
+    if (H < 0) return;
+    const int kl = (int)m.rev.size() - 1;
+    auto byte = [&](int64_t q) { return m.data[q]; };
+    int64_t a = 0, block_start = 0, ph = -1;
+    for (int64_t p = 0; p < m.n; p++) {
+        if (p > 0 && m.data[p] != m.data[p - 1]) a = p;
+        const int role = rle_role(byte, p, a);
+        if (!role) continue;
+        if (p >= H) {
+            ph = p;
+            break;
+        }
+        m.syms.push_back(role == 1 ? (uint32_t)m.data[p] : ((1u << 16) | (uint32_t)(role - 3)));
+        if (m.syms.size() % kBlockSyms == 0) {
+            const int64_t end = p + (role == 1 ? 1 : role);
+            BlockRec b;
+            b.start = block_start;
+            b.sym_start = (int64_t)m.syms.size() - kBlockSyms;
+            b.stored_len = (int32_t)(end - block_start);
+            b.nsyms = kBlockSyms;
+            b.can_store = block_start >= (int64_t)kWSize * rle_refills_fired_at(p, kl);
+            b.eof = 0;
+            m.blocks.push_back(b);
+            block_start = end;
+        }
+    }
+    p_out = ph;
+    kdone_out = rle_refills_fired_at(H, kl);
 }
 
 // ---- stage B: the chunked form the GPU runs ----
@@ -1161,7 +1198,13 @@ int main(int argc, char **argv) {
     uint32_t pend;
     int64_t preins;
     if (mode == "bulk" || mode == "chunk") m.match_all();
-    if (mode == "fvec" || mode == "fsweep") {
+    if (mode == "rle") {
+        // CompressionStrategy.Rle, one Write: the runs' closed form up to the hand-over loop-top, then the literal engine
+        kind = kR, pend = 0, p = 0, k_done = 0, preins = -1;
+        m.body_end = -1;
+        if (strategy == kRle && level >= 1 && wends.size() <= 1 && flush_mode == 0 && !m.rev.empty()) parse_rle_runs(m, p, k_done);
+        if (p > 0) m.body_end = p;  // (run_tail sizes its arrays by this)
+    } else if (mode == "fvec" || mode == "fsweep") {
         // DeflateFast, single Write: the vector form up to the last loop-top with a full lookahead, then the literal engine
         m.body_end = (m.lv.func == 1 && strategy != kRle && wends.size() <= 1 && flush_mode == 0 && n >= kMinLookahead) ? n - kMinLookahead : -1;
         kind = kR, pend = 0, p = 0, k_done = 0, preins = -1;

@@ -459,6 +459,51 @@ def test_cpp_host_mirror(tmp_path):
     assert r.returncode == 0 and "PASS" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+def test_rle_strategy_over_the_chip(engine, oracle):
+    """CompressionStrategy.Rle (Deflate.Rle.cs:18-104) off the literal engine: a match never leaves the run of equal bytes it
+    lies in, so a position's part in the parse follows from where its run began (zs_rle.h; kernels zs_rle.hip: a prefix maximum
+    over the run starts, two passes over the positions).  Bytes against the oracle at levels 1 / 6 / 9 on text (runs of one),
+    image rows, a bitmap, long and short runs, zeros, sizes around the window ends and the refill threshold (258 here, not
+    262); streams of several Writes stay with the literal engine (same bytes); 64 MiB of image rows and of text at 5 GB/s
+    and more (the literal engine: 0.5-2 MB/s)."""
+    import time
+    import torch
+    rng = np.random.default_rng(17)
+    cases = {
+        "alice": oracle_binding.corpus("alice29.txt"), "ptt5": oracle_binding.corpus("ptt5"), "kennedy": oracle_binding.corpus("kennedy.xls"),
+        "sparse": datagen.sparse(512, 300), "zeros": bytes(300000),
+        "long runs": np.repeat(rng.integers(0, 4, 40000, dtype=np.uint8), rng.integers(1, 700, 40000))[:2000000].tobytes(),
+        "short runs": np.repeat(rng.integers(0, 3, 400000, dtype=np.uint8), rng.integers(1, 6, 400000))[:700001].tobytes(),
+    }
+    for n in (4096 + 786, 5000, 65536, 65536 + 258, 65536 + 32768 - 258 + 600, 98304 + 600, 131072 + 522, 131072 + 786 + 258):
+        cases["zeros %d" % n] = bytes(n)
+        cases["runs %d" % n] = np.repeat(rng.integers(0, 3, n, dtype=np.uint8), rng.integers(1, 400, n))[:n].tobytes()
+    for name, d in cases.items():
+        for lvl in (1, 6, 9):
+            assert engine.deflate_batch([d], level=lvl, strategy=3)[0] == oracle.compress(d, lvl, 3), (name, lvl)
+    # a batch of them, and one written in several Writes (the literal engine)
+    bufs = [cases[k] for k in ("alice", "sparse", "zeros", "short runs", "runs 5000")]
+    assert engine.deflate_batch(bufs, level=6, strategy=3) == [oracle.compress(b, 6, 3) for b in bufs]
+    d = cases["long runs"][:300000]
+    ends = _write_ends(len(d), 70000, None)
+    z, _ = _deflate_writes(engine, d, ends, 6, strategy=3)
+    assert z == oracle.compress(d, 6, 3, chunks=[ends[0]] + [ends[i] - ends[i - 1] for i in range(1, len(ends))])
+    for name, data in (("sparse64", datagen.sparse(4096, 4096)), ("english64", datagen.english(64 << 20, datagen.GOLDEN))):
+        d_in = torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda()
+        cap = deflate_bound(len(data))
+        d_out = torch.empty(cap, dtype=torch.uint8, device="cuda")
+        engine.deflate_batch_device([d_in.data_ptr()], [len(data)], [d_out.data_ptr()], [cap], level=6, strategy=3)
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        m = engine.deflate_batch_device([d_in.data_ptr()], [len(data)], [d_out.data_ptr()], [cap], level=6, strategy=3)[0]
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t
+        z = d_out[:m].cpu().numpy().tobytes()
+        assert zlib.decompress(z) == data
+        assert z[:1 << 20] == oracle.compress(data[:8 << 20], 6, 3)[:1 << 20], name   # (the stream's first MiB: the same blocks)
+        assert len(data) / dt >= 5e9, "%s under Rle: %.1f ms = %.2f GB/s" % (name, dt * 1e3, len(data) / dt / 1e9)
+
+
 def test_fast_levels_single_stream_rate(engine, oracle):
     """DeflateFast on ONE text stream (Deflate.Fast.cs:20-128; the reference does 54.8 / 36.9 MB/s at levels 1 / 3 on its
     2018 laptop core, benchmarks.md:63,118): the window-wide sweeps of zs_fast_sweep_kernel hold 43-45 / 20 MB/s on 8 MiB of
@@ -845,7 +890,7 @@ def _write_ends(n, spec, rng):
     return ends
 
 
-def _deflate_writes(engine, data, ends, level):
+def _deflate_writes(engine, data, ends, level, strategy=0):
     import ctypes
     import time
     import torch
@@ -856,7 +901,7 @@ def _deflate_writes(engine, data, ends, level):
     arr = (ctypes.c_int64 * len(ends))(*ends)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    olen = engine.deflate_writes_device(d_in.data_ptr(), n, arr, d_out.data_ptr(), cap, level=level)
+    olen = engine.deflate_writes_device(d_in.data_ptr(), n, arr, d_out.data_ptr(), cap, level=level, strategy=strategy)
     dt = time.perf_counter() - t0
     return d_out[:olen].cpu().numpy().tobytes(), dt
 

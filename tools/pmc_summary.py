@@ -98,7 +98,7 @@ if tab:
               open(os.path.join(dst, "%s_pmc_insts_english64_L6.json" % tag), "w"), indent=1)
 
 # round 3: kernel statistics of the paths beside the headline, the counters of the DeflateFast kernel in a batch
-for w in ("fast512", "writes1000", "scanlines", "flushed64k"):
+for w in ("fast512", "fast1_L1", "fast1_L3", "writes1000", "scanlines", "flushed64k"):
     stw = glob.glob(os.path.join(src, "stats_" + w, "**", "*kernel_stats.csv"), recursive=True)
     if stw:
         rows = list(csv.reader(open(stw[0])))
@@ -127,6 +127,18 @@ if tabf:
     json.dump({"note": "rocprofv3 --pmc (separate passes) over `tools/prof_cases.py fast512 1`: DeflateFast, level 1, 512 x 512 KiB text "
                        "streams in one batch (256 MiB); mean per launch.", "kernels": tabf},
               open(os.path.join(dst, "%s_pmc_fast512_L1.json" % tag), "w"), indent=1)
+tab1 = {}
+for cn in names:
+    for k, v in counter_any("pmc_insts_fast1_L1", cn, "zs_fast").items():
+        tab1.setdefault(k, {})[cn] = int(v)
+if tab1:
+    for k, v in tab1.items():
+        if "SQ_INSTS_VALU" in v:
+            v["valu_issue_ms_on_the_4_simds_of_one_cu_2.4GHz"] = round(v["SQ_INSTS_VALU"] * 4 / 4 / 2.4e9 * 1e3, 3)
+    json.dump({"note": "rocprofv3 --pmc over `tools/prof_cases.py fast1_L1 1`: DeflateFast, level 1, ONE 8 MiB text stream -- one "
+                       "workgroup of zs_fast_sweep_kernel on one CU; mean per launch.  A wave64 vector instruction holds its SIMD for 4 "
+                       "cycles: the issue time is what the kernel's vector instructions alone take on that CU's four SIMDs.", "kernels": tab1},
+              open(os.path.join(dst, "%s_pmc_fast1_L1.json" % tag), "w"), indent=1)
 for name, out in (("flush_resume.log", "flush_resume.log"), ("patho.jsonl", "patho_final_build_L6.log"), ("fast_levels.log", "fast_levels.log"),
                   ("multiwrite_check.log", "multiwrite_check.log")):
     pth = os.path.join(src, name)

@@ -6,6 +6,7 @@
 #include "zs_lit_engine.h"
 #include "zs_fast_vec.h"
 #include "zs_fast_sweep.h"
+#include "zs_rle.h"
 
 namespace zs {
 
@@ -96,6 +97,9 @@ struct StreamDesc {
     // entries begin in the two cut lists, and how many there is room for (one per read boundary)
     int32_t cut_off, cut_cap;
     int64_t fv_list_off;  // where the stream's candidate lists begin in the batch's list area (zs_fast_vec_kernel), in words
+    // CompressionStrategy.Rle over the chip (zs_rle.h, zs_rle.hip): the loop-tops below rle_end are the body's, the tail engine
+    // goes on from the first one at or behind it (-1: not this stream); the stream's first tile in the batch's tile arrays
+    int32_t rle_end, rle_tile_off;
 };
 
 // zs_fast_vec_kernel's tile: the window [t0 - kFvBack, t0 + kFvTile + kFvFwd) in LDS as bytes, links and inserted bits

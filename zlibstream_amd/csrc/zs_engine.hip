@@ -56,7 +56,7 @@ struct zs_ctx {
     uint32_t *crc_tab = nullptr;
     DevBuf sd, st, work, wpre, geo, link, mm, maps, chunk_far, segmap, supmap, seg_entry, seg_symbase, seg_stale, entry, symbase, stale, syms, blk_end, blk_top, blocks, trees, info, pieces, scratch,
         stage_in, stage_out, wr, inf_desc, inf_state, par_ps, par_st, par_work, par_cbits, par_ccnt, par_surv, par_scnt, par_cands, par_tabs, par_blocks, par_cells,
-        par_windows, par_fail, run_syms, run_bits, run_scratch, run_outs, run_fail, adl_tr, adl_res, plan_blk, ins_bits, fv_lists, mm_bak, cut_pos, cut_bkt, win_groups, win_sg, win_maps, win_entries, persist_bak, resume_flag;
+        par_windows, par_fail, run_syms, run_bits, run_scratch, run_outs, run_fail, adl_tr, adl_res, plan_blk, ins_bits, fv_lists, mm_bak, cut_pos, cut_bkt, win_groups, win_sg, win_maps, win_entries, persist_bak, resume_flag, rle_tiles;
     bool resume_poisoned = false;  // a resumed run met a read the bulk form does not handle: the caller goes on with the literal engine
     void *pinned = nullptr;
     size_t pinned_cap = 0;
@@ -129,7 +129,8 @@ struct Plan {
     WorkList w_clear, w_adler, w_links, w_match, w_chunks, w_segs, w_sups, w_blocks, w_runs;
     int64_t n_pos = 0, n_syms = 0;
     int64_t n_chunks = 0, n_segs = 0, n_sups = 0, n_blocks = 0, n_pieces = 0, n_runs = 0;
-    bool any_fv = false;
+    bool any_fv = false, any_rle = false;
+    int64_t n_rle_tiles = 0;
     int64_t n_fv_list = 0;  // words of candidate lists (zs_fast_vec_kernel): one tile's worth per stream
     int64_t n_cuts = 0;     // entries of a cut list (batched cut rounds): one per read boundary
     // parse-segment tables (zs_core.h build_geometry), all streams: per segment (seg_off order); seg_cl and cstart hold one
@@ -244,6 +245,16 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
             s.fv_list_off = pl.n_fv_list;
             pl.n_fv_list += (int64_t)std::min<int64_t>(kFvTile, (len + 63) & ~63LL) * fv_list_entries(lv.chain);
         }
+        // CompressionStrategy.Rle, one Write: the parse is a function of where the runs of equal bytes begin (zs_rle.h)
+        s.rle_end = -1, s.rle_tile_off = 0;
+        if (strategy == kRle && level >= 1 && !multi && !flushing && final_run && !ro && regular && !getenv("ZS_NO_RLE_RUNS")) {
+            s.rle_end = (int32_t)rle_body_end(len);
+            if (s.rle_end >= 0) {
+                pl.any_rle = true;
+                s.rle_tile_off = (int32_t)pl.n_rle_tiles;
+                pl.n_rle_tiles += (s.rle_end + kMaxMatch + 1 + 4095) / 4096;
+            }
+        }
         s.n_wr = (multi || flushing) ? (int32_t)writes->ends.size() : 1;  // 0: a run without input (Finish alone)
         s.wr_end = nullptr;
         s.wr_flush = nullptr, s.wr_blk = nullptr, s.out_chunk = writes ? writes->chunk : 512, s.raw = writes && writes->raw;
@@ -287,10 +298,10 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
             pl.cstart.insert(pl.cstart.end(), geo.cstart.begin(), geo.cstart.end());
             pl.head.insert(pl.head.end(), geo.head.begin(), geo.head.end());
         } else {
-            if (s.fv_end >= 0)  // levels 1-3: the events of the single Write (the tail engine takes base and data end from them)
+            if (s.fv_end >= 0 || s.rle_end >= 0)  // levels 1-3, Rle: the events of the single Write (the tail engine takes base and data end from them)
                 for (size_t k = 0; k < rev.size(); k++) {
-                    const int64_t at = k ? rev[k].at - (kMinLookahead - 1) : 0;  // where the segment starts
-                    if (at > s.fv_end) break;
+                    const int64_t at = k ? rev[k].at - (s.rle_end >= 0 ? kMaxMatch : kMinLookahead - 1) : 0;  // where the segment starts
+                    if (at > (s.rle_end >= 0 ? s.rle_end : s.fv_end)) break;
                     pl.seg_c0.push_back(0), pl.seg_after.push_back((int32_t)rev[k].after), pl.seg_base.push_back((int32_t)rev[k].base);
                     pl.seg_S.push_back(0), pl.seg_cl.push_back((int32_t)pl.cl.size());
                     s.nsegs++;
@@ -786,6 +797,22 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
                                fv_list_entries(lv.chain));
         }
     }
+    if (pl.any_rle) {
+        // CompressionStrategy.Rle: the body's symbols from the runs of equal bytes (zs_rle.hip), the tail engine behind them
+        const size_t nt = (size_t)pl.n_rle_tiles;
+        if (!ensure(c, c->rle_tiles, 4 * (4 * nt + (size_t)n) + 256)) return false;
+        int32_t *rb = dev<int32_t>(c->rle_tiles);
+        RleTiles rt{rb, rb + nt, rb + 2 * nt, rb + 3 * nt, rb + 4 * nt};
+        int max_tiles = 0;
+        for (int i = 0; i < n; i++)
+            if (pl.sd[(size_t)i].rle_end >= 0) max_tiles = std::max(max_tiles, (pl.sd[(size_t)i].rle_end + kMaxMatch + 1 + 4095) / 4096);
+        const dim3 tg((unsigned)((max_tiles + 3) / 4), (unsigned)n);
+        hipLaunchKernelGGL(zs_rle_starts_kernel, tg, dim3(256), 0, stream, d_sd, rt);
+        hipLaunchKernelGGL(zs_rle_scan_kernel, dim3((unsigned)n), dim3(1024), 0, stream, d_sd, rt);
+        hipLaunchKernelGGL(zs_rle_pass_kernel<0>, tg, dim3(256), 0, stream, d_sd, rt, dev<uint32_t>(c->syms), dev<int32_t>(c->blk_end), dev<int32_t>(c->blk_top));
+        hipLaunchKernelGGL(zs_rle_sums_kernel, dim3((unsigned)n), dim3(1024), 0, stream, d_sd, d_st, rt);
+        hipLaunchKernelGGL(zs_rle_pass_kernel<1>, tg, dim3(256), 0, stream, d_sd, rt, dev<uint32_t>(c->syms), dev<int32_t>(c->blk_end), dev<int32_t>(c->blk_top));
+    }
     // the engine is left for a later run, or took the block in progress over from one: it needs K5's symbols and block ends
     const bool tail_late = ro && (!ro->final_run || ro->resume);
     // Beside the symbol kernel the tails of a few streams are free; those of hundreds are not: 256 tail workgroups of 1024
@@ -1156,7 +1183,7 @@ void zs_ctx_destroy(zs_ctx *c) {
     DevBuf *bufs[] = {&c->sd, &c->st, &c->work, &c->wpre, &c->geo, &c->link, &c->mm, &c->maps, &c->chunk_far, &c->segmap, &c->supmap, &c->seg_entry, &c->seg_symbase, &c->seg_stale, &c->entry, &c->symbase, &c->stale, &c->syms,
                       &c->blk_end, &c->blk_top, &c->blocks, &c->trees, &c->info, &c->pieces, &c->scratch, &c->stage_in, &c->stage_out, &c->wr, &c->inf_desc, &c->inf_state, &c->par_ps, &c->par_st, &c->par_work, &c->par_cbits, &c->par_ccnt, &c->par_surv, &c->par_scnt,
                       &c->par_cands, &c->par_tabs, &c->par_blocks, &c->par_cells, &c->par_windows, &c->par_fail, &c->run_syms, &c->run_bits,
-                      &c->run_scratch, &c->run_outs, &c->run_fail, &c->adl_tr, &c->adl_res, &c->plan_blk, &c->ins_bits, &c->fv_lists, &c->mm_bak, &c->cut_pos, &c->cut_bkt, &c->win_groups, &c->win_sg, &c->win_maps, &c->win_entries, &c->persist_bak, &c->resume_flag};
+                      &c->run_scratch, &c->run_outs, &c->run_fail, &c->adl_tr, &c->adl_res, &c->plan_blk, &c->ins_bits, &c->fv_lists, &c->mm_bak, &c->cut_pos, &c->cut_bkt, &c->win_groups, &c->win_sg, &c->win_maps, &c->win_entries, &c->persist_bak, &c->resume_flag, &c->rle_tiles};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     if (c->crc_tab) (void)hipFree(c->crc_tab);

@@ -2147,7 +2147,8 @@ __global__ __launch_bounds__(256) void zs_body_blocks_kernel(const StreamDesc *s
         r.sym_start = (int64_t)i * kBlockSyms;
         r.stored_len = (int32_t)(end - start);
         r.nsyms = kBlockSyms;
-        r.can_store = start >= s.base0 + (int64_t)kWSize * refills_fired_at(blk_top[s.blk_off + i] - s.base0, s.kl);
+        r.can_store = start >= s.base0 + (int64_t)kWSize * (s.rle_end >= 0 ? rle_refills_fired_at(blk_top[s.blk_off + i], s.kl)
+                                                                            : refills_fired_at(blk_top[s.blk_off + i] - s.base0, s.kl));
         r.eof = 0;
         blk[i] = r;
     }
@@ -3157,6 +3158,7 @@ __global__ __launch_bounds__(NT) void zs_fast_vec_kernel(const StreamDesc *sd, S
 }
 
 #include "zs_fast_sweep.hip"
+#include "zs_rle.hip"
 
 // Build_tree (Trees.cs:404-501) by one wave.  The priority queue is sifted by lane 0 exactly as the reference does
 // (zs_core.h build_tree: tie-breaking decides the tree); what surrounds it is data-parallel and costs as much as the
