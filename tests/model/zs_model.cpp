@@ -456,6 +456,46 @@ static void parse_rle_runs(Model &m, int64_t &p_out, int &kdone_out) {
     kdone_out = rle_refills_fired_at(H, kl);
 }
 
+
+// ---- statistics only (mode "spec"): a chunk's lazy parse started `warm` positions in front of it in the state "loop-top, nothing
+//      pending" -- does it stand in the true parse's node at the first loop-top at or behind the chunk's beginning?  (What a
+//      speculative form of the symbol kernel would need: SURVEY.md hard part 2 says yes on text, no on periodic data.)
+static void spec_stats(Model &m) {
+    const int64_t be = m.n - kMinLookahead;
+    std::vector<uint8_t> kind_at((size_t)m.n + 8, 255);
+    std::vector<uint32_t> pend_at((size_t)m.n + 8, 0);
+    {
+        int kind = kR;
+        int64_t p = 0;
+        uint32_t pend = 0;
+        while (p <= be) {
+            kind_at[(size_t)p] = (uint8_t)kind, pend_at[(size_t)p] = pend;
+            const uint32_t cK = p ? m.flt(m.mK[(size_t)p]) : 0, cK4 = p ? m.flt(m.mK4[(size_t)p]) : 0;
+            const Step st = lazy_step(kind, p, pend, cK, cK4, m.lv);
+            pend = st.kind == kXK ? cK : st.kind == kXK4 ? cK4 : 0;
+            kind = st.kind, p = st.pos;
+        }
+    }
+    for (int warm : {64, 128, 256, 512, 1024}) {
+        long chunks = 0, bad = 0;
+        for (int64_t cs = kChunk - (kMinLookahead - 1); cs <= be; cs += kChunk) {
+            int kind = kR;
+            int64_t p = cs - warm < 1 ? 1 : cs - warm;
+            uint32_t pend = 0;
+            while (p < cs) {
+                const uint32_t cK = m.flt(m.mK[(size_t)p]), cK4 = m.flt(m.mK4[(size_t)p]);
+                const Step st = lazy_step(kind, p, pend, cK, cK4, m.lv);
+                pend = st.kind == kXK ? cK : st.kind == kXK4 ? cK4 : 0;
+                kind = st.kind, p = st.pos;
+            }
+            chunks++;
+            if (p > be) continue;
+            if (kind_at[(size_t)p] != kind || pend_at[(size_t)p] != pend) bad++;
+        }
+        printf("spec: warm-up %4d: %ld of %ld chunks do not stand in the true parse's node at their first loop-top\n", warm, bad, chunks);
+    }
+}
+
 // ---- stage B: the chunked form the GPU runs ----
 struct Sink {
     int64_t base;  // stream-global index of the chunk's first symbol
@@ -1197,7 +1237,11 @@ int main(int argc, char **argv) {
     int kind, k_done;
     uint32_t pend;
     int64_t preins;
-    if (mode == "bulk" || mode == "chunk") m.match_all();
+    if (mode == "bulk" || mode == "chunk" || mode == "spec") m.match_all();
+    if (mode == "spec") {
+        spec_stats(m);
+        return 0;
+    }
     if (mode == "rle") {
         // CompressionStrategy.Rle, one Write: the runs' closed form up to the hand-over loop-top, then the literal engine
         kind = kR, pend = 0, p = 0, k_done = 0, preins = -1;

@@ -18,5 +18,5 @@ for name, data in (("sparse64", datagen.sparse(4096, 4096)), ("english64", datag
             m = eng.deflate_batch_device([d_in.data_ptr()], [len(data)], [d_out.data_ptr()], [cap], level=lvl, strategy=3)[0]
         torch.cuda.synchronize(); dt = (time.perf_counter() - t) / 5
         z = d_out[:m].cpu().numpy().tobytes()
-        ok = zlib.decompress(z) == data and z[:1 << 20] == orc.compress(data[:8 << 20], lvl, 3)[:1 << 20]
-        print(json.dumps({"workload": name + " Rle", "level": lvl, "compressed": m, "ms": round(dt * 1e3, 3), "GBps": round(len(data) / dt / 1e9, 2), "roundtrip + first MiB exact": ok}), flush=True)
+        ok = z == orc.compress(data, lvl, 3)
+        print(json.dumps({"workload": name + " Rle", "level": lvl, "compressed": m, "ms": round(dt * 1e3, 3), "GBps": round(len(data) / dt / 1e9, 2), "bit-identical to the oracle (whole stream)": ok}), flush=True)
