@@ -292,24 +292,25 @@ __global__ __launch_bounds__(NT) void zs_fast_sweep_kernel(const StreamDesc *sd,
             uint32_t row[NG];
 #pragma unroll
             for (int g = 0; g < NG; g++) row[g] = ex[64 * g + lane];
-            int cur = w0r, Lin = 0, before = 0;
-            bool term = false;
-            uint32_t mine = 0, mine_b = 0;
+            // (everything below is uniform: scalar registers, the path's state in three of them; a group's entry goes into lane g
+            // of two vector registers)
+            int cur = w0r, before = 0;   // cur: 0xFFF once the path has ended
+            uint32_t lin_term = 0;       // the hop that entered << 12 | path ended before << 21
+            int mine = 0, mine_b = 0;
 #pragma unroll
             for (int g = 0; g < NG; g++) {
-                const bool entered = !term && (cur >> 6) == g;
-                const uint32_t pub = (entered ? (uint32_t)cur : 0xFFFu) | ((uint32_t)Lin << 12) | (term ? 1u << 21 : 0u);
-                if (lane == g) mine = pub, mine_b = (uint32_t)before;
+                const bool entered = (cur >> 6) == g;
+                const int pub = __builtin_amdgcn_readfirstlane((int)((entered ? (uint32_t)cur : 0xFFFu) | lin_term));
+                mine = lane == g ? pub : mine, mine_b = lane == g ? __builtin_amdgcn_readfirstlane(before) : mine_b;
                 if (entered) {
                     const uint32_t p = (uint32_t)__builtin_amdgcn_readlane((int)row[g], cur & 63);
                     const int nj = fs_pj(p);
-                    if (nj != cur) Lin = fs_pl(p);
                     before += fs_pc(p);
-                    term = (nj >> 6) == g;  // an exit inside the group is a lane at which the path ends (it points at itself)
-                    cur = nj;
+                    if ((nj >> 6) == g) cur = 0xFFF, lin_term |= 1u << 21;  // an exit inside the group is a lane at which the path ends (it points at itself)
+                    else cur = nj, lin_term = (uint32_t)fs_pl(p) << 12;
                 }
             }
-            if (lane < NG) gent[lane] = mine, gbef[lane] = mine_b;
+            if (lane < NG) gent[lane] = (uint32_t)mine, gbef[lane] = (uint32_t)mine_b;
         }
         FS_PF(4);
         __syncthreads();  // -------- barrier 2: where the path enters the groups
