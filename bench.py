@@ -204,8 +204,8 @@ def pmc_traffic(kernel, tag):
 class DeviceBatch:
     """Buffers resident in HBM + their output buffers, and a timed loop over zs_deflate_batch_device."""
 
-    def __init__(self, eng, dev, datas):
-        self.eng, self.datas = eng, datas
+    def __init__(self, eng, dev, datas, strategy=0):
+        self.eng, self.datas, self.strategy = eng, datas, strategy
         self.n = sum(len(d) for d in datas)
         self.d_ins = [torch.frombuffer(bytearray(d), dtype=torch.uint8).to(dev) for d in datas]
         self.caps = [deflate_bound(len(d)) for d in datas]
@@ -219,7 +219,7 @@ class DeviceBatch:
         self.c_args = Engine.DeviceBatch(self.in_ptrs, self.in_lens, self.out_ptrs, self.caps)
 
     def step(self, level):
-        self.out_lens = self.eng.deflate_device_batch(self.c_args, level=level, stream=torch.cuda.current_stream().cuda_stream)
+        self.out_lens = self.eng.deflate_device_batch(self.c_args, level=level, strategy=self.strategy, stream=torch.cuda.current_stream().cuda_stream)
 
     def timed(self, level, steps, warmup, barrier=lambda: None):
         for _ in range(warmup):
@@ -260,13 +260,17 @@ INFLATE_STAGE_KERNELS = {"inf_decode": ["zs_inf_decode_lane_kernel", "zs_inf_cel
 def roofline(stage_ms, alg_bytes, traffic=None, kernels=None):
     dom = max(stage_ms, key=stage_ms.get)
     achieved = alg_bytes / (stage_ms[dom] * 1e-3) / 1e9
-    return {"bound": "hbm", "kernel": " + ".join(kernels) if kernels else "zs_%s_kernel" % dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    # scope: "kernel" -- `achieved` is over ONE kernel's launch time; "stage" -- over a stage of the call that is several launches
+    # (kernel_ms is then the stage's time and `traffic` the sum of its kernels'); profiles/rNN_*_kernel_stats.csv has every
+    # kernel's own average beside it
+    return {"bound": "hbm", "kernel": " + ".join(kernels) if kernels else "zs_%s_kernel" % dom, "scope": "stage" if kernels and len(kernels) > 1 else "kernel",
+            "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
             "kernel_ms": round(stage_ms[dom], 4)}
 
 
-def secondary_deflate(eng, dev, name, datas, level, steps, check_every=1):
-    b = DeviceBatch(eng, dev, datas)
+def secondary_deflate(eng, dev, name, datas, level, steps, check_every=1, strategy=0):
+    b = DeviceBatch(eng, dev, datas, strategy)
     dt, stage_ms = b.timed(level, steps, 1)
     b.check_roundtrip(check_every)
     total_out = sum(b.out_lens)
@@ -584,6 +588,25 @@ def main():
                 torch.cuda.empty_cache()
                 for lvl in (1, 3, 6):
                     sec["corpus_L%d" % lvl] = secondary_corpus(eng, dev, lvl, ks, with_cpu=not args.no_cpu_baseline)
+                # DeflateFast (Deflate.Fast.cs:20-128) on ONE stream: the window-wide sweeps of a single workgroup
+                # (zs_fast_sweep_kernel); the reference publishes 54.8 / 36.9 MB/s for alice29 at levels 1 / 3 (benchmarks.md:63,118)
+                en8 = datagen.english(8 << 20, 77)
+                for lvl in (1, 3):
+                    sec["english8_L%d" % lvl], b = secondary_deflate(eng, dev, "english8: ONE 8 MiB text stream (DeflateFast)", [en8], lvl, 2)
+                    if not args.no_cpu_baseline:
+                        cbs, refs, slen = cpu_baseline(en8, lvl, budget_s=2.0, name="english8")
+                        sec["english8_L%d" % lvl]["cpu_baseline"] = cbs
+                        if slen == len(en8):
+                            sec["english8_L%d" % lvl]["bit_identical_to_cpu"] = bool(b.stream_bytes(0) == refs)
+                    del b
+                # ... and in a batch (a stream per CU and round): 512 x 512 KiB
+                texts = [datagen.english(512 << 10, 1000 + i) for i in range(512)]
+                sec["fast512_L1"], b = secondary_deflate(eng, dev, "512 x 512 KiB text streams in one batch (DeflateFast)", texts, 1, 2, check_every=64)
+                del b, texts
+                # CompressionStrategy.Rle (Deflate.Rle.cs:18-104) over the chip (zs_rle.hip)
+                sec["sparse64_rle_L6"], b = secondary_deflate(eng, dev, "sparse64 under CompressionStrategy.Rle", [sp], 6, ks, strategy=3)
+                del b
+                torch.cuda.empty_cache()
                 sec["inflate1g"] = secondary_inflate(eng, dev, ks)
                 torch.cuda.empty_cache()
                 sec["host_path"] = secondary_host_path(eng, data, args.level)
