@@ -44,7 +44,7 @@ struct FsLayout {
 };
 template <int NT, int TILE>
 constexpr int fs_lds_bytes() {
-    return FsLayout<TILE>::bytes + 2 * FsLayout<TILE>::links + 2 * 4 * FsLayout<TILE>::bit_words + 4 * (2 * NT) + 4 * NT + 8 * (NT / 64) + 64;
+    return FsLayout<TILE>::bytes + 2 * FsLayout<TILE>::links + 2 * 4 * FsLayout<TILE>::bit_words + 4 * (2 * NT) + 4 * NT + 8 * (NT / 64) + 2 * (2 * NT) + 64;
 }
 // a pair of link halfwords as the link kernel left them -> the staged form (no membership bit yet); p = position of the low one
 __device__ __forceinline__ uint32_t fs_stage_links(uint32_t pair, int p) {
@@ -92,6 +92,8 @@ __global__ __launch_bounds__(NT) void zs_fast_sweep_kernel(const StreamDesc *sd,
     uint32_t *gent = ex + W;                                    // per group: entry index (0xFFF: none) | entering hop << 12 | path ended before << 21
     uint32_t *gbef = gent + NG;                                 // per group: loop-tops in the groups before it
     uint32_t *rb = gbef + NG;                                   // bit of a position: its link is 1 (the previous position of its bucket is its neighbour: runs)
+    uint16_t *gl = (uint16_t *)(rb + fsBitWords);               // a window position's link under the guess: the distance to the nearest position of its bucket
+                                                                // that the guess has in the set (at q & (RING - 1); 0x7FFF: none)
     // [0] first loop-top with a new result, [1] last loop-top, [2] final loop-tops of the sweep
     // (static: the compiler then knows the address space and the atomics below are LDS instructions, not flat ones)
     __shared__ uint32_t shv[4];
@@ -118,6 +120,23 @@ __global__ __launch_bounds__(NT) void zs_fast_sweep_kernel(const StreamDesc *sd,
 #else
 #define FS_PF(i)
 #endif
+    // The distance from tile index ci to the nearest entry of its chain that is in the set (0: none within reach): what a walker
+    // from there would step to.  For a final position this is its compressed link (fs_compress); for a window position it
+    // is the same walk under the guess, done once per sweep instead of once per walker that comes by (kennedy.xls: 22 chain
+    // entries per search, 6 of them to find the first member of the set).
+    auto nearest_in_set = [&](int ci) -> int {
+        int c1 = ci;
+        uint32_t l = wl[ci] & 0x7FFFu;
+        for (;;) {
+            c1 -= (int)l;
+            if (ci - c1 > kMaxDist) return 0;
+            const uint32_t v = wl[c1];
+            if (v >> 15) return ci - c1;
+            l = v & 0x7FFFu;
+            if (l == 1u) c1 = fs_run_skip(c1, bm, rb);
+        }
+    };
+    bool gl_stale = true;  // the guess's links have to be made again: a new tile (other positions have links), an event (a forced member, a cut)
     while (w0 <= body_end) {
         const int g0 = w0 & ~63;
         if (g0 + W > t0 + TILE) {
@@ -128,7 +147,7 @@ __global__ __launch_bounds__(NT) void zs_fast_sweep_kernel(const StreamDesc *sd,
                 for (int wd = (w0_staged >> 5) + tid; wd <= (x_end >> 5); wd += NT) gbits[wd] = bm[wd - (lo_old >> 5)];
                 __syncthreads();
             }
-            t0 = g0, w0_staged = w0;
+            t0 = g0, w0_staged = w0, gl_stale = true;
             const int lo = t0 - kFsBack;
             for (int i = tid; i < fsBytes / 16; i += NT) {
                 const int a = lo + i * 16;
@@ -199,11 +218,21 @@ __global__ __launch_bounds__(NT) void zs_fast_sweep_kernel(const StreamDesc *sd,
                 if (same) wl[w0 - lo] |= kFsNoLink, lk[w0] = 0, rb[(w0 - lo) >> 5] &= ~(1u << ((w0 - lo) & 31));  // the reference's prev[w0] = w0 + 1, prev[w0 + 1] = w0
             }
             trigger = k_fired < kl ? (int)read_end_before(k_fired + 1) - (kMinLookahead - 1) : -1;
+            gl_stale = true;
             __syncthreads();
         }
         int hi = g0 + W;
         if (body_end + 1 < hi) hi = body_end + 1;
         if (trigger >= 0 && trigger < hi) hi = trigger;
+        if (gl_stale) {
+            const int g_hi = g0 + W < lo + fsLinks ? g0 + W : lo + fsLinks;
+            for (int c = w0 + tid; c < g_hi; c += NT) {
+                const int d = nearest_in_set(c - lo);
+                gl[c & (RING - 1)] = (uint16_t)(d ? d : (int)kFsNoLink);
+            }
+            gl_stale = false;
+            __syncthreads();
+        }
         const int w0r = w0 - g0, hir = hi - g0, gi = g0 - lo;
         const int grp = wave, gbase = 64 * grp, self = gbase + lane;  // the lane's index in the window
         const int qi = gi + self, q = g0 + self;                       // ... in the tile, and its position
@@ -219,8 +248,8 @@ __global__ __launch_bounds__(NT) void zs_fast_sweep_kernel(const StreamDesc *sd,
             const uint64_t scan8 = lds_u64(wb, qi);
             bool walking = act && !dead && !known;
             int c = qi, rem = chain, maxd = kMaxDist;  // hash_head: <= MAX_DIST; later: cur_match > limit
-            uint32_t l = wl[qi] & 0x7FFFu;
-            if (qi - (int)l < gi + w0r) exact = kFsExact;  // (no link: 0x7FFF, below anything)
+            if (qi - (int)(wl[qi] & 0x7FFFu) < gi + w0r) exact = kFsExact;  // (no link: 0x7FFF, below anything)
+            uint32_t l = gl[q & (RING - 1)];
             if (only_prev) l = 1, rem = 1;                 // the search sees only q - 1 (equal-bucket refill), whatever the set says
             while (__ballot(walking)) {
 #ifdef ZS_FS_PROF
@@ -232,7 +261,7 @@ __global__ __launch_bounds__(NT) void zs_fast_sweep_kernel(const StreamDesc *sd,
                         walking = false;
                     } else {
                         const uint32_t v = wl[nc];
-                        c = nc, l = v & 0x7FFFu;
+                        c = nc, l = nc >= gi + w0r ? (uint32_t)gl[(lo + nc) & (RING - 1)] : v & 0x7FFFu;  // (inside the window: the guess's link)
                         if ((v >> 15) || only_prev) {
                             const uint64_t x = lds_u64(wb, nc) ^ scan8;
                             int len = (int)(__builtin_ctzll(x) >> 3);
@@ -405,28 +434,22 @@ __global__ __launch_bounds__(NT) void zs_fast_sweep_kernel(const StreamDesc *sd,
         nsyms += (int)shv[2];
         if (nsyms > next_cut) next_cut += kBlockSyms;
         if (tid == 0) shv[0] = 0xFFFFFFFFu, shv[1] = 0;
-        // ---- the links of what has become final, compressed (fs_compress); no barrier behind this: the next sweep's walkers
-        //      find the same candidates through either form of a link
-        const int c_hi = w0_new < lo + fsLinks ? w0_new : lo + fsLinks;  // (a last match may reach out of the tile: those links stay as they are)
-        for (int c = w0 + tid; c < c_hi; c += NT) {
-            const int ci = c - lo;
-            int c1 = ci, out = 0;
-            const uint32_t own = wl[ci];
-            uint32_t l = own & 0x7FFFu;
-            for (;;) {
-                c1 -= (int)l;
-                if (ci - c1 > kMaxDist) break;
-                const uint32_t v = wl[c1];
-                if (v >> 15) {
-                    out = ci - c1;
-                    break;
+        // ---- the links of what has become final, compressed (fs_compress), and the links of the next window under the new
+        //      guess; a walker that meets an entry another thread is rewriting finds the same candidates through either form
+        {
+            const int fin_hi = w0_new < lo + fsLinks ? w0_new : lo + fsLinks;  // (a last match may reach out of the tile: those links stay as they are)
+            const int g_hi = w0_new + W < lo + fsLinks ? w0_new + W : lo + fsLinks;
+            for (int c = w0 + tid; c < g_hi; c += NT) {
+                const int ci = c - lo, d = nearest_in_set(ci);
+                if (c < fin_hi) {
+                    wl[ci] = (uint16_t)((d ? (uint32_t)d : kFsNoLink) | (wl[ci] & 0x8000u));
+                    lk[c] = (uint16_t)d;
+                } else {
+                    gl[c & (RING - 1)] = (uint16_t)(d ? d : (int)kFsNoLink);
                 }
-                l = v & 0x7FFFu;
-                if (l == 1u) c1 = fs_run_skip(c1, bm, rb);
             }
-            wl[ci] = (uint16_t)((out ? (uint32_t)out : kFsNoLink) | (own & 0x8000u));
-            lk[c] = (uint16_t)out;
         }
+        __syncthreads();  // -------- barrier 5: the links
         ev_end = hi;
         x_end = g0 + Xr;
         w0 = w0_new;
