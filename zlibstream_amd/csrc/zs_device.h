@@ -89,20 +89,18 @@ struct StreamDesc {
     int64_t start_pos;  // resume: the run's first loop-top (buffer position); the engine before it ran up to there
     uint32_t adler_stream;
     uint32_t carry_byte;  // cont: the bits of the stream's last, incomplete byte from the run before
-    // DeflateFast for the lanes of a wave (zs_fast_vec.h, zs_fast_vec_kernel): last loop-top it handles (n - 262), -1: not
+    // DeflateFast as sweeps of a workgroup (zs_fast_sweep.h, zs_fast_sweep_kernel): last loop-top it handles (n - 262), -1: not
     // this stream; the stream's inserted-position bitmap (bit q of the array = position q)
     int32_t fv_end;
     uint32_t *ins_bits;
     // the cuts of equal-bucket events collected by the resolve kernel's dry passes (batched cut rounds): where the stream's
     // entries begin in the two cut lists, and how many there is room for (one per read boundary)
     int32_t cut_off, cut_cap;
-    int64_t fv_list_off;  // where the stream's candidate lists begin in the batch's list area (zs_fast_vec_kernel), in words
     // CompressionStrategy.Rle over the chip (zs_rle.h, zs_rle.hip): the loop-tops below rle_end are the body's, the tail engine
     // goes on from the first one at or behind it (-1: not this stream); the stream's first tile in the batch's tile arrays
     int32_t rle_end, rle_tile_off;
 };
 
-// zs_fast_vec_kernel's tile: the window [t0 - kFvBack, t0 + kFvTile + kFvFwd) in LDS as bytes, links and inserted bits
 // where each kernel's work items start in the work array (zs_worklist_kernel): 9 lists, then the total
 struct WorkOffsets {
     uint32_t off[10];
@@ -110,22 +108,9 @@ struct WorkOffsets {
 constexpr int kK5Feeders = 2;     // waves of the symbol kernel's workgroup that stage the walking wave's records in LDS
 constexpr int kK5Threads = 64 * (1 + kK5Feeders);
 constexpr int kSupSegs = 16;      // parse segments composed into one row of supmap ahead of the resolve kernel
-constexpr int kFvTile = 16384;
-constexpr int kFvBack = 32512;  // >= kMaxDist, multiple of 32
-constexpr int kFvFwd = 272;     // >= kMaxMatch + 8, multiple of 16
-constexpr int kFvBytes = kFvBack + kFvTile + kFvFwd;
-constexpr int kFvLinks = kFvBack + kFvTile;
-constexpr int kFvBitWords = kFvLinks / 32 + 8;  // the tile may start 16 positions into a word, and short matches reach out of it
-// the form that reads K1's links where they lie: two workgroups of 512 threads per CU
-constexpr int kFvLdsNoLinks = kFvBytes + 4 * kFvBitWords + 8192;
-constexpr int kFvLds = kFvBytes + 2 * kFvLinks + 4 * kFvBitWords + 8192;  // + the first 16 list entries per lane of the window and of the 64 positions behind it
-// candidate-list entries per position (zs_fast_vec_kernel): enough for most searches of the level -- max_chain candidates
-// among the ~45 % of a chain that was inserted -- in multiples of 16; a longer search walks on through the staged links
-constexpr int kFvQuitWalk = 96;  // walk steps per window behind the lists' ends beyond which a stream is left to the literal engine
-ZS_HD int fv_list_entries(int max_chain) { return max_chain <= 4 ? 16 : max_chain <= 8 ? 32 : 96; }
-// the last tile of a stream stages bitmap words for up to kFvTile + 256 positions past its loop-top, i.e. past the stream's end:
-// the bitmap array carries that much room behind the last stream
-constexpr size_t kFvBitSlack = (kFvTile + 512) / 8 + 64;
+// the sweep kernel's last tile stages bitmap words for its tile and a match's reach past the stream's end: the bitmap array carries
+// that much room behind the last stream
+constexpr size_t kFvBitSlack = (16384 + 512) / 8 + 64;
 
 // What a suspended literal engine keeps between runs (device memory, one per zs_deflate stream): the reference's own state
 // -- window, prev, head, the Deflate fields (Deflate.cs:128-226) -- plus the symbols of the block in progress and the

@@ -56,7 +56,7 @@ struct zs_ctx {
     uint32_t *crc_tab = nullptr;
     DevBuf sd, st, work, wpre, geo, link, mm, maps, chunk_far, segmap, supmap, seg_entry, seg_symbase, seg_stale, entry, symbase, stale, syms, blk_end, blk_top, blocks, trees, info, pieces, scratch,
         stage_in, stage_out, wr, inf_desc, inf_state, par_ps, par_st, par_work, par_cbits, par_ccnt, par_surv, par_scnt, par_cands, par_tabs, par_blocks, par_cells,
-        par_windows, par_fail, run_syms, run_bits, run_scratch, run_outs, run_fail, adl_tr, adl_res, plan_blk, ins_bits, fv_lists, mm_bak, cut_pos, cut_bkt, win_groups, win_sg, win_maps, win_entries, persist_bak, resume_flag, rle_tiles;
+        par_windows, par_fail, run_syms, run_bits, run_scratch, run_outs, run_fail, adl_tr, adl_res, plan_blk, ins_bits, mm_bak, cut_pos, cut_bkt, win_groups, win_sg, win_maps, win_entries, persist_bak, resume_flag, rle_tiles;
     bool resume_poisoned = false;  // a resumed run met a read the bulk form does not handle: the caller goes on with the literal engine
     void *pinned = nullptr;
     size_t pinned_cap = 0;
@@ -131,7 +131,6 @@ struct Plan {
     int64_t n_chunks = 0, n_segs = 0, n_sups = 0, n_blocks = 0, n_pieces = 0, n_runs = 0;
     bool any_fv = false, any_rle = false;
     int64_t n_rle_tiles = 0;
-    int64_t n_fv_list = 0;  // words of candidate lists (zs_fast_vec_kernel): one tile's worth per stream
     int64_t n_cuts = 0;     // entries of a cut list (batched cut rounds): one per read boundary
     // parse-segment tables (zs_core.h build_geometry), all streams: per segment (seg_off order); seg_cl and cstart hold one
     // entry more per stream (stream i's lists begin at seg_off + i / chunk_off + i); seg_cl's values index `cl`
@@ -239,11 +238,8 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
         const bool fast_par = fast_one && !force_seq && len >= kFastMinInput;
         s.fv_end = (fast_one && !fast_par && !getenv("ZS_NO_FAST_VEC")) ? (int32_t)(len - kMinLookahead) : -1;
         s.ins_bits = nullptr;
-        s.fv_list_off = 0;
         if (s.fv_end >= 0) {
             pl.any_fv = true;
-            s.fv_list_off = pl.n_fv_list;
-            pl.n_fv_list += (int64_t)std::min<int64_t>(kFvTile, (len + 63) & ~63LL) * fv_list_entries(lv.chain);
         }
         // CompressionStrategy.Rle, one Write: the parse is a function of where the runs of equal bytes begin (zs_rle.h)
         s.rle_end = -1, s.rle_tile_off = 0;
@@ -397,7 +393,7 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
     }
     if (pl.any_fv) {
         // one bit per position (pos_off is a multiple of 64: every stream's bitmap starts on a word)
-        if (!ensure(c, c->ins_bits, (size_t)pl.n_pos / 8 + kFvBitSlack) || !ensure(c, c->fv_lists, 4 * (size_t)pl.n_fv_list + 256)) return false;
+        if (!ensure(c, c->ins_bits, (size_t)pl.n_pos / 8 + kFvBitSlack)) return false;
         for (int i = 0; i < n; i++)
             if (pl.sd[(size_t)i].fv_end >= 0) pl.sd[(size_t)i].ins_bits = dev<uint32_t>(c->ins_bits) + pl.sd[(size_t)i].pos_off / 32;
     }
@@ -773,29 +769,10 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
     // fork: the tail engine (sequential, one workgroup per stream) needs only what the resolve kernel left, so it runs
     // on the second stream beside the symbol kernels
     if (pl.any_fv) {
-        // (The kernel's time is its lone parsing wave's, so a batch of more streams than CUs gets two workgroups of 512 threads
-        // per CU, with K1's links read where they lie: 512 x 512 KiB at level 1 104 -> 70 ms; up to one stream per CU: 1024
-        // threads and the links staged in LDS.  Three of 256 threads on a tile of half the size were slower than two -- 79 ms,
-        // also for 1024 streams.  ZS_FV_PER_CU=1/2 overrides.)
-        if (!getenv("ZS_FAST_VEC")) {
-            // window-wide sweeps of a workgroup (zs_fast_sweep.hip)
-            constexpr int fs_lds = fs_lds_bytes<1024, kFsTile1>();
-            hipLaunchKernelGGL((zs_fast_sweep_kernel<1024, kFsTile1>), dim3((unsigned)n), dim3(1024), fs_lds, stream, d_sd, d_st,
-                               dev<uint16_t>(c->link), dev<uint32_t>(c->syms), dev<int32_t>(c->blk_end), dev<int32_t>(c->blk_top), lv, strategy);
-        } else {
-        int n_fv_streams = 0;
-        for (int i = 0; i < n; i++) n_fv_streams += pl.sd[(size_t)i].fv_end >= 0;
-        int per_cu = n_fv_streams > 256 ? 2 : 1;
-        if (getenv("ZS_FV_PER_CU")) per_cu = atoi(getenv("ZS_FV_PER_CU"));
-        if (per_cu >= 2)
-            hipLaunchKernelGGL((zs_fast_vec_kernel<512, false, kFvTile>), dim3((unsigned)n), dim3(512), kFvLdsNoLinks, stream, d_sd, d_st, dev<uint16_t>(c->link),
-                               dev<uint32_t>(c->syms), dev<int32_t>(c->blk_end), dev<int32_t>(c->blk_top), lv, strategy, dev<uint32_t>(c->fv_lists),
-                               fv_list_entries(lv.chain));
-        else
-            hipLaunchKernelGGL((zs_fast_vec_kernel<1024, true, kFvTile>), dim3((unsigned)n), dim3(1024), kFvLds, stream, d_sd, d_st, dev<uint16_t>(c->link),
-                               dev<uint32_t>(c->syms), dev<int32_t>(c->blk_end), dev<int32_t>(c->blk_top), lv, strategy, dev<uint32_t>(c->fv_lists),
-                               fv_list_entries(lv.chain));
-        }
+        // window-wide sweeps of a workgroup (zs_fast_sweep.hip), one workgroup per stream
+        constexpr int fs_lds = fs_lds_bytes<1024, kFsTile1>();
+        hipLaunchKernelGGL((zs_fast_sweep_kernel<1024, kFsTile1>), dim3((unsigned)n), dim3(1024), fs_lds, stream, d_sd, d_st,
+                           dev<uint16_t>(c->link), dev<uint32_t>(c->syms), dev<int32_t>(c->blk_end), dev<int32_t>(c->blk_top), lv, strategy);
     }
     if (pl.any_rle) {
         // CompressionStrategy.Rle: the body's symbols from the runs of equal bytes (zs_rle.hip), the tail engine behind them
@@ -1067,7 +1044,7 @@ int batch_prefix_that_fits(zs_ctx *c, int n, const int64_t *in_len, const int64_
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return n;
     const DevBuf *held[] = {&c->link, &c->mm, &c->maps, &c->segmap, &c->supmap, &c->syms, &c->trees, &c->blocks, &c->info, &c->stage_in, &c->stage_out,
-                            &c->scratch, &c->fv_lists, &c->ins_bits, &c->mm_bak};
+                            &c->scratch, &c->ins_bits, &c->mm_bak};
     size_t have = 0;
     for (const DevBuf *b : held) have += b->cap;
     const double budget = 0.55 * ((double)free_b + (double)have);  // (the buffers are grown with an eighth of headroom each)
@@ -1155,8 +1132,6 @@ int zs_ctx_create(int device, zs_ctx **out) {
         hipFuncSetAttribute((const void *)zs_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kTailLds) != hipSuccess ||
         hipFuncSetAttribute((const void *)zs_fast_run_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kTailLds) != hipSuccess ||
         hipFuncSetAttribute((const void *)zs_fast_sweep_kernel<1024, kFsTile1>, hipFuncAttributeMaxDynamicSharedMemorySize, (fs_lds_bytes<1024, kFsTile1>())) != hipSuccess ||
-        hipFuncSetAttribute((const void *)zs_fast_vec_kernel<1024, true, kFvTile>, hipFuncAttributeMaxDynamicSharedMemorySize, kFvLds) != hipSuccess ||
-        hipFuncSetAttribute((const void *)zs_fast_vec_kernel<512, false, kFvTile>, hipFuncAttributeMaxDynamicSharedMemorySize, kFvLdsNoLinks) != hipSuccess ||
         hipFuncSetAttribute((const void *)zs_inf_window_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kWinMapLds) != hipSuccess ||
         hipFuncSetAttribute((const void *)zs_inf_chain_par_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kChainParLds) != hipSuccess ||
         hipFuncSetAttribute((const void *)zs_cuts_repair_kernel<256, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, kRepairLds) != hipSuccess ||
@@ -1183,7 +1158,7 @@ void zs_ctx_destroy(zs_ctx *c) {
     DevBuf *bufs[] = {&c->sd, &c->st, &c->work, &c->wpre, &c->geo, &c->link, &c->mm, &c->maps, &c->chunk_far, &c->segmap, &c->supmap, &c->seg_entry, &c->seg_symbase, &c->seg_stale, &c->entry, &c->symbase, &c->stale, &c->syms,
                       &c->blk_end, &c->blk_top, &c->blocks, &c->trees, &c->info, &c->pieces, &c->scratch, &c->stage_in, &c->stage_out, &c->wr, &c->inf_desc, &c->inf_state, &c->par_ps, &c->par_st, &c->par_work, &c->par_cbits, &c->par_ccnt, &c->par_surv, &c->par_scnt,
                       &c->par_cands, &c->par_tabs, &c->par_blocks, &c->par_cells, &c->par_windows, &c->par_fail, &c->run_syms, &c->run_bits,
-                      &c->run_scratch, &c->run_outs, &c->run_fail, &c->adl_tr, &c->adl_res, &c->plan_blk, &c->ins_bits, &c->fv_lists, &c->mm_bak, &c->cut_pos, &c->cut_bkt, &c->win_groups, &c->win_sg, &c->win_maps, &c->win_entries, &c->persist_bak, &c->resume_flag, &c->rle_tiles};
+                      &c->run_scratch, &c->run_outs, &c->run_fail, &c->adl_tr, &c->adl_res, &c->plan_blk, &c->ins_bits, &c->mm_bak, &c->cut_pos, &c->cut_bkt, &c->win_groups, &c->win_sg, &c->win_maps, &c->win_entries, &c->persist_bak, &c->resume_flag, &c->rle_tiles};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     if (c->crc_tab) (void)hipFree(c->crc_tab);

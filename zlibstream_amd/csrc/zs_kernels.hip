@@ -2664,499 +2664,9 @@ __global__ __launch_bounds__(64) void zs_fast_blocks_kernel(const StreamDesc *sd
     }
 }
 
-// ------------------------------------------------------------------ KV: DeflateFast for the lanes of a wave (zs_fast_vec.h)
-// One workgroup per stream.  All threads stage a tile -- bytes, K1's all-position links and the inserted-position bitmap
-// of [t0 - 32 512, t0 + 16 Ki) -- then wave 0 takes the stream through it 64 positions at a time: every lane searches its
-// position over the filtered chain (fv_search), the hops of the parse are followed through the lanes' results
-// (fv_resolve, v_readlane), the loop-tops' symbols leave with one compacted store and the window's inserted bits are
-// OR-ed into the bitmap.  Refill events (one per 32 KiB) are applied where the parse reaches their loop-top.  The state
-// it leaves -- loop-top, symbols, block cuts, fired events -- is what K4 / K5 leave for the lazy parse: the tail engine
-// and the block kernels go on from it (the tail rebuilds head / prev from the bitmap).
-struct FvLdsAcc {
-    const uint8_t *wb;    // bytes, index = position - lo
-    const uint16_t *wl;   // links, 0 = none
-    const uint32_t *bm;   // inserted bits, word k = positions [32 (bw0 + k), +32)
-    int64_t lo, bw0;
-    __device__ int link(int64_t c) const { return wl[c - lo]; }
-    __device__ bool ins(int64_t c) const { return (bm[(c >> 5) - bw0] >> (c & 31)) & 1u; }
-    __device__ int lcp(int64_t q, int64_t c) const {
-        const int a = (int)(q - lo), b = (int)(c - lo);
-        int len = 0;
-        while (len < kMaxMatch) {
-            const uint64_t x = lds_u64(wb, a + len) ^ lds_u64(wb, b + len);
-            if (x) {
-                len += (int)(__builtin_ctzll(x) >> 3);
-                break;
-            }
-            len += 8;
-        }
-        return len < kMaxMatch ? len : kMaxMatch;
-    }
-};
-struct FvLaneRes {  // the lanes' results, read by a wave-uniform lane index
-    int len, dist, touched;
-    __device__ FvResult operator()(int i) const {
-        const int k = __builtin_amdgcn_readfirstlane(i);
-        return FvResult{__builtin_amdgcn_readlane(len, k), __builtin_amdgcn_readlane(dist, k), __builtin_amdgcn_readlane(touched, k)};
-    }
-};
-// Candidate lists.  The chain a search walks is K1's all-position chain with the positions that were never inserted left
-// out, so everything about a position's candidates but their membership is a function of the data: once a tile is staged,
-// all 16 waves write for every position of it the first `list_m` entries of its chain -- distance and common-prefix length
-// with the position, (len - 2) << 16 | distance, 0 behind the last -- into the stream's list area.  The parsing wave then
-// has no chain to walk and no bytes to compare: a lane loads its position's entries (contiguous), tests their bits of the
-// inserted set and combines them in order (Longest_match, Deflate.cs:1022-1100: count against max_chain, first strictly
-// longer, stop at nice_match).  An entry at or above the window's first loop-top has no membership yet: such a lane is
-// *conditional*, and when the hops of the parse reach it as a loop-top the whole wave evaluates that one position again,
-// one entry per lane, with the set as it stands then -- instead of ending the window there (51 of 64 positions on text).
-// A list that ends before the search does (chains longer than list_m) is followed by the walk through the staged links.
-// NT threads; LL: K1's links of the tile staged in LDS (one workgroup per CU: 157 KiB), or read where they lie (62 KiB and, with
-// 512 threads, two workgroups -- two streams -- per CU: the kernel's time is its lone parsing wave's, so a batch of more
-// streams than CUs runs twice as many of them at a time; the lists' walks then hop through L2 / HBM, behind 7 to 14 % of
-// the time they had).
-template <int NT, bool LL, int TILE>
-__global__ __launch_bounds__(NT) void zs_fast_vec_kernel(const StreamDesc *sd, StreamState *st, uint16_t *link, uint32_t *syms,
-                                                           int32_t *blk_end, int32_t *blk_top, LevelCfg lv, int strategy, uint32_t *lists_g,
-                                                           int list_m) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    // (the tile: TILE positions behind 32 512 of history -- zs_device.h has the sizes for the 16 Ki-position one)
-    constexpr int fvBytes = kFvBack + TILE + kFvFwd, fvLinks = kFvBack + TILE, fvBitWords = fvLinks / 32 + 8;
-    const StreamDesc s = sd[blockIdx.x];
-    if (s.fv_end < 0) return;
-    uint8_t *wb = smem;
-    uint16_t *wl = LL ? (uint16_t *)(smem + fvBytes) : nullptr;
-    uint32_t *bm = (uint32_t *)(smem + fvBytes + (LL ? 2 * fvLinks : 0));
-    uint32_t *ent0 = bm + fvBitWords;  // the window's first 16 entries per lane (16 x 64 words), for the conditional lanes
-    uint32_t *pre0 = ent0 + 1024;       // the same for the 64 positions behind the window, asked for a window ahead
-    uint32_t *lists = lists_g + s.fv_list_off;
-    __shared__ int64_t sh_p, sh_nsyms, sh_trigger, sh_preins;
-    __shared__ int sh_k, sh_quit;
-    // (tried, round 3: the parsing wave a different wave of the workgroup from stream to stream, so that two workgroups on a
-    // CU would not have theirs on one SIMD -- no difference: 72.7 against 70.5 ms for 512 streams)
-    const int tid = threadIdx.x, lane = lane_id();
-    const int64_t n = s.n, body_end = s.fv_end;
-    const gcbytes in = as_global(s.in);
-    uint16_t *lk = link + s.pos_off;
-    uint32_t *gbits = s.ins_bits;
-    // read events of a single Write (zs_core.h): event k fires at the first loop-top >= E(k) - 261, E(k) = 64 Ki + 32 Ki (k - 1)
-    const int kl = s.kl;
-    if (tid == 0) sh_p = 0, sh_nsyms = 0, sh_k = 0, sh_quit = 0, sh_preins = -1, sh_trigger = kl >= 1 ? read_end_before(1) - (kMinLookahead - 1) : -1;
-    __syncthreads();
-    const bool aligned = (((uintptr_t)in) & 15) == 0;
-#ifdef ZS_FV_PROF
-    long long pf_stage = 0, pf_list = 0, pf_search = 0, pf_resolve = 0, pf_emit = 0, pf_windows = 0, pf_iters = 0, pf_conds = 0, pf_t;
-#define PF_T0() pf_t = wall_clock64()
-#define PF_ADD(x) { const long long now_ = wall_clock64(); x += now_ - pf_t; pf_t = now_; }
-#else
-#define PF_T0()
-#define PF_ADD(x)
-#endif
-    for (;;) {
-        const int64_t p_in = sh_p;
-        if (p_in > body_end || sh_quit) break;
-        const int64_t t0 = p_in & ~31LL, lo = t0 - kFvBack, bw0 = lo >> 5;  // lo is a multiple of 32: bitmap words line up
-        // a link, by index = position - lo (never below position 0); where they are not staged: read past L1 -- the parsing wave
-        // cuts links (an equal-bucket read) that it and, a tile later, the other waves then walk
-        auto LK = [&](int c) -> int { return LL ? (int)wl[c] : (int)__hip_atomic_load(lk + lo + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
-        PF_T0();
-        // ---- stage the tile
-        for (int i = tid; i < fvBytes / 16; i += NT) {
-            const int64_t a = lo + (int64_t)i * 16;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (a >= 0 && a + 15 < n && aligned) {
-                const u32x4 t = *(gcu32x4)(in + a);
-                v = make_uint4(t[0], t[1], t[2], t[3]);
-            } else if (a + 15 >= 0 && a < n) {
-                uint32_t t[4] = {0, 0, 0, 0};
-                for (int k = 0; k < 16; k++) {
-                    const int64_t b = a + k;
-                    if (b >= 0 && b < n) t[k >> 2] |= (uint32_t)in[b] << (8 * (k & 3));
-                }
-                v = make_uint4(t[0], t[1], t[2], t[3]);
-            }
-            ((uint4 *)wb)[i] = v;
-        }
-        for (int i = tid; LL && i < fvLinks / 8; i += NT) {
-            const int64_t a = lo + (int64_t)i * 8;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (a >= 0 && a + 7 < n) {
-                v = *(const uint4 *)(lk + a);
-            } else if (a + 7 >= 0 && a < n) {
-                uint32_t t[4] = {0, 0, 0, 0};
-                for (int k = 0; k < 8; k++) {
-                    const int64_t b = a + k;
-                    if (b >= 0 && b < n) t[k >> 1] |= (uint32_t)lk[b] << (16 * (k & 1));
-                }
-                v = make_uint4(t[0], t[1], t[2], t[3]);
-            }
-            ((uint4 *)wl)[i] = v;
-        }
-        for (int i = tid; i < fvBitWords; i += NT) bm[i] = bw0 + i >= 0 ? gbits[bw0 + i] : 0u;
-        __syncthreads();
-        PF_ADD(pf_stage);
-        // ---- the candidate lists of the tile's positions [t0, t0 + TILE): list i at lists[i * list_m ..]
-        {
-            const int min_i = (int)(1 - lo);  // position 0 is never a candidate
-            for (int i = tid; i < TILE; i += NT) {
-                const int64_t q = t0 + i;
-                uint32_t *dst = lists + (size_t)i * (size_t)list_m;
-                if (q > body_end) continue;
-                const int qi = (int)(q - lo);
-                const uint64_t scan8 = lds_u64(wb, qi);
-                int c = qi, e = 0;
-                while (e < list_m) {
-                    const int l = LK(c);
-                    const int nc = c - l, d = qi - nc;
-                    if (l == 0 || nc < min_i || d > kMaxDist) break;
-                    c = nc;
-                    const uint64_t x = lds_u64(wb, c) ^ scan8;
-                    int len = x ? (int)(__builtin_ctzll(x) >> 3) : 8;
-                    if (!x) {
-                        while (len < kMaxMatch) {
-                            const uint64_t y = lds_u64(wb, qi + len) ^ lds_u64(wb, c + len);
-                            if (y) {
-                                len += (int)(__builtin_ctzll(y) >> 3);
-                                break;
-                            }
-                            len += 8;
-                        }
-                        len = len < kMaxMatch ? len : kMaxMatch;
-                    }
-                    dst[e++] = (uint32_t)d | ((uint32_t)(len >= kMinMatch ? len - 2 : 0) << 16);
-                }
-                if (e < list_m) dst[e] = 0;
-            }
-        }
-        __threadfence_block();
-        __syncthreads();
-        PF_ADD(pf_list);
-        if (tid < 64) {
-            FvLdsAcc acc{wb, wl, bm, lo, bw0};
-            int64_t p0 = p_in, nsyms = sh_nsyms, trigger = sh_trigger, preins = sh_preins;
-            int k_fired = sh_k;
-            const bool search = strategy != kHuffmanOnly;
-            const uint32_t *bmr = bm - (lo >> 5) + bw0;  // bmr[(rel index) >> 5] with rel = position - lo: lo is a multiple of 32
-            const int nice = lv.nice, chain = lv.chain;
-            const int min_i = (int)(1 - lo);  // position 0 is never a candidate
-            // an equal-bucket event of this tile cuts the chain behind its loop-top (below); the lists were made before: an entry
-            // at the cut is the last one of its list that counts
-            int cut_i = -1;
-            long tile_walk = 0, tile_windows = 0;  // steps of the walks behind the lists' ends, windows
-            // the first 16 entries of the positions [pf_base, pf_base + 64) wait in pre0: a lane's loads from the list area are a
-            // round trip to L2 (~2 us per window when every window paid it); the loads for the positions behind a window leave at
-            // its start and land in pre0 at its end, and the next window -- which starts there or a few positions on --
-            // takes its lists from LDS
-            int64_t pf_base = -(1ll << 40);
-            while (p0 <= body_end && p0 + kFvLanes <= t0 + TILE) {
-                bool dead0 = false, dead1 = false, only1 = false;
-                if (trigger >= 0 && p0 >= trigger) {
-                    // the read event at loop-top p0: p0 + 1 is inserted first (Deflate.cs:1010-1013)
-                    k_fired++;
-                    preins = p0 + 1;
-                    if (lane == 0) atomicOr(&bm[((p0 + 1) >> 5) - bw0], 1u << ((p0 + 1) & 31));
-                    if (LK((int)(p0 + 1 - lo)) == 1) {
-                        dead0 = true, only1 = true;
-                        if (lane == 0) {
-                            if (LL) wl[p0 - lo] = 0;
-                            lk[p0] = 0;
-                            if (!LL) __threadfence();
-                        }  // the reference's prev[p0] = p0 + 1, prev[p0 + 1] = p0
-                        cut_i = (int)(p0 - lo);
-                    } else {
-                        dead1 = true;
-                    }
-                    trigger = k_fired < kl ? read_end_before(k_fired + 1) - (kMinLookahead - 1) : -1;
-                }
-                int limit = kFvLanes;
-                if (body_end - p0 + 1 < limit) limit = (int)(body_end - p0 + 1);
-                const int qi = (int)(p0 - lo) + lane, p0i = (int)(p0 - lo);
-                const bool dead = !search || lane >= limit || (lane == 0 && dead0) || (lane == 1 && dead1);
-                const bool only_prev = search && lane == 1 && only1;  // (HuffmanOnly: Longest_match is never called, Deflate.Fast.cs:61-66)
-                int found = 0, best = 2, bdist = 0, cond = 0;
-                int done = (dead || only_prev) ? 1 : 0;
-                if (only_prev && lane < limit) {
-                    const int len = acc.lcp(p0 + lane, p0 + lane - 1);
-                    if (len > 2) best = len, bdist = 1;
-                }
-                // ---- every lane combines its position's entries, 16 at a time
-                const uint32_t *mine = lists + (size_t)(p0 - t0 + lane) * (size_t)list_m;
-                int last_d = 0, listed = 0;  // where the list ended, for the walk that may have to go on
-
-                for (int k0 = 0; k0 < list_m; k0 += 16) {
-                    if (!__ballot(!done)) break;
-                    uint4 ev[4];
-                    const int64_t pidx = p0 + lane - pf_base;
-                    if (k0 == 0 && pidx >= 0 && pidx < 64) {
-#pragma unroll
-                        for (int u = 0; u < 4; u++) ev[u] = done ? make_uint4(0, 0, 0, 0) : *(const uint4 *)(pre0 + pidx * 16 + 4 * u);
-                    } else {
-#pragma unroll
-                        for (int u = 0; u < 4; u++) ev[u] = done ? make_uint4(0, 0, 0, 0) : *(const uint4 *)(mine + k0 + 4 * u);
-                    }
-                    const uint32_t *e16 = (const uint32_t *)ev;
-                    if (k0 == 0) {
-#pragma unroll
-                        for (int u = 0; u < 4; u++) *(uint4 *)(ent0 + lane * 16 + 4 * u) = ev[u];
-                    }
-                    uint32_t word[16];
-#pragma unroll
-                    for (int j = 0; j < 16; j++) {
-                        const int d = (int)(e16[j] & 0xFFFFu);
-                        const int nc = d ? qi - d : qi;
-                        word[j] = bmr[nc >> 5] >> (nc & 31);
-                    }
-#pragma unroll
-                    for (int j = 0; j < 16; j++) {
-                        const int d = (int)(e16[j] & 0xFFFFu), lenc = (int)(e16[j] >> 16);
-                        const int maxd = found ? kMaxDist - 1 : kMaxDist;  // hash_head: <= MAX_DIST; later: cur_match > limit
-                        const int valid = (done == 0) & (d != 0) & (d <= maxd);
-                        const int recent = valid & (qi - d >= p0i);  // no membership yet: the lane is conditional
-                        cond |= recent;
-                        const int go = valid & (recent ^ 1);
-                        done |= go ^ 1;
-                        last_d = go ? d : last_d;
-                        listed += go;
-                        const int isin = go & (int)(word[j] & 1u);
-                        const int len = lenc ? lenc + 2 : 2;
-                        found += isin;
-                        const int better = isin & (len > best);
-                        best = better ? len : best;
-                        bdist = better ? d : bdist;
-                        done |= (better & (len >= nice)) | (isin & (found >= chain)) | (go & (qi - d == cut_i));
-                    }
-                }
-                // ---- the loads for the 64 positions behind the window leave now (a wave's loads return in order: ahead of the
-                //      window's own they would be waited for with them) and are stored at the window's end
-                uint4 nx[4];
-                {
-                    const bool nx_ok = p0 + 64 + lane <= body_end && p0 + 128 <= t0 + TILE;
-                    const uint32_t *ahead = mine + (size_t)64 * (size_t)list_m;
-#pragma unroll
-                    for (int u = 0; u < 4; u++) nx[u] = nx_ok ? *(const uint4 *)(ahead + 4 * u) : make_uint4(0, 0, 0, 0);
-                }
-                // ---- a list that ended before the search did: on through the staged links (the walk the lists replaced)
-                {
-                    const int more = (done == 0) & (listed == list_m);
-                    done |= more ^ 1;
-                    if (__ballot(!done)) {
-                        const uint64_t scan8 = lds_u64(wb, qi);
-                        int c = more ? qi - last_d : qi, l = LK(c);
-                        while (__ballot(!done)) {
-#ifdef ZS_FV_PROF
-                            pf_iters++;
-#endif
-                            tile_walk++;
-                            const int nc = c - l, d = qi - nc;
-                            const int maxd = found ? kMaxDist - 1 : kMaxDist;
-                            const int valid = (done == 0) & (l != 0) & (nc >= min_i) & (d <= maxd);
-                            const int recent = valid & (nc >= p0i);
-                            cond |= recent;
-                            const int go = valid & (recent ^ 1);
-                            done |= go ^ 1;
-                            const int cc = go ? nc : qi;  // lanes that are done read their own position (in range)
-                            l = LK(cc);
-                            uint32_t word = bmr[cc >> 5];
-                            uint64_t c8 = lds_u64(wb, cc);
-                            asm volatile("" : "+v"(l), "+v"(word), "+v"(c8));
-                            const uint64_t x = c8 ^ scan8;
-                            c = cc;
-                            const int isin = go & (int)((word >> (cc & 31)) & 1u);
-                            int len = x ? (int)(__builtin_ctzll(x) >> 3) : 8;
-                            if (__ballot(isin && !x)) {
-                                if (isin && !x) {
-                                    while (len < kMaxMatch) {
-                                        const uint64_t y = lds_u64(wb, qi + len) ^ lds_u64(wb, cc + len);
-                                        if (y) {
-                                            len += (int)(__builtin_ctzll(y) >> 3);
-                                            break;
-                                        }
-                                        len += 8;
-                                    }
-                                    len = len < kMaxMatch ? len : kMaxMatch;
-                                }
-                            }
-                            found += isin;
-                            const int better = isin & (len > best);
-                            best = better ? len : best;
-                            bdist = better ? d : bdist;
-                            done |= (better & (len >= nice)) | (isin & (found >= chain));
-                        }
-                    }
-                }
-                FvResult r{best, bdist, 0};
-                PF_ADD(pf_search);
-                // ---- the hops of the parse through the lanes' results, followed on the scalar unit (v_readlane of the hop
-                //      length).  A conditional lane that turns out to be a loop-top is evaluated again first, by the whole wave,
-                //      one entry per lane, with the set as it stands: the loop-tops so far put their bits in, then the entries
-                //      are combined by ballots.  Lanes that end the window -- an event loop-top, beyond the limit -- stop it.
-                int adv = r.len >= kMinMatch ? r.len : 1;
-                const bool stopl = lane >= limit || (lane > 0 && trigger >= 0 && p0 + lane >= trigger);
-                const uint64_t stops = __ballot(stopl), conds = __ballot(cond != 0);
-                uint64_t tops = 0, flushed = 0;
-                int advance = 0;
-                auto flush_bits = [&](uint64_t which) {  // the loop-top, and the inside of its match when that is short (Deflate.Fast.cs:81-104)
-                    if ((which >> lane) & 1ull) {
-                        const int64_t pos = p0 + lane;
-                        const bool match = r.len >= kMinMatch;
-                        const uint64_t m = (match && r.len <= lv.lazy ? (1ull << r.len) - 1 : 1ull) << (pos & 31);
-                        atomicOr(&bm[(pos >> 5) - bw0], (uint32_t)m);
-                        if (m >> 32) atomicOr(&bm[(pos >> 5) - bw0 + 1], (uint32_t)(m >> 32));
-                    }
-                };
-                while (advance < 64 && !((stops >> advance) & 1ull)) {
-                    {
-                        // the plain hops in a loop of their own: bit test, mark, v_readlane, add
-                        const uint64_t special = stops | conds;
-                        while (advance < 64 && !((special >> advance) & 1ull)) {
-                            tops |= 1ull << advance;
-                            advance += __builtin_amdgcn_readlane(adv, advance);
-                        }
-                        if (advance >= 64 || ((stops >> advance) & 1ull)) break;
-                    }
-                    if ((conds >> advance) & 1ull) {
-#ifdef ZS_FV_PROF
-                        pf_conds++;
-#endif
-                        flush_bits(tops & ~flushed);
-                        flushed = tops;
-                        // position p0 + advance again, entry `lane` of each batch of 64 on lane `lane`
-                        const int qa = p0i + advance;
-                        int ufound = 0, ubest = 2, ubdist = 0, ustop = 0, ulast = 0, ulisted = 0;
-                        const uint32_t *its = lists + (size_t)(p0 - t0 + advance) * (size_t)list_m;
-                        for (int k0 = 0; k0 < list_m && !ustop; k0 += 64) {  // (uniform: every lane the same trip count)
-                            uint32_t e = 0;
-                            if (k0 + lane < list_m) e = (k0 == 0 && lane < 16) ? ent0[advance * 16 + lane] : its[k0 + lane];
-                            const int d = (int)(e & 0xFFFFu), lenc = (int)(e >> 16);
-                            const uint64_t term = __ballot(d == 0);  // the list's end (lanes past list_m read 0)
-                            int nent = term ? (int)__builtin_ctzll(term) : 64;
-                            const uint64_t atcut = __ballot(d != 0 && qa - d == cut_i);  // the chain is cut behind this entry
-                            bool cut_end = false;
-                            if (atcut && (int)__builtin_ctzll(atcut) < nent) nent = (int)__builtin_ctzll(atcut) + 1, cut_end = true;
-                            const int nc = d ? qa - d : qa;
-                            const uint32_t bit = (bmr[nc >> 5] >> (nc & 31)) & 1u;
-                            const uint64_t in_all = __ballot(lane < nent && bit);
-                            const int pre = ufound + (int)__builtin_popcountll(in_all & lanemask_lt());
-                            // an entry at MAX_DIST counts only as the first candidate found
-                            const bool isin = ((in_all >> lane) & 1ull) && (d < kMaxDist || pre == 0);
-                            const int len = lenc ? lenc + 2 : 2;
-                            const uint64_t in_m = __ballot(isin);
-                            // the search ends with the first candidate of nice length (it is longer than everything before it) or
-                            // with the max_chain-th candidate
-                            const uint64_t stoppers = __ballot(isin && (len >= nice || pre + 1 >= chain));
-                            const int cut = stoppers ? (int)__builtin_ctzll(stoppers) : 63;
-                            const uint64_t elig = in_m & (cut >= 63 ? ~0ull : ((2ull << cut) - 1ull));
-                            // the longest among them, the first of that length (a later one must be strictly longer to win)
-                            uint64_t cand = elig;
-                            int bl = 0;
-#pragma unroll
-                            for (int bbit = 8; bbit >= 0; bbit--) {
-                                const uint64_t mk = __ballot(((cand >> lane) & 1ull) && ((len >> bbit) & 1)) & cand;
-                                if (mk) cand = mk, bl |= 1 << bbit;
-                            }
-                            if (cand && bl > ubest) {
-                                const int w = (int)__builtin_ctzll(cand);
-                                ubest = bl, ubdist = __builtin_amdgcn_readlane(d, w);
-                            }
-                            ufound += (int)__builtin_popcountll(elig);
-                            ulisted += nent;
-                            if (nent > 0) ulast = __builtin_amdgcn_readlane(d, nent - 1);
-                            if (stoppers || cut_end) ustop = 1;
-                            if (nent < 64) break;  // the list's end (its terminator, or entry list_m)
-                        }
-                        if (!ustop && ulisted == list_m) {
-                            // the list ended before the search did: on through the staged links, every lane the same walk
-                            const uint64_t s8 = lds_u64(wb, qa);
-                            int c = qa - ulast;
-                            for (;;) {
-                                tile_walk++;
-                                const int l = LK(c);
-                                const int nc = c - l, d = qa - nc;
-                                if (l == 0 || nc < min_i || d > (ufound ? kMaxDist - 1 : kMaxDist)) break;
-                                c = nc;
-                                if (!((bmr[c >> 5] >> (c & 31)) & 1u)) continue;
-                                ufound++;
-                                const uint64_t x = lds_u64(wb, c) ^ s8;
-                                int len = x ? (int)(__builtin_ctzll(x) >> 3) : 8;
-                                if (!x) {
-                                    while (len < kMaxMatch) {
-                                        const uint64_t y = lds_u64(wb, qa + len) ^ lds_u64(wb, c + len);
-                                        if (y) {
-                                            len += (int)(__builtin_ctzll(y) >> 3);
-                                            break;
-                                        }
-                                        len += 8;
-                                    }
-                                    len = len < kMaxMatch ? len : kMaxMatch;
-                                }
-                                if (len > ubest) {
-                                    ubest = len, ubdist = d;
-                                    if (len >= nice) break;
-                                }
-                                if (ufound >= chain) break;
-                            }
-                        }
-                        if (lane == advance) r.len = ubest, r.dist = ubdist, adv = ubest >= kMinMatch ? ubest : 1;
-                    }
-                    tops |= 1ull << advance;
-                    advance += __builtin_amdgcn_readlane(adv, advance);
-                }
-                flush_bits(tops & ~flushed);
-                {
-                    // (the chunk loop above has read pre0 for this window; nothing reads it again before the next window)
-                    const bool have = p0 + 128 <= t0 + TILE;
-#pragma unroll
-                    for (int u = 0; u < 4; u++) *(uint4 *)(pre0 + lane * 16 + 4 * u) = nx[u];
-                    pf_base = have ? p0 + 64 : -(1ll << 40);
-                }
-                PF_ADD(pf_resolve);
-                // ---- the loop-tops' symbols, compacted; block cuts every kBlockSyms symbols (Deflate.cs:910-948)
-                if ((tops >> lane) & 1ull) {
-                    const int64_t g = nsyms + __builtin_popcountll(tops & lanemask_lt());
-                    const bool match = r.len >= kMinMatch;
-                    syms[s.sym_off + g] = match ? (((uint32_t)r.dist << 16) | (uint32_t)(r.len - 3)) : (uint32_t)wb[p0 + lane - lo];
-                    if ((g + 1) % kBlockSyms == 0) {
-                        blk_end[s.blk_off + g / kBlockSyms] = (int32_t)(p0 + lane + (match ? r.len : 1));
-                        blk_top[s.blk_off + g / kBlockSyms] = (int32_t)(p0 + lane);
-                    }
-                }
-                nsyms += __builtin_popcountll(tops);
-                p0 += advance;
-                tile_windows++;
-                PF_ADD(pf_emit);
-#ifdef ZS_FV_PROF
-                pf_windows++;
-#endif
-            }
-            // Data whose matches are long inserts little (Deflate.Fast.cs:81-104), and a search then walks hundreds of chain
-            // entries that were never inserted to find max_chain that were: the lists and the walks behind them are the wrong
-            // tool there (kennedy.xls: 0.2 MB/s).  The literal engine, whose prev[] holds the inserted positions only, is not
-            // fast but it is steady: a tile whose windows needed more than kFvQuitWalk steps each hands the rest of the
-            // stream to it (the tail kernel goes on from any loop-top; it restores its chains from the bitmap).
-            if (tile_windows > 16 && tile_walk > (long)kFvQuitWalk * tile_windows) sh_quit = 1;
-            // ---- leave the tile: the bitmap words that changed go back to the stream's bitmap
-            for (int64_t wd = (p_in >> 5) + lane; wd <= (p0 + 96) >> 5; wd += 64)
-                if (wd - bw0 < fvBitWords) gbits[wd] = bm[wd - bw0];
-            if (lane == 0) sh_p = p0, sh_nsyms = nsyms, sh_trigger = trigger, sh_preins = preins, sh_k = k_fired;
-        }
-        __threadfence_block();
-        __syncthreads();
-    }
-#ifdef ZS_FV_PROF
-    if (tid == 0 && blockIdx.x == 0)
-        printf("FVPROF n=%lld windows=%lld walk iterations=%lld conditional loop-tops=%lld ticks(100MHz): stage=%lld lists=%lld search=%lld resolve=%lld emit=%lld\n", (long long)n, pf_windows,
-               pf_iters, pf_conds, pf_stage, pf_list, pf_search, pf_resolve, pf_emit);
-#endif
-    if (tid == 0) {
-        StreamState &ss = st[blockIdx.x];
-        ss.tail_p = (int32_t)sh_p;
-        ss.tail_kind = kR;
-        ss.tail_pend = 0;
-        ss.k_done = sh_k;
-        ss.preins = (int32_t)sh_preins;
-        ss.body_syms = (uint32_t)sh_nsyms;
-    }
-}
-
+// ------------------------------------------------------------------ KS: DeflateFast (levels 1-3) as window-wide sweeps of a workgroup
+// (round 3's form -- one wave taking the stream through windows of 64 positions over per-position candidate lists, zs_fast_vec.h,
+// which the CPU model still runs as mode "fvec" -- did 9 MB/s on one stream and moved 76x the algorithmic bytes through HBM)
 #include "zs_fast_sweep.hip"
 #include "zs_rle.hip"
 
