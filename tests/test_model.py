@@ -90,6 +90,27 @@ def test_fast_levels_for_the_lanes_of_a_wave(model, tmp_path):
             run(files[name], 1 + (w // 64) % 3, 0, "fsweep", env={"ZS_FS_W": str(w), "ZS_FS_TILE": str(tile)})
 
 
+def test_rle_strategy_from_the_runs_of_equal_bytes(model, tmp_path):
+    """CompressionStrategy.Rle (Deflate.Rle.cs:18-104) as the device does it (zs_rle.h): a position's part in the parse from where
+    its run of equal bytes began -- symbols, block cuts (stored-block permission by the window base under the Rle refill
+    threshold of 258) and bytes against the oracle; the hand-over to the literal engine at the first loop-top at or behind
+    rle_body_end.  Text (runs of one), a bitmap, long and short runs, zeros, sizes around the window ends."""
+    rng = np.random.default_rng(23)
+    files = {"ptt5": model["ptt5"], "cp.html": model["cp.html"], "runs": model["runs"]}
+    extra = {"zeros300k": bytes(300000),
+             "long": np.repeat(rng.integers(0, 4, 20000, dtype=np.uint8), rng.integers(1, 700, 20000))[:1500000].tobytes(),
+             "short": np.repeat(rng.integers(0, 3, 300000, dtype=np.uint8), rng.integers(1, 6, 300000))[:500001].tobytes()}
+    for n in (4096 + 786, 65536, 65536 + 258, 65536 + 32768 - 258 + 600, 98304 + 600, 131072 + 522):
+        extra["z%d" % n] = bytes(n)
+        extra["r%d" % n] = np.repeat(rng.integers(0, 3, n, dtype=np.uint8), rng.integers(1, 400, n))[:n].tobytes()
+    for k, v in extra.items():
+        (tmp_path / k).write_bytes(v)
+        files[k] = str(tmp_path / k)
+    for name, path in files.items():
+        for level in (1, 6, 9):
+            run(path, level, 3, "rle")
+
+
 def test_resumed_runs_in_the_chunked_form(model, tmp_path):
     """A stream flushed after its first F bytes (Deflate.cs:583-613), the rest one Write: the first Write on the literal engine,
     the run behind the flush laid out by build_geometry's GeoStart::at_read -- its first pass through the loop reads, with a
