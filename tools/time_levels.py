@@ -31,7 +31,7 @@ if not ONLY_SMALL:
     run("english64", e64, 0, reps=3)   # DeflateStored: host-planned blocks + copy kernel
     run("sparse64", sp, 0, reps=3)
 
-# many streams at the fast levels: one workgroup per stream (zs_fast_vec_kernel), all streams at once
+# many streams at the fast levels: one workgroup per stream (zs_fast_sweep_kernel), all streams at once
 def run_batch(name, bufs, level, reps=1):
     d_ins = [torch.frombuffer(bytearray(b), dtype=torch.uint8).cuda() for b in bufs]
     caps = [deflate_bound(len(b)) for b in bufs]

@@ -1191,7 +1191,7 @@ const char *zs_ctx_stage_name(const zs_ctx *c, int s) {
     if (c && c->last_op == 1) return s >= 0 && s < 6 ? inf_names[s] : "";
     // levels 1-3: DeflateFast for the lanes of a wave runs where the lazy parse has its expand stage, and the speculative
     // chunk runs (run / verify / stitch) are timed with the tail engine
-    if (c && c->last_op == 2 && s == kStExpand) return "fast_vec";
+    if (c && c->last_op == 2 && s == kStExpand) return "fast_sweep";
     if (c && c->last_op == 2 && s == kStTail) return "fast_runs+tail";
     return s >= 0 && s < kStCount ? kStageNames[s] : "";
 }
