@@ -251,64 +251,42 @@ __global__ __launch_bounds__(NT) void zs_fast_sweep_kernel(const StreamDesc *sd,
             if (qi - (int)(wl[qi] & 0x7FFFu) < gi + w0r) exact = kFsExact;  // (no link: 0x7FFF, below anything)
             uint32_t l = gl[q & (RING - 1)];
             if (only_prev) l = 1, rem = 1;                 // the search sees only q - 1 (equal-bucket refill), whatever the set says
-            // Two kinds of trips (as in the match kernel, K2).  A *step* takes every walking lane to its next chain entry and, if
-            // that is in the set, looks at the two bytes a longer match would have to share with the scan at [best - 1, best]
-            // (Longest_match's own first test, Deflate.cs:1048-1056: a candidate that fails it cannot beat `best`, but it
-            // counts against max_chain): ~25 instructions.  Lanes whose candidate passes wait; once half as many wait as
-            // walk, one *compare* trip (~40 instructions) serves them all.  With the compare inside every step a trip was
-            // ~50 instructions whatever its lanes needed (level 3, chains of 32: 85 % of a sweep).
-            int st = walking ? 1 : 0;  // 1: walking; 2: at a candidate that passed the test
-            uint32_t scan_end = (uint32_t)(scan8 >> 8) & 0xFFFFu;  // the scan's bytes [best - 1, best]
-            for (;;) {
-                const int nwalk = (int)__builtin_popcountll(__ballot(st == 1)), npend = (int)__builtin_popcountll(__ballot(st == 2));
-                if (!(nwalk | npend)) break;
+            while (__ballot(walking)) {
 #ifdef ZS_FS_PROF
                 pf_skips++;
 #endif
-                if (nwalk && 2 * npend < nwalk) {
-                    if (st == 1) {
-                        const int nc = c - (int)l;
-                        if (qi - nc > maxd) {
-                            st = 0;
-                        } else {
-                            const uint32_t v = wl[nc];
-                            c = nc, l = nc >= gi + w0r ? (uint32_t)gl[(lo + nc) & (RING - 1)] : v & 0x7FFFu;  // (inside the window: the guess's link)
-                            if ((v >> 15) || only_prev) {
-                                maxd = kMaxDist - 1;
-                                if ((lds_u32(wb, nc + best - 1) & 0xFFFFu) == scan_end || only_prev) st = 2;
-                                else if (--rem == 0) st = 0;
-                            } else if (l == 1u) {
-                                c = fs_run_skip(nc, bm, rb);
+                if (walking) {
+                    const int nc = c - (int)l, d = qi - nc;
+                    if (d > maxd) {
+                        walking = false;
+                    } else {
+                        const uint32_t v = wl[nc];
+                        c = nc, l = nc >= gi + w0r ? (uint32_t)gl[(lo + nc) & (RING - 1)] : v & 0x7FFFu;  // (inside the window: the guess's link)
+                        if ((v >> 15) || only_prev) {
+                            const uint64_t x = lds_u64(wb, nc) ^ scan8;
+                            int len = (int)(__builtin_ctzll(x) >> 3);
+                            if (!x) {
+                                len = 8;
+                                while (len < kMaxMatch) {
+                                    const uint64_t y = lds_u64(wb, qi + len) ^ lds_u64(wb, nc + len);
+                                    if (y) {
+                                        len += (int)(__builtin_ctzll(y) >> 3);
+                                        break;
+                                    }
+                                    len += 8;
+                                }
+                                len = len < kMaxMatch ? len : kMaxMatch;
                             }
+                            maxd = kMaxDist - 1;
+                            if (len > best) {
+                                best = len, bdist = d;
+                                if (len >= nice) walking = false;
+                            }
+                            if (--rem == 0) walking = false;
+                        } else if (l == 1u) {
+                            c = fs_run_skip(nc, bm, rb);
                         }
                     }
-                    continue;
-                }
-#ifdef ZS_FS_PROF
-                pf_cmps++;
-#endif
-                if (st == 2) {
-                    const uint64_t x = lds_u64(wb, c) ^ scan8;
-                    int len = (int)(__builtin_ctzll(x) >> 3);
-                    if (!x) {
-                        len = 8;
-                        while (len < kMaxMatch) {
-                            const uint64_t y = lds_u64(wb, qi + len) ^ lds_u64(wb, c + len);
-                            if (y) {
-                                len += (int)(__builtin_ctzll(y) >> 3);
-                                break;
-                            }
-                            len += 8;
-                        }
-                        len = len < kMaxMatch ? len : kMaxMatch;
-                    }
-                    st = 1;
-                    if (len > best) {
-                        best = len, bdist = qi - c;
-                        scan_end = lds_u32(wb, qi + len - 1) & 0xFFFFu;
-                        if (len >= nice) st = 0;
-                    }
-                    if (--rem == 0) st = 0;
                 }
             }
         }
