@@ -276,5 +276,65 @@ int main(int argc, char **argv) {
         pct(progress, "positions made final per sweep");
         return 0;
     }
+    if (mode == "chunks") {
+        // the stream cut into chunks of C positions, all parsed at once round after round: chunk k starts at the loop-top its
+        // predecessor left through in the round before and reads the bits below it as that round left them; a chunk runs again
+        // only if something it reads has changed.  A round without a change is the fixed point, which is the sequential parse
+        // (induction from chunk 0, which reads nothing).
+        const int64_t C = atoll(argv[4]);
+        const int64_t nch = be / C + 1;
+        const int64_t back = (kMaxDist + 300 + C - 1) / C + 1;  // chunks whose bits a chunk may read
+        std::vector<uint8_t> prev((size_t)n + 600, 1), next, S((size_t)n + 600, 0);
+        std::vector<int64_t> ent((size_t)nch), ext((size_t)nch, -1), ent_used((size_t)nch, -1);
+        for (int64_t k = 0; k < nch; k++) ent[(size_t)k] = k * C;
+        std::vector<uint8_t> changed((size_t)nch, 1), ch2((size_t)nch, 0);
+        long runs = 0;
+        int rounds = 0;
+        for (;;) {
+            next = prev;
+            std::fill(ch2.begin(), ch2.end(), 0);
+            long active = 0, wrongbits = 0;
+            for (int64_t k = 0; k < nch; k++) {
+                bool act = rounds == 0;
+                for (int64_t j = std::max<int64_t>(0, k - back); j < k && !act; j++) act = changed[(size_t)j];
+                if (!act) continue;
+                active++;
+                const int64_t e = k == 0 ? 0 : (rounds == 0 ? k * C : ext[(size_t)k - 1]);
+                const int64_t hi = std::min<int64_t>((k + 1) * C, be + 1);
+                const int64_t lo = std::max<int64_t>(0, e - kMaxDist - 300);
+                std::copy(prev.begin() + lo, prev.begin() + e, S.begin() + lo);
+                std::fill(S.begin() + e, S.begin() + std::min<int64_t>(hi + 600, n + 600), 0);
+                int64_t t = e;
+                while (t < hi) {
+                    const uint32_t x = cx.eval(t, S);
+                    cx.mark(S, t, x);
+                    t += cx.adv(x);
+                }
+                // what it leaves: its bits on [e, t), its exit
+                bool diff = t != ext[(size_t)k] || e != ent_used[(size_t)k];
+                for (int64_t p = e; p < t; p++) {
+                    if (next[(size_t)p] != S[(size_t)p]) diff = true;
+                    next[(size_t)p] = S[(size_t)p];
+                }
+                ent_used[(size_t)k] = e;
+                ext[(size_t)k] = t;
+                ch2[(size_t)k] = diff;
+            }
+            rounds++;
+            runs += active;
+            long nchanged = 0;
+            for (int64_t k = 0; k < nch; k++) nchanged += ch2[(size_t)k];
+            for (int64_t p = 0; p <= be; p++) wrongbits += next[(size_t)p] != truth[(size_t)p];
+            printf("  round %d: %ld of %lld chunks ran, %ld changed what they leave, %ld wrong bits\n", rounds, active, (long long)nch, nchanged, wrongbits);
+            prev.swap(next);
+            changed = ch2;
+            if (!nchanged) break;
+            if (rounds > 4000) break;
+        }
+        long wrong = 0;
+        for (int64_t p = 0; p <= be; p++) wrong += prev[(size_t)p] != truth[(size_t)p];
+        printf("chunks C=%lld: %lld chunks, %d rounds, %.2f runs per chunk, wrong bits at the end %ld\n", (long long)C, (long long)nch, rounds, (double)runs / (double)nch, wrong);
+        return wrong ? 1 : 0;
+    }
     return 2;
 }

@@ -421,6 +421,198 @@ static void parse_fast_sweep(Model &m, int64_t &p_out, int &kdone_out, int64_t &
 }
 
 
+// ---- DeflateFast as rounds over the chunks of a stream (zs_fast_sweep.h, "Rounds"): what zs_fast_sweep_kernel does in its
+//      chunk form and zs_fast_commit_kernel behind it.  Every chunk of a round reads what the round before left -- the
+//      entry loop-top, the bits below it from the planes of the chunks that own them, the cuts of equal-bucket events --
+//      and leaves its own; K1's links are only read (a chunk works on its own copy).
+struct FrAcc {
+    const Model *m;
+    const uint16_t *lnk;
+    const uint8_t *ins_;
+    int64_t lo;
+    int link(int64_t c) const { return c < lo ? 0 : (int)lnk[(size_t)c]; }
+    bool ins(int64_t c) const { return ins_[(size_t)c] != 0; }
+    int lcp(int64_t q, int64_t c) const { return m->lcp(q, c); }
+};
+static void parse_fast_rounds(Model &m, int64_t &p_out, int &kdone_out, int64_t &preins_out) {
+    const int W = 1024, kBack = 32512;
+    const int target = getenv("ZS_FR_CHUNK") ? atoi(getenv("ZS_FR_CHUNK")) : 4096;
+    const int kl = (int)m.rev.size() - 1;
+    std::vector<FsChunk> ch;
+    fs_build_chunks(0, m.body_end, kl, target, ch);
+    const int nch = (int)ch.size();
+    const size_t N = (size_t)m.n + 4096;
+    std::vector<uint8_t> plane[2][2];
+    for (auto &a : plane)
+        for (auto &b : a) b.assign(N, 0);
+    std::vector<FsMeta> meta[2];
+    meta[0].assign((size_t)nch, FsMeta{-1, -1, 0, -1, 0, -1, 0, 0});
+    meta[1] = meta[0];
+    std::vector<std::vector<uint32_t>> prov((size_t)nch);
+    std::vector<uint16_t> lnk(N, 0);
+    std::vector<uint8_t> ins(N, 1);
+    std::vector<uint32_t> rprev(N, kFsFresh), rcur((size_t)W + 64);
+    const bool search = m.strategy != kHuffmanOnly;
+    long runs = 0;
+    int round = 0;
+    for (;; round++) {
+        const std::vector<FsMeta> &mp = meta[(round + 1) & 1];
+        std::vector<FsMeta> &mn = meta[round & 1];
+        int nchanged = 0;
+        for (int k = 0; k < nch; k++) {
+            const FsChunk &c = ch[(size_t)k];
+            const int64_t lo_read = (int64_t)c.b_lo - kBack - 64;
+            bool act = round == 0;
+            int j0 = k;
+            for (int j = k - 1; j >= 0 && (int64_t)ch[(size_t)j].b_hi + kMaxMatch > lo_read; j--) {
+                j0 = j;
+                if (round && mp[(size_t)j].changed) act = true;
+            }
+            if (!act) {
+                mn[(size_t)k] = mp[(size_t)k];
+                mn[(size_t)k].changed = 0;
+                continue;
+            }
+            runs++;
+            const int64_t E = k == 0 ? 0 : (round == 0 ? c.b_lo : mp[(size_t)k - 1].X);
+            const int64_t g00 = E & ~63LL, lo = std::max<int64_t>(0, g00 - kBack), top = std::min<int64_t>((int64_t)N, (int64_t)c.b_hi + 2048);
+            // ---- stage: K1's links, the set below E as the chunks that own the positions left it, "inserted" from E on
+            std::copy(m.link.begin() + lo, m.link.begin() + std::min<int64_t>(top, (int64_t)m.link.size()), lnk.begin() + lo);
+            for (int64_t p = lo; p < E; p++) {
+                uint8_t b = 1;
+                if (round)
+                    for (int j = k - 1; j >= j0; j--)
+                        if (mp[(size_t)j].E <= p) {
+                            b = plane[mp[(size_t)j].cur][j & 1][(size_t)p];
+                            break;
+                        }
+                ins[(size_t)p] = b;
+            }
+            for (int64_t p = E; p < top; p++) ins[(size_t)p] = 1;
+            if (round)
+                for (int j = j0; j < k; j++)
+                    if (mp[(size_t)j].cut >= lo) lnk[(size_t)mp[(size_t)j].cut] = 0;
+            FrAcc acc{&m, lnk.data(), ins.data(), lo};
+            for (int64_t q = std::max<int64_t>(lo, 1); q < E; q++) lnk[(size_t)q] = (uint16_t)fs_compress(acc, q);
+            for (int64_t q = E; q < top; q++) rprev[(size_t)q] = kFsFresh;
+            // ---- the sweeps of the chunk
+            FsState st{E, 0, -1, c.kfired0, -1, -1, -1, 0};
+            st.trigger = st.k_fired < kl ? m.rev[(size_t)st.k_fired + 1].at - (kMinLookahead - 1) : -1;
+            int64_t cut = -1, preins = -1;
+            std::vector<uint32_t> &out = prov[(size_t)k];
+            out.clear();
+            while (st.w0 < c.b_hi) {
+                const int64_t g0 = st.w0 & ~63LL;
+                if (st.trigger >= 0 && st.w0 >= st.trigger) {
+                    const int64_t t = st.w0;
+                    st.k_fired++;
+                    st.preins = preins = t + 1;
+                    ins[(size_t)t + 1] = 1;
+                    if (lnk[(size_t)t + 1] == 1) {
+                        st.dead_pos = t, st.only_pos = t + 1;
+                        lnk[(size_t)t] = 0;
+                        cut = t;
+                    } else {
+                        st.dead_pos = t + 1, st.only_pos = -1;
+                    }
+                    st.trigger = st.k_fired < kl ? m.rev[(size_t)st.k_fired + 1].at - (kMinLookahead - 1) : -1;
+                }
+                int64_t hi = std::min<int64_t>(g0 + W, c.b_hi);
+                if (st.trigger >= 0 && st.trigger < hi) hi = st.trigger;
+                for (int64_t q = st.w0; q < hi; q++) {
+                    if (q < st.ev_end && (rprev[(size_t)q] & kFsExact) && q != st.dead_pos && q != st.only_pos) {
+                        rcur[(size_t)(q - g0)] = rprev[(size_t)q];
+                        continue;
+                    }
+                    const int l0 = lnk[(size_t)q];
+                    const bool exact = l0 == 0 || q - l0 < st.w0;
+                    rcur[(size_t)(q - g0)] = fs_search(acc, q, m.lv.chain, m.lv.nice, !search || q == st.dead_pos, search && q == st.only_pos) | (exact ? kFsExact : 0u);
+                }
+                int64_t t = st.w0, tstar = -1, last_top = -1;
+                std::vector<int64_t> tops;
+                while (t < hi) {
+                    const uint32_t r = rcur[(size_t)(t - g0)];
+                    tops.push_back(t);
+                    if (tstar < 0 && !(t < st.ev_end && ((rprev[(size_t)t] ^ r) & kFsResMask) == 0)) tstar = t;
+                    last_top = t;
+                    t += fs_adv(r);
+                }
+                const int64_t X = t;
+                if (tstar < 0) tstar = last_top;
+                const int64_t w0_new = tstar + fs_adv(rcur[(size_t)(tstar - g0)]);
+                for (int64_t q : tops) {
+                    if (q > tstar) break;
+                    const uint32_t r = rcur[(size_t)(q - g0)];
+                    out.push_back(fs_len(r) >= kMinMatch ? (((uint32_t)fs_dist(r) << 16) | (uint32_t)(fs_len(r) - 3)) : (uint32_t)m.data[q]);
+                }
+                for (int64_t q = st.w0; q < X; q++) ins[(size_t)q] = 0;
+                for (int64_t q : tops) {
+                    const int span = fs_inserted_span(rcur[(size_t)(q - g0)], m.lv.lazy);
+                    for (int i = 0; i < span; i++) ins[(size_t)q + i] = 1;
+                }
+                if (st.preins >= st.w0) ins[(size_t)st.preins] = 1;
+                for (int64_t q = st.w0; q < hi; q++) rprev[(size_t)q] = rcur[(size_t)(q - g0)];
+                st.ev_end = hi;
+                for (int64_t q = st.w0; q < w0_new; q++) lnk[(size_t)q] = (uint16_t)fs_compress(acc, q);
+                st.w0 = w0_new;
+            }
+            // ---- what it leaves
+            const int64_t X = st.w0;
+            const FsMeta &old = mp[(size_t)k];
+            const int cur = round ? 1 - old.cur : 0;
+            bool diff = round == 0 || old.E != E || old.X != X || old.cut != cut;
+            std::vector<uint8_t> &pn = plane[cur][k & 1];
+            const std::vector<uint8_t> &po = plane[1 - cur][k & 1];
+            for (int64_t q = E; q < X; q++) {
+                pn[(size_t)q] = ins[(size_t)q];
+                if (round && po[(size_t)q] != ins[(size_t)q]) diff = true;
+            }
+            mn[(size_t)k] = FsMeta{(int32_t)E, (int32_t)X, (int32_t)out.size(), (int32_t)cut, st.k_fired, (int32_t)preins, diff ? 1 : 0, cur};
+            nchanged += diff;
+        }
+        if (!nchanged) break;
+        if (round > nch + 2) {
+            printf("frounds: no fixed point after %d rounds of %d chunks\n", round, nch);
+            break;
+        }
+    }
+    // ---- commit: the symbols in order with the block cuts, the set, the cuts in the links, the events
+    const std::vector<FsMeta> &mf = meta[round & 1];
+    m.ins.assign((size_t)m.n + 1024, 0);
+    int64_t block_start = 0;
+    preins_out = -1;
+    for (int k = 0; k < nch; k++) {
+        const FsMeta &f = mf[(size_t)k];
+        if (k && f.E != mf[(size_t)k - 1].X) printf("frounds: chunk %d starts at %d, its predecessor left at %d\n", k, f.E, mf[(size_t)k - 1].X);
+        if (f.preins >= 0) m.events.push_back(f.preins - 1), preins_out = f.preins;
+        if (f.cut >= 0) m.link[(size_t)f.cut] = 0;
+        int64_t q = f.E;
+        for (uint32_t sy : prov[(size_t)k]) {
+            const int adv = (sy >> 16) ? (int)(sy & 0xFFFF) + 3 : 1;
+            m.syms.push_back(sy);
+            if (m.syms.size() % kBlockSyms == 0) {
+                BlockRec b;
+                b.start = block_start;
+                b.sym_start = (int64_t)m.syms.size() - kBlockSyms;
+                b.stored_len = (int32_t)(q + adv - block_start);
+                b.nsyms = kBlockSyms;
+                b.can_store = block_start >= m.rev[(size_t)f.kend].base;
+                b.eof = 0;
+                m.blocks.push_back(b);
+                block_start = q + adv;
+            }
+            q += adv;
+        }
+        if (q != f.X) printf("frounds: chunk %d: its symbols end at %ld, it left at %d\n", k, (long)q, f.X);
+        for (int64_t p = f.E; p < f.X; p++) m.ins[(size_t)p] = plane[f.cur][k & 1][(size_t)p];
+    }
+    p_out = mf[(size_t)nch - 1].X;
+    kdone_out = mf[(size_t)nch - 1].kend;
+    if (preins_out >= p_out) m.ins[(size_t)preins_out] = 1;
+    if (getenv("ZS_FV_STATS")) printf("frounds: %d chunks of ~%d positions, %d rounds, %.2f runs per chunk\n", nch, target, round + 1, (double)runs / (double)nch);
+}
+
+
 // ---- CompressionStrategy.Rle without a sequential parse (zs_rle.h): every position's part in the parse from the first position
 //      of its run; the loop-tops below the hand-over position in order, blocks cut every kBlockSyms symbols, then the tail engine
 static void parse_rle_runs(Model &m, int64_t &p_out, int &kdone_out) {
@@ -1248,11 +1440,12 @@ int main(int argc, char **argv) {
         m.body_end = -1;
         if (strategy == kRle && level >= 1 && wends.size() <= 1 && flush_mode == 0 && !m.rev.empty()) parse_rle_runs(m, p, k_done);
         if (p > 0) m.body_end = p;  // (run_tail sizes its arrays by this)
-    } else if (mode == "fvec" || mode == "fsweep") {
+    } else if (mode == "fvec" || mode == "fsweep" || mode == "frounds") {
         // DeflateFast, single Write: the vector form up to the last loop-top with a full lookahead, then the literal engine
         m.body_end = (m.lv.func == 1 && strategy != kRle && wends.size() <= 1 && flush_mode == 0 && n >= kMinLookahead) ? n - kMinLookahead : -1;
         kind = kR, pend = 0, p = 0, k_done = 0, preins = -1;
         if (m.body_end >= 0 && mode == "fsweep") parse_fast_sweep(m, p, k_done, preins);
+        else if (m.body_end >= 0 && mode == "frounds") parse_fast_rounds(m, p, k_done, preins);
         else if (m.body_end >= 0) parse_fast_vec(m, p, k_done, preins);
     } else if (mode == "chunk") parse_chunked(m, p, kind, pend, k_done, preins);
     else parse_sequential(m, mode != "bulk", p, kind, pend, k_done, preins);

@@ -108,4 +108,61 @@ struct FsState {
     int64_t ev_end;    // positions below this were searched by the sweep before (their results are there to compare with)
 };
 
+// ---- Rounds over the chunks of a stream (round 4; zs_fast_sweep_kernel in its chunk form, tests/model mode "frounds").
+// A sweep's guess may as well come from another workgroup.  The stream is cut at positions b_0 = 0 < b_1 < ... (every read
+// event's trigger is one of them, the spans between are cut into pieces of about `target` positions); chunk k parses from
+// the first loop-top at or behind b_k -- the loop-top chunk k - 1 left through in the round before -- to the first at or
+// behind b_{k+1}, reading the set below its entry as the chunks before it left it in the round before ("inserted" in round
+// 0).  A chunk runs again only when something it reads has changed.  A round in which no chunk changes what it leaves is
+// the fixed point, and the fixed point is the reference's parse: chunk 0 reads nothing, and a chunk whose predecessors are
+// the reference's leaves the reference's (facts 1 and 2 above).  So the rounds end after at most as many as there are
+// chunks -- a sequential parse in the worst case; measured (tests/model/fast_jacobi.cpp, mode chunks): kennedy.xls 4 rounds
+// for 250 chunks, ptt5 9 for 126, text 26 (level 1) / 17 (level 3) for 115 chunks of 4096 positions.
+struct FsChunk {
+    int32_t stream;   // index into the batch
+    int32_t b_lo;     // the chunk's loop-tops: from the first at or behind b_lo ...
+    int32_t b_hi;     // ... to the last below b_hi (the stream's last chunk: body_end + 1)
+    int32_t kfired0;  // read events fired below b_lo (the event whose trigger is b_lo fires at the chunk's first loop-top)
+    int32_t first;    // the batch's index of the stream's first chunk
+    int32_t idx;      // the chunk's number within its stream
+};
+// what a chunk leaves (two copies, by the parity of the round)
+struct FsMeta {
+    int32_t E;        // the loop-top it started from
+    int32_t X;        // the loop-top it handed over at (the first at or behind b_hi)
+    int32_t nsyms;    // symbols of [E, X)
+    int32_t cut;      // the loop-top of an equal-bucket read event (its chain is cut behind it), -1
+    int32_t kend;     // read events fired at X
+    int32_t preins;   // the position its read event inserted ahead, -1
+    int32_t changed;  // this round's run left something else than the run before
+    int32_t cur;      // which of its two bit planes holds what it left
+};
+constexpr int kFsChunkMax = 10240;  // a chunk's positions: one staging of the tile covers it (zs_fast_sweep.hip: TILE - W - 258 - 64)
+constexpr int kFsChunkMin = 1024;
+template <class Vec>
+inline void fs_build_chunks(int stream, int64_t body_end, int kl, int target, Vec &out) {
+    const int32_t first = (int32_t)out.size();
+    if (target > kFsChunkMax) target = kFsChunkMax;
+    if (target < kFsChunkMin) target = kFsChunkMin;
+    int64_t s = 0;
+    int fired = 0;
+    for (int k = 1;; k++) {
+        const int64_t trig = k <= kl ? read_end_before(k) - (kMinLookahead - 1) : body_end + 1;
+        const int64_t e = trig <= body_end ? trig : body_end + 1;
+        const int64_t len = e - s;
+        int64_t pieces = (len + target - 1) / target;
+        if (pieces < 1) pieces = 1;
+        const int64_t step = ((len + pieces - 1) / pieces + 63) & ~63LL;
+        for (int64_t a = s; a < e; a += step) {
+            FsChunk c;
+            c.stream = stream, c.b_lo = (int32_t)a, c.b_hi = (int32_t)(a + step < e ? a + step : e), c.first = first;
+            c.kfired0 = (a == s || s == 0) ? fired : fired + 1;  // (the event of the span's trigger fires in the span's first chunk)
+            c.idx = (int32_t)out.size() - first;
+            out.push_back(c);
+        }
+        if (e > body_end) break;
+        s = e, fired = k - 1;  // (the event k itself fires inside the chunk that starts at its trigger)
+    }
+}
+
 }  // namespace zs
