@@ -99,6 +99,9 @@ struct StreamDesc {
     // CompressionStrategy.Rle over the chip (zs_rle.h, zs_rle.hip): the loop-tops below rle_end are the body's, the tail engine
     // goes on from the first one at or behind it (-1: not this stream); the stream's first tile in the batch's tile arrays
     int32_t rle_end, rle_tile_off;
+    // DeflateFast as rounds over the chunks of the stream (zs_fast_sweep.h "Rounds"): the stream's chunks in the batch's list (fr_n == 0: the
+    // stream is one workgroup's, from its first position to fv_end)
+    int32_t fr_first, fr_n;
 };
 
 // where each kernel's work items start in the work array (zs_worklist_kernel): 9 lists, then the total

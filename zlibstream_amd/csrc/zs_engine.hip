@@ -50,13 +50,14 @@ struct zs_ctx {
     // probing call (zs_inflate asking whether the stream's end has arrived), where the block chain ended
     std::vector<int64_t> inf_used;
     int64_t *inf_probe = nullptr;
+    int fast_rounds = 0;  // rounds the last call's DeflateFast took over its chunks (0: one workgroup per stream)
     int last_op = 0;  // 0: deflate stages, 1: block-parallel inflate stages, 2: deflate at levels 1-3 (for zs_ctx_stage_name)
     hipEvent_t ev[kStCount + 1] = {};
     double stage_ms[kStCount] = {};
     uint32_t *crc_tab = nullptr;
     DevBuf sd, st, work, wpre, geo, link, mm, maps, chunk_far, segmap, supmap, seg_entry, seg_symbase, seg_stale, entry, symbase, stale, syms, blk_end, blk_top, blocks, trees, info, pieces, scratch,
         stage_in, stage_out, wr, inf_desc, inf_state, par_ps, par_st, par_work, par_cbits, par_ccnt, par_surv, par_scnt, par_cands, par_tabs, par_blocks, par_cells,
-        par_windows, par_fail, run_syms, run_bits, run_scratch, run_outs, run_fail, adl_tr, adl_res, plan_blk, ins_bits, mm_bak, cut_pos, cut_bkt, win_groups, win_sg, win_maps, win_entries, persist_bak, resume_flag, rle_tiles;
+        par_windows, par_fail, run_syms, run_bits, run_scratch, run_outs, run_fail, adl_tr, adl_res, plan_blk, ins_bits, mm_bak, cut_pos, cut_bkt, win_groups, win_sg, win_maps, win_entries, persist_bak, resume_flag, rle_tiles, fr_chunks, fr_meta, fr_planes, fr_prov, fr_base, fr_counters;
     bool resume_poisoned = false;  // a resumed run met a read the bulk form does not handle: the caller goes on with the literal engine
     void *pinned = nullptr;
     size_t pinned_cap = 0;
@@ -131,6 +132,9 @@ struct Plan {
     int64_t n_chunks = 0, n_segs = 0, n_sups = 0, n_blocks = 0, n_pieces = 0, n_runs = 0;
     bool any_fv = false, any_rle = false;
     int64_t n_rle_tiles = 0;
+    std::vector<FsChunk> fr_chunks;  // levels 1-3 as rounds over the chunks of the streams (zs_fast_sweep.h "Rounds"); empty: one workgroup per stream
+    size_t fr_prov = 0;              // symbols of room in the chunks' provisional buffer
+    int fr_max_n = 0;                // the most chunks a stream has
     int64_t n_cuts = 0;     // entries of a cut list (batched cut rounds): one per read boundary
     // parse-segment tables (zs_core.h build_geometry), all streams: per segment (seg_off order); seg_cl and cstart hold one
     // entry more per stream (stream i's lists begin at seg_off + i / chunk_off + i); seg_cl's values index `cl`
@@ -243,6 +247,7 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
         }
         // CompressionStrategy.Rle, one Write: the parse is a function of where the runs of equal bytes begin (zs_rle.h)
         s.rle_end = -1, s.rle_tile_off = 0;
+        s.fr_first = 0, s.fr_n = 0;
         if (strategy == kRle && level >= 1 && !multi && !flushing && final_run && !ro && regular && !getenv("ZS_NO_RLE_RUNS")) {
             s.rle_end = (int32_t)rle_body_end(len);
             if (s.rle_end >= 0) {
@@ -354,6 +359,32 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
             if (s.nsegs > kSupSegs) pl.w_sups.add(i, (s.nsegs + kSupSegs - 1) / kSupSegs);  // shorter streams are resolved row by row
         }
         pl.w_blocks.add(i, s.max_blocks);
+    }
+    if (pl.any_fv && !getenv("ZS_FAST_NO_ROUNDS")) {
+        // levels 1-3, few streams: every stream's parse as rounds over its chunks, all chunks of the batch at once (zs_fast_sweep.h
+        // "Rounds"); a batch of many streams fills the chip with one workgroup per stream and parses every position once
+        int n_fv = 0;
+        int64_t pos_fv = 0;
+        for (int i = 0; i < n; i++)
+            if (pl.sd[(size_t)i].fv_end >= 0) n_fv++, pos_fv += pl.sd[(size_t)i].fv_end + 1;
+        const int max_streams = getenv("ZS_FR_MAX_STREAMS") ? atoi(getenv("ZS_FR_MAX_STREAMS")) : 64;
+        if (n_fv <= max_streams) {
+            int64_t target = getenv("ZS_FR_CHUNK") ? atoll(getenv("ZS_FR_CHUNK")) : pos_fv / 768;
+            target = target < 2048 ? 2048 : target > kFsChunkMax ? kFsChunkMax : target;
+            for (int i = 0; i < n; i++) {
+                StreamDesc &s = pl.sd[(size_t)i];
+                if (s.fv_end < 0) continue;
+                s.fr_first = (int32_t)pl.fr_chunks.size();
+                fs_build_chunks(i, (int64_t)s.fv_end, s.kl, (int)target, pl.fr_chunks);
+                s.fr_n = (int32_t)pl.fr_chunks.size() - s.fr_first;
+                pl.fr_max_n = s.fr_n > pl.fr_max_n ? s.fr_n : pl.fr_max_n;
+                for (int32_t k = s.fr_first; k < s.fr_first + s.fr_n; k++) {
+                    FsChunk &ck = pl.fr_chunks[(size_t)k];
+                    ck.prov_off = (uint32_t)pl.fr_prov;
+                    pl.fr_prov += (size_t)(ck.b_hi - ck.b_lo) + kMaxMatch + 64;  // (its loop-tops lie in [b_lo, b_hi + 258))
+                }
+            }
+        }
     }
     WorkList *const lists[kWorkLists] = {&pl.w_clear, &pl.w_adler, &pl.w_links, &pl.w_match, &pl.w_chunks, &pl.w_segs, &pl.w_sups, &pl.w_blocks, &pl.w_runs};
     for (WorkList *l : lists) l->finish(n);
@@ -771,8 +802,47 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
     if (pl.any_fv) {
         // window-wide sweeps of a workgroup (zs_fast_sweep.hip), one workgroup per stream
         constexpr int fs_lds = fs_lds_bytes<1024, kFsTile1>();
-        hipLaunchKernelGGL((zs_fast_sweep_kernel<1024, kFsTile1>), dim3((unsigned)n), dim3(1024), fs_lds, stream, d_sd, d_st,
-                           dev<uint16_t>(c->link), dev<uint32_t>(c->syms), dev<int32_t>(c->blk_end), dev<int32_t>(c->blk_top), lv, strategy);
+        if (!pl.fr_chunks.empty()) {
+            // rounds over the chunks of the streams: every round one workgroup per chunk, until a round changes nothing
+            const size_t nch = pl.fr_chunks.size(), plane_words = (size_t)pl.n_pos / 32 + kFvBitSlack / 4 + 64;
+            const int max_rounds = pl.fr_max_n + 2;  // (chunk r of a stream is the reference's after round r at the latest)
+            if (nch * sizeof(FsChunk) > 0xFFFFFFFFu || pl.fr_prov > 0xFFFFFFFFu) {
+                c->err = "too many chunks for the rounds over DeflateFast";
+                return false;
+            }
+            if (!ensure(c, c->fr_chunks, nch * sizeof(FsChunk)) || !ensure(c, c->fr_meta, 2 * nch * sizeof(FsMeta)) || !ensure(c, c->fr_planes, 16 * plane_words) ||
+                !ensure(c, c->fr_prov, 4 * pl.fr_prov + 64) || !ensure(c, c->fr_base, 4 * nch + 64) || !ensure(c, c->fr_counters, 4 * ((size_t)max_rounds + 16)))
+                return false;
+            ZS_HIP(c, hipMemcpyAsync(c->fr_chunks.p, pl.fr_chunks.data(), nch * sizeof(FsChunk), hipMemcpyHostToDevice, stream));
+            ZS_HIP(c, hipMemsetAsync(c->fr_counters.p, 0, 4 * ((size_t)max_rounds + 16), stream));
+            FsRounds fr{dev<FsChunk>(c->fr_chunks), dev<FsMeta>(c->fr_meta), dev<uint32_t>(c->fr_planes), dev<uint32_t>(c->fr_prov), dev<uint32_t>(c->fr_counters),
+                        (int64_t)plane_words, (int)nch, 0};
+            const int group = getenv("ZS_FR_GROUP") ? atoi(getenv("ZS_FR_GROUP")) : 4;  // rounds between two looks at the counter
+            uint32_t changed = 1;
+            int r = 0;
+            while (r < max_rounds && changed) {
+                for (int g = 0; g < group && r < max_rounds; g++, r++) {
+                    fr.round = r;
+                    hipLaunchKernelGGL((zs_fast_sweep_kernel<1024, kFsTile1, true>), dim3((unsigned)nch), dim3(1024), fs_lds, stream, d_sd, d_st, dev<uint16_t>(c->link),
+                                       dev<uint32_t>(c->syms), dev<int32_t>(c->blk_end), dev<int32_t>(c->blk_top), lv, strategy, fr);
+                }
+                ZS_HIP(c, hipMemcpyAsync(&changed, dev<uint32_t>(c->fr_counters) + (r - 1), 4, hipMemcpyDeviceToHost, stream));
+                ZS_HIP(c, hipStreamSynchronize(stream));
+            }
+            c->fast_rounds = r;
+            if (getenv("ZS_DEBUG")) fprintf(stderr, "zs: DeflateFast over %zu chunks of %d streams: %d rounds\n", nch, n, r);
+            if (changed) {
+                c->err = "the rounds over DeflateFast did not reach their fixed point";
+                return false;
+            }
+            const FsMeta *mf = dev<FsMeta>(c->fr_meta) + (size_t)((r - 1) & 1) * nch;
+            hipLaunchKernelGGL(zs_fast_commit_scan_kernel, dim3((unsigned)n), dim3(1024), 0, stream, d_sd, d_st, mf, dev<int32_t>(c->fr_base));
+            hipLaunchKernelGGL(zs_fast_commit_kernel, dim3((unsigned)nch), dim3(256), 0, stream, d_sd, fr, mf, dev<int32_t>(c->fr_base), dev<uint16_t>(c->link),
+                               dev<uint32_t>(c->syms), dev<int32_t>(c->blk_end), dev<int32_t>(c->blk_top));
+        } else {
+            hipLaunchKernelGGL((zs_fast_sweep_kernel<1024, kFsTile1, false>), dim3((unsigned)n), dim3(1024), fs_lds, stream, d_sd, d_st, dev<uint16_t>(c->link),
+                               dev<uint32_t>(c->syms), dev<int32_t>(c->blk_end), dev<int32_t>(c->blk_top), lv, strategy, FsRounds());
+        }
     }
     if (pl.any_rle) {
         // CompressionStrategy.Rle: the body's symbols from the runs of equal bytes (zs_rle.hip), the tail engine behind them
@@ -1131,7 +1201,8 @@ int zs_ctx_create(int device, zs_ctx **out) {
         hipFuncSetAttribute((const void *)zs_links_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLkLds) != hipSuccess ||
         hipFuncSetAttribute((const void *)zs_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kTailLds) != hipSuccess ||
         hipFuncSetAttribute((const void *)zs_fast_run_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kTailLds) != hipSuccess ||
-        hipFuncSetAttribute((const void *)zs_fast_sweep_kernel<1024, kFsTile1>, hipFuncAttributeMaxDynamicSharedMemorySize, (fs_lds_bytes<1024, kFsTile1>())) != hipSuccess ||
+        hipFuncSetAttribute((const void *)zs_fast_sweep_kernel<1024, kFsTile1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (fs_lds_bytes<1024, kFsTile1>())) != hipSuccess ||
+        hipFuncSetAttribute((const void *)zs_fast_sweep_kernel<1024, kFsTile1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (fs_lds_bytes<1024, kFsTile1>())) != hipSuccess ||
         hipFuncSetAttribute((const void *)zs_inf_window_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kWinMapLds) != hipSuccess ||
         hipFuncSetAttribute((const void *)zs_inf_chain_par_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kChainParLds) != hipSuccess ||
         hipFuncSetAttribute((const void *)zs_cuts_repair_kernel<256, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, kRepairLds) != hipSuccess ||
@@ -1158,7 +1229,7 @@ void zs_ctx_destroy(zs_ctx *c) {
     DevBuf *bufs[] = {&c->sd, &c->st, &c->work, &c->wpre, &c->geo, &c->link, &c->mm, &c->maps, &c->chunk_far, &c->segmap, &c->supmap, &c->seg_entry, &c->seg_symbase, &c->seg_stale, &c->entry, &c->symbase, &c->stale, &c->syms,
                       &c->blk_end, &c->blk_top, &c->blocks, &c->trees, &c->info, &c->pieces, &c->scratch, &c->stage_in, &c->stage_out, &c->wr, &c->inf_desc, &c->inf_state, &c->par_ps, &c->par_st, &c->par_work, &c->par_cbits, &c->par_ccnt, &c->par_surv, &c->par_scnt,
                       &c->par_cands, &c->par_tabs, &c->par_blocks, &c->par_cells, &c->par_windows, &c->par_fail, &c->run_syms, &c->run_bits,
-                      &c->run_scratch, &c->run_outs, &c->run_fail, &c->adl_tr, &c->adl_res, &c->plan_blk, &c->ins_bits, &c->mm_bak, &c->cut_pos, &c->cut_bkt, &c->win_groups, &c->win_sg, &c->win_maps, &c->win_entries, &c->persist_bak, &c->resume_flag, &c->rle_tiles};
+                      &c->run_scratch, &c->run_outs, &c->run_fail, &c->adl_tr, &c->adl_res, &c->plan_blk, &c->ins_bits, &c->mm_bak, &c->cut_pos, &c->cut_bkt, &c->win_groups, &c->win_sg, &c->win_maps, &c->win_entries, &c->persist_bak, &c->resume_flag, &c->rle_tiles, &c->fr_chunks, &c->fr_meta, &c->fr_planes, &c->fr_prov, &c->fr_base, &c->fr_counters};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
     if (c->crc_tab) (void)hipFree(c->crc_tab);

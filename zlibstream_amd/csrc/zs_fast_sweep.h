@@ -125,6 +125,8 @@ struct FsChunk {
     int32_t kfired0;  // read events fired below b_lo (the event whose trigger is b_lo fires at the chunk's first loop-top)
     int32_t first;    // the batch's index of the stream's first chunk
     int32_t idx;      // the chunk's number within its stream
+    uint32_t prov_off;  // where its symbols go until the rounds are over (the batch's provisional symbol buffer)
+    int32_t pad;
 };
 // what a chunk leaves (two copies, by the parity of the round)
 struct FsMeta {
@@ -158,6 +160,7 @@ inline void fs_build_chunks(int stream, int64_t body_end, int kl, int target, Ve
             c.stream = stream, c.b_lo = (int32_t)a, c.b_hi = (int32_t)(a + step < e ? a + step : e), c.first = first;
             c.kfired0 = (a == s || s == 0) ? fired : fired + 1;  // (the event of the span's trigger fires in the span's first chunk)
             c.idx = (int32_t)out.size() - first;
+            c.prov_off = 0, c.pad = 0;
             out.push_back(c);
         }
         if (e > body_end) break;

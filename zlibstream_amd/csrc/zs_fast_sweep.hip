@@ -75,14 +75,28 @@ __device__ __forceinline__ int fs_run_skip(int c, const uint32_t *bm, const uint
     return (wi << 5) + land + 1;
 }
 
-template <int NT, int TILE>
+// The chunk form's arguments (zs_fast_sweep.h "Rounds"): one workgroup per chunk and round.
+struct FsRounds {
+    const FsChunk *chunks;
+    FsMeta *meta;         // [2][nch]: what the chunks left, by the parity of the round
+    uint32_t *planes;     // [2][2][plane_words]: the chunks' bits, by FsMeta::cur and the parity of the chunk's number in the batch
+    uint32_t *prov;       // the chunks' symbols until the rounds are over
+    uint32_t *counters;   // per round: chunks that left something else than the round before
+    int64_t plane_words;
+    int nch, round;
+};
+static_assert(kFsChunkMax + 64 + 63 <= kFsTile1 - 1024 && kFsChunkMax + 64 + 63 + 1024 + 288 <= kFsTile1, "a chunk is covered by one staging of the tile");
+
+template <int NT, int TILE, bool CH>
 __global__ __launch_bounds__(NT) void zs_fast_sweep_kernel(const StreamDesc *sd, StreamState *st, uint16_t *link, uint32_t *syms, int32_t *blk_end,
-                                                             int32_t *blk_top, LevelCfg lv, int strategy) {
+                                                             int32_t *blk_top, LevelCfg lv, int strategy, FsRounds fr) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     constexpr int W = NT, NG = W / 64, RING = 2 * W;
     constexpr int fsBytes = FsLayout<TILE>::bytes, fsLinks = FsLayout<TILE>::links, fsBitWords = FsLayout<TILE>::bit_words;
     static_assert(TILE % 64 == 0 && TILE >= 2 * W && W + 258 < 4096 && NG <= 64, "tile / doubling word");
-    const StreamDesc s = sd[blockIdx.x];
+    FsChunk ck = FsChunk();
+    if constexpr (CH) ck = fr.chunks[blockIdx.x];
+    const StreamDesc s = sd[CH ? ck.stream : (int)blockIdx.x];
     if (s.fv_end < 0) return;
     uint8_t *wb = smem;                                         // bytes, index = position - lo
     uint16_t *wl = (uint16_t *)(smem + fsBytes);                // link entries
@@ -98,21 +112,85 @@ __global__ __launch_bounds__(NT) void zs_fast_sweep_kernel(const StreamDesc *sd,
     // (static: the compiler then knows the address space and the atomics below are LDS instructions, not flat ones)
     __shared__ uint32_t shv[4];
     const int tid = threadIdx.x, lane = lane_id(), wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (uniform, and the compiler knows)
-    const int n = s.n, body_end = s.fv_end;
+    const int n = s.n, body_end = CH ? ck.b_hi - 1 : s.fv_end;  // (a chunk's last loop-top lies below b_hi)
     const gcbytes in = as_global(s.in);
     uint16_t *lk = link + s.pos_off;
     uint32_t *gbits = s.ins_bits;
-    uint32_t *out_syms = syms + s.sym_off;
+    uint32_t *out_syms = CH ? fr.prov + ck.prov_off : syms + s.sym_off;
     const int kl = s.kl;
+    // ---- the chunk form: what the round before left -- the loop-top to start from, the chunks whose bits lie in reach (nearest
+    //      first) with their first loop-tops, planes and cuts -- and whether any of it has changed
+    __shared__ int32_t pE[64], pCut[64];
+    __shared__ uint32_t pOff[64];
+    __shared__ int32_t pvar[4];  // [0] chunks in reach, [1] something changed, [2] where the chunk before left
+    int E0 = 0, np = 0, cut_ev = -1, preins_ev = -1;
+    const int kc = (int)blockIdx.x;
+    const FsMeta *mp = nullptr;
+    FsMeta *mn = nullptr;
+    if constexpr (CH) {
+        mp = fr.meta + (size_t)((fr.round + 1) & 1) * (size_t)fr.nch, mn = fr.meta + (size_t)(fr.round & 1) * (size_t)fr.nch;
+        const int lo_read = ck.b_lo - kFsBack - 64;
+        if (threadIdx.x < 64) {
+            const int j = kc - 1 - (int)threadIdx.x;
+            bool reach = false, chg = false;
+            if (j >= ck.first && fr.chunks[j].b_hi + kMaxMatch > lo_read) {
+                reach = true;
+                if (fr.round) {
+                    const FsMeta m = mp[j];
+                    chg = m.changed != 0;
+                    pE[threadIdx.x] = m.E, pCut[threadIdx.x] = m.cut;
+                    pOff[threadIdx.x] = (uint32_t)((size_t)(m.cur * 2 + (j & 1)) * (size_t)fr.plane_words + (size_t)(s.pos_off >> 5));
+                    if (threadIdx.x == 0) pvar[2] = m.X;
+                }
+            }
+            const uint64_t rm = __ballot(reach), cm = __ballot(chg);
+            if (threadIdx.x == 0) pvar[0] = (int)__builtin_popcountll(rm), pvar[1] = (fr.round == 0 || cm != 0) ? 1 : 0;
+        }
+        __syncthreads();
+        np = fr.round ? pvar[0] : 0;
+        if (!pvar[1]) {  // nothing it reads has changed: what it left stays
+            if (threadIdx.x == 0) {
+                FsMeta m = mp[kc];
+                m.changed = 0;
+                mn[kc] = m;
+            }
+            return;
+        }
+        E0 = ck.idx == 0 ? 0 : (fr.round == 0 ? ck.b_lo : pvar[2]);
+        if (E0 >= ck.b_hi) {  // (a last span shorter than the match that crosses it)
+            if (threadIdx.x == 0) {
+                const FsMeta o = mp[kc];
+                const int chg = (fr.round == 0 || o.E != E0 || o.X != E0) ? 1 : 0;
+                mn[kc] = FsMeta{E0, E0, 0, -1, ck.kfired0, -1, chg, fr.round ? o.cur : 0};
+                if (chg) atomicAdd(&fr.counters[fr.round], 1u);
+            }
+            return;
+        }
+    }
+    // the bits of [p32, p32 + 32) below the chunk's first loop-top, from the planes of the chunks that own the positions
+    auto hist_word = [&](int p32) -> uint32_t {
+        if (p32 < 0) return 0u;
+        if (fr.round == 0) return 0xFFFFFFFFu;
+        uint32_t v = 0, seen = 0;
+        for (int t = 0; t < np; t++) {
+            const int a = pE[t] > p32 ? pE[t] : p32, b0 = t ? pE[t - 1] : E0, b = b0 < p32 + 32 ? b0 : p32 + 32;
+            if (a < b) {
+                const uint32_t m = (b - a >= 32 ? 0xFFFFFFFFu : ((1u << (b - a)) - 1u)) << (a - p32);
+                v |= fr.planes[(size_t)pOff[t] + (size_t)(p32 >> 5)] & m, seen |= m;
+            }
+        }
+        return v | ~seen;
+    };
     const bool search = strategy != kHuffmanOnly;  // (HuffmanOnly: Longest_match is never called, Deflate.Fast.cs:61-66)
     const int nice = lv.nice, chain = lv.chain, lazy = lv.lazy;
     const bool aligned = (((uintptr_t)in) & 15) == 0;
     // the state that goes from sweep to sweep, held by every thread (all of it is computed from shared values); positions are
     // below 2^31 (StreamDesc::n)
-    int w0 = 0, nsyms = 0, trigger = kl >= 1 ? (int)read_end_before(1) - (kMinLookahead - 1) : -1, preins = -1, dead_pos = -1, only_pos = -1, ev_end = 0;
-    int k_fired = 0, next_cut = kBlockSyms - 1;  // (the symbol with this index ends a block, Deflate.cs:910-948)
-    int t0 = -(1 << 30), w0_staged = 0;
-    int x_end = 0;  // where the last sweep's parse ended: the bits of [w0, x_end) are that parse's (the guess the results in the ring belong to)
+    int w0 = E0, nsyms = 0, preins = -1, dead_pos = -1, only_pos = -1, ev_end = 0;
+    int k_fired = CH ? ck.kfired0 : 0, next_cut = CH ? 0x7FFFFFFF : kBlockSyms - 1;  // (the symbol with this index ends a block, Deflate.cs:910-948; a chunk's symbols get their places later)
+    int trigger = k_fired < kl ? (int)read_end_before(k_fired + 1) - (kMinLookahead - 1) : -1;
+    int t0 = -(1 << 30), w0_staged = E0;
+    int x_end = E0;  // where the last sweep's parse ended: the bits of [w0, x_end) are that parse's (the guess the results in the ring belong to)
     if (tid == 0) shv[0] = 0xFFFFFFFFu, shv[1] = 0, shv[2] = 0;
 #ifdef ZS_FS_PROF
     long long pf[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pf_t = wall_clock64(), pf_sweeps = 0, pf_skips = 0, pf_cmps = 0;
@@ -129,7 +207,7 @@ __global__ __launch_bounds__(NT) void zs_fast_sweep_kernel(const StreamDesc *sd,
         uint32_t l = wl[ci] & 0x7FFFu;
         for (;;) {
             c1 -= (int)l;
-            if (ci - c1 > kMaxDist) return 0;
+            if (ci - c1 > kMaxDist || c1 < 6) return 0;  // (the tile's first entries are out of every walker's reach: a chunk compresses its whole history)
             const uint32_t v = wl[c1];
             if (v >> 15) return ci - c1;
             l = v & 0x7FFFu;
@@ -139,7 +217,7 @@ __global__ __launch_bounds__(NT) void zs_fast_sweep_kernel(const StreamDesc *sd,
     bool gl_stale = true;  // the guess's links have to be made again: a new tile (other positions have links), an event (a forced member, a cut)
     while (w0 <= body_end) {
         const int g0 = w0 & ~63;
-        if (g0 + W > t0 + TILE) {
+        if (CH ? t0 < 0 : g0 + W > t0 + TILE) {
             // ---- (leave the tile: the bits that became final go back to the stream's bitmap) stage the tile at g0
             __syncthreads();
             if (t0 >= 0) {
@@ -170,8 +248,13 @@ __global__ __launch_bounds__(NT) void zs_fast_sweep_kernel(const StreamDesc *sd,
             for (int i = tid; i < fsBitWords; i += NT) {
                 const int p32 = lo + 32 * i;  // first position of the word
                 uint32_t v = 0xFFFFFFFFu;
-                if (p32 + 32 <= x_end) v = p32 >= 0 ? gbits[p32 >> 5] : 0u;
-                else if (p32 < x_end) v = gbits[p32 >> 5] | (0xFFFFFFFFu << (uint32_t)(x_end - p32));
+                if constexpr (CH) {
+                    if (p32 + 32 <= x_end) v = hist_word(p32);
+                    else if (p32 < x_end) v = hist_word(p32) | (0xFFFFFFFFu << (uint32_t)(x_end - p32));
+                } else {
+                    if (p32 + 32 <= x_end) v = p32 >= 0 ? gbits[p32 >> 5] : 0u;
+                    else if (p32 < x_end) v = gbits[p32 >> 5] | (0xFFFFFFFFu << (uint32_t)(x_end - p32));
+                }
                 bm[i] = v;
             }
             __syncthreads();
@@ -201,6 +284,21 @@ __global__ __launch_bounds__(NT) void zs_fast_sweep_kernel(const StreamDesc *sd,
             }
             if (tid < 16) rb[fsLinks / 32 + tid] = 0;
             __syncthreads();
+            if constexpr (CH) {
+                // the cuts the chunks before left (equal-bucket read events), then the history's links compressed under its set:
+                // K1's links stay as they are for everybody else
+                if (tid == 0)
+                    for (int t = 0; t < np; t++) {
+                        const int ci = pCut[t] - lo;
+                        if (pCut[t] >= 0 && ci >= 0) wl[ci] |= kFsNoLink, rb[ci >> 5] &= ~(1u << (ci & 31));
+                    }
+                __syncthreads();
+                for (int ci = 6 + tid; ci < w0 - lo; ci += NT) {
+                    const int d = nearest_in_set(ci);
+                    wl[ci] = (uint16_t)((d ? (uint32_t)d : kFsNoLink) | (wl[ci] & 0x8000u));
+                }
+                __syncthreads();
+            }
             FS_PF(0);
         }
         const int lo = t0 - kFsBack;
@@ -212,10 +310,15 @@ __global__ __launch_bounds__(NT) void zs_fast_sweep_kernel(const StreamDesc *sd,
             preins = w0 + 1;
             if (same) dead_pos = w0, only_pos = w0 + 1;
             else dead_pos = w0 + 1, only_pos = -1;
+            preins_ev = w0 + 1;
+            if (same) cut_ev = w0;
             if (tid == 0) {
                 bm[(w0 + 1 - lo) >> 5] |= 1u << ((w0 + 1 - lo) & 31);
                 wl[w0 + 1 - lo] |= 0x8000u;
-                if (same) wl[w0 - lo] |= kFsNoLink, lk[w0] = 0, rb[(w0 - lo) >> 5] &= ~(1u << ((w0 - lo) & 31));  // the reference's prev[w0] = w0 + 1, prev[w0 + 1] = w0
+                if (same) {  // the reference's prev[w0] = w0 + 1, prev[w0 + 1] = w0
+                    wl[w0 - lo] |= kFsNoLink, rb[(w0 - lo) >> 5] &= ~(1u << ((w0 - lo) & 31));
+                    if (!CH) lk[w0] = 0;  // (a chunk's cut goes into K1's links once the rounds are over)
+                }
             }
             trigger = k_fired < kl ? (int)read_end_before(k_fired + 1) - (kMinLookahead - 1) : -1;
             gl_stale = true;
@@ -443,7 +546,7 @@ __global__ __launch_bounds__(NT) void zs_fast_sweep_kernel(const StreamDesc *sd,
                 const int ci = c - lo, d = nearest_in_set(ci);
                 if (c < fin_hi) {
                     wl[ci] = (uint16_t)((d ? (uint32_t)d : kFsNoLink) | (wl[ci] & 0x8000u));
-                    lk[c] = (uint16_t)d;
+                    if (!CH) lk[c] = (uint16_t)d;
                 } else {
                     gl[c & (RING - 1)] = (uint16_t)(d ? d : (int)kFsNoLink);
                 }
@@ -464,6 +567,28 @@ __global__ __launch_bounds__(NT) void zs_fast_sweep_kernel(const StreamDesc *sd,
                n, pf_sweeps, pf_skips, pf_cmps, pf[0], pf[1], pf[2], pf[3], pf[4], pf[5], pf[6], pf[7], pf[8], pf[9]);
 #endif
     __syncthreads();
+    if constexpr (CH) {
+        // ---- leave, chunk form: the bits of [E0, X) into the chunk's other plane; whether anything differs from what it left before
+        const int X = w0, lo = t0 - kFsBack;
+        const FsMeta o = mp[kc];
+        const int cur = fr.round ? 1 - o.cur : 0;
+        uint32_t *pn = fr.planes + (size_t)(cur * 2 + (kc & 1)) * (size_t)fr.plane_words + (size_t)(s.pos_off >> 5);
+        const uint32_t *po = fr.planes + (size_t)((1 - cur) * 2 + (kc & 1)) * (size_t)fr.plane_words + (size_t)(s.pos_off >> 5);
+        int diff = (fr.round == 0 || o.E != E0 || o.X != X || o.cut != cut_ev) ? 1 : 0;
+        for (int wd = (E0 >> 5) + tid; wd <= ((X - 1) >> 5); wd += NT) {
+            const uint32_t v = bm[wd - (lo >> 5)];
+            const int a = E0 > 32 * wd ? E0 - 32 * wd : 0, b = X < 32 * wd + 32 ? X - 32 * wd : 32;
+            const uint32_t m = (b - a >= 32 ? 0xFFFFFFFFu : ((1u << (b - a)) - 1u)) << a;
+            if (fr.round && ((po[wd] ^ v) & m)) diff = 1;
+            pn[wd] = v;
+        }
+        diff = __syncthreads_or(diff);
+        if (tid == 0) {
+            mn[kc] = FsMeta{E0, X, nsyms, cut_ev, k_fired, preins_ev, diff, cur};
+            if (diff) atomicAdd(&fr.counters[fr.round], 1u);
+        }
+        return;
+    }
     // ---- leave: the bits that became final go back to the stream's bitmap (the tail engine restores its chains from them and
     //      the links)
     if (t0 >= 0) {
@@ -486,5 +611,93 @@ __global__ __launch_bounds__(NT) void zs_fast_sweep_kernel(const StreamDesc *sd,
         ss.k_done = k_fired;
         ss.preins = preins;
         ss.body_syms = (uint32_t)nsyms;
+    }
+}
+
+// ---- The rounds are over (a round changed nothing: the chunks' symbols, bits and hand-over loop-tops are the reference's).
+// zs_fast_commit_scan_kernel, one workgroup per stream: every chunk's place in the stream's symbols, the stream's state for the
+// kernels behind.
+__global__ __launch_bounds__(1024) void zs_fast_commit_scan_kernel(const StreamDesc *sd, StreamState *st, const FsMeta *mf, int32_t *sym_base) {
+    const StreamDesc s = sd[blockIdx.x];
+    if (s.fv_end < 0 || s.fr_n <= 0) return;
+    __shared__ int sh[1024];
+    __shared__ int pre;
+    const int tid = threadIdx.x;
+    if (tid == 0) pre = -1;
+    __syncthreads();
+    int total = 0;
+    for (int t0 = 0; t0 < s.fr_n; t0 += 1024) {
+        const int t = t0 + tid;
+        const int v = t < s.fr_n ? mf[s.fr_first + t].nsyms : 0;
+        if (t < s.fr_n && mf[s.fr_first + t].preins >= 0) atomicMax(&pre, mf[s.fr_first + t].preins);
+        sh[tid] = v;
+        __syncthreads();
+        for (int o = 1; o < 1024; o <<= 1) {  // inclusive prefix sum
+            const int x = tid >= o ? sh[tid - o] : 0;
+            __syncthreads();
+            sh[tid] += x;
+            __syncthreads();
+        }
+        if (t < s.fr_n) sym_base[s.fr_first + t] = total + sh[tid] - v;
+        const int all = sh[1023];
+        __syncthreads();
+        total += all;
+    }
+    if (tid == 0) {
+        const FsMeta last = mf[s.fr_first + s.fr_n - 1];
+        StreamState &ss = st[blockIdx.x];
+        ss.tail_p = last.X;
+        ss.tail_kind = kR;
+        ss.tail_pend = 0;
+        ss.k_done = last.kend;
+        ss.preins = pre;
+        ss.body_syms = (uint32_t)total;
+    }
+}
+// zs_fast_commit_kernel, one workgroup per chunk: the chunk's symbols to their places, the block cut that falls among them
+// (every kBlockSyms symbols, Deflate.cs:910-948: its loop-top from the symbols' own lengths), its bits into the stream's bitmap
+// (zeroed beforehand; chunks share words at their ends), its event's cut into K1's links -- what the tail engine and the block
+// kernels read.
+__global__ __launch_bounds__(256) void zs_fast_commit_kernel(const StreamDesc *sd, FsRounds fr, const FsMeta *mf, const int32_t *sym_base, uint16_t *link, uint32_t *syms,
+                                                             int32_t *blk_end, int32_t *blk_top) {
+    const FsChunk ck = fr.chunks[blockIdx.x];
+    const StreamDesc s = sd[ck.stream];
+    const FsMeta f = mf[blockIdx.x];
+    const int base = sym_base[blockIdx.x], tid = threadIdx.x;
+    const uint32_t *src = fr.prov + ck.prov_off;
+    uint32_t *dst = syms + s.sym_off + base;
+    for (int i = tid; i < f.nsyms; i += 256) dst[i] = src[i];
+    const int g = base + (kBlockSyms - 1 - base % kBlockSyms);  // the first symbol index at or behind base that ends a block
+    if (g < base + f.nsyms) {
+        __shared__ int part[256];
+        const int i_cut = g - base;
+        int sum = 0;
+        for (int i = tid; i < i_cut; i += 256) {
+            const uint32_t sy = src[i];
+            sum += (sy >> 16) ? (int)(sy & 0xFFFFu) + kMinMatch : 1;
+        }
+        part[tid] = sum;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if (tid < o) part[tid] += part[tid + o];
+            __syncthreads();
+        }
+        if (tid == 0) {
+            const uint32_t sy = src[i_cut];
+            const int q = f.E + part[0];
+            blk_end[s.blk_off + g / kBlockSyms] = q + ((sy >> 16) ? (int)(sy & 0xFFFFu) + kMinMatch : 1);
+            blk_top[s.blk_off + g / kBlockSyms] = q;
+        }
+    }
+    const uint32_t *pl = fr.planes + (size_t)(f.cur * 2 + ((int)blockIdx.x & 1)) * (size_t)fr.plane_words + (size_t)(s.pos_off >> 5);
+    for (int wd = (f.E >> 5) + tid; f.X > f.E && wd <= ((f.X - 1) >> 5); wd += 256) {
+        const int a = f.E > 32 * wd ? f.E - 32 * wd : 0, b = f.X < 32 * wd + 32 ? f.X - 32 * wd : 32;
+        const uint32_t m = (b - a >= 32 ? 0xFFFFFFFFu : ((1u << (b - a)) - 1u)) << a;
+        atomicOr(&s.ins_bits[wd], pl[wd] & m);
+    }
+    if (tid == 0) {
+        if (f.cut >= 0) link[s.pos_off + f.cut] = 0;
+        // nothing at or above the hand-over loop-top but the pending pre-insert
+        if (f.preins >= 0 && f.preins >= mf[ck.first + s.fr_n - 1].X) atomicOr(&s.ins_bits[f.preins >> 5], 1u << (f.preins & 31));
     }
 }
