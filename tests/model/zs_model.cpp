@@ -453,7 +453,7 @@ static void parse_fast_rounds(Model &m, int64_t &p_out, int &kdone_out, int64_t 
     std::vector<uint8_t> ins(N, 1);
     std::vector<uint32_t> rprev(N, kFsFresh), rcur((size_t)W + 64);
     const bool search = m.strategy != kHuffmanOnly;
-    long runs = 0;
+    long runs = 0, runs_changed = 0;
     int round = 0;
     for (;; round++) {
         const std::vector<FsMeta> &mp = meta[(round + 1) & 1];
@@ -570,6 +570,7 @@ static void parse_fast_rounds(Model &m, int64_t &p_out, int &kdone_out, int64_t 
             mn[(size_t)k] = FsMeta{(int32_t)E, (int32_t)X, (int32_t)out.size(), (int32_t)cut, st.k_fired, (int32_t)preins, diff ? 1 : 0, cur};
             nchanged += diff;
         }
+        runs_changed += nchanged;
         if (!nchanged) break;
         if (round > nch + 2) {
             printf("frounds: no fixed point after %d rounds of %d chunks\n", round, nch);
@@ -609,7 +610,7 @@ static void parse_fast_rounds(Model &m, int64_t &p_out, int &kdone_out, int64_t 
     p_out = mf[(size_t)nch - 1].X;
     kdone_out = mf[(size_t)nch - 1].kend;
     if (preins_out >= p_out) m.ins[(size_t)preins_out] = 1;
-    if (getenv("ZS_FV_STATS")) printf("frounds: %d chunks of ~%d positions, %d rounds, %.2f runs per chunk\n", nch, target, round + 1, (double)runs / (double)nch);
+    if (getenv("ZS_FV_STATS")) printf("frounds: %d chunks of ~%d positions, %d rounds, %.2f runs per chunk, %.2f of them left something else than the run before\n", nch, target, round + 1, (double)runs / (double)nch, (double)runs_changed / (double)nch);
 }
 
 

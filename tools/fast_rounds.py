@@ -33,5 +33,16 @@ for chunk in [int(a) for a in sys.argv[1:]] or [0]:
             r["chunk"] = chunk
             bad += not r["ok"]
             print(json.dumps(r), flush=True)
+# the Canterbury corpus as one batch (BASELINE config 1)
+names = sorted(os.listdir(os.path.join(ROOT, "tests", "golden", "corpus")))
+files = [oracle_binding.corpus(f) for f in names]
+for lvl in (1, 2, 3):
+    eng.deflate_batch(files, level=lvl)
+    t = time.perf_counter()
+    outs = eng.deflate_batch(files, level=lvl)
+    dt = time.perf_counter() - t
+    ok = all(o == orc.compress(f, lvl) for o, f in zip(outs, files))
+    bad += not ok
+    print(json.dumps({"workload": "corpus, 11 files in one batch (host buffers)", "level": lvl, "ms": round(dt * 1e3, 2), "MBps": round(sum(map(len, files)) / dt / 1e6, 1), "ok": ok}), flush=True)
 print("failures:", bad)
 sys.exit(1 if bad else 0)

@@ -361,28 +361,43 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
         pl.w_blocks.add(i, s.max_blocks);
     }
     if (pl.any_fv && !getenv("ZS_FAST_NO_ROUNDS")) {
-        // levels 1-3, few streams: every stream's parse as rounds over its chunks, all chunks of the batch at once (zs_fast_sweep.h
-        // "Rounds"); a batch of many streams fills the chip with one workgroup per stream and parses every position once
-        int n_fv = 0;
-        int64_t pos_fv = 0;
+        // levels 1-3: every stream's parse as rounds over its chunks, all chunks of the batch at once (zs_fast_sweep.h "Rounds"),
+        // when that is the shorter way.  One workgroup per stream takes as long as the longest stream (45 / 20 MB/s at levels 1 /
+        // 3 on text); the rounds parse every chunk again and again -- text: ~27 / 18 times at levels 1 / 3, kennedy.xls 4 -- and so
+        // take the chip ~1 ms per 250 / 180 KB of the whole batch (profiles/r04_fast_rounds_*.log).  A few streams, or one much
+        // longer than the rest: rounds; a batch of equals: one workgroup each.
+        int64_t pos_fv = 0, max_fv = 0;
         for (int i = 0; i < n; i++)
-            if (pl.sd[(size_t)i].fv_end >= 0) n_fv++, pos_fv += pl.sd[(size_t)i].fv_end + 1;
-        const int max_streams = getenv("ZS_FR_MAX_STREAMS") ? atoi(getenv("ZS_FR_MAX_STREAMS")) : 64;
-        if (n_fv <= max_streams) {
-            int64_t target = getenv("ZS_FR_CHUNK") ? atoll(getenv("ZS_FR_CHUNK")) : pos_fv / 768;
+            if (pl.sd[(size_t)i].fv_end >= 0) {
+                pos_fv += pl.sd[(size_t)i].fv_end + 1;
+                max_fv = std::max<int64_t>(max_fv, pl.sd[(size_t)i].fv_end + 1);
+            }
+        const double ratio = getenv("ZS_FR_RATIO") ? atof(getenv("ZS_FR_RATIO")) : (level >= 3 ? 8.0 : 5.0);
+        if ((double)pos_fv <= ratio * (double)max_fv) {
+            // about one chunk per CU as long as the chunks stay above 2048 positions (a run's fixed cost -- staging 32 K positions of
+            // history -- is 15-30 us, a sweep makes ~390 positions final in 8 us), at most what one staging of the tile covers
+            // chunks of 2048 positions or more (a run's fixed cost -- staging 32 K positions of history -- is 15-30 us, a sweep makes
+            // ~390 positions final in 8 us), at most what one staging of the tile covers; between the two, as many chunks as fit
+            // the chip at once: a round of 260 chunks takes the 256 CUs twice as long as one of 250
+            int64_t target = getenv("ZS_FR_CHUNK") ? atoll(getenv("ZS_FR_CHUNK")) : pos_fv / 250;
             target = target < 2048 ? 2048 : target > kFsChunkMax ? kFsChunkMax : target;
-            for (int i = 0; i < n; i++) {
-                StreamDesc &s = pl.sd[(size_t)i];
-                if (s.fv_end < 0) continue;
-                s.fr_first = (int32_t)pl.fr_chunks.size();
-                fs_build_chunks(i, (int64_t)s.fv_end, s.kl, (int)target, pl.fr_chunks);
-                s.fr_n = (int32_t)pl.fr_chunks.size() - s.fr_first;
-                pl.fr_max_n = s.fr_n > pl.fr_max_n ? s.fr_n : pl.fr_max_n;
-                for (int32_t k = s.fr_first; k < s.fr_first + s.fr_n; k++) {
-                    FsChunk &ck = pl.fr_chunks[(size_t)k];
-                    ck.prov_off = (uint32_t)pl.fr_prov;
-                    pl.fr_prov += (size_t)(ck.b_hi - ck.b_lo) + kMaxMatch + 64;  // (its loop-tops lie in [b_lo, b_hi + 258))
+            for (;;) {
+                pl.fr_chunks.clear();
+                pl.fr_max_n = 0;
+                for (int i = 0; i < n; i++) {
+                    StreamDesc &s = pl.sd[(size_t)i];
+                    if (s.fv_end < 0) continue;
+                    s.fr_first = (int32_t)pl.fr_chunks.size();
+                    fs_build_chunks(i, (int64_t)s.fv_end, s.kl, (int)target, pl.fr_chunks);
+                    s.fr_n = (int32_t)pl.fr_chunks.size() - s.fr_first;
+                    pl.fr_max_n = s.fr_n > pl.fr_max_n ? s.fr_n : pl.fr_max_n;
                 }
+                if (pl.fr_chunks.size() <= 256 || target >= kFsChunkMax || getenv("ZS_FR_CHUNK")) break;
+                target += 128;
+            }
+            for (FsChunk &ck : pl.fr_chunks) {
+                ck.prov_off = (uint32_t)pl.fr_prov;
+                pl.fr_prov += (size_t)(ck.b_hi - ck.b_lo) + kMaxMatch + 64;  // (its loop-tops lie in [b_lo, b_hi + 258))
             }
         }
     }

@@ -583,6 +583,12 @@ __global__ __launch_bounds__(NT) void zs_fast_sweep_kernel(const StreamDesc *sd,
             pn[wd] = v;
         }
         diff = __syncthreads_or(diff);
+#ifdef ZS_FS_PROF
+        FS_PF(9);
+        if (tid == 0 && (kc == 40 || kc == 41) && (fr.round == 0 || fr.round == 3 || fr.round == 8))
+            printf("FSPROF chunk %d round %d [%d, %d) sweeps=%lld ticks(100MHz): prologue+stage+compress=%lld search=%lld hops=%lld barrier1=%lld path=%lld barrier2=%lld tops=%lld barrier3=%lld final+bits=%lld barrier4+links+leave=%lld\n",
+                   kc, fr.round, E0, X, pf_sweeps, pf[0], pf[1], pf[2], pf[3], pf[4], pf[5], pf[6], pf[7], pf[8], pf[9]);
+#endif
         if (tid == 0) {
             mn[kc] = FsMeta{E0, X, nsyms, cut_ev, k_fired, preins_ev, diff, cur};
             if (diff) atomicAdd(&fr.counters[fr.round], 1u);
