@@ -437,6 +437,10 @@ struct FrAcc {
 static void parse_fast_rounds(Model &m, int64_t &p_out, int &kdone_out, int64_t &preins_out) {
     const int W = 1024, kBack = 32512;
     const int target = getenv("ZS_FR_CHUNK") ? atoi(getenv("ZS_FR_CHUNK")) : 4096;
+    // a workgroup takes `range` consecutive chunks one after the other: a chunk reads what the chunks before it in its range
+    // have just left (this round), and what the round before left of the others
+    const int range_max = getenv("ZS_FR_RANGE") ? atoi(getenv("ZS_FR_RANGE")) : 1;
+    const bool range_vary = getenv("ZS_FR_RANGE_VARY") != nullptr;  // ... another range every round (the engine chooses them by what the round before changed)
     const int kl = (int)m.rev.size() - 1;
     std::vector<FsChunk> ch;
     fs_build_chunks(0, m.body_end, kl, target, ch);
@@ -446,7 +450,7 @@ static void parse_fast_rounds(Model &m, int64_t &p_out, int &kdone_out, int64_t 
     for (auto &a : plane)
         for (auto &b : a) b.assign(N, 0);
     std::vector<FsMeta> meta[2];
-    meta[0].assign((size_t)nch, FsMeta{-1, -1, 0, -1, 0, -1, 0, 0});
+    meta[0].assign((size_t)nch, FsMeta{-1, -1, 0, -1, 0, -1, 0, 0, 0, 0, 0, 0});
     meta[1] = meta[0];
     std::vector<std::vector<uint32_t>> prov((size_t)nch);
     std::vector<uint16_t> lnk(N, 0);
@@ -459,14 +463,18 @@ static void parse_fast_rounds(Model &m, int64_t &p_out, int &kdone_out, int64_t 
         const std::vector<FsMeta> &mp = meta[(round + 1) & 1];
         std::vector<FsMeta> &mn = meta[round & 1];
         int nchanged = 0;
+        const int range = range_vary ? 1 + (int)((uint32_t)(round * 2654435761u) >> 16) % range_max : range_max;
         for (int k = 0; k < nch; k++) {
             const FsChunk &c = ch[(size_t)k];
             const int64_t lo_read = (int64_t)c.b_lo - kBack - 64;
+            const int k0 = k / range * range;
+            auto view = [&](int j) -> const FsMeta & { return j >= k0 ? mn[(size_t)j] : mp[(size_t)j]; };
+            auto valid = [&](int j) { return round > 0 || j >= k0; };
             bool act = round == 0;
             int j0 = k;
-            for (int j = k - 1; j >= 0 && (int64_t)ch[(size_t)j].b_hi + kMaxMatch > lo_read; j--) {
+            for (int j = k - 1; j >= 0 && (int64_t)ch[(size_t)j].b_hi + kMaxMatch > lo_read && valid(j); j--) {
                 j0 = j;
-                if (round && mp[(size_t)j].changed) act = true;
+                if (round && fs_stale(view(j).chg_round, j, mp[(size_t)k].ran_round, mp[(size_t)k].seen_lo)) act = true;
             }
             if (!act) {
                 mn[(size_t)k] = mp[(size_t)k];
@@ -474,24 +482,22 @@ static void parse_fast_rounds(Model &m, int64_t &p_out, int &kdone_out, int64_t 
                 continue;
             }
             runs++;
-            const int64_t E = k == 0 ? 0 : (round == 0 ? c.b_lo : mp[(size_t)k - 1].X);
+            const int64_t E = k == 0 ? 0 : (valid(k - 1) ? view(k - 1).X : c.b_lo);
             const int64_t g00 = E & ~63LL, lo = std::max<int64_t>(0, g00 - kBack), top = std::min<int64_t>((int64_t)N, (int64_t)c.b_hi + 2048);
             // ---- stage: K1's links, the set below E as the chunks that own the positions left it, "inserted" from E on
             std::copy(m.link.begin() + lo, m.link.begin() + std::min<int64_t>(top, (int64_t)m.link.size()), lnk.begin() + lo);
             for (int64_t p = lo; p < E; p++) {
                 uint8_t b = 1;
-                if (round)
-                    for (int j = k - 1; j >= j0; j--)
-                        if (mp[(size_t)j].E <= p) {
-                            b = plane[mp[(size_t)j].cur][j & 1][(size_t)p];
-                            break;
-                        }
+                for (int j = k - 1; j >= j0; j--)
+                    if (view(j).E <= p) {
+                        b = plane[view(j).cur][j & 1][(size_t)p];
+                        break;
+                    }
                 ins[(size_t)p] = b;
             }
             for (int64_t p = E; p < top; p++) ins[(size_t)p] = 1;
-            if (round)
-                for (int j = j0; j < k; j++)
-                    if (mp[(size_t)j].cut >= lo) lnk[(size_t)mp[(size_t)j].cut] = 0;
+            for (int j = j0; j < k; j++)
+                if (view(j).cut >= lo) lnk[(size_t)view(j).cut] = 0;
             FrAcc acc{&m, lnk.data(), ins.data(), lo};
             for (int64_t q = std::max<int64_t>(lo, 1); q < E; q++) lnk[(size_t)q] = (uint16_t)fs_compress(acc, q);
             for (int64_t q = E; q < top; q++) rprev[(size_t)q] = kFsFresh;
@@ -567,7 +573,7 @@ static void parse_fast_rounds(Model &m, int64_t &p_out, int &kdone_out, int64_t 
                 pn[(size_t)q] = ins[(size_t)q];
                 if (round && po[(size_t)q] != ins[(size_t)q]) diff = true;
             }
-            mn[(size_t)k] = FsMeta{(int32_t)E, (int32_t)X, (int32_t)out.size(), (int32_t)cut, st.k_fired, (int32_t)preins, diff ? 1 : 0, cur};
+            mn[(size_t)k] = FsMeta{(int32_t)E, (int32_t)X, (int32_t)out.size(), (int32_t)cut, st.k_fired, (int32_t)preins, diff ? 1 : 0, cur, diff ? round : old.chg_round, round, k0, 0};
             nchanged += diff;
         }
         runs_changed += nchanged;

@@ -88,7 +88,8 @@ def test_fast_levels_for_the_lanes_of_a_wave(model, tmp_path):
                 # ... and as rounds over the chunks of the stream (zs_fast_sweep.h "Rounds": every chunk of a round parsed from
                 # what the round before left -- entry loop-tops, the set from the planes of the chunks that own the positions,
                 # the cuts of equal-bucket events -- until a round changes nothing; zs_fast_commit_kernel's part behind it)
-                run(files[name], level, strategy, "frounds", env={"ZS_FR_CHUNK": str((1024, 4096, 10240)[(level + strategy) % 3])})
+                # (ZS_FR_RANGE: chunks a workgroup takes in turn, each reading what the ones before it have just left)
+                run(files[name], level, strategy, "frounds", env={"ZS_FR_CHUNK": str((1024, 4096, 10240)[(level + strategy) % 3]), "ZS_FR_RANGE": str((1, 3, 8)[(level + 2 * strategy) % 3]), **({"ZS_FR_RANGE_VARY": "1"} if level == 2 else {})})  # (VARY: another range every round, at most the given one)
     for name in ("alice_98304", "zeros_98305", "lowent_98305", "runs", "ptt5", "fuzz208279"):
         for w, tile in ((64, 256), (256, 1024), (2048, 8192)):
             run(files[name], 1 + (w // 64) % 3, 0, "fsweep", env={"ZS_FS_W": str(w), "ZS_FS_TILE": str(tile)})

@@ -830,22 +830,47 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
                 return false;
             ZS_HIP(c, hipMemcpyAsync(c->fr_chunks.p, pl.fr_chunks.data(), nch * sizeof(FsChunk), hipMemcpyHostToDevice, stream));
             ZS_HIP(c, hipMemsetAsync(c->fr_counters.p, 0, 4 * ((size_t)max_rounds + 16), stream));
+            // more chunks than CUs: a workgroup takes a range of consecutive chunks in turn, every chunk reading what the chunks before
+            // it in the range have just left -- within a range the parse is sequential, and the rounds only have to settle what
+            // crosses the ranges' ends (1 MiB of text in chunks of 8192: 43 rounds and 27 runs per chunk with ranges of one, 21 and
+            // 11.5 with ranges of four, 6 and 3.5 with ranges of sixteen; tests/model mode frounds)
+            // A round's ranges are chosen from what the round before changed: while most chunks still change, as many ranges as CUs;
+            // once the chunks that will run again fit the chip (a changed chunk wakes the ~4 behind it), one chunk per workgroup --
+            // two active chunks of one range would wait for each other.
+            // (below two chipfuls of chunks ranges of one: the corpus, 336 chunks of 11 files, 13.9 / 19.1 ms against 16.5 / 23.6)
+            const int range_max = getenv("ZS_FR_RANGE") ? std::max(1, atoi(getenv("ZS_FR_RANGE"))) : nch >= 512 ? (int)((nch + 255) / 256) : 1;
             FsRounds fr{dev<FsChunk>(c->fr_chunks), dev<FsMeta>(c->fr_meta), dev<uint32_t>(c->fr_planes), dev<uint32_t>(c->fr_prov), dev<uint32_t>(c->fr_counters),
-                        (int64_t)plane_words, (int)nch, 0};
-            const int group = getenv("ZS_FR_GROUP") ? atoi(getenv("ZS_FR_GROUP")) : 4;  // rounds between two looks at the counter
+                        (int64_t)plane_words, (int)nch, 0, range_max};
+            const int group = getenv("ZS_FR_GROUP") ? atoi(getenv("ZS_FR_GROUP")) : 4;  // rounds between two looks at the counter (ranges of one)
             uint32_t changed = 1;
             int r = 0;
+            std::string trace;
             while (r < max_rounds && changed) {
-                for (int g = 0; g < group && r < max_rounds; g++, r++) {
+                const int g_n = fr.range > 1 ? 1 : group;
+                const unsigned n_wg = (unsigned)((nch + (size_t)fr.range - 1) / (size_t)fr.range);
+                for (int g = 0; g < g_n && r < max_rounds; g++, r++) {
                     fr.round = r;
-                    hipLaunchKernelGGL((zs_fast_sweep_kernel<1024, kFsTile1, true>), dim3((unsigned)nch), dim3(1024), fs_lds, stream, d_sd, d_st, dev<uint16_t>(c->link),
+                    hipLaunchKernelGGL((zs_fast_sweep_kernel<1024, kFsTile1, true>), dim3(n_wg), dim3(1024), fs_lds, stream, d_sd, d_st, dev<uint16_t>(c->link),
                                        dev<uint32_t>(c->syms), dev<int32_t>(c->blk_end), dev<int32_t>(c->blk_top), lv, strategy, fr);
                 }
                 ZS_HIP(c, hipMemcpyAsync(&changed, dev<uint32_t>(c->fr_counters) + (r - 1), 4, hipMemcpyDeviceToHost, stream));
                 ZS_HIP(c, hipStreamSynchronize(stream));
+                if (getenv("ZS_DEBUG")) {
+                    static auto t_last = std::chrono::steady_clock::now();
+                    const auto t_now = std::chrono::steady_clock::now();
+                    char b[64];
+                    snprintf(b, sizeof b, " %u/%d(%.2f)", changed, fr.range, r <= g_n ? 0.0 : std::chrono::duration<double, std::milli>(t_now - t_last).count());
+                    t_last = t_now;
+                    trace += b;
+                }
+                if (!getenv("ZS_FR_RANGE_FIXED")) {
+                    const size_t awake = std::min<size_t>(nch, 4 * (size_t)changed);
+                    const int tail = getenv("ZS_FR_TAIL_RANGE") ? atoi(getenv("ZS_FR_TAIL_RANGE")) : 1;
+                    fr.range = std::min<int>(range_max, std::max<int>(tail, (int)((awake + 255) / 256)));
+                }
             }
             c->fast_rounds = r;
-            if (getenv("ZS_DEBUG")) fprintf(stderr, "zs: DeflateFast over %zu chunks of %d streams: %d rounds\n", nch, n, r);
+            if (getenv("ZS_DEBUG")) fprintf(stderr, "zs: DeflateFast over %zu chunks of %d streams, up to %d to a workgroup: %d rounds (changed/range:%s)\n", nch, n, range_max, r, trace.c_str());
             if (changed) {
                 c->err = "the rounds over DeflateFast did not reach their fixed point";
                 return false;

@@ -138,7 +138,17 @@ struct FsMeta {
     int32_t preins;   // the position its read event inserted ahead, -1
     int32_t changed;  // this round's run left something else than the run before
     int32_t cur;      // which of its two bit planes holds what it left
+    // A workgroup may take a range of consecutive chunks in turn, each reading what the ones before it in the range have
+    // just left (this round) and of the others what the round before left; the ranges may differ from round to round.  What a
+    // run has seen of a chunk j before it: j's output of the run's own round if j >= seen_lo, else of the round before.
+    int32_t chg_round;  // the last round in which its run left something else
+    int32_t ran_round;  // the round of its last run
+    int32_t seen_lo;    // the first chunk of the range it ran in
+    int32_t pad;
 };
+// Does a chunk that last ran in round `ran` within a range that began at chunk `seen_lo` have to run again because of chunk
+// j before it, whose output last changed in round `chg`?
+ZS_HD bool fs_stale(int chg, int j, int ran, int seen_lo) { return chg > ran || (chg == ran && j < seen_lo); }
 constexpr int kFsChunkMax = 10240;  // a chunk's positions: one staging of the tile covers it (zs_fast_sweep.hip: TILE - W - 258 - 64)
 constexpr int kFsChunkMin = 1024;
 template <class Vec>

@@ -8,12 +8,13 @@
 // rounded down to 64 on; a wave owns the group of 64 positions with its number):
 //
 //   1. search     every lane searches its position under the set as it stands (final below w0, the last sweep's parse
-//                 behind it, "inserted" where nothing has been parsed yet): fs_search in two alternating phases -- all
-//                 walking lanes skip along their chains to the next entry that is in the set (a dozen instructions a step),
-//                 then all compare once -- because the CU is bound by instruction issue here (16 waves, every one of their
-//                 instructions costs the sweep 4 cycles) and a one-phase step is 70 instructions whatever the lane does.  A
-//                 search whose first candidate lies below w0 rests on final bits alone: its result is marked and the
-//                 position is not searched again
+//                 behind it, "inserted" where nothing has been parsed yet): fs_search, one chain entry per trip, lanes
+//                 leaving through the execution mask (the CU is bound by instruction issue here -- 16 waves, every one of
+//                 their instructions costs the sweep 4 cycles; forms with fewer, fuller trips were measured and were
+//                 slower, profiles/r04_fast_sweep_variants.md).  A window position's first step is its link under the
+//                 guess (gl: the distance to the nearest entry the guess has in the set, made once per sweep for all
+//                 walkers).  A search whose first candidate lies below w0 rests on final bits alone: its result is
+//                 marked and the position is not searched again
 //   2. hops       next(p) = p + 1 or p + match length.  Per lane, by six rounds of pointer doubling with ds_bpermute: the
 //                 first index behind its group that its hops lead to, the length of the hop that leaves the group and the
 //                 number of hops (the doubling tables stay in registers; the result goes to the exit table)  -- barrier 1
@@ -33,6 +34,16 @@
 //
 // What it leaves is what K4 / K5 leave for the lazy parse, so the tail engine (restored from the bitmap and the links --
 // compressed or not, le_restore_prev_ins finds the same predecessor) and the block kernels go on unchanged.
+//
+// Two forms (template parameter CH).  CH = false: one workgroup takes a stream from its first position to fv_end, tile after
+// tile; a batch of many streams fills the chip that way and parses every position once.  CH = true, the chunk form
+// (zs_fast_sweep.h "Rounds"): one workgroup per chunk of a stream and round -- the guess below the chunk's first loop-top
+// comes from the chunks before it as the round before left them (bit planes by chunk parity and FsMeta::cur, entry
+// loop-tops and event cuts in FsMeta), K1's links are only read (the history's links are compressed in LDS after staging,
+// an event's cut stays in LDS and FsMeta), the symbols go to the chunk's provisional buffer; a chunk whose inputs did not
+// change copies its FsMeta forward.  When a round has changed nothing, zs_fast_commit_scan_kernel / zs_fast_commit_kernel
+// put the symbols, block cuts, bits, cuts and the stream's state where the stream form would have left them.  8 MiB of text:
+// 117 / 192 MB/s at levels 1 / 3 against 48 / 21 for one workgroup; kennedy.xls 3.3 ms against 67.
 
 constexpr int kFsBack = 32512;   // >= kMaxDist, multiple of 64
 constexpr int kFsFwd = 272;      // >= kMaxMatch + 8, multiple of 16
@@ -84,6 +95,8 @@ struct FsRounds {
     uint32_t *counters;   // per round: chunks that left something else than the round before
     int64_t plane_words;
     int nch, round;
+    int range;            // consecutive chunks a workgroup takes in turn: a chunk reads what the chunks before it in its range have just
+                          // left, and of the others what the round before left
 };
 static_assert(kFsChunkMax + 64 + 63 <= kFsTile1 - 1024 && kFsChunkMax + 64 + 63 + 1024 + 288 <= kFsTile1, "a chunk is covered by one staging of the tile");
 
@@ -94,10 +107,6 @@ __global__ __launch_bounds__(NT) void zs_fast_sweep_kernel(const StreamDesc *sd,
     constexpr int W = NT, NG = W / 64, RING = 2 * W;
     constexpr int fsBytes = FsLayout<TILE>::bytes, fsLinks = FsLayout<TILE>::links, fsBitWords = FsLayout<TILE>::bit_words;
     static_assert(TILE % 64 == 0 && TILE >= 2 * W && W + 258 < 4096 && NG <= 64, "tile / doubling word");
-    FsChunk ck = FsChunk();
-    if constexpr (CH) ck = fr.chunks[blockIdx.x];
-    const StreamDesc s = sd[CH ? ck.stream : (int)blockIdx.x];
-    if (s.fv_end < 0) return;
     uint8_t *wb = smem;                                         // bytes, index = position - lo
     uint16_t *wl = (uint16_t *)(smem + fsBytes);                // link entries
     uint32_t *bm = (uint32_t *)(smem + fsBytes + 2 * fsLinks);  // inserted bits, word k = positions [lo + 32 k, + 32)
@@ -112,6 +121,19 @@ __global__ __launch_bounds__(NT) void zs_fast_sweep_kernel(const StreamDesc *sd,
     // (static: the compiler then knows the address space and the atomics below are LDS instructions, not flat ones)
     __shared__ uint32_t shv[4];
     const int tid = threadIdx.x, lane = lane_id(), wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (uniform, and the compiler knows)
+    // the chunk form: the workgroup's chunks in turn; the stream form: the stream
+    const int kc0 = CH ? (int)blockIdx.x * fr.range : (int)blockIdx.x, kc1 = CH ? (kc0 + fr.range < fr.nch ? kc0 + fr.range : fr.nch) : kc0 + 1;
+    for (int kc = kc0; kc < kc1; kc++) {
+    FsChunk ck = FsChunk();
+    if constexpr (CH) {
+        // what the chunk before in the range wrote is read from here on: stores of this workgroup's own lanes, and a workgroup's
+        // lanes share their CU's L1 -- the barrier's workgroup-scope fence is all it takes (an agent-scope fence writes the
+        // XCD's L2 back: 60 us a time on this part, whatever the chunk does)
+        if (kc > kc0) __syncthreads();
+        ck = fr.chunks[kc];
+    }
+    const StreamDesc s = sd[CH ? ck.stream : kc];
+    if (s.fv_end < 0) continue;
     const int n = s.n, body_end = CH ? ck.b_hi - 1 : s.fv_end;  // (a chunk's last loop-top lies below b_hi)
     const gcbytes in = as_global(s.in);
     uint16_t *lk = link + s.pos_off;
@@ -124,7 +146,6 @@ __global__ __launch_bounds__(NT) void zs_fast_sweep_kernel(const StreamDesc *sd,
     __shared__ uint32_t pOff[64];
     __shared__ int32_t pvar[4];  // [0] chunks in reach, [1] something changed, [2] where the chunk before left
     int E0 = 0, np = 0, cut_ev = -1, preins_ev = -1;
-    const int kc = (int)blockIdx.x;
     const FsMeta *mp = nullptr;
     FsMeta *mn = nullptr;
     if constexpr (CH) {
@@ -132,45 +153,45 @@ __global__ __launch_bounds__(NT) void zs_fast_sweep_kernel(const StreamDesc *sd,
         const int lo_read = ck.b_lo - kFsBack - 64;
         if (threadIdx.x < 64) {
             const int j = kc - 1 - (int)threadIdx.x;
+            // a chunk of the workgroup's own range has run in this round already; of the others there is what the round before
+            // left (nothing in round 0: their positions count as "inserted")
             bool reach = false, chg = false;
-            if (j >= ck.first && fr.chunks[j].b_hi + kMaxMatch > lo_read) {
+            if (j >= ck.first && fr.chunks[j].b_hi + kMaxMatch > lo_read && (fr.round > 0 || j >= kc0)) {
                 reach = true;
-                if (fr.round) {
-                    const FsMeta m = mp[j];
-                    chg = m.changed != 0;
-                    pE[threadIdx.x] = m.E, pCut[threadIdx.x] = m.cut;
-                    pOff[threadIdx.x] = (uint32_t)((size_t)(m.cur * 2 + (j & 1)) * (size_t)fr.plane_words + (size_t)(s.pos_off >> 5));
-                    if (threadIdx.x == 0) pvar[2] = m.X;
-                }
+                const FsMeta m = j >= kc0 ? mn[j] : mp[j];
+                chg = fr.round > 0 && fs_stale(m.chg_round, j, mp[kc].ran_round, mp[kc].seen_lo);
+                pE[threadIdx.x] = m.E, pCut[threadIdx.x] = m.cut;
+                pOff[threadIdx.x] = (uint32_t)((size_t)(m.cur * 2 + (j & 1)) * (size_t)fr.plane_words + (size_t)(s.pos_off >> 5));
+                if (threadIdx.x == 0) pvar[2] = m.X;
             }
             const uint64_t rm = __ballot(reach), cm = __ballot(chg);
-            if (threadIdx.x == 0) pvar[0] = (int)__builtin_popcountll(rm), pvar[1] = (fr.round == 0 || cm != 0) ? 1 : 0;
+            // (the chunks in reach are the nearest ones: lanes 0 .. np - 1)
+            if (threadIdx.x == 0) pvar[0] = (int)__builtin_popcountll(rm), pvar[1] = (fr.round == 0 || cm != 0) ? 1 : 0, pvar[3] = (int)(rm & 1ull);
         }
         __syncthreads();
-        np = fr.round ? pvar[0] : 0;
+        np = pvar[0];
         if (!pvar[1]) {  // nothing it reads has changed: what it left stays
             if (threadIdx.x == 0) {
                 FsMeta m = mp[kc];
                 m.changed = 0;
                 mn[kc] = m;
             }
-            return;
+            continue;
         }
-        E0 = ck.idx == 0 ? 0 : (fr.round == 0 ? ck.b_lo : pvar[2]);
+        E0 = ck.idx == 0 ? 0 : (pvar[3] ? pvar[2] : ck.b_lo);
         if (E0 >= ck.b_hi) {  // (a last span shorter than the match that crosses it)
             if (threadIdx.x == 0) {
                 const FsMeta o = mp[kc];
                 const int chg = (fr.round == 0 || o.E != E0 || o.X != E0) ? 1 : 0;
-                mn[kc] = FsMeta{E0, E0, 0, -1, ck.kfired0, -1, chg, fr.round ? o.cur : 0};
+                mn[kc] = FsMeta{E0, E0, 0, -1, ck.kfired0, -1, chg, fr.round ? o.cur : 0, chg ? fr.round : o.chg_round, fr.round, kc0, 0};
                 if (chg) atomicAdd(&fr.counters[fr.round], 1u);
             }
-            return;
+            continue;
         }
     }
     // the bits of [p32, p32 + 32) below the chunk's first loop-top, from the planes of the chunks that own the positions
     auto hist_word = [&](int p32) -> uint32_t {
         if (p32 < 0) return 0u;
-        if (fr.round == 0) return 0xFFFFFFFFu;
         uint32_t v = 0, seen = 0;
         for (int t = 0; t < np; t++) {
             const int a = pE[t] > p32 ? pE[t] : p32, b0 = t ? pE[t - 1] : E0, b = b0 < p32 + 32 ? b0 : p32 + 32;
@@ -590,10 +611,10 @@ __global__ __launch_bounds__(NT) void zs_fast_sweep_kernel(const StreamDesc *sd,
                    kc, fr.round, E0, X, pf_sweeps, pf[0], pf[1], pf[2], pf[3], pf[4], pf[5], pf[6], pf[7], pf[8], pf[9]);
 #endif
         if (tid == 0) {
-            mn[kc] = FsMeta{E0, X, nsyms, cut_ev, k_fired, preins_ev, diff, cur};
+            mn[kc] = FsMeta{E0, X, nsyms, cut_ev, k_fired, preins_ev, diff, cur, diff ? fr.round : o.chg_round, fr.round, kc0, 0};
             if (diff) atomicAdd(&fr.counters[fr.round], 1u);
         }
-        return;
+        continue;
     }
     // ---- leave: the bits that became final go back to the stream's bitmap (the tail engine restores its chains from them and
     //      the links)
@@ -618,6 +639,7 @@ __global__ __launch_bounds__(NT) void zs_fast_sweep_kernel(const StreamDesc *sd,
         ss.preins = preins;
         ss.body_syms = (uint32_t)nsyms;
     }
+    }  // (the workgroup's chunks)
 }
 
 // ---- The rounds are over (a round changed nothing: the chunks' symbols, bits and hand-over loop-tops are the reference's).
