@@ -588,8 +588,8 @@ def main():
                 torch.cuda.empty_cache()
                 for lvl in (1, 3, 6):
                     sec["corpus_L%d" % lvl] = secondary_corpus(eng, dev, lvl, ks, with_cpu=not args.no_cpu_baseline)
-                # DeflateFast (Deflate.Fast.cs:20-128) on ONE stream: the window-wide sweeps of a single workgroup
-                # (zs_fast_sweep_kernel); the reference publishes 54.8 / 36.9 MB/s for alice29 at levels 1 / 3 (benchmarks.md:63,118)
+                # DeflateFast (Deflate.Fast.cs:20-128) on ONE stream: rounds of window-wide sweeps over the stream's chunks
+                # (zs_fast_sweep_kernel, chunk form); the reference publishes 54.8 / 36.9 MB/s for alice29 at levels 1 / 3 (benchmarks.md:63,118)
                 en8 = datagen.english(8 << 20, 77)
                 for lvl in (1, 3):
                     sec["english8_L%d" % lvl], b = secondary_deflate(eng, dev, "english8: ONE 8 MiB text stream (DeflateFast)", [en8], lvl, 2)
@@ -599,7 +599,16 @@ def main():
                         if slen == len(en8):
                             sec["english8_L%d" % lvl]["bit_identical_to_cpu"] = bool(b.stream_bytes(0) == refs)
                     del b
-                # ... and in a batch (a stream per CU and round): 512 x 512 KiB
+                # ... the headline buffer at levels 1 and 3 (8191 chunks, 32 consecutive ones to a workgroup)
+                for lvl in (1, 3):
+                    sec["english64_L%d" % lvl], b = secondary_deflate(eng, dev, "english64: the headline buffer under DeflateFast", [data], lvl, 2)
+                    if not args.no_cpu_baseline:
+                        cbs, refs, slen = cpu_baseline(data, lvl, budget_s=6.5, name="english64")
+                        sec["english64_L%d" % lvl]["cpu_baseline"] = cbs
+                        if slen == len(data):
+                            sec["english64_L%d" % lvl]["bit_identical_to_cpu"] = bool(b.stream_bytes(0) == refs)
+                    del b
+                # ... and in a batch (one workgroup per stream): 512 x 512 KiB
                 texts = [datagen.english(512 << 10, 1000 + i) for i in range(512)]
                 sec["fast512_L1"], b = secondary_deflate(eng, dev, "512 x 512 KiB text streams in one batch (DeflateFast)", texts, 1, 2, check_every=64)
                 del b, texts

@@ -362,20 +362,21 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
     }
     if (pl.any_fv && !getenv("ZS_FAST_NO_ROUNDS")) {
         // levels 1-3: every stream's parse as rounds over its chunks, all chunks of the batch at once (zs_fast_sweep.h "Rounds"),
-        // when that is the shorter way.  One workgroup per stream takes as long as the longest stream (45 / 20 MB/s at levels 1 /
-        // 3 on text); the rounds parse every chunk again and again -- text: ~27 / 18 times at levels 1 / 3, kennedy.xls 4 -- and so
-        // take the chip ~1 ms per 250 / 180 KB of the whole batch (profiles/r04_fast_rounds_*.log).  A few streams, or one much
-        // longer than the rest: rounds; a batch of equals: one workgroup each.
+        // when that is the shorter way.  One workgroup per stream takes as long as the longest stream at 46 / 35 / 20 MB/s (levels
+        // 1 / 2 / 3 on text; kennedy.xls and ptt5 are slower).  The rounds take the whole batch through the chip at ~2.5 GB/s a few
+        // times over and then wait for the last disturbances to die out -- up to ~20 ms on text, less on anything else, and never
+        // longer than the longest stream takes one workgroup (profiles/r04_fast_batch_shapes.log: 4 x 4 MiB 33 against 89 ms,
+        // 32 x 4 MiB 55 against 92, 64 x 1 MiB 32 against 23, 128 x 256 KiB 11 against 6.6 at level 1; at level 3 the rounds win
+        // up to 64 x 1 MiB).
         int64_t pos_fv = 0, max_fv = 0;
         for (int i = 0; i < n; i++)
             if (pl.sd[(size_t)i].fv_end >= 0) {
                 pos_fv += pl.sd[(size_t)i].fv_end + 1;
                 max_fv = std::max<int64_t>(max_fv, pl.sd[(size_t)i].fv_end + 1);
             }
-        const double ratio = getenv("ZS_FR_RATIO") ? atof(getenv("ZS_FR_RATIO")) : (level >= 3 ? 8.0 : 5.0);
-        if ((double)pos_fv <= ratio * (double)max_fv) {
-            // about one chunk per CU as long as the chunks stay above 2048 positions (a run's fixed cost -- staging 32 K positions of
-            // history -- is 15-30 us, a sweep makes ~390 positions final in 8 us), at most what one staging of the tile covers
+        const double t_stream = (double)max_fv / (level >= 3 ? 20e6 : level == 2 ? 35e6 : 46e6);
+        const double t_rounds = std::min(0.020, (double)max_fv / 50e6) + (double)pos_fv / 2.5e9;
+        if (getenv("ZS_FR_RATIO") ? (double)pos_fv <= atof(getenv("ZS_FR_RATIO")) * (double)max_fv : t_rounds < t_stream) {
             // chunks of 2048 positions or more (a run's fixed cost -- staging 32 K positions of history -- is 15-30 us, a sweep makes
             // ~390 positions final in 8 us), at most what one staging of the tile covers; between the two, as many chunks as fit
             // the chip at once: a round of 260 chunks takes the 256 CUs twice as long as one of 250
