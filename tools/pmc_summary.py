@@ -98,7 +98,7 @@ if tab:
               open(os.path.join(dst, "%s_pmc_insts_english64_L6.json" % tag), "w"), indent=1)
 
 # round 3: kernel statistics of the paths beside the headline, the counters of the DeflateFast kernel in a batch
-for w in ("fast512", "fast1_L1", "fast1_L3", "writes1000", "scanlines", "flushed64k"):
+for w in ("fast512", "fast1_L1", "fast1_L3", "fast64_L1", "fast64_L3", "writes1000", "scanlines", "flushed64k"):
     stw = glob.glob(os.path.join(src, "stats_" + w, "**", "*kernel_stats.csv"), recursive=True)
     if stw:
         rows = list(csv.reader(open(stw[0])))
@@ -139,8 +139,39 @@ if tab1:
                        "workgroup of zs_fast_sweep_kernel on one CU; mean per launch.  A wave64 vector instruction holds its SIMD for 4 "
                        "cycles: the issue time is what the kernel's vector instructions alone take on that CU's four SIMDs.", "kernels": tab1},
               open(os.path.join(dst, "%s_pmc_fast1_L1.json" % tag), "w"), indent=1)
+# round 4: the rounds over the chunks of english64 at level 1 -- counters summed over the launches of one call (prof_cases runs a
+# warm-up call and one timed call: half of the sum)
+def counter_sum(dirname, cname, pat):
+    tot, cnt = {}, {}
+    for fn in glob.glob(os.path.join(src, dirname, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(fn)):
+            if r["Counter_Name"] != cname or pat not in r["Kernel_Name"]:
+                continue
+            k = short(r["Kernel_Name"])
+            tot[k] = tot.get(k, 0.0) + float(r["Counter_Value"])
+            cnt[k] = cnt.get(k, 0) + 1
+    return tot, cnt
+tab64 = {}
+for d, cs in (("pmc_insts_fast64_L1", names), ("pmc_fetch_fast64_L1", ["FETCH_SIZE"]), ("pmc_write_fast64_L1", ["WRITE_SIZE"])):
+    for cn in cs:
+        tot, cnt = counter_sum(d, cn, "zs_fast")
+        for k, v in tot.items():
+            tab64.setdefault(k, {})[cn] = int(v / 2)
+            tab64[k]["launches_per_call"] = cnt[k] // 2
+if tab64:
+    for k, v in tab64.items():
+        if "SQ_INSTS_VALU" in v:
+            v["valu_issue_ms_at_1024_simds_2.4GHz"] = round(v["SQ_INSTS_VALU"] * 4 / 1024 / 2.4e9 * 1e3, 3)
+        if "FETCH_SIZE" in v:
+            v["fetch_bytes_raw"] = v.pop("FETCH_SIZE") * 1024
+        if "WRITE_SIZE" in v:
+            v["write_bytes"] = v.pop("WRITE_SIZE") * 1024
+    json.dump({"note": "rocprofv3 --pmc (separate passes) over `tools/prof_cases.py fast64_L1 1`: DeflateFast, level 1, english64 as rounds over "
+                       "8191 chunks; SUMS over all launches of one call (the rounds of zs_fast_sweep_kernel in its chunk form, the commit "
+                       "kernels, the speculative-run probe).  Algorithmic bytes of the call: 67 MB in + 30.5 MB out.", "kernels": tab64},
+              open(os.path.join(dst, "%s_pmc_fast64_L1.json" % tag), "w"), indent=1)
 for name, out in (("flush_resume.log", "flush_resume.log"), ("patho.jsonl", "patho_final_build_L6.log"), ("fast_levels.log", "fast_levels.log"),
-                  ("multiwrite_check.log", "multiwrite_check.log")):
+                  ("multiwrite_check.log", "multiwrite_check.log"), ("fast_rounds.log", "fast_rounds.log"), ("fast_big.log", "fast_big.log")):
     pth = os.path.join(src, name)
     if os.path.exists(pth) and os.path.getsize(pth) > 0:
         shutil.copy(pth, os.path.join(dst, "%s_%s" % (tag, out)))

@@ -1,5 +1,5 @@
 """One workload per invocation, a few steps, for rocprofv3 (tools/profile_round.sh): the round-3 paths beside the headline.
-   python3 tools/prof_cases.py fast512 | fast1_L1 | fast1_L3 | writes1000 | scanlines | flushed64k"""
+   python3 tools/prof_cases.py fast512 | fast1_L1 | fast1_L3 | fast64_L1 | fast64_L3 | writes1000 | scanlines | flushed64k [steps]"""
 import io, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -20,9 +20,9 @@ if what == "fast1024":  # 1024 x 256 KiB: more streams than two per CU
         eng.deflate_device_batch(batch, level=1)
     torch.cuda.synchronize()
     print("fast1024 level 1: %.2f ms per batch of 256 MiB" % ((time.perf_counter() - t0) / steps * 1e3))
-elif what in ("fast1_L1", "fast1_L3"):  # DeflateFast on ONE 8 MiB text stream: zs_fast_sweep_kernel, one workgroup
+elif what in ("fast1_L1", "fast1_L3", "fast64_L1", "fast64_L3"):  # DeflateFast on ONE text stream of 8 / 64 MiB: zs_fast_sweep_kernel, rounds over its chunks
     lvl = 1 if what.endswith("L1") else 3
-    text = datagen.english(8 << 20, 77)
+    text = datagen.english(8 << 20, 77) if what.startswith("fast1_") else datagen.english(64 << 20)
     d_in = torch.frombuffer(bytearray(text), dtype=torch.uint8).cuda()
     cap = deflate_bound(len(text))
     d_out = torch.empty(cap, dtype=torch.uint8, device="cuda")
@@ -32,7 +32,7 @@ elif what in ("fast1_L1", "fast1_L3"):  # DeflateFast on ONE 8 MiB text stream: 
         eng.deflate_batch_device([d_in.data_ptr()], [len(text)], [d_out.data_ptr()], [cap], level=lvl)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
-    print("%s: %.2f ms per 8 MiB stream = %.1f MB/s" % (what, dt * 1e3, len(text) / dt / 1e6))
+    print("%s: %.2f ms per %d MiB stream = %.1f MB/s" % (what, dt * 1e3, len(text) >> 20, len(text) / dt / 1e6))
 elif what == "fast512":  # DeflateFast (level 1), 512 x 512 KiB text streams in one batch: zs_fast_sweep_kernel
     texts = [datagen.english(512 << 10, 1000 + i) for i in range(512)]
     d_ins = [torch.frombuffer(bytearray(b), dtype=torch.uint8).cuda() for b in texts]

@@ -30,7 +30,7 @@ rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VA
 echo "inst pmc done"
 else
 # round 3: the paths beside the headline -- DeflateFast in a batch, a stream written in small Writes, a stream that flushes
-for w in fast512 fast1_L1 fast1_L3 writes1000 scanlines flushed64k; do
+for w in fast512 fast1_L1 fast1_L3 fast64_L1 fast64_L3 writes1000 scanlines flushed64k; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$w -o run -- python3 $R/tools/prof_cases.py $w > $O/case_$w.log 2> $O/stats_$w.err
 done
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $O/pmc_insts_fast512 -o run -- python3 $R/tools/prof_cases.py fast512 1 > /dev/null 2> $O/pmc_insts_fast512.err
@@ -38,11 +38,17 @@ rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VA
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_fast512 -o run -- python3 $R/tools/prof_cases.py fast512 1 > /dev/null 2> $O/pmc_fetch_fast512.err
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_fast512 -o run -- python3 $R/tools/prof_cases.py fast512 1 > /dev/null 2> $O/pmc_write_fast512.err
 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $O/pmc_insts_fast1_L1 -o run -- python3 $R/tools/prof_cases.py fast1_L1 1 > /dev/null 2> $O/pmc_insts_fast1_L1.err
+# round 4: DeflateFast as rounds over the chunks of english64 (level 1): instructions and traffic of all the rounds of one call
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d $O/pmc_insts_fast64_L1 -o run -- python3 $R/tools/prof_cases.py fast64_L1 1 > /dev/null 2> $O/pmc_insts_fast64_L1.err
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_fast64_L1 -o run -- python3 $R/tools/prof_cases.py fast64_L1 1 > /dev/null 2> $O/pmc_fetch_fast64_L1.err
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_fast64_L1 -o run -- python3 $R/tools/prof_cases.py fast64_L1 1 > /dev/null 2> $O/pmc_write_fast64_L1.err
 echo "round 3 / 4 cases done"
 python3 $R/tools/flush_resume_bench.py > $O/flush_resume.log 2> $O/flush_resume.err
 python3 $R/tools/patho.py > $O/patho.jsonl 2> $O/patho.err  # (text lines, level 6; profiles/r03_patho.jsonl is the table with level 9 beside it)
 python3 $R/tools/fast_levels.py > $O/fast_levels.log 2> $O/fast_levels.err
 python3 $R/tools/multiwrite_check.py > $O/multiwrite_check.log 2> $O/multiwrite_check.err
+python3 $R/tools/fast_rounds.py > $O/fast_rounds.log 2> $O/fast_rounds.err
+python3 $R/tools/fast_big.py 64 > $O/fast_big.log 2> $O/fast_big.err
 echo "tables done"
 fi
 find $O -name "*.csv" -size +20M -delete
