@@ -66,6 +66,9 @@ struct zs_ctx {
     void *pin_io = nullptr;
     size_t pin_io_cap = 0;
     bool pin_io_busy = false;
+    void *pin_out = nullptr;  // ... and an inflate stream's decoded output (OutBuf)
+    size_t pin_out_cap = 0;
+    bool pin_out_busy = false;
 };
 
 namespace {
@@ -1281,6 +1284,7 @@ void zs_ctx_destroy(zs_ctx *c) {
     if (c->crc_tab) (void)hipFree(c->crc_tab);
     if (c->pinned) (void)hipHostFree(c->pinned);
     if (c->pin_io) (void)hipHostFree(c->pin_io);
+    if (c->pin_out) (void)hipHostFree(c->pin_out);
     for (auto &e : c->ev)
         if (e) (void)hipEventDestroy(e);
     for (auto &e : c->ev_part)
