@@ -443,7 +443,7 @@ static void parse_fast_rounds(Model &m, int64_t &p_out, int &kdone_out, int64_t 
     const bool range_vary = getenv("ZS_FR_RANGE_VARY") != nullptr;  // ... another range every round (the engine chooses them by what the round before changed)
     const int kl = (int)m.rev.size() - 1;
     std::vector<FsChunk> ch;
-    fs_build_chunks(0, m.body_end, kl, target, ch);
+    fs_build_chunks(0, m.body_end, kl, [&](int k) { return m.rev[(size_t)k].at - (kMinLookahead - 1); }, target, ch);
     const int nch = (int)ch.size();
     const size_t N = (size_t)m.n + 4096;
     std::vector<uint8_t> plane[2][2];
@@ -1423,7 +1423,9 @@ int main(int argc, char **argv) {
     m.flush_mode = flush_mode;
     m.incremental = mode == "inc";
     // the bulk form needs a regular read schedule: one Write, or NoFlush Writes whose sizes are multiples of kChunk
-    bool regular = build_read_events(n, wends, m.rev) && (wends.size() <= 1 || flush_mode == 0);
+    // (DeflateFast's sweeps take Write ends anywhere: an event is applied where a sweep starts)
+    const bool fast_mode = mode == "fsweep" || mode == "frounds";
+    bool regular = build_read_events(n, wends, m.rev, fast_mode) && (wends.size() <= 1 || flush_mode == 0);
     m.body_end = (m.lv.func == 2 && strategy != kRle && regular) ? n - kMinLookahead : -1;
     if (mode == "chunk") {
         // the chunked form takes any NoFlush schedule build_geometry accepts (zs_core.h)
@@ -1449,7 +1451,7 @@ int main(int argc, char **argv) {
         if (p > 0) m.body_end = p;  // (run_tail sizes its arrays by this)
     } else if (mode == "fvec" || mode == "fsweep" || mode == "frounds") {
         // DeflateFast, single Write: the vector form up to the last loop-top with a full lookahead, then the literal engine
-        m.body_end = (m.lv.func == 1 && strategy != kRle && wends.size() <= 1 && flush_mode == 0 && n >= kMinLookahead) ? n - kMinLookahead : -1;
+        m.body_end = (m.lv.func == 1 && strategy != kRle && (wends.size() <= 1 || (fast_mode && regular)) && flush_mode == 0 && n >= kMinLookahead) ? n - kMinLookahead : -1;
         kind = kR, pend = 0, p = 0, k_done = 0, preins = -1;
         if (m.body_end >= 0 && mode == "fsweep") parse_fast_sweep(m, p, k_done, preins);
         else if (m.body_end >= 0 && mode == "frounds") parse_fast_rounds(m, p, k_done, preins);

@@ -959,6 +959,44 @@ def _deflate_writes(engine, data, ends, level, strategy=0):
 
 
 @pytest.mark.gpu
+def test_several_writes_at_the_fast_levels_take_the_sweeps(engine, oracle):
+    """Levels 1-3 (DeflateFast, Deflate.Fast.cs:20-128) on a stream written in several NoFlush Writes: a Write end is a read event
+    like a window end (Fill_window reads, the position behind the loop-top is inserted ahead, Deflate.cs:967-1019), and the
+    sweeps apply an event where a sweep -- or a chunk of the rounds -- starts.  Stream.CopyTo's 81 920 bytes, 65 536, 70 001,
+    100 000, a first Write of 300 bytes then megabytes: byte-exact against the oracle's WriteCore loop, through the device entry
+    and through the Stream classes, and at device speed (8 MiB in 81 920-byte Writes took the literal engine 4-16 s).  Sizes
+    whose ends fall where a loop-top may or may not slide the window (16 385-byte scanlines) stay with the literal engine: exact,
+    slow."""
+    import time
+    text = datagen.english(8 << 20, 31)
+    ptt5 = oracle_binding.corpus("ptt5")
+    for data, size in ((text, 81920), (text, 65536), (text[:3 << 20], 70001), (text[:3 << 20], 100000), (ptt5, 81920), (bytes(600000), 81920)):
+        chunks = [size] * (len(data) // size) + ([len(data) % size] if len(data) % size else [])
+        ends = list(np.cumsum(chunks))
+        for lvl in (1, 2, 3):
+            z, dt = _deflate_writes(engine, data, ends, lvl)
+            assert z == oracle.compress(data, lvl, chunks=chunks), (len(data), size, lvl)
+            if len(data) == 8 << 20:
+                assert dt < 0.5, "%d-byte Writes at level %d: %.2f s -- the literal engine's pace" % (size, lvl, dt)
+    # a short first Write, then long ones; through the Stream class (host memory, the WriteCore loop)
+    data = text[:2 << 20]
+    chunks = [300, 1 << 20, (1 << 20) - 300]
+    out = io.BytesIO()
+    s = ZlibOutputStream(out, ZlibOptions(CompressionLevel=CompressionLevel(1)), engine=engine)
+    o = 0
+    for c in chunks:
+        s.write(data[o:o + c])
+        o += c
+    s.close()
+    assert out.getvalue() == oracle.compress(data, 1, chunks=chunks)
+    # scanline-sized Writes: the literal engine, the reference's bytes all the same
+    small = text[:200000]
+    chunks = [16385] * (len(small) // 16385) + [len(small) % 16385]
+    z, _ = _deflate_writes(engine, small, list(np.cumsum(chunks)), 1)
+    assert z == oracle.compress(small, 1, chunks=chunks)
+
+
+@pytest.mark.gpu
 def test_any_write_sizes_on_the_bulk_path(engine, oracle):
     """NoFlush Writes of any size -- 1000 bytes, a scanline of 16 385, Stream.CopyTo's 81 920 + 1, random sizes, Writes
     shorter than MIN_LOOKAHEAD mixed in -- take the bulk pipeline (zs_core.h build_geometry: segments cut at the clusters of

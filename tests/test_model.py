@@ -90,6 +90,13 @@ def test_fast_levels_for_the_lanes_of_a_wave(model, tmp_path):
                 # the cuts of equal-bucket events -- until a round changes nothing; zs_fast_commit_kernel's part behind it)
                 # (ZS_FR_RANGE: chunks a workgroup takes in turn, each reading what the ones before it have just left)
                 run(files[name], level, strategy, "frounds", env={"ZS_FR_CHUNK": str((1024, 4096, 10240)[(level + strategy) % 3]), "ZS_FR_RANGE": str((1, 3, 8)[(level + 2 * strategy) % 3]), **({"ZS_FR_RANGE_VARY": "1"} if level == 2 else {})})  # (VARY: another range every round, at most the given one)
+    # several NoFlush Writes at the fast levels: a Write end is a read event like a window end (Stream.CopyTo's 81 920 bytes, 65 536,
+    # 70 001; sizes whose ends fall where a loop-top may or may not slide the window -- 16 385-byte scanlines -- stay with the
+    # literal engine, which the model then runs for the whole stream)
+    for name in ("alice_98304", "lowent_98305", "ptt5", "runs", "low150k"):
+        for wchunk in (81920, 65536, 70001, 40000, 16385):
+            run(files[name], 1 + wchunk % 3, 0, "fsweep", wchunk=wchunk)
+            run(files[name], 1 + wchunk % 3, 0, "frounds", wchunk=wchunk, env={"ZS_FR_CHUNK": "2048", "ZS_FR_RANGE": "3"})
     for name in ("alice_98304", "zeros_98305", "lowent_98305", "runs", "ptt5", "fuzz208279"):
         for w, tile in ((64, 256), (256, 1024), (2048, 8192)):
             run(files[name], 1 + (w // 64) % 3, 0, "fsweep", env={"ZS_FS_W": str(w), "ZS_FS_TILE": str(tile)})

@@ -242,12 +242,17 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
             for (size_t k = 0; k + 1 < writes->flush.size(); k++) inner_flush = inner_flush || writes->flush[k] != 0;
         const bool slow_ok = lv.func == 2 && strategy != kRle && !cont && !lit_forced && !(multi && inner_flush) &&
                              build_geometry(len, multi ? writes->ends : no_ends_, geo, gs);
-        const bool regular = cont ? false : multi ? false : build_read_events(len, std::vector<int64_t>(one_write, one_write + 1), rev);
+        // levels 1-3 take several NoFlush Writes too when every read brings a full lookahead and no Write ends where its loop-top
+        // may or may not slide the window (zs_core.h build_read_events: Stream.CopyTo's 81 920-byte Writes do; a Write every few
+        // bytes does not)
+        const bool fast_multi = multi && !flushing && !cont && !ro && lv.func == 1 && strategy != kRle && !getenv("ZS_NO_FAST_MULTI") &&
+                                build_read_events(len, writes->ends, rev, true);
+        const bool regular = cont ? false : multi ? fast_multi : build_read_events(len, std::vector<int64_t>(one_write, one_write + 1), rev);
         s.body_end = slow_ok ? (int32_t)geo.body_end : -1;
         // levels 1-3, one Write: the speculative chunk runs for large streams (they verify on periodic data and are parallel
         // inside a stream), else -- and when they did not verify (force_seq) -- DeflateFast for the lanes of a wave
-        const bool fast_one = lv.func == 1 && strategy != kRle && !multi && !flushing && final_run && !ro && regular && len >= kMinLookahead;
-        const bool fast_par = fast_one && !force_seq && len >= kFastMinInput;
+        const bool fast_one = lv.func == 1 && strategy != kRle && (!multi || fast_multi) && !flushing && final_run && !ro && regular && len >= kMinLookahead;
+        const bool fast_par = fast_one && !multi && !force_seq && len >= kFastMinInput;
         s.fv_end = (fast_one && !fast_par && !getenv("ZS_NO_FAST_VEC")) ? (int32_t)(len - kMinLookahead) : -1;
         s.ins_bits = nullptr;
         if (s.fv_end >= 0) {
@@ -390,19 +395,31 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
             // the chip at once: a round of 260 chunks takes the 256 CUs twice as long as one of 250
             int64_t target = getenv("ZS_FR_CHUNK") ? atoll(getenv("ZS_FR_CHUNK")) : pos_fv / 250;
             target = target < 2048 ? 2048 : target > kFsChunkMax ? kFsChunkMax : target;
+            bool too_short = false;
             for (;;) {
                 pl.fr_chunks.clear();
                 pl.fr_max_n = 0;
+                too_short = false;
                 for (int i = 0; i < n; i++) {
                     StreamDesc &s = pl.sd[(size_t)i];
                     if (s.fv_end < 0) continue;
                     s.fr_first = (int32_t)pl.fr_chunks.size();
-                    fs_build_chunks(i, (int64_t)s.fv_end, s.kl, (int)target, pl.fr_chunks);
+                    {
+                        // the stream's read events are its segments (seg_after of event k - 1 = the data end before event k)
+                        const int32_t *after = pl.seg_after.data() + s.seg_off;
+                        const int64_t shortest = fs_build_chunks(i, (int64_t)s.fv_end, s.nsegs - 1, [&](int k) { return (int64_t)after[k - 1] - (kMinLookahead - 1); }, (int)target, pl.fr_chunks);
+                        if (shortest < kFsMinSpan) too_short = true;  // (Write ends a few hundred bytes apart: more chunks in a chunk's reach than it looks at)
+                    }
                     s.fr_n = (int32_t)pl.fr_chunks.size() - s.fr_first;
                     pl.fr_max_n = s.fr_n > pl.fr_max_n ? s.fr_n : pl.fr_max_n;
                 }
                 if (pl.fr_chunks.size() <= 256 || target >= kFsChunkMax || getenv("ZS_FR_CHUNK")) break;
                 target += 128;
+            }
+            if (too_short) {  // one workgroup per stream then
+                pl.fr_chunks.clear();
+                pl.fr_max_n = 0;
+                for (int i = 0; i < n; i++) pl.sd[(size_t)i].fr_first = pl.sd[(size_t)i].fr_n = 0;
             }
             for (FsChunk &ck : pl.fr_chunks) {
                 ck.prov_off = (uint32_t)pl.fr_prov;

@@ -151,16 +151,19 @@ struct FsMeta {
 ZS_HD bool fs_stale(int chg, int j, int ran, int seen_lo) { return chg > ran || (chg == ran && j < seen_lo); }
 constexpr int kFsChunkMax = 10240;  // a chunk's positions: one staging of the tile covers it (zs_fast_sweep.hip: TILE - W - 258 - 64)
 constexpr int kFsChunkMin = 1024;
-template <class Vec>
-inline void fs_build_chunks(int stream, int64_t body_end, int kl, int target, Vec &out) {
+// trig(k), k = 1 .. ntrig: the trigger of read event k (the data end before it - 261), ascending.  Returns the length of the
+// shortest chunk that has a chunk behind it (the kernel looks at 64 chunks in front of one: kFsMinSpan).
+constexpr int kFsMinSpan = 520;  // 64 chunks of this length cover the 32 512 + 64 + 258 positions a chunk's tile reaches back
+template <class Vec, class Trig>
+inline int64_t fs_build_chunks(int stream, int64_t body_end, int ntrig, const Trig &trig, int target, Vec &out) {
     const int32_t first = (int32_t)out.size();
     if (target > kFsChunkMax) target = kFsChunkMax;
     if (target < kFsChunkMin) target = kFsChunkMin;
     int64_t s = 0;
     int fired = 0;
     for (int k = 1;; k++) {
-        const int64_t trig = k <= kl ? read_end_before(k) - (kMinLookahead - 1) : body_end + 1;
-        const int64_t e = trig <= body_end ? trig : body_end + 1;
+        const int64_t tr = k <= ntrig ? (int64_t)trig(k) : body_end + 1;
+        const int64_t e = tr <= body_end ? tr : body_end + 1;
         const int64_t len = e - s;
         int64_t pieces = (len + target - 1) / target;
         if (pieces < 1) pieces = 1;
@@ -176,6 +179,9 @@ inline void fs_build_chunks(int stream, int64_t body_end, int kl, int target, Ve
         if (e > body_end) break;
         s = e, fired = k - 1;  // (the event k itself fires inside the chunk that starts at its trigger)
     }
+    int64_t shortest = 1 << 30;
+    for (size_t i = (size_t)first; i + 1 < out.size(); i++) shortest = shortest < out[i].b_hi - out[i].b_lo ? shortest : out[i].b_hi - out[i].b_lo;
+    return shortest;
 }
 
 }  // namespace zs

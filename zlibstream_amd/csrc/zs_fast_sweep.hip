@@ -209,7 +209,10 @@ __global__ __launch_bounds__(NT) void zs_fast_sweep_kernel(const StreamDesc *sd,
     // below 2^31 (StreamDesc::n)
     int w0 = E0, nsyms = 0, preins = -1, dead_pos = -1, only_pos = -1, ev_end = 0;
     int k_fired = CH ? ck.kfired0 : 0, next_cut = CH ? 0x7FFFFFFF : kBlockSyms - 1;  // (the symbol with this index ends a block, Deflate.cs:910-948; a chunk's symbols get their places later)
-    int trigger = k_fired < kl ? (int)read_end_before(k_fired + 1) - (kMinLookahead - 1) : -1;
+    // read event k fires at the first loop-top at or behind the data end before it - 261; the stream's events are its segment table
+    // (one Write: window ends; several: Write ends too)
+    auto trig_of = [&](int k) -> int { return k < s.nsegs ? s.seg_after[k - 1] - (kMinLookahead - 1) : -1; };
+    int trigger = trig_of(k_fired + 1);
     int t0 = -(1 << 30), w0_staged = E0;
     int x_end = E0;  // where the last sweep's parse ended: the bits of [w0, x_end) are that parse's (the guess the results in the ring belong to)
     if (tid == 0) shv[0] = 0xFFFFFFFFu, shv[1] = 0, shv[2] = 0;
@@ -341,7 +344,7 @@ __global__ __launch_bounds__(NT) void zs_fast_sweep_kernel(const StreamDesc *sd,
                     if (!CH) lk[w0] = 0;  // (a chunk's cut goes into K1's links once the rounds are over)
                 }
             }
-            trigger = k_fired < kl ? (int)read_end_before(k_fired + 1) - (kMinLookahead - 1) : -1;
+            trigger = trig_of(k_fired + 1);
             gl_stale = true;
             __syncthreads();
         }
