@@ -997,6 +997,34 @@ def test_several_writes_at_the_fast_levels_take_the_sweeps(engine, oracle):
 
 
 @pytest.mark.gpu
+def test_rle_streams_written_in_several_writes_run_as_one(engine, oracle):
+    """CompressionStrategy.Rle does not look at NoFlush Write ends (tests/test_oracle.py::test_rle_does_not_look_at_write_ends): a
+    stream written in 1000-byte, scanline or CopyTo-sized Writes runs over the chip like a single Write's (zs_rle.hip) -- the
+    oracle's bytes for that schedule, and at device speed; a schedule with a Write end just below a window end is the literal
+    engine's, exact all the same."""
+    rows = datagen.sparse(1024, 1024)  # 4 MiB
+    text = datagen.english(2 << 20, 3)
+    for data, size in ((rows, 1000), (rows, 16385), (text, 81920), (rows, 300)):
+        chunks = [size] * (len(data) // size) + ([len(data) % size] if len(data) % size else [])
+        ends = list(np.cumsum(chunks))
+        safe = not any(E >= 65536 - 262 and E % 32768 >= 32768 - 262 for E in ends[:-1])
+        for lvl in (1, 6):
+            if not safe and len(data) > (1 << 20):
+                data, chunks = data[:300000], None
+                chunks = [size] * (len(data) // size) + ([len(data) % size] if len(data) % size else [])
+                ends = list(np.cumsum(chunks))
+            z, dt = _deflate_writes(engine, data, ends, lvl, strategy=3)
+            assert z == oracle.compress(data, lvl, 3, chunks=chunks), (len(data), size, lvl)
+            if safe and len(data) >= (2 << 20):
+                assert dt < 0.2, "%d-byte Writes under Rle at level %d: %.2f s" % (size, lvl, dt)
+    # a Write that ends 100 bytes below the first window end: the literal engine
+    data = rows[:200000]
+    chunks = [65436, len(data) - 65436]
+    z, _ = _deflate_writes(engine, data, list(np.cumsum(chunks)), 6, strategy=3)
+    assert z == oracle.compress(data, 6, 3, chunks=chunks)
+
+
+@pytest.mark.gpu
 def test_any_write_sizes_on_the_bulk_path(engine, oracle):
     """NoFlush Writes of any size -- 1000 bytes, a scanline of 16 385, Stream.CopyTo's 81 920 + 1, random sizes, Writes
     shorter than MIN_LOOKAHEAD mixed in -- take the bulk pipeline (zs_core.h build_geometry: segments cut at the clusters of

@@ -155,3 +155,50 @@ def test_english_generator_is_pinned():
     """The chunked generator must keep producing the bytes the round-1 digests and benches were taken on."""
     assert hashlib.sha256(datagen.english(1 << 20)).hexdigest() == hashlib.sha256(datagen.english(64 << 20)[:1 << 20]).hexdigest()
     assert hashlib.sha256(datagen.english(64 << 20)).hexdigest() == "cd512dd3dd6a2448fbd2603c2434354d758470a43ca17346cbd9fac78f903633"
+
+
+def test_rle_does_not_look_at_write_ends():
+    """CompressionStrategy.Rle (Deflate.Rle.cs:18-104) leaves a Deflate call as soon as fewer than MAX_MATCH bytes are ahead
+    under NoFlush, so every run is measured with a full lookahead whatever the Writes are, and nothing is inserted anywhere:
+    a stream written in NoFlush Writes of any sizes is the single Write's stream, byte for byte -- as long as no Write ends
+    within 262 bytes below a window end, where its loop-top may slide the window earlier than a single Write's would (and
+    with that move a block's permission to be stored).  The device runs such schedules as one Write (zs_engine.hip
+    run_pipeline); this is the property it rests on, on random data -- incompressible stretches, long and short runs -- and
+    random schedules."""
+    import numpy as np
+    orc = oracle_binding.Oracle()
+    rng = np.random.default_rng(11)
+
+    def make(n):
+        parts, tot = [], 0
+        while tot < n:
+            k, m = int(rng.integers(0, 4)), int(rng.integers(1, 60000))
+            if k == 0:
+                b = rng.integers(0, 256, m, dtype=np.uint8).tobytes()
+            elif k == 1:
+                b = bytes([int(rng.integers(0, 256))]) * m
+            elif k == 2:
+                b = np.repeat(rng.integers(0, 3, m, dtype=np.uint8), rng.integers(1, 9, m))[:m].tobytes()
+            else:
+                b = np.repeat(rng.integers(0, 256, m // 50 + 1, dtype=np.uint8), rng.integers(1, 120, m // 50 + 1))[:m].tobytes()
+            parts.append(b)
+            tot += len(b)
+        return b"".join(parts)[:n]
+
+    safe_seen = 0
+    for it in range(60):
+        n = int(rng.integers(70000, 300000))
+        d = make(n)
+        lvl = int(rng.choice([1, 3, 6, 9]))
+        chunks, o = [], 0
+        while o < n:
+            c = int(rng.integers(1, 90000)) if rng.random() < 0.7 else int(rng.integers(1, 600))
+            c = min(c, n - o)
+            chunks.append(c)
+            o += c
+        ends = np.cumsum(chunks)[:-1]
+        if any(E >= 65536 - 262 and E % 32768 >= 32768 - 262 for E in ends):
+            continue
+        safe_seen += 1
+        assert orc.compress(d, lvl, 3, chunks=chunks) == orc.compress(d, lvl, 3), (it, n, lvl)
+    assert safe_seen >= 40

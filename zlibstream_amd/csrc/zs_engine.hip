@@ -206,6 +206,25 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
         out_len[i] = 0;
         if (status) status[i] = ZS_STREAM_ERROR;
     }
+    // CompressionStrategy.Rle does not look at Write ends: Deflate.Rle.cs leaves a Deflate call as soon as fewer than MAX_MATCH bytes
+    // are ahead under NoFlush (:24-38), so every match is measured with a full lookahead whatever the Writes are, and nothing is
+    // inserted anywhere.  What a Write end can move is the loop-top at which the window slides -- when it lies within 262 bytes
+    // below a window end -- and with it a block's permission to be stored.  Any other NoFlush schedule is the single Write's
+    // stream (checked against the oracle on random data and schedules, tests/test_oracle.py) and runs as one.
+    WriteSpec rle_one;
+    if (writes && writes->ends.size() > 1 && strategy == kRle && level >= 1 && !writes->flushing() && !ro && n == 1 && !getenv("ZS_NO_RLE_MULTI")) {
+        bool safe = true;
+        for (size_t k = 0; k + 1 < writes->ends.size() && safe; k++) {
+            const int64_t E = writes->ends[k];
+            safe = !(E >= kWindowSize - kMinLookahead && (E % kWSize) >= kWSize - kMinLookahead);
+        }
+        if (safe) {
+            rle_one = *writes;
+            rle_one.ends.assign(1, in_len[0]);
+            rle_one.flush.assign(1, 0);
+            writes = &rle_one;
+        }
+    }
     Plan pl;
     pl.sd.resize((size_t)n);
     // positions per workgroup of the link kernel (each replays 32 Ki positions of warm-up first): long spans for a
