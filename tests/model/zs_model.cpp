@@ -355,12 +355,28 @@ static void parse_fast_sweep(Model &m, int64_t &p_out, int &kdone_out, int64_t &
         while (t < hi) {
             const uint32_t r = rcur[(size_t)(t - g0)];
             tops.push_back(t);
-            if (tstar < 0 && !(t < st.ev_end && ((rprev[(size_t)t] ^ r) & kFsResMask) == 0)) tstar = t;
             last_top = t;
             t += fs_adv(r);
         }
         const int64_t X = t;  // the path's first position at or behind hi
-        if (tstar < 0) tstar = last_top;
+        // final: the loop-tops up to the first position at which the set this parse implies is not the guess it was searched
+        // under (a loop-top's search looks at the set below itself only: zs_fast_sweep.h fact 2)
+        {
+            std::vector<uint8_t> nb((size_t)(X - st.w0), 0);
+            for (int64_t q : tops) {
+                const int span = fs_inserted_span(rcur[(size_t)(q - g0)], m.lv.lazy);
+                for (int k = 0; k < span; k++) nb[(size_t)(q + k - st.w0)] = 1;
+            }
+            if (st.preins >= st.w0 && st.preins < X) nb[(size_t)(st.preins - st.w0)] = 1;
+            int64_t d = X;
+            for (int64_t q = st.w0; q < X; q++)
+                if (nb[(size_t)(q - st.w0)] != m.ins[(size_t)q]) {
+                    d = q;
+                    break;
+                }
+            for (int64_t q : tops)
+                if (q <= d) tstar = q;
+        }
         const int64_t w0_new = tstar + fs_adv(rcur[(size_t)(tstar - g0)]);
         // ---- the final loop-tops' symbols; block cuts every kBlockSyms symbols (Deflate.cs:910-948)
         for (int64_t q : tops) {
@@ -457,7 +473,7 @@ static void parse_fast_rounds(Model &m, int64_t &p_out, int &kdone_out, int64_t 
     std::vector<uint8_t> ins(N, 1);
     std::vector<uint32_t> rprev(N, kFsFresh), rcur((size_t)W + 64);
     const bool search = m.strategy != kHuffmanOnly;
-    long runs = 0, runs_changed = 0;
+    long runs = 0, runs_changed = 0, sweeps_total = 0;
     int round = 0;
     for (;; round++) {
         const std::vector<FsMeta> &mp = meta[(round + 1) & 1];
@@ -495,7 +511,13 @@ static void parse_fast_rounds(Model &m, int64_t &p_out, int &kdone_out, int64_t 
                     }
                 ins[(size_t)p] = b;
             }
+            // from E on: what the chunk's own run before left (a guess as good as any, and nearly right late in the rounds), "inserted"
+            // where it has none
             for (int64_t p = E; p < top; p++) ins[(size_t)p] = 1;
+            if (round && !getenv("ZS_FR_NO_SEED")) {
+                const FsMeta &own = mp[(size_t)k];
+                for (int64_t p = std::max<int64_t>(E, own.E); p < own.X; p++) ins[(size_t)p] = plane[own.cur][k & 1][(size_t)p];
+            }
             for (int j = j0; j < k; j++)
                 if (view(j).cut >= lo) lnk[(size_t)view(j).cut] = 0;
             FrAcc acc{&m, lnk.data(), ins.data(), lo};
@@ -539,12 +561,27 @@ static void parse_fast_rounds(Model &m, int64_t &p_out, int &kdone_out, int64_t 
                 while (t < hi) {
                     const uint32_t r = rcur[(size_t)(t - g0)];
                     tops.push_back(t);
-                    if (tstar < 0 && !(t < st.ev_end && ((rprev[(size_t)t] ^ r) & kFsResMask) == 0)) tstar = t;
                     last_top = t;
                     t += fs_adv(r);
                 }
                 const int64_t X = t;
-                if (tstar < 0) tstar = last_top;
+                {
+                    std::vector<uint8_t> nb((size_t)(X - st.w0), 0);
+                    for (int64_t q : tops) {
+                        const int span = fs_inserted_span(rcur[(size_t)(q - g0)], m.lv.lazy);
+                        for (int i = 0; i < span; i++) nb[(size_t)(q + i - st.w0)] = 1;
+                    }
+                    if (st.preins >= st.w0 && st.preins < X) nb[(size_t)(st.preins - st.w0)] = 1;
+                    int64_t d = X;
+                    for (int64_t q = st.w0; q < X; q++)
+                        if (nb[(size_t)(q - st.w0)] != ins[(size_t)q]) {
+                            d = q;
+                            break;
+                        }
+                    for (int64_t q : tops)
+                        if (q <= d) tstar = q;
+                    sweeps_total++;
+                }
                 const int64_t w0_new = tstar + fs_adv(rcur[(size_t)(tstar - g0)]);
                 for (int64_t q : tops) {
                     if (q > tstar) break;
@@ -616,7 +653,7 @@ static void parse_fast_rounds(Model &m, int64_t &p_out, int &kdone_out, int64_t 
     p_out = mf[(size_t)nch - 1].X;
     kdone_out = mf[(size_t)nch - 1].kend;
     if (preins_out >= p_out) m.ins[(size_t)preins_out] = 1;
-    if (getenv("ZS_FV_STATS")) printf("frounds: %d chunks of ~%d positions, %d rounds, %.2f runs per chunk, %.2f of them left something else than the run before\n", nch, target, round + 1, (double)runs / (double)nch, (double)runs_changed / (double)nch);
+    if (getenv("ZS_FV_STATS")) printf("frounds: %d chunks of ~%d positions, %d rounds, %.2f runs per chunk, %.2f of them left something else than the run before, %.1f sweeps per run\n", nch, target, round + 1, (double)runs / (double)nch, (double)runs_changed / (double)nch, (double)sweeps_total / (double)runs);
 }
 
 

@@ -885,7 +885,7 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
             // (below two chipfuls of chunks ranges of one: the corpus, 336 chunks of 11 files, 13.9 / 19.1 ms against 16.5 / 23.6)
             const int range_max = getenv("ZS_FR_RANGE") ? std::max(1, atoi(getenv("ZS_FR_RANGE"))) : nch >= 512 ? (int)((nch + 255) / 256) : 1;
             FsRounds fr{dev<FsChunk>(c->fr_chunks), dev<FsMeta>(c->fr_meta), dev<uint32_t>(c->fr_planes), dev<uint32_t>(c->fr_prov), dev<uint32_t>(c->fr_counters),
-                        (int64_t)plane_words, (int)nch, 0, range_max};
+                        (int64_t)plane_words, (int)nch, 0, getenv("ZS_FR_NO_SEED") ? 1 : 0, range_max};
             const int group = getenv("ZS_FR_GROUP") ? atoi(getenv("ZS_FR_GROUP")) : 4;  // rounds between two looks at the counter (ranges of one)
             uint32_t changed = 1;
             int r = 0;

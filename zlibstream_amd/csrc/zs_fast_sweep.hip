@@ -95,6 +95,7 @@ struct FsRounds {
     uint32_t *counters;   // per round: chunks that left something else than the round before
     int64_t plane_words;
     int nch, round;
+    int no_seed;          // (ZS_FR_NO_SEED: the chunk's own bits of the run before are not its first guess)
     int range;            // consecutive chunks a workgroup takes in turn: a chunk reads what the chunks before it in its range have just
                           // left, and of the others what the round before left
 };
@@ -120,6 +121,7 @@ __global__ __launch_bounds__(NT) void zs_fast_sweep_kernel(const StreamDesc *sd,
     // [0] first loop-top with a new result, [1] last loop-top, [2] final loop-tops of the sweep
     // (static: the compiler then knows the address space and the atomics below are LDS instructions, not flat ones)
     __shared__ uint32_t shv[4];
+    __shared__ int32_t gtop[NG], gtle[NG];  // per group: its last loop-top, its last loop-top at or below the group's first difference (-1: none)
     const int tid = threadIdx.x, lane = lane_id(), wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // (uniform, and the compiler knows)
     // the chunk form: the workgroup's chunks in turn; the stream form: the stream
     const int kc0 = CH ? (int)blockIdx.x * fr.range : (int)blockIdx.x, kc1 = CH ? (kc0 + fr.range < fr.nch ? kc0 + fr.range : fr.nch) : kc0 + 1;
@@ -187,6 +189,16 @@ __global__ __launch_bounds__(NT) void zs_fast_sweep_kernel(const StreamDesc *sd,
                 if (chg) atomicAdd(&fr.counters[fr.round], 1u);
             }
             continue;
+        }
+    }
+    // the positions from E0 on that the chunk's run before has bits for, and where they are
+    int seed_lo = 0, seed_hi = 0;
+    size_t seed_off = 0;
+    if constexpr (CH) {
+        if (fr.round > 0 && !fr.no_seed) {
+            const FsMeta o = mp[kc];
+            seed_lo = o.E > E0 ? o.E : E0, seed_hi = o.X;
+            seed_off = (size_t)(o.cur * 2 + (kc & 1)) * (size_t)fr.plane_words + (size_t)(s.pos_off >> 5);
         }
     }
     // the bits of [p32, p32 + 32) below the chunk's first loop-top, from the planes of the chunks that own the positions
@@ -275,6 +287,15 @@ __global__ __launch_bounds__(NT) void zs_fast_sweep_kernel(const StreamDesc *sd,
                 if constexpr (CH) {
                     if (p32 + 32 <= x_end) v = hist_word(p32);
                     else if (p32 < x_end) v = hist_word(p32) | (0xFFFFFFFFu << (uint32_t)(x_end - p32));
+                    // from the chunk's first loop-top on: what its own run before left -- a guess as good as any, and nearly the
+                    // parse itself late in the rounds (a sweep then makes its whole window final)
+                    if (fr.round > 0 && p32 + 32 > x_end) {
+                        const int sa = seed_lo > p32 ? seed_lo : p32, sb = seed_hi < p32 + 32 ? seed_hi : p32 + 32;
+                        if (sa < sb) {
+                            const uint32_t m = (sb - sa >= 32 ? 0xFFFFFFFFu : ((1u << (sb - sa)) - 1u)) << (sa - p32);
+                            v = (v & ~m) | (fr.planes[seed_off + (size_t)(p32 >> 5)] & m);
+                        }
+                    }
                 } else {
                     if (p32 + 32 <= x_end) v = p32 >= 0 ? gbits[p32 >> 5] : 0u;
                     else if (p32 < x_end) v = gbits[p32 >> 5] | (0xFFFFFFFFu << (uint32_t)(x_end - p32));
@@ -419,8 +440,6 @@ __global__ __launch_bounds__(NT) void zs_fast_sweep_kernel(const StreamDesc *sd,
         }
         uint32_t r = ((uint32_t)best << 16) | (uint32_t)bdist | exact;
         if (known) r = old;
-        // the result of the sweep before, if that sweep searched the position (the slot is the position's own)
-        const bool agr = q < ev_end && ((old ^ r) & kFsResMask) == 0;
         if (act) ring[slot] = r;
         FS_PF(1);
         // ---- 2. hops: pointer doubling inside the group; a lane that is not searched (behind hi: the path ends there) points
@@ -486,18 +505,51 @@ __global__ __launch_bounds__(NT) void zs_fast_sweep_kernel(const StreamDesc *sd,
             top = at == self && act;
         }
         const uint64_t tm = __ballot(top);
+        // the set this parse implies for the group's 64 positions: the last loop-top at or below the lane and what it inserts; no
+        // loop-top below the lane: the hop that enters the group covers it (short matches insert their inside,
+        // Deflate.Fast.cs:81-104)
+        bool ins;
         {
-            const uint64_t dis = tm & ~__ballot(agr);
+            const uint64_t below = tm & ((2ull << lane) - 1ull);
+            const int ti = below ? 63 - (int)__builtin_clzll(below) : 0;
+            const int span = __builtin_amdgcn_ds_bpermute(ti << 2, fs_inserted_span(r, lazy));
+            ins = below ? (lane - ti) < span : (lin >= kMinMatch && lin <= lazy);
+            if (q == preins) ins = true;
+        }
+        // What is final (zs_fast_sweep.h fact 2): a loop-top's search looks at the set below itself only, so the loop-tops up to
+        // the first position at which the implied set is not the guess they were searched under have the reference's results.
+        // Per group: that position, the last loop-top at or below it, the last loop-top of all.
+        const int wi = (gi + gbase) >> 5;
+        const uint64_t guess = (uint64_t)bm[wi] | ((uint64_t)bm[wi + 1] << 32);
+        {
+            int pe = 64;  // the group's lanes below this one are covered by the path (the rest, if any, lies behind its end)
+            if (term_before) pe = 0;
+            else if (tm) {
+                const int lt = 63 - (int)__builtin_clzll(tm);
+                pe = lt + __builtin_amdgcn_readlane(fs_adv(r), lt);
+            } else if (entry != 0xFFF) pe = entry & 63;
+            uint64_t cmp = pe >= 64 ? ~0ull : ((1ull << pe) - 1ull);
+            if (gbase < w0r) cmp = w0r - gbase >= 64 ? 0ull : cmp & ~((1ull << (w0r - gbase)) - 1ull);  // (below w0: final)
+            const uint64_t diff = (__ballot(ins) ^ guess) & cmp;
             if (lane == 0) {
-                if (dis) atomicMin(&shv[0], (uint32_t)(gbase + (int)__builtin_ctzll(dis)));
+                const int dg = diff ? (int)__builtin_ctzll(diff) : 64;
+                const uint64_t le = dg >= 63 ? tm : tm & ((2ull << dg) - 1ull);
+                gtop[grp] = tm ? gbase + 63 - (int)__builtin_clzll(tm) : -1;
+                gtle[grp] = le ? gbase + 63 - (int)__builtin_clzll(le) : -1;
+                if (diff) atomicMin(&shv[0], (uint32_t)grp);
                 if (tm) atomicMax(&shv[1], (uint32_t)(gbase + 63 - (int)__builtin_clzll(tm)));
             }
         }
         FS_PF(6);
-        __syncthreads();  // -------- barrier 3: the first loop-top with a new result, the last loop-top
+        __syncthreads();  // -------- barrier 3: the first group in which guess and parse part, the last loop-top
         FS_PF(7);
         const int last_top = (int)shv[1];
-        const int tstar = shv[0] != 0xFFFFFFFFu ? (int)shv[0] : last_top;
+        int tstar = last_top;
+        if (shv[0] != 0xFFFFFFFFu) {  // the last loop-top at or below the first difference: in its group, or the last one of a group before
+            int g = (int)shv[0];
+            tstar = gtle[g];
+            while (tstar < 0) tstar = gtop[--g];  // (the group of w0 has w0 itself)
+        }
         const uint32_t r_star = ring[(g0 + tstar) & (RING - 1)], r_last = ring[(g0 + last_top) & (RING - 1)];
         const int w0_new = g0 + tstar + fs_adv(r_star);
         const int Xr = last_top + fs_adv(r_last);  // where the path leaves the searched part of the window
@@ -515,25 +567,19 @@ __global__ __launch_bounds__(NT) void zs_fast_sweep_kernel(const StreamDesc *sd,
             }
             if (lane == 0 && tstar < gbase + 64) shv[2] = (uint32_t)(before + (int)__builtin_popcountll(fin));
         }
-        // ---- the next guess: the bits of this sweep's parse for the group's 64 positions
+        // ---- the next guess: the bits of this sweep's parse for the group's 64 positions; what lies behind the path's end keeps the
+        //      guess it had ("inserted", or what the chunk's run before left there)
         {
-            // the last loop-top at or below the lane, and what it inserts; no loop-top below the lane: the hop that enters
-            // the group covers it (short matches insert their inside, Deflate.Fast.cs:81-104)
-            const uint64_t below = tm & ((2ull << lane) - 1ull);
-            const int ti = below ? 63 - (int)__builtin_clzll(below) : 0;
-            const int span = __builtin_amdgcn_ds_bpermute(ti << 2, fs_inserted_span(r, lazy));
-            bool ins = below ? (lane - ti) < span : (lin >= kMinMatch && lin <= lazy);
-            if (self >= Xr || term_before) ins = true;  // behind the path's end: not parsed yet
-            if (q == preins) ins = true;
+            const bool parsed = self < Xr && !term_before;
             uint64_t m = __ballot(ins);
-            const int wi = (gi + gbase) >> 5;
+            const uint64_t pm = __ballot(parsed);
+            m = (m & pm) | (guess & ~pm);
             if (gbase < w0r) {  // the group of w0: what lies below it is final
-                const uint64_t keep = (1ull << (w0r - gbase)) - 1ull;
-                const uint64_t oldm = (uint64_t)bm[wi] | ((uint64_t)bm[wi + 1] << 32);
-                m = (m & ~keep) | (oldm & keep);
+                const uint64_t keep = w0r - gbase >= 64 ? ~0ull : (1ull << (w0r - gbase)) - 1ull;
+                m = (m & ~keep) | (guess & keep);
             }
             if (lane < 2) bm[wi + lane] = (uint32_t)(m >> (32 * lane));
-            if (self >= w0r) {  // ... and in the position's link entry, where the walkers look
+            if (self >= w0r && parsed) {  // ... and in the position's link entry, where the walkers look
                 const uint32_t v = wl[qi];
                 wl[qi] = (uint16_t)((v & 0x7FFFu) | (ins ? 0x8000u : 0u));
             }
@@ -542,13 +588,15 @@ __global__ __launch_bounds__(NT) void zs_fast_sweep_kernel(const StreamDesc *sd,
         if (Xr > W) {
             const int span = fs_inserted_span(r_last, lazy);
             if (tid < 9) {
-                uint32_t v = 0;
+                uint32_t v = bm[((gi + W) >> 5) + tid];  // (behind the match's end the guess stays)
                 for (int b = 0; b < 32; b++) {
                     const int idx = W + 32 * tid + b;
-                    v |= (uint32_t)((idx >= Xr || idx - last_top < span || g0 + idx == preins) ? 1 : 0) << b;
+                    if (idx < Xr) v = (v & ~(1u << b)) | ((uint32_t)((idx - last_top < span || g0 + idx == preins) ? 1 : 0) << b);
                 }
                 bm[((gi + W) >> 5) + tid] = v;
             }
+            // (the link entries carry the same bits as the bitmap, position for position: the searches read the one, the comparison
+            // of guess and parse the other)
             if (W + tid < Xr && gi + W + tid < fsLinks) {  // (tid < 258; behind the tile's links: the next staging takes the bits)
                 const int idx = W + tid;
                 const bool ins = idx - last_top < span || g0 + idx == preins;
