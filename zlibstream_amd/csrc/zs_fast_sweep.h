@@ -11,11 +11,15 @@
 //  2. Sweeps.  Let w0 be a loop-top with everything below it final, and G a *guess* of the bitmap from w0 on.  A sweep
 //     searches all W positions from w0 on at once under G, follows the hops of the parse from w0 through the results
 //     (next loop-top = p + 1 or p + match length) and takes the bitmap that parse implies as the next guess.  A loop-top's
-//     search only looks below itself, so by induction over the loop-tops: up to AND INCLUDING the first loop-top on the
-//     path whose result differs from the sweep before, the results of this sweep are the reference's (the guess they
-//     were searched under is, below each of them, the bitmap of a parse that has been the reference's so far).  They are
-//     final; the next sweep starts behind them.  Every sweep makes at least one loop-top final, whatever the data; on
-//     text a sweep of 1024 positions makes ~390 final, one of 4096 ~1100 (profiles/r04_fast_jacobi_convergence.txt).
+//     search only looks below itself, so by induction over the loop-tops: let d be the first position at which the implied
+//     bitmap is not G; every loop-top on the path at or below d was searched under the bitmap of a parse that has been the
+//     reference's so far, and its result is the reference's.  They are final; the next sweep starts behind the last of
+//     them.  (The first form of the rule compared results with the sweep before's, which is the same thing seen through
+//     the results and needs a sweep before: with the bits themselves a guess may come from anywhere -- "inserted"
+//     everywhere, another workgroup, the same chunk's parse of the round before.)  Every sweep makes at least one loop-top
+//     final, whatever the data and the guess; on text a sweep of 1024 positions makes ~395 final from the guess "inserted"
+//     (461 at level 3), one of 4096 ~1100 (profiles/r04_fast_jacobi_convergence.txt), and nearly the whole window from a
+//     guess that is nearly the parse.
 //  3. Path compression.  Below w0 the set is final, so the link of a final position c may be replaced by the distance to
 //     the nearest INSERTED position of its bucket below c -- what prev[] holds in the reference (fs_compress).  A walk that
 //     skips uninserted positions finds the same candidates in the same order through either link, so the replacement

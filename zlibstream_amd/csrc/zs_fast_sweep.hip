@@ -22,11 +22,12 @@
 //                 group to group is a v_readlane), and publishes per group: where the path enters it, the hop that enters,
 //                 the loop-tops before it.  The other waves compress links meanwhile (5.)                    -- barrier 2
 //   4. loop-tops  per group: the lanes on the path, by walking the doubling tables down from the entry (six ds_bpermute);
-//                 the first whose result differs from the sweep before (results are kept in a ring by position): LDS
-//                 atomic min                                                                                 -- barrier 3
-//   5. final      loop-tops up to and including that one are final: their symbols leave in order; every group writes the
-//                 bits of its 64 positions as this sweep's parse has them (loop-tops, the inside of short matches,
-//                 "inserted" behind the path's end), into the bitmap and into the link entries              -- barrier 4
+//                 the set the parse implies for the group's 64 positions, compared with the guess (the bitmap): the first
+//                 group in which they part (LDS atomic min), per group the last loop-top at or below its first
+//                 difference                                                                                 -- barrier 3
+//   5. final      the loop-tops at or below the first difference are final: their symbols leave in order; every group writes
+//                 the bits of its 64 positions as this sweep's parse has them (loop-tops, the inside of short matches; what
+//                 lies behind the path's end keeps its guess), into the bitmap and into the link entries     -- barrier 4
 //      compress   (in step 3 of the next sweep, by the waves that do not follow the path) the links of the positions that
 //                 became final are replaced by the distance to the nearest inserted position of their bucket (fs_compress),
 //                 in LDS and in the stream's link array; walkers find the same candidates through either link
@@ -39,7 +40,7 @@
 // tile; a batch of many streams fills the chip that way and parses every position once.  CH = true, the chunk form
 // (zs_fast_sweep.h "Rounds"): one workgroup per chunk of a stream and round -- the guess below the chunk's first loop-top
 // comes from the chunks before it as the round before left them (bit planes by chunk parity and FsMeta::cur, entry
-// loop-tops and event cuts in FsMeta), K1's links are only read (the history's links are compressed in LDS after staging,
+// loop-tops and event cuts in FsMeta), the guess from there on is what the chunk's own run before left, K1's links are only read (the history's links are compressed in LDS after staging,
 // an event's cut stays in LDS and FsMeta), the symbols go to the chunk's provisional buffer; a chunk whose inputs did not
 // change copies its FsMeta forward.  When a round has changed nothing, zs_fast_commit_scan_kernel / zs_fast_commit_kernel
 // put the symbols, block cuts, bits, cuts and the stream's state where the stream form would have left them.  8 MiB of text:
