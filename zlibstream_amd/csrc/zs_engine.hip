@@ -395,11 +395,11 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
     if (pl.any_fv && !getenv("ZS_FAST_NO_ROUNDS")) {
         // levels 1-3: every stream's parse as rounds over its chunks, all chunks of the batch at once (zs_fast_sweep.h "Rounds"),
         // when that is the shorter way.  One workgroup per stream takes as long as the longest stream at 46 / 35 / 20 MB/s (levels
-        // 1 / 2 / 3 on text; kennedy.xls and ptt5 are slower).  The rounds take the whole batch through the chip at ~2.5 GB/s a few
-        // times over and then wait for the last disturbances to die out -- up to ~20 ms on text, less on anything else, and never
-        // longer than the longest stream takes one workgroup (profiles/r04_fast_batch_shapes.log: 4 x 4 MiB 33 against 89 ms,
-        // 32 x 4 MiB 55 against 92, 64 x 1 MiB 32 against 23, 128 x 256 KiB 11 against 6.6 at level 1; at level 3 the rounds win
-        // up to 64 x 1 MiB).
+        // 1 / 2 / 3 on text; kennedy.xls and ptt5 are slower).  The rounds take the whole batch through the chip at ~3.5 GB/s a few
+        // times over and then wait for the last disturbances to die out -- up to ~16 ms on text, less on anything else, and never
+        // longer than the longest stream takes one workgroup (profiles/r04_fast_batch_shapes.log: 4 x 4 MiB 26 against 88 ms,
+        // 32 x 4 MiB 46 against 91, 32 x 1 MiB 21 against 23, 64 x 1 MiB 26 against 23, 128 x 256 KiB 10 against 6.6 at level 1; at
+        // level 3 the rounds win up to 64 x 1 MiB: 31 against 49).
         int64_t pos_fv = 0, max_fv = 0;
         for (int i = 0; i < n; i++)
             if (pl.sd[(size_t)i].fv_end >= 0) {
@@ -407,7 +407,7 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
                 max_fv = std::max<int64_t>(max_fv, pl.sd[(size_t)i].fv_end + 1);
             }
         const double t_stream = (double)max_fv / (level >= 3 ? 20e6 : level == 2 ? 35e6 : 46e6);
-        const double t_rounds = std::min(0.020, (double)max_fv / 50e6) + (double)pos_fv / 2.5e9;
+        const double t_rounds = std::min(0.016, (double)max_fv / 60e6) + (double)pos_fv / 3.5e9;
         if (getenv("ZS_FR_RATIO") ? (double)pos_fv <= atof(getenv("ZS_FR_RATIO")) * (double)max_fv : t_rounds < t_stream) {
             // chunks of 2048 positions or more (a run's fixed cost -- staging 32 K positions of history -- is 15-30 us, a sweep makes
             // ~390 positions final in 8 us), at most what one staging of the tile covers; between the two, as many chunks as fit
