@@ -444,6 +444,11 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
                 ck.prov_off = (uint32_t)pl.fr_prov;
                 pl.fr_prov += (size_t)(ck.b_hi - ck.b_lo) + kMaxMatch + 64;  // (its loop-tops lie in [b_lo, b_hi + 258))
             }
+            if (pl.fr_prov > 0xFFFF0000u) {  // (prov_off is 32 bits: a batch beyond ~4 G positions takes one workgroup per stream)
+                pl.fr_chunks.clear();
+                pl.fr_max_n = 0, pl.fr_prov = 0;
+                for (int i = 0; i < n; i++) pl.sd[(size_t)i].fr_first = pl.sd[(size_t)i].fr_n = 0;
+            }
         }
     }
     WorkList *const lists[kWorkLists] = {&pl.w_clear, &pl.w_adler, &pl.w_links, &pl.w_match, &pl.w_chunks, &pl.w_segs, &pl.w_sups, &pl.w_blocks, &pl.w_runs};
@@ -866,10 +871,6 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
             // rounds over the chunks of the streams: every round one workgroup per chunk, until a round changes nothing
             const size_t nch = pl.fr_chunks.size(), plane_words = (size_t)pl.n_pos / 32 + kFvBitSlack / 4 + 64;
             const int max_rounds = pl.fr_max_n + 2;  // (chunk r of a stream is the reference's after round r at the latest)
-            if (nch * sizeof(FsChunk) > 0xFFFFFFFFu || pl.fr_prov > 0xFFFFFFFFu) {
-                c->err = "too many chunks for the rounds over DeflateFast";
-                return false;
-            }
             if (!ensure(c, c->fr_chunks, nch * sizeof(FsChunk)) || !ensure(c, c->fr_meta, 2 * nch * sizeof(FsMeta)) || !ensure(c, c->fr_planes, 16 * plane_words) ||
                 !ensure(c, c->fr_prov, 4 * pl.fr_prov + 64) || !ensure(c, c->fr_base, 4 * nch + 64) || !ensure(c, c->fr_counters, 4 * ((size_t)max_rounds + 16)))
                 return false;
