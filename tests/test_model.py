@@ -35,10 +35,44 @@ def model(tmp_path_factory):
     return files
 
 
-def run(path, level, strategy=0, mode="chunk", wchunk=None, flush=0, env=None):
+def _run(path, level, strategy=0, mode="chunk", wchunk=None, flush=0, env=None):
     cmd = [EXE, path, str(level), str(strategy), mode, str(wchunk or 0), str(flush)]
     r = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, **env) if env else None)
     assert r.returncode == 0 and "PASS" in r.stdout, (cmd, r.stdout[-500:])
+
+
+_pending = None
+
+
+class batch:
+    """The model runs inside the block go to the host's cores side by side (each is its own process); leaving the block waits for
+    all of them and raises the first failure."""
+
+    def __enter__(self):
+        global _pending
+        from concurrent.futures import ThreadPoolExecutor
+        self.pool = ThreadPoolExecutor(max_workers=max(1, min(8, len(os.sched_getaffinity(0)))))
+        self.futures = []
+        _pending = self
+        return self
+
+    def __exit__(self, *exc):
+        global _pending
+        _pending = None
+        try:
+            if exc[0] is None:
+                for f in self.futures:
+                    f.result()
+        finally:
+            self.pool.shutdown(wait=True, cancel_futures=True)
+        return False
+
+
+def run(*args, **kwargs):
+    if _pending is not None:
+        _pending.futures.append(_pending.pool.submit(_run, *args, **kwargs))
+    else:
+        _run(*args, **kwargs)
 
 
 def test_chunked_pipeline_matches_oracle(model):
@@ -77,29 +111,31 @@ def test_fast_levels_for_the_lanes_of_a_wave(model, tmp_path):
     rng.integers(0, 4)
     (tmp_path / "fuzz208279").write_bytes(fuzz_cases.deflate_batch_case(rng)[2][2])
     files["fuzz208279"] = str(tmp_path / "fuzz208279")
-    for name in ("alice_98304", "zeros_98305", "lowent_98305", "alice_65537", "ptt5", "cp.html", "runs", "low150k", "zeros150k", "alice_600", "alice_5", "fuzz208279"):
-        for level in (1, 2, 3):
-            for strategy in (0, 2) if name in ("ptt5", "cp.html", "runs") else (0, 1, 2, 4):
-                run(files[name], level, strategy, "fvec")
-                # ... and as window-wide sweeps of a workgroup (zs_fast_sweep.h, zs_fast_sweep_kernel): the control flow of
-                # the kernel -- windows aligned to 64 positions, the guess of the inserted set, what a sweep makes final,
-                # events at a sweep's first loop-top, compressed links -- at the kernel's window and at small ones
-                run(files[name], level, strategy, "fsweep")
-                # ... and as rounds over the chunks of the stream (zs_fast_sweep.h "Rounds": every chunk of a round parsed from
-                # what the round before left -- entry loop-tops, the set from the planes of the chunks that own the positions,
-                # the cuts of equal-bucket events -- until a round changes nothing; zs_fast_commit_kernel's part behind it)
-                # (ZS_FR_RANGE: chunks a workgroup takes in turn, each reading what the ones before it have just left)
-                run(files[name], level, strategy, "frounds", env={"ZS_FR_CHUNK": str((1024, 4096, 10240)[(level + strategy) % 3]), "ZS_FR_RANGE": str((1, 3, 8)[(level + 2 * strategy) % 3]), **({"ZS_FR_RANGE_VARY": "1"} if level == 2 else {})})  # (VARY: another range every round, at most the given one)
+    with batch():
+        for name in ("alice_98304", "zeros_98305", "lowent_98305", "alice_65537", "ptt5", "cp.html", "runs", "low150k", "zeros150k", "alice_600", "alice_5", "fuzz208279"):
+            for level in (1, 2, 3):
+                for strategy in (0, 2) if name in ("ptt5", "cp.html", "runs") else (0, 1, 2, 4):
+                    run(files[name], level, strategy, "fvec")
+                    # ... and as window-wide sweeps of a workgroup (zs_fast_sweep.h, zs_fast_sweep_kernel): the control flow of
+                    # the kernel -- windows aligned to 64 positions, the guess of the inserted set, what a sweep makes final,
+                    # events at a sweep's first loop-top, compressed links -- at the kernel's window and at small ones
+                    run(files[name], level, strategy, "fsweep")
+                    # ... and as rounds over the chunks of the stream (zs_fast_sweep.h "Rounds": every chunk of a round parsed from
+                    # what the round before left -- entry loop-tops, the set from the planes of the chunks that own the positions,
+                    # the cuts of equal-bucket events -- until a round changes nothing; zs_fast_commit_kernel's part behind it)
+                    # (ZS_FR_RANGE: chunks a workgroup takes in turn, each reading what the ones before it have just left)
+                    run(files[name], level, strategy, "frounds", env={"ZS_FR_CHUNK": str((1024, 4096, 10240)[(level + strategy) % 3]), "ZS_FR_RANGE": str((1, 3, 8)[(level + 2 * strategy) % 3]), **({"ZS_FR_RANGE_VARY": "1"} if level == 2 else {})})  # (VARY: another range every round, at most the given one)
     # several NoFlush Writes at the fast levels: a Write end is a read event like a window end (Stream.CopyTo's 81 920 bytes, 65 536,
     # 70 001; sizes whose ends fall where a loop-top may or may not slide the window -- 16 385-byte scanlines -- stay with the
     # literal engine, which the model then runs for the whole stream)
-    for name in ("alice_98304", "lowent_98305", "ptt5", "runs", "low150k"):
-        for wchunk in (81920, 65536, 70001, 40000, 16385):
-            run(files[name], 1 + wchunk % 3, 0, "fsweep", wchunk=wchunk)
-            run(files[name], 1 + wchunk % 3, 0, "frounds", wchunk=wchunk, env={"ZS_FR_CHUNK": "2048", "ZS_FR_RANGE": "3"})
-    for name in ("alice_98304", "zeros_98305", "lowent_98305", "runs", "ptt5", "fuzz208279"):
-        for w, tile in ((64, 256), (256, 1024), (2048, 8192)):
-            run(files[name], 1 + (w // 64) % 3, 0, "fsweep", env={"ZS_FS_W": str(w), "ZS_FS_TILE": str(tile)})
+    with batch():
+        for name in ("alice_98304", "lowent_98305", "ptt5", "runs", "low150k"):
+            for wchunk in (81920, 65536, 70001, 40000, 16385):
+                run(files[name], 1 + wchunk % 3, 0, "fsweep", wchunk=wchunk)
+                run(files[name], 1 + wchunk % 3, 0, "frounds", wchunk=wchunk, env={"ZS_FR_CHUNK": "2048", "ZS_FR_RANGE": "3"})
+        for name in ("alice_98304", "zeros_98305", "lowent_98305", "runs", "ptt5", "fuzz208279"):
+            for w, tile in ((64, 256), (256, 1024), (2048, 8192)):
+                run(files[name], 1 + (w // 64) % 3, 0, "fsweep", env={"ZS_FS_W": str(w), "ZS_FS_TILE": str(tile)})
 
 
 def test_rle_strategy_from_the_runs_of_equal_bytes(model, tmp_path):
@@ -201,15 +237,18 @@ def test_regular_multi_write_takes_the_chunked_form(model):
     """NoFlush Writes whose sizes are multiples of 2048 (Stream.CopyTo's 81920 and the like): one read event per Write end,
     handled like the window-full refills -- including events whose loop-top shares its bucket with the next position
     (zeros, runs)."""
-    for name in ("alice_98304", "alice_98305", "lowent_98043", "zeros_98305", "zeros_65541", "runs", "ptt5"):
-        for w in (2048, 4096, 8192, 32768, 65536, 81920):
-            for level in (4, 6, 9):
-                if level == 9 and name == "ptt5":
-                    continue
-                r = subprocess.run([EXE, model[name], str(level), "0", "chunk", str(w), "0"], capture_output=True, text=True)
-                assert r.returncode == 0 and "PASS" in r.stdout, (name, w, level, r.stdout[-400:])
-                if os.path.getsize(model[name]) > w + 600:
-                    assert "tail_from=0 " not in r.stdout + " ", (name, w, level)   # the bulk form really ran
+    def one(name, w, level):
+        r = subprocess.run([EXE, model[name], str(level), "0", "chunk", str(w), "0"], capture_output=True, text=True)
+        assert r.returncode == 0 and "PASS" in r.stdout, (name, w, level, r.stdout[-400:])
+        if os.path.getsize(model[name]) > w + 600:
+            assert "tail_from=0 " not in r.stdout + " ", (name, w, level)   # the bulk form really ran
+    with batch() as b:
+        for name in ("alice_98304", "alice_98305", "lowent_98043", "zeros_98305", "zeros_65541", "runs", "ptt5"):
+            for w in (2048, 4096, 8192, 32768, 65536, 81920):
+                for level in (4, 6, 9):
+                    if level == 9 and name == "ptt5":
+                        continue
+                    b.futures.append(b.pool.submit(one, name, w, level))
 
 
 def test_any_write_sizes_take_the_chunked_form(model, tmp_path):
