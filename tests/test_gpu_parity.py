@@ -507,7 +507,7 @@ def test_rle_strategy_over_the_chip(engine, oracle):
 def test_fast_levels_single_stream_rate(engine, oracle):
     """DeflateFast on ONE text stream (Deflate.Fast.cs:20-128; the reference does 54.8 / 36.9 MB/s at levels 1 / 3 on its
     2018 laptop core, benchmarks.md:63,118; the oracle on the GPU box's host 79 / 50): as rounds over the stream's chunks
-    zs_fast_sweep_kernel holds 203 / 272 MB/s on 8 MiB of text resident in HBM (one workgroup for the whole stream: 48 / 21;
+    zs_fast_sweep_kernel holds 289 / 437 MB/s on 8 MiB of text resident in HBM (one workgroup for the whole stream: 48 / 21;
     round 3's one-wave form: 9.1 / 4.0).  The floors below leave a third of margin for a busy box; the bytes of a 2 MiB prefix
     are the oracle's, and an 8 MiB text stream must not go through the speculative chunk runs first (zs_fast_probe_kernel:
     they never verify on text)."""
@@ -517,7 +517,7 @@ def test_fast_levels_single_stream_rate(engine, oracle):
     d_in = torch.frombuffer(bytearray(text), dtype=torch.uint8).cuda()
     cap = deflate_bound(len(text))
     d_out = torch.empty(cap, dtype=torch.uint8, device="cuda")
-    for lvl, floor in ((1, 130e6), (3, 180e6)):
+    for lvl, floor in ((1, 190e6), (3, 290e6)):
         assert engine.deflate_batch([text[:2 << 20]], level=lvl)[0] == oracle.compress(text[:2 << 20], lvl), lvl
         engine.deflate_batch_device([d_in.data_ptr()], [len(text)], [d_out.data_ptr()], [cap], level=lvl)
         torch.cuda.synchronize()
