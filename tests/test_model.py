@@ -128,6 +128,16 @@ def test_fast_levels_for_the_lanes_of_a_wave(model, tmp_path):
     # several NoFlush Writes at the fast levels: a Write end is a read event like a window end (Stream.CopyTo's 81 920 bytes, 65 536,
     # 70 001; sizes whose ends fall where a loop-top may or may not slide the window -- 16 385-byte scanlines -- stay with the
     # literal engine, which the model then runs for the whole stream)
+    # a body whose last match ends four bytes in front of the stream's end hands over at n - 4: the tail engine's restore inserts
+    # the stream's last positions only where the parse did (tools/fuzz_streams.py seed 560345: 40 000 zeros in five Writes)
+    (tmp_path / "zeros39996").write_bytes(bytes(39996))
+    (tmp_path / "zeros40000").write_bytes(bytes(40000))
+    with batch():
+        for level in (1, 2, 3):
+            for mode in ("fvec", "fsweep", "frounds"):
+                run(str(tmp_path / "zeros39996"), level, 0, mode)
+            run(str(tmp_path / "zeros40000"), level, 0, "fsweep", wchunk="6144,8192,1000,263,24401")
+            run(str(tmp_path / "zeros40000"), level, 0, "frounds", wchunk="6144,8192,1000,263,24401")
     with batch():
         for name in ("alice_98304", "lowent_98305", "ptt5", "runs", "low150k"):
             for wchunk in (81920, 65536, 70001, 40000, 16385):

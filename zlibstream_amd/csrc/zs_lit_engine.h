@@ -806,7 +806,10 @@ ZS_HD_NOINLINE inline void le_restore_finish(LitEngine &e, int64_t p, const uint
     int64_t q = e.n - 5;
     if (q < 0) q = 0;
     if (q < e.base) q = e.base;
-    for (; q < p && q <= e.n - kMinMatch; q++) le_insert(e, (int)(q - e.base));
+    // (DeflateFast: only what the parse inserted -- a body whose last match ends four bytes in front of the stream's end hands over
+    // at n - 4, and n - 5 is no loop-top)
+    for (; q < p && q <= e.n - kMinMatch; q++)
+        if (ins(q)) le_insert(e, (int)(q - e.base));
     if (preins >= p && preins >= 1) {
         // the refill at loop-top preins-1 inserted preins before preins-1 (Deflate.cs:1010-1013)
         int w = (int)(preins - e.base);
