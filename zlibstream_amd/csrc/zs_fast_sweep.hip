@@ -20,7 +20,8 @@
 //                 number of hops (the doubling tables stay in registers; the result goes to the exit table)  -- barrier 1
 //   3. path       ONE wave follows the path from w0 through the exit table, whose rows it holds in registers (a hop from
 //                 group to group is a v_readlane), and publishes per group: where the path enters it, the hop that enters,
-//                 the loop-tops before it.  The other waves compress links meanwhile (5.)                    -- barrier 2
+//                 the loop-tops before it (the other waves wait: four waves share a SIMD's issue, and sixteen copies of the
+//                 walk cost more than one)                                                                   -- barrier 2
 //   4. loop-tops  per group: the lanes on the path, by walking the doubling tables down from the entry (six ds_bpermute);
 //                 the set the parse implies for the group's 64 positions, compared with the guess (the bitmap): the first
 //                 group in which they part (LDS atomic min), per group the last loop-top at or below its first
@@ -28,23 +29,26 @@
 //   5. final      the loop-tops at or below the first difference are final: their symbols leave in order; every group writes
 //                 the bits of its 64 positions as this sweep's parse has them (loop-tops, the inside of short matches; what
 //                 lies behind the path's end keeps its guess), into the bitmap and into the link entries     -- barrier 4
-//      compress   (in step 3 of the next sweep, by the waves that do not follow the path) the links of the positions that
-//                 became final are replaced by the distance to the nearest inserted position of their bucket (fs_compress),
-//                 in LDS and in the stream's link array; walkers find the same candidates through either link
-//                 (zs_fast_sweep.h, fact 3), so nothing waits for this
+//   6. links      the links of the positions that became final are replaced by the distance to the nearest inserted position
+//                 of their bucket (fs_compress; in LDS, and in the stream's link array in the stream form); the next window's
+//                 positions get their links under the new guess (gl).  Walkers find the same candidates through either
+//                 form of a link (zs_fast_sweep.h, fact 3)                                                  -- barrier 5
 //
 // What it leaves is what K4 / K5 leave for the lazy parse, so the tail engine (restored from the bitmap and the links --
 // compressed or not, le_restore_prev_ins finds the same predecessor) and the block kernels go on unchanged.
 //
 // Two forms (template parameter CH).  CH = false: one workgroup takes a stream from its first position to fv_end, tile after
 // tile; a batch of many streams fills the chip that way and parses every position once.  CH = true, the chunk form
-// (zs_fast_sweep.h "Rounds"): one workgroup per chunk of a stream and round -- the guess below the chunk's first loop-top
-// comes from the chunks before it as the round before left them (bit planes by chunk parity and FsMeta::cur, entry
-// loop-tops and event cuts in FsMeta), the guess from there on is what the chunk's own run before left, K1's links are only read (the history's links are compressed in LDS after staging,
-// an event's cut stays in LDS and FsMeta), the symbols go to the chunk's provisional buffer; a chunk whose inputs did not
-// change copies its FsMeta forward.  When a round has changed nothing, zs_fast_commit_scan_kernel / zs_fast_commit_kernel
-// put the symbols, block cuts, bits, cuts and the stream's state where the stream form would have left them.  8 MiB of text:
-// 117 / 192 MB/s at levels 1 / 3 against 48 / 21 for one workgroup; kennedy.xls 3.3 ms against 67.
+// (zs_fast_sweep.h "Rounds"): one workgroup per chunk of a stream -- or per range of consecutive chunks, taken in turn -- and
+// round.  The guess below a chunk's first loop-top comes from the chunks before it as the round before left them, or as they
+// have just left them if they belong to the workgroup's own range (bit planes by chunk parity and FsMeta::cur; entry
+// loop-tops, event cuts and the rounds of last run and last change in FsMeta); the guess from there on is what the chunk's own
+// run before left.  K1's links are only read (the history's links are compressed in LDS after staging, an event's cut stays
+// in LDS and FsMeta), the symbols go to the chunk's provisional buffer; a chunk none of whose inputs has changed since it
+// last read them copies its FsMeta forward.  When a round has changed nothing, zs_fast_commit_scan_kernel /
+// zs_fast_commit_kernel put the symbols, block cuts, bits, cuts and the stream's state where the stream form would have left
+// them.  64 MiB of text: 1.38 / 1.93 GB/s at levels 1 / 3, 8 MiB 289 / 437 MB/s (one workgroup: 48 / 21 MB/s); kennedy.xls 2.8 ms
+// against 67.
 
 constexpr int kFsBack = 32512;   // >= kMaxDist, multiple of 64
 constexpr int kFsFwd = 272;      // >= kMaxMatch + 8, multiple of 16
