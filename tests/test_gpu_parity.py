@@ -567,6 +567,13 @@ def test_fast_levels_as_rounds_over_chunks_and_as_one_workgroup_per_stream(engin
                     assert engine.deflate_batch([d], level=1 + ei % 3, strategy=strategy)[0] == oracle.compress(d, 1 + ei % 3, strategy), (env, name, strategy)
             for k in env:
                 del os.environ[k]
+        # rounds that are cut short (they cannot be, by themselves: chunk r is final after round r) hand the batch to the other form
+        os.environ["ZS_FR_MAX_ROUNDS"] = "3"
+        try:
+            for lvl in (1, 3):
+                assert engine.deflate_batch([cases["english1m"]], level=lvl)[0] == oracle.compress(cases["english1m"], lvl), lvl
+        finally:
+            del os.environ["ZS_FR_MAX_ROUNDS"]
         # one long stream among short ones: rounds; twelve equals: one workgroup each
         mixed = [cases["kennedy"], cases["text300k"][:70000], b"", cases["zeros_65537"], cases["ptt5"], cases["alice_263"]]
         equals = [datagen.english(200000, 100 + i) for i in range(12)]

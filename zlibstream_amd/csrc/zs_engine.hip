@@ -51,6 +51,7 @@ struct zs_ctx {
     std::vector<int64_t> inf_used;
     int64_t *inf_probe = nullptr;
     int fast_rounds = 0;  // rounds the last call's DeflateFast took over its chunks (0: one workgroup per stream)
+    bool no_rounds_once = false;  // the next plan takes one workgroup per stream (set when the rounds gave up)
     int last_op = 0;  // 0: deflate stages, 1: block-parallel inflate stages, 2: deflate at levels 1-3 (for zs_ctx_stage_name)
     hipEvent_t ev[kStCount + 1] = {};
     double stage_ms[kStCount] = {};
@@ -392,7 +393,9 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
         }
         pl.w_blocks.add(i, s.max_blocks);
     }
-    if (pl.any_fv && !getenv("ZS_FAST_NO_ROUNDS")) {
+    const bool no_rounds_this_call = c->no_rounds_once;
+    c->no_rounds_once = false;
+    if (pl.any_fv && !getenv("ZS_FAST_NO_ROUNDS") && !no_rounds_this_call) {
         // levels 1-3: every stream's parse as rounds over its chunks, all chunks of the batch at once (zs_fast_sweep.h "Rounds"),
         // when that is the shorter way.  One workgroup per stream takes as long as the longest stream at 46 / 35 / 20 MB/s (levels
         // 1 / 2 / 3 on text; kennedy.xls and ptt5 are slower).  The rounds take the whole batch through the chip at ~3.5 GB/s a few
@@ -870,7 +873,7 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
         if (!pl.fr_chunks.empty()) {
             // rounds over the chunks of the streams: every round one workgroup per chunk, until a round changes nothing
             const size_t nch = pl.fr_chunks.size(), plane_words = (size_t)pl.n_pos / 32 + kFvBitSlack / 4 + 64;
-            const int max_rounds = pl.fr_max_n + 2;  // (chunk r of a stream is the reference's after round r at the latest)
+            const int max_rounds = getenv("ZS_FR_MAX_ROUNDS") ? atoi(getenv("ZS_FR_MAX_ROUNDS")) : pl.fr_max_n + 2;  // (chunk r of a stream is the reference's after round r at the latest)
             if (!ensure(c, c->fr_chunks, nch * sizeof(FsChunk)) || !ensure(c, c->fr_meta, 2 * nch * sizeof(FsMeta)) || !ensure(c, c->fr_planes, 16 * plane_words) ||
                 !ensure(c, c->fr_prov, 4 * pl.fr_prov + 64) || !ensure(c, c->fr_base, 4 * nch + 64) || !ensure(c, c->fr_counters, 4 * ((size_t)max_rounds + 16)))
                 return false;
@@ -918,8 +921,11 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
             c->fast_rounds = r;
             if (getenv("ZS_DEBUG")) fprintf(stderr, "zs: DeflateFast over %zu chunks of %d streams, up to %d to a workgroup: %d rounds (changed/range:%s)\n", nch, n, range_max, r, trace.c_str());
             if (changed) {
-                c->err = "the rounds over DeflateFast did not reach their fixed point";
-                return false;
+                // (cannot happen: chunk r of a stream is the reference's after round r at the latest.  Should it, the batch takes one
+                // workgroup per stream instead of failing the call)
+                ZS_HIP(c, hipStreamSynchronize(c->aux));
+                c->no_rounds_once = true;
+                return run_pipeline(c, n, in, in_len, out, out_cap, out_len, status, level, strategy, hash_variant, stream, writes, force_seq, ro, false, force_lit);
             }
             const FsMeta *mf = dev<FsMeta>(c->fr_meta) + (size_t)((r - 1) & 1) * nch;
             hipLaunchKernelGGL(zs_fast_commit_scan_kernel, dim3((unsigned)n), dim3(1024), 0, stream, d_sd, d_st, mf, dev<int32_t>(c->fr_base));
