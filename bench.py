@@ -190,14 +190,29 @@ def cpu_inflate_baseline(z, out_len):
             "sample": "one %d-byte level-6 stream -> %d bytes, 1 thread, 1 warm-up + 2 timed passes" % (len(z), out_len)}
 
 
-def pmc_traffic(kernel, tag):
-    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/*pmc_traffic_<tag>.json), if any."""
+def pmc_file(tag):
+    """The newest committed PMC summary for a workload tag (profiles/rNN_pmc_<tag>.json, written by tools/pmc_summary.py)."""
     pdir = os.path.join(ROOT, "profiles")
-    cands = sorted(f for f in os.listdir(pdir) if f.endswith("pmc_traffic_%s.json" % tag)) if os.path.isdir(pdir) else []
-    if not cands:
-        return None
-    k = json.load(open(os.path.join(pdir, cands[-1])))["kernels"].get(kernel)
-    return k["hbm_bytes_corrected"] if k else None
+    cands = sorted(f for f in os.listdir(pdir) if f.endswith("pmc_%s.json" % tag)) if os.path.isdir(pdir) else []
+    return os.path.join(pdir, cands[-1]) if cands else None
+
+
+def pmc_traffic(kernel, tag, per_call=False):
+    """(HBM bytes, source) of `kernel` from the committed PMC passes -- NOT measured in this run: rocprofv3 --pmc needs its own
+    passes (MI355X_MICROARCH.md), so the line carries the committed figure and names the file it came from.  Per launch, or --
+    `per_call`, a stage of many launches -- summed over the launches of one call.  Corrected as the guide prescribes
+    (2 x FETCH_SIZE + WRITE_SIZE: an upper bound)."""
+    f = pmc_file(tag)
+    if f is None:
+        return None, None
+    ks = json.load(open(f))["kernels"]
+    k = ks.get(kernel) or next((v for n, v in ks.items() if n.startswith(kernel + "<")), None)
+    if not k:
+        return None, None
+    b = k.get("hbm_bytes_corrected")
+    if b is None and "fetch_bytes_raw" in k:
+        b = 2 * k["fetch_bytes_raw"] + k["write_bytes"]
+    return b, "profiles/" + os.path.basename(f)
 
 
 # ---------------------------------------------------------------- device legs
@@ -257,26 +272,43 @@ INFLATE_STAGE_KERNELS = {"inf_decode": ["zs_inf_decode_lane_kernel", "zs_inf_cel
                          "inf_chain": ["zs_inf_chain_par_kernel", "zs_inf_chain_kernel"]}
 
 
-def roofline(stage_ms, alg_bytes, traffic=None, kernels=None):
+# stages of a deflate call that are many launches of one kernel (the rounds of the chunk form): name, PMC tag by level
+MULTI_LAUNCH_STAGES = {"fast_sweep": "zs_fast_sweep_kernel"}
+
+
+def roofline(stage_ms, alg_bytes, traffic=None, kernels=None, source=None, launches=None):
     dom = max(stage_ms, key=stage_ms.get)
     achieved = alg_bytes / (stage_ms[dom] * 1e-3) / 1e9
+    if dom in MULTI_LAUNCH_STAGES and kernels is None:
+        kernels = [MULTI_LAUNCH_STAGES[dom]]
+        launches = launches or "rounds"
     # scope: "kernel" -- `achieved` is over ONE kernel's launch time; "stage" -- over a stage of the call that is several launches
     # (kernel_ms is then the stage's time and `traffic` the sum of its kernels'); profiles/rNN_*_kernel_stats.csv has every
     # kernel's own average beside it
-    return {"bound": "hbm", "kernel": " + ".join(kernels) if kernels else "zs_%s_kernel" % dom, "scope": "stage" if kernels and len(kernels) > 1 else "kernel",
-            "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
-            "kernel_ms": round(stage_ms[dom], 4)}
+    r = {"bound": "hbm", "kernel": " + ".join(kernels) if kernels else "zs_%s_kernel" % dom,
+         "scope": "stage" if (kernels and len(kernels) > 1) or launches else "kernel",
+         "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+         "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": source if traffic is not None else None,
+         "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": round(stage_ms[dom], 4)}
+    if launches:
+        r["launches"] = launches
+    return r
 
 
-def secondary_deflate(eng, dev, name, datas, level, steps, check_every=1, strategy=0):
+def pmc_stage(stage_ms, tag):
+    """Committed PMC traffic of the dominant stage's kernel for the workload `tag` (per launch; per call for a stage of rounds)."""
+    dom = max(stage_ms, key=stage_ms.get)
+    return pmc_traffic(MULTI_LAUNCH_STAGES.get(dom, "zs_%s_kernel" % dom), tag)
+
+
+def secondary_deflate(eng, dev, name, datas, level, steps, check_every=1, strategy=0, pmc_tag=None):
     b = DeviceBatch(eng, dev, datas, strategy)
     dt, stage_ms = b.timed(level, steps, 1)
     b.check_roundtrip(check_every)
     total_out = sum(b.out_lens)
     res = {"workload": name, "level": level, "buffers": len(datas), "input_bytes": b.n, "compressed_bytes": total_out,
            "value": round(b.n * steps / dt / 1e6, 2), "unit": "MB/s", "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps,
-           "roundtrip": True, "roofline": roofline(stage_ms, b.n + total_out),
+           "roundtrip": True, "roofline": roofline(stage_ms, b.n + total_out, *(pmc_stage(stage_ms, pmc_tag) if pmc_tag else (None, None))),
            "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()}}
     return res, b
 
@@ -285,9 +317,9 @@ def inflate_roofline(stage_ms, alg_bytes):
     """The dominant stage of an inflate call with the kernels it is made of; traffic = the sum of theirs (PMC passes)."""
     dom = max(stage_ms, key=stage_ms.get)
     ks = INFLATE_STAGE_KERNELS.get(dom, ["zs_%s_kernel" % dom])
-    parts = [pmc_traffic(k, "inflate1g") for k in ks]
-    traffic = sum(p for p in parts if p) if any(parts) else None
-    return roofline(stage_ms, alg_bytes, traffic, ks)
+    parts = [pmc_traffic(k, "traffic_inflate1g") for k in ks]
+    traffic = sum(p for p, _ in parts if p) if any(p for p, _ in parts) else None
+    return roofline(stage_ms, alg_bytes, traffic, ks, next((f for p, f in parts if p), None))
 
 
 def secondary_inflate(eng, dev, steps, streams=16, size=64 << 20):
@@ -390,6 +422,58 @@ def secondary_stream_api(data, level, reps=2):
         return out
     finally:
         os.unlink(path)
+
+
+LINE_LIMIT = 4096  # the driver reads the LAST stdout line; round 4's 21.7 KB line came back unparsed
+
+
+def compact_line(line):
+    """The one stdout line: the contract's keys, `roofline`, `cpu_baseline`, and of every secondary leg just
+    [value, roofline.frac, cpu value] -- under LINE_LIMIT bytes whatever the legs hold.  The full report goes to a file."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data", "config", "roofline", "cpu_baseline", "compressed_size_delta_vs_cpu", "bit_identical_to_cpu", "stage_ms",
+            "pipelined")
+    out = {k: line[k] for k in keep if k in line}
+    if "sharded_batch1024" in line:
+        sb = line["sharded_batch1024"]
+        out["sharded_batch1024"] = {k: sb[k] for k in ("value", "unit", "n_gpus", "scaling", "ms_per_step", "steps", "n1_same_workload") if k in sb}
+    sec = line.get("secondary")
+    if sec:
+        summ = {}
+        for name, leg in sec.items():
+            if "value" in leg:
+                cb = leg.get("cpu_baseline") or {}
+                cpu = cb.get("value", (cb.get("1_thread") or {}).get("value"))
+                summ[name] = [leg["value"], (leg.get("roofline") or {}).get("frac"), cpu]
+            else:  # legs that are several figures (host_path, stream_api)
+                summ[name] = {k: v.get("value", v.get("deflate_MBps")) for k, v in leg.items() if isinstance(v, dict)}
+        out["secondary_summary"] = {"columns": ["value (the leg's unit: MB/s)", "roofline.frac", "cpu_baseline MB/s (1 thread)"], "legs": summ,
+                                    "not_bit_identical_to_cpu": sorted(k for k, v in sec.items() if v.get("bit_identical_to_cpu") is False),
+                                    "full_report": "bench_secondary.json"}
+    text = json.dumps(out)
+    if len(text) >= LINE_LIMIT:  # never expected; shed the optional keys rather than lose the line
+        for k in ("stage_ms", "pipelined", "sharded_batch1024"):
+            out.pop(k, None)
+        out["cpu_baseline"] = {k: v for k, v in out.get("cpu_baseline", {}).items() if k in ("value", "unit", "cores", "kind", "sample")}
+        text = json.dumps(out)
+    assert len(text) < LINE_LIMIT, len(text)
+    return text
+
+
+def emit_report(line):
+    """Full report -> bench_secondary.json (repo root; gpurun_out/ too when it exists) and stderr; the compact line -> stdout, last."""
+    full = json.dumps(line, indent=1)
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        try:
+            if os.path.isdir(d):
+                with open(os.path.join(d, "bench_secondary.json"), "w") as f:
+                    f.write(full + "\n")
+        except OSError:
+            pass
+    if "secondary" in line:
+        print(json.dumps({"secondary": line["secondary"]}), file=sys.stderr, flush=True)
+    sys.stdout.flush()
+    print(compact_line(line), flush=True)
 
 
 def main():
@@ -546,8 +630,8 @@ def main():
                        "compressed_bytes": total_out, "input_bytes_per_rank": per_rank_bytes,
                        "parallelism": "independent buffers, %d GPU(s), no collective in the data path" % world},
             "roofline": roofline(stage_ms, n + sum(main_batch.out_lens),
-                                 pmc_traffic("zs_%s_kernel" % max(stage_ms, key=stage_ms.get), "english64_L6")
-                                 if workload == "english64" and args.level == 6 and args.size == 64 << 20 else None),
+                                 *(pmc_stage(stage_ms, "traffic_english64_L6")
+                                   if workload == "english64" and args.level == 6 and args.size == 64 << 20 else (None, None))),
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
         }
         if shard_note:
@@ -592,7 +676,7 @@ def main():
                 # (zs_fast_sweep_kernel, chunk form); the reference publishes 54.8 / 36.9 MB/s for alice29 at levels 1 / 3 (benchmarks.md:63,118)
                 en8 = datagen.english(8 << 20, 77)
                 for lvl in (1, 3):
-                    sec["english8_L%d" % lvl], b = secondary_deflate(eng, dev, "english8: ONE 8 MiB text stream (DeflateFast)", [en8], lvl, 2)
+                    sec["english8_L%d" % lvl], b = secondary_deflate(eng, dev, "english8: ONE 8 MiB text stream (DeflateFast)", [en8], lvl, 2, pmc_tag="fast1_L%d" % lvl)
                     if not args.no_cpu_baseline:
                         cbs, refs, slen = cpu_baseline(en8, lvl, budget_s=2.0, name="english8")
                         sec["english8_L%d" % lvl]["cpu_baseline"] = cbs
@@ -601,7 +685,7 @@ def main():
                     del b
                 # ... the headline buffer at levels 1 and 3 (8191 chunks, 32 consecutive ones to a workgroup)
                 for lvl in (1, 3):
-                    sec["english64_L%d" % lvl], b = secondary_deflate(eng, dev, "english64: the headline buffer under DeflateFast", [data], lvl, 2)
+                    sec["english64_L%d" % lvl], b = secondary_deflate(eng, dev, "english64: the headline buffer under DeflateFast", [data], lvl, 2, pmc_tag="fast64_L%d" % lvl)
                     if not args.no_cpu_baseline:
                         cbs, refs, slen = cpu_baseline(data, lvl, budget_s=6.5, name="english64")
                         sec["english64_L%d" % lvl]["cpu_baseline"] = cbs
@@ -610,7 +694,7 @@ def main():
                     del b
                 # ... and in a batch (one workgroup per stream): 512 x 512 KiB
                 texts = [datagen.english(512 << 10, 1000 + i) for i in range(512)]
-                sec["fast512_L1"], b = secondary_deflate(eng, dev, "512 x 512 KiB text streams in one batch (DeflateFast)", texts, 1, 2, check_every=64)
+                sec["fast512_L1"], b = secondary_deflate(eng, dev, "512 x 512 KiB text streams in one batch (DeflateFast)", texts, 1, 2, check_every=64, pmc_tag="fast512_L1")
                 del b, texts
                 # CompressionStrategy.Rle (Deflate.Rle.cs:18-104) over the chip (zs_rle.hip)
                 sec["sparse64_rle_L6"], b = secondary_deflate(eng, dev, "sparse64 under CompressionStrategy.Rle", [sp], 6, ks, strategy=3)
@@ -622,7 +706,7 @@ def main():
                 eng.close()  # the stream-API tool is its own process with its own context
                 sec["stream_api"] = secondary_stream_api(data, args.level)
                 line["secondary"] = sec
-        print(json.dumps(line))
+        emit_report(line)
     if world > 1:
         dist.destroy_process_group()
 
