@@ -61,6 +61,8 @@ struct ParCand {
     int64_t out_bytes;
     int32_t bfinal, ok;
     int32_t tab, pad_;  // >= 0: measured by the lane kernel, with tables and checkpoints in tabs[tab] (see zs_inf_decode_lane_kernel)
+    int64_t tok_off;    // the candidate's slab in the token array (zs_inflate_tok.hip), and its room in tokens
+    int32_t tok_cap, pad2_;
 };
 struct ParBlock {
     int64_t bit, out_off, out_bytes;
@@ -71,6 +73,7 @@ struct ParState {
     int32_t ok;        // 1: block-parallel path valid for this stream
     int32_t win_off;   // index of the stream's first window in `windows` (set by the host once the block counts are known)
     int64_t out_len, end_bit;
+    int32_t lane_blocks, pad_;  // 1: the chain has blocks with checkpoints but no tokens (the lane decoder and its flatten pass have work)
 };
 
 // ---- shared block decoder (wave-uniform) ----
@@ -608,6 +611,7 @@ __global__ __launch_bounds__(256) void zs_inf_flatten_kernel(const ParStream *ps
             ParCand &d = cands[s.cand_off + at + i];
             d.bit = cand_bits[((int64_t)s.chunk_off + c) * kFindMaxCand + i];
             d.end_bit = 0, d.out_bytes = 0, d.bfinal = 0, d.ok = 0, d.tab = -1, d.pad_ = 0;
+            d.tok_off = 0, d.tok_cap = 0, d.pad2_ = 0;
         }
         base += sc[255];
         __syncthreads();
@@ -618,6 +622,7 @@ __global__ __launch_bounds__(256) void zs_inf_flatten_kernel(const ParStream *ps
         st[si].nblk = 0;
         st[si].out_len = 0;
         st[si].end_bit = 0;
+        st[si].lane_blocks = 0, st[si].pad_ = 0;
     }
 }
 
@@ -969,6 +974,7 @@ __global__ __launch_bounds__(1024) void zs_inf_chain_par_kernel(const ParStream 
         if (reach[i]) {
             const ParCand q = cd[i];
             bl[nb] = {q.bit, out, q.out_bytes, lane_decode ? q.tab : -1, 0};
+            if (lane_decode && q.tab >= 0 && !(q.tab & 0x40000000)) ss.lane_blocks = 1;
             nb++, out += q.out_bytes;
             if (q.bfinal) ss.end_bit = q.end_bit;  // exactly one marked candidate is final: the chain ends there
         }
@@ -1044,7 +1050,10 @@ __global__ __launch_bounds__(64) void zs_inf_chain_kernel(const ParStream *ps, P
             ok = 0;
             break;
         }
-        if (threadIdx.x == 0) bl[nb] = {cur, out, nbytes, tab, 0};
+        if (threadIdx.x == 0) {
+            bl[nb] = {cur, out, nbytes, tab, 0};
+            if (tab >= 0 && !(tab & 0x40000000)) ss.lane_blocks = 1;
+        }
         nb++;
         out += nbytes;
         cur = end;
@@ -1106,7 +1115,7 @@ __global__ __launch_bounds__(64) void zs_inf_decode_lane_kernel(const ParStream 
     live = live && st[w.x].ok && (int)w.y < st[w.x].nblk;
     ParBlock k = {0, 0, 0, -1, 0};
     if (live) k = blocks[s.blk_off + w.y];
-    live = live && k.tab >= 0;
+    live = live && k.tab >= 0 && !(k.tab & 0x40000000);  // (kTabTok: the block has tokens, zs_inf_expand_kernel's)
     const LaneTabs *T = tabs + (live ? k.tab : 0);
     if (live) {
         const uint4 *src = (const uint4 *)T;  // LaneTabs starts with an InfTables image: 16-byte aligned
@@ -1283,7 +1292,7 @@ __global__ __launch_bounds__(256) void zs_inf_cellflat_kernel(const ParStream *p
     const ParStream s = ps[w.x];
     if (!st[w.x].ok || (int)w.y >= st[w.x].nblk) return;
     const ParBlock k = blocks[s.blk_off + w.y];
-    if (k.tab < 0) return;
+    if (k.tab < 0 || (k.tab & 0x40000000)) return;
     const LaneTabs &T = tabs[k.tab];
     const int nsub = T.nsub;
     for (int i = threadIdx.x; i <= nsub; i += 256) ck[i] = T.ck_out[i];
