@@ -58,7 +58,7 @@ struct zs_ctx {
     double stage_ms[kStCount] = {};
     uint32_t *crc_tab = nullptr;
     DevBuf sd, st, work, wpre, geo, link, mm, maps, chunk_far, segmap, supmap, seg_entry, seg_symbase, seg_stale, entry, symbase, stale, syms, blk_end, blk_top, blocks, trees, info, pieces, scratch,
-        stage_in, stage_out, wr, inf_desc, inf_state, par_ps, par_st, par_work, par_cbits, par_ccnt, par_surv, par_scnt, par_cands, par_tabs, par_toktabs, par_toks, par_tokstat, par_blocks, par_cells,
+        stage_in, stage_out, wr, inf_desc, inf_state, par_ps, par_st, par_work, par_cbits, par_ccnt, par_surv, par_scnt, par_cands, par_tabs, par_toktabs, par_toks, par_ctoks, par_tokstat, par_tails, par_blocks, par_cells,
         par_windows, par_fail, run_syms, run_bits, run_scratch, run_outs, run_fail, adl_tr, adl_res, plan_blk, ins_bits, mm_bak, cut_pos, cut_bkt, win_groups, win_sg, win_maps, win_entries, persist_bak, resume_flag, rle_tiles, own_in, fr_chunks, fr_meta, fr_planes, fr_prov, fr_base, fr_counters;
     bool resume_poisoned = false;  // a resumed run met a read the bulk form does not handle: the caller goes on with the literal engine
     void *pinned = nullptr;
@@ -1322,7 +1322,7 @@ void zs_ctx_destroy(zs_ctx *c) {
     (void)hipSetDevice(c->device);
     DevBuf *bufs[] = {&c->sd, &c->st, &c->work, &c->wpre, &c->geo, &c->link, &c->mm, &c->maps, &c->chunk_far, &c->segmap, &c->supmap, &c->seg_entry, &c->seg_symbase, &c->seg_stale, &c->entry, &c->symbase, &c->stale, &c->syms,
                       &c->blk_end, &c->blk_top, &c->blocks, &c->trees, &c->info, &c->pieces, &c->scratch, &c->stage_in, &c->stage_out, &c->wr, &c->inf_desc, &c->inf_state, &c->par_ps, &c->par_st, &c->par_work, &c->par_cbits, &c->par_ccnt, &c->par_surv, &c->par_scnt,
-                      &c->par_cands, &c->par_tabs, &c->par_toktabs, &c->par_toks, &c->par_tokstat, &c->par_blocks, &c->par_cells, &c->par_windows, &c->par_fail, &c->run_syms, &c->run_bits,
+                      &c->par_cands, &c->par_tabs, &c->par_toktabs, &c->par_toks, &c->par_ctoks, &c->par_tokstat, &c->par_tails, &c->par_blocks, &c->par_cells, &c->par_windows, &c->par_fail, &c->run_syms, &c->run_bits,
                       &c->run_scratch, &c->run_outs, &c->run_fail, &c->adl_tr, &c->adl_res, &c->plan_blk, &c->ins_bits, &c->mm_bak, &c->cut_pos, &c->cut_bkt, &c->win_groups, &c->win_sg, &c->win_maps, &c->win_entries, &c->persist_bak, &c->resume_flag, &c->rle_tiles, &c->own_in, &c->fr_chunks, &c->fr_meta, &c->fr_planes, &c->fr_prov, &c->fr_base, &c->fr_counters};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
@@ -1622,10 +1622,13 @@ bool run_inflate_par(zs_ctx *c, const std::vector<int> &idx, const void *const *
     // ZS_INF_LANE_DECODE=1: round 4's form (measure, then decode again lane by lane, then chase the lanes' markers)
     static const bool tok_mode = !getenv("ZS_INF_LANE_DECODE") && !getenv("ZS_INF_WAVE_MEASURE") && !getenv("ZS_INF_WAVE_DECODE");
     int64_t tok_total = 0;
-    if (tok_mode && !c->inf_probe) {  // (a probing call decodes nothing: no slabs, the measuring pass stores no tokens)
-        if (!ensure(c, c->par_tokstat, 64)) return false;
-        hipLaunchKernelGGL(zs_inf_tokalloc_kernel, dim3(1), dim3(1024), 0, stream, d_ps, d_st, m, dev<ParCand>(c->par_cands), dev<int64_t>(c->par_tokstat));
-        ZS_HIP(c, hipMemcpyAsync(&tok_total, c->par_tokstat.p, 8, hipMemcpyDeviceToHost, stream));
+    if (tok_mode) {
+        if (!ensure(c, c->par_tokstat, 128) || !ensure(c, c->par_tails, 4 * (size_t)kSbTailBuf * (size_t)m)) return false;
+        hipLaunchKernelGGL(zs_inf_tails_kernel, dim3((unsigned)m), dim3(64), 0, stream, d_ps, dev<uint32_t>(c->par_tails));
+        if (!c->inf_probe) {  // (a probing call decodes nothing: no slabs, the measuring pass stores no tokens)
+            hipLaunchKernelGGL(zs_inf_tokalloc_kernel, dim3(1), dim3(1024), 0, stream, d_ps, d_st, m, dev<ParCand>(c->par_cands), dev<int64_t>(c->par_tokstat));
+            ZS_HIP(c, hipMemcpyAsync(&tok_total, c->par_tokstat.p, 8, hipMemcpyDeviceToHost, stream));
+        }
     }
     mark(1);
     ZS_HIP(c, hipMemcpyAsync(st.data(), d_st, sizeof(ParState) * (size_t)m, hipMemcpyDeviceToHost, stream));
@@ -1658,16 +1661,21 @@ bool run_inflate_par(zs_ctx *c, const std::vector<int> &idx, const void *const *
             hipLaunchKernelGGL(zs_inf_measure_kernel, dim3((unsigned)w.size()), dim3(64), 0, stream, d_ps, d_st, dev<uint2>(c->par_work),
                                dev<ParCand>(c->par_cands));
         } else if (tok_mode) {
-            if (!ensure(c, c->par_toktabs, sizeof(TokTabs) * w.size()) || !ensure(c, c->par_tabs, sizeof(LaneTabs) * w.size()) ||
-                !ensure(c, c->par_toks, 4 * (size_t)tok_total + 64))
-                return false;
+            if (!ensure(c, c->par_toktabs, sizeof(TokTabs) * w.size()) || !ensure(c, c->par_tabs, sizeof(LaneTabs) * w.size())) return false;
+            // the tokens twice (the lanes' slabs, the blocks' lists); without room for them the blocks are decoded again lane by lane
+            int mdbg = getenv("ZS_INF_MEASURE_DBG") ? atoi(getenv("ZS_INF_MEASURE_DBG")) : 0;
+            if (!ensure(c, c->par_toks, 4 * (size_t)tok_total + 64) || !ensure(c, c->par_ctoks, 4 * (size_t)tok_total + 64)) {
+                c->err.clear();
+                if (!ensure(c, c->par_toks, 64) || !ensure(c, c->par_ctoks, 64)) return false;
+                mdbg = 3;
+            }
             int32_t *stats = nullptr;
             if (getenv("ZS_DEBUG_INF") && !c->inf_probe) {
-                ZS_HIP(c, hipMemsetAsync((uint8_t *)c->par_tokstat.p + 16, 0, 32, stream));
+                ZS_HIP(c, hipMemsetAsync((uint8_t *)c->par_tokstat.p + 16, 0, 64, stream));
                 stats = (int32_t *)((uint8_t *)c->par_tokstat.p + 16);
             }
             hipLaunchKernelGGL(zs_inf_measure_tok_kernel, dim3((unsigned)w.size()), dim3(64), 0, stream, d_ps, d_st, dev<uint2>(c->par_work),
-                               dev<ParCand>(c->par_cands), dev<TokTabs>(c->par_toktabs), dev<LaneTabs>(c->par_tabs), dev<uint32_t>(c->par_toks), stats);
+                               dev<ParCand>(c->par_cands), dev<TokTabs>(c->par_toktabs), dev<LaneTabs>(c->par_tabs), dev<uint32_t>(c->par_toks), dev<uint32_t>(c->par_ctoks), dev<uint32_t>(c->par_tails), stats, mdbg);
             if (stats) {
                 int32_t hs[4] = {0, 0, 0, 0};
                 ZS_HIP(c, hipMemcpyAsync(hs, stats, 16, hipMemcpyDeviceToHost, stream));
@@ -1749,8 +1757,8 @@ bool run_inflate_par(zs_ctx *c, const std::vector<int> &idx, const void *const *
         bool lane_work = lane_decode && !tok_mode;
         for (int j = 0; j < m && tok_mode; j++) lane_work = lane_work || (st[(size_t)j].ok && st[(size_t)j].lane_blocks);
         if (lane_decode && tok_mode)
-            hipLaunchKernelGGL(zs_inf_expand_kernel, dim3((unsigned)w.size()), dim3(1024), kExpLds, stream, d_ps, d_st, dev<uint2>(c->par_work),
-                               dev<ParBlock>(c->par_blocks), dev<TokTabs>(c->par_toktabs), dev<uint32_t>(c->par_toks), dev<uint16_t>(c->par_cells),
+            hipLaunchKernelGGL(zs_inf_expand_kernel, dim3((unsigned)w.size()), dim3(kExpThreads), kExpLds, stream, d_ps, d_st, dev<uint2>(c->par_work),
+                               dev<ParBlock>(c->par_blocks), dev<TokTabs>(c->par_toktabs), dev<uint32_t>(c->par_ctoks), dev<uint16_t>(c->par_cells),
                                dev<int32_t>(c->par_fail), getenv("ZS_DEBUG_INF") ? (int32_t *)((uint8_t *)c->par_tokstat.p + 16) : nullptr);
         if (lane_work)
             hipLaunchKernelGGL(zs_inf_decode_lane_kernel, dim3((unsigned)((w.size() + kDecBlocks - 1) / kDecBlocks)), dim3(64), 0, stream, d_ps,
@@ -1782,9 +1790,10 @@ bool run_inflate_par(zs_ctx *c, const std::vector<int> &idx, const void *const *
         ZS_HIP(c, hipMemcpyAsync(bfail.data(), c->par_fail.p, 4 * (size_t)m, hipMemcpyDeviceToHost, stream));
         ZS_HIP(c, hipStreamSynchronize(stream));
         if (tok_mode && getenv("ZS_DEBUG_INF")) {
-            int32_t hs[8] = {};
-            (void)hipMemcpy(hs, (uint8_t *)c->par_tokstat.p + 16, 32, hipMemcpyDeviceToHost);
-            fprintf(stderr, "[zs] inflate expand: %d blocks with tokens, %d steps, %d rounds of pointer jumping\n", hs[6], hs[4], hs[5]);
+            int32_t hs[16] = {};
+            (void)hipMemcpy(hs, (uint8_t *)c->par_tokstat.p + 16, 64, hipMemcpyDeviceToHost);
+            fprintf(stderr, "[zs] inflate expand: %d blocks with tokens, %d steps, %d rounds of pointer jumping; cycles / 256 of wave 0 in phases: scan %d, barrier %d, fetch+words %d, cells %d, rounds %d, out %d, barrier %d\n",
+                    hs[6], hs[4], hs[5], hs[8], hs[9], hs[10], hs[11], hs[12], hs[13], hs[14]);
         }
         if (prof) {
             c->last_op = 1;

@@ -114,36 +114,83 @@ struct InfBits {
     }
 };
 
-// canonical tables from code lengths; returns 0 complete, > 0 incomplete, < 0 oversubscribed
+// canonical tables from code lengths; returns 0 complete, > 0 incomplete, < 0 oversubscribed.
+// One wave, its lanes on the symbols and then on the table entries (round 5; until then every lane ran the reference's serial
+// loops over all symbols -- InfTree.cs:125-365 -- with the same values: ~0.1 ms per block header, more than the decode of the
+// block's symbols by 64 lanes took):
+//   counts and ranks   lane l has symbols l, l + 64, ...; a ballot per code length gives the symbols of that length in the
+//                      chunk and, below the lane, the symbol's rank among them -- its place in symtab (by length, then symbol);
+//   primary table      lane l has entries l, l + 64, ...: an entry's index is the first pbits bits of a code; canonical codes
+//                      ascend with their length, so its length is the number of lengths whose codes end at or below it and
+//                      its symbol follows from where that length's codes begin (left-aligned 15-bit values).
 __device__ int inf_build(const uint8_t *lens, int n, uint16_t *primary, int pbits, uint16_t *count, uint16_t *symtab) {
     const int lane = threadIdx.x & 63;
-    uint16_t offs[16];
-    for (int i = 0; i < 16; i++) count[i] = 0;
-    for (int i = 0; i < n; i++) count[lens[i]]++;
+    const uint64_t below = lane ? (~0ull >> (64 - lane)) : 0ull;
+    int cnt[16];
+#pragma unroll
+    for (int L = 0; L < 16; L++) cnt[L] = 0;
+    int myl[5], myr[5];  // n <= 320: at most five symbols per lane
+#pragma unroll
+    for (int c = 0; c < 5; c++) {
+        myl[c] = 16, myr[c] = 0;
+        if (c * 64 < n) {  // (uniform)
+            const int i = c * 64 + lane;
+            const int l = i < n ? (int)lens[i] : 16;
+            int r = 0;
+#pragma unroll
+            for (int L = 0; L < 16; L++) {
+                const uint64_t m = __ballot(l == L);
+                r = l == L ? cnt[L] + (int)__builtin_popcountll(m & below) : r;
+                cnt[L] += (int)__builtin_popcountll(m);
+            }
+            myl[c] = l, myr[c] = r;
+        }
+    }
+#pragma unroll
+    for (int L = 0; L < 16; L++)
+        if (lane == L) count[L] = (uint16_t)cnt[L];
     int left = 1;
+#pragma unroll
     for (int len = 1; len <= 15; len++) {
         left <<= 1;
-        left -= count[len];
+        left -= cnt[len];
         if (left < 0) return left;
     }
-    offs[1] = 0;
-    for (int len = 1; len < 15; len++) offs[len + 1] = (uint16_t)(offs[len] + count[len]);
-    for (int i = 0; i < n; i++)
-        if (lens[i]) symtab[offs[lens[i]]++] = (uint16_t)i;
-    // primary table: every lane fills a strided share of the entries
-    for (int i = lane; i < (1 << pbits); i += 64) primary[i] = kInfEsc;
+    int offs[16];  // symbols shorter than len
+    uint32_t end[16];  // left-aligned 15-bit value behind the last code of length len
+    offs[0] = 0, offs[1] = 0, end[0] = 0;
+#pragma unroll
+    for (int len = 1; len <= 15; len++) {
+        if (len < 15) offs[len + 1] = offs[len] + cnt[len];
+        end[len] = end[len - 1] + ((uint32_t)cnt[len] << (15 - len));
+    }
+#pragma unroll
+    for (int c = 0; c < 5; c++) {
+        int o = 0;
+#pragma unroll
+        for (int L = 1; L <= 15; L++) o = myl[c] == L ? offs[L] : o;
+        if (myl[c] >= 1 && myl[c] <= 15) symtab[o + myr[c]] = (uint16_t)(c * 64 + lane);
+    }
     __syncthreads();
-    unsigned code = 0;
-    int index = 0;
-    for (int len = 1; len <= pbits; len++) {
-        for (int k = 0; k < count[len]; k++) {
-            unsigned rev = bit_reverse(code, len);
-            uint16_t e = (uint16_t)((symtab[index] << 4) | len);
-            for (unsigned r = rev + ((unsigned)lane << len); r < (1u << pbits); r += 64u << len) primary[r] = e;
-            code++;
-            index++;
+    uint32_t endp = end[10];  // pbits is 7 (bit-length code), 9 (distances) or 10 (literals / lengths)
+    endp = pbits == 7 ? end[7] : pbits == 9 ? end[9] : endp;
+    for (int x = lane; x < (1 << pbits); x += 64) {
+        const uint32_t rv = (__brev((uint32_t)x) >> (32 - pbits)) << (15 - pbits);  // the entry's bits, first bit on top
+        uint16_t e = kInfEsc;  // a longer code, or none
+        if (rv < endp) {
+            int len = 1;
+#pragma unroll
+            for (int L = 1; L <= 9; L++) len += (L < pbits && rv >= end[L]) ? 1 : 0;
+            uint32_t lo = 0;
+            int id = 0;
+#pragma unroll
+            for (int L = 1; L <= 9; L++) {
+                lo = len == L + 1 ? end[L] : lo;
+                id = len == L + 1 ? offs[L + 1] : id;
+            }
+            e = (uint16_t)((symtab[id + (int)((rv - lo) >> (15 - len))] << 4) | len);
         }
-        code <<= 1;
+        primary[x] = e;
     }
     __syncthreads();
     return left;

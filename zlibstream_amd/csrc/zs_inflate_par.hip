@@ -355,7 +355,8 @@ struct LaneBits {
         return v;
     }
 };
-__device__ int lane_slow(const LaneBits &b, const uint16_t *count, const uint16_t *symtab, int &len_out) {
+template <typename Bits>
+__device__ int lane_slow(const Bits &b, const uint16_t *count, const uint16_t *symtab, int &len_out) {
     int code = 0, first = 0, index = 0;
     uint64_t bits = b.buf;
     for (int len = 1; len <= 15; len++) {
