@@ -153,6 +153,11 @@ ZS_API int zs_png_filter_device(zs_ctx *ctx, const void *pixels, int64_t row_byt
 
 /* Stage timing of the last *_batch_device call, measured with hipEvents on
  * the stream the kernels ran on.  Enable before the call. */
+/* Counters of a context for tests and measurements (-1: no such counter): "fast_rounds" -- rounds the last call's DeflateFast took
+ * over its chunks (0: one workgroup per stream); "fast_fallbacks", "round_runs", "cut_rounds", "lit_fallbacks" -- batches that took
+ * one of the slower paths since the context was made; "lit_engine_bytes" -- input bytes the one-wave literal engine parsed
+ * beyond the streams' last 261. */
+ZS_API int64_t zs_ctx_counter(const zs_ctx *ctx, const char *name);
 ZS_API void zs_ctx_set_profiling(zs_ctx *ctx, int enable);
 ZS_API int zs_ctx_stage_count(const zs_ctx *ctx);
 ZS_API const char *zs_ctx_stage_name(const zs_ctx *ctx, int stage);

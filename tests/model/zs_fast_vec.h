@@ -1,4 +1,5 @@
-// zs_fast_vec.h -- DeflateFast (levels 1-3, Deflate.Fast.cs:20-128) for the lanes of a wave.
+// zs_fast_vec.h -- DeflateFast (levels 1-3, Deflate.Fast.cs:20-128) for the lanes of a wave: round 3's form, kept for the CPU
+// model only (mode "fvec"; the product's kernels are zs_fast_sweep.hip).
 //
 // DeflateFast inserts only some positions into the hash chains (every loop-top, and the inside of a match no longer than
 // max_lazy), so its chains depend on its own parse and the parse cannot be cut into independent pieces (SURVEY.md hard
@@ -25,7 +26,7 @@
 // link[t + 1] == 1) the search at t is dead, the one at t + 1 sees only t, and the chain is cut behind t (link[t] = 0,
 // the 2-cycle prev[t] = t + 1, prev[t + 1] = t of the reference); otherwise the search at t + 1 is dead.
 #pragma once
-#include "zs_core.h"
+#include "../../zlibstream_amd/csrc/zs_core.h"
 
 namespace zs {
 

@@ -20,7 +20,7 @@
 #include "../../oracle/zs_oracle.h"
 #include "../../zlibstream_amd/csrc/zs_core.h"
 #include "../../zlibstream_amd/csrc/zs_lit_engine.h"
-#include "../../zlibstream_amd/csrc/zs_fast_vec.h"
+#include "zs_fast_vec.h"
 #include "../../zlibstream_amd/csrc/zs_fast_sweep.h"
 #include "../../zlibstream_amd/csrc/zs_rle.h"
 

@@ -69,7 +69,7 @@ def test_config2_english64_levels_1_and_9_sample_and_roundtrip(engine, oracle):
         assert engine.deflate_batch([small], level=level)[0] == oracle.compress(small, level)
 
 
-def test_config2_english64_at_the_fast_levels_bit_exact_and_at_rate(engine, oracle):
+def test_config2_english64_at_the_fast_levels_bit_exact_and_at_rate(engine, oracle, rate_floors):
     """english64 under DeflateFast (levels 1-3, Deflate.Fast.cs:20-128), the whole 64 MiB against the oracle's bytes: one stream
     as rounds over 8191 chunks, 32 consecutive ones to a workgroup while most of them still change (zs_fast_sweep.h "Rounds").
     Measured 1.38 / 1.17 / 1.93 GB/s at levels 1 / 2 / 3 with the input resident in HBM (one workgroup for the stream: 48 / 21
@@ -88,7 +88,7 @@ def test_config2_english64_at_the_fast_levels_bit_exact_and_at_rate(engine, orac
         torch.cuda.synchronize()
         dt = time.perf_counter() - t
         assert d_out[:m].cpu().numpy().tobytes() == oracle.compress(data, level), level
-        assert len(data) / dt >= floor, "level %d: %.1f ms = %.0f MB/s" % (level, dt * 1e3, len(data) / dt / 1e6)
+        rate_floors.check(len(data) / dt >= floor, "level %d: %.1f ms = %.0f MB/s" % (level, dt * 1e3, len(data) / dt / 1e6))
 
 
 # ---------------------------------------------------------------- config 5: 16 x 64 MiB level-6 streams -> 1 GiB

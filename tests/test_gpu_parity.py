@@ -459,7 +459,7 @@ def test_cpp_host_mirror(tmp_path):
     assert r.returncode == 0 and "PASS" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
-def test_rle_strategy_over_the_chip(engine, oracle):
+def test_rle_strategy_over_the_chip(engine, oracle, rate_floors):
     """CompressionStrategy.Rle (Deflate.Rle.cs:18-104) off the literal engine: a match never leaves the run of equal bytes it
     lies in, so a position's part in the parse follows from where its run began (zs_rle.h; kernels zs_rle.hip: a prefix maximum
     over the run starts, two passes over the positions).  Bytes against the oracle at levels 1 / 6 / 9 on text (runs of one),
@@ -501,10 +501,10 @@ def test_rle_strategy_over_the_chip(engine, oracle):
         z = d_out[:m].cpu().numpy().tobytes()
         assert zlib.decompress(z) == data
         assert z[:1 << 20] == oracle.compress(data[:8 << 20], 6, 3)[:1 << 20], name   # (the stream's first MiB: the same blocks)
-        assert len(data) / dt >= 5e9, "%s under Rle: %.1f ms = %.2f GB/s" % (name, dt * 1e3, len(data) / dt / 1e9)
+        rate_floors.check(len(data) / dt >= 5e9, "%s under Rle: %.1f ms = %.2f GB/s" % (name, dt * 1e3, len(data) / dt / 1e9))
 
 
-def test_fast_levels_single_stream_rate(engine, oracle):
+def test_fast_levels_single_stream_rate(engine, oracle, rate_floors):
     """DeflateFast on ONE text stream (Deflate.Fast.cs:20-128; the reference does 54.8 / 36.9 MB/s at levels 1 / 3 on its
     2018 laptop core, benchmarks.md:63,118; the oracle on the GPU box's host 79 / 50): as rounds over the stream's chunks
     zs_fast_sweep_kernel holds 289 / 437 MB/s on 8 MiB of text resident in HBM (one workgroup for the whole stream: 48 / 21;
@@ -526,7 +526,7 @@ def test_fast_levels_single_stream_rate(engine, oracle):
         torch.cuda.synchronize()
         dt = time.perf_counter() - t
         assert zlib.decompress(d_out[:m].cpu().numpy().tobytes()) == text
-        assert len(text) / dt >= floor, "level %d: %.1f ms = %.1f MB/s" % (lvl, dt * 1e3, len(text) / dt / 1e6)
+        rate_floors.check(len(text) / dt >= floor, "level %d: %.1f ms = %.1f MB/s" % (lvl, dt * 1e3, len(text) / dt / 1e6))
 
 
 @pytest.mark.gpu
@@ -1101,7 +1101,7 @@ def test_cut_rounds_with_more_slots_than_a_grid_dimension(engine, oracle):
 
 
 @pytest.mark.gpu
-def test_scanline_and_odd_sized_writes_at_64_mib_run_at_device_speed(engine, oracle):
+def test_scanline_and_odd_sized_writes_at_64_mib_run_at_device_speed(engine, oracle, rate_floors):
     """The verdict's cases at BASELINE size: 64 MiB of text in 1000-byte and 81 921-byte Writes and a 4096 x 4096 RGBA image
     written one filtered scanline (16 385 bytes) per Write, level 6, resident in HBM: at least 1 GB/s (the literal engine
     does 2 MB/s), a round trip through an independent inflater, and the first 4 MiB -- written the same way -- byte for byte
@@ -1114,7 +1114,7 @@ def test_scanline_and_odd_sized_writes_at_64_mib_run_at_device_speed(engine, ora
         z, dt = _deflate_writes(engine, data, ends, 6)   # (the first call sizes the workspace)
         z, dt = _deflate_writes(engine, data, ends, 6)
         assert zlib.decompress(z) == data, (name, size)
-        assert len(data) / dt >= 1e9, "%s in %d-byte Writes: %.1f ms = %.2f GB/s" % (name, size, dt * 1e3, len(data) / dt / 1e9)
+        rate_floors.check(len(data) / dt >= 1e9, "%s in %d-byte Writes: %.1f ms = %.2f GB/s" % (name, size, dt * 1e3, len(data) / dt / 1e9))
         part = data[:4 << 20]
         pe = _write_ends(len(part), size, None)
         zp, _ = _deflate_writes(engine, part, pe, 6)
@@ -1288,3 +1288,35 @@ def test_long_chain_levels_on_runs_and_zero_pages_go_through_rounds(engine, orac
             assert engine.deflate_batch(more, level=6) == want_more, var
         finally:
             del os.environ[var]
+
+
+@pytest.mark.gpu
+def test_inflate_by_pieces_past_the_buffering_threshold():
+    """zs_inflate's bounded form (zs_stream_api.inc: once ZS_INF_PIECE_BYTES -- 64 MiB in production -- have been buffered without the
+    stream's end in sight, the complete blocks so far are decoded and leave the buffer): a text stream fed 8 KiB at a time
+    through several thresholds with bytes behind its trailer, and 48 MiB of zeros whose pieces decode to a thousand times
+    their size.  The threshold is read when the library loads: a process of its own."""
+    import subprocess
+    import sys
+    code = r'''
+import io, sys, zlib
+sys.path.insert(0, %r)
+from zlibstream_amd import ZlibInputStream, Engine, datagen
+eng = Engine(0)
+for d, trail in ((datagen.english(6 << 20, 5), b"BEHIND-THE-TRAILER" * 40), (bytes(48 << 20), b"xyz")):
+    z = zlib.compress(d, 6)
+    s = ZlibInputStream(io.BytesIO(z + trail), engine=eng)
+    got = bytearray()
+    while True:
+        part = s.read(1 << 20)
+        if not part:
+            break
+        got += part
+    assert bytes(got) == d, (len(got), len(d))
+    assert s.TotalIn == len(z) and s.TotalOut == len(d), (s.TotalIn, len(z), s.TotalOut)
+    assert s.Adler == zlib.adler32(d)
+print("pieces ok")
+''' % oracle_binding.ROOT
+    env = dict(os.environ, ZS_INF_PIECE_BYTES="20000")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "pieces ok" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])

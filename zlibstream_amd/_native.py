@@ -10,7 +10,7 @@ LIB_PATH = (os.environ.get("ZS_LIB") if os.environ.get("ZS_DEV") == "1" else Non
 
 SYMBOLS = [
     "zs_ctx_create", "zs_ctx_destroy", "zs_ctx_last_error", "zs_deflate_bound", "zs_deflate_batch_device",
-    "zs_deflate_batch", "zs_ctx_set_profiling", "zs_ctx_stage_count", "zs_ctx_stage_name", "zs_ctx_stage_ms",
+    "zs_deflate_batch", "zs_ctx_counter", "zs_ctx_set_profiling", "zs_ctx_stage_count", "zs_ctx_stage_name", "zs_ctx_stage_ms",
     "zs_deflate_init", "zs_deflate", "zs_deflate_end", "zs_last_message", "zs_adler32_device",
     "zs_inflate_batch_device", "zs_inflate_batch", "zs_inflate_init", "zs_inflate", "zs_inflate_end", "zs_inflate_message", "zs_inflate_surplus",
     "zs_device_count", "zs_partition", "zs_deflate_batch_multi", "zs_inflate_batch_multi", "zs_png_filter_device", "zs_deflate_writes_device", "zs_deflate_batch_multi_device", "zs_inflate_batch_multi_device",
@@ -59,6 +59,8 @@ def lib():
     L.zs_inflate_batch_device.argtypes = inf_args + [vp]
     L.zs_inflate_batch.restype = i32
     L.zs_inflate_batch.argtypes = inf_args
+    L.zs_ctx_counter.restype = i64
+    L.zs_ctx_counter.argtypes = [vp, ctypes.c_char_p]
     L.zs_ctx_set_profiling.restype = None
     L.zs_ctx_set_profiling.argtypes = [vp, i32]
     L.zs_ctx_stage_count.restype = i32

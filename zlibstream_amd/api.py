@@ -108,6 +108,10 @@ class Engine:
     def set_profiling(self, on):
         self._lib.zs_ctx_set_profiling(self._h, 1 if on else 0)
 
+    def counter(self, name):
+        """zs_ctx_counter: "fast_rounds", "fast_fallbacks", "round_runs", "cut_rounds", "lit_fallbacks", "lit_engine_bytes"."""
+        return int(self._lib.zs_ctx_counter(self._h, name.encode()))
+
     def stage_ms(self):
         n = self._lib.zs_ctx_stage_count(self._h)
         return {self._lib.zs_ctx_stage_name(self._h, i).decode(): self._lib.zs_ctx_stage_ms(self._h, i) for i in range(n)}

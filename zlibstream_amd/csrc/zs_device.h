@@ -4,7 +4,6 @@
 #include <cstddef>
 #include "zs_core.h"
 #include "zs_lit_engine.h"
-#include "zs_fast_vec.h"
 #include "zs_fast_sweep.h"
 #include "zs_rle.h"
 

@@ -47,6 +47,7 @@ struct zs_ctx {
     int round_runs = 0;      // batches with streams in the batched cut rounds (their cuts were not one CU's job)
     int cut_rounds = 0;      // rounds of those
     int lit_fallbacks = 0;   // batches run again with a stream on the literal engine (zs_core.h kMapPoisonBit)
+    int64_t lit_engine_bytes = 0;  // input bytes parsed by the one-wave literal engine beyond the streams' last 261 (zs_ctx_counter)
     // inflate: compressed bytes each stream of the last call used, trailer included (0: unknown / not ended); and, for a
     // probing call (zs_inflate asking whether the stream's end has arrived), where the block chain ended
     std::vector<int64_t> inf_used;
@@ -142,6 +143,7 @@ struct Plan {
     int64_t n_chunks = 0, n_segs = 0, n_sups = 0, n_blocks = 0, n_pieces = 0, n_runs = 0;
     bool any_fv = false, any_rle = false;
     int64_t n_rle_tiles = 0;
+    int64_t lit_bytes = 0;           // input bytes of this plan that only the literal engine parses
     std::vector<FsChunk> fr_chunks;  // levels 1-3 as rounds over the chunks of the streams (zs_fast_sweep.h "Rounds"); empty: one workgroup per stream
     size_t fr_prov = 0;              // symbols of room in the chunks' provisional buffer
     int fr_max_n = 0;                // the most chunks a stream has
@@ -393,7 +395,14 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
             if (s.nsegs > kSupSegs) pl.w_sups.add(i, (s.nsegs + kSupSegs - 1) / kSupSegs);  // shorter streams are resolved row by row
         }
         pl.w_blocks.add(i, s.max_blocks);
+        // what none of the parallel forms takes is the one-wave literal engine's: the whole run, not just its last 261 bytes
+        if (s.body_end < 0 && s.fv_end < 0 && s.rle_end < 0 && s.fast_runs == 0 && s.plan_nblk == 0 && !(level == 0 && strategy != kRle && !ro)) {
+            const int64_t from = resume ? ro->p0 : (ro && cont) ? 0 : 0;
+            pl.lit_bytes += std::max<int64_t>(0, len - from - (kMinLookahead - 1));
+        }
     }
+    c->lit_engine_bytes += pl.lit_bytes;
+    c->fast_rounds = 0;
     const bool no_rounds_this_call = c->no_rounds_once;
     c->no_rounds_once = false;
     if (pl.any_fv && !getenv("ZS_FAST_NO_ROUNDS") && !no_rounds_this_call) {
@@ -874,10 +883,22 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
         if (!pl.fr_chunks.empty()) {
             // rounds over the chunks of the streams: every round one workgroup per chunk, until a round changes nothing
             const size_t nch = pl.fr_chunks.size(), plane_words = (size_t)pl.n_pos / 32 + kFvBitSlack / 4 + 64;
-            const int max_rounds = getenv("ZS_FR_MAX_ROUNDS") ? atoi(getenv("ZS_FR_MAX_ROUNDS")) : pl.fr_max_n + 2;  // (chunk r of a stream is the reference's after round r at the latest)
+            // the switches of the measurements, read once (not per round)
+            static const int env_max_rounds = getenv("ZS_FR_MAX_ROUNDS") ? atoi(getenv("ZS_FR_MAX_ROUNDS")) : 0;
+            static const int env_range = getenv("ZS_FR_RANGE") ? std::max(1, atoi(getenv("ZS_FR_RANGE"))) : 0;
+            static const int env_group = getenv("ZS_FR_GROUP") ? atoi(getenv("ZS_FR_GROUP")) : 4;
+            static const int env_tail = getenv("ZS_FR_TAIL_RANGE") ? atoi(getenv("ZS_FR_TAIL_RANGE")) : 1;
+            static const bool env_no_seed = getenv("ZS_FR_NO_SEED") != nullptr, env_fixed = getenv("ZS_FR_RANGE_FIXED") != nullptr, env_dbg = getenv("ZS_DEBUG") != nullptr;
+            const int max_rounds = env_max_rounds ? env_max_rounds : pl.fr_max_n + 2;  // (chunk r of a stream is the reference's after round r at the latest)
             if (!ensure(c, c->fr_chunks, nch * sizeof(FsChunk)) || !ensure(c, c->fr_meta, 2 * nch * sizeof(FsMeta)) || !ensure(c, c->fr_planes, 16 * plane_words) ||
-                !ensure(c, c->fr_prov, 4 * pl.fr_prov + 64) || !ensure(c, c->fr_base, 4 * nch + 64) || !ensure(c, c->fr_counters, 4 * ((size_t)max_rounds + 16)))
-                return false;
+                !ensure(c, c->fr_prov, 4 * pl.fr_prov + 64) || !ensure(c, c->fr_base, 4 * nch + 64) || !ensure(c, c->fr_counters, 4 * ((size_t)max_rounds + 16))) {
+                // no room for the rounds' planes and provisional symbols: one workgroup per stream needs none of them
+                c->err.clear();
+                ZS_HIP(c, hipStreamSynchronize(c->aux));
+                ZS_HIP(c, hipStreamSynchronize(stream));
+                c->no_rounds_once = true;
+                return run_pipeline(c, n, in, in_len, out, out_cap, out_len, status, level, strategy, hash_variant, stream, writes, force_seq, ro, false, force_lit);
+            }
             ZS_HIP(c, hipMemcpyAsync(c->fr_chunks.p, pl.fr_chunks.data(), nch * sizeof(FsChunk), hipMemcpyHostToDevice, stream));
             ZS_HIP(c, hipMemsetAsync(c->fr_counters.p, 0, 4 * ((size_t)max_rounds + 16), stream));
             // more chunks than CUs: a workgroup takes a range of consecutive chunks in turn, every chunk reading what the chunks before
@@ -888,10 +909,10 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
             // once the chunks that will run again fit the chip (a changed chunk wakes the ~4 behind it), one chunk per workgroup --
             // two active chunks of one range would wait for each other.
             // (below two chipfuls of chunks ranges of one: the corpus, 336 chunks of 11 files, 13.9 / 19.1 ms against 16.5 / 23.6)
-            const int range_max = getenv("ZS_FR_RANGE") ? std::max(1, atoi(getenv("ZS_FR_RANGE"))) : nch >= 512 ? (int)((nch + 255) / 256) : 1;
+            const int range_max = env_range ? env_range : nch >= 512 ? (int)((nch + 255) / 256) : 1;
             FsRounds fr{dev<FsChunk>(c->fr_chunks), dev<FsMeta>(c->fr_meta), dev<uint32_t>(c->fr_planes), dev<uint32_t>(c->fr_prov), dev<uint32_t>(c->fr_counters),
-                        (int64_t)plane_words, (int)nch, 0, getenv("ZS_FR_NO_SEED") ? 1 : 0, range_max};
-            const int group = getenv("ZS_FR_GROUP") ? atoi(getenv("ZS_FR_GROUP")) : 4;  // rounds between two looks at the counter (ranges of one)
+                        (int64_t)plane_words, (int)nch, 0, env_no_seed ? 1 : 0, range_max};
+            const int group = env_group;  // rounds between two looks at the counter (ranges of one)
             uint32_t changed = 1;
             int r = 0;
             std::string trace;
@@ -905,7 +926,7 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
                 }
                 ZS_HIP(c, hipMemcpyAsync(&changed, dev<uint32_t>(c->fr_counters) + (r - 1), 4, hipMemcpyDeviceToHost, stream));
                 ZS_HIP(c, hipStreamSynchronize(stream));
-                if (getenv("ZS_DEBUG")) {
+                if (env_dbg) {
                     static auto t_last = std::chrono::steady_clock::now();
                     const auto t_now = std::chrono::steady_clock::now();
                     char b[64];
@@ -913,14 +934,14 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
                     t_last = t_now;
                     trace += b;
                 }
-                if (!getenv("ZS_FR_RANGE_FIXED")) {
+                if (!env_fixed) {
                     const size_t awake = std::min<size_t>(nch, 4 * (size_t)changed);
-                    const int tail = getenv("ZS_FR_TAIL_RANGE") ? atoi(getenv("ZS_FR_TAIL_RANGE")) : 1;
+                    const int tail = env_tail;
                     fr.range = std::min<int>(range_max, std::max<int>(tail, (int)((awake + 255) / 256)));
                 }
             }
             c->fast_rounds = r;
-            if (getenv("ZS_DEBUG")) fprintf(stderr, "zs: DeflateFast over %zu chunks of %d streams, up to %d to a workgroup: %d rounds (changed/range:%s)\n", nch, n, range_max, r, trace.c_str());
+            if (env_dbg) fprintf(stderr, "zs: DeflateFast over %zu chunks of %d streams, up to %d to a workgroup: %d rounds (changed/range:%s)\n", nch, n, range_max, r, trace.c_str());
             if (changed) {
                 // (cannot happen: chunk r of a stream is the reference's after round r at the latest.  Should it, the batch takes one
                 // workgroup per stream instead of failing the call)
@@ -946,12 +967,19 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
         int max_tiles = 0;
         for (int i = 0; i < n; i++)
             if (pl.sd[(size_t)i].rle_end >= 0) max_tiles = std::max(max_tiles, (pl.sd[(size_t)i].rle_end + kMaxMatch + 1 + 4095) / 4096);
-        const dim3 tg((unsigned)((max_tiles + 3) / 4), (unsigned)n);
-        hipLaunchKernelGGL(zs_rle_starts_kernel, tg, dim3(256), 0, stream, d_sd, rt);
+        // (a grid's y ends at 65 535: the tile kernels take the streams in slices)
+        auto tiles = [&](auto &&launch) {
+            for (int s0 = 0; s0 < n; s0 += 65535) launch(dim3((unsigned)((max_tiles + 3) / 4), (unsigned)std::min(n - s0, 65535)), s0);
+        };
+        tiles([&](dim3 tg, int s0) { hipLaunchKernelGGL(zs_rle_starts_kernel, tg, dim3(256), 0, stream, d_sd, rt, s0); });
         hipLaunchKernelGGL(zs_rle_scan_kernel, dim3((unsigned)n), dim3(1024), 0, stream, d_sd, rt);
-        hipLaunchKernelGGL(zs_rle_pass_kernel<0>, tg, dim3(256), 0, stream, d_sd, rt, dev<uint32_t>(c->syms), dev<int32_t>(c->blk_end), dev<int32_t>(c->blk_top));
+        tiles([&](dim3 tg, int s0) {
+            hipLaunchKernelGGL(zs_rle_pass_kernel<0>, tg, dim3(256), 0, stream, d_sd, rt, dev<uint32_t>(c->syms), dev<int32_t>(c->blk_end), dev<int32_t>(c->blk_top), s0);
+        });
         hipLaunchKernelGGL(zs_rle_sums_kernel, dim3((unsigned)n), dim3(1024), 0, stream, d_sd, d_st, rt);
-        hipLaunchKernelGGL(zs_rle_pass_kernel<1>, tg, dim3(256), 0, stream, d_sd, rt, dev<uint32_t>(c->syms), dev<int32_t>(c->blk_end), dev<int32_t>(c->blk_top));
+        tiles([&](dim3 tg, int s0) {
+            hipLaunchKernelGGL(zs_rle_pass_kernel<1>, tg, dim3(256), 0, stream, d_sd, rt, dev<uint32_t>(c->syms), dev<int32_t>(c->blk_end), dev<int32_t>(c->blk_top), s0);
+        });
     }
     // the engine is left for a later run, or took the block in progress over from one: it needs K5's symbols and block ends
     const bool tail_late = ro && (!ro->final_run || ro->resume);
@@ -1353,6 +1381,18 @@ void zs_ctx_set_profiling(zs_ctx *c, int enable) {
     if (c) c->profiling = enable != 0;
 }
 int zs_ctx_stage_count(const zs_ctx *) { return kStCount; }
+int64_t zs_ctx_counter(const zs_ctx *c, const char *name) {
+    if (!c || !name) return -1;
+    const std::string k(name);
+    if (k == "fast_rounds") return c->fast_rounds;        // rounds of the last call's DeflateFast over its chunks (0: a workgroup per stream)
+    if (k == "fast_fallbacks") return c->fast_fallbacks;  // speculative DeflateFast batches redone sequentially
+    if (k == "round_runs") return c->round_runs;          // batches with streams in the batched cut rounds
+    if (k == "cut_rounds") return c->cut_rounds;
+    if (k == "lit_fallbacks") return c->lit_fallbacks;    // batches run again with a stream on the literal engine
+    if (k == "lit_engine_bytes") return c->lit_engine_bytes;  // input bytes the one-wave literal engine has parsed (all calls)
+    return -1;
+}
+
 const char *zs_ctx_stage_name(const zs_ctx *c, int s) {
     static const char *const inf_names[6] = {"inf_find", "inf_measure", "inf_chain", "inf_decode", "inf_windows", "inf_resolve"};
     if (c && c->last_op == 1) return s >= 0 && s < 6 ? inf_names[s] : "";

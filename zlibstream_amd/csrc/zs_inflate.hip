@@ -450,7 +450,9 @@ __global__ __launch_bounds__(64) void zs_inflate_kernel(const InfDesc *descs, In
 done:
     __syncthreads();
     // a piece whose input ends inside a block (or inside the trailer): not an error, the piece ends in front of that block
-    if (d.partial && status == ZS_BUF_ && msg != kInfOutputFull) status = ZS_OK_, msg = kInfOk;
+    // a piece stops in front of the first block that is not complete -- or does not fit the output any more, as long as a
+    // block before it did (the caller takes the piece and comes again: a stream of any length in bounded memory)
+    if (d.partial && status == ZS_BUF_ && (msg != kInfOutputFull || good_out > pos0)) status = ZS_OK_, msg = kInfOk;
     if (pos > flushed) {
         if (pos - flushed > kInfRing / 2) flush_to(flushed + kInfRing / 2);
         flush_to(pos);

@@ -22,8 +22,10 @@ struct RleTiles {
 
 __device__ __forceinline__ int rle_ntiles(const StreamDesc &s) { return (s.rle_end + kMaxMatch + 1 + kRleTile - 1) / kRleTile; }
 
-__global__ __launch_bounds__(256) void zs_rle_starts_kernel(const StreamDesc *sd, RleTiles rt) {
-    const StreamDesc s = sd[blockIdx.y];
+// (a grid's y ends at 65 535: the host launches the streams in slices, si0 is the slice's first)
+__global__ __launch_bounds__(256) void zs_rle_starts_kernel(const StreamDesc *sd, RleTiles rt, int si0) {
+    const int si = si0 + (int)blockIdx.y;
+    const StreamDesc s = sd[si];
     if (s.rle_end < 0) return;
     const int tile = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6), lane = lane_id();
     if (tile >= rle_ntiles(s)) return;
@@ -36,7 +38,7 @@ __global__ __launch_bounds__(256) void zs_rle_starts_kernel(const StreamDesc *sd
         if (m) last = tile * kRleTile + it * 64 + 63 - (int)__builtin_clzll(m);
     }
     if (lane == 0) rt.last[s.rle_tile_off + tile] = last;
-    if (tile == 0 && lane == 0) rt.ph[blockIdx.y] = 0x7FFFFFFF;
+    if (tile == 0 && lane == 0) rt.ph[si] = 0x7FFFFFFF;
 }
 
 __global__ __launch_bounds__(1024) void zs_rle_scan_kernel(const StreamDesc *sd, RleTiles rt) {
@@ -65,8 +67,9 @@ __global__ __launch_bounds__(1024) void zs_rle_scan_kernel(const StreamDesc *sd,
 }
 
 template <int EMIT>
-__global__ __launch_bounds__(256) void zs_rle_pass_kernel(const StreamDesc *sd, RleTiles rt, uint32_t *syms, int32_t *blk_end, int32_t *blk_top) {
-    const StreamDesc s = sd[blockIdx.y];
+__global__ __launch_bounds__(256) void zs_rle_pass_kernel(const StreamDesc *sd, RleTiles rt, uint32_t *syms, int32_t *blk_end, int32_t *blk_top, int si0) {
+    const int si = si0 + (int)blockIdx.y;
+    const StreamDesc s = sd[si];
     if (s.rle_end < 0) return;
     const int tile = (int)blockIdx.x * 4 + (int)(threadIdx.x >> 6), lane = lane_id();
     if (tile >= rle_ntiles(s)) return;
@@ -114,7 +117,7 @@ __global__ __launch_bounds__(256) void zs_rle_pass_kernel(const StreamDesc *sd, 
         }
         const uint64_t body = __ballot(role != 0 && p < H);
         const uint64_t behind = __ballot(role != 0 && p >= H);
-        if (!EMIT && behind && lane == 0) atomicMin(&rt.ph[blockIdx.y], p0 + (int)__builtin_ctzll(behind));
+        if (!EMIT && behind && lane == 0) atomicMin(&rt.ph[si], p0 + (int)__builtin_ctzll(behind));
         if (EMIT && ((body >> lane) & 1ull)) {
             const int g = gbase + count + (int)__builtin_popcountll(body & lanemask_lt());
             out[g] = role == 1 ? (uint32_t)d0 : ((1u << 16) | (uint32_t)(role - kMinMatch));
