@@ -59,7 +59,7 @@ struct zs_ctx {
     double stage_ms[kStCount] = {};
     uint32_t *crc_tab = nullptr;
     DevBuf sd, st, work, wpre, geo, link, mm, maps, chunk_far, segmap, supmap, seg_entry, seg_symbase, seg_stale, entry, symbase, stale, syms, blk_end, blk_top, blocks, trees, info, pieces, scratch,
-        stage_in, stage_out, wr, inf_desc, inf_state, par_ps, par_st, par_work, par_cbits, par_ccnt, par_surv, par_scnt, par_cands, par_tabs, par_toktabs, par_toks, par_ctoks, par_tokstat, par_tails, par_blocks, par_cells,
+        stage_in, stage_out, wr, inf_desc, inf_state, par_ps, par_st, par_work, par_cbits, par_ccnt, par_surv, par_scnt, par_cands, par_tabs, par_toktabs, par_toks, par_ctoks, par_tokstat, par_tails, par_retry, par_blocks, par_cells,
         par_windows, par_fail, run_syms, run_bits, run_scratch, run_outs, run_fail, adl_tr, adl_res, plan_blk, ins_bits, mm_bak, cut_pos, cut_bkt, win_groups, win_sg, win_maps, win_entries, persist_bak, resume_flag, rle_tiles, own_in, fr_chunks, fr_meta, fr_planes, fr_prov, fr_base, fr_counters;
     bool resume_poisoned = false;  // a resumed run met a read the bulk form does not handle: the caller goes on with the literal engine
     void *pinned = nullptr;
@@ -1350,7 +1350,7 @@ void zs_ctx_destroy(zs_ctx *c) {
     (void)hipSetDevice(c->device);
     DevBuf *bufs[] = {&c->sd, &c->st, &c->work, &c->wpre, &c->geo, &c->link, &c->mm, &c->maps, &c->chunk_far, &c->segmap, &c->supmap, &c->seg_entry, &c->seg_symbase, &c->seg_stale, &c->entry, &c->symbase, &c->stale, &c->syms,
                       &c->blk_end, &c->blk_top, &c->blocks, &c->trees, &c->info, &c->pieces, &c->scratch, &c->stage_in, &c->stage_out, &c->wr, &c->inf_desc, &c->inf_state, &c->par_ps, &c->par_st, &c->par_work, &c->par_cbits, &c->par_ccnt, &c->par_surv, &c->par_scnt,
-                      &c->par_cands, &c->par_tabs, &c->par_toktabs, &c->par_toks, &c->par_ctoks, &c->par_tokstat, &c->par_tails, &c->par_blocks, &c->par_cells, &c->par_windows, &c->par_fail, &c->run_syms, &c->run_bits,
+                      &c->par_cands, &c->par_tabs, &c->par_toktabs, &c->par_toks, &c->par_ctoks, &c->par_tokstat, &c->par_tails, &c->par_retry, &c->par_blocks, &c->par_cells, &c->par_windows, &c->par_fail, &c->run_syms, &c->run_bits,
                       &c->run_scratch, &c->run_outs, &c->run_fail, &c->adl_tr, &c->adl_res, &c->plan_blk, &c->ins_bits, &c->mm_bak, &c->cut_pos, &c->cut_bkt, &c->win_groups, &c->win_sg, &c->win_maps, &c->win_entries, &c->persist_bak, &c->resume_flag, &c->rle_tiles, &c->own_in, &c->fr_chunks, &c->fr_meta, &c->fr_planes, &c->fr_prov, &c->fr_base, &c->fr_counters};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
@@ -1704,7 +1704,9 @@ bool run_inflate_par(zs_ctx *c, const std::vector<int> &idx, const void *const *
             if (!ensure(c, c->par_toktabs, sizeof(TokTabs) * w.size()) || !ensure(c, c->par_tabs, sizeof(LaneTabs) * w.size())) return false;
             // the tokens twice (the lanes' slabs, the blocks' lists); without room for them the blocks are decoded again lane by lane
             int mdbg = getenv("ZS_INF_MEASURE_DBG") ? atoi(getenv("ZS_INF_MEASURE_DBG")) : 0;
-            if (!ensure(c, c->par_toks, 4 * (size_t)tok_total + 64) || !ensure(c, c->par_ctoks, 4 * (size_t)tok_total + 64)) {
+            // (behind the slabs: room for the blocks that are measured a second time, zs_inf_tokretry_kernel)
+            const int64_t tok_reserve = c->inf_probe ? 0 : std::max<int64_t>(tok_total / 16, 2 << 20);
+            if (!ensure(c, c->par_toks, 4 * (size_t)(tok_total + tok_reserve) + 64) || !ensure(c, c->par_ctoks, 4 * (size_t)(tok_total + tok_reserve) + 64)) {
                 c->err.clear();
                 if (!ensure(c, c->par_toks, 64) || !ensure(c, c->par_ctoks, 64)) return false;
                 mdbg = 3;
@@ -1715,7 +1717,20 @@ bool run_inflate_par(zs_ctx *c, const std::vector<int> &idx, const void *const *
                 stats = (int32_t *)((uint8_t *)c->par_tokstat.p + 16);
             }
             hipLaunchKernelGGL(zs_inf_measure_tok_kernel, dim3((unsigned)w.size()), dim3(64), 0, stream, d_ps, d_st, dev<uint2>(c->par_work),
-                               dev<ParCand>(c->par_cands), dev<TokTabs>(c->par_toktabs), dev<LaneTabs>(c->par_tabs), dev<uint32_t>(c->par_toks), dev<uint32_t>(c->par_ctoks), dev<uint32_t>(c->par_tails), stats, mdbg);
+                               dev<ParCand>(c->par_cands), dev<TokTabs>(c->par_toktabs), dev<LaneTabs>(c->par_tabs), dev<uint32_t>(c->par_toks), dev<uint32_t>(c->par_ctoks), dev<uint32_t>(c->par_tails), stats, mdbg, nullptr, nullptr);
+            if (mdbg != 3 && !c->inf_probe) {
+                // blocks measured without room for their tokens: once more, with room for their known length
+                if (!ensure(c, c->par_retry, 4 * (size_t)kTokRetryMax + 64)) return false;
+                uint8_t *rb = (uint8_t *)c->par_retry.p;
+                unsigned long long *d_cursor = (unsigned long long *)(rb + 4 * (size_t)kTokRetryMax);
+                int32_t *d_rcnt = (int32_t *)(rb + 4 * (size_t)kTokRetryMax + 8);
+                ZS_HIP(c, hipMemsetAsync(d_cursor, 0, 16, stream));
+                hipLaunchKernelGGL(zs_inf_tokretry_kernel, dim3((unsigned)((w.size() + 255) / 256)), dim3(256), 0, stream, d_ps, dev<uint2>(c->par_work), (int)w.size(),
+                                   dev<ParCand>(c->par_cands), tok_total, tok_reserve, d_cursor, d_rcnt, (int32_t *)rb);
+                hipLaunchKernelGGL(zs_inf_measure_tok_kernel, dim3((unsigned)std::min<size_t>(w.size(), (size_t)kTokRetryMax)), dim3(64), 0, stream, d_ps, d_st,
+                                   dev<uint2>(c->par_work), dev<ParCand>(c->par_cands), dev<TokTabs>(c->par_toktabs), dev<LaneTabs>(c->par_tabs), dev<uint32_t>(c->par_toks),
+                                   dev<uint32_t>(c->par_ctoks), dev<uint32_t>(c->par_tails), (int32_t *)nullptr, mdbg, d_rcnt, (int32_t *)rb);
+            }
             if (stats) {
                 int32_t hs[4] = {0, 0, 0, 0};
                 ZS_HIP(c, hipMemcpyAsync(hs, stats, 16, hipMemcpyDeviceToHost, stream));

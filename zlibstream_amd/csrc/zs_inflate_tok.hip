@@ -213,6 +213,31 @@ __global__ __launch_bounds__(64) void zs_inf_tails_kernel(const ParStream *ps, u
     tails[(int64_t)blockIdx.x * kSbTailBuf + threadIdx.x] = (int)threadIdx.x < kSbTail && q >= 0 && s.in_len > 0 ? base[q] : 0u;
 }
 
+// A block that was measured but whose tokens found no room -- its decode ran past the next candidate, a header-like bit pattern
+// inside it -- is measured once more with a slab for what is now known to be its length (the lane decoder took ~1 ms for one
+// such block per stream: one wave, one block).  One thread per candidate: room from a reserve behind the slabs, the candidate
+// into the list of the second launch.
+constexpr int kTokRetryMax = 1024;
+__global__ __launch_bounds__(256) void zs_inf_tokretry_kernel(const ParStream *ps, const uint2 *work, int nwork, ParCand *cands, int64_t reserve_off, int64_t reserve_cap,
+                                                              unsigned long long *cursor, int32_t *retry_cnt, int32_t *retry_list) {
+    const int wi = blockIdx.x * 256 + threadIdx.x;
+    if (wi >= nwork) return;
+    const uint2 w = work[wi];
+    ParCand &c = cands[ps[w.x].cand_off + w.y];
+    if (!c.ok || c.tab < 0 || (c.tab & kTabTok)) return;
+    const int64_t span = c.end_bit - c.bit;
+    if (span <= 0) return;
+    const int S = tok_sub_bits(span);
+    const int64_t nsub = (span + S - 1) / S + 1, need = nsub <= kCkMax ? nsub * tok_unit(S) : 0;
+    if (!need) return;
+    const int64_t off = (int64_t)atomicAdd(cursor, (unsigned long long)need);
+    if (off + need > reserve_cap) return;
+    const int at = atomicAdd(retry_cnt, 1);
+    if (at >= kTokRetryMax) return;
+    c.tok_off = reserve_off + off, c.tok_cap = (int32_t)need;
+    retry_list[at] = wi;
+}
+
 struct TokW {  // a lane's token writer: four tokens leave as one 16-byte store
     uint32_t *base;
     int n, cap;  // tokens put; room (a multiple of 4; 0: nothing is stored)
@@ -370,10 +395,15 @@ struct TokLds {
 };
 
 __global__ __launch_bounds__(64) void zs_inf_measure_tok_kernel(const ParStream *ps, const ParState *st, const uint2 *work, ParCand *cands, TokTabs *tabs,
-                                                                LaneTabs *ltabs, uint32_t *toks, uint32_t *ctoks, const uint32_t *tails, int32_t *stats, int dbg) {
+                                                                LaneTabs *ltabs, uint32_t *toks, uint32_t *ctoks, const uint32_t *tails, int32_t *stats, int dbg,
+                                                                const int32_t *retry_cnt, const int32_t *retry_list) {
     __shared__ __attribute__((aligned(16))) TokLds M;
     ParLds &L = M.L;
-    const uint2 w = work[blockIdx.x];
+    // (the second launch: the blocks of the retry list, each with its known end for a hint)
+    const bool retry = retry_list != nullptr;
+    if (retry && (int)blockIdx.x >= (*retry_cnt < kTokRetryMax ? *retry_cnt : kTokRetryMax)) return;
+    const int wi = retry ? retry_list[blockIdx.x] : (int)blockIdx.x;
+    const uint2 w = work[wi];
     const ParStream s = ps[w.x];
     const int ncand = st[w.x].ncand;
     if ((int)w.y >= ncand) return;
@@ -386,6 +416,7 @@ __global__ __launch_bounds__(64) void zs_inf_measure_tok_kernel(const ParStream 
     }
     // the block most likely ends where the next candidate begins (candidate bits are final since the flatten pass)
     int64_t hint = (int)w.y + 1 < ncand ? cands[s.cand_off + w.y + 1].bit : nbits;
+    if (retry) hint = c.end_bit;
     if (hint <= cbit || hint > nbits) hint = nbits;
     InfBits hb{s.in, s.in_len, 0, 0, 0, false, L.ibuf, -1};
     inf_seek(hb, cbit);
@@ -416,8 +447,8 @@ __global__ __launch_bounds__(64) void zs_inf_measure_tok_kernel(const ParStream 
     const int64_t tok_off = c.tok_off;
     const int tok_cap = c.tok_cap;
     const __attribute__((address_space(1))) uint8_t *gin = (const __attribute__((address_space(1))) uint8_t *)(uintptr_t)s.in;
-    TokTabs &T = tabs[blockIdx.x];
-    LaneTabs &LT = ltabs[blockIdx.x];  // checkpoints and tables: a block whose tokens found no room is decoded again lane by lane
+    TokTabs &T = tabs[wi];
+    LaneTabs &LT = ltabs[wi];  // checkpoints and tables: a block whose tokens found no room is decoded again lane by lane
     uint32_t *bnd = M.bnd + lane;
     SyncBits sbits;
     sbits.init(gin, s.in_len, tails + (int64_t)w.x * kSbTailBuf, M.win + lane);
@@ -550,13 +581,13 @@ __global__ __launch_bounds__(64) void zs_inf_measure_tok_kernel(const ParStream 
             LT.ck_bit[nck] = (uint32_t)(end_bit - cbit);
             LT.ck_out[nck] = (uint32_t)out_base;
             LT.nsub = nck;
-            c.tab = (int32_t)blockIdx.x;
+            c.tab = (int32_t)wi;
         }
     }
     if (lane == 0) {
         if (store) {
             T.tok_off = tok_off, T.ntok = (uint32_t)total_syms, T.pad_ = 0;
-            c.tab = (int32_t)blockIdx.x | kTabTok;
+            c.tab = (int32_t)wi | kTabTok;
         }
         c.end_bit = end_bit;
         c.out_bytes = out_base;
