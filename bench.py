@@ -265,9 +265,9 @@ class DeviceBatch:
 
 
 # stages of an inflate call that are several launches: the kernels whose time and HBM traffic the stage's figures sum
-INFLATE_STAGE_KERNELS = {"inf_decode": ["zs_inf_decode_lane_kernel", "zs_inf_cellflat_kernel", "zs_inf_decode_kernel"],
+INFLATE_STAGE_KERNELS = {"inf_decode": ["zs_inf_expand_kernel", "zs_inf_decode_lane_kernel", "zs_inf_cellflat_kernel", "zs_inf_decode_kernel"],
                          "inf_find": ["zs_inf_prefilter_kernel", "zs_inf_check_kernel", "zs_inf_flatten_kernel"],
-                         "inf_measure": ["zs_inf_measure_sync_kernel"], "inf_resolve": ["zs_inf_resolve_kernel"],
+                         "inf_measure": ["zs_inf_measure_tok_kernel"], "inf_resolve": ["zs_inf_resolve_kernel"],
                          "inf_windows": ["zs_inf_window_kernel", "zs_inf_winchain_kernel"],
                          "inf_chain": ["zs_inf_chain_par_kernel", "zs_inf_chain_kernel"]}
 
@@ -301,6 +301,11 @@ def pmc_stage(stage_ms, tag):
     return pmc_traffic(MULTI_LAUNCH_STAGES.get(dom, "zs_%s_kernel" % dom), tag)
 
 
+def roofline_with_pmc(stage_ms, alg_bytes, pmc_tag):
+    traffic, source = pmc_stage(stage_ms, pmc_tag) if pmc_tag else (None, None)
+    return roofline(stage_ms, alg_bytes, traffic=traffic, source=source)
+
+
 def secondary_deflate(eng, dev, name, datas, level, steps, check_every=1, strategy=0, pmc_tag=None):
     b = DeviceBatch(eng, dev, datas, strategy)
     dt, stage_ms = b.timed(level, steps, 1)
@@ -308,7 +313,7 @@ def secondary_deflate(eng, dev, name, datas, level, steps, check_every=1, strate
     total_out = sum(b.out_lens)
     res = {"workload": name, "level": level, "buffers": len(datas), "input_bytes": b.n, "compressed_bytes": total_out,
            "value": round(b.n * steps / dt / 1e6, 2), "unit": "MB/s", "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps,
-           "roundtrip": True, "roofline": roofline(stage_ms, b.n + total_out, *(pmc_stage(stage_ms, pmc_tag) if pmc_tag else (None, None))),
+           "roundtrip": True, "roofline": roofline_with_pmc(stage_ms, b.n + total_out, pmc_tag),
            "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()}}
     return res, b
 
@@ -629,9 +634,8 @@ def main():
             "config": {"workload": wl, "level": args.level, "buffer_bytes": len(datas[0]) if datas else 0, "buffers_per_gpu": len(datas),
                        "compressed_bytes": total_out, "input_bytes_per_rank": per_rank_bytes,
                        "parallelism": "independent buffers, %d GPU(s), no collective in the data path" % world},
-            "roofline": roofline(stage_ms, n + sum(main_batch.out_lens),
-                                 *(pmc_stage(stage_ms, "traffic_english64_L6")
-                                   if workload == "english64" and args.level == 6 and args.size == 64 << 20 else (None, None))),
+            "roofline": roofline_with_pmc(stage_ms, n + sum(main_batch.out_lens),
+                                          "traffic_english64_L6" if workload == "english64" and args.level == 6 and args.size == 64 << 20 else None),
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
         }
         if shard_note:

@@ -59,6 +59,8 @@ def test_traffic_names_its_source():
     assert b and src.startswith("profiles/") and src.endswith("pmc_traffic_english64_L6.json")
     r = m.roofline({"match": 2.7, "links": 0.3}, 94534690, b, None, src)
     assert r["traffic_source"] == src and r["scope"] == "kernel"
+    r = m.roofline_with_pmc({"match": 2.7, "links": 0.3}, 94534690, "traffic_english64_L6")
+    assert r["kernel"] == "zs_match_kernel" and r["traffic_source"] == src and r["traffic"] == b
     # the rounds of the chunk form are a stage of many launches, and say so
     b, src = m.pmc_traffic("zs_fast_sweep_kernel", "fast64_L1")
     r = m.roofline({"fast_sweep": 46.6, "links": 0.3}, 97620422, b, None, src)

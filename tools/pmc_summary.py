@@ -176,7 +176,7 @@ for name, out in (("flush_resume.log", "flush_resume.log"), ("patho.jsonl", "pat
     if os.path.exists(pth) and os.path.getsize(pth) > 0:
         shutil.copy(pth, os.path.join(dst, "%s_%s" % (tag, out)))
 
-for name, out in (("bench_default.json", "bench_default.json"), ("bench_english64.json", "bench_english64_L6.json"), ("bench_sparse64.json", "bench_sparse64_L6.json"),
+for name, out in (("bench_default.json", "bench_default.json"), ("bench_full.json", "bench_full.json"), ("bench_english64.json", "bench_english64_L6.json"), ("bench_sparse64.json", "bench_sparse64_L6.json"),
                   ("bench_batch128.json", "bench_batch128x1MiB_L6.json"), ("bench_inflate.json", "bench_inflate1g.json"),
                   ("time_levels.jsonl", "time_levels.jsonl"), ("host_path.jsonl", "host_path.jsonl"),
                   ("bench_english64_pipelined.json", "bench_english64_L6_pipelined3.json"),

@@ -13,6 +13,7 @@ cd /tmp && export TMPDIR=/tmp
 if [ "$PART" = main ]; then
 rm -rf "$O"; mkdir -p "$O"
 python3 $R/bench.py --steps 10 --warmup 2 > $O/bench_default.json 2> $O/bench_default.err
+cp $R/bench_secondary.json $O/bench_full.json  # (the stdout line is the compact one; the full report is a file)
 echo "bench default done"
 python3 $R/bench.py --steps 9 --warmup 2 --no-cpu-baseline --no-secondary --inflight 3 > $O/bench_english64_pipelined.json 2> $O/bench_english64_pipelined.err
 python3 $R/tools/time_levels.py > $O/time_levels.jsonl 2> $O/time_levels.err
