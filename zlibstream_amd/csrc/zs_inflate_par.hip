@@ -534,10 +534,13 @@ __device__ bool find_check_header(const __attribute__((address_space(1))) uint8_
 __global__ __launch_bounds__(256) void zs_inf_prefilter_kernel(const ParStream *ps, const uint2 *work, int32_t *surv_g, int32_t *surv_cnt) {
     __shared__ int nsurv;
     __shared__ int32_t surv[kFindMaxSurv];  // bit offsets (chunk-relative) that passed the register prefilter
+    __shared__ uint8_t kraft9[512];  // entry i: the Kraft weights (128 >> v, 0 for v = 0) of the three 3-bit fields of i
     const uint2 w = work[blockIdx.x];
     const ParStream s = ps[w.x];
     const int chunk = (int)w.y;
     if (threadIdx.x == 0) nsurv = 0;
+    for (int i = threadIdx.x; i < 512; i += 256)
+        kraft9[i] = (uint8_t)(((0x80u >> (i & 7)) & 0x7Fu) + ((0x80u >> ((i >> 3) & 7)) & 0x7Fu) + ((0x80u >> (i >> 6)) & 0x7Fu));
     __syncthreads();
     // the thread's 16 bytes plus the 16 that follow, as four 64-bit words (zero past the end of the stream)
     const int64_t byte0 = (int64_t)chunk * kFindChunk + (int64_t)threadIdx.x * 16;
@@ -582,11 +585,10 @@ __global__ __launch_bounds__(256) void zs_inf_prefilter_kernel(const ParStream *
             const int nb = 3 * ncode;
             g0 = nb < 30 ? g0 & ((1u << nb) - 1u) : g0;
             g1 = nb <= 30 ? 0u : g1 & ((1u << (nb - 30)) - 1u);
-            int kraft = 0;  // units of 2^-7: a length v > 0 adds 128 >> v, which is (128 >> v) & 127 for every v
-#pragma unroll
-            for (int i = 0; i < 10; i++) kraft += (int)((0x80u >> ((g0 >> (3 * i)) & 7)) & 0x7Fu);
-#pragma unroll
-            for (int i = 0; i < 9; i++) kraft += (int)((0x80u >> ((g1 >> (3 * i)) & 7)) & 0x7Fu);
+            // units of 2^-7: a length v > 0 adds 128 >> v.  Three fields a lookup (a 512-entry table in LDS; field by field the sum was
+            // 95 of the trip's ~110 vector instructions, and a fifth of all bit offsets take this trip)
+            const int kraft = (int)kraft9[g0 & 511u] + (int)kraft9[(g0 >> 9) & 511u] + (int)kraft9[(g0 >> 18) & 511u] + (int)kraft9[(g0 >> 27) & 7u] +
+                              (int)kraft9[g1 & 511u] + (int)kraft9[(g1 >> 9) & 511u] + (int)kraft9[g1 >> 18];
             if (kraft != 128) continue;
             int at = atomicAdd(&nsurv, 1);
             if (at < kFindMaxSurv) surv[at] = (int32_t)(base + r - (int64_t)chunk * kFindChunk * 8);
