@@ -1320,3 +1320,48 @@ print("pieces ok")
     env = dict(os.environ, ZS_INF_PIECE_BYTES="20000")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "pieces ok" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
+
+
+@pytest.mark.gpu
+def test_runs_behind_a_flush_at_the_fast_levels_take_the_sweeps(engine, oracle, rate_floors):
+    """Levels 1-3 (DeflateFast, Deflate.Fast.cs:20-128) behind a flush (Deflate.cs:583-613): until round 5 every run of such a
+    stream was the one-wave literal engine's (0.5-2 MB/s -- ImageSharp's default is a fast level).  A run of one Write that begins
+    where a flush left the engine now starts the sweeps' stream form at that position: the links below it are the suspended
+    engine's prev[] (zs_import_chains_kernel: DeflateFast's chains hold inserted positions only, so they ARE the compressed
+    links), the set below it "inserted" wherever the chains reach, the first read an event like any other.  Random schedules
+    over four kinds of data, flushes around window ends, every flush mode; the literal engine's share by zs_ctx_counter."""
+    import time
+    text = datagen.english(3 << 20, datagen.GOLDEN + 5)
+    rng = np.random.default_rng(77)
+    low = rng.choice(np.array([0, 0, 0, 0, 1, 2, 255], dtype=np.uint8), 2 << 20).tobytes()
+    rnd = rng.integers(0, 256, 1 << 20, dtype=np.uint8).tobytes()
+    runs = np.repeat(rng.integers(0, 256, 40000, dtype=np.uint8), rng.integers(1, 90, 40000))[:2 << 20].tobytes()
+    img = datagen.sparse(512, 512)
+    cases = []
+    for data, level in ((text, 1), (text, 2), (text, 3), (low, 1), (rnd, 2), (runs, 3), (img, 1), (bytes(1 << 20), 2), (low, 3), (runs, 1)):
+        sizes, fl, o = [], [], 0
+        while o < min(len(data), 1536 << 10):
+            c = int(rng.choice([6144, 7000, 8192, 20000, 32768, 50000, 65536, 100000, 150000, 262144, 300, 40]))
+            c = min(c, len(data) - o)
+            sizes.append(c), fl.append(int(rng.choice([1, 2, 2, 2, 3, 0])))
+            o += c
+        cases.append((data[:o], sizes, fl, level))
+    for k in (1, 5, 100, 261, 262, 263):  # flushes that leave the window to slide before it is full, runs behind them
+        cases.append((text, [65536 - k, 7000, 9000, 32768 - 7000 - 9000 + k - 3, 8000, 50000], [2, 2, 1, 3, 2, 2], 1))
+        cases.append((low, [98304 - k, 6500, 40000, 6200], [3, 2, 2, 0], 3))
+    for data, sizes, fl, level in cases:
+        data = data[:sum(sizes)]
+        z = _flushed_stream(engine, data, sizes, fl, level)
+        assert zlib.decompress(z) == data, (len(data), sizes[:8], fl[:8], level)
+        assert z == oracle.compress_writes(data, level, 0, sizes, fl), (len(data), sizes[:8], fl[:8], level)
+    # a Sync flush behind every 256 KiB Write at level 1: the literal engine parses the runs' last 261 bytes and nothing else
+    sizes = [262144] * 12
+    before = engine.counter("lit_engine_bytes")
+    _flushed_stream(engine, text, sizes, [2] * 12, 1)
+    t0 = time.perf_counter()
+    z = _flushed_stream(engine, text, sizes, [2] * 12, 1)
+    dt = time.perf_counter() - t0
+    assert z == oracle.compress_writes(text[:sum(sizes)], 1, 0, sizes, [2] * 12)
+    lit = engine.counter("lit_engine_bytes") - before
+    assert lit <= 4096, "%d bytes of two 3 MiB streams went through the literal engine beyond the runs' last 261" % lit
+    rate_floors.check(sum(sizes) / dt >= 20e6, "level 1, a Sync flush behind every 256 KiB: %.1f ms = %.1f MB/s" % (dt * 1e3, sum(sizes) / dt / 1e6))

@@ -182,6 +182,7 @@ struct WriteSpec {
 // holds absolute ends.
 struct RunOpts {
     bool final_run = true, cont = false;
+    int64_t hist = 0;  // leading bytes of the buffer that earlier runs have parsed (history: up to 64 KiB)
     LitPersist *persist = nullptr;
     int64_t abs_off = 0;
     uint32_t adler_stream = 1, carry_byte = 0;
@@ -270,13 +271,22 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
         // bytes does not)
         const bool fast_multi = multi && !flushing && !cont && !ro && lv.func == 1 && strategy != kRle && !getenv("ZS_NO_FAST_MULTI") &&
                                 build_read_events(len, writes->ends, rev, true);
-        const bool regular = cont ? false : multi ? fast_multi : build_read_events(len, std::vector<int64_t>(one_write, one_write + 1), rev);
+        // levels 1-3 behind a flush (round 5): the run goes on from the suspended engine's chains too -- zs_import_chains_kernel's
+        // links ARE DeflateFast's chains for the history (prev[] names inserted positions only), so with "inserted" for every
+        // position the chains reach, the sweeps start at p0 as they start at 0; one Write, the engine standing at the flush
+        const bool fast_resume = resume && ro->at_read && lv.func == 1 && strategy != kRle && !multi && !inner_flush && !lit_forced && !getenv("ZS_NO_FAST_RESUME") &&
+                                 len - ro->p0 >= 2 * kMinLookahead &&
+                                 build_read_events(len, std::vector<int64_t>(one_write, one_write + 1), rev, true, ro->p0, ro->base0);
+        const bool regular = fast_resume ? true : cont ? false : multi ? fast_multi : build_read_events(len, std::vector<int64_t>(one_write, one_write + 1), rev);
         s.body_end = slow_ok ? (int32_t)geo.body_end : -1;
         // levels 1-3, one Write: the speculative chunk runs for large streams (they verify on periodic data and are parallel
         // inside a stream), else -- and when they did not verify (force_seq) -- DeflateFast for the lanes of a wave
-        const bool fast_one = lv.func == 1 && strategy != kRle && (!multi || fast_multi) && !flushing && final_run && !ro && regular && len >= kMinLookahead;
-        const bool fast_par = fast_one && !multi && !force_seq && len >= kFastMinInput;
-        s.fv_end = (fast_one && !fast_par && !getenv("ZS_NO_FAST_VEC")) ? (int32_t)(len - kMinLookahead) : -1;
+        // (round 5: also the first run of a stream that flushes -- one Write, the flush at its end: the tail engine closes the
+        // block and is left suspended as it is behind the slow levels' bulk runs)
+        const bool fast_one = lv.func == 1 && strategy != kRle && regular && len >= kMinLookahead && !cont && !resume &&
+                              ((!flushing && final_run && !ro && (!multi || fast_multi)) || (ro && !multi && !inner_flush && !lit_forced && !getenv("ZS_NO_FAST_RESUME")));
+        const bool fast_par = fast_one && !multi && !force_seq && !ro && len >= kFastMinInput;
+        s.fv_end = ((fast_one && !fast_par && !getenv("ZS_NO_FAST_VEC")) || fast_resume) ? (int32_t)(len - kMinLookahead) : -1;
         s.ins_bits = nullptr;
         if (s.fv_end >= 0) {
             pl.any_fv = true;
@@ -296,8 +306,8 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
         s.wr_end = nullptr;
         s.wr_flush = nullptr, s.wr_blk = nullptr, s.out_chunk = writes ? writes->chunk : 512, s.raw = writes && writes->raw;
         s.kl = num_refills(len - (resume ? ro->base0 : 0));
-        s.resume = resume && slow_ok ? 1 : 0, s.cont_bits = (cont || resume) ? 1 : 0, s.mid_write = (ro && (ro->mid_write || (resume && !ro->at_read))) ? 1 : 0;
-        if (resume && !slow_ok) {
+        s.resume = resume && (slow_ok || fast_resume) ? 1 : 0, s.cont_bits = (cont || resume) ? 1 : 0, s.mid_write = (ro && (ro->mid_write || (resume && !ro->at_read))) ? 1 : 0;
+        if (resume && !slow_ok && !fast_resume) {
             c->err = "the run cannot go on in the bulk pipeline from where the literal engine stopped";
             return false;
         }
@@ -335,9 +345,15 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
             pl.cstart.insert(pl.cstart.end(), geo.cstart.begin(), geo.cstart.end());
             pl.head.insert(pl.head.end(), geo.head.begin(), geo.head.end());
         } else {
+            if (fast_resume) {  // segment 0: the engine as the flush left it -- the data ends at p0, so the first event fires at the run's first loop-top
+                // (an event's trigger is the data end before it - 261, and a negative one means "none": p0 below 261 counts as 261)
+                pl.seg_c0.push_back(0), pl.seg_after.push_back((int32_t)std::max<int64_t>(ro->p0, kMinLookahead - 1)), pl.seg_base.push_back((int32_t)ro->base0);
+                pl.seg_S.push_back(0), pl.seg_cl.push_back((int32_t)pl.cl.size());
+                s.nsegs++;
+            }
             if (s.fv_end >= 0 || s.rle_end >= 0)  // levels 1-3, Rle: the events of the single Write (the tail engine takes base and data end from them)
                 for (size_t k = 0; k < rev.size(); k++) {
-                    const int64_t at = k ? rev[k].at - (s.rle_end >= 0 ? kMaxMatch : kMinLookahead - 1) : 0;  // where the segment starts
+                    const int64_t at = (k || fast_resume) ? rev[k].at - (s.rle_end >= 0 ? kMaxMatch : kMinLookahead - 1) : 0;  // where the segment starts
                     if (at > (s.rle_end >= 0 ? s.rle_end : s.fv_end)) break;
                     pl.seg_c0.push_back(0), pl.seg_after.push_back((int32_t)rev[k].after), pl.seg_base.push_back((int32_t)rev[k].base);
                     pl.seg_S.push_back(0), pl.seg_cl.push_back((int32_t)pl.cl.size());
@@ -397,7 +413,7 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
         pl.w_blocks.add(i, s.max_blocks);
         // what none of the parallel forms takes is the one-wave literal engine's: the whole run, not just its last 261 bytes
         if (s.body_end < 0 && s.fv_end < 0 && s.rle_end < 0 && s.fast_runs == 0 && s.plan_nblk == 0 && !(level == 0 && strategy != kRle && !ro)) {
-            const int64_t from = resume ? ro->p0 : (ro && cont) ? 0 : 0;
+            const int64_t from = resume ? ro->p0 : ro ? ro->hist : 0;
             pl.lit_bytes += std::max<int64_t>(0, len - from - (kMinLookahead - 1));
         }
     }
@@ -405,7 +421,7 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
     c->fast_rounds = 0;
     const bool no_rounds_this_call = c->no_rounds_once;
     c->no_rounds_once = false;
-    if (pl.any_fv && !getenv("ZS_FAST_NO_ROUNDS") && !no_rounds_this_call) {
+    if (pl.any_fv && !getenv("ZS_FAST_NO_ROUNDS") && !no_rounds_this_call && !(ro && ro->resume)) {  // (a resumed run: the stream form, from p0)
         // levels 1-3: every stream's parse as rounds over its chunks, all chunks of the batch at once (zs_fast_sweep.h "Rounds"),
         // when that is the shorter way.  One workgroup per stream takes as long as the longest stream at 46 / 35 / 20 MB/s (levels
         // 1 / 2 / 3 on text; kennedy.xls and ptt5 are slower).  The rounds take the whole batch through the chip at ~3.5 GB/s a few
@@ -596,6 +612,12 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
         if (blocks > 2048) blocks = 2048;
         if (blocks < 1) blocks = 1;
         hipLaunchKernelGGL(zs_zero_kernel, dim3(blocks), dim3(256), 0, stream, z);
+        if (ro && ro->resume && pl.sd[0].fv_end >= 0) {
+            // a resumed run at levels 1-3: below p0 the set is what the suspended engine's chains contain -- every position they
+            // reach is in it (and no walk meets another one): all ones
+            const int64_t lo = std::max<int64_t>(0, ro->p0 - kWSize - 64) / 32 * 4, hi = (ro->p0 / 32 + 1) * 4;
+            ZS_HIP(c, hipMemsetAsync((uint8_t *)pl.sd[0].ins_bits + lo, 0xFF, (size_t)(hi - lo), stream));
+        }
     }
 
     const StreamDesc *d_sd = dev<StreamDesc>(c->sd);

@@ -152,7 +152,7 @@ __global__ __launch_bounds__(NT) void zs_fast_sweep_kernel(const StreamDesc *sd,
     __shared__ int32_t pE[64], pCut[64];
     __shared__ uint32_t pOff[64];
     __shared__ int32_t pvar[4];  // [0] chunks in reach, [1] something changed, [2] where the chunk before left
-    int E0 = 0, np = 0, cut_ev = -1, preins_ev = -1;
+    int E0 = CH ? 0 : (int)s.start_pos, np = 0, cut_ev = -1, preins_ev = -1;  // (the stream form of a resumed run begins where the flush left the engine)
     const FsMeta *mp = nullptr;
     FsMeta *mn = nullptr;
     if constexpr (CH) {
