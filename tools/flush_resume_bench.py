@@ -33,15 +33,20 @@ def run(data, writes, flushes, level=6, chunk=1 << 26):
     L.zs_deflate_end(z)
     return bytes(res), times
 text = datagen.english(64 << 20, datagen.GOLDEN)
+LEVEL = int(sys.argv[1]) if len(sys.argv) > 1 else 6  # (levels 1-3: DeflateFast behind a flush, the sweeps since round 5)
+if LEVEL != 6:
+    print("== level %d" % LEVEL)
 for name, writes, flushes in (("sync flush after 4 KiB, then one 64 MiB Write", [4096, (64 << 20) - 4096], [2, 0]),
                               ("full flush after 1 MiB, then 63 MiB in 1 MiB Writes", [1 << 20] * 64, [3] + [0] * 63),
                               ("a Sync flush behind every 1 MiB Write", [1 << 20] * 64, [2] * 64),
                               ("a Sync flush behind every 64 KiB Write", [65536] * 1024, [2] * 1024),
                               ("a Sync flush behind every 8 KiB Write (8 MiB)", [8192] * 1024, [2] * 1024),
                               ("no flush, one Write (the fast path, for comparison)", [64 << 20], [0])):
+    if LEVEL != 6 and len(writes) > 100 and sum(writes) > (8 << 20):
+        writes, flushes = writes[:128], flushes[:128]  # (8 MiB of the 64 KiB case at the fast levels)
     data = text[:sum(writes)]
-    run(data, writes, flushes)
-    z, times = run(data, writes, flushes)
+    run(data, writes, flushes, LEVEL)
+    z, times = run(data, writes, flushes, LEVEL)
     ok = zlib.decompress(z) == data
     part = data[:6 << 20]
     pw, pf, o = [], [], 0
@@ -52,8 +57,8 @@ for name, writes, flushes in (("sync flush after 4 KiB, then one 64 MiB Write", 
             o += w
     # (the reference's bytes are those of ZlibOutputStream.WriteCore's loop with its 512-byte chunk: a flush whose output
     # does not fit one chunk is entered again and leaves another empty block)
-    zp, _ = run(part, pw, pf, chunk=512)
-    exact = zp == orc.compress_writes(part, 6, 0, pw, pf)
+    zp, _ = run(part, pw, pf, LEVEL, chunk=512)
+    exact = zp == orc.compress_writes(part, LEVEL, 0, pw, pf)
     behind = sum(times[1:]) if len(writes) > 1 else sum(times)  # (one Write: the whole stream)
     print("%-58s roundtrip %s, first 6 MiB (512-byte chunks) exact %s; calls behind the first Write: %.1f ms = %.2f GB/s (host memory in, host memory out)"
           % (name, ok, exact, behind * 1e3, (len(data) - writes[0]) / behind / 1e9 if len(writes) > 1 else len(data) / sum(times) / 1e9), flush=True)

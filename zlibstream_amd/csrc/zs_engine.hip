@@ -269,14 +269,17 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
         // levels 1-3 take several NoFlush Writes too when every read brings a full lookahead and no Write ends where its loop-top
         // may or may not slide the window (zs_core.h build_read_events: Stream.CopyTo's 81 920-byte Writes do; a Write every few
         // bytes does not)
-        const bool fast_multi = multi && !flushing && !cont && !ro && lv.func == 1 && strategy != kRle && !getenv("ZS_NO_FAST_MULTI") &&
+        const bool fast_multi = multi && !inner_flush && !cont && !resume && lv.func == 1 && strategy != kRle && !getenv("ZS_NO_FAST_MULTI") &&
                                 build_read_events(len, writes->ends, rev, true);
         // levels 1-3 behind a flush (round 5): the run goes on from the suspended engine's chains too -- zs_import_chains_kernel's
         // links ARE DeflateFast's chains for the history (prev[] names inserted positions only), so with "inserted" for every
         // position the chains reach, the sweeps start at p0 as they start at 0; one Write, the engine standing at the flush
-        const bool fast_resume = resume && ro->at_read && lv.func == 1 && strategy != kRle && !multi && !inner_flush && !lit_forced && !getenv("ZS_NO_FAST_RESUME") &&
+        // (several NoFlush Writes behind the flush as well, on the conditions of a stream's several Writes: every read brings a
+        // full lookahead, no Write ends where its loop-top may or may not slide the window)
+        const bool fast_resume = resume && ro->at_read && lv.func == 1 && strategy != kRle && !inner_flush && !lit_forced && !getenv("ZS_NO_FAST_RESUME") &&
                                  len - ro->p0 >= 2 * kMinLookahead &&
-                                 build_read_events(len, std::vector<int64_t>(one_write, one_write + 1), rev, true, ro->p0, ro->base0);
+                                 (multi ? build_read_events(len, writes->ends, rev, true, ro->p0, ro->base0)
+                                        : build_read_events(len, std::vector<int64_t>(one_write, one_write + 1), rev, true, ro->p0, ro->base0));
         const bool regular = fast_resume ? true : cont ? false : multi ? fast_multi : build_read_events(len, std::vector<int64_t>(one_write, one_write + 1), rev);
         s.body_end = slow_ok ? (int32_t)geo.body_end : -1;
         // levels 1-3, one Write: the speculative chunk runs for large streams (they verify on periodic data and are parallel
@@ -284,7 +287,7 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
         // (round 5: also the first run of a stream that flushes -- one Write, the flush at its end: the tail engine closes the
         // block and is left suspended as it is behind the slow levels' bulk runs)
         const bool fast_one = lv.func == 1 && strategy != kRle && regular && len >= kMinLookahead && !cont && !resume &&
-                              ((!flushing && final_run && !ro && (!multi || fast_multi)) || (ro && !multi && !inner_flush && !lit_forced && !getenv("ZS_NO_FAST_RESUME")));
+                              ((!flushing && final_run && !ro && (!multi || fast_multi)) || (ro && (!multi || fast_multi) && !inner_flush && !lit_forced && !getenv("ZS_NO_FAST_RESUME")));
         const bool fast_par = fast_one && !multi && !force_seq && !ro && len >= kFastMinInput;
         s.fv_end = ((fast_one && !fast_par && !getenv("ZS_NO_FAST_VEC")) || fast_resume) ? (int32_t)(len - kMinLookahead) : -1;
         s.ins_bits = nullptr;
@@ -421,7 +424,7 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
     c->fast_rounds = 0;
     const bool no_rounds_this_call = c->no_rounds_once;
     c->no_rounds_once = false;
-    if (pl.any_fv && !getenv("ZS_FAST_NO_ROUNDS") && !no_rounds_this_call && !(ro && ro->resume)) {  // (a resumed run: the stream form, from p0)
+    if (pl.any_fv && !getenv("ZS_FAST_NO_ROUNDS") && !no_rounds_this_call && !(ro && ro->resume && getenv("ZS_NO_RESUME_ROUNDS"))) {
         // levels 1-3: every stream's parse as rounds over its chunks, all chunks of the batch at once (zs_fast_sweep.h "Rounds"),
         // when that is the shorter way.  One workgroup per stream takes as long as the longest stream at 46 / 35 / 20 MB/s (levels
         // 1 / 2 / 3 on text; kennedy.xls and ptt5 are slower).  The rounds take the whole batch through the chip at ~3.5 GB/s a few
@@ -432,8 +435,8 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
         int64_t pos_fv = 0, max_fv = 0;
         for (int i = 0; i < n; i++)
             if (pl.sd[(size_t)i].fv_end >= 0) {
-                pos_fv += pl.sd[(size_t)i].fv_end + 1;
-                max_fv = std::max<int64_t>(max_fv, pl.sd[(size_t)i].fv_end + 1);
+                pos_fv += pl.sd[(size_t)i].fv_end + 1 - pl.sd[(size_t)i].start_pos;
+                max_fv = std::max<int64_t>(max_fv, pl.sd[(size_t)i].fv_end + 1 - pl.sd[(size_t)i].start_pos);
             }
         const double t_stream = (double)max_fv / (level >= 3 ? 20e6 : level == 2 ? 35e6 : 46e6);
         const double t_rounds = std::min(0.016, (double)max_fv / 60e6) + (double)pos_fv / 3.5e9;
@@ -455,7 +458,10 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
                     {
                         // the stream's read events are its segments (seg_after of event k - 1 = the data end before event k)
                         const int32_t *after = pl.seg_after.data() + s.seg_off;
-                        const int64_t shortest = fs_build_chunks(i, (int64_t)s.fv_end, s.nsegs - 1, [&](int k) { return (int64_t)after[k - 1] - (kMinLookahead - 1); }, (int)target, pl.fr_chunks);
+                        // (a resumed run: segment 0 is the engine as the flush left it, event 1 the read at p0 itself)
+                        const bool res = s.resume != 0;
+                        const int64_t shortest = fs_build_chunks(i, (int64_t)s.fv_end, s.nsegs - 1, [&](int k) { return (int64_t)after[k - 1] - (kMinLookahead - 1); }, (int)target, pl.fr_chunks,
+                                                                 res ? 2 : 1, res ? s.start_pos : 0);
                         if (shortest < kFsMinSpan) too_short = true;  // (Write ends a few hundred bytes apart: more chunks in a chunk's reach than it looks at)
                     }
                     s.fr_n = (int32_t)pl.fr_chunks.size() - s.fr_first;
@@ -615,8 +621,10 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
         if (ro && ro->resume && pl.sd[0].fv_end >= 0) {
             // a resumed run at levels 1-3: below p0 the set is what the suspended engine's chains contain -- every position they
             // reach is in it (and no walk meets another one): all ones
-            const int64_t lo = std::max<int64_t>(0, ro->p0 - kWSize - 64) / 32 * 4, hi = (ro->p0 / 32 + 1) * 4;
-            ZS_HIP(c, hipMemsetAsync((uint8_t *)pl.sd[0].ins_bits + lo, 0xFF, (size_t)(hi - lo), stream));
+            // (exactly the bits below p0: the chunk form's commit ORs the run's own bits in)
+            const int64_t lo = std::max<int64_t>(0, ro->p0 - kWSize - 64) / 32, hi = ro->p0 / 32;
+            if (hi > lo) ZS_HIP(c, hipMemsetAsync(pl.sd[0].ins_bits + lo, 0xFF, (size_t)(hi - lo) * 4, stream));
+            ZS_HIP(c, hipMemsetD32Async((hipDeviceptr_t)(pl.sd[0].ins_bits + hi), (int)((1u << (ro->p0 & 31)) - 1u), 1, stream));
         }
     }
 

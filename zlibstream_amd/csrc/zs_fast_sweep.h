@@ -158,14 +158,16 @@ constexpr int kFsChunkMin = 1024;
 // trig(k), k = 1 .. ntrig: the trigger of read event k (the data end before it - 261), ascending.  Returns the length of the
 // shortest chunk that has a chunk behind it (the kernel looks at 64 chunks in front of one: kFsMinSpan).
 constexpr int kFsMinSpan = 520;  // 64 chunks of this length cover the 32 512 + 64 + 258 positions a chunk's tile reaches back
+// k0 / s0: a run that takes the stream over at position s0 (behind a flush), whose event k0 - 1 is the read at that very
+// position: the chunks begin there, and that event fires at the first chunk's first loop-top.
 template <class Vec, class Trig>
-inline int64_t fs_build_chunks(int stream, int64_t body_end, int ntrig, const Trig &trig, int target, Vec &out) {
+inline int64_t fs_build_chunks(int stream, int64_t body_end, int ntrig, const Trig &trig, int target, Vec &out, int k0 = 1, int64_t s0 = 0) {
     const int32_t first = (int32_t)out.size();
     if (target > kFsChunkMax) target = kFsChunkMax;
     if (target < kFsChunkMin) target = kFsChunkMin;
-    int64_t s = 0;
+    int64_t s = s0;
     int fired = 0;
-    for (int k = 1;; k++) {
+    for (int k = k0;; k++) {
         const int64_t tr = k <= ntrig ? (int64_t)trig(k) : body_end + 1;
         const int64_t e = tr <= body_end ? tr : body_end + 1;
         const int64_t len = e - s;

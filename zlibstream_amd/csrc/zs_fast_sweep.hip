@@ -185,7 +185,7 @@ __global__ __launch_bounds__(NT) void zs_fast_sweep_kernel(const StreamDesc *sd,
             }
             continue;
         }
-        E0 = ck.idx == 0 ? 0 : (pvar[3] ? pvar[2] : ck.b_lo);
+        E0 = ck.idx == 0 ? (int)s.start_pos : (pvar[3] ? pvar[2] : ck.b_lo);  // (a resumed run's first chunk begins where the flush left the engine)
         if (E0 >= ck.b_hi) {  // (a last span shorter than the match that crosses it)
             if (threadIdx.x == 0) {
                 const FsMeta o = mp[kc];
