@@ -20,6 +20,8 @@ namespace SixLabors.ZlibStream
         [DllImport(Lib)] public static extern void zs_ctx_destroy(IntPtr ctx);
         [DllImport(Lib)] public static extern IntPtr zs_ctx_last_error(IntPtr ctx);
         [DllImport(Lib)] public static extern int zs_device_count();
+        // counters for tests and diagnostics ("lit_engine_bytes", "fast_rounds", "lit_fallbacks", ...; -1: no such counter)
+        [DllImport(Lib)] public static extern long zs_ctx_counter(IntPtr ctx, [MarshalAs(UnmanagedType.LPStr)] string name);
 
         // ---- Deflate..ctor (Deflate.cs:228-310); IntPtr.Zero where the ctor throws ArgumentOutOfRangeException
         [DllImport(Lib)] public static extern IntPtr zs_deflate_init(IntPtr ctx, int level, int strategy, int windowBits, int memLevel, int hashVariant);
