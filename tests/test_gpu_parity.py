@@ -1365,3 +1365,37 @@ def test_runs_behind_a_flush_at_the_fast_levels_take_the_sweeps(engine, oracle, 
     lit = engine.counter("lit_engine_bytes") - before
     assert lit <= 4096, "%d bytes of two 3 MiB streams went through the literal engine beyond the runs' last 261" % lit
     rate_floors.check(sum(sizes) / dt >= 20e6, "level 1, a Sync flush behind every 256 KiB: %.1f ms = %.1f MB/s" % (dt * 1e3, sum(sizes) / dt / 1e6))
+
+
+@pytest.mark.gpu
+def test_inflate_device_pointers_at_odd_addresses(engine):
+    """zs_inflate_batch_device takes the caller's pointers as they are: compressed streams that begin at any byte address (the
+    measuring pass and the header check read the stream through aligned dwords -- SyncBits / HdrBits `skew` -- and the stream's
+    last 128 bytes through a padded copy), outputs at any address (the resolve pass's 4-byte stores take the cells' phase into
+    account).  Five streams in one device buffer at offsets 1, 2, 3, 5 and 7 past 16-byte boundaries, outputs likewise."""
+    import torch
+    datas = [datagen.english(1 << 20, 11), datagen.english((1 << 20) + 3, 12), bytes(700001), datagen.sparse(512, 300),
+             np.random.default_rng(5).integers(0, 4, 900007, dtype=np.uint8).tobytes()]
+    zs = [zlib.compress(d, 6) for d in datas]
+    offs, total = [], 0
+    for z, skew in zip(zs, (1, 2, 3, 5, 7)):
+        total = (total + 15) // 16 * 16 + skew
+        offs.append(total)
+        total += len(z)
+    zbuf = torch.zeros(total + 64, dtype=torch.uint8, device="cuda")
+    for z, o in zip(zs, offs):
+        zbuf[o:o + len(z)] = torch.frombuffer(bytearray(z), dtype=torch.uint8).cuda()
+    ooffs, ototal = [], 0
+    for d, skew in zip(datas, (3, 1, 7, 2, 5)):
+        ototal = (ototal + 15) // 16 * 16 + skew
+        ooffs.append(ototal)
+        ototal += len(d)
+    obuf = torch.zeros(ototal + 64, dtype=torch.uint8, device="cuda")
+    lens = engine.inflate_batch_device([zbuf.data_ptr() + o for o in offs], [len(z) for z in zs], [obuf.data_ptr() + o for o in ooffs],
+                                       [len(d) for d in datas])
+    host = obuf.cpu().numpy().tobytes()
+    for i, d in enumerate(datas):
+        assert lens[i] == len(d) and host[ooffs[i]:ooffs[i] + len(d)] == d, i
+    # nothing written in front of or behind an output
+    for i, d in enumerate(datas):
+        assert host[ooffs[i] - 1] == 0 and host[ooffs[i] + len(d)] == 0, i
