@@ -281,7 +281,7 @@ def roofline(stage_ms, alg_bytes, traffic=None, kernels=None, source=None, launc
     achieved = alg_bytes / (stage_ms[dom] * 1e-3) / 1e9
     if dom in MULTI_LAUNCH_STAGES and kernels is None:
         kernels = [MULTI_LAUNCH_STAGES[dom]]
-        launches = launches or "rounds"
+        launches = launches or "rounds"  # (a count where the caller knows it)
     # scope: "kernel" -- `achieved` is over ONE kernel's launch time; "stage" -- over a stage of the call that is several launches
     # (kernel_ms is then the stage's time and `traffic` the sum of its kernels'); profiles/rNN_*_kernel_stats.csv has every
     # kernel's own average beside it
@@ -301,9 +301,12 @@ def pmc_stage(stage_ms, tag):
     return pmc_traffic(MULTI_LAUNCH_STAGES.get(dom, "zs_%s_kernel" % dom), tag)
 
 
-def roofline_with_pmc(stage_ms, alg_bytes, pmc_tag):
+def roofline_with_pmc(stage_ms, alg_bytes, pmc_tag, launches=None):
     traffic, source = pmc_stage(stage_ms, pmc_tag) if pmc_tag else (None, None)
-    return roofline(stage_ms, alg_bytes, traffic=traffic, source=source)
+    r = roofline(stage_ms, alg_bytes, traffic=traffic, source=source, launches=launches)
+    if isinstance(r.get("launches"), int) and r["launches"] > 0:
+        r["mean_launch_ms"] = round(r["kernel_ms"] / r["launches"], 4)
+    return r
 
 
 def secondary_deflate(eng, dev, name, datas, level, steps, check_every=1, strategy=0, pmc_tag=None):
@@ -311,9 +314,11 @@ def secondary_deflate(eng, dev, name, datas, level, steps, check_every=1, strate
     dt, stage_ms = b.timed(level, steps, 1)
     b.check_roundtrip(check_every)
     total_out = sum(b.out_lens)
+    # (DeflateFast as rounds over chunks: the stage is that many launches of one kernel -- zs_ctx_counter says how many the last call took)
+    rounds = eng.counter("fast_rounds") if max(stage_ms, key=stage_ms.get) in MULTI_LAUNCH_STAGES else 0
     res = {"workload": name, "level": level, "buffers": len(datas), "input_bytes": b.n, "compressed_bytes": total_out,
            "value": round(b.n * steps / dt / 1e6, 2), "unit": "MB/s", "ms_per_step": round(dt / steps * 1e3, 3), "steps": steps,
-           "roundtrip": True, "roofline": roofline_with_pmc(stage_ms, b.n + total_out, pmc_tag),
+           "roundtrip": True, "roofline": roofline_with_pmc(stage_ms, b.n + total_out, pmc_tag, rounds if rounds > 0 else None),
            "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()}}
     return res, b
 
