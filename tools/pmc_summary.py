@@ -178,7 +178,7 @@ for name, out in (("flush_resume.log", "flush_resume.log"), ("patho.jsonl", "pat
 
 for name, out in (("bench_default.json", "bench_default.json"), ("bench_full.json", "bench_full.json"), ("bench_english64.json", "bench_english64_L6.json"), ("bench_sparse64.json", "bench_sparse64_L6.json"),
                   ("bench_batch128.json", "bench_batch128x1MiB_L6.json"), ("bench_inflate.json", "bench_inflate1g.json"),
-                  ("time_levels.jsonl", "time_levels.jsonl"), ("host_path.jsonl", "host_path.jsonl"),
+                  ("time_levels.jsonl", "time_levels.jsonl"), ("flush_resume_L1.log", "flush_resume_L1.log"), ("small_trace.log", "small_trace.log"), ("host_path.jsonl", "host_path.jsonl"),
                   ("bench_english64_pipelined.json", "bench_english64_L6_pipelined3.json"),
                   ("bench_inflate_single.json", "bench_inflate_single64.json")):
     p = os.path.join(src, name)

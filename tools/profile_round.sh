@@ -45,6 +45,9 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_fast64_L1 -o run 
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_fast64_L1 -o run -- python3 $R/tools/prof_cases.py fast64_L1 1 > /dev/null 2> $O/pmc_write_fast64_L1.err
 echo "round 3 / 4 cases done"
 python3 $R/tools/flush_resume_bench.py > $O/flush_resume.log 2> $O/flush_resume.err
+python3 $R/tools/flush_resume_bench.py 1 > $O/flush_resume_L1.log 2> $O/flush_resume_L1.err  # round 5: DeflateFast behind a flush
+python3 $R/tools/small_trace.py 6 65536 > $O/small_trace.log 2> $O/small_trace.err
+python3 $R/tools/small_trace.py 1 65536 >> $O/small_trace.log 2>> $O/small_trace.err
 python3 $R/tools/patho.py > $O/patho.jsonl 2> $O/patho.err  # (text lines, level 6; profiles/r03_patho.jsonl is the table with level 9 beside it)
 python3 $R/tools/fast_levels.py > $O/fast_levels.log 2> $O/fast_levels.err
 python3 $R/tools/multiwrite_check.py > $O/multiwrite_check.log 2> $O/multiwrite_check.err
