@@ -1696,7 +1696,8 @@ bool run_inflate_par(zs_ctx *c, const std::vector<int> &idx, const void *const *
         if (!ensure(c, c->par_tokstat, 128) || !ensure(c, c->par_tails, 4 * (size_t)kSbTailBuf * (size_t)m)) return false;
         hipLaunchKernelGGL(zs_inf_tails_kernel, dim3((unsigned)m), dim3(64), 0, stream, d_ps, dev<uint32_t>(c->par_tails));
         if (!c->inf_probe) {  // (a probing call decodes nothing: no slabs, the measuring pass stores no tokens)
-            hipLaunchKernelGGL(zs_inf_tokalloc_kernel, dim3(1), dim3(1024), 0, stream, d_ps, d_st, m, dev<ParCand>(c->par_cands), dev<int64_t>(c->par_tokstat));
+            hipLaunchKernelGGL(zs_inf_tokalloc_kernel, dim3((unsigned)m), dim3(1024), 0, stream, d_ps, d_st, dev<ParCand>(c->par_cands));
+            hipLaunchKernelGGL(zs_inf_tokbase_kernel, dim3(1), dim3(1024), 0, stream, d_st, m, dev<int64_t>(c->par_tokstat));
             ZS_HIP(c, hipMemcpyAsync(&tok_total, c->par_tokstat.p, 8, hipMemcpyDeviceToHost, stream));
         }
     }

@@ -74,6 +74,7 @@ struct ParState {
     int32_t win_off;   // index of the stream's first window in `windows` (set by the host once the block counts are known)
     int64_t out_len, end_bit;
     int32_t lane_blocks, pad_;  // 1: the chain has blocks with checkpoints but no tokens (the lane decoder and its flatten pass have work)
+    int64_t tok_base, tok_need;  // the stream's slabs in the token array: where they begin, how many tokens they hold (zs_inflate_tok.hip)
 };
 
 // ---- shared block decoder (wave-uniform) ----
@@ -690,6 +691,7 @@ __global__ __launch_bounds__(256) void zs_inf_flatten_kernel(const ParStream *ps
         st[si].out_len = 0;
         st[si].end_bit = 0;
         st[si].lane_blocks = 0, st[si].pad_ = 0;
+        st[si].tok_base = 0, st[si].tok_need = 0;
     }
 }
 

@@ -68,49 +68,77 @@ __device__ __forceinline__ void tok_copy(uint32_t *dst, const uint32_t *src, int
 }
 
 // Slabs: candidate i of a stream may decode up to the next candidate's header (its most likely end), in subsequences of S
-// bits, each with room for S / 2 tokens and a re-entry's kTokPre.  One workgroup lays all candidates of the batch out.
-__global__ __launch_bounds__(1024) void zs_inf_tokalloc_kernel(const ParStream *ps, const ParState *st, int nstreams, ParCand *cands, int64_t *total) {
+// bits, each with room for S / 4 tokens and a re-entry's kTokPre.  One workgroup per stream lays the stream's candidates out
+// (offsets inside the stream's share), one more adds the shares up (a batch of a thousand streams laid out by one workgroup,
+// stream after stream, was 3 ms of barriers).
+__global__ __launch_bounds__(1024) void zs_inf_tokalloc_kernel(const ParStream *ps, ParState *st, ParCand *cands) {
+    __shared__ int64_t wsum[16];
+    __shared__ int64_t run;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, si = blockIdx.x;
+    if (tid == 0) run = 0;
+    __syncthreads();
+    const ParStream s = ps[si];
+    const int n = st[si].ok ? st[si].ncand : 0;
+    const int64_t nbits = s.in_len * 8;
+    for (int c0 = 0; c0 < n; c0 += 1024) {
+        const int i = c0 + tid;
+        int64_t need = 0;
+        if (i < n) {
+            const int64_t bit = cands[s.cand_off + i].bit;
+            int64_t hint = i + 1 < n ? cands[s.cand_off + i + 1].bit : nbits;
+            if (hint <= bit || hint > nbits) hint = nbits;
+            const int S = tok_sub_bits(hint - bit);
+            const int64_t nsub = (hint - bit + S - 1) / S + 1;
+            need = nsub <= kCkMax ? nsub * tok_unit(S) : 0;
+        }
+        int64_t v = need;
+        for (int d = 1; d < 64; d <<= 1) {
+            const int64_t t = __shfl_up(v, d);
+            if (lane >= d) v += t;
+        }
+        if (lane == 63) wsum[wave] = v;
+        __syncthreads();
+        int64_t base = run, tot = 0;
+        for (int k = 0; k < 16; k++) {
+            if (k < wave) base += wsum[k];
+            tot += wsum[k];
+        }
+        if (i < n) {
+            ParCand &c = cands[s.cand_off + i];
+            c.tok_off = base + v - need;  // (inside the stream's share: the measuring kernel adds ParState::tok_base)
+            c.tok_cap = (int32_t)need;
+        }
+        __syncthreads();
+        if (tid == 0) run += tot;
+        __syncthreads();
+    }
+    if (tid == 0) st[si].tok_need = run;
+}
+__global__ __launch_bounds__(1024) void zs_inf_tokbase_kernel(ParState *st, int nstreams, int64_t *total) {
     __shared__ int64_t wsum[16];
     __shared__ int64_t run;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) run = 0;
     __syncthreads();
-    for (int si = 0; si < nstreams; si++) {
-        const ParStream s = ps[si];
-        const int n = st[si].ok ? st[si].ncand : 0;
-        const int64_t nbits = s.in_len * 8;
-        for (int c0 = 0; c0 < n; c0 += 1024) {
-            const int i = c0 + tid;
-            int64_t need = 0;
-            if (i < n) {
-                const int64_t bit = cands[s.cand_off + i].bit;
-                int64_t hint = i + 1 < n ? cands[s.cand_off + i + 1].bit : nbits;
-                if (hint <= bit || hint > nbits) hint = nbits;
-                const int S = tok_sub_bits(hint - bit);
-                const int64_t nsub = (hint - bit + S - 1) / S + 1;
-                need = nsub <= kCkMax ? nsub * tok_unit(S) : 0;
-            }
-            int64_t v = need;
-            for (int d = 1; d < 64; d <<= 1) {
-                const int64_t t = __shfl_up(v, d);
-                if (lane >= d) v += t;
-            }
-            if (lane == 63) wsum[wave] = v;
-            __syncthreads();
-            int64_t base = run, tot = 0;
-            for (int k = 0; k < 16; k++) {
-                if (k < wave) base += wsum[k];
-                tot += wsum[k];
-            }
-            if (i < n) {
-                ParCand &c = cands[s.cand_off + i];
-                c.tok_off = base + v - need;
-                c.tok_cap = (int32_t)need;
-            }
-            __syncthreads();
-            if (tid == 0) run += tot;
-            __syncthreads();
+    for (int c0 = 0; c0 < nstreams; c0 += 1024) {
+        const int i = c0 + tid;
+        const int64_t need = i < nstreams ? st[i].tok_need : 0;
+        int64_t v = need;
+        for (int d = 1; d < 64; d <<= 1) {
+            const int64_t t = __shfl_up(v, d);
+            if (lane >= d) v += t;
         }
+        if (lane == 63) wsum[wave] = v;
+        __syncthreads();
+        int64_t base = run, tot = 0;
+        for (int k = 0; k < 16; k++) {
+            if (k < wave) base += wsum[k];
+            tot += wsum[k];
+        }
+        if (i < nstreams) st[i].tok_base = base + v - need;
+        __syncthreads();
+        if (tid == 0) run += tot;
+        __syncthreads();
     }
     if (tid == 0) *total = run;
 }
@@ -444,7 +472,7 @@ __global__ __launch_bounds__(64) void zs_inf_measure_tok_kernel(const ParStream 
     const int64_t b0 = inf_tell(hb);  // first symbol of the block
     const int S = tok_sub_bits(hint - cbit);  // (as zs_inf_tokalloc_kernel sized the slab)
     const int unit = tok_unit(S), mcap = tok_main_cap(S);
-    const int64_t tok_off = c.tok_off;
+    const int64_t tok_off = retry ? c.tok_off : st[w.x].tok_base + c.tok_off;  // (a retried block's room comes from the reserve: absolute)
     const int tok_cap = c.tok_cap;
     const __attribute__((address_space(1))) uint8_t *gin = (const __attribute__((address_space(1))) uint8_t *)(uintptr_t)s.in;
     TokTabs &T = tabs[wi];
