@@ -965,7 +965,8 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
                     trace += b;
                 }
                 if (!env_fixed) {
-                    const size_t awake = std::min<size_t>(nch, 4 * (size_t)changed);
+                    static const double env_wake = getenv("ZS_FR_WAKE") ? atof(getenv("ZS_FR_WAKE")) : 4.0;
+                    const size_t awake = std::min<size_t>(nch, (size_t)(env_wake * (double)changed));
                     const int tail = env_tail;
                     fr.range = std::min<int>(range_max, std::max<int>(tail, (int)((awake + 255) / 256)));
                 }
@@ -1069,7 +1070,7 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
                 }
         }
         ZS_HIP(c, hipMemsetAsync(c->run_fail.p, 0, 4 * (size_t)n + 64, stream));
-        hipLaunchKernelGGL(zs_fast_run_kernel, dim3((unsigned)pl.n_runs), dim3(1024), kTailLds, stream, d_sd, d_work + o_runs,
+        hipLaunchKernelGGL(zs_fast_run_kernel, dim3((unsigned)pl.n_runs), dim3(1024), kFastRunLds, stream, d_sd, d_work + o_runs,
                            dev<uint16_t>(c->link), dev<uint32_t>(c->run_syms), dev<uint32_t>(c->run_bits), dev<uint8_t>(c->run_scratch),
                            dev<FastRunOut>(c->run_outs), c->crc_tab, lv, strategy, hash_variant);
         hipLaunchKernelGGL(zs_fast_verify_kernel, dim3((unsigned)pl.n_runs), dim3(256), 0, stream, d_sd, d_work + o_runs,
@@ -1351,7 +1352,7 @@ int zs_ctx_create(int device, zs_ctx **out) {
         hipFuncSetAttribute((const void *)zs_resolve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kResolveLds) != hipSuccess ||
         hipFuncSetAttribute((const void *)zs_links_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kLkLds) != hipSuccess ||
         hipFuncSetAttribute((const void *)zs_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kTailLds) != hipSuccess ||
-        hipFuncSetAttribute((const void *)zs_fast_run_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kTailLds) != hipSuccess ||
+        hipFuncSetAttribute((const void *)zs_fast_run_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kFastRunLds) != hipSuccess ||
         hipFuncSetAttribute((const void *)zs_fast_sweep_kernel<1024, kFsTile1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (fs_lds_bytes<1024, kFsTile1>())) != hipSuccess ||
         hipFuncSetAttribute((const void *)zs_fast_sweep_kernel<1024, kFsTile1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (fs_lds_bytes<1024, kFsTile1>())) != hipSuccess ||
         hipFuncSetAttribute((const void *)zs_inf_window_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kWinMapLds) != hipSuccess ||

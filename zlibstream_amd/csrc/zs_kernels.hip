@@ -2437,6 +2437,8 @@ __global__ __launch_bounds__(1024) void zs_tail_kernel(const StreamDesc *sd, Str
 }
 
 constexpr int kTailLds = (int)kScratchHead + 2 * kWSize + 4096;  // window, prev, CRC tables
+constexpr int kFastRunLds = kTailLds + kHeadCacheLds;          // ... and the cache in front of the run's hash heads (zs_lit_engine.h)
+static_assert(kFastRunLds + 1024 <= 160 * 1024, "a run's LDS");
 
 // ------------------------------------------------------------------ KF: DeflateFast by speculative chunk runs
 // One workgroup per run (1024 threads restore the engine state, wave 0 runs Deflate.Fast.cs:20-128 literally).
@@ -2467,6 +2469,7 @@ __global__ __launch_bounds__(1024) void zs_fast_run_kernel(const StreamDesc *sd,
     uint32_t *tabl = (uint32_t *)(smem + kScratchHead + 2 * kWSize);
     load_crc_tab(tabl, crc_tab_g);
     e.crc_tab = tabl;
+    e.hc_val = (uint16_t *)(smem + kTailLds), e.hc_nib = (uint32_t *)(smem + kTailLds + 2 * kHeadCache), e.hc_pres = e.hc_nib + kHeadCache / 8;
     e.data = s.in;
     e.n = s.n;
     e.lv = lv;
@@ -2497,9 +2500,39 @@ __global__ __launch_bounds__(1024) void zs_fast_run_kernel(const StreamDesc *sd,
         for (int i = tid; i < kHashSize; i += nth) e.head[i] = (uint16_t)(head32[i] ? head32[i] - 1 : 0);
     }
     __syncthreads();
+    // the cache in front of the table (zs_lit_engine.h): which buckets have a head at all, and in every slot the most recent
+    // of the four buckets that share it
+    for (int w = tid; w < kHashSize / 32; w += nth) {
+        uint32_t bits_w = 0;
+        for (int k = 0; k < 32; k++) bits_w |= (uint32_t)(e.head[32 * w + k] != 0) << k;
+        e.hc_pres[w] = bits_w;
+    }
+    for (int w = tid; w < kHeadCache / 8; w += nth) {
+        uint32_t nw = 0;
+        for (int k = 0; k < 8; k++) {
+            const int i = 8 * w + k;
+            int best_v = 0, best_t = 0;
+            for (int t = 0; t < 4; t++) {
+                const int v = e.head[t * kHeadCache + i];
+                if (v > best_v) best_v = v, best_t = t;
+            }
+            e.hc_val[i] = (uint16_t)best_v;
+            if (best_v) nw |= (8u | (uint32_t)best_t) << (4 * k);
+        }
+        e.hc_nib[w] = nw;
+    }
+    __syncthreads();
+#ifdef ZS_FV_PROF
+    const long long tk_pre = wall_clock64();
+#endif
     if (tid >= 64) return;
-    le_run_fast(e, tid, 64);
+    le_run_fast_hot(e, tid);
     le_flush_ins(e);
+#ifdef ZS_FV_PROF
+    if (tid == 0 && (blockIdx.x == 3 || blockIdx.x == 100))
+        printf("FASTRUN %d: engine ticks(100MHz)=%lld syms=%lld: refill+checks=%lld insert=%lld match=%lld tally+advance=%lld flush=%lld\n", (int)blockIdx.x,
+               wall_clock64() - tk_pre, (long long)e.nsyms, e.pf[0], e.pf[1], e.pf[2], e.pf[3], e.pf[4]);
+#endif
     if (tid == 0) {
         FastRunOut &o = outs[run];
         o.mark_pos = e.mark_pos, o.mark_nsyms = e.mark_nsyms;
@@ -2608,11 +2641,13 @@ __global__ __launch_bounds__(64) void zs_fast_plan_kernel(const StreamDesc *sd, 
     // a stream whose symbol count is a multiple of kBlockSyms ends with an empty last block, like the reference
 }
 
-// one workgroup per run: copy the run's own symbols into place; thread 0 re-walks them to find the byte positions of
-// the block cuts that fall inside the run
+// one workgroup per run: copy the run's own symbols into place; the byte positions of the block cuts that fall inside the run
+// from the symbols' own lengths (a cut every kBlockSyms symbols: at most a few per run, none in most -- one thread walking
+// all of a run's symbols for them was 0.5 ms of sparse64's 7)
 __global__ __launch_bounds__(256) void zs_fast_stitch_kernel(const StreamDesc *sd, const uint2 *work, const uint32_t *run_syms,
                                                              const FastRunOut *outs, uint32_t *syms, int32_t *blk_end,
                                                              int32_t *blk_top) {
+    __shared__ long long part[256];
     const uint2 w = work[blockIdx.x];
     const StreamDesc s = sd[w.x];
     const int64_t run = (int64_t)s.run_off + w.y;
@@ -2620,19 +2655,32 @@ __global__ __launch_bounds__(256) void zs_fast_stitch_kernel(const StreamDesc *s
     const uint32_t *src = run_syms + run * kFastRunSyms + o.mark_nsyms;
     uint32_t *dst = syms + s.sym_off + o.sym_dst;
     const int64_t cnt = o.nsyms - o.mark_nsyms;
-    for (int64_t i = threadIdx.x; i < cnt; i += 256) dst[i] = src[i];
-    if (threadIdx.x == 0) {
-        int64_t pos = o.mark_pos;
-        for (int64_t i = 0; i < cnt; i++) {
+    const int tid = threadIdx.x;
+    for (int64_t i = tid; i < cnt; i += 256) dst[i] = src[i];
+    // symbol i of the run is the stream's symbol sym_dst + i; the first one that ends a block:
+    int64_t i_cut = (kBlockSyms - 1) - o.sym_dst % kBlockSyms, i_done = 0, pos = o.mark_pos;
+    for (; i_cut < cnt; i_cut += kBlockSyms) {
+        long long sum = 0;
+        for (int64_t i = i_done + tid; i < i_cut; i += 256) {
             const uint32_t v = src[i];
-            const int64_t start = pos;
-            pos += (v >> 16) ? (int64_t)(v & 0xFFFF) + 3 : 1;
-            const int64_t g = o.sym_dst + i;
-            if ((g + 1) % kBlockSyms == 0) {
-                blk_end[s.blk_off + g / kBlockSyms] = (int32_t)pos;
-                blk_top[s.blk_off + g / kBlockSyms] = (int32_t)start;  // DeflateFast flushes at the loop-top that emitted the symbol
-            }
+            sum += (v >> 16) ? (long long)(v & 0xFFFF) + 3 : 1;
         }
+        part[tid] = sum;
+        __syncthreads();
+        for (int k = 128; k > 0; k >>= 1) {
+            if (tid < k) part[tid] += part[tid + k];
+            __syncthreads();
+        }
+        const int64_t start = pos + part[0];
+        __syncthreads();
+        const uint32_t v = src[i_cut];
+        pos = start + ((v >> 16) ? (int64_t)(v & 0xFFFF) + 3 : 1);
+        if (tid == 0) {
+            const int64_t g = o.sym_dst + i_cut;
+            blk_end[s.blk_off + g / kBlockSyms] = (int32_t)pos;
+            blk_top[s.blk_off + g / kBlockSyms] = (int32_t)start;  // DeflateFast flushes at the loop-top that emitted the symbol
+        }
+        i_done = i_cut + 1;
     }
 }
 

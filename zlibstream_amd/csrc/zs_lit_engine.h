@@ -103,6 +103,13 @@ struct LitEngine {
     // (le_tail_head_bucket) -- bytes that a slide would change under them, hence the condition
     int no_head;
     int tail_head[3];
+    // a table in device memory (the speculative chunk runs: window + prev fill the LDS) behind a direct-mapped cache in LDS:
+    // every insert reads its bucket's head before anything else can go on, and a round trip to the memory side of the chip
+    // is 1-2 us with the stores in front of it.  Slot h & (kHeadCache - 1): the value in hc_val, a nibble in hc_nib -- 8 | (h >> 13)
+    // when the slot holds bucket h -- and an entry that makes room goes back to the table; hc_pres has a bit per bucket: 0 =
+    // the bucket is empty in the table too (a first occurrence costs no load).  nullptr: no cache
+    uint16_t *hc_val;
+    uint32_t *hc_nib, *hc_pres;
     // outputs
     uint32_t *syms;     // symbol i: dist << 16 | lc  (dist 0 = literal)
     int64_t nsyms;      // symbols emitted so far in this stream (body + tail)
@@ -119,6 +126,7 @@ ZS_HD void le_defaults(LitEngine &e) {
     e.final_run = 1, e.suspended = 0, e.stopped = 0, e.last_event_abs = -1;
     e.pre_rec = nullptr, e.pre_lo = e.pre_hi = 0;
     e.no_head = 0, e.tail_head[0] = e.tail_head[1] = e.tail_head[2] = 0;
+    e.hc_val = nullptr, e.hc_nib = nullptr, e.hc_pres = nullptr;
     e.block_syms = kBlockSyms, e.block_sym_start = 0, e.block_start_abs = 0, e.defer_start = 0;
     e.nsyms = 0, e.nblocks = 0;
 }
@@ -203,6 +211,28 @@ ZS_HD void le_flush_ins(LitEngine &e) {
     e.ins_word_idx = -1, e.ins_word = 0;
 }
 
+constexpr int kHeadCacheBits = 13, kHeadCache = 1 << kHeadCacheBits;  // 8192 slots: 16 KiB of values, 4 KiB of nibbles; 4 KiB of presence bits
+constexpr int kHeadCacheLds = 2 * kHeadCache + kHeadCache / 2 + kHashSize / 8;
+static_assert(kHashSize == 4 * kHeadCache, "a slot's tag is two bits");
+// head[h] as InsertString reads it, with `str` left in its place (Deflate.cs:866-877), through the cache; `head` is the table
+// in device memory.  One wave, every lane with the same arguments.
+template <class Val, class Nib, class Pres, class Head>
+ZS_HD int le_head_swap(Val val, Nib nib, Pres pres, Head head, uint32_t h, int str) {
+    const uint32_t i = h & (uint32_t)(kHeadCache - 1), sh = 4u * (i & 7u), want = 8u | (h >> kHeadCacheBits);
+    const uint32_t nw = nib[i >> 3], pw = pres[h >> 5], cv = val[i];
+    const uint32_t have = (nw >> sh) & 15u;
+    int cur;
+    if (have == want) {
+        cur = (int)cv;
+    } else {
+        cur = ((pw >> (h & 31u)) & 1u) ? (int)head[h] : 0;
+        if (have & 8u) head[((have & 3u) << kHeadCacheBits) | i] = (uint16_t)cv;  // (not waited for)
+        nib[i >> 3] = (nw & ~(15u << sh)) | (want << sh);
+        pres[h >> 5] = pw | (1u << (h & 31u));
+    }
+    val[i] = (uint16_t)str;
+    return cur;
+}
 // Deflate.cs:866-877
 ZS_HD int le_insert(LitEngine &e, int str) {
     if (e.ins_bits) {
@@ -240,6 +270,11 @@ ZS_HD int le_insert(LitEngine &e, int str) {
             return ZS_LDS_PTR(const uint16_t, e.prev)[str & kWMask];
         }
     }
+    if (e.hc_val) {
+        const int cur = le_head_swap(ZS_LDS_PTR(uint16_t, e.hc_val), ZS_LDS_PTR(uint32_t, e.hc_nib), ZS_LDS_PTR(uint32_t, e.hc_pres), e.head, h, str);
+        if (cur != str) ZS_LDS_PTR(uint16_t, e.prev)[str & kWMask] = (uint16_t)cur;
+        return cur;
+    }
     int cur = e.head[h];
     if (cur != str) {
         ZS_LDS_PTR(uint16_t, e.prev)[str & kWMask] = (uint16_t)cur;
@@ -266,12 +301,15 @@ ZS_HD void le_slide(LitEngine &e, int lane, int nlanes) {
     V4 *w = (V4 *)e.window;
     for (int i = lane; i < kWSize / 16; i += nlanes) w[i] = w[i + kWSize / 16];
     if (!e.no_head) slide16(e.head, kHashSize);
+    if (e.hc_val) slide16(e.hc_val, kHeadCache);  // (a slot nobody holds slides too; a bucket that slides to 0 keeps its presence bit: a load finds the 0)
     slide16(e.prev, kWSize);
 #else
     for (int i = lane; i < kWSize; i += nlanes) e.window[i] = e.window[i + kWSize];
     if (!e.no_head)
         for (int i = lane; i < kHashSize; i += nlanes) e.head[i] = (uint16_t)(e.head[i] >= kWSize ? e.head[i] - kWSize : 0);
     for (int i = lane; i < kWSize; i += nlanes) e.prev[i] = (uint16_t)(e.prev[i] >= kWSize ? e.prev[i] - kWSize : 0);
+    if (e.hc_val)
+        for (int i = lane; i < kHeadCache; i += nlanes) e.hc_val[i] = (uint16_t)(e.hc_val[i] >= kWSize ? e.hc_val[i] - kWSize : 0);
 #endif
     for (int k = 0; k < 3; k++) e.tail_head[k] = e.tail_head[k] >= kWSize ? e.tail_head[k] - kWSize : 0;  // the heads kept apart (no_head)
 }
@@ -488,6 +526,10 @@ ZS_HD_NOINLINE inline void le_end_write(LitEngine &e, int lane, int nlanes) {
     if (f == 3) {
         ZS_WAVE_SYNC();
         for (int i = lane; i < kHashSize; i += nlanes) e.head[i] = 0;
+        if (e.hc_val) {
+            for (int i = lane; i < kHeadCache / 8; i += nlanes) e.hc_nib[i] = 0;
+            for (int i = lane; i < kHashSize / 32; i += nlanes) e.hc_pres[i] = 0;
+        }
         ZS_WAVE_SYNC();
     }
     e.cur_wr++;
@@ -599,6 +641,7 @@ ZS_HD_NOINLINE inline void le_run_slow(LitEngine &e, int lane, int nlanes) {
 // Deflate.Fast.cs:20-128 with flush == Finish, run to the end of the stream.
 ZS_HD_NOINLINE inline void le_run_fast(LitEngine &e, int lane, int nlanes) {
     for (;;) {
+        LE_PF_T0();
         if (e.lookahead < kMinLookahead) {
             int dummy = 0;
             le_refill(e, lane, nlanes, dummy);
@@ -611,11 +654,14 @@ ZS_HD_NOINLINE inline void le_run_fast(LitEngine &e, int lane, int nlanes) {
         }
         if (e.mark_abs >= 0 && e.mark_pos < 0 && e.base + e.strstart >= e.mark_abs) e.mark_pos = e.base + e.strstart, e.mark_nsyms = e.nsyms;
         if (e.stop_abs >= 0 && e.base + e.strstart >= e.stop_abs) return;  // a speculative run ends at a loop-top, nothing is flushed
+        LE_PF(0);
         int hash_head = 0;
         if (e.lookahead >= kMinMatch) hash_head = le_insert(e, e.strstart);
+        LE_PF(1);
         if (hash_head != 0 && e.strstart - hash_head <= kMaxDist) {
             if (e.strategy != kHuffmanOnly) e.match_length = le_longest_match(e, hash_head);
         }
+        LE_PF(2);
         bool bflush;
         if (e.match_length >= kMinMatch) {
             bflush = le_tally(e, e.strstart - e.match_start, e.match_length - kMinMatch, lane);
@@ -636,11 +682,170 @@ ZS_HD_NOINLINE inline void le_run_fast(LitEngine &e, int lane, int nlanes) {
             e.lookahead--;
             e.strstart++;
         }
+        LE_PF(3);
         if (bflush) le_flush_block(e, false, lane);
+        LE_PF(4);
     }
     le_flush_block(e, true, lane);
 }
 
+
+#if defined(__HIPCC__)
+// le_run_fast for the speculative chunk runs (zs_fast_run_kernel), statement for statement, with the state that every
+// symbol touches in registers.  The engine's struct lives in the wave's scratch memory -- it goes to the out-of-line pieces by
+// reference -- and a symbol of the generic loop is some forty dependent round trips to it: 0.9 us, of which the searches
+// and compares are a tenth (sparse64 at level 1: 5.8 of 7.2 ms).  Here the struct is read at entry and written back where the
+// rare pieces need it (a read: once per 32 Ki positions; the stream's last 261 positions go to the generic loop).  The hashes
+// of 64 consecutive positions are made at once, a position per lane, and picked with v_readlane: one LDS round trip for the
+// window bytes and one for the CRC tables per 64 inserts instead of per insert; the bitmap of inserted positions is
+// written with atomics nobody waits for.  Needs: one Write, no block cuts (no_blocks), the head cache.
+__device__ inline void le_run_fast_hot(LitEngine &e, int lane) {
+    typedef __attribute__((address_space(1))) uint32_t *g_u32p;
+    typedef __attribute__((address_space(1))) uint16_t *g_u16p;
+    if (!e.hc_val || !e.no_blocks || e.wr_end || e.pre_rec || e.no_head || !e.ins_bits || (e.hash_variant != kHashMul && !e.crc_tab)) {
+        le_run_fast(e, lane, 64);
+        return;
+    }
+    auto wl = ZS_LDS_PTR(const uint8_t, e.window);
+    auto pl = ZS_LDS_PTR(uint16_t, e.prev);
+    auto cval = ZS_LDS_PTR(uint16_t, e.hc_val);
+    auto cnib = ZS_LDS_PTR(uint32_t, e.hc_nib);
+    auto cpres = ZS_LDS_PTR(uint32_t, e.hc_pres);
+    auto crc = ZS_LDS_PTR(const uint32_t, e.crc_tab);
+    const uint8_t *const win = e.window;
+    const g_u16p head_g = (g_u16p)e.head;
+    const g_u32p syms = (g_u32p)e.syms, bits = (g_u32p)e.ins_bits;
+    const bool mul = e.hash_variant == kHashMul, search = e.strategy != kHuffmanOnly;
+    const int lazy = e.lv.lazy, nice_cfg = e.lv.nice;
+    // (prev_length is not touched by DeflateFast: Longest_match starts from what the restore left)
+    const int best0 = e.prev_length == 0 ? 1 : e.prev_length, chain_eff = e.prev_length >= e.lv.good ? e.lv.chain >> 2 : e.lv.chain;
+    const int64_t mark_abs = e.mark_abs, stop_abs = e.stop_abs;
+    int strstart = e.strstart, lookahead = e.lookahead, match_length = e.match_length, match_start = e.match_start;
+    int nsyms = (int)e.nsyms, ins_idx = (int)e.ins_word_idx;
+    uint32_t ins_word = e.ins_word;
+    bool marked = e.mark_pos >= 0;
+    int ins_off = 0, mark_rel = 0, stop_rel = 0;
+    auto rel = [](int64_t a, int64_t base) -> int {
+        const int64_t r = a - base;
+        return r > (1 << 30) ? (1 << 30) : r < -(1 << 30) ? -(1 << 30) : (int)r;
+    };
+    auto rebase = [&]() { ins_off = (int)(e.base - e.ins_base), mark_rel = rel(mark_abs, e.base), stop_rel = rel(stop_abs, e.base); };
+    rebase();
+    auto write_back = [&]() {
+        e.strstart = strstart, e.lookahead = lookahead, e.match_length = match_length, e.match_start = match_start;
+        e.nsyms = nsyms, e.ins_word_idx = ins_idx, e.ins_word = ins_word;
+    };
+    int hb = -(1 << 20);  // the hashes of positions [hb, hb + 64), lane l: position hb + l
+    uint32_t hv = 0;
+    auto insert = [&](int str) -> int {
+        {
+            const int i = ins_off + str, wi = i >> 5;
+            const uint32_t bit = 1u << (i & 31);
+            if (wi == ins_idx) {
+                ins_word |= bit;
+            } else if (wi > ins_idx) {
+                if (ins_idx >= 0) (void)__hip_atomic_fetch_or(bits + ins_idx, ins_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ins_idx = wi, ins_word = bit;
+            } else {
+                (void)__hip_atomic_fetch_or(bits + wi, bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        if ((unsigned)(str - hb) >= 64u) {
+            hb = str;
+            const uint32_t v = le_load32(win + hb + lane + 2);
+            hv = (mul ? hash_mul(v) : crc32c_u32_tab(crc, v)) & kHashMask;
+        }
+        const uint32_t h = (uint32_t)__builtin_amdgcn_readlane((int)hv, __builtin_amdgcn_readfirstlane(str - hb));
+        const int cur = le_head_swap(cval, cnib, cpres, head_g, h, str);
+        if (cur != str) pl[str & kWMask] = (uint16_t)cur;
+        return cur;
+    };
+#ifdef ZS_FV_PROF
+    long long hp[5] = {0, 0, 0, 0, 0}, hp_t = wall_clock64();
+#define HOT_PF(i) { const long long now_ = wall_clock64(); hp[i] += now_ - hp_t; hp_t = now_; }
+#define HOT_PF_OUT() { for (int k_ = 0; k_ < 5; k_++) e.pf[k_] += hp[k_]; }
+#else
+#define HOT_PF(i)
+#define HOT_PF_OUT()
+#endif
+    for (;;) {
+        if (lookahead < kMinLookahead) {
+            write_back();
+            int dummy = 0;
+            le_refill(e, lane, 64, dummy);
+            if (e.suspended) return;
+            if (e.lookahead < kMinLookahead) {  // no more to read: the stream's last loop-tops
+                HOT_PF_OUT();
+                le_run_fast(e, lane, 64);
+                return;
+            }
+            strstart = e.strstart, lookahead = e.lookahead, match_start = e.match_start;
+            ins_idx = (int)e.ins_word_idx, ins_word = e.ins_word;  // (the read's pre-insert)
+            rebase();
+            hb = -(1 << 20);  // (the window may have slid)
+        }
+        if (mark_abs >= 0 && !marked && strstart >= mark_rel) e.mark_pos = e.base + strstart, e.mark_nsyms = nsyms, marked = true;
+        if (stop_abs >= 0 && strstart >= stop_rel) {
+            write_back();
+            HOT_PF_OUT();
+            return;
+        }
+        HOT_PF(0);
+        int hash_head = 0;
+        if (lookahead >= kMinMatch) hash_head = insert(strstart);
+        HOT_PF(1);
+        if (hash_head != 0 && strstart - hash_head <= kMaxDist && search) {
+            // Longest_match (le_longest_match)
+            int chain_length = chain_eff, best_len = best0, cur_match = hash_head;
+            const int limit = strstart > kMaxDist ? strstart - kMaxDist : 0;
+            const int nice = nice_cfg > lookahead ? lookahead : nice_cfg;
+            auto sc = wl + strstart;
+            const uint8_t s0 = sc[0], s1 = sc[1];
+            uint8_t sb0 = sc[best_len - 1], sb1 = sc[best_len];
+            do {
+                if (cur_match >= strstart) break;
+                auto ml = wl + cur_match;
+                const uint8_t mb1 = ml[best_len], mb0 = ml[best_len - 1], m0 = ml[0], m1 = ml[1];
+                const int next = pl[cur_match & kWMask];
+                if (!((mb1 ^ sb1) | (mb0 ^ sb0) | (m0 ^ s0) | (m1 ^ s1))) {
+                    const int len = le_match_len_wave(win + strstart, win + cur_match);
+                    if (len > best_len) {
+                        match_start = cur_match;
+                        best_len = len;
+                        if (len >= nice) break;
+                        sb0 = sc[best_len - 1], sb1 = sc[best_len];
+                    }
+                }
+                cur_match = next;
+            } while (cur_match > limit && --chain_length != 0);
+            match_length = best_len < lookahead ? best_len : lookahead;
+        }
+        HOT_PF(2);
+        if (match_length >= kMinMatch) {
+            if (lane == 0) syms[nsyms] = ((uint32_t)(strstart - match_start) << 16) | (uint32_t)(match_length - kMinMatch);
+            nsyms++;
+            lookahead -= match_length;
+            if (match_length <= lazy && lookahead >= kMinMatch) {
+                match_length--;
+                do {
+                    strstart++;
+                    (void)insert(strstart);
+                } while (--match_length != 0);
+                strstart++;
+            } else {
+                strstart += match_length;
+                match_length = 0;
+            }
+        } else {
+            if (lane == 0) syms[nsyms] = (uint32_t)wl[strstart];
+            nsyms++;
+            lookahead--;
+            strstart++;
+        }
+        HOT_PF(3);
+    }
+}
+#endif
 
 // Deflate.Stored.cs:24-84 (level 0; memLevel 7 -> pending 32 KiB -> max_block_size 32763), flush == Finish.
 ZS_HD_NOINLINE inline void le_run_stored(LitEngine &e, int lane, int nlanes) {
