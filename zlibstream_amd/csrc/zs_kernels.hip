@@ -2470,6 +2470,8 @@ __global__ __launch_bounds__(1024) void zs_fast_run_kernel(const StreamDesc *sd,
     load_crc_tab(tabl, crc_tab_g);
     e.crc_tab = tabl;
     e.hc_val = (uint16_t *)(smem + kTailLds), e.hc_nib = (uint32_t *)(smem + kTailLds + 2 * kHeadCache), e.hc_pres = e.hc_nib + kHeadCache / 8;
+    e.hc_claim = e.hc_pres + kHashSize / 32;
+    for (int i = tid; i < kHeadCache / 32; i += nth) e.hc_claim[i] = 0;
     e.data = s.in;
     e.n = s.n;
     e.lv = lv;
@@ -2598,6 +2600,9 @@ __global__ __launch_bounds__(256) void zs_fast_verify_kernel(const StreamDesc *s
             const uint32_t vb = ib >= 0 ? (bb[ib >> 5] >> (ib & 31)) & 1u : va;  // before run j's start: restored as inserted; require run j-1 agrees
             const uint32_t want = ib >= 0 ? vb : 1u;
             mism |= (va != want);
+#ifdef ZS_FV_PROF
+            if (va != want && j == 1) printf("VERIFY run %d: position %lld run before has %u, this run %u (mark %lld)\n", j, (long long)p, va, want, (long long)b.mark_pos);
+#endif
         }
         if (mism) bad = 1;
         // refills inside the compared window must have happened at the same loop-tops (the string they pre-insert
@@ -2608,6 +2613,9 @@ __global__ __launch_bounds__(256) void zs_fast_verify_kernel(const StreamDesc *s
                 bool found = false;
                 for (int v = 0; v < b.n_ev; v++) found |= b.ev[v] == a.ev[u];
                 if (!found) bad = 1;
+#ifdef ZS_FV_PROF
+                if (!found && j == 1) printf("VERIFY run %d: event of the run before at %lld not in this run\n", j, (long long)a.ev[u]);
+#endif
             }
             for (int v = 0; v < b.n_ev; v++) {
                 if (b.ev[v] < lo - 1 || b.ev[v] > b.mark_pos) continue;

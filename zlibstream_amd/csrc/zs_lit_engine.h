@@ -109,7 +109,7 @@ struct LitEngine {
     // when the slot holds bucket h -- and an entry that makes room goes back to the table; hc_pres has a bit per bucket: 0 =
     // the bucket is empty in the table too (a first occurrence costs no load).  nullptr: no cache
     uint16_t *hc_val;
-    uint32_t *hc_nib, *hc_pres;
+    uint32_t *hc_nib, *hc_pres, *hc_claim;  // (hc_claim: a bit per slot, all 0 between two uses: le_run_fast_hot's runs of first occurrences)
     // outputs
     uint32_t *syms;     // symbol i: dist << 16 | lc  (dist 0 = literal)
     int64_t nsyms;      // symbols emitted so far in this stream (body + tail)
@@ -126,7 +126,7 @@ ZS_HD void le_defaults(LitEngine &e) {
     e.final_run = 1, e.suspended = 0, e.stopped = 0, e.last_event_abs = -1;
     e.pre_rec = nullptr, e.pre_lo = e.pre_hi = 0;
     e.no_head = 0, e.tail_head[0] = e.tail_head[1] = e.tail_head[2] = 0;
-    e.hc_val = nullptr, e.hc_nib = nullptr, e.hc_pres = nullptr;
+    e.hc_val = nullptr, e.hc_nib = nullptr, e.hc_pres = nullptr, e.hc_claim = nullptr;
     e.block_syms = kBlockSyms, e.block_sym_start = 0, e.block_start_abs = 0, e.defer_start = 0;
     e.nsyms = 0, e.nblocks = 0;
 }
@@ -212,7 +212,7 @@ ZS_HD void le_flush_ins(LitEngine &e) {
 }
 
 constexpr int kHeadCacheBits = 13, kHeadCache = 1 << kHeadCacheBits;  // 8192 slots: 16 KiB of values, 4 KiB of nibbles; 4 KiB of presence bits
-constexpr int kHeadCacheLds = 2 * kHeadCache + kHeadCache / 2 + kHashSize / 8;
+constexpr int kHeadCacheLds = 2 * kHeadCache + kHeadCache / 2 + kHashSize / 8 + kHeadCache / 8;
 static_assert(kHashSize == 4 * kHeadCache, "a slot's tag is two bits");
 // head[h] as InsertString reads it, with `str` left in its place (Deflate.cs:866-877), through the cache; `head` is the table
 // in device memory.  One wave, every lane with the same arguments.
@@ -300,7 +300,34 @@ ZS_HD void le_slide(LitEngine &e, int lane, int nlanes) {
     };
     V4 *w = (V4 *)e.window;
     for (int i = lane; i < kWSize / 16; i += nlanes) w[i] = w[i + kWSize / 16];
-    if (!e.no_head) slide16(e.head, kHashSize);
+    // (a table in device memory -- the speculative runs' -- eight loads in flight per lane: one at a time the 64 round trips of a
+    // wave were 50 us of every slide)
+    auto slide16_far = [&](uint16_t *a, int count) {
+        typedef __attribute__((address_space(1))) V4 *g_v4p;
+        const g_v4p v = (g_v4p)a;
+        int i = lane;
+        for (; i + 7 * nlanes < count / 8; i += 8 * nlanes) {
+            V4 t[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) t[u] = v[i + u * nlanes];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+#pragma unroll
+                for (int k = 0; k < 4; k++) t[u].x[k] = t[u].x[k] & 0x7FFF7FFFu & (((t[u].x[k] >> 15) & 0x00010001u) * 0xFFFFu);
+                v[i + u * nlanes] = t[u];
+            }
+        }
+        for (; i < count / 8; i += nlanes) {
+            V4 t = v[i];
+#pragma unroll
+            for (int k = 0; k < 4; k++) t.x[k] = t.x[k] & 0x7FFF7FFFu & (((t.x[k] >> 15) & 0x00010001u) * 0xFFFFu);
+            v[i] = t;
+        }
+    };
+    if (!e.no_head) {
+        if (e.hc_val) slide16_far(e.head, kHashSize);
+        else slide16(e.head, kHashSize);
+    }
     if (e.hc_val) slide16(e.hc_val, kHeadCache);  // (a slot nobody holds slides too; a bucket that slides to 0 keeps its presence bit: a load finds the 0)
     slide16(e.prev, kWSize);
 #else
@@ -336,6 +363,30 @@ ZS_HD_NOINLINE inline void le_fill_window(LitEngine &e, int lane, int nlanes) {
         uint8_t *dst = e.window + e.strstart + e.lookahead;
         const uint8_t *src = e.data + e.avail_end;
         ZS_WAVE_SYNC();
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (e.hc_val && ((((uintptr_t)src) ^ ((uintptr_t)dst)) & 15) == 0 && cnt >= 64) {
+            // (the speculative runs: window in LDS, data in device memory, the two equally aligned whenever the caller's buffer is
+            // 16-byte aligned -- the window's first byte is a multiple of 32 KiB of the stream) 16 bytes per lane, four loads in
+            // flight; byte by byte a read of 32 KiB was 512 round trips
+            typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+            typedef const __attribute__((address_space(1))) u32x4_t *g_c4p;
+            typedef const __attribute__((address_space(1))) uint8_t *g_c1p;
+            const int head = (int)((16u - ((uint32_t)(uintptr_t)src & 15u)) & 15u);
+            const g_c1p sb = (g_c1p)src;
+            auto db = ZS_LDS_PTR(uint8_t, dst);
+            if (lane < head) db[lane] = sb[lane];
+            const int n16 = (cnt - head) / 16;
+            const g_c4p sv = (g_c4p)(src + head);
+            auto dv = ZS_LDS_PTR(u32x4_t, (u32x4_t *)(dst + head));
+            int i = lane;
+            for (; i + 3 * nlanes < n16; i += 4 * nlanes) {
+                const u32x4_t a = sv[i], b = sv[i + nlanes], c = sv[i + 2 * nlanes], d = sv[i + 3 * nlanes];
+                dv[i] = a, dv[i + nlanes] = b, dv[i + 2 * nlanes] = c, dv[i + 3 * nlanes] = d;
+            }
+            for (; i < n16; i += nlanes) dv[i] = sv[i];
+            for (int k = head + 16 * n16 + lane; k < cnt; k += nlanes) db[k] = sb[k];
+        } else
+#endif
         for (int i = lane; i < cnt; i += nlanes) dst[i] = src[i];  // lane-strided
         ZS_WAVE_SYNC();
         e.avail_end += cnt;
@@ -735,8 +786,16 @@ __device__ inline void le_run_fast_hot(LitEngine &e, int lane) {
         e.strstart = strstart, e.lookahead = lookahead, e.match_length = match_length, e.match_start = match_start;
         e.nsyms = nsyms, e.ins_word_idx = ins_idx, e.ins_word = ins_word;
     };
-    int hb = -(1 << 20);  // the hashes of positions [hb, hb + 64), lane l: position hb + l
-    uint32_t hv = 0;
+    int hb = -(1 << 20);  // the hashes of positions [hb, hb + 64), lane l: position hb + l; and their bytes
+    uint32_t hv = 0, lit = 0;
+    auto fill = [&](int at) {
+        hb = at;
+        const uint32_t v = le_load32(win + hb + lane + 2);
+        lit = wl[hb + lane];
+        hv = (mul ? hash_mul(v) : crc32c_u32_tab(crc, v)) & kHashMask;
+    };
+    auto cclaim = ZS_LDS_PTR(uint32_t, e.hc_claim);
+    int lit_streak = 0;  // literals in a row whose buckets had no head
     auto insert = [&](int str) -> int {
         {
             const int i = ins_off + str, wi = i >> 5;
@@ -750,11 +809,7 @@ __device__ inline void le_run_fast_hot(LitEngine &e, int lane) {
                 (void)__hip_atomic_fetch_or(bits + wi, bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
-        if ((unsigned)(str - hb) >= 64u) {
-            hb = str;
-            const uint32_t v = le_load32(win + hb + lane + 2);
-            hv = (mul ? hash_mul(v) : crc32c_u32_tab(crc, v)) & kHashMask;
-        }
+        if ((unsigned)(str - hb) >= 64u) fill(str);
         const uint32_t h = (uint32_t)__builtin_amdgcn_readlane((int)hv, __builtin_amdgcn_readfirstlane(str - hb));
         const int cur = le_head_swap(cval, cnib, cpres, head_g, h, str);
         if (cur != str) pl[str & kWMask] = (uint16_t)cur;
@@ -783,6 +838,7 @@ __device__ inline void le_run_fast_hot(LitEngine &e, int lane) {
             ins_idx = (int)e.ins_word_idx, ins_word = e.ins_word;  // (the read's pre-insert)
             rebase();
             hb = -(1 << 20);  // (the window may have slid)
+            HOT_PF(4);
         }
         if (mark_abs >= 0 && !marked && strstart >= mark_rel) e.mark_pos = e.base + strstart, e.mark_nsyms = nsyms, marked = true;
         if (stop_abs >= 0 && strstart >= stop_rel) {
@@ -791,30 +847,88 @@ __device__ inline void le_run_fast_hot(LitEngine &e, int lane) {
             return;
         }
         HOT_PF(0);
+        // A run of first occurrences (the first period of an image row: 256 literals): positions whose buckets have no head at
+        // all -- the presence bit says so without a load -- are literals whatever else happens, and as long as no two of them
+        // share a slot of the cache their inserts do not meet either: up to 64 loop-tops at once, a position per lane.  A lane
+        // is out if its bucket has a head, if a lane below it claimed its slot (a returning LDS atomic on a bit per slot), or if
+        // its loop-top would read, mark or stop; the lanes below the first such lane go.
+        if (lit_streak >= 2 && strstart > 0 && e.hc_claim) {
+            if (hb != strstart) fill(strstart);
+            int cap = lookahead - kMinLookahead + 1;
+            if (mark_abs >= 0 && !marked && mark_rel - strstart < cap) cap = mark_rel - strstart;
+            if (stop_abs >= 0 && stop_rel - strstart < cap) cap = stop_rel - strstart;
+            const uint32_t h = hv, i = h & (uint32_t)(kHeadCache - 1), sh = 4u * (i & 7u), cbit = 1u << (i & 31u);
+            const uint32_t pw = cpres[h >> 5], have = (cnib[i >> 3] >> sh) & 15u, cv = cval[i];
+            const uint32_t was = __hip_atomic_fetch_or(cclaim + (i >> 5), cbit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            // no head anywhere, or the slot holds the bucket and its head is out of reach (the same strings 64 KiB earlier): no search
+            const int str = strstart + lane;
+            const bool absent = ((pw >> (h & 31u)) & 1u) == 0, hit = have == (8u | (h >> kHeadCacheBits));
+            const bool far = hit && (cv == 0 || str - (int)cv > kMaxDist);
+            const bool bad = !(absent || far) || (was & cbit) != 0 || lane >= cap;
+            const uint64_t bm = __ballot(bad);
+            (void)__hip_atomic_fetch_and(cclaim + (i >> 5), ~cbit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const int m = bm ? (int)__builtin_ctzll(bm) : 64;
+            if (m > 0) {
+                if (lane < m) {
+                    if (!hit) {
+                        if (have & 8u) head_g[((have & 3u) << kHeadCacheBits) | i] = (uint16_t)cv;
+                        (void)__hip_atomic_fetch_and(cnib + (i >> 3), ~(15u << sh), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        (void)__hip_atomic_fetch_or(cnib + (i >> 3), (8u | (h >> kHeadCacheBits)) << sh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        (void)__hip_atomic_fetch_or(cpres + (h >> 5), 1u << (h & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                    cval[i] = (uint16_t)str;
+                    pl[str & kWMask] = hit ? (uint16_t)cv : (uint16_t)0;
+                    syms[nsyms + lane] = lit;
+                }
+                // the bits of positions [strstart, strstart + m), as m inserts in a row leave them
+                for (int i0 = ins_off + strstart, left = m; left > 0;) {
+                    const int wi = i0 >> 5, take = 32 - (i0 & 31) < left ? 32 - (i0 & 31) : left;
+                    const uint32_t mask = (take >= 32 ? 0xFFFFFFFFu : ((1u << take) - 1u)) << (i0 & 31);
+                    if (wi == ins_idx) {
+                        ins_word |= mask;
+                    } else if (wi > ins_idx) {
+                        if (ins_idx >= 0) (void)__hip_atomic_fetch_or(bits + ins_idx, ins_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        ins_idx = wi, ins_word = mask;
+                    } else {
+                        (void)__hip_atomic_fetch_or(bits + wi, mask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    i0 += take, left -= take;
+                }
+                strstart += m, lookahead -= m, nsyms += m;
+                HOT_PF(3);
+                continue;
+            }
+            lit_streak = 0;
+        }
         int hash_head = 0;
         if (lookahead >= kMinMatch) hash_head = insert(strstart);
         HOT_PF(1);
         if (hash_head != 0 && strstart - hash_head <= kMaxDist && search) {
-            // Longest_match (le_longest_match)
+            // Longest_match (le_longest_match).  The reference looks at four bytes of a candidate before it compares
+            // (Deflate.cs:1072-1078); a candidate that fails them has at most best_len equal bytes, so comparing every candidate
+            // gives the same answer -- and here the compare is one LDS round trip for all 258 bytes (a lane per 8 bytes), the same
+            // round trip that brings the candidate's link: one per candidate instead of two
             int chain_length = chain_eff, best_len = best0, cur_match = hash_head;
             const int limit = strstart > kMaxDist ? strstart - kMaxDist : 0;
             const int nice = nice_cfg > lookahead ? lookahead : nice_cfg;
-            auto sc = wl + strstart;
-            const uint8_t s0 = sc[0], s1 = sc[1];
-            uint8_t sb0 = sc[best_len - 1], sb1 = sc[best_len];
+            const int off = lane < 33 ? lane * 8 : 0;  // 33 x 8 = 264 >= kMaxMatch; the other lanes repeat lane 0's bytes
+            const uint64_t sx = le_load64(win + strstart + off);
             do {
                 if (cur_match >= strstart) break;
-                auto ml = wl + cur_match;
-                const uint8_t mb1 = ml[best_len], mb0 = ml[best_len - 1], m0 = ml[0], m1 = ml[1];
                 const int next = pl[cur_match & kWMask];
-                if (!((mb1 ^ sb1) | (mb0 ^ sb0) | (m0 ^ s0) | (m1 ^ s1))) {
-                    const int len = le_match_len_wave(win + strstart, win + cur_match);
-                    if (len > best_len) {
-                        match_start = cur_match;
-                        best_len = len;
-                        if (len >= nice) break;
-                        sb0 = sc[best_len - 1], sb1 = sc[best_len];
-                    }
+                const uint64_t x = le_load64(win + cur_match + off) ^ sx;
+                const uint64_t differ = __ballot(x != 0 && lane < 33);
+                int len = kMaxMatch;
+                if (differ) {
+                    const int fl = (int)__builtin_ctzll(differ);
+                    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)x, fl), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(x >> 32), fl);
+                    len = fl * 8 + (int)(__builtin_ctzll((uint64_t)lo | ((uint64_t)hi << 32)) >> 3);
+                    len = len < kMaxMatch ? len : kMaxMatch;
+                }
+                if (len > best_len) {
+                    match_start = cur_match;
+                    best_len = len;
+                    if (len >= nice) break;
                 }
                 cur_match = next;
             } while (cur_match > limit && --chain_length != 0);
@@ -836,11 +950,13 @@ __device__ inline void le_run_fast_hot(LitEngine &e, int lane) {
                 strstart += match_length;
                 match_length = 0;
             }
+            lit_streak = 0;
         } else {
             if (lane == 0) syms[nsyms] = (uint32_t)wl[strstart];
             nsyms++;
             lookahead--;
             strstart++;
+            lit_streak = (hash_head == 0 || strstart - 1 - hash_head > kMaxDist) ? lit_streak + 1 : 0;
         }
         HOT_PF(3);
     }
