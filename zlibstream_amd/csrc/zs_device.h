@@ -44,6 +44,8 @@ struct StreamDesc {
     int32_t n_adler;
     int32_t fast_runs; // > 0: DeflateFast by speculative chunk runs (zs_fast_run_kernel); the tail kernel skips the stream
     int32_t run_off;   // index of run 0 in the run arrays
+    int32_t run_slots; // run slots its runs take in the arrays (= fast_runs; more for the one run of a whole stream, whose symbols and bits take the slots in a row)
+    int32_t run_pad_;
     int32_t seg_off;   // index of parse segment 0 in segmap / seg_entry / seg_symbase / seg_stale
     int32_t nsegs;
     int32_t sup_off;   // index of the stream's first row in supmap (one row per kSupSegs parse segments, zs_supmap_kernel)
@@ -186,6 +188,7 @@ struct FastRunOut {
     int64_t final_base;            // window base at the end (last run: decides whether the last block may be stored)
     int64_t sym_dst;               // where the run's own symbols go in the stream's symbol array (set by the stitch kernel)
     int64_t ev[16];                // loop-tops of the refills the run performed
+    int64_t n_match;               // symbols that took the engine a loop-top of their own (warm-up included): what one run over the whole stream would cost
     int32_t ok, n_ev;
 };
 

@@ -203,7 +203,7 @@ struct RunOpts {
 // `writes` (optional, one stream only): the Writes of a multi-Write stream, or of one whose Writes carry a flush mode
 bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len, void *const *out, const int64_t *out_cap,
                   int64_t *out_len, int *status, int level, int strategy, int hash_variant, hipStream_t stream,
-                  const WriteSpec *writes = nullptr, bool force_seq = false, RunOpts *ro = nullptr, bool rounds = false,
+                  const WriteSpec *writes = nullptr, int force_seq = 0, RunOpts *ro = nullptr, bool rounds = false,
                   const std::vector<uint8_t> *force_lit = nullptr) {
     if (level == -1) level = 6;
     LevelCfg lv = level_cfg(level);
@@ -288,7 +288,9 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
         // block and is left suspended as it is behind the slow levels' bulk runs)
         const bool fast_one = lv.func == 1 && strategy != kRle && regular && len >= kMinLookahead && !cont && !resume &&
                               ((!flushing && final_run && !ro && (!multi || fast_multi)) || (ro && (!multi || fast_multi) && !inner_flush && !lit_forced && !getenv("ZS_NO_FAST_RESUME")));
-        const bool fast_par = fast_one && !multi && !force_seq && !ro && len >= kFastMinInput;
+        // (force_seq: 1 -- the runs did not verify, or the data does not look periodic: the sweeps; 2 -- they did not verify and the
+        // stream is few symbols: one run of the engine for the whole stream, below)
+        const bool fast_par = fast_one && !multi && force_seq != 1 && !ro && len >= kFastMinInput;
         s.fv_end = ((fast_one && !fast_par && !getenv("ZS_NO_FAST_VEC")) || fast_resume) ? (int32_t)(len - kMinLookahead) : -1;
         s.ins_bits = nullptr;
         if (s.fv_end >= 0) {
@@ -370,9 +372,11 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
         s.sup_off = (int32_t)pl.n_sups;
         pl.n_sups += (s.nsegs + kSupSegs - 1) / kSupSegs;
         // levels 1-3, one Write, large enough: speculative chunk runs instead of one sequential engine
-        s.fast_runs = fast_par ? (int32_t)((len + kFastChunk - 1) / kFastChunk) : 0;
+        s.fast_runs = fast_par ? (force_seq == 2 ? 1 : (int32_t)((len + kFastChunk - 1) / kFastChunk)) : 0;
+        s.run_slots = fast_par ? (force_seq == 2 ? (int32_t)((len + 4096) / kFastChunk + 1) : s.fast_runs) : 0;
+        s.run_pad_ = 0;
         s.run_off = (int32_t)pl.n_runs;
-        pl.n_runs += s.fast_runs;
+        pl.n_runs += s.run_slots;
         pl.w_runs.add(i, s.fast_runs);
         s.blk_off = (int32_t)pl.n_blocks;
         // level 0 runs with memLevel 7: a block is flushed every 8191 symbols (only Rle tallies symbols there)
@@ -1057,7 +1061,7 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
     if (pl.n_runs) {
         // DeflateFast by speculative chunk runs; a run whose hand-over state does not verify sends the batch to the
         // sequential engine (the result is the reference's bytes either way)
-        if (!getenv("ZS_FAST_NO_PROBE")) {
+        if (!getenv("ZS_FAST_NO_PROBE") && force_seq == 0) {
             // only data that looks periodic is worth the attempt (zs_fast_probe_kernel); anything else goes to the sweeps right away
             hipLaunchKernelGGL(zs_fast_probe_kernel, dim3((unsigned)n), dim3(256), 0, stream, d_sd, dev<uint16_t>(c->link), dev<int32_t>(c->run_fail));
             std::vector<int32_t> np((size_t)n, 0);
@@ -1066,14 +1070,14 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
             for (int i = 0; i < n; i++)
                 if (np[(size_t)i]) {
                     ZS_HIP(c, hipStreamSynchronize(c->aux));  // (the forked passes read the workspace that is about to be reused)
-                    return run_pipeline(c, n, in, in_len, out, out_cap, out_len, status, level, strategy, hash_variant, stream, writes, true, ro, false, force_lit);
+                    return run_pipeline(c, n, in, in_len, out, out_cap, out_len, status, level, strategy, hash_variant, stream, writes, 1, ro, false, force_lit);
                 }
         }
         ZS_HIP(c, hipMemsetAsync(c->run_fail.p, 0, 4 * (size_t)n + 64, stream));
-        hipLaunchKernelGGL(zs_fast_run_kernel, dim3((unsigned)pl.n_runs), dim3(1024), kFastRunLds, stream, d_sd, d_work + o_runs,
+        hipLaunchKernelGGL(zs_fast_run_kernel, dim3((unsigned)pl.w_runs.size()), dim3(1024), kFastRunLds, stream, d_sd, d_work + o_runs,
                            dev<uint16_t>(c->link), dev<uint32_t>(c->run_syms), dev<uint32_t>(c->run_bits), dev<uint8_t>(c->run_scratch),
                            dev<FastRunOut>(c->run_outs), c->crc_tab, lv, strategy, hash_variant);
-        hipLaunchKernelGGL(zs_fast_verify_kernel, dim3((unsigned)pl.n_runs), dim3(256), 0, stream, d_sd, d_work + o_runs,
+        hipLaunchKernelGGL(zs_fast_verify_kernel, dim3((unsigned)pl.w_runs.size()), dim3(256), 0, stream, d_sd, d_work + o_runs,
                            dev<uint32_t>(c->run_bits), dev<FastRunOut>(c->run_outs), dev<int32_t>(c->run_fail));
         std::vector<int32_t> rfail((size_t)n, 0);
         ZS_HIP(c, hipMemcpyAsync(rfail.data(), c->run_fail.p, 4 * (size_t)n, hipMemcpyDeviceToHost, stream));
@@ -1082,19 +1086,38 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
             if (rfail[(size_t)i]) {
                 ZS_HIP(c, hipStreamSynchronize(c->aux));  // the forked tree pass reads the workspace that is about to be reused
                 c->fast_fallbacks++;
-                if (getenv("ZS_DEBUG")) {
-                    std::vector<FastRunOut> ro((size_t)pl.n_runs);
-                    (void)hipMemcpy(ro.data(), c->run_outs.p, sizeof(FastRunOut) * ro.size(), hipMemcpyDeviceToHost);
+                std::vector<FastRunOut> outs((size_t)pl.n_runs);
+                ZS_HIP(c, hipMemcpy(outs.data(), c->run_outs.p, sizeof(FastRunOut) * outs.size(), hipMemcpyDeviceToHost));
+                if (getenv("ZS_DEBUG"))
                     for (int j = 0; j < pl.sd[(size_t)i].fast_runs; j++) {
-                        const FastRunOut &o = ro[(size_t)pl.sd[(size_t)i].run_off + j];
+                        const FastRunOut &o = outs[(size_t)pl.sd[(size_t)i].run_off + j];
                         fprintf(stderr, "zs: stream %d run %d ok=%d mark=%lld (+%lld syms) end=%lld nsyms=%lld n_ev=%d\n", i, j, o.ok,
                                 (long long)o.mark_pos, (long long)o.mark_nsyms, (long long)o.end_pos, (long long)o.nsyms, o.n_ev);
                     }
+                // Data whose parse does not fall back into step (a period that is no divisor of anything, zeros, 8 KiB rows): the
+                // rounds settle one range a round on it -- the stream at one workgroup's 46 / 35 / 20 MB/s -- while one run of
+                // the engine over the whole stream costs ~1 us a symbol, and the runs have just counted the symbols: 5 MiB of a
+                // 7-byte period is 20 K matches, 20 ms against 375; ptt5 nine times over is 600 K symbols, 600 ms against 53.  One run per
+                // stream when that is the shorter way for the batch by a margin (both are estimates).
+                double t_engine = 0, t_sweeps = 0;
+                for (int k = 0; k < n; k++) {
+                    const StreamDesc &sk = pl.sd[(size_t)k];
+                    if (sk.fast_runs <= 0) continue;
+                    // (a run's warm-up is a fifth of it: the counts of whole runs, scaled)
+                    int64_t syms = 0, matches = 0;
+                    for (int j = 0; j < sk.fast_runs; j++) syms += outs[(size_t)sk.run_off + j].nsyms, matches += outs[(size_t)sk.run_off + j].n_match;
+                    const double scale = sk.fast_runs > 1 ? 0.8 : 1.0;
+                    const double te = scale * (1.2e-6 * (double)matches + 0.03e-6 * (double)(syms - matches)) + (double)sk.n / 1.5e9;
+                    if (getenv("ZS_DEBUG")) fprintf(stderr, "zs: stream %d: ~%.0f symbols one at a time, ~%.0f in runs of literals, %d bytes\n", k, scale * (double)matches, scale * (double)(syms - matches), sk.n);
+                    t_engine = std::max(t_engine, te);
+                    t_sweeps = std::max(t_sweeps, (double)sk.n / (level >= 3 ? 20e6 : level == 2 ? 35e6 : 46e6));
                 }
-                return run_pipeline(c, n, in, in_len, out, out_cap, out_len, status, level, strategy, hash_variant, stream, writes, true, ro, false, force_lit);
+                const int mode = (force_seq == 0 && !getenv("ZS_NO_WHOLE_RUNS") && (getenv("ZS_WHOLE_RUNS") || t_engine < 0.7 * t_sweeps)) ? 2 : 1;
+                if (getenv("ZS_DEBUG")) fprintf(stderr, "zs: the runs did not verify: %s (engine %.1f ms, sweeps up to %.1f ms)\n", mode == 2 ? "one run per stream" : "the sweeps", t_engine * 1e3, t_sweeps * 1e3);
+                return run_pipeline(c, n, in, in_len, out, out_cap, out_len, status, level, strategy, hash_variant, stream, writes, mode, ro, false, force_lit);
             }
         hipLaunchKernelGGL(zs_fast_plan_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, d_sd, d_st, dev<FastRunOut>(c->run_outs), n);
-        hipLaunchKernelGGL(zs_fast_stitch_kernel, dim3((unsigned)pl.n_runs), dim3(256), 0, stream, d_sd, d_work + o_runs,
+        hipLaunchKernelGGL(zs_fast_stitch_kernel, dim3((unsigned)pl.w_runs.size()), dim3(256), 0, stream, d_sd, d_work + o_runs,
                            dev<uint32_t>(c->run_syms), dev<FastRunOut>(c->run_outs), dev<uint32_t>(c->syms), dev<int32_t>(c->blk_end),
                            dev<int32_t>(c->blk_top));
         hipLaunchKernelGGL(zs_fast_blocks_kernel, dim3((unsigned)n), dim3(64), 0, stream, d_sd, d_st, dev<FastRunOut>(c->run_outs),

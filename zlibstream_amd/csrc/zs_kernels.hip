@@ -2459,7 +2459,7 @@ __global__ __launch_bounds__(1024) void zs_fast_run_kernel(const StreamDesc *sd,
     if (x < 0) x = 0;
     uint8_t *sc = run_scratch + run * kFastRunScratch;
     uint32_t *bits = run_bits + run * kFastRunBitWords;
-    for (int64_t i = tid; i < kFastRunBitWords; i += nth) bits[i] = 0;
+    for (int64_t i = tid; i < kFastRunBitWords * (s.fast_runs == 1 ? (int64_t)s.run_slots : 1); i += nth) bits[i] = 0;
     LitEngine e;
     le_defaults(e);
     e.window = smem;
@@ -2544,6 +2544,7 @@ __global__ __launch_bounds__(1024) void zs_fast_run_kernel(const StreamDesc *sd,
         o.final_base = e.base;
         o.sym_dst = 0;
         o.ok = 1, o.n_ev = e.n_ev;
+        o.n_match = e.n_match;
         if (j == 0) o.mark_pos = 0, o.mark_nsyms = 0;
     }
 }

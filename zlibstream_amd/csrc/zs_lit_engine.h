@@ -109,6 +109,7 @@ struct LitEngine {
     // when the slot holds bucket h -- and an entry that makes room goes back to the table; hc_pres has a bit per bucket: 0 =
     // the bucket is empty in the table too (a first occurrence costs no load).  nullptr: no cache
     uint16_t *hc_val;
+    int64_t n_match;  // loop-tops le_run_fast_hot took one at a time -- matches, literals outside the runs of literals (the speculative runs report it)
     uint32_t *hc_nib, *hc_pres, *hc_claim;  // (hc_claim: a bit per slot, all 0 between two uses: le_run_fast_hot's runs of first occurrences)
     // outputs
     uint32_t *syms;     // symbol i: dist << 16 | lc  (dist 0 = literal)
@@ -126,7 +127,7 @@ ZS_HD void le_defaults(LitEngine &e) {
     e.final_run = 1, e.suspended = 0, e.stopped = 0, e.last_event_abs = -1;
     e.pre_rec = nullptr, e.pre_lo = e.pre_hi = 0;
     e.no_head = 0, e.tail_head[0] = e.tail_head[1] = e.tail_head[2] = 0;
-    e.hc_val = nullptr, e.hc_nib = nullptr, e.hc_pres = nullptr, e.hc_claim = nullptr;
+    e.hc_val = nullptr, e.hc_nib = nullptr, e.hc_pres = nullptr, e.hc_claim = nullptr, e.n_match = 0;
     e.block_syms = kBlockSyms, e.block_sym_start = 0, e.block_start_abs = 0, e.defer_start = 0;
     e.nsyms = 0, e.nblocks = 0;
 }
@@ -772,7 +773,7 @@ __device__ inline void le_run_fast_hot(LitEngine &e, int lane) {
     const int best0 = e.prev_length == 0 ? 1 : e.prev_length, chain_eff = e.prev_length >= e.lv.good ? e.lv.chain >> 2 : e.lv.chain;
     const int64_t mark_abs = e.mark_abs, stop_abs = e.stop_abs;
     int strstart = e.strstart, lookahead = e.lookahead, match_length = e.match_length, match_start = e.match_start;
-    int nsyms = (int)e.nsyms, ins_idx = (int)e.ins_word_idx;
+    int nsyms = (int)e.nsyms, ins_idx = (int)e.ins_word_idx, n_match = 0;
     uint32_t ins_word = e.ins_word;
     bool marked = e.mark_pos >= 0;
     int ins_off = 0, mark_rel = 0, stop_rel = 0;
@@ -784,7 +785,7 @@ __device__ inline void le_run_fast_hot(LitEngine &e, int lane) {
     rebase();
     auto write_back = [&]() {
         e.strstart = strstart, e.lookahead = lookahead, e.match_length = match_length, e.match_start = match_start;
-        e.nsyms = nsyms, e.ins_word_idx = ins_idx, e.ins_word = ins_word;
+        e.nsyms = nsyms, e.ins_word_idx = ins_idx, e.ins_word = ins_word, e.n_match = n_match;
     };
     int hb = -(1 << 20);  // the hashes of positions [hb, hb + 64), lane l: position hb + l; and their bytes
     uint32_t hv = 0, lit = 0;
@@ -901,6 +902,7 @@ __device__ inline void le_run_fast_hot(LitEngine &e, int lane) {
             lit_streak = 0;
         }
         int hash_head = 0;
+        n_match++;  // (a loop-top taken by itself: a match, or a literal outside the runs of literals)
         if (lookahead >= kMinMatch) hash_head = insert(strstart);
         HOT_PF(1);
         if (hash_head != 0 && strstart - hash_head <= kMaxDist && search) {
