@@ -207,6 +207,10 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
                   const std::vector<uint8_t> *force_lit = nullptr) {
     if (level == -1) level = 6;
     LevelCfg lv = level_cfg(level);
+    static const bool host_times = getenv("ZS_HOST_TIMES") != nullptr;  // (where the host's share of a call goes: stderr, microseconds)
+    const auto ht0 = std::chrono::steady_clock::now();
+    auto ht_us = [&]() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - ht0).count(); };
+    double ht_plan = 0, ht_launched = 0;
     for (int i = 0; i < n; i++) {  // what the caller sees if a HIP call fails before the results are known
         out_len[i] = 0;
         if (status) status[i] = ZS_STREAM_ERROR;
@@ -644,6 +648,7 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
     // stream beside the link and match kernels (their stages are reported as 0: 0.015 and 0.03 ms on english64 alone, and
     // their events are not recorded).  The host enqueues them behind the first launches of the critical path: every call
     // in front of K1 is ~5 us in which the device waits for the host.
+    ht_plan = ht_us();
     ZS_HIP(c, hipEventRecord(c->ev_pre0, stream));
     auto side_work = [&]() -> bool {
         ZS_HIP(c, hipStreamWaitEvent(c->aux, c->ev_pre0, 0));
@@ -1146,7 +1151,9 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
     ZS_HIP(c, hipGetLastError());
     StreamState *hst = (StreamState *)c->pinned;
     ZS_HIP(c, hipMemcpyAsync(hst, d_st, sizeof(StreamState) * (size_t)n, hipMemcpyDeviceToHost, stream));
+    ht_launched = ht_us();
     ZS_HIP(c, hipStreamSynchronize(stream));
+    if (host_times) fprintf(stderr, "zs: host: plan + uploads %.0f us, all launched at %.0f us, device done at %.0f us\n", ht_plan, ht_launched, ht_us());
     c->last_op = lv.func == 1 ? 2 : 0;
     if (getenv("ZS_DEBUG_CHAIN") && n == 1) {  // the chain of one position as the kernels saw it (buffer positions)
         const int64_t q0 = atoll(getenv("ZS_DEBUG_CHAIN")) - (ro ? ro->abs_off : 0);
