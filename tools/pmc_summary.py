@@ -98,7 +98,7 @@ if tab:
               open(os.path.join(dst, "%s_pmc_insts_english64_L6.json" % tag), "w"), indent=1)
 
 # round 3: kernel statistics of the paths beside the headline, the counters of the DeflateFast kernel in a batch
-for w in ("fast512", "fast1_L1", "fast1_L3", "fast64_L1", "fast64_L3", "writes1000", "scanlines", "flushed64k"):
+for w in ("fast512", "fast1_L1", "fast1_L3", "fast64_L1", "fast64_L3", "writes1000", "scanlines", "flushed64k", "sparse64_L1"):
     stw = glob.glob(os.path.join(src, "stats_" + w, "**", "*kernel_stats.csv"), recursive=True)
     if stw:
         rows = list(csv.reader(open(stw[0])))
@@ -178,7 +178,7 @@ for name, out in (("flush_resume.log", "flush_resume.log"), ("patho.jsonl", "pat
 
 for name, out in (("bench_default.json", "bench_default.json"), ("bench_full.json", "bench_full.json"), ("bench_english64.json", "bench_english64_L6.json"), ("bench_sparse64.json", "bench_sparse64_L6.json"),
                   ("bench_batch128.json", "bench_batch128x1MiB_L6.json"), ("bench_inflate.json", "bench_inflate1g.json"),
-                  ("time_levels.jsonl", "time_levels.jsonl"), ("flush_resume_L1.log", "flush_resume_L1.log"), ("small_trace.log", "small_trace.log"), ("host_path.jsonl", "host_path.jsonl"),
+                  ("time_levels.jsonl", "time_levels.jsonl"), ("flush_resume_L1.log", "flush_resume_L1.log"), ("small_trace.log", "small_trace.log"), ("sparse_l1.log", "sparse64_levels_1_2_3.log"), ("spec_cases.log", "image_like_data_at_the_fast_levels.log"), ("flush_trace.log", "flush_trace.log"), ("host_path.jsonl", "host_path.jsonl"),
                   ("bench_english64_pipelined.json", "bench_english64_L6_pipelined3.json"),
                   ("bench_inflate_single.json", "bench_inflate_single64.json")):
     p = os.path.join(src, name)

@@ -53,6 +53,11 @@ python3 $R/tools/fast_levels.py > $O/fast_levels.log 2> $O/fast_levels.err
 python3 $R/tools/multiwrite_check.py > $O/multiwrite_check.log 2> $O/multiwrite_check.err
 python3 $R/tools/fast_rounds.py > $O/fast_rounds.log 2> $O/fast_rounds.err
 python3 $R/tools/fast_big.py 64 > $O/fast_big.log 2> $O/fast_big.err
+# round 5: config 3 at level 1 (the speculative runs' engine), image-like data whose runs do not verify, a stream that flushes per call
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_sparse64_L1 -o run -- python3 $R/tools/sparse_l1.py 1 > $O/case_sparse64_L1.log 2> $O/stats_sparse64_L1.err
+python3 $R/tools/sparse_l1.py > $O/sparse_l1.log 2> $O/sparse_l1.err
+python3 $R/tools/spec_cases.py > $O/spec_cases.log 2> $O/spec_cases.err
+for a in "6 65536 64" "6 8192 128" "1 65536 64" "1 8192 128" "6 1048576 16" "1 1048576 16"; do python3 $R/tools/flush_trace.py $a >> $O/flush_trace.log 2>> $O/flush_trace.err; done
 echo "tables done"
 fi
 find $O -name "*.csv" -size +20M -delete

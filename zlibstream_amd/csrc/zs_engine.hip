@@ -294,7 +294,8 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
                               ((!flushing && final_run && !ro && (!multi || fast_multi)) || (ro && (!multi || fast_multi) && !inner_flush && !lit_forced && !getenv("ZS_NO_FAST_RESUME")));
         // (force_seq: 1 -- the runs did not verify, or the data does not look periodic: the sweeps; 2 -- they did not verify and the
         // stream is few symbols: one run of the engine for the whole stream, below)
-        const bool fast_par = fast_one && !multi && force_seq != 1 && !ro && len >= kFastMinInput;
+        static const int64_t fast_min_input = getenv("ZS_FAST_MIN_INPUT") ? atoll(getenv("ZS_FAST_MIN_INPUT")) : kFastMinInput;
+        const bool fast_par = fast_one && !multi && force_seq != 1 && !ro && len >= fast_min_input;
         s.fv_end = ((fast_one && !fast_par && !getenv("ZS_NO_FAST_VEC")) || fast_resume) ? (int32_t)(len - kMinLookahead) : -1;
         s.ins_bits = nullptr;
         if (s.fv_end >= 0) {
