@@ -643,6 +643,23 @@ def test_speculative_runs_engine_on_image_like_data(engine, oracle):
     # several such streams in one batch, and beside a text stream that takes the sweeps
     batch = [cases["rows"], datagen.english(1 << 20, 5), cases["rows, odd size"], cases["ptt5 x 9"]]
     assert engine.deflate_batch(batch, level=1) == [oracle.compress(b, 1) for b in batch]
+    # below 4 MiB (from 64 KiB on, a few streams): planned for the sweeps and for the runs, the links decide -- data that is all
+    # period takes the runs (and, where they do not verify, one run of the engine), anything else the sweeps
+    small = {
+        "zeros 1 MiB": bytes(1 << 20), "zeros 100 000": bytes(100000), "period 7": (bytes([1, 2, 3, 4, 5, 6, 7]) * 40000)[:270001],
+        "rows 512 x 512": datagen.sparse(512, 512), "rows 4096 x 20": datagen.sparse(4096, 20), "rows 512 x 40": datagen.sparse(512, 40),
+        "runs": np.repeat(rng.integers(0, 4, 3000, dtype=np.uint8), rng.integers(1, 600, 3000)).tobytes(),
+        "text": datagen.english(300000, 8), "ptt5": oracle_binding.corpus("ptt5"), "just 64 KiB of zeros": bytes(65536), "65535 zeros": bytes(65535),
+    }
+    for name, d in small.items():
+        for lvl in (1, 2, 3):
+            assert engine.deflate_batch([d], level=lvl)[0] == oracle.compress(d, lvl), (name, lvl)
+    for names in (("zeros 1 MiB", "rows 512 x 512", "period 7"), ("zeros 1 MiB", "text", "rows 4096 x 20"), ("rows 512 x 40", "65535 zeros", "runs")):
+        batch = [small[k] for k in names]
+        assert engine.deflate_batch(batch, level=1) == [oracle.compress(b, 1) for b in batch], names
+    d = small["rows 512 x 512"]
+    assert engine.deflate_batch([d], level=3, hash_variant=1)[0] == oracle.compress(d, 3, hash_variant=1)
+    assert engine.deflate_batch([d], level=1, strategy=1)[0] == oracle.compress(d, 1, strategy=1)  # Filtered
     # (rows of 16 KiB -- config 3 -- and kennedy.xls verify; rows of 8 KiB, ptt5 and the ramp do not: their parses do not fall back
     # into step inside the warm-up, the batch is redone as rounds, which on such data settle one range a round)
 

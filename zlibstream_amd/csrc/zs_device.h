@@ -178,7 +178,8 @@ constexpr int kCutBudget = 12;    // ... and cuts of any kind (a cut without suc
 // (position + set of inserted strings in the 32 KiB before it) equals the previous run's final state.
 constexpr int kFastChunk = 262144;
 constexpr int kFastWarm = 65536;
-constexpr int kFastMinInput = 4 << 20;  // below this the vector form alone is faster than a failed attempt plus the vector form
+constexpr int kFastMinInput = 4 << 20;  // below this the vector form alone is faster than a failed attempt plus the vector form, unless the data is all period
+constexpr int kFastMinPeriodic = 64 << 10;  // ... in which case the runs are tried from here on (zeros, image rows, a short period: the sweeps settle one range a round on them)
 constexpr int64_t kFastRunSyms = kFastWarm + kFastChunk + 1024;             // symbol slots per run
 constexpr int64_t kFastRunBitWords = (kFastWarm + kFastChunk + 2048) / 32;  // inserted-position bitmap words per run
 constexpr int64_t kFastRunScratch = 2 * kHashSize + 4 * kHashSize;          // u16 head + u32 head32

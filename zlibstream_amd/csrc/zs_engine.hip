@@ -142,6 +142,7 @@ struct Plan {
     int64_t n_pos = 0, n_syms = 0;
     int64_t n_chunks = 0, n_segs = 0, n_sups = 0, n_blocks = 0, n_pieces = 0, n_runs = 0;
     bool any_fv = false, any_rle = false;
+    bool any_dual = false;  // levels 1-3, a few streams below 4 MiB: planned for the sweeps and for the speculative runs, the links decide (zs_fast_probe_kernel)
     int64_t n_rle_tiles = 0;
     int64_t lit_bytes = 0;           // input bytes of this plan that only the literal engine parses
     std::vector<FsChunk> fr_chunks;  // levels 1-3 as rounds over the chunks of the streams (zs_fast_sweep.h "Rounds"); empty: one workgroup per stream
@@ -234,6 +235,16 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
             writes = &rle_one;
         }
     }
+    // Levels 1-3, a few streams of 256 KiB .. 4 MiB: data that is all period (zeros, image rows, a short period) takes the sweeps'
+    // rounds one range a round -- 1 MiB of zeros 57 ms -- and the speculative runs' engine 7; anything else is better off with
+    // the sweeps, and which it is the links tell (zs_fast_probe_kernel).  Such a batch is planned for both; the kernels behind
+    // the link kernel see the one the probe chose.
+    static const int64_t fast_min_input = getenv("ZS_FAST_MIN_INPUT") ? atoll(getenv("ZS_FAST_MIN_INPUT")) : kFastMinPeriodic;
+    bool allow_dual = lv.func == 1 && strategy != kRle && !writes && !ro && !rounds && force_seq == 0 && !force_lit && n <= 16 && !getenv("ZS_NO_FAST_VEC") &&
+                      !getenv("ZS_FAST_NO_ROUNDS");
+    for (int i = 0; i < n && allow_dual; i++) allow_dual = in_len[i] >= fast_min_input && in_len[i] < kFastMinInput;
+    bool dual_broken = false;
+plan_again:
     Plan pl;
     pl.sd.resize((size_t)n);
     // positions per workgroup of the link kernel (each replays 32 Ki positions of warm-up first): long spans for a
@@ -294,9 +305,10 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
                               ((!flushing && final_run && !ro && (!multi || fast_multi)) || (ro && (!multi || fast_multi) && !inner_flush && !lit_forced && !getenv("ZS_NO_FAST_RESUME")));
         // (force_seq: 1 -- the runs did not verify, or the data does not look periodic: the sweeps; 2 -- they did not verify and the
         // stream is few symbols: one run of the engine for the whole stream, below)
-        static const int64_t fast_min_input = getenv("ZS_FAST_MIN_INPUT") ? atoll(getenv("ZS_FAST_MIN_INPUT")) : kFastMinInput;
-        const bool fast_par = fast_one && !multi && force_seq != 1 && !ro && len >= fast_min_input;
-        s.fv_end = ((fast_one && !fast_par && !getenv("ZS_NO_FAST_VEC")) || fast_resume) ? (int32_t)(len - kMinLookahead) : -1;
+        // (a run's buffers are 1.7 MB whatever the stream's length: streams below 4 MiB only in batches of a few -- allow_dual)
+        const bool fast_par = fast_one && !multi && force_seq != 1 && !ro && (len >= kFastMinInput || allow_dual || (force_seq == 2 && n <= 16 && len >= fast_min_input));
+        if (allow_dual && !fast_par) dual_broken = true;
+        s.fv_end = ((fast_one && (!fast_par || allow_dual) && !getenv("ZS_NO_FAST_VEC")) || fast_resume) ? (int32_t)(len - kMinLookahead) : -1;
         s.ins_bits = nullptr;
         if (s.fv_end >= 0) {
             pl.any_fv = true;
@@ -429,6 +441,11 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
             pl.lit_bytes += std::max<int64_t>(0, len - from - (kMinLookahead - 1));
         }
     }
+    if (allow_dual && dual_broken) {  // (a stream the fast forms do not take after all: the batch as it always was planned)
+        allow_dual = false, dual_broken = false;
+        goto plan_again;
+    }
+    pl.any_dual = allow_dual;
     c->lit_engine_bytes += pl.lit_bytes;
     c->fast_rounds = 0;
     const bool no_rounds_this_call = c->no_rounds_once;
@@ -882,6 +899,27 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
                            dev<uint16_t>(c->link), c->crc_tab, hash_variant, (int)link_span);
     if (ro && ro->resume)
         hipLaunchKernelGGL(zs_import_chains_kernel, dim3(64), dim3(1024), 0, stream, d_sd, 0, dev<uint16_t>(c->link), c->crc_tab, hash_variant, ro->p0);
+    if (pl.any_dual) {
+        // the links are there: sweeps or speculative runs (above, allow_dual)?  The other plan is struck from the descriptors
+        bool periodic = true;
+        if (!getenv("ZS_FAST_NO_PROBE")) {
+            hipLaunchKernelGGL(zs_fast_probe_kernel, dim3((unsigned)n), dim3(256), 0, stream, d_sd, dev<uint16_t>(c->link), dev<int32_t>(c->run_fail));
+            std::vector<int32_t> np((size_t)n, 0);
+            ZS_HIP(c, hipMemcpyAsync(np.data(), c->run_fail.p, 4 * (size_t)n, hipMemcpyDeviceToHost, stream));
+            ZS_HIP(c, hipStreamSynchronize(stream));
+            for (int i = 0; i < n; i++) periodic = periodic && np[(size_t)i] == 0;
+        }
+        for (int i = 0; i < n; i++) {
+            StreamDesc &sk = pl.sd[(size_t)i];
+            if (periodic) sk.fv_end = -1, sk.fr_first = 0, sk.fr_n = 0;
+            else sk.fast_runs = 0, sk.run_slots = 0;
+        }
+        if (periodic) pl.any_fv = false, pl.fr_chunks.clear(), pl.fr_max_n = 0;
+        else pl.n_runs = 0;
+        memcpy(c->pinned, pl.sd.data(), sizeof(StreamDesc) * (size_t)n);  // (the staging copy's uploads are through: the stream was just waited for)
+        ZS_HIP(c, hipMemcpyAsync(c->sd.p, c->pinned, sizeof(StreamDesc) * (size_t)n, hipMemcpyHostToDevice, stream));
+        if (getenv("ZS_DEBUG")) fprintf(stderr, "zs: %d stream(s) below 4 MiB at level %d: %s\n", n, level, periodic ? "all period, the speculative runs" : "the sweeps");
+    }
     mark(3);
     if (strategy == kHuffmanOnly) {
         // Longest_match is never called (Deflate.Slow.cs:66-71): every position has no match
@@ -1067,7 +1105,7 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
     if (pl.n_runs) {
         // DeflateFast by speculative chunk runs; a run whose hand-over state does not verify sends the batch to the
         // sequential engine (the result is the reference's bytes either way)
-        if (!getenv("ZS_FAST_NO_PROBE") && force_seq == 0) {
+        if (!getenv("ZS_FAST_NO_PROBE") && force_seq == 0 && !pl.any_dual) {
             // only data that looks periodic is worth the attempt (zs_fast_probe_kernel); anything else goes to the sweeps right away
             hipLaunchKernelGGL(zs_fast_probe_kernel, dim3((unsigned)n), dim3(256), 0, stream, d_sd, dev<uint16_t>(c->link), dev<int32_t>(c->run_fail));
             std::vector<int32_t> np((size_t)n, 0);

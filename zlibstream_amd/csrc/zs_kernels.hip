@@ -2572,7 +2572,9 @@ __global__ __launch_bounds__(256) void zs_fast_probe_kernel(const StreamDesc *sd
     }
     atomicAdd(&same, mine);
     __syncthreads();
-    if (threadIdx.x == 0) not_periodic[blockIdx.x] = same * 4 < 64 * 256 * 3;
+    // (below 4 MiB a failed attempt is not small beside the sweeps it falls back to: only what is nearly all period -- image rows,
+    // runs, a short period: 0.97 and more; ptt5's 0.80 stays with the sweeps)
+    if (threadIdx.x == 0) not_periodic[blockIdx.x] = s.n >= kFastMinInput ? same * 4 < 64 * 256 * 3 : same * 16 < 64 * 256 * 15;
 }
 
 // run j (j >= 1) is exact iff it entered its chunk where run j-1 stopped, with the same strings inserted in the
