@@ -45,7 +45,7 @@ struct StreamDesc {
     int32_t fast_runs; // > 0: DeflateFast by speculative chunk runs (zs_fast_run_kernel); the tail kernel skips the stream
     int32_t run_off;   // index of run 0 in the run arrays
     int32_t run_slots; // run slots its runs take in the arrays (= fast_runs; more for the one run of a whole stream, whose symbols and bits take the slots in a row)
-    int32_t run_pad_;
+    int32_t run_chunk; // bytes of the stream per run (64 .. 256 KiB: as many runs as the chip has CUs, if the batch is long enough for that)
     int32_t seg_off;   // index of parse segment 0 in segmap / seg_entry / seg_symbase / seg_stale
     int32_t nsegs;
     int32_t sup_off;   // index of the stream's first row in supmap (one row per kSupSegs parse segments, zs_supmap_kernel)

@@ -252,6 +252,10 @@ plan_again:
     int64_t total_len = 0;
     for (int i = 0; i < n; i++) total_len += in_len[i];
     const int64_t link_span = total_len >= (48ll << 20) ? 262144 : total_len >= (24ll << 20) ? 131072 : 65536;
+    // a speculative run's share of its stream (levels 1-3, image-like data): a run is one wave on one CU, so a batch shorter than
+    // 256 runs of 256 KiB is cut finer, down to 64 KiB a run (64 KiB of warm-up in front of each: at most twice the work)
+    const int run_chunk = getenv("ZS_FAST_CHUNK") ? std::max(65536, std::min((int)kFastChunk, atoi(getenv("ZS_FAST_CHUNK")) & ~65535))
+                                                  : (int)std::max<int64_t>(65536, std::min<int64_t>(kFastChunk, ((total_len / 256 + 65535) >> 16) << 16));
     for (int i = 0; i < n; i++) {
         StreamDesc &s = pl.sd[(size_t)i];
         int64_t len = in_len[i];
@@ -389,9 +393,9 @@ plan_again:
         s.sup_off = (int32_t)pl.n_sups;
         pl.n_sups += (s.nsegs + kSupSegs - 1) / kSupSegs;
         // levels 1-3, one Write, large enough: speculative chunk runs instead of one sequential engine
-        s.fast_runs = fast_par ? (force_seq == 2 ? 1 : (int32_t)((len + kFastChunk - 1) / kFastChunk)) : 0;
+        s.run_chunk = run_chunk;
+        s.fast_runs = fast_par ? (force_seq == 2 ? 1 : (int32_t)((len + run_chunk - 1) / run_chunk)) : 0;
         s.run_slots = fast_par ? (force_seq == 2 ? (int32_t)((len + 4096) / kFastChunk + 1) : s.fast_runs) : 0;
-        s.run_pad_ = 0;
         s.run_off = (int32_t)pl.n_runs;
         pl.n_runs += s.run_slots;
         pl.w_runs.add(i, s.fast_runs);

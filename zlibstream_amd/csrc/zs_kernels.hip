@@ -2453,7 +2453,7 @@ __global__ __launch_bounds__(1024) void zs_fast_run_kernel(const StreamDesc *sd,
     const int j = (int)w.y;
     const int64_t run = (int64_t)s.run_off + j;
     const int tid = threadIdx.x, nth = blockDim.x;
-    const int64_t cj = (int64_t)j * kFastChunk;
+    const int64_t cj = (int64_t)j * s.run_chunk;
     const bool last = j + 1 == s.fast_runs;
     int64_t x = cj - kFastWarm;
     if (x < 0) x = 0;
@@ -2480,7 +2480,7 @@ __global__ __launch_bounds__(1024) void zs_fast_run_kernel(const StreamDesc *sd,
     e.syms = run_syms + run * kFastRunSyms;
     e.blocks = dummy_blk;
     e.no_blocks = 1;
-    e.stop_abs = last ? -1 : cj + kFastChunk;
+    e.stop_abs = last ? -1 : cj + s.run_chunk;
     e.mark_abs = cj;
     e.ins_bits = bits;
     e.ins_base = x;
@@ -2591,8 +2591,8 @@ __global__ __launch_bounds__(256) void zs_fast_verify_kernel(const StreamDesc *s
     if (threadIdx.x == 0) bad = (b.mark_pos < 0 || b.mark_pos != a.end_pos);
     __syncthreads();
     if (!bad) {
-        const int64_t xa = (j - 1) * (int64_t)kFastChunk - kFastWarm < 0 ? 0 : (j - 1) * (int64_t)kFastChunk - kFastWarm;
-        const int64_t xb = (int64_t)j * kFastChunk - kFastWarm < 0 ? 0 : (int64_t)j * kFastChunk - kFastWarm;
+        const int64_t xa = (j - 1) * (int64_t)s.run_chunk - kFastWarm < 0 ? 0 : (j - 1) * (int64_t)s.run_chunk - kFastWarm;
+        const int64_t xb = (int64_t)j * s.run_chunk - kFastWarm < 0 ? 0 : (int64_t)j * s.run_chunk - kFastWarm;
         const uint32_t *ba = run_bits + (run - 1) * kFastRunBitWords, *bb = run_bits + run * kFastRunBitWords;
         int64_t lo = b.mark_pos - kWSize;
         if (lo < 0) lo = 0;
