@@ -1458,3 +1458,55 @@ def test_inflate_device_pointers_at_odd_addresses(engine):
     # nothing written in front of or behind an output
     for i, d in enumerate(datas):
         assert host[ooffs[i] - 1] == 0 and host[ooffs[i] + len(d)] == 0, i
+
+
+@pytest.mark.gpu
+def test_inflate_small_streams_take_the_block_parallel_pass(engine, rate_floors):
+    """Streams from 1 KiB of compressed bytes on go through the finder / measure / expand passes (until late in round 5: from
+    256 KiB; below that one wave per stream at 4 MB/s -- 120 ms for a 600 KiB text stream): sizes around the line, kinds of
+    data, one block and many, stored and fixed blocks, streams packed back to back in one device buffer (a reader that runs
+    over its stream's end would see the next one's bytes), a batch of hundreds; and the times."""
+    import time
+    import torch
+    rng = np.random.default_rng(77)
+    cases = []
+    for n in (1, 100, 1000, 2500, 4096, 20000, 65536, 100000, 262144, 600000):
+        cases.append(datagen.english(n, 3 + n))
+    cases += [bytes(5000), bytes(300000), datagen.sparse(128, 64), rng.integers(0, 256, 3000, dtype=np.uint8).tobytes(),
+              rng.integers(0, 256, 70000, dtype=np.uint8).tobytes(), rng.integers(0, 3, 50000, dtype=np.uint8).tobytes()]
+    streams = []
+    for i, d in enumerate(cases):
+        lvl = (6, 1, 9, 0)[i % 4]
+        c = zlib.compressobj(lvl, zlib.DEFLATED, 15, 8, (0, 0, 4, 2, 3)[i % 5])  # default, Fixed, HuffmanOnly, Rle among them
+        z = c.compress(d[: len(d) // 2]) + (c.flush(zlib.Z_SYNC_FLUSH) if i % 3 == 0 else b"") + c.compress(d[len(d) // 2:]) + c.flush()
+        streams.append(z)
+    for z, d in zip(streams, cases):  # one at a time
+        assert engine.inflate_batch([z], [len(d)])[0] == d, (len(d), len(z))
+    assert engine.inflate_batch(streams, [len(d) for d in cases]) == cases  # all in one batch
+    # packed back to back on the device
+    zbuf = torch.frombuffer(bytearray(b"".join(streams)), dtype=torch.uint8).cuda()
+    outs = [torch.zeros(len(d) + 1, dtype=torch.uint8, device="cuda") for d in cases]
+    offs = np.cumsum([0] + [len(z) for z in streams])
+    lens = engine.inflate_batch_device([zbuf.data_ptr() + int(o) for o in offs[:-1]], [len(z) for z in streams], [o.data_ptr() for o in outs], [len(d) for d in cases])
+    for i, d in enumerate(cases):
+        assert lens[i] == len(d) and outs[i][: len(d)].cpu().numpy().tobytes() == d and int(outs[i][len(d)]) == 0, i
+    # a corrupted small stream still reports the reference's error
+    bad = bytearray(streams[7])
+    bad[len(bad) // 2] ^= 0x55
+    with pytest.raises(Exception):
+        engine.inflate_batch([bytes(bad)], [len(cases[7])])
+    # the times: one 600 KiB text stream, and 256 streams of 64 KiB
+    big = [datagen.english(64 << 10, 500 + i) for i in range(256)]
+    zb = [zlib.compress(d, 6) for d in big]
+    for zs_, ds_, what, floor in (([streams[9]], [cases[9]], "one 600 KB text stream", 100e6), (zb, big, "256 streams of 64 KiB", 2e9)):
+        d_z = [torch.frombuffer(bytearray(z), dtype=torch.uint8).cuda() for z in zs_]
+        d_o = [torch.empty(len(d), dtype=torch.uint8, device="cuda") for d in ds_]
+        a = ([z.data_ptr() for z in d_z], [len(z) for z in zs_], [o.data_ptr() for o in d_o], [len(d) for d in ds_])
+        engine.inflate_batch_device(*a)
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        got = engine.inflate_batch_device(*a)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t
+        assert list(got) == [len(d) for d in ds_] and all(d_o[i].cpu().numpy().tobytes() == ds_[i] for i in range(0, len(ds_), 17))
+        rate_floors.check(sum(len(d) for d in ds_) / dt >= floor, "inflate of %s: %.2f ms = %.1f MB/s" % (what, dt * 1e3, sum(len(d) for d in ds_) / dt / 1e6))

@@ -1,7 +1,8 @@
 """Random zlib streams through the block-parallel inflate (zs_inflate_batch) against their plaintext, for a number of seconds:
 data kinds (text, zeros, runs, noise, image rows, mixtures), producers (system zlib at every level / strategy / memLevel with
 random flush points, this library's deflate), sizes from below the parallel path's threshold to a few MiB, batches of 1-6.
-   python tools/fuzz_inflate.py [seconds] [seed]      (prints every failing case with its seed)"""
+   python tools/fuzz_inflate.py [seconds] [seed] [small]     (prints every failing case with its seed; `small`: streams of a few bytes
+   to a few hundred KiB in batches of up to 40 -- the sizes around the line between the one-wave decoder and the block-parallel pass)"""
 import os, sys, time, zlib
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -10,6 +11,7 @@ from zlibstream_amd import Engine, datagen
 eng = Engine(0)
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+SMALL = len(sys.argv) > 3 and sys.argv[3] == "small"
 
 
 def make_data(rng, n):
@@ -60,10 +62,13 @@ t_end, cases, fails, seed = time.time() + budget, 0, 0, seed0
 nbytes = 0
 while time.time() < t_end:
     rng = np.random.default_rng(seed)
-    nb = int(rng.integers(1, 7))
+    nb = int(rng.integers(1, 41)) if SMALL else int(rng.integers(1, 7))
     datas, streams, notes = [], [], []
     for _ in range(nb):
-        n = int(rng.choice([int(rng.integers(1, 300000)), int(rng.integers(300000, 4 << 20)), int(rng.integers(4 << 20, 12 << 20))], p=[0.2, 0.6, 0.2]))
+        if SMALL:
+            n = int(rng.choice([int(rng.integers(1, 3000)), int(rng.integers(3000, 40000)), int(rng.integers(40000, 700000))], p=[0.3, 0.4, 0.3]))
+        else:
+            n = int(rng.choice([int(rng.integers(1, 300000)), int(rng.integers(300000, 4 << 20)), int(rng.integers(4 << 20, 12 << 20))], p=[0.2, 0.6, 0.2]))
         d = make_data(rng, n)
         z, note = make_stream(rng, d)
         datas.append(d), streams.append(z), notes.append("%d bytes -> %d, %s" % (len(d), len(z), note))

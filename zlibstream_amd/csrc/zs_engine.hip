@@ -1711,7 +1711,10 @@ bool run_inflate_piece(zs_ctx *c, const void *in, int64_t in_len, bool first, in
     return true;
 }
 
-constexpr int64_t kParMinInput = 256 * 1024;  // shorter streams go straight to the one-wave decoder
+// shorter streams go straight to the one-wave decoder (4 MB/s: 0.25 ms for a kilobyte of compressed text, what the block-parallel
+// pass costs before it has decoded anything; until late in round 5 the line was drawn at 256 KiB -- a 600 KiB text stream took 120 ms,
+// it takes 1.05 now, 256 streams of 64 KiB 1.25 instead of 14.2)
+constexpr int64_t kParMinInput = 1024;
 
 // Block-parallel path for the streams listed in `idx`; streams it cannot handle are appended to `rest`.
 bool run_inflate_par(zs_ctx *c, const std::vector<int> &idx, const void *const *in, const int64_t *in_len, void *const *out,
@@ -1999,7 +2002,8 @@ bool run_inflate_par(zs_ctx *c, const std::vector<int> &idx, const void *const *
 bool run_inflate(zs_ctx *c, int n, const void *const *in, const int64_t *in_len, void *const *out, const int64_t *out_cap,
                  int64_t *out_len, int *status, hipStream_t stream, uint32_t *adler_out = nullptr) {
     std::vector<int> par, seq;
-    for (int i = 0; i < n; i++) (in_len[i] >= kParMinInput ? par : seq).push_back(i);
+    static const int64_t par_min = getenv("ZS_INF_PAR_MIN") ? atoll(getenv("ZS_INF_PAR_MIN")) : kParMinInput;
+    for (int i = 0; i < n; i++) (in_len[i] >= par_min ? par : seq).push_back(i);
     std::vector<int> st((size_t)n, 0);
     if (!run_inflate_par(c, par, in, in_len, out, out_cap, out_len, st.data(), stream, seq, adler_out)) return false;
     bool ok = true;
