@@ -34,7 +34,7 @@ def make(rng):
         p = rng.integers(0, 256, int(rng.integers(1, 600)), dtype=np.uint8).tobytes()
         data = (p * (n // len(p) + 1))[:n]
     n = len(data)
-    style = int(rng.integers(0, 5))
+    style = int(rng.integers(0, 6))
     sizes = []
     o = 0
     while o < n:
@@ -42,6 +42,7 @@ def make(rng):
         elif style == 1: c = int(rng.integers(1, 70000))
         elif style == 2: c = int(rng.integers(6000, 400000))
         elif style == 3: c = int(rng.choice([32768, 65536, 65274, 65275, 32506, 98304])) - int(rng.integers(0, 300))
+        elif style == 5: c = int(rng.integers(300, 5000))  # (runs of a few KiB between flushes: the line between the literal engine and the bulk path)
         else: c = int(rng.integers(200000, 2000000))
         c = max(1, min(c, n - o)); sizes.append(c); o += c
     pf = float(rng.choice([0.0, 0.05, 0.3, 1.0]))
