@@ -240,7 +240,7 @@ bool run_pipeline(zs_ctx *c, int n, const void *const *in, const int64_t *in_len
     // the sweeps, and which it is the links tell (zs_fast_probe_kernel).  Such a batch is planned for both; the kernels behind
     // the link kernel see the one the probe chose.
     static const int64_t fast_min_input = getenv("ZS_FAST_MIN_INPUT") ? atoll(getenv("ZS_FAST_MIN_INPUT")) : kFastMinPeriodic;
-    bool allow_dual = lv.func == 1 && strategy != kRle && !writes && !ro && !rounds && force_seq == 0 && !force_lit && n <= 16 && !getenv("ZS_NO_FAST_VEC") &&
+    bool allow_dual = lv.func == 1 && strategy != kRle && strategy != kHuffmanOnly && !writes && !ro && !rounds && force_seq == 0 && !force_lit && n <= 16 && !getenv("ZS_NO_FAST_VEC") &&
                       !getenv("ZS_FAST_NO_ROUNDS");
     for (int i = 0; i < n && allow_dual; i++) allow_dual = in_len[i] >= fast_min_input && in_len[i] < kFastMinInput;
     bool dual_broken = false;
@@ -310,7 +310,9 @@ plan_again:
         // (force_seq: 1 -- the runs did not verify, or the data does not look periodic: the sweeps; 2 -- they did not verify and the
         // stream is few symbols: one run of the engine for the whole stream, below)
         // (a run's buffers are 1.7 MB whatever the stream's length: streams below 4 MiB only in batches of a few -- allow_dual)
-        const bool fast_par = fast_one && !multi && force_seq != 1 && !ro && (len >= kFastMinInput || allow_dual || (force_seq == 2 && n <= 16 && len >= fast_min_input));
+        // (HuffmanOnly: nothing is searched, every position a literal -- the sweeps take that at 7 GB/s, the runs' engine symbol by symbol)
+        const bool fast_par = fast_one && !multi && force_seq != 1 && !ro && strategy != kHuffmanOnly &&
+                              (len >= kFastMinInput || allow_dual || (force_seq == 2 && n <= 16 && len >= fast_min_input));
         if (allow_dual && !fast_par) dual_broken = true;
         s.fv_end = ((fast_one && (!fast_par || allow_dual) && !getenv("ZS_NO_FAST_VEC")) || fast_resume) ? (int32_t)(len - kMinLookahead) : -1;
         s.ins_bits = nullptr;
