@@ -1166,7 +1166,7 @@ plan_again:
                 if (getenv("ZS_DEBUG")) fprintf(stderr, "zs: the runs did not verify: %s (engine %.1f ms, sweeps up to %.1f ms)\n", mode == 2 ? "one run per stream" : "the sweeps", t_engine * 1e3, t_sweeps * 1e3);
                 return run_pipeline(c, n, in, in_len, out, out_cap, out_len, status, level, strategy, hash_variant, stream, writes, mode, ro, false, force_lit);
             }
-        hipLaunchKernelGGL(zs_fast_plan_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, stream, d_sd, d_st, dev<FastRunOut>(c->run_outs), n);
+        hipLaunchKernelGGL(zs_fast_plan_kernel, dim3((unsigned)n), dim3(256), 0, stream, d_sd, d_st, dev<FastRunOut>(c->run_outs), n);
         hipLaunchKernelGGL(zs_fast_stitch_kernel, dim3((unsigned)pl.w_runs.size()), dim3(256), 0, stream, d_sd, d_work + o_runs,
                            dev<uint32_t>(c->run_syms), dev<FastRunOut>(c->run_outs), dev<uint32_t>(c->syms), dev<int32_t>(c->blk_end),
                            dev<int32_t>(c->blk_top));

@@ -2635,21 +2635,39 @@ __global__ __launch_bounds__(256) void zs_fast_verify_kernel(const StreamDesc *s
     }
 }
 
-// per stream: where each run's own symbols go; block cuts every kBlockSyms symbols
-__global__ __launch_bounds__(64) void zs_fast_plan_kernel(const StreamDesc *sd, StreamState *st, FastRunOut *outs, int nstreams) {
-    const int si = blockIdx.x * 64 + threadIdx.x;
+// per stream: where each run's own symbols go; block cuts every kBlockSyms symbols.  One workgroup per stream, a prefix sum over
+// its runs (one thread walking 256 runs was 0.06 ms of sparse64's 3.4).
+__global__ __launch_bounds__(256) void zs_fast_plan_kernel(const StreamDesc *sd, StreamState *st, FastRunOut *outs, int nstreams) {
+    __shared__ long long part[256];
+    __shared__ long long carry;
+    const int si = blockIdx.x, tid = threadIdx.x;
     if (si >= nstreams) return;
     const StreamDesc s = sd[si];
     if (s.fast_runs <= 0) return;
-    int64_t total = 0;
-    for (int j = 0; j < s.fast_runs; j++) {
-        FastRunOut &o = outs[s.run_off + j];
-        o.sym_dst = total;
-        total += o.nsyms - o.mark_nsyms;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (int j0 = 0; j0 < s.fast_runs; j0 += 256) {
+        const int j = j0 + tid;
+        const long long own = j < s.fast_runs ? (long long)(outs[s.run_off + j].nsyms - outs[s.run_off + j].mark_nsyms) : 0;
+        part[tid] = own;
+        __syncthreads();
+        for (int o = 1; o < 256; o <<= 1) {  // inclusive prefix sum
+            const long long x = tid >= o ? part[tid - o] : 0;
+            __syncthreads();
+            part[tid] += x;
+            __syncthreads();
+        }
+        if (j < s.fast_runs) outs[s.run_off + j].sym_dst = carry + part[tid] - own;
+        __syncthreads();
+        if (tid == 255) carry += part[255];
+        __syncthreads();
     }
-    st[si].nsyms = (uint32_t)total;
-    st[si].nblocks = (int32_t)(total / kBlockSyms) + 1;
-    // a stream whose symbol count is a multiple of kBlockSyms ends with an empty last block, like the reference
+    if (tid == 0) {
+        const long long total = carry;
+        st[si].nsyms = (uint32_t)total;
+        st[si].nblocks = (int32_t)(total / kBlockSyms) + 1;
+        // a stream whose symbol count is a multiple of kBlockSyms ends with an empty last block, like the reference
+    }
 }
 
 // one workgroup per run: copy the run's own symbols into place; the byte positions of the block cuts that fall inside the run
