@@ -1050,6 +1050,7 @@ __global__ __launch_bounds__(1024) void zs_inf_chain_par_kernel(const ParStream 
     if (tid == 0) ss.nblk = tot_c, ss.out_len = tot_b;
 }
 
+constexpr int64_t kWalkMinInput = 256 * 1024;  // below it the walking kernel measures stored blocks only (zs_inf_chain_kernel)
 __global__ __launch_bounds__(64) void zs_inf_chain_kernel(const ParStream *ps, ParState *st, const ParCand *cands, ParBlock *blocks,
                                                           int lane_decode, int tried) {
     __shared__ ParLds L;
@@ -1106,8 +1107,18 @@ __global__ __launch_bounds__(64) void zs_inf_chain_kernel(const ParStream *ps, P
             ok = 0;
             break;
         } else {
-            // a block the finder does not report (stored / fixed codes): measure it here
+            // a block the finder does not report (stored / fixed codes): measure it here.  (Not a compressed block of a short
+            // stream: measured here symbol by symbol and then decoded again by one wave it takes twice what the one-wave
+            // decoder takes for the whole stream -- 60 KB of fixed-code text 21 ms against 13; the stream is left to that one.)
             inf_seek(b, cur);
+            if (!probing && s.in_len < kWalkMinInput && cur + 3 <= s.in_len * 8) {
+                const int64_t by = cur >> 3;
+                const uint32_t two = (uint32_t)s.in[by] | (by + 1 < s.in_len ? (uint32_t)s.in[by + 1] << 8 : 0u);
+                if (((two >> ((cur & 7) + 1)) & 3u) != 0u) {
+                    ok = 0;
+                    break;
+                }
+            }
             BlockOut r = inf_block<0>(b, L.T, L.lens, L.ll, nullptr, (int64_t)1 << 40);
             if (r.err) {
                 ok = 0;
