@@ -861,7 +861,7 @@ def test_the_bulk_path_goes_on_from_the_flush_itself(engine, oracle, monkeypatch
 @pytest.mark.gpu
 def test_short_runs_between_flushes_take_the_bulk_path(engine, oracle):
     """A stream that flushes every few KiB (a protocol's messages): every run behind a flush is the bulk pipeline's from
-    6 KiB on.  Such a run may end before it has slid the window the engine before it left, or have that engine's positions
+    1 KiB on (6 KiB until late in round 5).  Such a run may end before it has slid the window the engine before it left, or have that engine's positions
     in its own last window: the tail engine then takes what lies behind the data in the window from that engine's image, and
     its hash heads are that engine's under the run's own positions (zs_tail_kernel, StreamDesc::start_pos).  Random
     schedules over four kinds of data; flushes in the last 262 bytes of a window (the window slides before it is full,
@@ -897,6 +897,21 @@ def test_short_runs_between_flushes_take_the_bulk_path(engine, oracle):
     dt = time.perf_counter() - t0
     assert z == oracle.compress_writes(text, 6, 0, sizes, [2] * 64)
     assert dt < 1.0, "%.2f s for 64 flushed Writes of 64 KiB: the runs did not leave the literal engine (6 s)" % dt
+    # late in round 5 the line moved from 6 KiB to 1 KiB (a resumed run's body may be shorter than a chunk): runs of 1 .. 5 KiB
+    # behind every flush mode at slow and fast levels, byte-exact, and the literal engine's share of them by its counter
+    for data, level in ((text, 6), (low, 9), (runs, 4), (text, 1), (low, 3), (rnd, 6), (bytes(1 << 20), 2)):
+        sizes, fl, o = [], [], 0
+        while o < 300000:
+            c = int(rng.integers(1024, 5200))
+            sizes.append(c), fl.append(int(rng.choice([1, 2, 2, 3])))
+            o += c
+        data = data[:o]
+        before = engine.counter("lit_engine_bytes")
+        z = _flushed_stream(engine, data, sizes, fl, level)
+        lit = engine.counter("lit_engine_bytes") - before
+        assert z == oracle.compress_writes(data, level, 0, sizes, fl), (level, sizes[:6], fl[:6])
+        # (the first run -- nothing to resume from -- and what a schedule's odd spots leave; not run after run)
+        assert lit <= 0.2 * len(data), "level %d: the literal engine took %d of %d bytes in runs of 1-5 KiB" % (level, lit, len(data))
 
 
 @pytest.mark.gpu
