@@ -59,7 +59,7 @@ struct zs_ctx {
     double stage_ms[kStCount] = {};
     uint32_t *crc_tab = nullptr;
     DevBuf sd, st, work, wpre, geo, link, mm, maps, chunk_far, segmap, supmap, seg_entry, seg_symbase, seg_stale, entry, symbase, stale, syms, blk_end, blk_top, blocks, trees, info, pieces, scratch,
-        stage_in, stage_out, wr, inf_desc, inf_state, par_ps, par_st, par_work, par_cbits, par_ccnt, par_surv, par_scnt, par_cands, par_tabs, par_toktabs, par_toks, par_ctoks, par_tokstat, par_tails, par_retry, par_blocks, par_cells,
+        stage_in, stage_out, wr, inf_desc, inf_state, par_ps, par_st, par_work, par_cbits, par_ccnt, par_surv, par_scnt, par_cands, par_tabs, par_toktabs, par_toks, par_ctoks, par_tokstat, par_tails, par_retry, par_fxtab, par_blocks, par_cells,
         par_windows, par_fail, run_syms, run_bits, run_scratch, run_outs, run_fail, adl_tr, adl_res, plan_blk, ins_bits, mm_bak, cut_pos, cut_bkt, win_groups, win_sg, win_maps, win_entries, persist_bak, resume_flag, rle_tiles, own_in, fr_chunks, fr_meta, fr_planes, fr_prov, fr_base, fr_counters;
     bool resume_poisoned = false;  // a resumed run met a read the bulk form does not handle: the caller goes on with the literal engine
     void *pinned = nullptr;
@@ -1456,7 +1456,7 @@ void zs_ctx_destroy(zs_ctx *c) {
     (void)hipSetDevice(c->device);
     DevBuf *bufs[] = {&c->sd, &c->st, &c->work, &c->wpre, &c->geo, &c->link, &c->mm, &c->maps, &c->chunk_far, &c->segmap, &c->supmap, &c->seg_entry, &c->seg_symbase, &c->seg_stale, &c->entry, &c->symbase, &c->stale, &c->syms,
                       &c->blk_end, &c->blk_top, &c->blocks, &c->trees, &c->info, &c->pieces, &c->scratch, &c->stage_in, &c->stage_out, &c->wr, &c->inf_desc, &c->inf_state, &c->par_ps, &c->par_st, &c->par_work, &c->par_cbits, &c->par_ccnt, &c->par_surv, &c->par_scnt,
-                      &c->par_cands, &c->par_tabs, &c->par_toktabs, &c->par_toks, &c->par_ctoks, &c->par_tokstat, &c->par_tails, &c->par_retry, &c->par_blocks, &c->par_cells, &c->par_windows, &c->par_fail, &c->run_syms, &c->run_bits,
+                      &c->par_cands, &c->par_tabs, &c->par_toktabs, &c->par_toks, &c->par_ctoks, &c->par_tokstat, &c->par_tails, &c->par_retry, &c->par_fxtab, &c->par_blocks, &c->par_cells, &c->par_windows, &c->par_fail, &c->run_syms, &c->run_bits,
                       &c->run_scratch, &c->run_outs, &c->run_fail, &c->adl_tr, &c->adl_res, &c->plan_blk, &c->ins_bits, &c->mm_bak, &c->cut_pos, &c->cut_bkt, &c->win_groups, &c->win_sg, &c->win_maps, &c->win_entries, &c->persist_bak, &c->resume_flag, &c->rle_tiles, &c->own_in, &c->fr_chunks, &c->fr_meta, &c->fr_planes, &c->fr_prov, &c->fr_base, &c->fr_counters};
     for (DevBuf *b : bufs)
         if (b->p) (void)hipFree(b->p);
@@ -1725,7 +1725,7 @@ bool run_inflate_par(zs_ctx *c, const std::vector<int> &idx, const void *const *
     const int m = (int)idx.size();
     if (m == 0) return true;
     std::vector<ParStream> ps((size_t)m);
-    int64_t nchunks = 0, ncand = 0, nblk = 0, ncells = 0;
+    int64_t nchunks = 0, ncand = 0, nblk = 0, ncells = 0, nfx = 0;
     std::vector<uint2> w_find;
     for (int j = 0; j < m; j++) {
         const int i = idx[(size_t)j];
@@ -1738,6 +1738,8 @@ bool run_inflate_par(zs_ctx *c, const std::vector<int> &idx, const void *const *
         p.blk_off = (int32_t)nblk, p.max_blk = (int32_t)(in_len[i] / 256 + 64);
         nblk += p.max_blk;
         p.cell_off = ncells;
+        p.fx_off = (int32_t)nfx, p.fx_regions = (int32_t)(in_len[i] * 8 / kFxRegionBits + 1);
+        nfx += p.fx_regions;
         if (c->inf_probe) p.out_cap = (int64_t)0x7FFFFFFF - 1024;  // a probing call decodes nothing: any output size is fine
         else ncells += (out_cap[i] + 63) & ~63LL;
         for (int k = 0; k < p.nchunks; k++) w_find.push_back(make_uint2((unsigned)j, (unsigned)k));
@@ -1862,8 +1864,19 @@ bool run_inflate_par(zs_ctx *c, const std::vector<int> &idx, const void *const *
     if (chain_par)
         hipLaunchKernelGGL(zs_inf_chain_par_kernel, dim3((unsigned)m), dim3(1024), kChainParLds, stream, d_ps, d_st, dev<ParCand>(c->par_cands),
                            dev<ParBlock>(c->par_blocks), lane_decode ? 1 : 0);
+    // a stream the finder's blocks do not chain (fixed-code or stored blocks among them): its fixed blocks found ahead of the walk,
+    // a wave per 64 KiB (zs_inf_fixed_scan_kernel; the waves of the streams that chained leave at once)
+    const FxEntry *d_fx = nullptr;
+    static const bool fx_scan = !getenv("ZS_INF_NO_FIXED_SCAN");
+    if (chain_par && fx_scan && !c->inf_probe && m <= 65535 && nfx > 0 && nfx < (1 << 22) &&
+        ensure(c, c->par_fxtab, sizeof(FxEntry) * (size_t)nfx * kFxEntries + 64)) {
+        int max_regions = 1;
+        for (int j = 0; j < m; j++) max_regions = std::max(max_regions, (int)ps[(size_t)j].fx_regions);
+        d_fx = dev<FxEntry>(c->par_fxtab);
+        hipLaunchKernelGGL(zs_inf_fixed_scan_kernel, dim3((unsigned)max_regions, (unsigned)m), dim3(64), 0, stream, d_ps, d_st, dev<FxEntry>(c->par_fxtab));
+    }
     hipLaunchKernelGGL(zs_inf_chain_kernel, dim3((unsigned)m), dim3(64), 0, stream, d_ps, d_st, dev<ParCand>(c->par_cands),
-                       dev<ParBlock>(c->par_blocks), lane_decode ? 1 : 0, (chain_par ? 1 : 0) | (c->inf_probe ? 2 : 0));
+                       dev<ParBlock>(c->par_blocks), lane_decode ? 1 : 0, (chain_par ? 1 : 0) | (c->inf_probe ? 2 : 0), d_fx);
     mark(3);
     ZS_HIP(c, hipMemcpyAsync(st.data(), d_st, sizeof(ParState) * (size_t)m, hipMemcpyDeviceToHost, stream));
     ZS_HIP(c, hipStreamSynchronize(stream));

@@ -54,6 +54,7 @@ struct ParStream {
     int32_t cand_off, max_cand;   // flattened candidate list
     int32_t blk_off, max_blk;     // chain blocks
     int64_t cell_off;             // u16 cells of this stream's output
+    int32_t fx_off, fx_regions;   // fixed-code blocks found ahead of the walk (zs_inf_fixed_scan_kernel): the stream's regions in the table
 };
 struct ParCand {
     int64_t bit;       // block header bit offset
@@ -1221,8 +1222,63 @@ __device__ BlockOut inf_fixed_end(const uint8_t *in, int64_t n_bytes, int64_t hd
         S = S < 4096 ? S * 4 : 4096;
     }
 }
+// ---- fixed-code blocks found ahead of the walk.  The walk over a stream of fixed blocks is one chain -- a block's start is the
+// block before's end -- but what the walk needs of a block (its end, its output bytes) is a function of its start alone.  So one
+// wave per 64 KiB of the stream decodes from a guessed bit (as if a block began there) to the next end-of-block code -- a true
+// block's end once the decoder is in step -- and goes on block by block while the headers say "fixed", writing down
+// (start, end, bytes) for every block it believes in.  The walk then looks its block's start up in its region's entries: found, the
+// block costs a search; not found (the region's wave was not in step by its first end-of-block, a block of another kind in
+// between), the walk measures the block itself (inf_fixed_end).  An entry is looked up by a true start only, and for a true start it
+// holds what inf_fixed_end would give: entries behind guesses that went wrong are never read.
+constexpr int64_t kFxRegionBits = 8 * 65536;
+constexpr int kFxEntries = 16;  // per region (a fixed block of 16 Ki symbols is ~25 KB: two or three to a region)
+struct FxEntry {
+    int64_t start, end, out_bytes;
+    int32_t bfinal, pad_;
+};
+__global__ __launch_bounds__(64) void zs_inf_fixed_scan_kernel(const ParStream *ps, const ParState *st, FxEntry *tab) {
+    const uint2 w = make_uint2(blockIdx.y, blockIdx.x);  // (stream, region)
+    const ParStream s = ps[w.x];
+    if ((int)w.y >= s.fx_regions) return;
+    const int lane = (int)(threadIdx.x & 63);
+    FxEntry *out = tab + ((int64_t)s.fx_off + w.y) * kFxEntries;
+    if (lane < kFxEntries) out[lane].start = -1;
+    if (!st[w.x].ok || st[w.x].nblk >= 1) return;  // (no chain to make, or zs_inf_chain_par_kernel has made it)
+    // (a stream of fixed blocks begins with one: a stream whose blocks do not chain for another reason -- the empty stored blocks of
+    // flush markers -- is not decoded as fixed code on a guess, 3.5 ms per call for nothing)
+    if (s.in_len < 3 || ((s.in[2] >> 1) & 3u) != 1u) return;
+    const int64_t nbits = s.in_len * 8, r_lo = (int64_t)w.y * kFxRegionBits, r_hi = r_lo + kFxRegionBits;
+    // The guess lies a region's length in front of the region (two or three blocks): a decoder that begins in the middle of a
+    // symbol may take bits for an end-of-block code before it is in step -- what follows is then no header -- but the decode
+    // from any position ends at a true end-of-block once it is in step, and everything behind that is true.  `pseudo`: pos is a
+    // position symbols are decoded from on trust, not a header.
+    int64_t pos = w.y == 0 ? 16 : (r_lo - kFxRegionBits > 16 ? r_lo - kFxRegionBits : 19);
+    bool pseudo = w.y != 0;
+    int n = 0;
+    for (int budget = 96; budget > 0 && n < kFxEntries && pos < r_hi && pos + 3 <= nbits; budget--) {
+        if (!pseudo) {
+            const int64_t by = pos >> 3;
+            const uint32_t two = (uint32_t)s.in[by] | (by + 1 < s.in_len ? (uint32_t)s.in[by + 1] << 8 : 0u);
+            if (((two >> ((pos & 7) + 1)) & 3u) != 1u) {  // a stored or dynamic block, or bits that are no header: on as a guess
+                pseudo = true, pos += 3;
+                continue;
+            }
+        }
+        const BlockOut r = inf_fixed_end(s.in, s.in_len, pseudo ? pos - 3 : pos);
+        if (r.err) {
+            pseudo = true, pos += 997;
+            continue;
+        }
+        if (!pseudo && pos >= r_lo) {
+            if (lane == 0) out[n] = FxEntry{pos, r.end_bit, r.out_bytes, r.bfinal, 0};
+            n++;
+        }
+        pos = r.end_bit, pseudo = false;
+    }
+}
+
 __global__ __launch_bounds__(64) void zs_inf_chain_kernel(const ParStream *ps, ParState *st, const ParCand *cands, ParBlock *blocks,
-                                                          int lane_decode, int tried) {
+                                                          int lane_decode, int tried, const FxEntry *fxtab) {
     __shared__ ParLds L;
     const ParStream s = ps[blockIdx.x];
     ParState &ss = st[blockIdx.x];
@@ -1294,7 +1350,22 @@ __global__ __launch_bounds__(64) void zs_inf_chain_kernel(const ParStream *ps, P
             {
                 const int64_t by = cur >> 3;
                 const uint32_t two = by < s.in_len ? ((uint32_t)s.in[by] | (by + 1 < s.in_len ? (uint32_t)s.in[by + 1] << 8 : 0u)) : 0u;
-                if (((two >> ((cur & 7) + 1)) & 3u) == 1u && !kNoFixedEnd) r = inf_fixed_end(s.in, s.in_len, cur);  // a fixed-code block: 64 lanes on it
+                if (((two >> ((cur & 7) + 1)) & 3u) == 1u && !kNoFixedEnd) {
+                    // a fixed-code block: found ahead of the walk (zs_inf_fixed_scan_kernel), or 64 lanes on it now
+                    bool have = false;
+                    const int64_t reg = cur / kFxRegionBits;
+                    if (fxtab && reg < s.fx_regions) {
+                        const FxEntry *fe = fxtab + ((int64_t)s.fx_off + reg) * kFxEntries;
+                        const int lane = (int)(threadIdx.x & 63);
+                        const uint64_t hit = __ballot(lane < kFxEntries && fe[lane < kFxEntries ? lane : 0].start == cur);
+                        if (hit) {
+                            const FxEntry e = fe[__builtin_ctzll(hit)];
+                            r = BlockOut{e.out_bytes, e.end, e.bfinal, 0};
+                            have = true;
+                        }
+                    }
+                    if (!have) r = inf_fixed_end(s.in, s.in_len, cur);
+                }
                 else r = inf_block<0>(b, L.T, L.lens, L.ll, nullptr, (int64_t)1 << 40);
             }
             if (r.err) {
