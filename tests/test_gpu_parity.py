@@ -1525,3 +1525,44 @@ def test_inflate_small_streams_take_the_block_parallel_pass(engine, rate_floors)
         dt = time.perf_counter() - t
         assert list(got) == [len(d) for d in ds_] and all(d_o[i].cpu().numpy().tobytes() == ds_[i] for i in range(0, len(ds_), 17))
         rate_floors.check(sum(len(d) for d in ds_) / dt >= floor, "inflate of %s: %.2f ms = %.1f MB/s" % (what, dt * 1e3, sum(len(d) for d in ds_) / dt / 1e6))
+
+
+@pytest.mark.gpu
+def test_inflate_streams_of_fixed_code_blocks(engine, rate_floors):
+    """CompressionStrategy.Fixed / Z_FIXED: blocks without a header the finder could tell from data.  Their starts are found ahead
+    of the chain's walk by waves that decode from guessed bits (zs_inf_fixed_scan_kernel), the walk measures what they missed with its
+    64 lanes (inf_fixed_end): zlib's and this library's own fixed streams, several in a batch beside a dynamic one, sizes around a
+    region's 64 KiB, a corrupted one; 16 MiB in tens of milliseconds (2.1 s when the walk went symbol by symbol)."""
+    import time
+    import torch
+    rng = np.random.default_rng(5)
+    datas = [datagen.english(n, 40 + i) for i, n in enumerate((70000, 300000, 1 << 20, (4 << 20) + 12345))]
+    datas += [datagen.sparse(512, 700), rng.integers(0, 5, 900000, dtype=np.uint8).tobytes(), bytes(500000)]
+    streams = []
+    for d in datas:
+        c = zlib.compressobj(6, zlib.DEFLATED, 15, 8, zlib.Z_FIXED)
+        streams.append(c.compress(d) + c.flush())
+    for z, d in zip(streams, datas):
+        assert engine.inflate_batch([z], [len(d)])[0] == d, len(d)
+    own = engine.deflate_batch([datas[3], datas[4]], level=6, strategy=4)  # this library's CompressionStrategy.Fixed
+    mixed_z = streams + own + [zlib.compress(datas[2], 6)]
+    mixed_d = datas + [datas[3], datas[4], datas[2]]
+    assert engine.inflate_batch(mixed_z, [len(d) for d in mixed_d]) == mixed_d
+    bad = bytearray(streams[2])
+    bad[len(bad) // 2] ^= 0x10
+    with pytest.raises(Exception):
+        engine.inflate_batch([bytes(bad)], [len(datas[2])])
+    big = datagen.english(16 << 20, 7)
+    c = zlib.compressobj(6, zlib.DEFLATED, 15, 8, zlib.Z_FIXED)
+    z = c.compress(big) + c.flush()
+    d_z = torch.frombuffer(bytearray(z), dtype=torch.uint8).cuda()
+    out = torch.empty(len(big), dtype=torch.uint8, device="cuda")
+    a = ([d_z.data_ptr()], [len(z)], [out.data_ptr()], [len(big)])
+    engine.inflate_batch_device(*a)
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    n = engine.inflate_batch_device(*a)[0]
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t
+    assert n == len(big) and out.cpu().numpy().tobytes() == big
+    rate_floors.check(len(big) / dt >= 200e6, "inflate of 16 MiB under Z_FIXED: %.1f ms = %.1f MB/s" % (dt * 1e3, len(big) / dt / 1e6))
