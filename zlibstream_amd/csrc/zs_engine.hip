@@ -1733,9 +1733,9 @@ bool run_inflate_par(zs_ctx *c, const std::vector<int> &idx, const void *const *
         p.in = (const uint8_t *)in[i], p.out = (uint8_t *)out[i], p.in_len = in_len[i], p.out_cap = out_cap[i];
         p.chunk_off = (int32_t)nchunks, p.nchunks = (int32_t)((in_len[i] + kFindChunk - 1) / kFindChunk);
         nchunks += p.nchunks;
-        p.cand_off = (int32_t)ncand, p.max_cand = (int32_t)(in_len[i] / 1024 + 64);
+        p.cand_off = (int32_t)ncand, p.max_cand = (int32_t)(in_len[i] / 128 + 64);
         ncand += p.max_cand;
-        p.blk_off = (int32_t)nblk, p.max_blk = (int32_t)(in_len[i] / 256 + 64);
+        p.blk_off = (int32_t)nblk, p.max_blk = (int32_t)(in_len[i] / 96 + 64);
         nblk += p.max_blk;
         p.cell_off = ncells;
         p.fx_off = (int32_t)nfx, p.fx_regions = (int32_t)(in_len[i] * 8 / kFxRegionBits + 1);

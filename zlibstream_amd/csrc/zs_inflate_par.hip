@@ -42,7 +42,7 @@ __device__ __forceinline__ void store_u4_a2(uint16_t *p, uint32_t a, uint32_t b,
 }
 
 constexpr int kFindChunk = 4096;     // input bytes per finder workgroup
-constexpr int kFindMaxCand = 12;     // candidates kept per chunk
+constexpr int kFindMaxCand = 32;     // candidates kept per chunk (12 until late in round 5: blocks of ~100 symbols -- memLevel 1 -- are 22 to a chunk)
 constexpr int kFindMaxSurv = 512;    // prefilter survivors per chunk (32768 bit offsets; ~0.5 % survive on random data)
 constexpr int kParMaxBlocks = 1 << 16;
 
